@@ -1,0 +1,387 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/vnr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg — never by instantvnr_amd.  PARITY UNPINNED (see
+vnr_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvnr_oracle.so")
+MAX_LEVELS = 32
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "vnr_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class GridConfig(C.Structure):
+    _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32),
+                ("log2_hashmap_size", C.c_uint32), ("base_resolution", C.c_uint32),
+                ("per_level_scale", C.c_float), ("interpolation", C.c_uint32)]
+
+
+class GridLayout(C.Structure):
+    _fields_ = [("offsets", C.c_uint32 * (MAX_LEVELS + 1)), ("scale", C.c_float * MAX_LEVELS),
+                ("resolution", C.c_uint32 * MAX_LEVELS)]
+
+
+class Tfn(C.Structure):
+    _fields_ = [("colors", C.POINTER(C.c_float)), ("n_colors", C.c_int),
+                ("alphas", C.POINTER(C.c_float)), ("n_alphas", C.c_int),
+                ("range_lo", C.c_float), ("range_hi", C.c_float), ("range_rcp_norm", C.c_float)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("frame_index", C.c_int),
+                ("cam_from", C.c_float * 3), ("cam_at", C.c_float * 3), ("cam_up", C.c_float * 3),
+                ("fovy", C.c_float), ("xfm", C.c_float * 12),
+                ("vol_dims", C.c_int * 3), ("bbox_lo", C.c_float * 3), ("bbox_hi", C.c_float * 3),
+                ("sampling_rate", C.c_float),
+                ("mc_dims", C.c_int * 3), ("mc_spacings", C.c_float * 3),
+                ("mc_max_opacity", C.POINTER(C.c_float)),
+                ("tfn", Tfn), ("pixel_lo", C.c_uint32), ("pixel_hi", C.c_uint32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("n_slots", C.c_uint64),
+                ("n_iterations", C.c_uint32), ("n_rays_hit", C.c_uint32)]
+
+
+VALUE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float))
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    global _lib
+    with _lock:
+        if _lib is None:
+            build()
+            L = C.CDLL(_SO)
+            L.vnro_f32_to_f16.restype = C.c_uint16
+            L.vnro_f32_to_f16.argtypes = [C.c_float]
+            L.vnro_f16_to_f32.restype = C.c_float
+            L.vnro_f16_to_f32.argtypes = [C.c_uint16]
+            L.vnro_grid_make_layout.restype = C.c_uint32
+            L.vnro_grid_index.restype = C.c_uint32
+            L.vnro_mlp_n_params.restype = C.c_size_t
+            L.vnro_mlp_n_params.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+            L.vnro_tex3d.restype = C.c_float
+            L.vnro_sample_volume.restype = C.c_float
+            L.vnro_lcg_next.restype = C.c_float
+            L.vnro_pcg32_next_uint.restype = C.c_uint32
+            L.vnro_pcg32_next_float.restype = C.c_float
+            L.vnro_dda_trace.restype = C.c_size_t
+            L.vnro_psnr.restype = C.c_double
+            _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# --------------------------------------------------------------------------- fp16
+def f32_to_f16_bits(x):
+    L = lib()
+    x = _f32(x).ravel()
+    return np.array([L.vnro_f32_to_f16(float(v)) for v in x], dtype=np.uint16)
+
+
+# --------------------------------------------------------------------------- grid
+def grid_config(n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale=2.0,
+                interpolation=0):
+    return GridConfig(n_levels, n_features, log2_hashmap_size, base_resolution,
+                      float(per_level_scale), interpolation)
+
+
+def grid_layout(cfg):
+    lay = GridLayout()
+    total = lib().vnro_grid_make_layout(C.byref(cfg), C.byref(lay))
+    n = cfg.n_levels
+    return {"total_entries": int(total), "offsets": np.array(lay.offsets[:n + 1], dtype=np.uint32),
+            "scale": np.array(lay.scale[:n], dtype=np.float32),
+            "resolution": np.array(lay.resolution[:n], dtype=np.uint32)}
+
+
+def grid_index(hashmap_size, resolution, p):
+    arr = (C.c_uint32 * 3)(*[int(v) & 0xFFFFFFFF for v in p])
+    return int(lib().vnro_grid_index(C.c_uint32(hashmap_size), C.c_uint32(resolution), arr))
+
+
+def padded_width(cfg):
+    return ((cfg.n_levels * cfg.n_features + 15) // 16) * 16
+
+
+def grid_encode(cfg, table_f16_bits, coords):
+    """table: uint16 view of fp16 table; coords [n,3] fp32 -> uint16 [n, padded]"""
+    coords = _f32(coords)
+    n = coords.shape[0]
+    pw = padded_width(cfg)
+    out = np.zeros((n, pw), dtype=np.uint16)
+    table = np.ascontiguousarray(table_f16_bits, dtype=np.uint16)
+    lib().vnro_grid_encode(C.byref(cfg), _p(table, C.c_uint16), _p(coords, C.c_float), C.c_size_t(n),
+                           _p(out, C.c_uint16), C.c_uint32(pw))
+    return out
+
+
+def mlp_n_params(in_width, width, n_hidden_matmuls):
+    return int(lib().vnro_mlp_n_params(in_width, width, n_hidden_matmuls))
+
+
+def mlp_forward(weights_bits, in_width, width, n_hidden_matmuls, x_bits, activation=1, acc_mode=0,
+                want_activations=False):
+    w = np.ascontiguousarray(weights_bits, dtype=np.uint16)
+    x = np.ascontiguousarray(x_bits, dtype=np.uint16)
+    n = x.shape[0]
+    out = np.zeros(n, dtype=np.float32)
+    act = np.zeros((n_hidden_matmuls + 1, n, width), dtype=np.uint16) if want_activations else None
+    lib().vnro_mlp_forward(_p(w, C.c_uint16), C.c_uint32(in_width), C.c_uint32(width),
+                           C.c_uint32(n_hidden_matmuls), C.c_int(activation), C.c_int(acc_mode),
+                           _p(x, C.c_uint16), C.c_size_t(n), _p(out, C.c_float),
+                           _p(act, C.c_uint16) if act is not None else None)
+    return (out, act) if want_activations else out
+
+
+def network_inference(cfg, width, n_hidden_layers, params_bits, coords, activation=1, acc_mode=0):
+    params = np.ascontiguousarray(params_bits, dtype=np.uint16)
+    coords = _f32(coords)
+    n = coords.shape[0]
+    out = np.zeros(n, dtype=np.float32)
+    lib().vnro_network_inference(C.byref(cfg), C.c_uint32(width), C.c_uint32(n_hidden_layers),
+                                 C.c_int(activation), C.c_int(acc_mode), _p(params, C.c_uint16),
+                                 _p(coords, C.c_float), C.c_size_t(n), _p(out, C.c_float))
+    return out
+
+
+def n_params(cfg, width, n_hidden_layers):
+    lay = grid_layout(cfg)
+    return mlp_n_params(padded_width(cfg), width, n_hidden_layers - 1) + lay["total_entries"] * cfg.n_features
+
+
+# --------------------------------------------------------------------------- volume
+def _dims(d):
+    return (C.c_int * 3)(int(d[0]), int(d[1]), int(d[2]))
+
+
+def sample_volume(vol, coords, nodal):
+    """vol: [z,y,x] fp32 (x fastest); coords [n,3] in [0,1]"""
+    vol = _f32(vol)
+    dims = _dims(vol.shape[::-1])
+    coords = _f32(coords)
+    out = np.zeros(coords.shape[0], dtype=np.float32)
+    lib().vnro_sample_volume_batch(_p(vol, C.c_float), dims, _p(coords, C.c_float),
+                                   C.c_size_t(coords.shape[0]), C.c_int(1 if nodal else 0), _p(out, C.c_float))
+    return out
+
+
+# --------------------------------------------------------------------------- tfn
+class TfnHolder:
+    """keeps numpy buffers alive for a vnro_tfn"""
+
+    def __init__(self, colors_rgb, alphas, range_lo=0.0, range_hi=1.0):
+        c = _f32(colors_rgb).reshape(-1, 3)
+        self.colors = np.ascontiguousarray(np.concatenate([c, np.ones((c.shape[0], 1), np.float32)], axis=1))
+        self.alphas = _f32(alphas).ravel().copy()
+        self.c = Tfn(_p(self.colors, C.c_float), self.colors.shape[0], _p(self.alphas, C.c_float),
+                     self.alphas.shape[0], range_lo, range_hi,
+                     float(np.float32(1.0) / (np.float32(range_hi) - np.float32(range_lo))))
+
+
+def tfn_sample(tfn, values):
+    values = _f32(values).ravel()
+    rgb = (C.c_float * 3)()
+    a = C.c_float()
+    out = np.zeros((values.shape[0], 4), dtype=np.float32)
+    L = lib()
+    for i, v in enumerate(values):
+        L.vnro_tfn_sample(C.byref(tfn.c), C.c_float(float(v)), rgb, C.byref(a))
+        out[i] = (rgb[0], rgb[1], rgb[2], a.value)
+    return out
+
+
+# --------------------------------------------------------------------------- macrocell
+def macrocell_shape(vol_dims):
+    mc = (C.c_int * 3)()
+    sp = (C.c_float * 3)()
+    lib().vnro_macrocell_shape(_dims(vol_dims), mc, sp)
+    return tuple(mc), np.array(list(sp), dtype=np.float32)
+
+
+def macrocell_compute_implicit(vol):
+    vol = _f32(vol)
+    vd = vol.shape[::-1]
+    mc, _ = macrocell_shape(vd)
+    vr = np.zeros((mc[2], mc[1], mc[0], 2), dtype=np.float32)
+    lib().vnro_macrocell_compute_implicit(_p(vol, C.c_float), _dims(vd), _dims(mc), _p(vr, C.c_float))
+    return vr
+
+
+def macrocell_update_explicit(value_range, vol_dims, coords, values):
+    coords = _f32(coords)
+    values = _f32(values)
+    mc = value_range.shape[:3][::-1]
+    lib().vnro_macrocell_update_explicit(_p(coords, C.c_float), _p(values, C.c_float), C.c_size_t(coords.shape[0]),
+                                         _dims(vol_dims), _dims(mc), _p(value_range, C.c_float))
+    return value_range
+
+
+def macrocell_max_opacity(tfn, value_range):
+    n = value_range.size // 2
+    out = np.zeros(value_range.shape[:3], dtype=np.float32)
+    lib().vnro_macrocell_max_opacity(C.byref(tfn.c), _p(value_range, C.c_float), C.c_size_t(n), _p(out, C.c_float))
+    return out
+
+
+# --------------------------------------------------------------------------- rng
+def lcg_floats(v0, v1, n):
+    class Lcg(C.Structure):
+        _fields_ = [("state", C.c_uint32)]
+    r = Lcg()
+    L = lib()
+    L.vnro_lcg_init(C.byref(r), C.c_uint32(v0), C.c_uint32(v1))
+    return np.array([L.vnro_lcg_next(C.byref(r)) for _ in range(n)], dtype=np.float32)
+
+
+class Pcg32(C.Structure):
+    _fields_ = [("state", C.c_uint64), ("inc", C.c_uint64)]
+
+
+def pcg32(initstate=0x853c49e6748fea9b, initseq=0xda3e39cb94b95bdb):
+    r = Pcg32()
+    lib().vnro_pcg32_seed(C.byref(r), C.c_uint64(initstate), C.c_uint64(initseq))
+    return r
+
+
+# --------------------------------------------------------------------------- rendering
+def default_transform(dims):
+    """object->world = translate(-dims/2) * scale(dims)  (ref: core/network.cu:569)"""
+    d = np.asarray(dims, dtype=np.float32)
+    return np.array([d[0], 0, 0, 0, d[1], 0, 0, 0, d[2], -d[0] / 2, -d[1] / 2, -d[2] / 2], dtype=np.float32)
+
+
+class SceneHolder:
+    def __init__(self, width, height, vol_dims, tfn, mc_max_opacity, cam_from, cam_at=(0, 0, 0), cam_up=(0, 1, 0),
+                 fovy=60.0, frame_index=1, sampling_rate=1.0, bbox=((0, 0, 0), (1, 1, 1)), xfm=None,
+                 pixel_range=None):
+        self.tfn = tfn
+        self.mc = np.ascontiguousarray(mc_max_opacity, dtype=np.float32)
+        mc_dims, mc_sp = macrocell_shape(vol_dims)
+        assert tuple(self.mc.shape[::-1]) == tuple(mc_dims), (self.mc.shape, mc_dims)
+        s = Scene()
+        s.width, s.height, s.frame_index = width, height, frame_index
+        s.cam_from[:] = [float(v) for v in cam_from]
+        s.cam_at[:] = [float(v) for v in cam_at]
+        s.cam_up[:] = [float(v) for v in cam_up]
+        s.fovy = fovy
+        x = default_transform(vol_dims) if xfm is None else _f32(xfm)
+        s.xfm[:] = [float(v) for v in x]
+        s.vol_dims[:] = [int(v) for v in vol_dims]
+        s.bbox_lo[:] = [float(v) for v in bbox[0]]
+        s.bbox_hi[:] = [float(v) for v in bbox[1]]
+        s.sampling_rate = sampling_rate
+        s.mc_dims[:] = list(mc_dims)
+        s.mc_spacings[:] = [float(v) for v in mc_sp]
+        s.mc_max_opacity = _p(self.mc, C.c_float)
+        s.tfn = tfn.c
+        pr = pixel_range or (0, width * height)
+        s.pixel_lo, s.pixel_hi = pr
+        self.c = s
+
+
+def render_streaming(scene, value_fn, n_iters=16, accumulation=None):
+    """value_fn(coords[n,3] float32) -> values[n] float32"""
+    s = scene.c
+    npx = s.width * s.height
+    acc = np.zeros((npx, 4), dtype=np.float32) if accumulation is None else accumulation
+    frame = np.zeros((npx, 4), dtype=np.float32)
+    stats = RenderStats()
+
+    def _cb(_user, cptr, n, vptr):
+        coords = np.ctypeslib.as_array(cptr, shape=(n, 3))
+        vals = np.ctypeslib.as_array(vptr, shape=(n,))
+        vals[:] = value_fn(coords)
+
+    cb = VALUE_FN(_cb)
+    lib().vnro_render_streaming(C.byref(s), C.c_int(n_iters), cb, None, _p(acc, C.c_float), _p(frame, C.c_float),
+                                C.byref(stats))
+    st = {"n_samples": stats.n_samples, "n_slots": stats.n_slots, "n_iterations": stats.n_iterations,
+          "n_rays_hit": stats.n_rays_hit}
+    return frame.reshape(s.height, s.width, 4), acc, st
+
+
+def render_monolithic(scene, vol, accumulation=None, n_threads=1):
+    s = scene.c
+    vol = _f32(vol)
+    npx = s.width * s.height
+    acc = np.zeros((npx, 4), dtype=np.float32) if accumulation is None else accumulation
+    frame = np.zeros((npx, 4), dtype=np.float32)
+    L = lib()
+
+    def work(lo, hi):
+        L.vnro_render_monolithic(C.byref(s), _p(vol, C.c_float), C.c_int(lo), C.c_int(hi), _p(acc, C.c_float),
+                                 _p(frame, C.c_float))
+
+    if n_threads <= 1:
+        work(0, s.height)
+    else:
+        # interleaved scanline blocks; ctypes releases the GIL during the call
+        rows = [(r, min(r + 4, s.height)) for r in range(0, s.height, 4)]
+        it = iter(rows)
+        lk = threading.Lock()
+
+        def runner():
+            while True:
+                with lk:
+                    rg = next(it, None)
+                if rg is None:
+                    return
+                work(*rg)
+
+        ts = [threading.Thread(target=runner) for _ in range(n_threads)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    return frame.reshape(s.height, s.width, 4), acc
+
+
+def dda_trace(org, dir_, t_min, t_max, grid, max_cells=4096):
+    cells = np.zeros((max_cells, 3), dtype=np.int32)
+    ts = np.zeros((max_cells, 2), dtype=np.float32)
+    o = (C.c_float * 3)(*[float(v) for v in org])
+    d = (C.c_float * 3)(*[float(v) for v in dir_])
+    n = lib().vnro_dda_trace(o, d, C.c_float(t_min), C.c_float(t_max), _dims(grid), _p(cells, C.c_int),
+                             _p(ts, C.c_float), C.c_size_t(max_cells))
+    n = min(int(n), max_cells)
+    return cells[:n], ts[:n]
+
+
+# --------------------------------------------------------------------------- metrics
+def grid_coords(lower, size, rdims):
+    n = int(size[0]) * int(size[1]) * int(size[2])
+    out = np.zeros((n, 3), dtype=np.float32)
+    r = (C.c_float * 3)(*[float(v) for v in rdims])
+    lib().vnro_generate_grid_coords(_dims(lower), _dims(size), r, _p(out, C.c_float))
+    return out
+
+
+def psnr(pred, ref, ref_min=None, ref_max=None):
+    pred = _f32(pred).ravel()
+    ref = _f32(ref).ravel()
+    lo = float(ref.min()) if ref_min is None else ref_min
+    hi = float(ref.max()) if ref_max is None else ref_max
+    return float(lib().vnro_psnr(_p(pred, C.c_float), _p(ref, C.c_float), C.c_size_t(pred.size), C.c_float(lo),
+                                 C.c_float(hi)))

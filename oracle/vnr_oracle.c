@@ -1,0 +1,1075 @@
+/* vnr_oracle.c — CPU oracle (plain C) for the instantvnr hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY — see vnr_oracle.h.  PARITY UNPINNED (the
+ * reference has no tests / golden vectors and cannot be built here).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
+ * -ffp-contract=off matters: every fused multiply-add below is an explicit
+ * fmaf() placed where nvcc's default -fmad=true would contract the
+ * reference's expression, and nowhere else.
+ *
+ * All "ref:" citations are relative to /root/reference.
+ */
+#include "vnr_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FLOAT_LARGE 1e20f   /* ref: core/instantvnr_types.h:157 */
+#define NEARLY_ONE 0.9999f  /* ref: core/instantvnr_types.h:160 */
+
+/* ------------------------------------------------------------------------ */
+/* fp16                                                                      */
+/* ------------------------------------------------------------------------ */
+
+uint16_t vnro_f32_to_f16(float f)
+{
+  /* IEEE binary32 -> binary16, round-to-nearest-even, subnormals kept
+   * (what `(__half)x` does on sm>=70 and v_cvt_f16_f32 does on gfx950). */
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const uint32_t ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) { /* inf / nan */
+    return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? (0x200u | ((ax >> 13) & 0x3ffu)) : 0u));
+  }
+  if (ax >= 0x477ff000u) { /* >= 65520 rounds to inf */
+    return (uint16_t)(sign | 0x7c00u);
+  }
+  if (ax < 0x33000001u) { /* <= 2^-25: rounds to zero (tie at exactly 2^-25 -> even = 0) */
+    return (uint16_t)sign;
+  }
+  int32_t e = (int32_t)(ax >> 23) - 127;
+  uint32_t m = (ax & 0x7fffffu) | 0x800000u; /* 24-bit significand */
+  uint32_t shift;
+  uint32_t he;
+  if (e < -14) { /* subnormal half */
+    shift = (uint32_t)(13 + (-14 - e));
+    he = 0;
+  } else {
+    shift = 13;
+    he = (uint32_t)(e + 15);
+  }
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u);
+  const uint32_t half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) q++;
+  uint32_t h;
+  if (he == 0) {
+    h = q; /* may carry into exponent 1, which is the correct encoding */
+  } else {
+    h = ((he - 1) << 10) + q; /* q has the implicit bit at position 10 */
+  }
+  return (uint16_t)(sign | h);
+}
+
+float vnro_f16_to_f32(uint16_t h)
+{
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  const uint32_t e = (h >> 10) & 0x1fu;
+  const uint32_t m = h & 0x3ffu;
+  uint32_t x;
+  if (e == 0) {
+    if (m == 0) {
+      x = sign;
+    } else {
+      /* subnormal: value = m * 2^-24 */
+      float v = (float)m * 5.9604644775390625e-8f;
+      memcpy(&x, &v, 4);
+      x |= sign;
+    }
+  } else if (e == 31) {
+    x = sign | 0x7f800000u | (m << 13);
+  } else {
+    x = sign | ((e + 112u) << 23) | (m << 13);
+  }
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+/* half + half, correctly rounded (fp32 add of two halves then RNE is exact
+ * double rounding-free because 24 >= 2*11+2). */
+static inline uint16_t h_add(uint16_t a, uint16_t b)
+{
+  return vnro_f32_to_f16(vnro_f16_to_f32(a) + vnro_f16_to_f32(b));
+}
+
+/* ------------------------------------------------------------------------ */
+/* hash grid encoding                                                        */
+/* ------------------------------------------------------------------------ */
+
+static inline uint32_t next_multiple_u32(uint32_t v, uint32_t d) { return ((v + d - 1) / d) * d; }
+
+/* EXTERNAL (tcnn `GridEncodingTemplated` ctor, encodings/grid.h, v1.4-1.5 era):
+ * per-level scale/resolution as used by ref core/networks/tcnn_impl_decoder.cu:41-42,
+ * level size = min(next_multiple(res^3, 8), 2^log2_hashmap_size); offsets are
+ * prefix sums in entries (ref uses them as hashmap_offset_table[level]*F,
+ * tcnn_impl_decoder.cu:38-39). */
+uint32_t vnro_grid_make_layout(const vnro_grid_config* cfg, vnro_grid_layout* out)
+{
+  const float log2_pls = log2f(cfg->per_level_scale); /* ref: tcnn_device_api.h:52 */
+  uint32_t offset = 0;
+  for (uint32_t l = 0; l < cfg->n_levels; ++l) {
+    const float scale = exp2f((float)l * log2_pls) * (float)cfg->base_resolution - 1.0f; /* ref: tcnn_impl_decoder.cu:41 */
+    const uint32_t res = (uint32_t)ceilf(scale) + 1u;                                     /* ref: tcnn_impl_decoder.cu:42 */
+    const uint32_t max_params = 0xffffffffu / 2u;
+    const double cube = (double)res * (double)res * (double)res;
+    uint32_t n = cube > (double)max_params ? max_params : (uint32_t)cube;
+    n = next_multiple_u32(n, 8u);
+    const uint32_t cap = 1u << cfg->log2_hashmap_size;
+    if (n > cap) n = cap;
+    out->offsets[l] = offset;
+    out->scale[l] = scale;
+    out->resolution[l] = res;
+    offset += n;
+  }
+  out->offsets[cfg->n_levels] = offset;
+  return offset;
+}
+
+/* EXTERNAL (tcnn `grid_index` + `fast_hash`, common_device.h / grid.h); call
+ * site ref: core/networks/tcnn_impl_decoder.cu:68-69. */
+uint32_t vnro_grid_index(uint32_t hashmap_size, uint32_t resolution, const uint32_t p[3])
+{
+  uint32_t stride = 1;
+  uint32_t index = 0;
+  for (uint32_t dim = 0; dim < 3 && stride <= hashmap_size; ++dim) {
+    index += p[dim] * stride;
+    stride *= resolution;
+  }
+  if (hashmap_size < stride) {
+    index = (p[0] * 1u) ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u);
+  }
+  return index % hashmap_size;
+}
+
+/* ref: core/networks/tcnn_impl_decoder.cu:7-175 (encode_one_level), Linear /
+ * Smoothstep interpolation, Hash grid, quantize_threshold = 0, max_level = inf. */
+static void encode_one_level(const vnro_grid_config* cfg, const vnro_grid_layout* lay,
+                             const uint16_t* table, uint32_t level, const float in[3],
+                             uint16_t* out /* [F] */)
+{
+  const uint32_t F = cfg->n_features;
+  const uint16_t* grid = table + (size_t)lay->offsets[level] * F;         /* :38 */
+  const uint32_t hashmap_size = lay->offsets[level + 1] - lay->offsets[level]; /* :39 */
+  const float scale = lay->scale[level];
+  const uint32_t res = lay->resolution[level];
+
+  float pos[3];
+  uint32_t pos_grid[3];
+  for (int d = 0; d < 3; ++d) {
+    /* EXTERNAL tcnn pos_fract (call site :54/:63): pos = x*scale+0.5 (fma under
+     * nvcc -fmad), floor, fract, then interpolation function. */
+    float p = fmaf(in[d], scale, 0.5f);
+    const float t = floorf(p);
+    pos_grid[d] = (uint32_t)(int32_t)t;
+    p -= t;
+    if (cfg->interpolation == 1) p = p * p * (3.0f - 2.0f * p); /* smoothstep */
+    pos[d] = p;
+  }
+
+  uint16_t result[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* PerLevelVec result = {} (:96) */
+  for (uint32_t idx = 0; idx < 8; ++idx) {       /* :99-123 */
+    float weight = 1.0f;
+    uint32_t pl[3];
+    for (uint32_t d = 0; d < 3; ++d) {
+      if ((idx & (1u << d)) == 0) {
+        weight *= 1.0f - pos[d];
+        pl[d] = pos_grid[d];
+      } else {
+        weight *= pos[d];
+        pl[d] = pos_grid[d] + 1u;
+      }
+    }
+    const uint32_t index = vnro_grid_index(hashmap_size, res, pl) * F;
+    for (uint32_t f = 0; f < F; ++f) {
+      const float data = vnro_f16_to_f32(grid[index + f]);
+      /* result[f] += (T)(weight * data): fp16 accumulate (:119-121) */
+      result[f] = h_add(result[f], vnro_f32_to_f16(weight * data));
+    }
+  }
+  for (uint32_t f = 0; f < F; ++f) out[f] = result[f];
+}
+
+void vnro_grid_encode(const vnro_grid_config* cfg, const uint16_t* table, const float* coords,
+                      size_t n, uint16_t* out, uint32_t padded_width)
+{
+  vnro_grid_layout lay;
+  vnro_grid_make_layout(cfg, &lay);
+  const uint32_t F = cfg->n_features;
+  for (size_t i = 0; i < n; ++i) {
+    uint16_t* row = out + i * padded_width;
+    memset(row, 0, sizeof(uint16_t) * padded_width); /* pad = 0 (tcnn_impl_decoder.cu:331-336) */
+    for (uint32_t l = 0; l < cfg->n_levels; ++l) {
+      /* column = level*F + f  (row-major-in-sample layout, :226) */
+      encode_one_level(cfg, &lay, table, l, coords + 3 * i, row + l * F);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* fully fused MLP forward                                                   */
+/* ------------------------------------------------------------------------ */
+
+size_t vnro_mlp_n_params(uint32_t in_width, uint32_t width, uint32_t n_hidden_matmuls)
+{
+  return (size_t)width * in_width + (size_t)n_hidden_matmuls * width * width + (size_t)16 * width;
+}
+
+/* one dense layer y[o] = sum_k W[o][k] x[k]; W row-major [out][in]
+ * (ref: tcnn_threadblock.h:104 reads W as col-major B with ld = WIDTH,
+ * i.e. B[k][o] = W[o*WIDTH + k]).  acc_mode F32: fp32 accumulation in k
+ * order.  acc_mode F16: emulates the reference's half accumulator fragment
+ * (tcnn_threadblock.h:83, OUT_T = __half): each 16-wide k block is summed in
+ * fp32 together with the running half accumulator and rounded to half. */
+static float dense_dot(const uint16_t* w_row, const uint16_t* x, uint32_t in, int acc_mode)
+{
+  if (acc_mode == VNRO_ACC_F32) {
+    float s = 0.0f;
+    for (uint32_t k = 0; k < in; ++k) s += vnro_f16_to_f32(w_row[k]) * vnro_f16_to_f32(x[k]);
+    return s;
+  }
+  uint16_t acc = 0;
+  for (uint32_t k0 = 0; k0 < in; k0 += 16) {
+    float s = vnro_f16_to_f32(acc);
+    for (uint32_t k = k0; k < k0 + 16 && k < in; ++k)
+      s += vnro_f16_to_f32(w_row[k]) * vnro_f16_to_f32(x[k]);
+    acc = vnro_f32_to_f16(s);
+  }
+  return vnro_f16_to_f32(acc);
+}
+
+static inline uint16_t apply_act_f16(float v, int activation)
+{
+  /* activation is applied on the half result fragment (tcnn_threadblock.h:125) */
+  uint16_t h = vnro_f32_to_f16(v);
+  if (activation == VNRO_ACT_RELU && (h & 0x8000u)) h = 0; /* relu(-0) = 0 too */
+  return h;
+}
+
+/* ref: tcnn_impl.cu:191-246 (layer order + weight offsets), tcnn_threadblock.h:59-144,
+ * :221-328, :446-505; final half -> float cast tcnn_impl.cu:421-431. */
+void vnro_mlp_forward(const uint16_t* weights, uint32_t in_width, uint32_t width,
+                      uint32_t n_hidden_matmuls, int activation, int acc_mode,
+                      const uint16_t* input, size_t n, float* out, uint16_t* act_out)
+{
+  uint16_t* a = (uint16_t*)malloc(sizeof(uint16_t) * width);
+  uint16_t* b = (uint16_t*)malloc(sizeof(uint16_t) * width);
+  const uint16_t* w_first = weights;
+  const uint16_t* w_hidden = weights + (size_t)width * in_width;            /* first_layer_size, tcnn_impl.cu:209 */
+  const uint16_t* w_last = w_hidden + (size_t)n_hidden_matmuls * width * width; /* :241 */
+  for (size_t i = 0; i < n; ++i) {
+    const uint16_t* x = input + i * in_width;
+    for (uint32_t o = 0; o < width; ++o)
+      a[o] = apply_act_f16(dense_dot(w_first + (size_t)o * in_width, x, in_width, acc_mode), activation);
+    if (act_out) memcpy(act_out + ((size_t)0 * n + i) * width, a, sizeof(uint16_t) * width);
+    for (uint32_t l = 0; l < n_hidden_matmuls; ++l) {
+      const uint16_t* w = w_hidden + (size_t)l * width * width;
+      for (uint32_t o = 0; o < width; ++o)
+        b[o] = apply_act_f16(dense_dot(w + (size_t)o * width, a, width, acc_mode), activation);
+      uint16_t* t = a; a = b; b = t;
+      if (act_out) memcpy(act_out + ((size_t)(l + 1) * n + i) * width, a, sizeof(uint16_t) * width);
+    }
+    /* last layer: 16 padded outputs, output activation None, only neuron 0 is used */
+    const float y = dense_dot(w_last, a, width, acc_mode);
+    out[i] = vnro_f16_to_f32(vnro_f32_to_f16(y));
+  }
+  free(a);
+  free(b);
+}
+
+void vnro_network_inference(const vnro_grid_config* cfg, uint32_t width, uint32_t n_hidden_layers,
+                            int activation, int acc_mode, const uint16_t* params,
+                            const float* coords, size_t n, float* out)
+{
+  const uint32_t in_width = next_multiple_u32(cfg->n_levels * cfg->n_features, 16u);
+  const uint32_t n_hidden_matmuls = n_hidden_layers - 1; /* EXTERNAL tcnn FullyFusedMLP */
+  const size_t n_mlp = vnro_mlp_n_params(in_width, width, n_hidden_matmuls);
+  const uint16_t* table = params + n_mlp; /* EXTERNAL: MLP first, then grid */
+  const size_t chunk = 4096;
+  uint16_t* enc = (uint16_t*)malloc(sizeof(uint16_t) * chunk * in_width);
+  for (size_t i0 = 0; i0 < n; i0 += chunk) {
+    const size_t m = (n - i0 < chunk) ? (n - i0) : chunk;
+    vnro_grid_encode(cfg, table, coords + 3 * i0, m, enc, in_width);
+    vnro_mlp_forward(params, in_width, width, n_hidden_matmuls, activation, acc_mode, enc, m, out + i0, NULL);
+  }
+  free(enc);
+}
+
+/* ------------------------------------------------------------------------ */
+/* ground-truth volume sampling                                              */
+/* ------------------------------------------------------------------------ */
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* EXTERNAL: CUDA tex3D, normalised coords, cudaFilterModeLinear, clamp
+ * addressing (ref: core/array.h:79; clamp explicit in
+ * device/device_nnvolume_array.cpp:449-450).  xB = x*N - 0.5, i = floor(xB),
+ * a = frac(xB).  The hardware uses 9-bit fixed-point weights; the oracle uses
+ * exact fp32 weights (tolerance ~2^-8 relative on interpolants vs. real CUDA). */
+float vnro_tex3d(const float* vol, const int dims[3], float px, float py, float pz)
+{
+  const float xb = px * (float)dims[0] - 0.5f;
+  const float yb = py * (float)dims[1] - 0.5f;
+  const float zb = pz * (float)dims[2] - 0.5f;
+  const float fx0 = floorf(xb), fy0 = floorf(yb), fz0 = floorf(zb);
+  const float a = xb - fx0, b = yb - fy0, g = zb - fz0;
+  const int x0 = clampi((int)fx0, 0, dims[0] - 1), x1 = clampi((int)fx0 + 1, 0, dims[0] - 1);
+  const int y0 = clampi((int)fy0, 0, dims[1] - 1), y1 = clampi((int)fy0 + 1, 0, dims[1] - 1);
+  const int z0 = clampi((int)fz0, 0, dims[2] - 1), z1 = clampi((int)fz0 + 1, 0, dims[2] - 1);
+  const size_t sx = 1, sy = (size_t)dims[0], sz = (size_t)dims[0] * dims[1];
+  const float v000 = vol[x0 * sx + y0 * sy + z0 * sz], v100 = vol[x1 * sx + y0 * sy + z0 * sz];
+  const float v010 = vol[x0 * sx + y1 * sy + z0 * sz], v110 = vol[x1 * sx + y1 * sy + z0 * sz];
+  const float v001 = vol[x0 * sx + y0 * sy + z1 * sz], v101 = vol[x1 * sx + y0 * sy + z1 * sz];
+  const float v011 = vol[x0 * sx + y1 * sy + z1 * sz], v111 = vol[x1 * sx + y1 * sy + z1 * sz];
+  const float c00 = v000 * (1.0f - a) + v100 * a;
+  const float c10 = v010 * (1.0f - a) + v110 * a;
+  const float c01 = v001 * (1.0f - a) + v101 * a;
+  const float c11 = v011 * (1.0f - a) + v111 * a;
+  const float c0 = c00 * (1.0f - b) + c10 * b;
+  const float c1 = c01 * (1.0f - b) + c11 * b;
+  return c0 * (1.0f - g) + c1 * g;
+}
+
+/* ref: core/renderer/raytracing.h:105-110 (sampleVolume) */
+float vnro_sample_volume(const float* vol, const int dims[3], float px, float py, float pz)
+{
+  const float rx = 1.0f / (float)dims[0], ry = 1.0f / (float)dims[1], rz = 1.0f / (float)dims[2];
+  px = px * (1.0f - rx) + 0.5f * rx;
+  py = py * (1.0f - ry) + 0.5f * ry;
+  pz = pz * (1.0f - rz) + 0.5f * rz;
+  return vnro_tex3d(vol, dims, px, py, pz);
+}
+
+void vnro_sample_volume_batch(const float* vol, const int dims[3], const float* coords, size_t n,
+                              int nodal, float* out)
+{
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = coords + 3 * i;
+    out[i] = nodal ? vnro_sample_volume(vol, dims, p[0], p[1], p[2]) /* renderer */
+                   : vnro_tex3d(vol, dims, p[0], p[1], p[2]);        /* sampler: neural_sampler.cu:150-154 */
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* transfer function                                                         */
+/* ------------------------------------------------------------------------ */
+
+/* ref: core/renderer/raytracing.h:71-81 (array1dNodal) + EXTERNAL CUDA tex1D
+ * linear filter, normalised coords, clamp. */
+static void array1d_nodal(const float* data, int len, int stride, float v, float* out)
+{
+  if (len == 0) { for (int c = 0; c < stride; ++c) out[c] = 0.0f; return; }
+  v = clampf(v, 0.0f, 1.0f);
+  const float t = fmaf(v, (float)(len - 1), 0.5f) * (1.0f / (float)len);
+  const float xb = t * (float)len - 0.5f;
+  const float f0 = floorf(xb);
+  const float a = xb - f0;
+  const int i0 = clampi((int)f0, 0, len - 1), i1 = clampi((int)f0 + 1, 0, len - 1);
+  for (int c = 0; c < stride; ++c) out[c] = data[i0 * stride + c] * (1.0f - a) + data[i1 * stride + c] * a;
+}
+
+/* ref: core/renderer/raytracing.h:147-155 */
+void vnro_tfn_sample(const vnro_tfn* tfn, float value, float rgb[3], float* alpha)
+{
+  const float v = (clampf(value, tfn->range_lo, tfn->range_hi) - tfn->range_lo) * tfn->range_rcp_norm;
+  float rgba[4];
+  array1d_nodal(tfn->colors, tfn->n_colors, 4, v, rgba);
+  float a;
+  array1d_nodal(tfn->alphas, tfn->n_alphas, 1, v, &a);
+  rgb[0] = rgba[0]; rgb[1] = rgba[1]; rgb[2] = rgba[2];
+  *alpha = a;
+}
+
+/* ------------------------------------------------------------------------ */
+/* macrocell                                                                 */
+/* ------------------------------------------------------------------------ */
+
+#define MC_SIZE (1 << VNRO_MACROCELL_SIZE_MIP)
+
+/* ref: core/macrocell.cu:195-201 */
+void vnro_macrocell_shape(const int vol_dims[3], int mc_dims[3], float mc_spacings[3])
+{
+  for (int d = 0; d < 3; ++d) {
+    mc_dims[d] = (vol_dims[d] + MC_SIZE - 1) / MC_SIZE;
+    mc_spacings[d] = (float)MC_SIZE / (float)vol_dims[d];
+  }
+}
+
+/* ref: core/macrocell.cu:11-40.  Float atomicMin/Max (instantvnr_types.h:185-199)
+ * are order independent, so a sequential min/max is exact. */
+static void update_single_macrocell(int vx, int vy, int vz, const int mc_dims[3], float* mc, float value)
+{
+  const int cx = vx >> VNRO_MACROCELL_SIZE_MIP, cy = vy >> VNRO_MACROCELL_SIZE_MIP, cz = vz >> VNRO_MACROCELL_SIZE_MIP;
+  if (cx < 0 || cx >= mc_dims[0]) return;
+  if (cy < 0 || cy >= mc_dims[1]) return;
+  if (cz < 0 || cz >= mc_dims[2]) return;
+  const size_t idx = (size_t)cx + (size_t)cy * mc_dims[0] + (size_t)cz * mc_dims[1] * mc_dims[0];
+  const float lo = value - 1.0f, hi = value + 1.0f;
+  if (lo < mc[2 * idx]) mc[2 * idx] = lo;
+  if (hi > mc[2 * idx + 1]) mc[2 * idx + 1] = hi;
+}
+
+static void update_voxel_and_neighbours(int x, int y, int z, const int mc_dims[3], float* mc, float value)
+{
+  const int sx = (x % MC_SIZE) == 0 ? -1 : ((x % MC_SIZE) == (MC_SIZE - 1) ? 1 : 0);
+  const int sy = (y % MC_SIZE) == 0 ? -1 : ((y % MC_SIZE) == (MC_SIZE - 1) ? 1 : 0);
+  const int sz = (z % MC_SIZE) == 0 ? -1 : ((z % MC_SIZE) == (MC_SIZE - 1) ? 1 : 0);
+  update_single_macrocell(x, y, z, mc_dims, mc, value);
+  update_single_macrocell(x + sx, y, z, mc_dims, mc, value);
+  update_single_macrocell(x, y + sy, z, mc_dims, mc, value);
+  update_single_macrocell(x + sx, y + sy, z, mc_dims, mc, value);
+  update_single_macrocell(x, y, z + sz, mc_dims, mc, value);
+  update_single_macrocell(x + sx, y, z + sz, mc_dims, mc, value);
+  update_single_macrocell(x, y + sy, z + sz, mc_dims, mc, value);
+  update_single_macrocell(x + sx, y + sy, z + sz, mc_dims, mc, value);
+}
+
+/* ref: core/macrocell.cu:42-73 */
+void vnro_macrocell_update_explicit(const float* coords, const float* values, size_t n,
+                                    const int vol_dims[3], const int mc_dims[3], float* value_range)
+{
+  for (size_t i = 0; i < n; ++i) {
+    int v[3];
+    for (int d = 0; d < 3; ++d) {
+      /* clamp((uint32_t)floorf(c*dims), 0, dims-1): a negative float->uint32 cast is
+       * UB in C++/saturates to 0 on CUDA; coords are in [0,1] on this path. */
+      const float f = floorf(coords[3 * i + d] * (float)vol_dims[d]);
+      uint32_t u = f <= 0.0f ? 0u : (f >= 4294967040.0f ? 0xffffffffu : (uint32_t)f);
+      if (u > (uint32_t)(vol_dims[d] - 1)) u = (uint32_t)(vol_dims[d] - 1);
+      v[d] = (int)u;
+    }
+    update_voxel_and_neighbours(v[0], v[1], v[2], mc_dims, value_range, values[i]);
+  }
+}
+
+/* ref: core/macrocell.cu:75-111, 221-229: value = tex3D at voxel centres */
+void vnro_macrocell_compute_implicit(const float* vol, const int vol_dims[3],
+                                     const int mc_dims[3], float* value_range)
+{
+  for (int z = 0; z < vol_dims[2]; ++z)
+    for (int y = 0; y < vol_dims[1]; ++y)
+      for (int x = 0; x < vol_dims[0]; ++x) {
+        const float fx = ((float)x + 0.5f) / (float)vol_dims[0];
+        const float fy = ((float)y + 0.5f) / (float)vol_dims[1];
+        const float fz = ((float)z + 0.5f) / (float)vol_dims[2];
+        const float value = vnro_tex3d(vol, vol_dims, fx, fy, fz);
+        update_voxel_and_neighbours(x, y, z, mc_dims, value_range, value);
+      }
+}
+
+/* ref: core/macrocell.cu:153-193 */
+void vnro_macrocell_max_opacity(const vnro_tfn* tfn, const float* value_range, size_t n_cells,
+                                float* max_opacity)
+{
+  const int len = tfn->n_alphas;
+  if (len <= 0) return; /* :245 */
+  for (size_t i = 0; i < n_cells; ++i) {
+    const float rx = value_range[2 * i] + 1.0f;
+    const float ry = value_range[2 * i + 1] - 1.0f;
+    const float lower = (clampf(rx, tfn->range_lo, tfn->range_hi) - tfn->range_lo) * tfn->range_rcp_norm;
+    const float upper = (clampf(ry, tfn->range_lo, tfn->range_hi) - tfn->range_lo) * tfn->range_rcp_norm;
+    /* uint32_t i_lower = floorf(..) - 1: float -> uint32; -1.0f converts to 0 on CUDA (saturating) */
+    const float fl = floorf(fmaf(lower, (float)(len - 1), 0.5f)) - 1.0f;
+    const float fu = floorf(fmaf(upper, (float)(len - 1), 0.5f)) + 1.0f;
+    uint32_t il = fl <= 0.0f ? 0u : (uint32_t)fl;
+    uint32_t iu = fu <= 0.0f ? 0u : (uint32_t)fu;
+    if (il > (uint32_t)(len - 1)) il = (uint32_t)(len - 1);
+    if (iu > (uint32_t)(len - 1)) iu = (uint32_t)(len - 1);
+    float op = 0.0f;
+    for (uint32_t j = il; j <= iu; ++j) op = fmaxf(op, tfn->alphas[j]);
+    max_opacity[i] = op;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* RNG                                                                       */
+/* ------------------------------------------------------------------------ */
+
+/* EXTERNAL gdt::LCG<16> (gdt/random/random.h; ref use: instantvnr_types.h:155) */
+void vnro_lcg_init(vnro_lcg* r, uint32_t val0, uint32_t val1)
+{
+  uint32_t v0 = val0, v1 = val1, s0 = 0;
+  for (int n = 0; n < 16; ++n) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+  }
+  r->state = v0;
+}
+
+float vnro_lcg_next(vnro_lcg* r)
+{
+  r->state = 1664525u * r->state + 1013904223u;
+  return (float)(r->state & 0x00FFFFFFu) / (float)0x01000000;
+}
+
+/* EXTERNAL pcg32 (tcnn default_rng_t; ref use: neural_sampler.cu:36-41) */
+void vnro_pcg32_seed(vnro_pcg32* r, uint64_t initstate, uint64_t initseq)
+{
+  r->state = 0u;
+  r->inc = (initseq << 1u) | 1u;
+  vnro_pcg32_next_uint(r);
+  r->state += initstate;
+  vnro_pcg32_next_uint(r);
+}
+
+uint32_t vnro_pcg32_next_uint(vnro_pcg32* r)
+{
+  const uint64_t oldstate = r->state;
+  r->state = oldstate * 0x5851f42d4c957f2dULL + r->inc;
+  const uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+  const uint32_t rot = (uint32_t)(oldstate >> 59u);
+  return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+
+float vnro_pcg32_next_float(vnro_pcg32* r)
+{
+  union { uint32_t u; float f; } x;
+  x.u = (vnro_pcg32_next_uint(r) >> 9) | 0x3f800000u;
+  return x.f - 1.0f;
+}
+
+void vnro_pcg32_advance(vnro_pcg32* r, int64_t delta_)
+{
+  uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = r->inc, acc_mult = 1u, acc_plus = 0u;
+  uint64_t delta = (uint64_t)delta_;
+  while (delta > 0) {
+    if (delta & 1) {
+      acc_mult *= cur_mult;
+      acc_plus = acc_plus * cur_mult + cur_plus;
+    }
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+    delta /= 2;
+  }
+  r->state = acc_mult * r->state + acc_plus;
+}
+
+/* ------------------------------------------------------------------------ */
+/* vector helpers                                                            */
+/* ------------------------------------------------------------------------ */
+
+typedef struct { float x, y, z; } v3;
+typedef struct { int x, y, z; } i3;
+
+static inline v3 v3_make(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v3_mul(v3 a, v3 b) { return v3_make(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 v3_scale(float s, v3 a) { return v3_make(s * a.x, s * a.y, s * a.z); }
+static inline float v3_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 v3_cross(v3 a, v3 b)
+{
+  return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* EXTERNAL gdt normalize: v * (1/sqrt(dot(v,v))) */
+static inline v3 v3_normalize(v3 a) { return v3_scale(1.0f / sqrtf(v3_dot(a, a)), a); }
+static inline float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+static inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+typedef struct { v3 vx, vy, vz, p; } affine;
+
+static affine affine_from(const float m[12])
+{
+  affine a;
+  a.vx = v3_make(m[0], m[1], m[2]);
+  a.vy = v3_make(m[3], m[4], m[5]);
+  a.vz = v3_make(m[6], m[7], m[8]);
+  a.p = v3_make(m[9], m[10], m[11]);
+  return a;
+}
+static inline v3 xfm_vector(const affine* a, v3 v)
+{
+  return v3_add(v3_add(v3_scale(v.x, a->vx), v3_scale(v.y, a->vy)), v3_scale(v.z, a->vz));
+}
+static inline v3 xfm_point(const affine* a, v3 v) { return v3_add(xfm_vector(a, v), a->p); }
+/* EXTERNAL gdt AffineSpace::inverse(): linear inverse = adjoint / det, p' = -(L^-1 p) */
+static affine affine_inverse(const affine* a)
+{
+  const v3 c0 = v3_cross(a->vy, a->vz), c1 = v3_cross(a->vz, a->vx), c2 = v3_cross(a->vx, a->vy);
+  const float det = v3_dot(a->vx, c0);
+  const float r = 1.0f / det;
+  affine o;
+  /* rows of the adjoint are the cross products; columns of the inverse: */
+  o.vx = v3_scale(r, v3_make(c0.x, c1.x, c2.x));
+  o.vy = v3_scale(r, v3_make(c0.y, c1.y, c2.y));
+  o.vz = v3_scale(r, v3_make(c0.z, c1.z, c2.z));
+  const v3 t = xfm_vector(&o, a->p);
+  o.p = v3_make(-t.x, -t.y, -t.z);
+  return o;
+}
+
+/* ------------------------------------------------------------------------ */
+/* ray / box, camera                                                         */
+/* ------------------------------------------------------------------------ */
+
+/* ref: core/renderer/raytracing.h:9-36 */
+static int intersect_box(float* _t0, float* _t1, v3 org, v3 dir, v3 lower, v3 upper)
+{
+  float t0 = *_t0, t1 = *_t1;
+  const int sx = fabsf(dir.x) <= FLT_MIN, sy = fabsf(dir.y) <= FLT_MIN, sz = fabsf(dir.z) <= FLT_MIN;
+  const v3 rcp = v3_make(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  const v3 t_lo = v3_make(sx ? FLOAT_LARGE : (lower.x - org.x) * rcp.x,
+                          sy ? FLOAT_LARGE : (lower.y - org.y) * rcp.y,
+                          sz ? FLOAT_LARGE : (lower.z - org.z) * rcp.z);
+  const v3 t_hi = v3_make(sx ? -FLOAT_LARGE : (upper.x - org.x) * rcp.x,
+                          sy ? -FLOAT_LARGE : (upper.y - org.y) * rcp.y,
+                          sz ? -FLOAT_LARGE : (upper.z - org.z) * rcp.z);
+  t0 = fmaxf(t0, max3f(fminf(t_lo.x, t_hi.x), fminf(t_lo.y, t_hi.y), fminf(t_lo.z, t_hi.z)));
+  t1 = fminf(t1, min3f(fmaxf(t_lo.x, t_hi.x), fmaxf(t_lo.y, t_hi.y), fmaxf(t_lo.z, t_hi.z)));
+  *_t0 = t0;
+  *_t1 = t1;
+  return t1 > t0;
+}
+
+typedef struct { v3 position, direction, horizontal, vertical; } camera_t;
+
+/* ref: renderer.cpp:87-96 */
+static camera_t make_camera(const vnro_scene* s)
+{
+  camera_t c;
+  const v3 from = v3_make(s->cam_from[0], s->cam_from[1], s->cam_from[2]);
+  const v3 at = v3_make(s->cam_at[0], s->cam_at[1], s->cam_at[2]);
+  const v3 up = v3_make(s->cam_up[0], s->cam_up[1], s->cam_up[2]);
+  const float t = 2.0f * tanf(s->fovy * 0.5f * (float)M_PI / 180.0f);
+  const float aspect = (float)s->width / (float)s->height;
+  c.position = from;
+  c.direction = v3_normalize(v3_sub(at, from));
+  c.horizontal = v3_scale(t * aspect, v3_normalize(v3_cross(c.direction, up)));
+  c.vertical = v3_scale(1.0f / aspect, v3_cross(c.horizontal, c.direction));
+  /* NOTE: ref divides by aspect (vec / float); gdt implements vec/float as multiplication by
+   * rcp(float) — treated as equal within render tolerance. */
+  return c;
+}
+
+typedef struct { v3 org, dir; } ray_t;
+
+/* ref: core/renderer/method_raymarching.cu:658-685 (compute_ray) */
+static ray_t compute_ray(const vnro_scene* s, const camera_t* cam, const affine* wto, uint32_t pixel)
+{
+  const uint32_t ix = pixel % (uint32_t)s->width, iy = pixel / (uint32_t)s->width;
+  const float sx = ((float)ix + 0.5f) / (float)s->width;
+  const float sy = ((float)iy + 0.5f) / (float)s->height;
+  ray_t r;
+  r.org = xfm_point(wto, cam->position);
+  const v3 d = v3_add(v3_add(cam->direction, v3_scale(sx - 0.5f, cam->horizontal)), v3_scale(sy - 0.5f, cam->vertical));
+  r.dir = xfm_vector(wto, v3_normalize(d));
+  return r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* DDA (ref: core/renderer/dda.h)                                            */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  v3 t_next;
+  i3 cell;
+  float next_cell_begin;
+} dda_iter;
+
+/* ref: dda.h:26-46 */
+static void dda_init(dda_iter* it, v3 org, v3 dir, float t_min, float t_max, i3 grid)
+{
+  (void)t_max;
+  const v3 oiv = v3_add(org, v3_scale(t_min, dir));
+  const v3 fc = v3_make(fmaxf(0.0f, fminf((float)grid.x - 1.0f, floorf(oiv.x))),
+                        fmaxf(0.0f, fminf((float)grid.y - 1.0f, floorf(oiv.y))),
+                        fmaxf(0.0f, fminf((float)grid.z - 1.0f, floorf(oiv.z))));
+  const v3 fe = v3_make(dir.x > 0.0f ? fc.x + 1.0f : fc.x, dir.y > 0.0f ? fc.y + 1.0f : fc.y,
+                        dir.z > 0.0f ? fc.z + 1.0f : fc.z);
+  const v3 ts = v3_make(fabsf(1.0f / dir.x), fabsf(1.0f / dir.y), fabsf(1.0f / dir.z));
+  it->t_next = v3_make(dir.x == 0.0f ? FLOAT_LARGE : fabsf(fe.x - oiv.x) * ts.x,
+                       dir.y == 0.0f ? FLOAT_LARGE : fabsf(fe.y - oiv.y) * ts.y,
+                       dir.z == 0.0f ? FLOAT_LARGE : fabsf(fe.z - oiv.z) * ts.z);
+  it->cell.x = (int)fc.x; it->cell.y = (int)fc.y; it->cell.z = (int)fc.z;
+  it->next_cell_begin = 0.0f;
+}
+
+typedef int (*dda_cell_fn)(void* ctx, i3 cell, float t0, float t1);
+
+/* ref: dda.h:48-122 */
+static int dda_next(dda_iter* it, v3 dir, float t_min, float t_max, i3 grid, dda_cell_fn fn, void* ctx)
+{
+  const i3 stop = { dir.x > 0.0f ? grid.x : -1, dir.y > 0.0f ? grid.y : -1, dir.z > 0.0f ? grid.z : -1 };
+  if (it->cell.x == stop.x) return 0;
+  if (it->cell.y == stop.y) return 0;
+  if (it->cell.z == stop.z) return 0;
+  const v3 ts = v3_make(fabsf(1.0f / dir.x), fabsf(1.0f / dir.y), fabsf(1.0f / dir.z));
+  const i3 delta = { dir.x > 0.0f ? 1 : -1, dir.y > 0.0f ? 1 : -1, dir.z > 0.0f ? 1 : -1 };
+  const float t_closest = min3f(it->t_next.x, it->t_next.y, it->t_next.z);
+  const float cell_t0 = fmaxf(t_min + it->next_cell_begin, t_min);
+  const float cell_t1 = fminf(t_min + t_closest, t_max);
+  if (cell_t0 >= cell_t1) return 0;
+  const int go = fn(ctx, it->cell, cell_t0, cell_t1);
+  if (go || fmaxf(t_min + it->next_cell_begin, t_min) >= cell_t1) {
+    if (it->t_next.x == t_closest) { it->t_next.x += ts.x; it->cell.x += delta.x; if (it->cell.x == stop.x) return 0; }
+    if (it->t_next.y == t_closest) { it->t_next.y += ts.y; it->cell.y += delta.y; if (it->cell.y == stop.y) return 0; }
+    if (it->t_next.z == t_closest) { it->t_next.z += ts.z; it->cell.z += delta.z; if (it->cell.z == stop.z) return 0; }
+    it->next_cell_begin = t_closest;
+  }
+  return go;
+}
+
+/* ref: dda.h:124-137 */
+static int dda_resumable(const dda_iter* it, v3 dir, float t_min, float t_max, i3 grid)
+{
+  const i3 stop = { dir.x > 0.0f ? grid.x : -1, dir.y > 0.0f ? grid.y : -1, dir.z > 0.0f ? grid.z : -1 };
+  if (it->cell.x == stop.x) return 0;
+  if (it->cell.y == stop.y) return 0;
+  if (it->cell.z == stop.z) return 0;
+  const float t_closest = min3f(it->t_next.x, it->t_next.y, it->t_next.z);
+  const float cell_t0 = fmaxf(t_min + it->next_cell_begin, t_min);
+  const float cell_t1 = fminf(t_min + t_closest, t_max);
+  return cell_t0 < cell_t1;
+}
+
+/* ref: dda.h:140-287 (dda3, monolithic traversal) */
+static void dda3(v3 org, v3 dir, float t_min, float t_max, i3 grid, dda_cell_fn fn, void* ctx)
+{
+  if (t_min >= t_max) return;
+  dda_iter it;
+  dda_init(&it, org, dir, t_min, t_max, grid);
+  const v3 ts = v3_make(fabsf(1.0f / dir.x), fabsf(1.0f / dir.y), fabsf(1.0f / dir.z));
+  const i3 stop = { dir.x > 0.0f ? grid.x : -1, dir.y > 0.0f ? grid.y : -1, dir.z > 0.0f ? grid.z : -1 };
+  const i3 delta = { dir.x > 0.0f ? 1 : -1, dir.y > 0.0f ? 1 : -1, dir.z > 0.0f ? 1 : -1 };
+  for (;;) {
+    const float t_closest = min3f(it.t_next.x, it.t_next.y, it.t_next.z);
+    const float cell_t0 = fmaxf(t_min + it.next_cell_begin, t_min);
+    const float cell_t1 = fminf(t_min + t_closest, t_max);
+    if (cell_t0 >= cell_t1) return;
+    if (!fn(ctx, it.cell, cell_t0, cell_t1)) return;
+    if (it.t_next.x == t_closest) { it.t_next.x += ts.x; it.cell.x += delta.x; if (it.cell.x == stop.x) return; }
+    if (it.t_next.y == t_closest) { it.t_next.y += ts.y; it.cell.y += delta.y; if (it.cell.y == stop.y) return; }
+    if (it.t_next.z == t_closest) { it.t_next.z += ts.z; it.cell.z += delta.z; if (it.cell.z == stop.z) return; }
+    it.next_cell_begin = t_closest;
+  }
+}
+
+typedef struct { int* cells; float* ts; size_t n, cap; } trace_ctx;
+static int trace_cell(void* c, i3 cell, float t0, float t1)
+{
+  trace_ctx* t = (trace_ctx*)c;
+  if (t->n < t->cap) {
+    t->cells[3 * t->n + 0] = cell.x; t->cells[3 * t->n + 1] = cell.y; t->cells[3 * t->n + 2] = cell.z;
+    t->ts[2 * t->n + 0] = t0; t->ts[2 * t->n + 1] = t1;
+  }
+  t->n++;
+  return 1;
+}
+size_t vnro_dda_trace(const float org[3], const float dir[3], float t_min, float t_max,
+                      const int grid[3], int* cells, float* ts, size_t max_cells)
+{
+  trace_ctx c = { cells, ts, 0, max_cells };
+  const i3 g = { grid[0], grid[1], grid[2] };
+  dda3(v3_make(org[0], org[1], org[2]), v3_make(dir[0], dir[1], dir[2]), t_min, t_max, g, trace_cell, &c);
+  return c.n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* marching helpers                                                          */
+/* ------------------------------------------------------------------------ */
+
+/* ref: core/renderer/raytracing.h:172-186 */
+static inline float opacity_upper_bound(const vnro_scene* s, i3 cell)
+{
+  const size_t idx = (size_t)cell.x + (size_t)cell.y * (size_t)s->mc_dims[0] +
+                     (size_t)cell.z * (size_t)s->mc_dims[0] * (size_t)s->mc_dims[1];
+  return s->mc_max_opacity[idx];
+}
+
+/* ref: core/renderer/raytracing.h:188-194 */
+static inline float adaptive_sampling_rate(float base_step, float max_opacity)
+{
+  const float scale = 15.0f * base_step;
+  const float r = fabsf(clampf(max_opacity, 0.1f, 1.0f) - 1.0f);
+  return fmaxf(base_step + scale * (r * r), base_step);
+}
+
+/* ref: core/renderer/raytracing.h:166-170 */
+static inline float opacity_correction(float step_rcp, float distance, float opacity)
+{
+  return 1.0f - powf(1.0f - opacity, step_rcp * distance);
+}
+
+/* ref: core/renderer/raytracing.h:196-207 */
+static void write_pixel(const vnro_scene* s, float* accumulation, float* frame, const float rgba[4], uint32_t pixel)
+{
+  float out[4];
+  for (int c = 0; c < 4; ++c) {
+    float v = rgba[c];
+    if (s->frame_index != 1) v = accumulation[4 * pixel + c] + v;
+    accumulation[4 * pixel + c] = v;
+    out[c] = v;
+  }
+  for (int c = 0; c < 4; ++c) frame[4 * pixel + c] = out[c] / (float)s->frame_index;
+}
+
+/* ------------------------------------------------------------------------ */
+/* sample-streaming ray marcher (mode 5)                                     */
+/* ref: core/renderer/method_raymarching.cu:544-973                          */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  uint32_t pixel_index;
+  float jitter;
+  float alpha;
+  v3 color;
+  dda_iter iter;
+} payload_t;
+
+typedef int (*sample_body_fn)(void* ctx, float t0, float t1);
+
+typedef struct {
+  const vnro_scene* s;
+  dda_iter* iter;
+  float t_min, step;
+  sample_body_fn body;
+  void* body_ctx;
+} exec_ctx;
+
+/* the lambda of RayMarchingIter::exec, ref: method_raymarching.cu:565-580 */
+static int exec_cell(void* c, i3 cell, float t0, float t1)
+{
+  exec_ctx* e = (exec_ctx*)c;
+  const float r = opacity_upper_bound(e->s, cell);
+  if (fabsf(r) <= FLT_EPSILON) return 1; /* empty cell */
+  const float ss = adaptive_sampling_rate(e->step, r);
+  float tx = t0, ty = fminf(t1, t0 + ss);
+  while (ty > tx) {
+    e->iter->next_cell_begin = ty - e->t_min;
+    if (!e->body(e->body_ctx, tx, ty)) return 0;
+    tx = ty;
+    ty = fminf(tx + ss, t1);
+  }
+  return 1;
+}
+
+/* ref: method_raymarching.cu:555-600 */
+static void iter_exec(const vnro_scene* s, dda_iter* iter, v3 dir, float t_min, float t_max, float step,
+                      sample_body_fn body, void* body_ctx)
+{
+  const v3 rcp = v3_make(1.0f / s->mc_spacings[0], 1.0f / s->mc_spacings[1], 1.0f / s->mc_spacings[2]);
+  const v3 m_dir = v3_mul(dir, rcp);
+  const i3 grid = { s->mc_dims[0], s->mc_dims[1], s->mc_dims[2] };
+  exec_ctx e = { s, iter, t_min, step, body, body_ctx };
+  while (dda_next(iter, m_dir, t_min, t_max, grid, exec_cell, &e)) {}
+}
+
+typedef struct { ray_t ray; float jitter; float* coords; uint32_t n_rays, i; int k, n_iters; } intersect_ctx;
+static int intersect_body(void* c, float t0, float t1)
+{
+  intersect_ctx* x = (intersect_ctx*)c;
+  /* lerp(r,a,b) = (1-r)*a + r*b  (instantvnr_types.h:162-166) */
+  const float t = (1.0f - x->jitter) * t0 + x->jitter * t1;
+  const v3 p = v3_add(x->ray.org, v3_scale(t, x->ray.dir));
+  float* dst = x->coords + 3 * ((size_t)x->n_rays * x->k + x->i);
+  dst[0] = p.x; dst[1] = p.y; dst[2] = p.z;
+  return (++x->k) < x->n_iters;
+}
+
+typedef struct {
+  const vnro_scene* s; const float* samples; uint32_t n_rays, i; int k, n_iters;
+  float alpha; v3 color; float step_rcp;
+} compose_ctx;
+static int compose_body(void* c, float t0, float t1)
+{
+  compose_ctx* x = (compose_ctx*)c;
+  const float value = x->samples[(size_t)x->n_rays * x->k + x->i];
+  float rgb[3], a;
+  vnro_tfn_sample(&x->s->tfn, value, rgb, &a);
+  a = opacity_correction(x->step_rcp, t1 - t0, a);
+  const float tr = 1.0f - x->alpha;
+  x->alpha += tr * a;
+  x->color.x += tr * rgb[0] * a;
+  x->color.y += tr * rgb[1] * a;
+  x->color.z += tr * rgb[2] * a;
+  return ((++x->k) < x->n_iters) && (x->alpha < NEARLY_ONE);
+}
+
+void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, void* user,
+                           float* accumulation, float* frame, vnro_render_stats* stats)
+{
+  const uint32_t n_pixels = (uint32_t)s->width * (uint32_t)s->height;
+  const camera_t cam = make_camera(s);
+  const affine otw = affine_from(s->xfm);
+  const affine wto = affine_inverse(&otw);
+  const v3 lo = v3_make(s->bbox_lo[0], s->bbox_lo[1], s->bbox_lo[2]);
+  const v3 hi = v3_make(s->bbox_hi[0], s->bbox_hi[1], s->bbox_hi[2]);
+  const float step = 1.0f / s->sampling_rate, step_rcp = s->sampling_rate; /* object.cpp:303-304 */
+  const v3 rcp = v3_make(1.0f / s->mc_spacings[0], 1.0f / s->mc_spacings[1], 1.0f / s->mc_spacings[2]);
+  const i3 grid = { s->mc_dims[0], s->mc_dims[1], s->mc_dims[2] };
+
+  payload_t* cur = (payload_t*)malloc(sizeof(payload_t) * n_pixels);
+  payload_t* nxt = (payload_t*)malloc(sizeof(payload_t) * n_pixels);
+  float* coords = (float*)calloc((size_t)n_pixels * n_iters * 3, sizeof(float));
+  float* values = (float*)calloc((size_t)n_pixels * n_iters, sizeof(float));
+  vnro_render_stats st = {0, 0, 0, 0};
+
+  /* raygen, ref: method_raymarching.cu:840-875 */
+  uint32_t n_rays = 0;
+  const uint32_t p_lo = s->pixel_lo, p_hi = s->pixel_hi < n_pixels ? s->pixel_hi : n_pixels;
+  for (uint32_t i = p_lo; i < p_hi; ++i) {
+    vnro_lcg rng;
+    vnro_lcg_init(&rng, (uint32_t)s->frame_index, i);
+    const float jitter = vnro_lcg_next(&rng); /* get_floats().x */
+    const ray_t ray = compute_ray(s, &cam, &wto, i);
+    float tmin = 0.0f, tmax = FLOAT_LARGE;
+    if (intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi)) {
+      payload_t p;
+      p.pixel_index = i; p.jitter = jitter; p.alpha = 0.0f; p.color = v3_make(0, 0, 0);
+      dda_init(&p.iter, v3_mul(ray.org, rcp), v3_mul(ray.dir, rcp), tmin, tmax, grid); /* :544-553 */
+      cur[n_rays++] = p;
+    } else {
+      const float zero[4] = {0, 0, 0, 0};
+      write_pixel(s, accumulation, frame, zero, i);
+    }
+  }
+  st.n_rays_hit = n_rays;
+
+  /* loop, ref: method_raymarching.cu:931-958 */
+  while (n_rays > 0) {
+    st.n_iterations++;
+    st.n_slots += (uint64_t)n_rays * (uint64_t)n_iters;
+    /* intersect, :687-730 (iterator state is NOT saved here) */
+    for (uint32_t i = 0; i < n_rays; ++i) {
+      payload_t p = cur[i];
+      const ray_t ray = compute_ray(s, &cam, &wto, p.pixel_index);
+      float tmin = 0.0f, tmax = FLOAT_LARGE;
+      intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi);
+      intersect_ctx x = { ray, p.jitter, coords, n_rays, i, 0, n_iters };
+      iter_exec(s, &p.iter, ray.dir, tmin, tmax, step, intersect_body, &x);
+      st.n_samples += (uint64_t)x.k;
+    }
+    /* inference of ALL n_iters*n_rays slots (stale coords included), :950-953 */
+    fn(user, coords, (size_t)n_rays * n_iters, values);
+    /* compose, :732-838 */
+    uint32_t n_next = 0;
+    for (uint32_t i = 0; i < n_rays; ++i) {
+      payload_t p = cur[i];
+      const ray_t ray = compute_ray(s, &cam, &wto, p.pixel_index);
+      float tmin = 0.0f, tmax = FLOAT_LARGE;
+      intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi);
+      compose_ctx x = { s, values, n_rays, i, 0, n_iters, p.alpha, p.color, step_rcp };
+      iter_exec(s, &p.iter, ray.dir, tmin, tmax, step, compose_body, &x);
+      p.alpha = x.alpha; p.color = x.color;
+      const int resumable = dda_resumable(&p.iter, v3_mul(ray.dir, rcp), tmin, tmax, grid);
+      if (p.alpha < NEARLY_ONE && resumable) {
+        nxt[n_next++] = p;
+      } else {
+        const float rgba[4] = { p.color.x, p.color.y, p.color.z, p.alpha };
+        write_pixel(s, accumulation, frame, rgba, p.pixel_index);
+      }
+    }
+    payload_t* t = cur; cur = nxt; nxt = t;
+    n_rays = n_next;
+  }
+  if (stats) *stats = st;
+  free(cur); free(nxt); free(coords); free(values);
+}
+
+/* ------------------------------------------------------------------------ */
+/* monolithic ground-truth marcher (mode 4 semantics, NO_SHADING)            */
+/* ref: core/renderer/method_raymarching.cu:263-308, 401-536                 */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  const vnro_scene* s; const float* vol; ray_t ray; float jitter, step, step_rcp;
+  float alpha; v3 color;
+} mono_ctx;
+
+static int mono_cell(void* c, i3 cell, float t0, float t1)
+{
+  mono_ctx* m = (mono_ctx*)c;
+  const float r = opacity_upper_bound(m->s, cell);
+  if (fabsf(r) <= FLT_EPSILON) return 1;
+  /* sample_size_scaler, :263-268 */
+  float ss = adaptive_sampling_rate(m->step, r);
+  {
+    const int32_t N = (int32_t)((t1 - t0) / ss + 1.0f);
+    ss = (t1 - t0) / (float)N;
+  }
+  float tx = t0, ty = fminf(t1, t0 + ss);
+  while (ty > tx) {
+    const float t = (1.0f - m->jitter) * tx + m->jitter * ty;
+    const v3 p = v3_add(m->ray.org, v3_scale(t, m->ray.dir));
+    const float value = vnro_sample_volume(m->vol, m->s->vol_dims, p.x, p.y, p.z);
+    float rgb[3], a;
+    vnro_tfn_sample(&m->s->tfn, value, rgb, &a);
+    a = opacity_correction(m->step_rcp, ty - tx, a);
+    const float tr = 1.0f - m->alpha;
+    m->color.x += tr * rgb[0] * a;
+    m->color.y += tr * rgb[1] * a;
+    m->color.z += tr * rgb[2] * a;
+    m->alpha += tr * a;
+    if (!(m->alpha < NEARLY_ONE)) return 0;
+    tx = ty;
+    ty = fminf(tx + ss, t1);
+  }
+  return 1;
+}
+
+void vnro_render_monolithic(const vnro_scene* s, const float* vol, int row_lo, int row_hi,
+                            float* accumulation, float* frame)
+{
+  const camera_t cam = make_camera(s);
+  const affine otw = affine_from(s->xfm);
+  const affine wto = affine_inverse(&otw);
+  const v3 lo = v3_make(s->bbox_lo[0], s->bbox_lo[1], s->bbox_lo[2]);
+  const v3 hi = v3_make(s->bbox_hi[0], s->bbox_hi[1], s->bbox_hi[2]);
+  const v3 rcp = v3_make(1.0f / s->mc_spacings[0], 1.0f / s->mc_spacings[1], 1.0f / s->mc_spacings[2]);
+  const i3 grid = { s->mc_dims[0], s->mc_dims[1], s->mc_dims[2] };
+  for (int iy = row_lo; iy < row_hi; ++iy)
+    for (int ix = 0; ix < s->width; ++ix) {
+      const uint32_t pixel = (uint32_t)ix + (uint32_t)iy * (uint32_t)s->width;
+      vnro_lcg rng;
+      vnro_lcg_init(&rng, (uint32_t)s->frame_index, pixel);
+      mono_ctx m;
+      m.s = s; m.vol = vol; m.ray = compute_ray(s, &cam, &wto, pixel);
+      m.step = 1.0f / s->sampling_rate; m.step_rcp = s->sampling_rate;
+      m.alpha = 0.0f; m.color = v3_make(0, 0, 0);
+      float t0 = 0.0f, t1 = FLOAT_LARGE;
+      if (intersect_box(&t0, &t1, m.ray.org, m.ray.dir, lo, hi)) {
+        m.jitter = vnro_lcg_next(&rng);
+        dda3(v3_mul(m.ray.org, rcp), v3_mul(m.ray.dir, rcp), t0, t1, grid, mono_cell, &m);
+      }
+      const float rgba[4] = { m.color.x, m.color.y, m.color.z, m.alpha };
+      write_pixel(s, accumulation, frame, rgba, pixel);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* metrics                                                                   */
+/* ------------------------------------------------------------------------ */
+
+/* ref: core/network.cu:51-68 */
+void vnro_generate_grid_coords(const int lower[3], const int size[3], const float rdims[3], float* coords)
+{
+  const size_t n = (size_t)size[0] * size[1] * size[2];
+  const size_t stride = (size_t)size[0] * size[1];
+  for (size_t i = 0; i < n; ++i) {
+    const int x = lower[0] + (int)(i % (size_t)size[0]);
+    const int y = lower[1] + (int)((i % stride) / (size_t)size[0]);
+    const int z = lower[2] + (int)(i / stride);
+    coords[3 * i + 0] = ((float)x + 0.5f) * rdims[0];
+    coords[3 * i + 1] = ((float)y + 0.5f) * rdims[1];
+    coords[3 * i + 2] = ((float)z + 0.5f) * rdims[2];
+  }
+}
+
+/* ref: core/network.cu:450-471 (MSE in fp32 sums there; double here, same formula) */
+double vnro_psnr(const float* pred, const float* ref, size_t n, float ref_min, float ref_max)
+{
+  double err = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    const double d = (double)pred[i] - (double)ref[i];
+    err += d * d;
+  }
+  const double range = (double)ref_max - (double)ref_min;
+  const double mse = err / (double)n;
+  return 10.0 * log10(range * range / mse);
+}

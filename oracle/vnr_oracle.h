@@ -1,0 +1,177 @@
+/* vnr_oracle.h — CPU oracle for the instantvnr hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under instantvnr_amd/ links, imports or
+ * calls this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may use it, and there only as the checker.
+ *
+ * It is a plain-C restatement of the arithmetic of the reference
+ * (VIDILabs/instantvnr); every function cites the reference file:line it
+ * follows.  Where the arithmetic lives in a dependency that is NOT under
+ * /root/reference (tiny-cuda-nn fork `wilsonCernWq/tiny-cuda-nn`, un-vendored
+ * submodule `.gitmodules:1-3`, no pinned SHA; gdt/OVR headers), the published
+ * upstream algorithm is restated and the assumption is spelled out at the
+ * function.
+ *
+ * PARITY STATUS: **parity unpinned**.  The reference ships no tests, golden
+ * vectors or fixtures for this path and cannot be compiled here (needs CUDA,
+ * OptiX, OVR, tcnn).  The oracle is pinned only against (a) hand-computed
+ * cases in tests/test_oracle_*.py and (b) the reference's in-tree restatement
+ * of the tcnn inference kernels (core/networks/tcnn_impl_decoder.cu,
+ * tcnn_threadblock.h), which is what fixes the forward semantics.
+ */
+#ifndef VNR_ORACLE_H
+#define VNR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- fp16 ------------------------------------------------------------- */
+uint16_t vnro_f32_to_f16(float f);  /* round-to-nearest-even */
+float    vnro_f16_to_f32(uint16_t h);
+
+/* ---- hash grid -------------------------------------------------------- */
+typedef struct {
+  uint32_t n_levels;
+  uint32_t n_features;        /* per level: 1,2,4,8 */
+  uint32_t log2_hashmap_size;
+  uint32_t base_resolution;
+  float    per_level_scale;   /* tcnn default 2.0 */
+  uint32_t interpolation;     /* 0 = Linear (default), 1 = Smoothstep */
+} vnro_grid_config;
+
+#define VNRO_MAX_LEVELS 32
+
+typedef struct {
+  uint32_t offsets[VNRO_MAX_LEVELS + 1]; /* in entries (x n_features for elements) */
+  float    scale[VNRO_MAX_LEVELS];
+  uint32_t resolution[VNRO_MAX_LEVELS];
+} vnro_grid_layout;
+
+/* returns total number of table entries (sum over levels) */
+uint32_t vnro_grid_make_layout(const vnro_grid_config* cfg, vnro_grid_layout* out);
+
+/* index of corner p in a level (entries, not elements) */
+uint32_t vnro_grid_index(uint32_t hashmap_size, uint32_t resolution, const uint32_t p[3]);
+
+/* coords: [n][3] fp32 AoS in [0,1]; table: fp16 [total_entries * F];
+ * out: fp16 [n][padded_width] row-major (padded_width = roundup(L*F,16), pad = 0) */
+void vnro_grid_encode(const vnro_grid_config* cfg, const uint16_t* table,
+                      const float* coords, size_t n, uint16_t* out, uint32_t padded_width);
+
+/* ---- fully fused MLP -------------------------------------------------- */
+enum { VNRO_ACT_NONE = 0, VNRO_ACT_RELU = 1 };
+enum { VNRO_ACC_F32 = 0, VNRO_ACC_F16 = 1 };
+
+/* weights: fp16, row-major [out][in] per layer: first (W x in_width),
+ * n_hidden_matmuls x (W x W), last (16 x W).  input fp16 [n][in_width].
+ * out fp32 [n] = output neuron 0.  If act_out != NULL it receives the
+ * post-activation fp16 hidden activations: [(n_hidden_matmuls+1)][n][W]. */
+void vnro_mlp_forward(const uint16_t* weights, uint32_t in_width, uint32_t width,
+                      uint32_t n_hidden_matmuls, int activation, int acc_mode,
+                      const uint16_t* input, size_t n, float* out, uint16_t* act_out);
+
+size_t vnro_mlp_n_params(uint32_t in_width, uint32_t width, uint32_t n_hidden_matmuls);
+
+/* encode + mlp, params blob = MLP weights first, then grid (tcnn order) */
+void vnro_network_inference(const vnro_grid_config* cfg, uint32_t width, uint32_t n_hidden_layers,
+                            int activation, int acc_mode, const uint16_t* params,
+                            const float* coords, size_t n, float* out);
+
+/* ---- ground-truth volume sampling ------------------------------------ */
+/* tex3D<float>(p) on a normalised-coordinate, linear-filter, clamp texture */
+float vnro_tex3d(const float* vol, const int dims[3], float px, float py, float pz);
+/* renderer's sampleVolume(): nodal remap then tex3D */
+float vnro_sample_volume(const float* vol, const int dims[3], float px, float py, float pz);
+void  vnro_sample_volume_batch(const float* vol, const int dims[3], const float* coords, size_t n,
+                               int nodal, float* out);
+
+/* ---- transfer function ------------------------------------------------ */
+typedef struct {
+  const float* colors; /* [n_colors][4] rgba, a = 1 */
+  int n_colors;
+  const float* alphas; /* [n_alphas] */
+  int n_alphas;
+  float range_lo, range_hi, range_rcp_norm;
+} vnro_tfn;
+
+void vnro_tfn_sample(const vnro_tfn* tfn, float value, float rgb[3], float* alpha);
+
+/* ---- macrocell --------------------------------------------------------- */
+#define VNRO_MACROCELL_SIZE_MIP 4
+void vnro_macrocell_shape(const int vol_dims[3], int mc_dims[3], float mc_spacings[3]);
+void vnro_macrocell_update_explicit(const float* coords, const float* values, size_t n,
+                                    const int vol_dims[3], const int mc_dims[3], float* value_range);
+void vnro_macrocell_compute_implicit(const float* vol, const int vol_dims[3],
+                                     const int mc_dims[3], float* value_range);
+void vnro_macrocell_max_opacity(const vnro_tfn* tfn, const float* value_range, size_t n_cells,
+                                float* max_opacity);
+
+/* ---- RNG --------------------------------------------------------------- */
+typedef struct { uint32_t state; } vnro_lcg;
+void  vnro_lcg_init(vnro_lcg* r, uint32_t v0, uint32_t v1); /* 16-round TEA */
+float vnro_lcg_next(vnro_lcg* r);
+
+typedef struct { uint64_t state, inc; } vnro_pcg32;
+void     vnro_pcg32_seed(vnro_pcg32* r, uint64_t initstate, uint64_t initseq);
+uint32_t vnro_pcg32_next_uint(vnro_pcg32* r);
+float    vnro_pcg32_next_float(vnro_pcg32* r);
+void     vnro_pcg32_advance(vnro_pcg32* r, int64_t delta);
+
+/* ---- rendering --------------------------------------------------------- */
+typedef struct {
+  /* framebuffer */
+  int width, height;
+  int frame_index; /* 1 for the first frame */
+  /* camera (world space) */
+  float cam_from[3], cam_at[3], cam_up[3], fovy;
+  /* object->world transform: columns vx,vy,vz and translation p */
+  float xfm[12];
+  /* volume */
+  int   vol_dims[3];
+  float bbox_lo[3], bbox_hi[3]; /* object-space clip box */
+  float sampling_rate;
+  /* macrocell */
+  int   mc_dims[3];
+  float mc_spacings[3];
+  const float* mc_max_opacity;
+  /* tfn */
+  vnro_tfn tfn;
+  /* tiling: only pixels with pixel_lo <= index < pixel_hi are rendered (others untouched) */
+  uint32_t pixel_lo, pixel_hi;
+} vnro_scene;
+
+/* batch value callback: values[i] = f(coords[i]) for object-space coords */
+typedef void (*vnro_value_fn)(void* user, const float* coords, size_t n, float* values);
+
+typedef struct {
+  uint64_t n_samples;     /* live samples evaluated */
+  uint64_t n_slots;       /* N_ITERS * alive rays summed over iterations (reference's inferred slots) */
+  uint32_t n_iterations;
+  uint32_t n_rays_hit;
+} vnro_render_stats;
+
+/* mode 5 sample-streaming loop.  accumulation/frame: [w*h][4] */
+void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, void* user,
+                           float* accumulation, float* frame, vnro_render_stats* stats);
+
+/* monolithic ground-truth marcher (mode 4 semantics) on a dense fp32 volume;
+ * rows [row_lo,row_hi) only, so callers can thread over scanlines */
+void vnro_render_monolithic(const vnro_scene* s, const float* vol, int row_lo, int row_hi,
+                            float* accumulation, float* frame);
+
+/* DDA traversal trace for tests: cells visited + [t0,t1] per cell (grid space already applied) */
+size_t vnro_dda_trace(const float org[3], const float dir[3], float t_min, float t_max,
+                      const int grid[3], int* cells, float* ts, size_t max_cells);
+
+/* ---- metrics ------------------------------------------------------------ */
+void vnro_generate_grid_coords(const int lower[3], const int size[3], const float rdims[3], float* coords);
+double vnro_psnr(const float* pred, const float* ref, size_t n, float ref_min, float ref_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

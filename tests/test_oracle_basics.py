@@ -1,0 +1,210 @@
+"""Pins the CPU oracle against hand-computable cases and independent restatements.
+
+The reference has no tests/golden vectors, so these are the
+oracle's own known-answer tests: IEEE fp16 vs numpy, the published pcg32 test
+vector, an independent pure-Python TEA/LCG, hash-grid sizing of the reference's
+example model, and a pure-numpy hash-grid/MLP restatement on tiny cases.
+"""
+import numpy as np
+import pytest
+
+
+def test_fp16_conversion_matches_ieee(oracle):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([
+        rng.normal(size=2000).astype(np.float32),
+        (rng.normal(size=2000) * 1e-5).astype(np.float32),
+        (rng.normal(size=500) * 3e4).astype(np.float32),
+        np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 1e9, -1e9, 5.9604645e-8, 2.9802322e-8,
+                  2.9802326e-8, 6.1035156e-5, 6.0975552e-5, 1.0009766, 1.00048828125, 1.00146484375],
+                 dtype=np.float32),
+    ])
+    got = oracle.f32_to_f16_bits(xs)
+    want = xs.astype(np.float16).view(np.uint16)
+    assert np.array_equal(got, want)
+    L = oracle.lib()
+    back = np.array([L.vnro_f16_to_f32(int(h)) for h in range(0, 0x7c00, 37)], dtype=np.float32)
+    assert np.array_equal(back, np.arange(0, 0x7c00, 37, dtype=np.uint16).view(np.float16).astype(np.float32))
+
+
+def test_pcg32_published_vector(oracle):
+    # pcg32 reference demo output for pcg32_srandom(42u, 54u) (pcg-random.org, pcg32-demo)
+    import ctypes as C
+    r = oracle.pcg32(42, 54)
+    L = oracle.lib()
+    got = [L.vnro_pcg32_next_uint(C.byref(r)) for _ in range(6)]
+    assert got == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+    # advance(n) == n draws
+    a = oracle.pcg32(1337, 0xda3e39cb94b95bdb)
+    b = oracle.pcg32(1337, 0xda3e39cb94b95bdb)
+    for _ in range(1000):
+        L.vnro_pcg32_next_uint(C.byref(a))
+    L.vnro_pcg32_advance(C.byref(b), C.c_int64(1000))
+    assert a.state == b.state
+    f = L.vnro_pcg32_next_float(C.byref(a))
+    assert 0.0 <= f < 1.0
+
+
+def _tea_lcg_py(v0, v1, n):
+    M = 0xFFFFFFFF
+    s0 = 0
+    for _ in range(16):
+        s0 = (s0 + 0x9e3779b9) & M
+        v0 = (v0 + ((((v1 << 4) & M) + 0xa341316c & M) ^ ((v1 + s0) & M) ^ (((v1 >> 5) + 0xc8013ea4) & M))) & M
+        v1 = (v1 + ((((v0 << 4) & M) + 0xad90777d & M) ^ ((v0 + s0) & M) ^ (((v0 >> 5) + 0x7e95761e) & M))) & M
+    st = v0
+    out = []
+    for _ in range(n):
+        st = (1664525 * st + 1013904223) & M
+        out.append(np.float32(st & 0x00FFFFFF) / np.float32(0x01000000))
+    return np.array(out, dtype=np.float32)
+
+
+@pytest.mark.parametrize("v0,v1", [(1, 0), (1, 12345), (7, 1048575), (0, 0)])
+def test_tea_lcg_matches_independent_python(oracle, v0, v1):
+    got = oracle.lcg_floats(v0, v1, 4)
+    assert np.array_equal(got, _tea_lcg_py(v0, v1, 4))
+    assert np.all((got >= 0) & (got < 1))
+
+
+def test_grid_layout_of_example_model(oracle):
+    # example-model.json:19-25 -> L=8, F=8, T=2^19, base 16; SURVEY §8(a6): 2 920 448 entries
+    cfg = oracle.grid_config(8, 8, 19, 16)
+    lay = oracle.grid_layout(cfg)
+    assert lay["total_entries"] == 2920448
+    assert list(lay["resolution"]) == [16, 32, 64, 128, 256, 512, 1024, 2048]
+    assert list(np.diff(lay["offsets"].astype(np.int64))) == [4096, 32768, 262144] + [524288] * 5
+    assert np.allclose(lay["scale"], [15, 31, 63, 127, 255, 511, 1023, 2047])
+    # MLP (in 64, 4 hidden layers => 3 hidden matmuls) = 17408 fp16  
+    assert oracle.mlp_n_params(64, 64, 3) == 17408
+    assert oracle.n_params(cfg, 64, 4) == 17408 + 2920448 * 8 == 23380992
+
+
+def test_grid_index_dense_and_hash(oracle):
+    # dense: stride never exceeds hashmap size
+    assert oracle.grid_index(4096, 16, (3, 2, 1)) == 3 + 2 * 16 + 1 * 256
+    # hashed: prime-XOR hash (tcnn fast_hash) mod T
+    T = 1 << 19
+    p = (1000, 2000, 3000)
+    want = ((p[0] * 1) ^ ((p[1] * 2654435761) & 0xFFFFFFFF) ^ ((p[2] * 805459861) & 0xFFFFFFFF)) % T
+    assert oracle.grid_index(T, 1024, p) == want
+
+
+def _encode_numpy(cfg, lay, table, coords):
+    """independent restatement with numpy scalars (fp32 positions, fp16 accumulate)"""
+    L, F = cfg.n_levels, cfg.n_features
+    out = np.zeros((coords.shape[0], ((L * F + 15) // 16) * 16), dtype=np.float16)
+    for i, x in enumerate(coords.astype(np.float32)):
+        for l in range(L):
+            off, size = int(lay["offsets"][l]), int(lay["offsets"][l + 1] - lay["offsets"][l])
+            scale, res = np.float32(lay["scale"][l]), int(lay["resolution"][l])
+            # fma(x, scale, 0.5) evaluated exactly in float64 then rounded once
+            pos = (x.astype(np.float64) * np.float64(scale) + 0.5).astype(np.float32)
+            g = np.floor(pos)
+            w = (pos - g).astype(np.float32)
+            g = g.astype(np.int64)
+            acc = np.zeros(F, dtype=np.float16)
+            for idx in range(8):
+                wt = np.float32(1)
+                pl = []
+                for d in range(3):
+                    if idx & (1 << d):
+                        wt = np.float32(wt * w[d]); pl.append(int(g[d]) + 1)
+                    else:
+                        wt = np.float32(wt * (np.float32(1) - w[d])); pl.append(int(g[d]))
+                stride, index, d = 1, 0, 0
+                while d < 3 and stride <= size:
+                    index += pl[d] * stride; stride *= res; d += 1
+                index &= 0xFFFFFFFF
+                if size < stride:
+                    index = (pl[0] ^ ((pl[1] * 2654435761) & 0xFFFFFFFF) ^ ((pl[2] * 805459861) & 0xFFFFFFFF))
+                index %= size
+                for f in range(F):
+                    data = np.float32(table[(off + index) * F + f])
+                    acc[f] = np.float16(np.float32(acc[f]) + np.float32(np.float16(np.float32(wt * data))))
+            out[i, l * F:(l + 1) * F] = acc
+    return out
+
+
+@pytest.mark.parametrize("L,F,log2T,base", [(2, 2, 4, 2), (4, 2, 10, 4), (3, 8, 8, 4), (5, 4, 12, 8), (2, 1, 6, 3)])
+def test_grid_encode_matches_independent_numpy(oracle, L, F, log2T, base):
+    cfg = oracle.grid_config(L, F, log2T, base)
+    lay = oracle.grid_layout(cfg)
+    rng = np.random.default_rng(L * 100 + F)
+    table = rng.uniform(-1, 1, lay["total_entries"] * F).astype(np.float16)
+    coords = rng.uniform(0, 1, (40, 3)).astype(np.float32)
+    coords[0] = (0, 0, 0); coords[1] = (1, 1, 1); coords[2] = (0.5, 0.25, 0.75)
+    got = oracle.grid_encode(cfg, table.view(np.uint16), coords).view(np.float16)
+    want = _encode_numpy(cfg, lay, table, coords)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+def test_grid_encode_hand_case_index_ramp(oracle):
+    """L=1, base 2 -> scale 1, res 2, 8 dense entries; table[e] = e (feature 0), -e (feature 1).
+    At x = (0.5, 0.5, 0.5): pos = 1.0 -> cell (1,1,1), frac 0 -> only corner 0 has weight 1:
+    index = (1 + 2 + 4) % 8 = 7."""
+    cfg = oracle.grid_config(1, 2, 4, 2)
+    lay = oracle.grid_layout(cfg)
+    assert lay["total_entries"] == 8 and lay["resolution"][0] == 2
+    table = np.zeros(16, dtype=np.float16)
+    table[0::2] = np.arange(8); table[1::2] = -np.arange(8)
+    out = oracle.grid_encode(cfg, table.view(np.uint16), np.array([[0.5, 0.5, 0.5]], np.float32)).view(np.float16)
+    assert out.shape == (1, 16)
+    assert out[0, 0] == 7 and out[0, 1] == -7 and np.all(out[0, 2:] == 0)
+    # x = (0.25, 0.5, 0.5): pos.x = 0.75 -> cell 0, frac .75: 0.25*table[6] + 0.75*table[7] = 6.75
+    out = oracle.grid_encode(cfg, table.view(np.uint16), np.array([[0.25, 0.5, 0.5]], np.float32)).view(np.float16)
+    assert out[0, 0] == np.float16(6.75) and out[0, 1] == np.float16(-6.75)
+
+
+def _mlp_numpy(w, in_w, W, nh, x):
+    """sequential fp32 accumulation, fp16 activations (matches VNRO_ACC_F32)"""
+    o = 0
+    W1 = w[o:o + W * in_w].reshape(W, in_w).astype(np.float32); o += W * in_w
+    Wh = [w[o + i * W * W:o + (i + 1) * W * W].reshape(W, W).astype(np.float32) for i in range(nh)]; o += nh * W * W
+    Wl = w[o:o + 16 * W].reshape(16, W).astype(np.float32)
+
+    def dense(M, v):
+        out = np.zeros(M.shape[0], dtype=np.float32)
+        for r in range(M.shape[0]):
+            s = np.float32(0)
+            for k in range(M.shape[1]):
+                s = np.float32(s + np.float32(M[r, k] * v[k]))
+            out[r] = s
+        return out
+
+    ys = []
+    for row in x.astype(np.float32):
+        a = np.maximum(dense(W1, row).astype(np.float16), np.float16(0)).astype(np.float32)
+        for M in Wh:
+            a = np.maximum(dense(M, a).astype(np.float16), np.float16(0)).astype(np.float32)
+        ys.append(np.float32(np.float16(dense(Wl[:1], a)[0])))
+    return np.array(ys, dtype=np.float32)
+
+
+@pytest.mark.parametrize("in_w,W,nh", [(16, 16, 0), (32, 64, 2), (64, 64, 1), (16, 32, 3)])
+def test_mlp_forward_matches_independent_numpy(oracle, in_w, W, nh):
+    rng = np.random.default_rng(in_w + W + nh)
+    n = oracle.mlp_n_params(in_w, W, nh)
+    w = rng.uniform(-0.4, 0.4, n).astype(np.float16)
+    x = rng.uniform(-1, 1, (12, in_w)).astype(np.float16)
+    got = oracle.mlp_forward(w.view(np.uint16), in_w, W, nh, x.view(np.uint16))
+    want = _mlp_numpy(w, in_w, W, nh, x)
+    assert np.array_equal(got, want)
+    # fp16-accumulate emulation (the reference's half accumulator) stays within the stated tolerance
+    got16 = oracle.mlp_forward(w.view(np.uint16), in_w, W, nh, x.view(np.uint16), acc_mode=1)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.max(np.abs(got16 - want)) <= 2.0 ** -6 * scale
+
+
+def test_network_inference_is_encode_then_mlp(oracle):
+    cfg = oracle.grid_config(4, 4, 10, 4)
+    W, H = 32, 3
+    lay = oracle.grid_layout(cfg)
+    n_mlp = oracle.mlp_n_params(16, W, H - 1)
+    rng = np.random.default_rng(5)
+    params = np.concatenate([rng.uniform(-0.4, 0.4, n_mlp), rng.uniform(-1, 1, lay["total_entries"] * 4)]).astype(np.float16)
+    coords = rng.uniform(0, 1, (64, 3)).astype(np.float32)
+    out = oracle.network_inference(cfg, W, H, params.view(np.uint16), coords)
+    enc = oracle.grid_encode(cfg, params[n_mlp:].view(np.uint16), coords)
+    out2 = oracle.mlp_forward(params[:n_mlp].view(np.uint16), 16, W, H - 1, enc)
+    assert np.array_equal(out, out2)

@@ -1,0 +1,162 @@
+"""ctypes binding of libvnr_amd.so (include/vnr_amd.h).  No CPU fallback: if the library is missing
+or no gfx950 device is present, calls fail loudly."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+SO_PATH = os.path.join(_HERE, "libvnr_amd.so")
+HEADER = os.path.join(ROOT, "include", "vnr_amd.h")
+
+_lib = None
+
+
+class VnrAmdError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """compile libvnr_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)"""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8", "-s"]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("n_reference_slots", C.c_uint64), ("n_iterations", C.c_uint32),
+                ("n_rays_hit", C.c_uint32), ("infer_kernel_ms", C.c_double), ("infer_kernel_launches", C.c_uint64)]
+
+
+def declared_symbols():
+    """every function name declared in include/vnr_amd.h"""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vnrAmd[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise VnrAmdError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+    L = C.CDLL(SO_PATH)
+    P, I, U32, U64, F, D, SZ = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_size_t
+    FP = C.POINTER(C.c_float)
+    IP = C.POINTER(C.c_int)
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("vnrAmdGetLastError", C.c_char_p)
+    sig("vnrAmdVersion", C.c_char_p)
+    sig("vnrAmdInit", I, I)
+    sig("vnrAmdDeviceCount", I)
+    sig("vnrAmdHasDevice", I)
+    sig("vnrAmdMalloc", P, SZ)
+    sig("vnrAmdFree", I, P)
+    sig("vnrAmdMemcpyH2D", I, P, P, SZ)
+    sig("vnrAmdMemcpyD2H", I, P, P, SZ)
+    sig("vnrAmdMemset", I, P, I, SZ)
+    sig("vnrAmdSynchronize", I)
+    sig("vnrAmdDefaultStream", P)
+    sig("vnrAmdJsonConvert", I, P, SZ, I, I, C.POINTER(P), C.POINTER(SZ))
+    sig("vnrAmdJsonSave", I, P, SZ, I, C.c_char_p, I)
+    sig("vnrAmdFreeHost", None, P)
+    sig("vnrAmdCreateCamera", P)
+    sig("vnrAmdCameraSet", I, P, FP, FP, FP)
+    sig("vnrAmdCameraSetFovy", I, P, F)
+    sig("vnrAmdCameraGet", I, P, FP, FP, FP, FP)
+    sig("vnrAmdReleaseCamera", None, P)
+    sig("vnrAmdCreateTransferFunction", P)
+    sig("vnrAmdTransferFunctionSetColor", I, P, FP, I)
+    sig("vnrAmdTransferFunctionSetAlpha", I, P, FP, I)
+    sig("vnrAmdTransferFunctionSetValueRange", I, P, F, F)
+    sig("vnrAmdTransferFunctionGetSizes", I, P, IP, IP)
+    sig("vnrAmdTransferFunctionGet", I, P, FP, FP, FP)
+    sig("vnrAmdReleaseTransferFunction", None, P)
+    sig("vnrAmdCreateSimpleVolumeFromMemory", P, P, IP, I, F, F)
+    sig("vnrAmdCreateSimpleVolumeFromRawFile", P, C.c_char_p, IP, I, SZ, I, F, F)
+    sig("vnrAmdCreateSimpleVolumePerlin", P, IP, U32, I, F)
+    sig("vnrAmdSimpleVolumeDeviceData", P, P)
+    sig("vnrAmdCreateNeuralVolume", P, P, SZ, I, P, I)
+    sig("vnrAmdCreateNeuralVolumeFromDims", P, P, SZ, I, IP)
+    sig("vnrAmdCreateNeuralVolumeFromParams", P, P, SZ, I)
+    sig("vnrAmdNeuralVolumeSetModel", I, P, P, SZ, I)
+    sig("vnrAmdNeuralVolumeSetParams", I, P, P, SZ, I)
+    sig("vnrAmdNeuralVolumeGetPSNR", D, P, I)
+    sig("vnrAmdNeuralVolumeGetTestingLoss", D, P)
+    sig("vnrAmdNeuralVolumeGetTrainingLoss", D, P)
+    sig("vnrAmdNeuralVolumeGetTrainingStep", I, P)
+    sig("vnrAmdNeuralVolumeGetNumberOfBlobs", I, P)
+    sig("vnrAmdNeuralVolumeTrain", I, P, I, I)
+    sig("vnrAmdNeuralVolumeSerializeParamsToFile", I, P, C.c_char_p)
+    sig("vnrAmdNeuralVolumeSerializeParams", I, P, C.POINTER(P), C.POINTER(SZ))
+    sig("vnrAmdNeuralVolumeInference", I, P, SZ, P, P, P)
+    sig("vnrAmdNeuralVolumeEncode", I, P, SZ, P, P, P)
+    sig("vnrAmdNeuralVolumeGetInfo", I, P, IP, IP, IP, IP, IP, C.POINTER(U64))
+    sig("vnrAmdNeuralVolumeGetParamsFP16", I, P, P, SZ)
+    sig("vnrAmdNeuralVolumeSetParamsFP16", I, P, P, SZ)
+    sig("vnrAmdNeuralVolumeTrainBegin", I, P)
+    sig("vnrAmdNeuralVolumeGradients", P, P, C.POINTER(SZ))
+    sig("vnrAmdNeuralVolumeTrainEnd", I, P, F, I)
+    sig("vnrAmdNeuralVolumeSetSamplerSeed", I, P, U64, U64)
+    sig("vnrAmdNeuralVolumeSetInitSeed", I, P, U64)
+    sig("vnrAmdVolumeSetClippingBox", I, P, FP, FP)
+    sig("vnrAmdVolumeSetScaling", I, P, FP)
+    sig("vnrAmdVolumeGetValueRange", I, P, FP)
+    sig("vnrAmdVolumeGetDims", I, P, IP)
+    sig("vnrAmdVolumeIsNetwork", I, P)
+    sig("vnrAmdVolumeGetMacrocell", I, P, IP, FP, C.POINTER(P), C.POINTER(P))
+    sig("vnrAmdReleaseVolume", None, P)
+    sig("vnrAmdCreateRenderer", P, P)
+    sig("vnrAmdRendererSetFramebufferSize", I, P, I, I)
+    sig("vnrAmdRendererSetTransferFunction", I, P, P)
+    sig("vnrAmdRendererSetCamera", I, P, P)
+    sig("vnrAmdRendererSetMode", I, P, I)
+    sig("vnrAmdRendererSetDenoiser", I, P, I)
+    sig("vnrAmdRendererSetVolumeSamplingRate", I, P, F)
+    sig("vnrAmdRendererSetVolumeDensityScale", I, P, F)
+    sig("vnrAmdRendererResetAccumulation", I, P)
+    sig("vnrAmdRender", I, P)
+    sig("vnrAmdRendererMapFrame", P, P)
+    sig("vnrAmdRendererSetOutputAsDeviceFramebuffer", I, P, I)
+    sig("vnrAmdRendererSetPixelRange", I, P, U32, U32)
+    sig("vnrAmdRendererGetFrameStats", I, P, C.POINTER(FrameStats))
+    sig("vnrAmdRendererSetProfiling", I, P, I)
+    sig("vnrAmdReleaseRenderer", None, P)
+    sig("vnrAmdMemoryQuery", None, C.POINTER(SZ), C.POINTER(SZ))
+    sig("vnrAmdFreeTemporaryGPUMemory", None)
+    sig("vnrAmdSimpleVolumeTakeSamples", I, P, SZ, FP, FP, P, P, P)
+    sig("vnrAmdSimpleVolumeSample", I, P, SZ, P, P, I, P)
+    sig("vnrAmdNeuralVolumeUpdateMacrocell", I, P, SZ, P, P, P)
+    sig("vnrAmdVolumeUpdateMaxOpacity", I, P, P)
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().vnrAmdGetLastError().decode("utf-8", "replace")
+
+
+def check(status):
+    if status != 0:
+        raise VnrAmdError(last_error())
+
+
+def check_ptr(p):
+    if not p:
+        raise VnrAmdError(last_error())
+    return p
+
+
+def require_device():
+    if not lib().vnrAmdHasDevice():
+        raise VnrAmdError("no HIP device: the MI355X path has no CPU fallback")

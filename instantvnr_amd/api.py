@@ -1,0 +1,477 @@
+"""Python mirror of the reference's `vnr*` API (api.h:90-188) on top of the C-ABI (include/vnr_amd.h).
+
+Same function names, argument meaning and error behaviour (errors raise, like the reference's
+std::runtime_error).  JSON arguments may be dicts, JSON text, BSON bytes, or a path string (the reference
+treats a JSON string value as a path: api.cpp:77-83).  This layer is host plumbing only — all compute runs in
+libvnr_amd.so; there is no CPU fallback.
+"""
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _lib
+from ._lib import VnrAmdError, check, check_ptr, lib
+
+JSON_TEXT, JSON_BSON, JSON_TEXT_FILE, JSON_BSON_FILE = 0, 1, 2, 3
+
+VALUE_TYPES = {np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.uint16): 2, np.dtype(np.int16): 3,
+               np.dtype(np.uint32): 4, np.dtype(np.int32): 5, np.dtype(np.float32): 8, np.dtype(np.float64): 12}
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _vec(v, n=3):
+    a = np.ascontiguousarray(v, dtype=np.float32).ravel()
+    assert a.size == n
+    return a
+
+
+def _json_arg(j, params=False):
+    """-> (buffer, size, format, keepalive)"""
+    if isinstance(j, (dict, list)):
+        b = json.dumps(j).encode()
+        return b, len(b), JSON_TEXT
+    if isinstance(j, (bytes, bytearray, memoryview)):
+        b = bytes(j)
+        return b, len(b), JSON_BSON
+    if isinstance(j, str):
+        s = j.lstrip()
+        if s.startswith("{") or s.startswith("/") and s[1:2] in "/*":
+            b = j.encode()
+            return b, len(b), JSON_TEXT
+        b = j.encode() + b"\0"
+        return b, len(b), JSON_BSON_FILE if params else JSON_TEXT_FILE
+    raise TypeError("unsupported JSON argument")
+
+
+# ------------------------------------------------------------------------------------------------ device memory
+class DeviceArray:
+    """typed device buffer for hosts without a HIP binding (wraps vnrAmdMalloc/Memcpy)"""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = check_ptr(lib().vnrAmdMalloc(max(self.nbytes, 1)))
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        d.upload(a)
+        return d
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes
+        if self.nbytes:
+            check(lib().vnrAmdMemcpyH2D(self.ptr, a.ctypes.data_as(C.c_void_p), self.nbytes))
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            check(lib().vnrAmdMemcpyD2H(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def zero(self):
+        check(lib().vnrAmdMemset(self.ptr, 0, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            lib().vnrAmdFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------ handles
+class _Handle:
+    _release = None
+
+    def __init__(self, h):
+        self.h = check_ptr(h)
+
+    def release(self):
+        if self.h and self._release:
+            getattr(lib(), self._release)(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class vnrVolume(_Handle):
+    _release = "vnrAmdReleaseVolume"
+    _keep = None
+
+
+class vnrRenderer(_Handle):
+    _release = "vnrAmdReleaseRenderer"
+    _keep = None
+
+
+class vnrTransferFunction(_Handle):
+    _release = "vnrAmdReleaseTransferFunction"
+
+
+class vnrCamera(_Handle):
+    _release = "vnrAmdReleaseCamera"
+
+
+# ------------------------------------------------------------------------------------------------ json (api.h:90-96)
+def _convert(data, size, fmt_in, fmt_out):
+    out = C.c_void_p()
+    n = C.c_size_t()
+    check(lib().vnrAmdJsonConvert(data, size, fmt_in, fmt_out, C.byref(out), C.byref(n)))
+    b = C.string_at(out, n.value)
+    lib().vnrAmdFreeHost(out)
+    return b
+
+
+def vnrCreateJsonText(filename):
+    f = filename.encode() + b"\0"
+    return json.loads(_convert(f, len(f), JSON_TEXT_FILE, JSON_TEXT))
+
+
+def vnrCreateJsonBinary(filename):
+    """returns the BSON document as bytes (binary members cannot live in a Python dict losslessly)"""
+    f = filename.encode() + b"\0"
+    return _convert(f, len(f), JSON_BSON_FILE, JSON_BSON)
+
+
+def vnrSaveJsonText(j, filename):
+    b, n, f = _json_arg(j)
+    check(lib().vnrAmdJsonSave(b, n, f, filename.encode(), JSON_TEXT))
+
+
+def vnrSaveJsonBinary(j, filename):
+    b, n, f = _json_arg(j, params=True)
+    check(lib().vnrAmdJsonSave(b, n, f, filename.encode(), JSON_BSON))
+
+
+def json_to_bson(j):
+    b, n, f = _json_arg(j)
+    return _convert(b, n, f, JSON_BSON)
+
+
+def bson_to_json_text(b):
+    return _convert(bytes(b), len(b), JSON_BSON, JSON_TEXT).decode()
+
+
+# ------------------------------------------------------------------------------------------------ camera (api.h:103-110)
+def vnrCreateCamera():
+    return vnrCamera(lib().vnrAmdCreateCamera())
+
+
+def vnrCameraSet(cam, frm, at, up, fovy=None):
+    check(lib().vnrAmdCameraSet(cam.h, _fp(_vec(frm)), _fp(_vec(at)), _fp(_vec(up))))
+    if fovy is not None:
+        check(lib().vnrAmdCameraSetFovy(cam.h, float(fovy)))
+
+
+def _cam_get(cam):
+    f, a, u = (np.zeros(3, np.float32) for _ in range(3))
+    fov = C.c_float()
+    check(lib().vnrAmdCameraGet(cam.h, _fp(f), _fp(a), _fp(u), C.byref(fov)))
+    return f, a, u, fov.value
+
+
+def vnrCameraGetPosition(cam):
+    return _cam_get(cam)[0]
+
+
+def vnrCameraGetFocus(cam):
+    return _cam_get(cam)[1]
+
+
+def vnrCameraGetUpVec(cam):
+    return _cam_get(cam)[2]
+
+
+# ------------------------------------------------------------------------------------------------ volumes (api.h:117-148)
+def vnrCreateSimpleVolume(data, value_range=None):
+    """data: numpy array [z, y, x] (x fastest) — stands in for vnrCreateSimpleVolume(scene json, "GPU")"""
+    a = np.ascontiguousarray(data)
+    if a.dtype not in VALUE_TYPES:
+        raise VnrAmdError("unknown data type")
+    dims = (C.c_int * 3)(a.shape[2], a.shape[1], a.shape[0])
+    lo, hi = (1.0, 0.0) if value_range is None else value_range
+    return vnrVolume(lib().vnrAmdCreateSimpleVolumeFromMemory(a.ctypes.data_as(C.c_void_p), dims, VALUE_TYPES[a.dtype], lo, hi))
+
+
+def vnrCreateSimpleVolumeFromRawFile(filename, dims, dtype, offset=0, big_endian=False, value_range=None):
+    d = (C.c_int * 3)(*[int(v) for v in dims])
+    lo, hi = (1.0, 0.0) if value_range is None else value_range
+    return vnrVolume(lib().vnrAmdCreateSimpleVolumeFromRawFile(filename.encode(), d, VALUE_TYPES[np.dtype(dtype)], offset,
+                                                               1 if big_endian else 0, lo, hi))
+
+
+def vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=4.0):
+    d = (C.c_int * 3)(*[int(v) for v in dims])
+    return vnrVolume(lib().vnrAmdCreateSimpleVolumePerlin(d, seed, octaves, base_frequency))
+
+
+def vnrCreateNeuralVolume(config, groundtruth_or_dims=None, online_macrocell_construction=True):
+    """the three overloads of api.h:122-124: (config, groundtruth[, online]), (config, dims), (params)"""
+    L = lib()
+    if groundtruth_or_dims is None:
+        b, n, f = _json_arg(config, params=True)
+        return vnrVolume(L.vnrAmdCreateNeuralVolumeFromParams(b, n, f))
+    b, n, f = _json_arg(config)
+    if isinstance(groundtruth_or_dims, vnrVolume):
+        v = vnrVolume(L.vnrAmdCreateNeuralVolume(b, n, f, groundtruth_or_dims.h, 1 if online_macrocell_construction else 0))
+        v._keep = groundtruth_or_dims
+        return v
+    d = (C.c_int * 3)(*[int(x) for x in groundtruth_or_dims])
+    return vnrVolume(L.vnrAmdCreateNeuralVolumeFromDims(b, n, f, d))
+
+
+def vnrNeuralVolumeSetModel(v, config):
+    b, n, f = _json_arg(config)
+    check(lib().vnrAmdNeuralVolumeSetModel(v.h, b, n, f))
+
+
+def vnrNeuralVolumeSetParams(v, params):
+    b, n, f = _json_arg(params, params=True)
+    check(lib().vnrAmdNeuralVolumeSetParams(v.h, b, n, f))
+
+
+def _dbl(x):
+    if x == -1.0 and _lib.last_error():
+        pass
+    return x
+
+
+def vnrNeuralVolumeGetPSNR(v, verbose=False):
+    r = lib().vnrAmdNeuralVolumeGetPSNR(v.h, 1 if verbose else 0)
+    if r == -1.0:
+        raise VnrAmdError(_lib.last_error())
+    return r
+
+
+def vnrNeuralVolumeGetTestingLoss(v):
+    r = lib().vnrAmdNeuralVolumeGetTestingLoss(v.h)
+    if r == -1.0:
+        raise VnrAmdError(_lib.last_error())
+    return r
+
+
+def vnrNeuralVolumeGetTrainingLoss(v):
+    return lib().vnrAmdNeuralVolumeGetTrainingLoss(v.h)
+
+
+def vnrNeuralVolumeGetTrainingStep(v):
+    return lib().vnrAmdNeuralVolumeGetTrainingStep(v.h)
+
+
+def vnrNeuralVolumeGetNumberOfBlobs(v):
+    return lib().vnrAmdNeuralVolumeGetNumberOfBlobs(v.h)
+
+
+def vnrNeuralVolumeTrain(v, steps, fast_mode):
+    check(lib().vnrAmdNeuralVolumeTrain(v.h, int(steps), 1 if fast_mode else 0))
+
+
+def vnrNeuralVolumeSerializeParams(v, filename=None):
+    """with a filename: writes BSON params.json; without: returns the BSON bytes"""
+    if filename is not None:
+        check(lib().vnrAmdNeuralVolumeSerializeParamsToFile(v.h, filename.encode()))
+        return None
+    out = C.c_void_p()
+    n = C.c_size_t()
+    check(lib().vnrAmdNeuralVolumeSerializeParams(v.h, C.byref(out), C.byref(n)))
+    b = C.string_at(out, n.value)
+    lib().vnrAmdFreeHost(out)
+    return b
+
+
+def vnrVolumeSetClippingBox(v, lower, upper):
+    check(lib().vnrAmdVolumeSetClippingBox(v.h, _fp(_vec(lower)), _fp(_vec(upper))))
+
+
+def vnrVolumeSetScaling(v, scale):
+    check(lib().vnrAmdVolumeSetScaling(v.h, _fp(_vec(scale))))
+
+
+def vnrVolumeGetValueRange(v):
+    r = np.zeros(2, np.float32)
+    check(lib().vnrAmdVolumeGetValueRange(v.h, _fp(r)))
+    return tuple(r)
+
+
+# ------------------------------------------------------------------------------------------------ tfn (api.h:154-162)
+def vnrCreateTransferFunction():
+    return vnrTransferFunction(lib().vnrAmdCreateTransferFunction())
+
+
+def vnrTransferFunctionSetColor(t, colors):
+    c = np.ascontiguousarray(colors, dtype=np.float32).reshape(-1, 3)
+    check(lib().vnrAmdTransferFunctionSetColor(t.h, _fp(c), c.shape[0]))
+
+
+def vnrTransferFunctionSetAlpha(t, alphas):
+    """alphas: [n,2] (position, alpha) like the reference's vec2f list, or [n] alpha values"""
+    a = np.asarray(alphas, dtype=np.float32)
+    if a.ndim == 1:
+        a = np.stack([np.linspace(0, 1, a.size, dtype=np.float32), a], axis=1)
+    a = np.ascontiguousarray(a)
+    check(lib().vnrAmdTransferFunctionSetAlpha(t.h, _fp(a), a.shape[0]))
+
+
+def vnrTransferFunctionSetValueRange(t, rng):
+    check(lib().vnrAmdTransferFunctionSetValueRange(t.h, float(rng[0]), float(rng[1])))
+
+
+# ------------------------------------------------------------------------------------------------ renderer (api.h:168-178)
+def vnrCreateRenderer(v):
+    r = vnrRenderer(lib().vnrAmdCreateRenderer(v.h))
+    r._keep = v
+    r._size = (0, 0)
+    r._device_output = False
+    return r
+
+
+def vnrRendererSetFramebufferSize(r, size):
+    check(lib().vnrAmdRendererSetFramebufferSize(r.h, int(size[0]), int(size[1])))
+    r._size = (int(size[0]), int(size[1]))
+
+
+def vnrRendererSetTransferFunction(r, t):
+    check(lib().vnrAmdRendererSetTransferFunction(r.h, t.h))
+
+
+def vnrRendererSetCamera(r, cam):
+    check(lib().vnrAmdRendererSetCamera(r.h, cam.h))
+
+
+def vnrRendererSetMode(r, mode):
+    check(lib().vnrAmdRendererSetMode(r.h, int(mode)))
+
+
+def vnrRendererSetDenoiser(r, flag):
+    check(lib().vnrAmdRendererSetDenoiser(r.h, 1 if flag else 0))
+
+
+def vnrRendererSetVolumeSamplingRate(r, v):
+    check(lib().vnrAmdRendererSetVolumeSamplingRate(r.h, float(v)))
+
+
+def vnrRendererSetVolumeDensityScale(r, v):
+    check(lib().vnrAmdRendererSetVolumeDensityScale(r.h, float(v)))
+
+
+def vnrRendererResetAccumulation(r):
+    check(lib().vnrAmdRendererResetAccumulation(r.h))
+
+
+def vnrRender(r):
+    check(lib().vnrAmdRender(r.h))
+
+
+def vnrRendererMapFrame(r):
+    """host frame as a numpy view [h, w, 4] (valid until two frames later), or the raw device pointer"""
+    p = check_ptr(lib().vnrAmdRendererMapFrame(r.h))
+    if r._device_output:
+        return p
+    w, h = r._size
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(h, w, 4))
+
+
+# AMD extensions -------------------------------------------------------------------------------------------------
+def vnrRendererSetPixelRange(r, lo, hi):
+    check(lib().vnrAmdRendererSetPixelRange(r.h, int(lo), int(hi)))
+
+
+def vnrRendererSetOutputAsDeviceFramebuffer(r, flag):
+    check(lib().vnrAmdRendererSetOutputAsDeviceFramebuffer(r.h, 1 if flag else 0))
+    r._device_output = bool(flag)
+
+
+def vnrRendererSetProfiling(r, flag):
+    check(lib().vnrAmdRendererSetProfiling(r.h, 1 if flag else 0))
+
+
+def vnrRendererGetFrameStats(r):
+    s = _lib.FrameStats()
+    check(lib().vnrAmdRendererGetFrameStats(r.h, C.byref(s)))
+    return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+def neural_info(v):
+    vals = [C.c_int() for _ in range(5)]
+    n = C.c_uint64()
+    check(lib().vnrAmdNeuralVolumeGetInfo(v.h, *[C.byref(x) for x in vals], C.byref(n)))
+    keys = ["n_levels", "n_features_per_level", "padded_width", "n_neurons", "n_hidden_layers"]
+    d = {k: x.value for k, x in zip(keys, vals)}
+    d["n_params"] = n.value
+    return d
+
+
+def neural_set_params_fp16(v, params):
+    p = np.ascontiguousarray(params).view(np.uint16)
+    check(lib().vnrAmdNeuralVolumeSetParamsFP16(v.h, p.ctypes.data_as(C.c_void_p), p.size))
+
+
+def neural_get_params_fp16(v):
+    n = neural_info(v)["n_params"]
+    p = np.empty(n, dtype=np.uint16)
+    check(lib().vnrAmdNeuralVolumeGetParamsFP16(v.h, p.ctypes.data_as(C.c_void_p), n))
+    return p.view(np.float16)
+
+
+def neural_inference(v, coords):
+    """coords [n,3] float32 (host) -> values [n] float32 (host), through the fused HIP kernel"""
+    c = DeviceArray.from_numpy(np.ascontiguousarray(coords, dtype=np.float32))
+    o = DeviceArray((c.shape[0],), np.float32)
+    check(lib().vnrAmdNeuralVolumeInference(v.h, c.shape[0], c.ptr, o.ptr, None))
+    check(lib().vnrAmdSynchronize())
+    return o.numpy()
+
+
+def neural_encode(v, coords):
+    info = neural_info(v)
+    c = DeviceArray.from_numpy(np.ascontiguousarray(coords, dtype=np.float32))
+    o = DeviceArray((c.shape[0], info["padded_width"]), np.uint16)
+    check(lib().vnrAmdNeuralVolumeEncode(v.h, c.shape[0], c.ptr, o.ptr, None))
+    check(lib().vnrAmdSynchronize())
+    return o.numpy().view(np.float16)
+
+
+def volume_macrocell(v):
+    dims = (C.c_int * 3)()
+    sp = (C.c_float * 3)()
+    vr, mo = C.c_void_p(), C.c_void_p()
+    check(lib().vnrAmdVolumeGetMacrocell(v.h, dims, sp, C.byref(vr), C.byref(mo)))
+    n = dims[0] * dims[1] * dims[2]
+    value_range = np.empty((dims[2], dims[1], dims[0], 2), np.float32)
+    max_opacity = np.empty((dims[2], dims[1], dims[0]), np.float32)
+    check(lib().vnrAmdMemcpyD2H(value_range.ctypes.data_as(C.c_void_p), vr, n * 8))
+    check(lib().vnrAmdMemcpyD2H(max_opacity.ctypes.data_as(C.c_void_p), mo, n * 4))
+    return {"dims": tuple(dims), "spacings": np.array(list(sp), np.float32), "value_range": value_range,
+            "max_opacity": max_opacity}
+
+
+def simple_volume_sample(v, coords, nodal):
+    c = DeviceArray.from_numpy(np.ascontiguousarray(coords, dtype=np.float32))
+    o = DeviceArray((c.shape[0],), np.float32)
+    check(lib().vnrAmdSimpleVolumeSample(v.h, c.shape[0], c.ptr, o.ptr, 1 if nodal else 0, None))
+    check(lib().vnrAmdSynchronize())
+    return o.numpy()
+
+
+def simple_volume_take_samples(v, n, lower=(0, 0, 0), upper=(1, 1, 1)):
+    c = DeviceArray((n, 3), np.float32)
+    o = DeviceArray((n,), np.float32)
+    check(lib().vnrAmdSimpleVolumeTakeSamples(v.h, n, _fp(_vec(lower)), _fp(_vec(upper)), c.ptr, o.ptr, None))
+    check(lib().vnrAmdSynchronize())
+    return c.numpy(), o.numpy()

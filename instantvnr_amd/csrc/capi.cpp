@@ -1,0 +1,608 @@
+// capi.cpp — C-ABI of libvnr_amd (include/vnr_amd.h): opaque handles over the C++ objects, error codes
+// + last-error string instead of the reference's exceptions (api.cpp).
+#include "../../include/vnr_amd.h"
+
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+
+#include "renderer.h"
+
+using namespace vnr;
+
+struct vnrAmdVolume_t { std::shared_ptr<VolumeBase> v; };
+struct vnrAmdRenderer_t { std::unique_ptr<Renderer> r; std::shared_ptr<VolumeBase> volume; };
+struct vnrAmdTransferFunction_t { TransferFunctionData d; };
+struct vnrAmdCamera_t { CameraData d; };
+
+namespace {
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F&& f)
+{
+  try {
+    f();
+    return VNR_AMD_OK;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+  } catch (...) {
+    g_last_error = "unknown error";
+  }
+  return VNR_AMD_ERROR;
+}
+
+template <typename T, typename F>
+T* guarded_new(F&& f)
+{
+  T* out = nullptr;
+  guarded([&]() { out = f(); });
+  return out;
+}
+
+Json parse_json_arg(const void* data, size_t size, int format)
+{
+  if (!data) throw std::runtime_error("null JSON argument");
+  switch (format) {
+  case VNR_AMD_JSON_TEXT: return Json::parse_text((const char*)data, size);
+  case VNR_AMD_JSON_BSON: return Json::from_bson((const uint8_t*)data, size);
+  case VNR_AMD_JSON_TEXT_FILE: return Json::load_text_file(std::string((const char*)data, size ? strnlen((const char*)data, size) : strlen((const char*)data)));
+  case VNR_AMD_JSON_BSON_FILE: return Json::load_bson_file(std::string((const char*)data, size ? strnlen((const char*)data, size) : strlen((const char*)data)));
+  default: throw std::runtime_error("unknown JSON format");
+  }
+}
+
+// api.cpp:180-185: a config that is a JSON string is a path to a JSON text file
+Json resolve_config(const Json& j) { return j.is_string() ? Json::load_text_file(j.as_string()) : j; }
+// api.cpp:269-278: params that are a JSON string are a path to a BSON file
+Json resolve_params(const Json& j) { return j.is_string() ? Json::load_bson_file(j.as_string()) : j; }
+
+NeuralVolume* as_neural(vnrAmdVolume v)
+{
+  if (!v || !v->v) throw std::runtime_error("null volume");
+  if (!v->v->is_network()) throw std::runtime_error("expecting a neural volume");  // api.cpp:137-139
+  return static_cast<NeuralVolume*>(v->v.get());
+}
+SimpleVolume* as_simple(vnrAmdVolume v)
+{
+  if (!v || !v->v) throw std::runtime_error("null volume");
+  if (v->v->is_network()) throw std::runtime_error("expecting a simple volume");  // api.cpp:128-130
+  return static_cast<SimpleVolume*>(v->v.get());
+}
+void* dup_bytes(const void* p, size_t n)
+{
+  void* out = std::malloc(n ? n : 1);
+  if (!out) throw std::runtime_error("out of host memory");
+  if (n) std::memcpy(out, p, n);
+  return out;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ runtime
+Runtime& Runtime::get()
+{
+  static Runtime r;
+  return r;
+}
+
+void Runtime::init(int dev)
+{
+  if (ready() && (dev < 0 || dev == device)) return;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) throw std::runtime_error("[vnr] no HIP capable devices found!");
+  if (dev < 0) {
+    dev = 0;
+    if (const char* e = std::getenv("VNR_AMD_DEVICE")) dev = std::atoi(e);
+    else if (const char* e2 = std::getenv("VNR_CUDA_DEVICE")) dev = std::atoi(e2);  // renderer.cpp:300
+  }
+  if (dev >= count) throw std::runtime_error("[vnr] device index out of range");
+  VNR_HIP_CHECK(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  VNR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (stream) (void)hipStreamDestroy(stream);
+  VNR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  device = dev;
+}
+
+extern "C" {
+
+const char* vnrAmdGetLastError(void) { return g_last_error.c_str(); }
+const char* vnrAmdVersion(void) { return "instantvnr_amd 0.1 (gfx950)"; }
+int vnrAmdInit(int device) { return guarded([&]() { Runtime::get().init(device); }); }
+int vnrAmdDeviceCount(void)
+{
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+int vnrAmdHasDevice(void) { return vnrAmdDeviceCount() > 0 ? 1 : 0; }
+
+void* vnrAmdMalloc(size_t bytes)
+{
+  void* p = nullptr;
+  guarded([&]() {
+    if (!Runtime::get().ready()) Runtime::get().init(-1);
+    VNR_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+  });
+  return p;
+}
+int vnrAmdFree(void* p) { return guarded([&]() { if (p) VNR_HIP_CHECK(hipFree(p)); }); }
+int vnrAmdMemcpyH2D(void* d, const void* h, size_t n)
+{
+  return guarded([&]() {
+    VNR_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, Runtime::get().stream));
+    VNR_HIP_CHECK(hipStreamSynchronize(Runtime::get().stream));
+  });
+}
+int vnrAmdMemcpyD2H(void* h, const void* d, size_t n)
+{
+  return guarded([&]() {
+    VNR_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, Runtime::get().stream));
+    VNR_HIP_CHECK(hipStreamSynchronize(Runtime::get().stream));
+  });
+}
+int vnrAmdMemset(void* d, int value, size_t n)
+{
+  return guarded([&]() {
+    VNR_HIP_CHECK(hipMemsetAsync(d, value, n, Runtime::get().stream));
+    VNR_HIP_CHECK(hipStreamSynchronize(Runtime::get().stream));
+  });
+}
+int vnrAmdSynchronize(void) { return guarded([&]() { VNR_HIP_CHECK(hipDeviceSynchronize()); }); }
+void* vnrAmdDefaultStream(void)
+{
+  void* s = nullptr;
+  guarded([&]() { if (!Runtime::get().ready()) Runtime::get().init(-1); s = (void*)Runtime::get().stream; });
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------ JSON
+int vnrAmdJsonConvert(const void* data, size_t size, int format_in, int format_out, void** out, size_t* out_size)
+{
+  return guarded([&]() {
+    const Json j = parse_json_arg(data, size, format_in);
+    if (format_out == VNR_AMD_JSON_BSON) {
+      const std::vector<uint8_t> b = j.to_bson();
+      *out = dup_bytes(b.data(), b.size());
+      *out_size = b.size();
+    } else if (format_out == VNR_AMD_JSON_TEXT) {
+      const std::string s = j.dump(4);
+      *out = dup_bytes(s.data(), s.size());
+      *out_size = s.size();
+    } else {
+      throw std::runtime_error("format_out must be TEXT or BSON");
+    }
+  });
+}
+
+int vnrAmdJsonSave(const void* data, size_t size, int format_in, const char* filename, int format_out)
+{
+  return guarded([&]() {
+    const Json j = parse_json_arg(data, size, format_in);
+    if (format_out == VNR_AMD_JSON_BSON || format_out == VNR_AMD_JSON_BSON_FILE) {  // api.cpp:41-47
+      const std::vector<uint8_t> b = j.to_bson();
+      std::ofstream ofs(filename, std::ios::binary | std::ios::out);
+      ofs.write((const char*)b.data(), (std::streamsize)b.size());
+      if (!ofs) throw std::runtime_error(std::string("cannot write ") + filename);
+    } else {  // api.cpp:34-39
+      std::ofstream ofs(filename, std::ios::out);
+      ofs << j.dump(4) << std::endl;
+      if (!ofs) throw std::runtime_error(std::string("cannot write ") + filename);
+    }
+  });
+}
+
+void vnrAmdFreeHost(void* p) { std::free(p); }
+
+// ------------------------------------------------------------------------------------------------ camera
+vnrAmdCamera vnrAmdCreateCamera(void) { return guarded_new<vnrAmdCamera_t>([]() { return new vnrAmdCamera_t(); }); }
+int vnrAmdCameraSet(vnrAmdCamera c, const float from[3], const float at[3], const float up[3])
+{
+  return guarded([&]() {
+    if (!c) throw std::runtime_error("null camera");
+    c->d.from = {from[0], from[1], from[2]};
+    c->d.at = {at[0], at[1], at[2]};
+    c->d.up = {up[0], up[1], up[2]};
+  });
+}
+int vnrAmdCameraSetFovy(vnrAmdCamera c, float fovy)
+{
+  return guarded([&]() { if (!c) throw std::runtime_error("null camera"); c->d.fovy = fovy; });
+}
+int vnrAmdCameraGet(vnrAmdCamera c, float from[3], float at[3], float up[3], float* fovy)
+{
+  return guarded([&]() {
+    if (!c) throw std::runtime_error("null camera");
+    if (from) { from[0] = c->d.from.x; from[1] = c->d.from.y; from[2] = c->d.from.z; }
+    if (at) { at[0] = c->d.at.x; at[1] = c->d.at.y; at[2] = c->d.at.z; }
+    if (up) { up[0] = c->d.up.x; up[1] = c->d.up.y; up[2] = c->d.up.z; }
+    if (fovy) *fovy = c->d.fovy;
+  });
+}
+void vnrAmdReleaseCamera(vnrAmdCamera c) { delete c; }
+
+// ------------------------------------------------------------------------------------------------ transfer function
+vnrAmdTransferFunction vnrAmdCreateTransferFunction(void)
+{
+  return guarded_new<vnrAmdTransferFunction_t>([]() { return new vnrAmdTransferFunction_t(); });
+}
+int vnrAmdTransferFunctionSetColor(vnrAmdTransferFunction t, const float* rgb, int n)
+{
+  return guarded([&]() {
+    if (!t) throw std::runtime_error("null transfer function");
+    t->d.color.resize((size_t)n);
+    for (int i = 0; i < n; ++i) t->d.color[i] = {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+  });
+}
+int vnrAmdTransferFunctionSetAlpha(vnrAmdTransferFunction t, const float* xy, int n)
+{
+  return guarded([&]() {
+    if (!t) throw std::runtime_error("null transfer function");
+    t->d.alpha.resize((size_t)n);
+    for (int i = 0; i < n; ++i) t->d.alpha[i] = {xy[2 * i], xy[2 * i + 1]};
+  });
+}
+int vnrAmdTransferFunctionSetValueRange(vnrAmdTransferFunction t, float lo, float hi)
+{
+  return guarded([&]() {
+    if (!t) throw std::runtime_error("null transfer function");
+    t->d.range_lo = lo; t->d.range_hi = hi; t->d.range_set = true;
+  });
+}
+int vnrAmdTransferFunctionGetSizes(vnrAmdTransferFunction t, int* nc, int* na)
+{
+  return guarded([&]() {
+    if (!t) throw std::runtime_error("null transfer function");
+    if (nc) *nc = (int)t->d.color.size();
+    if (na) *na = (int)t->d.alpha.size();
+  });
+}
+int vnrAmdTransferFunctionGet(vnrAmdTransferFunction t, float* rgb, float* xy, float range[2])
+{
+  return guarded([&]() {
+    if (!t) throw std::runtime_error("null transfer function");
+    if (rgb) for (size_t i = 0; i < t->d.color.size(); ++i) { rgb[3 * i] = t->d.color[i].x; rgb[3 * i + 1] = t->d.color[i].y; rgb[3 * i + 2] = t->d.color[i].z; }
+    if (xy) for (size_t i = 0; i < t->d.alpha.size(); ++i) { xy[2 * i] = t->d.alpha[i].x; xy[2 * i + 1] = t->d.alpha[i].y; }
+    if (range) { range[0] = t->d.range_lo; range[1] = t->d.range_hi; }
+  });
+}
+void vnrAmdReleaseTransferFunction(vnrAmdTransferFunction t) { delete t; }
+
+// ------------------------------------------------------------------------------------------------ simple volume
+vnrAmdVolume vnrAmdCreateSimpleVolumeFromMemory(const void* host_data, const int dims[3], int value_type, float lo, float hi)
+{
+  return guarded_new<vnrAmdVolume_t>([&]() {
+    auto sv = std::make_shared<SimpleVolume>();
+    sv->load_host(host_data, {dims[0], dims[1], dims[2]}, value_type, lo, hi);
+    auto* h = new vnrAmdVolume_t();
+    h->v = sv;
+    return h;
+  });
+}
+vnrAmdVolume vnrAmdCreateSimpleVolumeFromRawFile(const char* filename, const int dims[3], int value_type, size_t offset,
+                                                 int big_endian, float lo, float hi)
+{
+  return guarded_new<vnrAmdVolume_t>([&]() {
+    auto sv = std::make_shared<SimpleVolume>();
+    sv->load_raw_file(filename, {dims[0], dims[1], dims[2]}, value_type, offset, big_endian != 0, lo, hi);
+    auto* h = new vnrAmdVolume_t();
+    h->v = sv;
+    return h;
+  });
+}
+vnrAmdVolume vnrAmdCreateSimpleVolumePerlin(const int dims[3], uint32_t seed, int octaves, float base_frequency)
+{
+  return guarded_new<vnrAmdVolume_t>([&]() {
+    auto sv = std::make_shared<SimpleVolume>();
+    sv->generate_perlin({dims[0], dims[1], dims[2]}, seed, octaves, base_frequency);
+    auto* h = new vnrAmdVolume_t();
+    h->v = sv;
+    return h;
+  });
+}
+const float* vnrAmdSimpleVolumeDeviceData(vnrAmdVolume v)
+{
+  const float* p = nullptr;
+  guarded([&]() { p = as_simple(v)->d_data(); });
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------ neural volume
+vnrAmdVolume vnrAmdCreateNeuralVolume(const void* config, size_t size, int format, vnrAmdVolume groundtruth, int online_mc)
+{
+  return guarded_new<vnrAmdVolume_t>([&]() {
+    SimpleVolume* src = as_simple(groundtruth);
+    const Json cfg = resolve_config(parse_json_arg(config, size, format));
+    auto nv = std::make_shared<NeuralVolume>();
+    if (const char* e = std::getenv("VNR_AMD_INIT_SEED")) nv->init_seed = std::strtoull(e, nullptr, 10);
+    nv->keep_source_alive(groundtruth->v);
+    nv->set_network(src->dims(), cfg, src, !online_mc);  // api.cpp:181-184
+    auto* h = new vnrAmdVolume_t();
+    h->v = nv;
+    return h;
+  });
+}
+vnrAmdVolume vnrAmdCreateNeuralVolumeFromDims(const void* config, size_t size, int format, const int dims[3])
+{
+  return guarded_new<vnrAmdVolume_t>([&]() {
+    const Json cfg = resolve_config(parse_json_arg(config, size, format));
+    auto nv = std::make_shared<NeuralVolume>();
+    if (const char* e = std::getenv("VNR_AMD_INIT_SEED")) nv->init_seed = std::strtoull(e, nullptr, 10);
+    nv->set_network({dims[0], dims[1], dims[2]}, cfg, nullptr, false);  // api.cpp:190-204
+    auto* h = new vnrAmdVolume_t();
+    h->v = nv;
+    return h;
+  });
+}
+vnrAmdVolume vnrAmdCreateNeuralVolumeFromParams(const void* params, size_t size, int format)
+{
+  return guarded_new<vnrAmdVolume_t>([&]() {
+    const Json p = resolve_params(parse_json_arg(params, size, format));
+    if (!p.contains("volume")) throw std::runtime_error("expecting a model config with volume dims tag");  // api.cpp:214-216
+    const Json& d = p.at("volume").at("dims");
+    const vec3i dims = {(int)d.at("x").as_int(), (int)d.at("y").as_int(), (int)d.at("z").as_int()};
+    auto nv = std::make_shared<NeuralVolume>();
+    nv->init_seed = 1;
+    nv->set_network(dims, p.at("model"), nullptr, false);
+    nv->load_params_from_json(p);
+    auto* h = new vnrAmdVolume_t();
+    h->v = nv;
+    return h;
+  });
+}
+int vnrAmdNeuralVolumeSetModel(vnrAmdVolume v, const void* config, size_t size, int format)
+{
+  return guarded([&]() { as_neural(v)->set_model(resolve_config(parse_json_arg(config, size, format))); });
+}
+int vnrAmdNeuralVolumeSetParams(vnrAmdVolume v, const void* params, size_t size, int format)
+{
+  return guarded([&]() { as_neural(v)->load_params_from_json(resolve_params(parse_json_arg(params, size, format))); });
+}
+double vnrAmdNeuralVolumeGetPSNR(vnrAmdVolume v, int verbose)
+{
+  double r = -1.0;
+  guarded([&]() { r = as_neural(v)->get_psnr(!verbose); });
+  return r;
+}
+double vnrAmdNeuralVolumeGetTestingLoss(vnrAmdVolume v)
+{
+  double r = -1.0;
+  guarded([&]() { r = as_neural(v)->test_loss(); });
+  return r;
+}
+double vnrAmdNeuralVolumeGetTrainingLoss(vnrAmdVolume v)
+{
+  double r = -1.0;
+  guarded([&]() { NeuralVolume* n = as_neural(v); r = n->network().training_loss(n->stream); });
+  return r;
+}
+int vnrAmdNeuralVolumeGetTrainingStep(vnrAmdVolume v)
+{
+  int r = -1;
+  guarded([&]() { r = (int)as_neural(v)->network().steps(); });
+  return r;
+}
+int vnrAmdNeuralVolumeGetNumberOfBlobs(vnrAmdVolume v)
+{
+  int r = -1;
+  guarded([&]() { r = as_neural(v)->num_blobs(); });
+  return r;
+}
+int vnrAmdNeuralVolumeTrain(vnrAmdVolume v, int steps, int fast_mode)
+{
+  return guarded([&]() { as_neural(v)->train((size_t)std::max(steps, 0), fast_mode != 0); });
+}
+int vnrAmdNeuralVolumeSerializeParamsToFile(vnrAmdVolume v, const char* filename)
+{
+  return guarded([&]() {
+    Json root = Json::object();
+    as_neural(v)->save_params_to_json(root);
+    const std::vector<uint8_t> b = root.to_bson();
+    std::ofstream ofs(filename, std::ios::binary | std::ios::out);
+    ofs.write((const char*)b.data(), (std::streamsize)b.size());
+    if (!ofs) throw std::runtime_error(std::string("cannot write ") + filename);
+  });
+}
+int vnrAmdNeuralVolumeSerializeParams(vnrAmdVolume v, void** bson, size_t* size)
+{
+  return guarded([&]() {
+    Json root = Json::object();
+    as_neural(v)->save_params_to_json(root);
+    const std::vector<uint8_t> b = root.to_bson();
+    *bson = dup_bytes(b.data(), b.size());
+    *size = b.size();
+  });
+}
+int vnrAmdNeuralVolumeInference(vnrAmdVolume v, size_t n, const float* d_coords, float* d_values, void* stream)
+{
+  return guarded([&]() {
+    NeuralVolume* nv = as_neural(v);
+    if (!nv->network().valid()) throw std::runtime_error("network is not valid");
+    nv->inference(n, d_coords, d_values, resolve_stream(stream));
+  });
+}
+int vnrAmdNeuralVolumeEncode(vnrAmdVolume v, size_t n, const float* d_coords, uint16_t* d_features, void* stream)
+{
+  return guarded([&]() { as_neural(v)->network().encode(d_coords, d_features, n, resolve_stream(stream)); });
+}
+int vnrAmdNeuralVolumeGetInfo(vnrAmdVolume v, int* n_levels, int* n_features, int* padded_width, int* n_neurons,
+                              int* n_hidden_layers, uint64_t* n_params)
+{
+  return guarded([&]() {
+    Network& n = as_neural(v)->network();
+    if (n_levels) *n_levels = (int)n.config().n_levels;
+    if (n_features) *n_features = (int)n.config().n_features;
+    if (padded_width) *padded_width = (int)n.padded_width();
+    if (n_neurons) *n_neurons = (int)n.config().n_neurons;
+    if (n_hidden_layers) *n_hidden_layers = (int)n.config().n_hidden_layers;
+    if (n_params) *n_params = (uint64_t)n.n_params();
+  });
+}
+int vnrAmdNeuralVolumeGetParamsFP16(vnrAmdVolume v, uint16_t* host_out, size_t count)
+{
+  return guarded([&]() { NeuralVolume* n = as_neural(v); n->network().get_params_f16(host_out, count, n->stream); });
+}
+int vnrAmdNeuralVolumeSetParamsFP16(vnrAmdVolume v, const uint16_t* host_in, size_t count)
+{
+  return guarded([&]() { NeuralVolume* n = as_neural(v); n->network().set_params_f16(host_in, count, n->stream); });
+}
+int vnrAmdNeuralVolumeTrainBegin(vnrAmdVolume v) { return guarded([&]() { as_neural(v)->train_begin(); }); }
+float* vnrAmdNeuralVolumeGradients(vnrAmdVolume v, size_t* count)
+{
+  float* p = nullptr;
+  guarded([&]() {
+    Network& n = as_neural(v)->network();
+    p = n.grads();
+    if (count) *count = n.grads_count();
+  });
+  return p;
+}
+int vnrAmdNeuralVolumeTrainEnd(vnrAmdVolume v, float grad_scale, int fast_mode)
+{
+  return guarded([&]() { as_neural(v)->train_end(grad_scale, fast_mode != 0); });
+}
+int vnrAmdNeuralVolumeSetSamplerSeed(vnrAmdVolume v, uint64_t seed, uint64_t stream_id)
+{
+  return guarded([&]() {
+    NeuralVolume* n = as_neural(v);
+    if (!n->source()) throw std::runtime_error("missing a reference volume");
+    n->source()->set_sampler_seed(seed, stream_id);
+  });
+}
+int vnrAmdNeuralVolumeSetInitSeed(vnrAmdVolume v, uint64_t seed)
+{
+  return guarded([&]() { as_neural(v)->init_seed = seed; });
+}
+
+// ------------------------------------------------------------------------------------------------ general volume
+int vnrAmdVolumeSetClippingBox(vnrAmdVolume v, const float lower[3], const float upper[3])
+{
+  return guarded([&]() {  // api.cpp:322-338
+    if (!v || !v->v) throw std::runtime_error("null volume");
+    VolumeBase& vb = *v->v;
+    const vec3f half = {vb.desc.dims.x / 2.0f, vb.desc.dims.y / 2.0f, vb.desc.dims.z / 2.0f};
+    const affine3f inv = affine_inverse(vb.transform);
+    vb.clipbox.lower = xfm_point(inv, vec3f{lower[0], lower[1], lower[2]} - half);
+    vb.clipbox.upper = xfm_point(inv, vec3f{upper[0], upper[1], upper[2]} - half);
+  });
+}
+int vnrAmdVolumeSetScaling(vnrAmdVolume v, const float scale[3])
+{
+  return guarded([&]() {  // api.cpp:340-351: transform = scale(s) * transform
+    if (!v || !v->v) throw std::runtime_error("null volume");
+    v->v->transform = affine_scale_then({scale[0], scale[1], scale[2]}, v->v->transform);
+  });
+}
+int vnrAmdVolumeGetValueRange(vnrAmdVolume v, float range[2])
+{
+  return guarded([&]() {
+    if (!v || !v->v) throw std::runtime_error("null volume");
+    range[0] = v->v->desc.range_lo; range[1] = v->v->desc.range_hi;
+  });
+}
+int vnrAmdVolumeGetDims(vnrAmdVolume v, int dims[3])
+{
+  return guarded([&]() {
+    if (!v || !v->v) throw std::runtime_error("null volume");
+    dims[0] = v->v->desc.dims.x; dims[1] = v->v->desc.dims.y; dims[2] = v->v->desc.dims.z;
+  });
+}
+int vnrAmdVolumeIsNetwork(vnrAmdVolume v) { return (v && v->v && v->v->is_network()) ? 1 : 0; }
+int vnrAmdVolumeGetMacrocell(vnrAmdVolume v, int mc_dims[3], float mc_spacings[3], const float** d_value_range, const float** d_max_opacity)
+{
+  return guarded([&]() {
+    if (!v || !v->v) throw std::runtime_error("null volume");
+    MacroCell& m = v->v->macrocell();
+    const vec3i d = m.dims();
+    const vec3f s = m.spacings();
+    if (mc_dims) { mc_dims[0] = d.x; mc_dims[1] = d.y; mc_dims[2] = d.z; }
+    if (mc_spacings) { mc_spacings[0] = s.x; mc_spacings[1] = s.y; mc_spacings[2] = s.z; }
+    if (d_value_range) *d_value_range = m.d_value_range();
+    if (d_max_opacity) *d_max_opacity = m.d_max_opacity();
+  });
+}
+void vnrAmdReleaseVolume(vnrAmdVolume v) { delete v; }
+
+// ------------------------------------------------------------------------------------------------ renderer
+vnrAmdRenderer vnrAmdCreateRenderer(vnrAmdVolume v)
+{
+  return guarded_new<vnrAmdRenderer_t>([&]() {
+    if (!v || !v->v) throw std::runtime_error("null volume");
+    auto* h = new vnrAmdRenderer_t();
+    h->volume = v->v;
+    h->r = std::make_unique<Renderer>(v->v);
+    return h;
+  });
+}
+#define VNR_REN(r) do { if (!(r) || !(r)->r) throw std::runtime_error("null renderer"); } while (0)
+int vnrAmdRendererSetFramebufferSize(vnrAmdRenderer r, int w, int h) { return guarded([&]() { VNR_REN(r); r->r->resize(w, h); }); }
+int vnrAmdRendererSetTransferFunction(vnrAmdRenderer r, vnrAmdTransferFunction t)
+{
+  return guarded([&]() { VNR_REN(r); if (!t) throw std::runtime_error("null transfer function"); r->r->set_transfer_function(t->d); });
+}
+int vnrAmdRendererSetCamera(vnrAmdRenderer r, vnrAmdCamera c)
+{
+  return guarded([&]() { VNR_REN(r); if (!c) throw std::runtime_error("null camera"); r->r->set_camera(c->d); });
+}
+int vnrAmdRendererSetMode(vnrAmdRenderer r, int mode) { return guarded([&]() { VNR_REN(r); r->r->set_mode(mode); }); }
+int vnrAmdRendererSetDenoiser(vnrAmdRenderer r, int) { return guarded([&]() { VNR_REN(r); }); }
+int vnrAmdRendererSetVolumeSamplingRate(vnrAmdRenderer r, float rate) { return guarded([&]() { VNR_REN(r); r->r->set_sampling_rate(rate); }); }
+int vnrAmdRendererSetVolumeDensityScale(vnrAmdRenderer r, float s) { return guarded([&]() { VNR_REN(r); r->r->set_density_scale(s); }); }
+int vnrAmdRendererResetAccumulation(vnrAmdRenderer r) { return guarded([&]() { VNR_REN(r); r->r->reset_accumulation(); }); }
+int vnrAmdRender(vnrAmdRenderer r) { return guarded([&]() { VNR_REN(r); r->r->render(); }); }
+const float* vnrAmdRendererMapFrame(vnrAmdRenderer r)
+{
+  const float* p = nullptr;
+  guarded([&]() { VNR_REN(r); p = r->r->map_frame(); });
+  return p;
+}
+int vnrAmdRendererSetOutputAsDeviceFramebuffer(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_device_output(e != 0); }); }
+int vnrAmdRendererSetPixelRange(vnrAmdRenderer r, uint32_t lo, uint32_t hi) { return guarded([&]() { VNR_REN(r); r->r->set_pixel_range(lo, hi); }); }
+int vnrAmdRendererGetFrameStats(vnrAmdRenderer r, vnrAmdFrameStats* s)
+{
+  return guarded([&]() {
+    VNR_REN(r);
+    const FrameStats& f = r->r->stats();
+    s->n_samples = f.n_samples; s->n_reference_slots = f.n_reference_slots; s->n_iterations = f.n_iterations;
+    s->n_rays_hit = f.n_rays_hit; s->infer_kernel_ms = f.infer_kernel_ms; s->infer_kernel_launches = f.infer_kernel_launches;
+  });
+}
+int vnrAmdRendererSetProfiling(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_profiling(e != 0); }); }
+void vnrAmdReleaseRenderer(vnrAmdRenderer r) { delete r; }
+
+// ------------------------------------------------------------------------------------------------ misc
+void vnrAmdMemoryQuery(size_t* used_by_renderer, size_t* used_by_network)
+{
+  if (used_by_renderer) *used_by_renderer = Runtime::get().bytes_renderer;
+  if (used_by_network) *used_by_network = Runtime::get().bytes_network;
+}
+void vnrAmdFreeTemporaryGPUMemory(void) {}
+
+// ------------------------------------------------------------------------------------------------ building blocks
+int vnrAmdSimpleVolumeTakeSamples(vnrAmdVolume v, size_t n, const float lower[3], const float upper[3], float* d_coords,
+                                  float* d_values, void* stream)
+{
+  return guarded([&]() {
+    as_simple(v)->take_samples(d_coords, d_values, n, {lower[0], lower[1], lower[2]}, {upper[0], upper[1], upper[2]}, resolve_stream(stream));
+  });
+}
+int vnrAmdSimpleVolumeSample(vnrAmdVolume v, size_t n, const float* d_coords, float* d_values, int nodal, void* stream)
+{
+  return guarded([&]() { as_simple(v)->sample(d_coords, d_values, n, nodal != 0, resolve_stream(stream)); });
+}
+int vnrAmdNeuralVolumeUpdateMacrocell(vnrAmdVolume v, size_t n, const float* d_coords, const float* d_values, void* stream)
+{
+  return guarded([&]() { as_neural(v)->macrocell().update_explicit(d_coords, d_values, n, resolve_stream(stream)); });
+}
+int vnrAmdVolumeUpdateMaxOpacity(vnrAmdVolume v, vnrAmdTransferFunction t)
+{
+  return guarded([&]() {
+    if (!v || !v->v) throw std::runtime_error("null volume");
+    if (!t) throw std::runtime_error("null transfer function");
+    v->v->set_transfer_function(t->d, Runtime::get().stream);
+    VNR_HIP_CHECK(hipStreamSynchronize(Runtime::get().stream));
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// network.h — hash-grid encoding + fully fused MLP ("NetworkWithInputEncoding") for gfx950.
+//
+// Replaces the reference's network engine: core/networks/tcnn_network.h:79-272 (AbstractNetwork /
+// TcnnNetwork<3,1>), core/networks/tcnn_impl*.cu (inference restatement) and the un-vendored
+// tiny-cuda-nn Trainer behind them (forward/backward/L1 loss/Adam+ExponentialDecay).
+#pragma once
+
+#include "common.h"
+#include "json.h"
+
+namespace vnr {
+
+constexpr int kMaxLevels = 32;
+constexpr int kWidth = 64;        // FullyFusedMLP n_neurons supported by the MFMA kernels
+constexpr int kLossScale = 128;   // tcnn default loss scale for fp16 (EXTERNAL)
+
+struct LevelInfo {
+  float scale;
+  uint32_t resolution;
+  uint32_t size;    // entries in this level
+  uint32_t offset;  // first entry of this level (entries, x F for elements)
+  uint32_t hashed;  // 1: prime-XOR hash (size is a power of two), 0: dense index
+};
+
+struct GridDevice {
+  LevelInfo levels[kMaxLevels];
+  uint32_t n_levels;
+  uint32_t n_features;     // per level
+  uint32_t interpolation;  // 0 linear, 1 smoothstep
+};
+
+struct ModelConfig {
+  // encoding (tcnn HashGrid; example-model.json:19-25)
+  uint32_t n_levels = 8, n_features = 8, log2_hashmap_size = 19, base_resolution = 16;
+  float per_level_scale = 2.0f;
+  uint32_t interpolation = 0;
+  // network (FullyFusedMLP; example-model.json:26-32)
+  uint32_t n_neurons = 64, n_hidden_layers = 4;
+  uint32_t activation = 1;  // 0 None, 1 ReLU
+  // optimizer (ExponentialDecay{Adam}; example-model.json:2-15)
+  float learning_rate = 5e-3f, beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-15f, l2_reg = 1e-6f;
+  uint32_t decay_start = 2000, decay_interval = 1000;
+  float decay_base = 0.99f;
+  bool has_decay = true;
+  // loss
+  uint32_t loss = 0;  // 0 L1, 1 L2
+};
+
+class Network {
+public:
+  Network() = default;
+  // tcnn_network.h:163-221 deserialize_model: builds loss/optimizer/encoding/network from the model JSON.
+  // Throws on unsupported otypes (the reference swallows the tcnn error and stays invalid, :211-213).
+  void configure(const Json& model, uint64_t init_seed);
+  bool valid() const { return n_params_ > 0; }
+
+  const ModelConfig& config() const { return cfg_; }
+  const Json& model_json() const { return model_; }
+  const GridDevice& grid() const { return grid_; }
+  uint32_t padded_width() const { return in_width_; }
+  uint32_t n_hidden_matmuls() const { return cfg_.n_hidden_layers - 1; }
+  size_t n_params() const { return n_params_; }
+  size_t n_mlp_params() const { return n_mlp_; }
+  size_t n_grid_params() const { return n_params_ - n_mlp_; }
+  size_t model_size_bytes() const { return n_params_ * sizeof(uint16_t); }  // tcnn_network.h:138
+  uint64_t steps() const { return steps_; }
+
+  // parameters, tcnn order: MLP weights (first, hidden..., last[16 x W]), then grid level by level; fp16
+  void set_params_f16(const uint16_t* host, size_t count, hipStream_t s);
+  void get_params_f16(uint16_t* host, size_t count, hipStream_t s) const;
+  // tcnn Trainer::serialize / deserialize ({n_params, params_type, params_binary}); EXTERNAL format
+  Json serialize_params(hipStream_t s) const;
+  void deserialize_params(const Json& j, hipStream_t s);
+
+  // inference: coords [n][3] fp32 -> out [n] fp32.  n either by value or read on the device from d_n.
+  void inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s) const;
+  // encode only: fp16 [n][padded_width]
+  void encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const;
+
+  // training step pieces (tcnn Trainer::training_step, EXTERNAL): forward+loss+backward into grads()
+  void forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s);
+  float* grads() { return grads_.ptr; }
+  size_t grads_count() const { return grads_.count; }
+  void optimizer_step(float grad_scale, hipStream_t s);
+  double training_loss(hipStream_t s);  // mean loss of the last forward_backward
+
+  size_t bytes_allocated() const;
+
+private:
+  void build_layout();
+  void initialize_params(uint64_t seed, hipStream_t s);
+  void refresh_inference_weights(hipStream_t s);
+
+  ModelConfig cfg_;
+  Json model_;
+  GridDevice grid_{};
+  uint32_t in_width_ = 0;
+  size_t n_params_ = 0, n_mlp_ = 0;
+  uint64_t steps_ = 0;
+
+  DeviceBuffer<uint16_t> params_f16_{MemTag::Network};   // tcnn-order blob (inference + serialisation)
+  DeviceBuffer<uint16_t> mlp_packed_{MemTag::Network};   // MFMA/LDS image of the MLP weights
+  DeviceBuffer<float> params_f32_{MemTag::Network};      // fp32 master copy (training)
+  DeviceBuffer<float> grads_{MemTag::Network};           // fp32 gradient of the whole blob
+  DeviceBuffer<float> adam_m_{MemTag::Network}, adam_v_{MemTag::Network};
+  // training workspace
+  DeviceBuffer<uint16_t> ws_features_{MemTag::Network};  // [B][in_width]
+  DeviceBuffer<uint16_t> ws_acts_{MemTag::Network};      // [(nh+1)][B][64]
+  DeviceBuffer<uint16_t> ws_dfeat_{MemTag::Network};     // [B][in_width] dL/dfeatures (fp16, loss-scaled)
+  DeviceBuffer<float> ws_loss_{MemTag::Network};         // [blocks] partial loss sums
+  size_t ws_batch_ = 0;
+  uint32_t lds_halves_ = 0;
+};
+
+// layout helpers shared with tests
+uint32_t grid_make_layout(const ModelConfig& cfg, GridDevice* out);
+
+}  // namespace vnr

@@ -1,0 +1,261 @@
+// network_host.hip — host side of the network engine: model JSON -> layout, parameter blob handling,
+// (de)serialisation in tcnn's Trainer::serialize format, launch wrappers.
+//
+// Reference: core/networks/tcnn_network.h:157-272; EXTERNAL tiny-cuda-nn (GridEncodingTemplated ctor,
+// FullyFusedMLP, Trainer::serialize/deserialize) — assumptions listed in SURVEY.md Appendix A.
+#include "network.h"
+
+#include <algorithm>
+
+namespace vnr {
+
+void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width, uint32_t n_hidden_matmuls, hipStream_t s);
+void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
+                  const uint16_t* table, const uint16_t* packed, uint32_t lds_halves, const float* coords, float* out,
+                  uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s);
+void launch_init_params(float* master, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
+                        uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s);
+void launch_f16_to_f32(const uint16_t* in, float* out, size_t n, hipStream_t s);
+void launch_f32_to_f16(const float* in, uint16_t* out, size_t n, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+uint16_t f32_to_f16(float f)
+{
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const uint32_t ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? (0x200u | ((ax >> 13) & 0x3ffu)) : 0u));
+  if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+  if (ax < 0x33000001u) return (uint16_t)sign;
+  const int32_t e = (int32_t)(ax >> 23) - 127;
+  const uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+  const uint32_t shift = e < -14 ? (uint32_t)(-1 - e) : 13u;
+  const uint32_t he = e < -14 ? 0u : (uint32_t)(e + 15);
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) q++;
+  return (uint16_t)(sign | (he == 0 ? q : ((he - 1) << 10) + q));
+}
+
+float f16_to_f32(uint16_t h)
+{
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  uint32_t x;
+  if (e == 0) {
+    if (m == 0) x = sign;
+    else { float v = (float)m * 5.9604644775390625e-8f; std::memcpy(&x, &v, 4); x |= sign; }
+  } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+  else x = sign | ((e + 112u) << 23) | (m << 13);
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+// EXTERNAL tcnn GridEncodingTemplated ctor (level sizing) + grid_index's hash decision; scale/resolution
+// as used by core/networks/tcnn_impl_decoder.cu:41-42.
+uint32_t grid_make_layout(const ModelConfig& cfg, GridDevice* out)
+{
+  if (cfg.n_levels > (uint32_t)kMaxLevels) throw std::runtime_error("too many hash-grid levels");
+  const float log2_pls = std::log2(cfg.per_level_scale);
+  uint32_t offset = 0;
+  for (uint32_t l = 0; l < cfg.n_levels; ++l) {
+    const float scale = exp2f((float)l * log2_pls) * (float)cfg.base_resolution - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+    const uint32_t max_params = 0xffffffffu / 2u;
+    const double cube = (double)res * (double)res * (double)res;
+    uint32_t n = cube > (double)max_params ? max_params : (uint32_t)cube;
+    n = next_multiple(n, 8u);
+    const uint32_t cap = 1u << cfg.log2_hashmap_size;
+    if (n > cap) n = cap;
+    // hash iff the dense stride walk exceeds the level size (tcnn grid_index)
+    uint32_t stride = 1;
+    for (uint32_t dim = 0; dim < 3 && stride <= n; ++dim) stride *= res;
+    LevelInfo& lv = out->levels[l];
+    lv.scale = scale;
+    lv.resolution = res;
+    lv.size = n;
+    lv.offset = offset;
+    lv.hashed = n < stride ? 1u : 0u;
+    if (lv.hashed && (n & (n - 1)) != 0) throw std::runtime_error("internal: hashed level with non power-of-two size");
+    offset += n;
+  }
+  out->n_levels = cfg.n_levels;
+  out->n_features = cfg.n_features;
+  out->interpolation = cfg.interpolation;
+  return offset;
+}
+
+static uint32_t json_u32(const Json& j, const char* key, uint32_t def) { return j.contains(key) ? (uint32_t)j.at(key).as_int() : def; }
+static float json_f32(const Json& j, const char* key, float def) { return j.contains(key) ? j.at(key).as_float() : def; }
+static std::string json_str(const Json& j, const char* key, const char* def) { return j.contains(key) ? j.at(key).as_string() : std::string(def); }
+
+void Network::configure(const Json& config, uint64_t init_seed)
+{
+  // tcnn_network.h:167-175: only loss / encoding / network are kept in the serialised model; the optimizer
+  // options persist across re-configuration (m_optimizer_opts).
+  const Json loss = config.value("loss", Json::object());
+  const Json enc = config.value("encoding", Json::object());
+  const Json net = config.value("network", Json::object());
+  ModelConfig c = cfg_;  // keeps previous optimizer options unless given
+  if (config.contains("optimizer")) {
+    const Json& opt = config.at("optimizer");
+    const std::string ot = json_str(opt, "otype", "Adam");
+    const Json* adam = &opt;
+    if (ot == "ExponentialDecay") {
+      c.has_decay = true;
+      c.decay_start = json_u32(opt, "decay_start", 10000);
+      c.decay_interval = json_u32(opt, "decay_interval", 10000);  // tcnn defaults
+      c.decay_base = json_f32(opt, "decay_base", 0.33f);
+      if (!opt.contains("nested")) throw std::runtime_error("ExponentialDecay optimizer needs a 'nested' optimizer");
+      adam = &opt.at("nested");
+    } else {
+      c.has_decay = false;
+    }
+    if (json_str(*adam, "otype", "Adam") != "Adam") throw std::runtime_error("unsupported optimizer otype (Adam / ExponentialDecay{Adam} only)");
+    c.learning_rate = json_f32(*adam, "learning_rate", 1e-3f);
+    c.beta1 = json_f32(*adam, "beta1", 0.9f);
+    c.beta2 = json_f32(*adam, "beta2", 0.999f);
+    c.epsilon = json_f32(*adam, "epsilon", 1e-8f);
+    c.l2_reg = json_f32(*adam, "l2_reg", 1e-8f);
+  }
+  const std::string lt = json_str(loss, "otype", "L2");
+  if (lt == "L1") c.loss = 0;
+  else if (lt == "L2") c.loss = 1;
+  else throw std::runtime_error("unsupported loss otype: " + lt);
+
+  const std::string et = json_str(enc, "otype", "");
+  if (et != "HashGrid" && et != "Grid") throw std::runtime_error("unsupported encoding otype: '" + et + "' (HashGrid only)");
+  if (json_str(enc, "type", "Hash") != "Hash") throw std::runtime_error("unsupported grid type (Hash only)");
+  c.n_levels = json_u32(enc, "n_levels", 16);
+  c.n_features = json_u32(enc, "n_features_per_level", 2);
+  c.log2_hashmap_size = json_u32(enc, "log2_hashmap_size", 19);
+  c.base_resolution = json_u32(enc, "base_resolution", 16);
+  c.per_level_scale = json_f32(enc, "per_level_scale", 2.0f);
+  const std::string it = json_str(enc, "interpolation", "Linear");
+  if (it == "Linear") c.interpolation = 0;
+  else if (it == "Smoothstep") c.interpolation = 1;
+  else throw std::runtime_error("unsupported interpolation: " + it);
+  if (c.n_features != 1 && c.n_features != 2 && c.n_features != 4 && c.n_features != 8)
+    throw std::runtime_error("n_features_per_level must be 1, 2, 4 or 8");  // method_raymarching.cu:1241-1244
+  if (c.log2_hashmap_size > 28) throw std::runtime_error("log2_hashmap_size too large");
+
+  const std::string nt = json_str(net, "otype", "FullyFusedMLP");
+  if (nt != "FullyFusedMLP") throw std::runtime_error("unsupported network otype: " + nt + " (FullyFusedMLP only)");
+  c.n_neurons = json_u32(net, "n_neurons", 128);
+  c.n_hidden_layers = json_u32(net, "n_hidden_layers", 5);
+  if (c.n_neurons != (uint32_t)kWidth) throw std::runtime_error("FullyFusedMLP n_neurons must be 64 in this build");
+  if (c.n_hidden_layers < 1) throw std::runtime_error("n_hidden_layers must be >= 1");
+  const std::string act = json_str(net, "activation", "ReLU");
+  if (act == "ReLU") c.activation = 1;
+  else if (act == "None") c.activation = 0;
+  else throw std::runtime_error("unsupported activation: " + act);
+  if (json_str(net, "output_activation", "None") != "None") throw std::runtime_error("unsupported output_activation (None only)");
+
+  cfg_ = c;
+  model_ = Json::object();
+  model_["loss"] = loss;
+  model_["encoding"] = enc;
+  model_["network"] = net;
+  build_layout();
+  steps_ = 0;
+  initialize_params(init_seed, Runtime::get().stream);
+}
+
+void Network::build_layout()
+{
+  const uint32_t total_entries = grid_make_layout(cfg_, &grid_);
+  in_width_ = next_multiple(cfg_.n_levels * cfg_.n_features, 16u);
+  if (in_width_ > 128) throw std::runtime_error("encoded width > 128 is not supported");
+  n_mlp_ = (size_t)kWidth * in_width_ + (size_t)n_hidden_matmuls() * kWidth * kWidth + (size_t)16 * kWidth;
+  n_params_ = n_mlp_ + (size_t)total_entries * cfg_.n_features;
+  if ((n_params_ - n_mlp_) * sizeof(uint16_t) >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
+  lds_halves_ = (in_width_ / 16) * 1024 + n_hidden_matmuls() * 4096 + 64;
+  params_f16_.resize(n_params_);
+  mlp_packed_.resize(lds_halves_);
+  // training state is allocated lazily on the first training step
+  params_f32_.release(); grads_.release(); adam_m_.release(); adam_v_.release();
+  ws_batch_ = 0;
+}
+
+void Network::initialize_params(uint64_t seed, hipStream_t s)
+{
+  params_f32_.resize(n_params_);
+  launch_init_params(params_f32_.ptr, params_f16_.ptr, n_mlp_, n_params_, in_width_, n_hidden_matmuls(), seed, s);
+  refresh_inference_weights(s);
+}
+
+void Network::refresh_inference_weights(hipStream_t s)
+{
+  launch_pack_mlp(params_f16_.ptr, mlp_packed_.ptr, in_width_, n_hidden_matmuls(), s);
+}
+
+void Network::set_params_f16(const uint16_t* host, size_t count, hipStream_t s)
+{
+  if (count != n_params_) throw std::runtime_error("parameter count mismatch: got " + std::to_string(count) + ", model has " + std::to_string(n_params_));
+  VNR_HIP_CHECK(hipMemcpyAsync(params_f16_.ptr, host, count * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+  if (params_f32_.count == n_params_) launch_f16_to_f32(params_f16_.ptr, params_f32_.ptr, n_params_, s);
+  refresh_inference_weights(s);
+  VNR_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void Network::get_params_f16(uint16_t* host, size_t count, hipStream_t s) const
+{
+  if (count != n_params_) throw std::runtime_error("parameter count mismatch");
+  VNR_HIP_CHECK(hipMemcpyAsync(host, params_f16_.ptr, count * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+  VNR_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// EXTERNAL tcnn Trainer::serialize(): {"n_params", "params_type": "__half", "params_binary"} (key names
+// confirmed by apps/view_model.cpp:124-126); no optimizer state with the reference's default arguments.
+Json Network::serialize_params(hipStream_t s) const
+{
+  std::vector<uint16_t> host(n_params_);
+  get_params_f16(host.data(), n_params_, s);
+  Json j = Json::object();
+  j["n_params"] = (uint64_t)n_params_;
+  j["params_type"] = "__half";
+  j["params_binary"] = Json::binary(host.data(), host.size() * sizeof(uint16_t));
+  return j;
+}
+
+void Network::deserialize_params(const Json& j, hipStream_t s)
+{
+  const size_t n = (size_t)j.at("n_params").as_int();
+  if (n != n_params_) throw std::runtime_error("Can't set params because buffer has the wrong size: " + std::to_string(n) + " vs " + std::to_string(n_params_));
+  const std::string type = j.at("params_type").as_string();
+  const std::string& bin = j.at("params_binary").as_binary();
+  std::vector<uint16_t> host(n);
+  if (type == "__half") {
+    if (bin.size() != n * 2) throw std::runtime_error("params_binary has the wrong size");
+    std::memcpy(host.data(), bin.data(), n * 2);
+  } else if (type == "float") {
+    if (bin.size() != n * 4) throw std::runtime_error("params_binary has the wrong size");
+    const float* f = (const float*)bin.data();
+    for (size_t i = 0; i < n; ++i) host[i] = f32_to_f16(f[i]);
+  } else {
+    throw std::runtime_error("Unknown params_type: " + type);
+  }
+  set_params_f16(host.data(), n, s);
+  if (j.contains("optimizer") || j.contains("step")) { /* optimizer state is not stored by the reference */ }
+}
+
+void Network::inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s) const
+{
+  launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, params_f16_.ptr + n_mlp_, mlp_packed_.ptr,
+               lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s);
+}
+
+void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const
+{
+  launch_fused(1, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, params_f16_.ptr + n_mlp_, mlp_packed_.ptr,
+               lds_halves_, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s);
+}
+
+size_t Network::bytes_allocated() const
+{
+  return params_f16_.bytes() + mlp_packed_.bytes() + params_f32_.bytes() + grads_.bytes() + adam_m_.bytes() +
+         adam_v_.bytes() + ws_features_.bytes() + ws_acts_.bytes() + ws_dfeat_.bytes() + ws_loss_.bytes();
+}
+
+}  // namespace vnr

@@ -1,0 +1,357 @@
+// network_infer.hip — fused hash-grid encode + MLP inference for gfx950 (the dominant kernel of the hot path).
+//
+// Replaces tcnn `NetworkWithInputEncoding::inference` as called from core/network.cu:1043-1052
+// (NeuralVolume::inference -> tcnn_network.h:254-271 -> tcnn_impl.cu:438-448); semantic spec:
+// core/networks/tcnn_impl_decoder.cu:7-175 (encode), tcnn_threadblock.h:59-144,221-328,446-505 (MLP),
+// tcnn_impl.cu:104-286 (the reference's own fused encode+MLP kernel).
+//
+// MI355X design (not the reference's 32-lane WMMA / shared-memory activation tiling):
+//  * one wave64 owns 64 samples end to end; nothing but the weights ever touches LDS.
+//  * encode: lane = sample, level is wave-uniform, so every gather instruction reads 64 spatially coherent
+//    samples of ONE level (scalar level constants, best L1/L2 locality); features stay in VGPRs as fp16.
+//  * MLP on v_mfma_f32_32x32x16_f16 computed TRANSPOSED: Y^T[64 x samples] = W[64 x K] . X^T[K x samples].
+//    Weights are the A operand (read from an LDS image, conflict-free ds_read_b128), activations the B operand.
+//    The 32x32 accumulator of one layer (column = sample on the lane, rows = neurons in registers) is, after
+//    ReLU + fp16 pack, directly the B operand of the next layer (k-order permutation folded into the packed
+//    weight image), so activations never leave registers.  v_permlane32_swap builds the first layer's B
+//    operand from the per-lane feature vectors.
+//  * persistent blocks, XCD-contiguous tile ranges, sample count optionally read from device memory so the
+//    ray marcher never syncs with the host.
+#include "grid_device.h"
+
+namespace vnr {
+
+// ------------------------------------------------------------------------------------------------
+// packed (LDS image) weight layout, in halves:
+//   layer 1      : [s < K_IN/16][h < 2][row < 64][j < 8]  = W1[row][16 s + 8 h + j]
+//   hidden l     : [s < 4][h < 2][row < 64][j < 8]        = Wh[row][16 s + 8 (j>>2) + 4 h + (j&3)]
+//   last (row 0) : [s < 4][h < 2][j < 8]                  = Wl[0][16 s + 8 (j>>2) + 4 h + (j&3)]
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t packed_mlp_halves(uint32_t in_width, uint32_t n_hidden_matmuls)
+{
+  return (in_width / 16) * 1024 + n_hidden_matmuls * 4096 + 64;
+}
+
+__global__ void pack_mlp_kernel(const half_t* __restrict__ params, half_t* __restrict__ packed, uint32_t in_width,
+                                uint32_t n_hidden_matmuls)
+{
+  const uint32_t total = packed_mlp_halves(in_width, n_hidden_matmuls);
+  const uint32_t l1 = (in_width / 16) * 1024;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    half_t v;
+    if (e < l1) {
+      const uint32_t j = e & 7, row = (e >> 3) & 63, h = (e >> 9) & 1, s = e >> 10;
+      v = params[row * in_width + 16 * s + 8 * h + j];
+    } else if (e < l1 + n_hidden_matmuls * 4096) {
+      const uint32_t r = e - l1;
+      const uint32_t layer = r >> 12, q = r & 4095;
+      const uint32_t j = q & 7, row = (q >> 3) & 63, h = (q >> 9) & 1, s = q >> 10;
+      const uint32_t k = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+      v = params[kWidth * in_width + layer * 4096 + row * 64 + k];
+    } else {
+      const uint32_t q = e - l1 - n_hidden_matmuls * 4096;
+      const uint32_t j = q & 7, h = (q >> 3) & 1, s = q >> 4;
+      const uint32_t k = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+      v = params[kWidth * in_width + n_hidden_matmuls * 4096 + k];  // row 0 of the 16 x 64 last layer
+    }
+    packed[e] = v;
+  }
+}
+
+void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width, uint32_t n_hidden_matmuls, hipStream_t s)
+{
+  const uint32_t total = packed_mlp_halves(in_width, n_hidden_matmuls);
+  pack_mlp_kernel<<<div_round_up(total, 256), 256, 0, s>>>((const half_t*)params, (half_t*)packed, in_width, n_hidden_matmuls);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct InferArgs {
+  GridDevice grid;
+  const half_t* table;       // grid part of the parameter blob
+  const half_t* packed_mlp;  // LDS image
+  const float* coords;       // [n][3]
+  float* out;                // [n]
+  half_t* features_out;      // encode-only / training: [n][K_IN] row-major (may be null)
+  half_t* acts_out;          // training: [(nh+1)][n][64] post-activation hidden outputs (may be null)
+  const uint32_t* n_ptr;     // if non-null the sample count is read from here
+  uint32_t n;
+  uint32_t n_hidden_matmuls;
+  uint32_t activation;       // 0 none, 1 relu
+  uint32_t lds_halves;
+};
+
+struct float3_packed { float x, y, z; };
+
+__device__ __forceinline__ half8_t pack_act(const f32x16& acc, int sh, bool relu)
+{
+  float8_t v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = acc[8 * sh + j];
+  half8_t r = __builtin_convertvector(v, half8_t);
+  if (relu) {
+    const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    r = __builtin_elementwise_max(r, zero);
+  }
+  return r;
+}
+
+// swaps the upper 32 lanes of a with the lower 32 lanes of b:  a' = [a.lo | b.lo],  b' = [a.hi | b.hi]
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b)
+{
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+
+__device__ __forceinline__ void swap_halves8(half8_t& p, half8_t& q)
+{
+  uint4_t a = __builtin_bit_cast(uint4_t, p), b = __builtin_bit_cast(uint4_t, q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t x = a[i], y = b[i];
+    swap_halves(x, y);
+    a[i] = x;
+    b[i] = y;
+  }
+  p = __builtin_bit_cast(half8_t, a);
+  q = __builtin_bit_cast(half8_t, b);
+}
+
+// MODE 0: inference (out only), 1: encode only (features_out), 2: training forward (features + acts + out)
+template <int F, int K_IN, int MODE>
+__global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
+{
+  constexpr int L_PAD = K_IN / F;   // levels incl. zero padding
+  constexpr int S1 = K_IN / 16;     // k-steps of the first layer
+  constexpr int NCHUNK = K_IN / 8;  // half8 chunks of the feature vector
+  extern __shared__ __attribute__((aligned(16))) half_t lds[];
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+
+  if (MODE != 1) {  // stage the packed weights once per (persistent) block
+    const uint4_t* src = (const uint4_t*)args.packed_mlp;
+    uint4_t* dst = (uint4_t*)lds;
+    for (uint32_t i = threadIdx.x; i < args.lds_halves / 8; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
+
+  const uint32_t n = args.n_ptr ? *args.n_ptr : args.n;
+  const uint32_t n_tiles = (n + 63u) >> 6;
+  // XCD-contiguous tile ranges: blocks with equal (blockIdx % 8) share an XCD / L2 (speed only)
+  const uint32_t xcd = blockIdx.x & 7u;
+  const uint32_t per_xcd = (n_tiles + 7u) >> 3;
+  const uint32_t waves_per_xcd = (gridDim.x >> 3) * 4u;
+  const uint32_t tile_end = min(n_tiles, (xcd + 1u) * per_xcd);
+  const uint32_t nh = args.n_hidden_matmuls;
+  const bool relu = args.activation == 1;
+  const uint32_t h = lane >> 5;   // lane half
+  const uint32_t r = lane & 31u;  // row (A operand) / column (B, D operands)
+
+  for (uint32_t tile = xcd * per_xcd + (blockIdx.x >> 3) * 4u + wave; tile < tile_end; tile += waves_per_xcd) {
+    const uint32_t i = tile * 64u + lane;
+    const uint32_t ic = min(i, n - 1u);
+    const float3_packed p = ((const float3_packed*)args.coords)[ic];
+
+    // ---- encode: lane = sample, level wave-uniform ------------------------------------------------
+    half8_t feat[NCHUNK];
+#pragma unroll
+    for (int l = 0; l < L_PAD; ++l) {
+      half_t o[F];
+      if (l < (int)args.grid.n_levels) {
+        encode_level<F>(args.grid.levels[l], args.grid.interpolation, args.table, p.x, p.y, p.z, o);
+      } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f) feat[(l * F + f) / 8][(l * F + f) % 8] = o[f];
+    }
+
+    if (MODE != 0 && args.features_out && i < n) {
+      half8_t* dst = (half8_t*)(args.features_out + (size_t)i * K_IN);
+#pragma unroll
+      for (int c = 0; c < NCHUNK; ++c) dst[c] = feat[c];
+    }
+    if (MODE == 1) continue;
+
+    // ---- first layer: B operand = X^T via permlane32 swaps --------------------------------------
+    // before: lane (sample) holds chunks 2s (P) and 2s+1 (Q) of its own sample.
+    // after : P = B fragment of column tile 0, Q = B fragment of column tile 1 (k = 16 s + 8 h + j).
+#pragma unroll
+    for (int s = 0; s < S1; ++s) swap_halves8(feat[2 * s], feat[2 * s + 1]);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
+
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const half8_t a = *(const half8_t*)(lds + ((s * 2 + h) * 64 + m * 32 + r) * 8);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, feat[2 * s + nt], acc[m][nt], 0, 0, 0);
+      }
+    }
+
+    // activations as next-layer B fragments: bf[k-step][column tile]
+    half8_t bf[4][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bf[2 * m + sh][nt] = pack_act(acc[m][nt], sh, relu);
+
+    if (MODE == 2 && args.acts_out) {
+      // element j of bf[s][nt] on lane (r, h) is neuron 16 s + 8 (j>>2) + 4 h + (j&3) of sample tile*64 + 32 nt + r
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const uint32_t smp = tile * 64u + 32u * nt + r;
+        if (smp < n) {
+          half_t* row = args.acts_out + (size_t)smp * 64;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const half4_t lo = {bf[s][nt][0], bf[s][nt][1], bf[s][nt][2], bf[s][nt][3]};
+            const half4_t hi = {bf[s][nt][4], bf[s][nt][5], bf[s][nt][6], bf[s][nt][7]};
+            *(half4_t*)(row + 16 * s + 4 * h) = lo;
+            *(half4_t*)(row + 16 * s + 8 + 4 * h) = hi;
+          }
+        }
+      }
+    }
+
+    // ---- hidden layers ----------------------------------------------------------------------------
+    for (uint32_t layer = 0; layer < nh; ++layer) {
+      const half_t* w = lds + S1 * 1024 + layer * 4096;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * 64 + m * 32 + r) * 8);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s][nt], acc[m][nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) bf[2 * m + sh][nt] = pack_act(acc[m][nt], sh, relu);
+
+      if (MODE == 2 && args.acts_out) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const uint32_t smp = tile * 64u + 32u * nt + r;
+          if (smp < n) {
+            half_t* row = args.acts_out + ((size_t)(layer + 1) * n + smp) * 64;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const half4_t lo = {bf[s][nt][0], bf[s][nt][1], bf[s][nt][2], bf[s][nt][3]};
+              const half4_t hi = {bf[s][nt][4], bf[s][nt][5], bf[s][nt][6], bf[s][nt][7]};
+              *(half4_t*)(row + 16 * s + 4 * h) = lo;
+              *(half4_t*)(row + 16 * s + 8 + 4 * h) = hi;
+            }
+          }
+        }
+      }
+    }
+
+    // ---- last layer: output neuron 0 only (the other 15 padded rows are never read) --------------
+    const half_t* wl = lds + S1 * 1024 + nh * 4096;
+    float part[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const half8_t wv = *(const half8_t*)(wl + (s * 2 + h) * 8);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const half2_t a2 = {bf[s][nt][2 * q], bf[s][nt][2 * q + 1]};
+          const half2_t w2 = {wv[2 * q], wv[2 * q + 1]};
+          part[nt] = __builtin_amdgcn_fdot2(a2, w2, part[nt], false);
+        }
+      }
+    }
+    // combine the two lane halves: lanes < 32 get column tile 0, lanes >= 32 column tile 1
+    uint32_t p0 = __builtin_bit_cast(uint32_t, part[0]), p1 = __builtin_bit_cast(uint32_t, part[1]);
+    swap_halves(p0, p1);
+    const float y = __builtin_bit_cast(float, p0) + __builtin_bit_cast(float, p1);
+    // network output is produced in half precision and then cast to float (tcnn_impl.cu:421-431)
+    if (i < n) args.out[i] = (float)(half_t)y;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int F, int K_IN, int MODE>
+static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
+{
+  const Runtime& rt = Runtime::get();
+  const uint32_t n_tiles = div_round_up(n_max, 64);
+  uint32_t blocks = div_round_up(n_tiles, 4);
+  const uint32_t max_blocks = (uint32_t)rt.n_cus * 4u;  // persistent: <= 4 blocks of 4 waves per CU
+  if (blocks > max_blocks) blocks = max_blocks;
+  blocks = next_multiple(blocks, 8);
+  const size_t shmem = MODE == 1 ? 16 : (size_t)a.lds_halves * sizeof(uint16_t);
+  auto kernel = fused_infer_kernel<F, K_IN, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  kernel<<<blocks, 256, shmem, s>>>(a);
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+template <int MODE>
+static void dispatch(uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max, hipStream_t s)
+{
+#define VNR_CASE(f, k) if (F == f && K_IN == k) return launch_one<f, k, MODE>(a, n_max, s)
+  VNR_CASE(1, 16); VNR_CASE(1, 32);
+  VNR_CASE(2, 16); VNR_CASE(2, 32); VNR_CASE(2, 48); VNR_CASE(2, 64);
+  VNR_CASE(4, 16); VNR_CASE(4, 32); VNR_CASE(4, 48); VNR_CASE(4, 64);
+  VNR_CASE(8, 16); VNR_CASE(8, 32); VNR_CASE(8, 48); VNR_CASE(8, 64); VNR_CASE(8, 96); VNR_CASE(8, 128);
+#undef VNR_CASE
+  throw std::runtime_error("unsupported encoding shape: n_features_per_level=" + std::to_string(F) +
+                           " padded width=" + std::to_string(K_IN));
+}
+
+void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
+                  const uint16_t* table, const uint16_t* packed, uint32_t lds_halves, const float* coords, float* out,
+                  uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s)
+{
+  if (n_max == 0) return;
+  if (n_max > 0xffffffc0ull) throw std::runtime_error("inference batch too large (max 2^32-64 samples per call)");
+  InferArgs a;
+  a.grid = grid;
+  a.table = (const half_t*)table;
+  a.packed_mlp = (const half_t*)packed;
+  a.coords = coords;
+  a.out = out;
+  a.features_out = (half_t*)features_out;
+  a.acts_out = (half_t*)acts_out;
+  a.n_ptr = d_n;
+  a.n = (uint32_t)n;
+  a.n_hidden_matmuls = n_hidden_matmuls;
+  a.activation = activation;
+  a.lds_halves = lds_halves;
+  if (mode == 0) dispatch<0>(grid.n_features, in_width, a, n_max, s);
+  else if (mode == 1) dispatch<1>(grid.n_features, in_width, a, n_max, s);
+  else dispatch<2>(grid.n_features, in_width, a, n_max, s);
+}
+
+}  // namespace vnr

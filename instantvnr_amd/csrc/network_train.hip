@@ -1,0 +1,572 @@
+// network_train.hip — training step of the hash-grid + MLP network on gfx950.
+//
+// Replaces tcnn `Trainer::training_step` as called from core/networks/tcnn_network.h:223-252 (the source is
+// in the un-vendored tiny-cuda-nn submodule: EXTERNAL).  Restated from the published upstream design:
+//   forward (keeps fp16 features + hidden activations) -> L1/L2 loss with loss scale 128 -> MLP backward ->
+//   weight gradients -> hash-grid backward (scatter-add) -> Adam (fp32 master weights, per-parameter step
+//   count, zero-gradient grid entries skipped, l2_reg on matrix weights only) under ExponentialDecay.
+// Differences chosen for MI355X (documented in DESIGN.md): gradients are accumulated in ONE fp32 buffer
+// (tcnn: fp16 with half2 atomics) so a data-parallel run all-reduces a single tensor; the MLP backward
+// runs on MFMA with the same transposed register-resident scheme as the forward.
+#include "grid_device.h"
+
+namespace vnr {
+
+void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
+                  const uint16_t* table, const uint16_t* packed, uint32_t lds_halves, const float* coords, float* out,
+                  uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ pcg32
+struct Pcg32 {
+  uint64_t state, inc;
+  __host__ __device__ Pcg32(uint64_t initstate, uint64_t initseq = 0xda3e39cb94b95bdbULL)
+  {
+    state = 0u;
+    inc = (initseq << 1u) | 1u;
+    next_uint();
+    state += initstate;
+    next_uint();
+  }
+  __host__ __device__ uint32_t next_uint()
+  {
+    const uint64_t old = state;
+    state = old * 0x5851f42d4c957f2dULL + inc;
+    const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    const uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+  }
+  __host__ __device__ float next_float()
+  {
+    const uint32_t u = (next_uint() >> 9) | 0x3f800000u;
+    return __builtin_bit_cast(float, u) - 1.0f;
+  }
+  __host__ __device__ void advance(uint64_t delta)
+  {
+    uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+    while (delta > 0) {
+      if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+      cur_plus = (cur_mult + 1) * cur_plus;
+      cur_mult *= cur_mult;
+      delta >>= 1;
+    }
+    state = acc_mult * state + acc_plus;
+  }
+};
+
+// EXTERNAL tcnn init: MLP Xavier-uniform per weight matrix, grid uniform(-1e-4, 1e-4)
+__global__ void init_params_kernel(float* __restrict__ master, half_t* __restrict__ params, size_t n_mlp, size_t n_total,
+                                   uint32_t in_width, uint32_t n_hidden_matmuls, uint64_t seed)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e0 = t * 4;
+  if (e0 >= n_total) return;
+  Pcg32 rng(seed);
+  rng.advance(e0);
+  const size_t first = (size_t)kWidth * in_width, hidden_end = first + (size_t)n_hidden_matmuls * kWidth * kWidth;
+  for (size_t e = e0; e < e0 + 4 && e < n_total; ++e) {
+    const float u = rng.next_float();
+    float scale;
+    if (e < first) scale = sqrtf(6.0f / (float)(in_width + kWidth));
+    else if (e < hidden_end) scale = sqrtf(6.0f / (float)(kWidth + kWidth));
+    else if (e < n_mlp) scale = sqrtf(6.0f / (float)(kWidth + 16));
+    else scale = 1e-4f;
+    const float v = u * (2.0f * scale) - scale;
+    master[e] = v;
+    params[e] = (half_t)v;
+  }
+}
+
+void launch_init_params(float* master, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
+                        uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s)
+{
+  const size_t threads = (n_total + 3) / 4;
+  init_params_kernel<<<div_round_up(threads, 256), 256, 0, s>>>(master, (half_t*)params, n_mlp, n_total, in_width,
+                                                                n_hidden_matmuls, seed);
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+__global__ void f16_to_f32_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (half_t)in[i];
+}
+void launch_f16_to_f32(const uint16_t* in, float* out, size_t n, hipStream_t s)
+{
+  f16_to_f32_kernel<<<min(div_round_up(n, 256), 4096u), 256, 0, s>>>((const half_t*)in, out, n);
+}
+void launch_f32_to_f16(const float* in, uint16_t* out, size_t n, hipStream_t s)
+{
+  f32_to_f16_kernel<<<min(div_round_up(n, 256), 4096u), 256, 0, s>>>(in, (half_t*)out, n);
+}
+
+// ------------------------------------------------------------------------------------------------ loss
+// EXTERNAL tcnn L1Loss / L2Loss: values = |d|/N (d^2/N), gradient = loss_scale * sign(d)/N (2 d/N), stored fp16.
+__global__ void loss_grad_kernel(const float* __restrict__ y, const float* __restrict__ target, uint32_t n, uint32_t loss_type,
+                                 half_t* __restrict__ dy, float* __restrict__ loss_partials)
+{
+  __shared__ float red[256];
+  float acc = 0.0f;
+  const float inv_n = 1.0f / (float)n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float d = y[i] - target[i];
+    float g;
+    if (loss_type == 0) { acc += fabsf(d) * inv_n; g = copysignf(1.0f, d); }
+    else { acc += d * d * inv_n; g = 2.0f * d; }
+    dy[i] = (half_t)((float)kLossScale * g * inv_n);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = red[0];
+}
+
+// ------------------------------------------------------------------------------------------------ backward weights image
+// LDS image for the MLP backward (halves):
+//   last row  : [s<4][h][j]                      = Wl[0][kk]                       (64)
+//   hidden l  : [s<4][h][row<64][j]              = Wh_l[kk][row]   (transposed)     (4096 each)
+//   first     : [s<4][h][row<RP][j], RP = roundup(in_width,32) = W1[kk][row] or 0   (64*RP)
+// with kk = 16 s + 8 (j>>2) + 4 h + (j&3)  (the k-order of an accumulator tile reused as B operand).
+__host__ __device__ inline uint32_t packedT_halves(uint32_t in_width, uint32_t nh) { return 64 + nh * 4096 + 64 * (((in_width + 31) / 32) * 32); }
+
+__global__ void pack_mlp_T_kernel(const half_t* __restrict__ params, half_t* __restrict__ packed, uint32_t in_width, uint32_t nh)
+{
+  const uint32_t rp = ((in_width + 31) / 32) * 32;
+  const uint32_t total = packedT_halves(in_width, nh);
+  const uint32_t first_sz = kWidth * in_width;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    half_t v;
+    if (e < 64) {
+      const uint32_t j = e & 7, h = (e >> 3) & 1, s = e >> 4;
+      v = params[first_sz + nh * 4096 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+    } else if (e < 64 + nh * 4096) {
+      const uint32_t q = (e - 64) & 4095, layer = (e - 64) >> 12;
+      const uint32_t j = q & 7, row = (q >> 3) & 63, h = (q >> 9) & 1, s = q >> 10;
+      const uint32_t kk = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+      v = params[first_sz + layer * 4096 + kk * 64 + row];
+    } else {
+      const uint32_t q = e - 64 - nh * 4096;
+      const uint32_t j = q & 7, row = (q >> 3) % rp, hs = (q >> 3) / rp, h = hs & 1, s = hs >> 1;
+      const uint32_t kk = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+      v = row < in_width ? params[kk * in_width + row] : (half_t)0.0f;
+    }
+    packed[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ MLP backward (MFMA)
+struct BackwardArgs {
+  const half_t* packedT;
+  const half_t* dy;      // [n] loss-scaled dL/dy
+  const half_t* acts;    // [(nh+1)][n][64]
+  half_t* d_out;         // [(nh+1)][n][64]  dL/d(pre-activation) of every hidden layer output
+  half_t* dfeat;         // [n][in_width]
+  uint32_t n, nh, activation, in_width, lds_halves;
+};
+
+__device__ __forceinline__ half8_t load_frag_rowmajor(const half_t* row, int s, uint32_t h)
+{
+  const half4_t lo = *(const half4_t*)(row + 16 * s + 4 * h);
+  const half4_t hi = *(const half4_t*)(row + 16 * s + 8 + 4 * h);
+  return half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ void store_frag_rowmajor(half_t* row, int s, uint32_t h, const half8_t& v)
+{
+  *(half4_t*)(row + 16 * s + 4 * h) = half4_t{v[0], v[1], v[2], v[3]};
+  *(half4_t*)(row + 16 * s + 8 + 4 * h) = half4_t{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ half8_t pack_plain(const f32x16& acc, int sh)
+{
+  float8_t v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = acc[8 * sh + j];
+  return __builtin_convertvector(v, half8_t);
+}
+__device__ __forceinline__ half8_t mask_relu(const half8_t& d, const half8_t& a)
+{
+  half8_t r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = a[j] > (half_t)0.0f ? d[j] : (half_t)0.0f;
+  return r;
+}
+
+template <int MT>  // MT = number of 32-row tiles of the feature gradient (roundup(in_width, 32) / 32)
+__global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs args)
+{
+  extern __shared__ __attribute__((aligned(16))) half_t lds[];
+  {
+    const uint4_t* src = (const uint4_t*)args.packedT;
+    uint4_t* dst = (uint4_t*)lds;
+    for (uint32_t i = threadIdx.x; i < args.lds_halves / 8; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t h = lane >> 5, r = lane & 31u;
+  const uint32_t n = args.n, nh = args.nh;
+  const bool relu = args.activation == 1;
+  const uint32_t n_tiles = (n + 63u) >> 6;
+  constexpr int RP = MT * 32;
+
+  for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+    half8_t bf[4][2];
+    uint32_t smp[2];
+    bool ok[2];
+    // ---- through the last layer: d_nh[k] = Wl[0][k] * dy, masked by relu'(a_nh) -------------------
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      smp[nt] = tile * 64u + 32u * nt + r;
+      ok[nt] = smp[nt] < n;
+      const uint32_t sc = ok[nt] ? smp[nt] : n - 1u;
+      const float g = (float)args.dy[sc];
+      const half_t* arow = args.acts + ((size_t)nh * n + sc) * 64;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8_t wv = *(const half8_t*)(lds + (s * 2 + h) * 8);
+        half8_t d;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = (half_t)((float)wv[j] * g);
+        if (relu) d = mask_relu(d, load_frag_rowmajor(arow, s, h));
+        bf[s][nt] = d;
+        if (ok[nt]) store_frag_rowmajor(args.d_out + ((size_t)nh * n + smp[nt]) * 64, s, h, d);
+      }
+    }
+    // ---- hidden layers, last to first: d_l^T = Wh_l^T . d_{l+1}^T, masked ----------------------------
+    for (int layer = (int)nh - 1; layer >= 0; --layer) {
+      const half_t* w = lds + 64 + layer * 4096;
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * 64 + m * 32 + r) * 8);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s][nt], acc[m][nt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const uint32_t sc = ok[nt] ? smp[nt] : n - 1u;
+        const half_t* arow = args.acts + ((size_t)layer * n + sc) * 64;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int sh = 0; sh < 2; ++sh) {
+            half8_t d = pack_plain(acc[m][nt], sh);
+            if (relu) d = mask_relu(d, load_frag_rowmajor(arow, 2 * m + sh, h));
+            bf[2 * m + sh][nt] = d;
+            if (ok[nt]) store_frag_rowmajor(args.d_out + ((size_t)layer * n + smp[nt]) * 64, 2 * m + sh, h, d);
+          }
+      }
+    }
+    // ---- feature gradient: dfeat^T = W1^T . d_0^T -------------------------------------------------
+    {
+      const half_t* w = lds + 64 + nh * 4096;
+      f32x16 acc[MT][2];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * RP + m * 32 + r) * 8);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s][nt], acc[m][nt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (!ok[nt]) continue;
+        half_t* row = args.dfeat + (size_t)smp[nt] * args.in_width;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int sh = 0; sh < 2; ++sh) {
+            const half8_t d = pack_plain(acc[m][nt], sh);
+            const uint32_t f0 = 32 * m + 16 * sh;  // features f0 + 4h + {0..3} and f0 + 8 + 4h + {0..3}
+            if (f0 < args.in_width) {
+              *(half4_t*)(row + f0 + 4 * h) = half4_t{d[0], d[1], d[2], d[3]};
+              *(half4_t*)(row + f0 + 8 + 4 * h) = half4_t{d[4], d[5], d[6], d[7]};
+            }
+          }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients (VALU, fp32 accumulate)
+// dW[out][in] = sum_b d[b][out] * x[b][in].  blockIdx.y selects the matrix: 0 = first layer (x = features),
+// 1..nh = hidden (x = acts[l-1]), nh+1 = last layer row 0 (d = dy, x = acts[nh]).
+struct WGradArgs {
+  const half_t* features;  // [n][in_width]
+  const half_t* acts;      // [(nh+1)][n][64]
+  const half_t* d_all;     // [(nh+1)][n][64]
+  const half_t* dy;        // [n]
+  float* grads;            // tcnn-order fp32 gradient blob
+  uint32_t n, nh, in_width;
+};
+
+constexpr int kWgChunk = 128;
+
+template <int IN_T>  // compile-time padded input width of the matrices handled by this launch (16, 32, 64, 128)
+__global__ void __launch_bounds__(256) weight_grad_kernel(const WGradArgs args, uint32_t layer_lo)
+{
+  constexpr int IG = IN_T / 4;       // threads along the input dimension (4 inputs each)
+  constexpr int OG = 256 / IG;       // thread groups along the output dimension
+  constexpr int R = 64 / OG;         // output rows per thread
+  __shared__ __attribute__((aligned(16))) half_t sd[kWgChunk * 64];
+  __shared__ __attribute__((aligned(16))) half_t sx[kWgChunk * IN_T];
+  const uint32_t layer = layer_lo + blockIdx.y;
+  const uint32_t n = args.n, nh = args.nh;
+  const uint32_t b0 = blockIdx.x * kWgChunk;
+  const uint32_t nb = min((uint32_t)kWgChunk, n - b0);
+
+  if (layer == nh + 1) {
+    // last layer: dWl[0][k] = sum_b dy[b] * a_nh[b][k]
+    const uint32_t k = threadIdx.x & 63u, sub = threadIdx.x >> 6;
+    float acc = 0.0f;
+    for (uint32_t b = sub; b < nb; b += 4) acc += (float)args.dy[b0 + b] * (float)args.acts[((size_t)nh * n + b0 + b) * 64 + k];
+    atomicAdd(&args.grads[(size_t)kWidth * args.in_width + (size_t)nh * 4096 + k], acc);
+    return;
+  }
+  const uint32_t in_w = layer == 0 ? args.in_width : 64u;
+  const half_t* dsrc = args.d_all + ((size_t)layer * n + b0) * 64;
+  const half_t* xsrc = layer == 0 ? args.features + (size_t)b0 * args.in_width : args.acts + ((size_t)(layer - 1) * n + b0) * 64;
+  // stage the chunk (row-major, zero padded to IN_T columns)
+  for (uint32_t e = threadIdx.x; e < nb * 8; e += 256) ((uint4_t*)sd)[e] = ((const uint4_t*)dsrc)[e];
+  for (uint32_t e = threadIdx.x; e < nb * (IN_T / 8); e += 256) {
+    const uint32_t b = e / (IN_T / 8), c = e % (IN_T / 8);
+    uint4_t v = {0, 0, 0, 0};
+    if (c * 8 < in_w) v = *(const uint4_t*)(xsrc + (size_t)b * in_w + c * 8);
+    ((uint4_t*)sx)[e] = v;
+  }
+  __syncthreads();
+  const uint32_t ig = threadIdx.x % IG, og = threadIdx.x / IG;
+  float acc[R][4];
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[rr][c] = 0.0f;
+  for (uint32_t b = 0; b < nb; ++b) {
+    const half4_t xv = *(const half4_t*)(sx + b * IN_T + ig * 4);
+    half_t dv[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) dv[rr] = sd[b * 64 + og * R + rr];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[rr][c] = __builtin_fmaf((float)dv[rr], (float)xv[c], acc[rr][c]);
+  }
+  float* g = args.grads + (layer == 0 ? 0 : (size_t)kWidth * args.in_width + (size_t)(layer - 1) * 4096);
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t col = ig * 4 + c;
+      if (col < in_w) atomicAdd(&g[(size_t)(og * R + rr) * in_w + col], acc[rr][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ grid backward
+// EXTERNAL tcnn kernel_grid_backward: for every (sample, level): grad[idx*F+f] += w * dL/dfeature[f].
+template <int F>
+__global__ void grid_backward_kernel(const GridDevice grid, const float* __restrict__ coords, const half_t* __restrict__ dfeat,
+                                     uint32_t n, uint32_t in_width, float* __restrict__ grid_grads)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t level = blockIdx.y;
+  const LevelInfo lv = grid.levels[level];
+  float g[F];
+  bool any = false;
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    g[f] = (float)dfeat[(size_t)i * in_width + level * F + f];
+    any |= g[f] != 0.0f;
+  }
+  if (!any) return;
+  const CornerSetup c = level_setup(lv, grid.interpolation, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
+  float* base = grid_grads + (size_t)lv.offset * F;
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    const uint32_t idx = level_index(lv, c.g[0] + (corner & 1), c.g[1] + ((corner >> 1) & 1), c.g[2] + ((corner >> 2) & 1));
+    const float w = corner_weight(c, corner);
+#pragma unroll
+    for (int f = 0; f < F; ++f) atomicAdd(&base[(size_t)idx * F + f], w * g[f]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+// EXTERNAL tcnn adam_step (optimizers/adam.h): see header comment.  Also clears the gradient for the next step.
+__global__ void adam_kernel(size_t n_total, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float epsilon,
+                            float l2_reg, float* __restrict__ master, half_t* __restrict__ params, float* __restrict__ grads,
+                            float* __restrict__ m1, float* __restrict__ m2, uint32_t* __restrict__ steps)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  float gradient = grads[i] * grad_mul;
+  grads[i] = 0.0f;
+  if (i >= n_matrix && gradient == 0.0f) return;  // untouched hash-grid entries are skipped entirely
+  const float w = master[i];
+  if (i < n_matrix) gradient += l2_reg * w;       // no L2 regularisation for grid parameters
+  const float m = m1[i] = beta1 * m1[i] + (1.0f - beta1) * gradient;
+  const float v = m2[i] = beta2 * m2[i] + (1.0f - beta2) * (gradient * gradient);
+  const uint32_t step = ++steps[i];
+  const float lr_t = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+  const float eff = lr_t / (sqrtf(v) + epsilon);
+  const float nw = w - eff * m;
+  master[i] = nw;
+  params[i] = (half_t)nw;
+}
+
+// ------------------------------------------------------------------------------------------------ host
+void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width, uint32_t n_hidden_matmuls, hipStream_t s);
+
+struct TrainScratch {  // per-Network extra buffers that do not need to live in the class interface
+  DeviceBuffer<float> y{MemTag::Network};
+  DeviceBuffer<uint16_t> dy{MemTag::Network};
+  DeviceBuffer<uint16_t> d_all{MemTag::Network};
+  DeviceBuffer<uint16_t> packedT{MemTag::Network};
+  DeviceBuffer<uint32_t> steps{MemTag::Network};
+  float lr = 0.0f;
+  bool lr_init = false;
+  uint32_t loss_blocks = 0;
+};
+
+}  // namespace vnr
+
+#include <map>
+#include <memory>
+
+namespace vnr {
+
+static std::map<const Network*, std::unique_ptr<TrainScratch>>& scratch_map()
+{
+  static std::map<const Network*, std::unique_ptr<TrainScratch>> m;
+  return m;
+}
+static TrainScratch& scratch_of(const Network* n)
+{
+  auto& m = scratch_map();
+  auto it = m.find(n);
+  if (it == m.end()) it = m.emplace(n, std::make_unique<TrainScratch>()).first;
+  return *it->second;
+}
+void network_release_scratch(const Network* n) { scratch_map().erase(n); }
+
+void Network::forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s)
+{
+  if (!valid()) throw std::runtime_error("network is not configured");
+  if (batch == 0) return;
+  TrainScratch& ts = scratch_of(this);
+  const uint32_t nh = n_hidden_matmuls();
+  const uint32_t n = (uint32_t)batch;
+  // lazily allocate the training state
+  if (params_f32_.count != n_params_) { params_f32_.resize(n_params_); launch_f16_to_f32(params_f16_.ptr, params_f32_.ptr, n_params_, s); }
+  if (grads_.count != n_params_) { grads_.resize(n_params_); grads_.zero(s); }
+  if (adam_m_.count != n_params_) { adam_m_.resize(n_params_); adam_m_.zero(s); adam_v_.resize(n_params_); adam_v_.zero(s); }
+  if (ts.steps.count != n_params_) { ts.steps.resize(n_params_); ts.steps.zero(s); }
+  if (ws_batch_ != batch) {
+    ws_features_.resize(batch * in_width_);
+    ws_acts_.resize((size_t)(nh + 1) * batch * 64);
+    ws_dfeat_.resize(batch * in_width_);
+    ts.d_all.resize((size_t)(nh + 1) * batch * 64);
+    ts.y.resize(batch);
+    ts.dy.resize(batch);
+    ts.loss_blocks = std::min<uint32_t>(div_round_up(batch, 256), 1024u);
+    ws_loss_.resize(ts.loss_blocks);
+    ws_batch_ = batch;
+  }
+  const uint32_t pt = packedT_halves(in_width_, nh);
+  ts.packedT.ensure(pt);
+
+  // 1. forward, keeping features and hidden activations
+  launch_fused(2, grid_, in_width_, nh, cfg_.activation, params_f16_.ptr + n_mlp_, mlp_packed_.ptr, lds_halves_, d_coords,
+               ts.y.ptr, ws_features_.ptr, ws_acts_.ptr, batch, nullptr, batch, s);
+  // 2. loss + output gradient
+  loss_grad_kernel<<<ts.loss_blocks, 256, 0, s>>>(ts.y.ptr, d_targets, n, cfg_.loss, (half_t*)ts.dy.ptr, ws_loss_.ptr);
+  // 3. MLP backward
+  pack_mlp_T_kernel<<<div_round_up(pt, 256), 256, 0, s>>>((const half_t*)params_f16_.ptr, (half_t*)ts.packedT.ptr, in_width_, nh);
+  BackwardArgs ba;
+  ba.packedT = (const half_t*)ts.packedT.ptr; ba.dy = (const half_t*)ts.dy.ptr; ba.acts = (const half_t*)ws_acts_.ptr;
+  ba.d_out = (half_t*)ts.d_all.ptr; ba.dfeat = (half_t*)ws_dfeat_.ptr;
+  ba.n = n; ba.nh = nh; ba.activation = cfg_.activation; ba.in_width = in_width_; ba.lds_halves = pt;
+  {
+    const uint32_t blocks = std::min<uint32_t>(div_round_up(div_round_up(batch, 64), 4), (uint32_t)Runtime::get().n_cus * 4u);
+    const size_t shmem = (size_t)pt * 2;
+    const int mt = (int)((in_width_ + 31) / 32);
+    auto launch = [&](auto kernel) {
+      VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      kernel<<<blocks, 256, shmem, s>>>(ba);
+    };
+    if (mt == 1) launch(mlp_backward_kernel<1>);
+    else if (mt == 2) launch(mlp_backward_kernel<2>);
+    else if (mt == 3) launch(mlp_backward_kernel<3>);
+    else launch(mlp_backward_kernel<4>);
+  }
+  // 4. weight gradients
+  WGradArgs wa;
+  wa.features = (const half_t*)ws_features_.ptr; wa.acts = (const half_t*)ws_acts_.ptr; wa.d_all = (const half_t*)ts.d_all.ptr;
+  wa.dy = (const half_t*)ts.dy.ptr; wa.grads = grads_.ptr; wa.n = n; wa.nh = nh; wa.in_width = in_width_;
+  {
+    const dim3 g1(div_round_up(batch, kWgChunk), 1);
+    if (in_width_ <= 16) weight_grad_kernel<16><<<g1, 256, 0, s>>>(wa, 0);
+    else if (in_width_ <= 32) weight_grad_kernel<32><<<g1, 256, 0, s>>>(wa, 0);
+    else if (in_width_ <= 64) weight_grad_kernel<64><<<g1, 256, 0, s>>>(wa, 0);
+    else weight_grad_kernel<128><<<g1, 256, 0, s>>>(wa, 0);
+    const dim3 g2(div_round_up(batch, kWgChunk), nh + 1);  // hidden layers 1..nh and the last layer nh+1
+    weight_grad_kernel<64><<<g2, 256, 0, s>>>(wa, 1);
+  }
+  // 5. hash-grid backward
+  {
+    const dim3 g(div_round_up(batch, 256), cfg_.n_levels);
+    float* gg = grads_.ptr + n_mlp_;
+    switch (cfg_.n_features) {
+    case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg); break;
+    case 2: grid_backward_kernel<2><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg); break;
+    case 4: grid_backward_kernel<4><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg); break;
+    default: grid_backward_kernel<8><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg); break;
+    }
+  }
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+void Network::optimizer_step(float grad_scale, hipStream_t s)
+{
+  if (grads_.count != n_params_) throw std::runtime_error("optimizer_step before forward_backward");
+  TrainScratch& ts = scratch_of(this);
+  if (!ts.lr_init) { ts.lr = cfg_.learning_rate; ts.lr_init = true; }
+  adam_kernel<<<div_round_up(n_params_, 256), 256, 0, s>>>(n_params_, n_mlp_, grad_scale / (float)kLossScale, ts.lr, cfg_.beta1,
+                                                           cfg_.beta2, cfg_.epsilon, cfg_.l2_reg, params_f32_.ptr,
+                                                           (half_t*)params_f16_.ptr, grads_.ptr, adam_m_.ptr, adam_v_.ptr, ts.steps.ptr);
+  VNR_HIP_CHECK(hipGetLastError());
+  ++steps_;
+  // EXTERNAL tcnn ExponentialDecayOptimizer::step
+  if (cfg_.has_decay && steps_ >= cfg_.decay_start && cfg_.decay_interval > 0 && steps_ % cfg_.decay_interval == 0) ts.lr *= cfg_.decay_base;
+  refresh_inference_weights(s);
+}
+
+double Network::training_loss(hipStream_t s)
+{
+  TrainScratch& ts = scratch_of(this);
+  if (ts.loss_blocks == 0) return 0.0;
+  std::vector<float> h(ts.loss_blocks);
+  ws_loss_.download(h.data(), ts.loss_blocks, s);
+  double sum = 0.0;
+  for (float v : h) sum += v;
+  return sum;
+}
+
+}  // namespace vnr

@@ -1,0 +1,628 @@
+// render.hip — sample-streaming ray marcher (rendering mode 5) and the monolithic ground-truth marcher
+// (mode 4 on a dense volume) for gfx950, plus the Renderer host object.
+//
+// Reference: core/renderer/method_raymarching.cu:187-261,544-973 (streaming), :263-308,401-536 (monolithic),
+// core/renderer/dda.h:20-138, core/renderer/raytracing.h:9-36,147-207, renderer.cpp:59-140.
+//
+// MI355X design (per-ray arithmetic identical to the reference, structure is not):
+//  * reference iteration = intersect kernel (DDA walk, writes N_ITERS slots per ray) -> inference of ALL
+//    N_ITERS x R slots -> compose kernel (walks the DDA a second time) -> 4-byte D2H + stream sync.
+//  * here one fused `march` kernel per iteration composes the previous batch of a ray and immediately emits its
+//    next batch (one DDA walk per iteration, ray state stays in registers in between), rays are compacted with
+//    wave64 ballot + popcount, and SAMPLES are compacted with a wave prefix sum, so the network only ever sees
+//    live samples (the reference infers stale slots).  Sample (t0,t1) pairs are staged in LDS while a lane walks.
+//  * the sample count never visits the host: the fused inference kernel reads it from device memory; the host
+//    launches the iteration count of the previous frame speculatively and only then looks at a pinned counter.
+#include "renderer.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdlib>
+
+#include "sampling_device.h"
+
+namespace vnr {
+
+#define VNR_FLOAT_LARGE 1e20f
+#define VNR_NEARLY_ONE 0.9999f
+
+struct RayList {  // per ray payload, SoA (RayMarchingData, method_raymarching.cu:59-93)
+  uint32_t* pixel_index;
+  float* jitter;
+  float* alpha;
+  vec3f* color;
+  vec3i* cell;
+  vec3f* t_next;
+  float* next_cell_begin;
+  uint32_t* sample_base;
+  uint32_t* sample_count;
+};
+
+struct RenderParams {
+  vec4f* frame;
+  vec4f* accumulation;
+  int width, height, frame_index;
+  uint32_t pixel_lo, pixel_hi;
+  vec3f cam_pos, cam_dir, cam_hor, cam_ver;
+  affine3f wto;
+  vec3i vol_dims;
+  const float* volume;
+  vec3f bbox_lo, bbox_hi;
+  float step, step_rcp;
+  vec3i mc_dims;
+  vec3f mc_rcp;
+  const float* mc_max_opacity;
+  DeviceTfn tfn;
+  int n_iters;
+};
+
+enum { C_RAYS0 = 0, C_RAYS1 = 1, C_SAMPLES0 = 2, C_SAMPLES1 = 3, C_HIT = 4, C_STAT_SAMPLES = 6, C_STAT_REFRAYS = 8, C_COUNT = 16 };
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// raytracing.h:9-36
+__device__ __forceinline__ bool intersect_box(float& t0, float& t1, vec3f org, vec3f dir, vec3f lower, vec3f upper)
+{
+  const bool sx = fabsf(dir.x) <= FLT_MIN, sy = fabsf(dir.y) <= FLT_MIN, sz = fabsf(dir.z) <= FLT_MIN;
+  const vec3f rcp = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+  const vec3f lo = {sx ? VNR_FLOAT_LARGE : (lower.x - org.x) * rcp.x, sy ? VNR_FLOAT_LARGE : (lower.y - org.y) * rcp.y,
+                    sz ? VNR_FLOAT_LARGE : (lower.z - org.z) * rcp.z};
+  const vec3f hi = {sx ? -VNR_FLOAT_LARGE : (upper.x - org.x) * rcp.x, sy ? -VNR_FLOAT_LARGE : (upper.y - org.y) * rcp.y,
+                    sz ? -VNR_FLOAT_LARGE : (upper.z - org.z) * rcp.z};
+  t0 = fmaxf(t0, max3f(fminf(lo.x, hi.x), fminf(lo.y, hi.y), fminf(lo.z, hi.z)));
+  t1 = fminf(t1, min3f(fmaxf(lo.x, hi.x), fmaxf(lo.y, hi.y), fmaxf(lo.z, hi.z)));
+  return t1 > t0;
+}
+
+// method_raymarching.cu:658-685
+__device__ __forceinline__ void compute_ray(const RenderParams& p, uint32_t pixel, vec3f& org, vec3f& dir)
+{
+  const uint32_t ix = pixel % (uint32_t)p.width, iy = pixel / (uint32_t)p.width;
+  const float sx = ((float)ix + 0.5f) / (float)p.width, sy = ((float)iy + 0.5f) / (float)p.height;
+  org = xfm_point(p.wto, p.cam_pos);
+  const vec3f d = (p.cam_dir + (sx - 0.5f) * p.cam_hor) + (sy - 0.5f) * p.cam_ver;
+  dir = xfm_vector(p.wto, normalize(d));
+}
+
+// gdt::LCG<16> (EXTERNAL; instantvnr_types.h:155)
+__device__ __forceinline__ float tea_lcg_first(uint32_t v0, uint32_t v1)
+{
+  uint32_t s0 = 0;
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+  }
+  const uint32_t state = 1664525u * v0 + 1013904223u;
+  return (float)(state & 0x00FFFFFFu) / (float)0x01000000;
+}
+
+// raytracing.h:188-194 / :166-170 / :196-207
+__device__ __forceinline__ float adaptive_sampling_rate(float base_step, float max_opacity)
+{
+  const float scale = 15.0f * base_step;
+  const float r = fabsf(clampf(max_opacity, 0.1f, 1.0f) - 1.0f);
+  return fmaxf(base_step + scale * (r * r), base_step);
+}
+__device__ __forceinline__ float opacity_correction(float step_rcp, float distance, float opacity)
+{
+  return 1.0f - __builtin_powf(1.0f - opacity, step_rcp * distance);
+}
+__device__ __forceinline__ void write_pixel(const RenderParams& p, vec4f rgba, uint32_t pixel)
+{
+  if (p.frame_index != 1) {
+    const vec4f a = p.accumulation[pixel];
+    rgba = {a.x + rgba.x, a.y + rgba.y, a.z + rgba.z, a.w + rgba.w};
+  }
+  p.accumulation[pixel] = rgba;
+  const float f = (float)p.frame_index;
+  p.frame[pixel] = {rgba.x / f, rgba.y / f, rgba.z / f, rgba.w / f};
+}
+
+// ------------------------------------------------------------------------------------------------ DDA (dda.h)
+struct DDAState {
+  vec3f t_next;
+  vec3i cell;
+  float next_cell_begin;
+};
+
+// dda.h:26-46
+__device__ __forceinline__ void dda_init(DDAState& it, vec3f org, vec3f dir, float t_min, vec3i grid)
+{
+  const vec3f oiv = org + t_min * dir;
+  const vec3f fc = {fmaxf(0.0f, fminf((float)grid.x - 1.0f, floorf(oiv.x))), fmaxf(0.0f, fminf((float)grid.y - 1.0f, floorf(oiv.y))),
+                    fmaxf(0.0f, fminf((float)grid.z - 1.0f, floorf(oiv.z)))};
+  const vec3f fe = {dir.x > 0.0f ? fc.x + 1.0f : fc.x, dir.y > 0.0f ? fc.y + 1.0f : fc.y, dir.z > 0.0f ? fc.z + 1.0f : fc.z};
+  const vec3f ts = {fabsf(1.0f / dir.x), fabsf(1.0f / dir.y), fabsf(1.0f / dir.z)};
+  it.t_next = {dir.x == 0.0f ? VNR_FLOAT_LARGE : fabsf(fe.x - oiv.x) * ts.x, dir.y == 0.0f ? VNR_FLOAT_LARGE : fabsf(fe.y - oiv.y) * ts.y,
+               dir.z == 0.0f ? VNR_FLOAT_LARGE : fabsf(fe.z - oiv.z) * ts.z};
+  it.cell = {(int)fc.x, (int)fc.y, (int)fc.z};
+  it.next_cell_begin = 0.0f;
+}
+
+// dda.h:48-122; fn(cell, t0, t1) -> bool
+template <typename F>
+__device__ __forceinline__ bool dda_next(DDAState& it, vec3f dir, float t_min, float t_max, vec3i grid, F&& fn)
+{
+  const vec3i stop = {dir.x > 0.0f ? grid.x : -1, dir.y > 0.0f ? grid.y : -1, dir.z > 0.0f ? grid.z : -1};
+  if (it.cell.x == stop.x) return false;
+  if (it.cell.y == stop.y) return false;
+  if (it.cell.z == stop.z) return false;
+  const vec3f ts = {fabsf(1.0f / dir.x), fabsf(1.0f / dir.y), fabsf(1.0f / dir.z)};
+  const vec3i delta = {dir.x > 0.0f ? 1 : -1, dir.y > 0.0f ? 1 : -1, dir.z > 0.0f ? 1 : -1};
+  const float t_closest = min3f(it.t_next.x, it.t_next.y, it.t_next.z);
+  const float cell_t0 = fmaxf(t_min + it.next_cell_begin, t_min);
+  const float cell_t1 = fminf(t_min + t_closest, t_max);
+  if (cell_t0 >= cell_t1) return false;
+  const bool go = fn(it.cell, cell_t0, cell_t1);
+  if (go || fmaxf(t_min + it.next_cell_begin, t_min) >= cell_t1) {
+    if (it.t_next.x == t_closest) { it.t_next.x += ts.x; it.cell.x += delta.x; if (it.cell.x == stop.x) return false; }
+    if (it.t_next.y == t_closest) { it.t_next.y += ts.y; it.cell.y += delta.y; if (it.cell.y == stop.y) return false; }
+    if (it.t_next.z == t_closest) { it.t_next.z += ts.z; it.cell.z += delta.z; if (it.cell.z == stop.z) return false; }
+    it.next_cell_begin = t_closest;
+  }
+  return go;
+}
+
+// dda.h:124-137
+__device__ __forceinline__ bool dda_resumable(const DDAState& it, vec3f dir, float t_min, float t_max, vec3i grid)
+{
+  const vec3i stop = {dir.x > 0.0f ? grid.x : -1, dir.y > 0.0f ? grid.y : -1, dir.z > 0.0f ? grid.z : -1};
+  if (it.cell.x == stop.x) return false;
+  if (it.cell.y == stop.y) return false;
+  if (it.cell.z == stop.z) return false;
+  const float t_closest = min3f(it.t_next.x, it.t_next.y, it.t_next.z);
+  const float cell_t0 = fmaxf(t_min + it.next_cell_begin, t_min);
+  const float cell_t1 = fminf(t_min + t_closest, t_max);
+  return cell_t0 < cell_t1;
+}
+
+__device__ __forceinline__ float opacity_upper_bound(const RenderParams& p, vec3i cell)
+{
+  const uint32_t idx = cell.x + cell.y * (uint32_t)p.mc_dims.x + cell.z * (uint32_t)p.mc_dims.x * (uint32_t)p.mc_dims.y;
+  return p.mc_max_opacity[idx];
+}
+
+// RayMarchingIter::exec (method_raymarching.cu:555-600); body(t0, t1) -> bool
+template <typename B>
+__device__ __forceinline__ void iter_exec(const RenderParams& p, DDAState& it, vec3f m_dir, float t_min, float t_max, float step, B&& body)
+{
+  auto cell_fn = [&](vec3i cell, float t0, float t1) -> bool {
+    const float r = opacity_upper_bound(p, cell);
+    if (fabsf(r) <= FLT_EPSILON) return true;
+    const float ss = adaptive_sampling_rate(step, r);
+    float tx = t0, ty = fminf(t1, t0 + ss);
+    while (ty > tx) {
+      it.next_cell_begin = ty - t_min;
+      if (!body(tx, ty)) return false;
+      tx = ty;
+      ty = fminf(tx + ss, t1);
+    }
+    return true;
+  };
+  while (dda_next(it, m_dir, t_min, t_max, p.mc_dims, cell_fn)) {}
+}
+
+// ------------------------------------------------------------------------------------------------ streaming march kernel
+// FIRST: thread = pixel of the tile (raygen, method_raymarching.cu:840-875) and emits the first batch.
+// !FIRST: thread = alive ray: compose the batch inferred last iteration (:732-838), then emit the next (:687-730).
+template <bool FIRST>
+__global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const RayList cur, const RayList nxt,
+                                                    const float* __restrict__ values, const float* __restrict__ dts_in,
+                                                    float* __restrict__ coords, float* __restrict__ dts_out,
+                                                    uint32_t* __restrict__ counters, int parity)
+{
+  extern __shared__ float s_t[];  // [2][n_iters][256]
+  float* s_t0 = s_t;
+  float* s_t1 = s_t + (size_t)p.n_iters * 256;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t n_in = FIRST ? (p.pixel_hi - p.pixel_lo) : counters[C_RAYS0 + parity];
+  uint32_t* n_rays_out = counters + C_RAYS0 + (parity ^ 1);
+  uint32_t* n_samples_out = counters + C_SAMPLES0 + parity;
+  const uint32_t n_round = (n_in + 255u) & ~255u;
+
+  for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
+    const uint32_t i = base + tid;
+    const bool active = i < n_in;
+    uint32_t pixel = 0;
+    float jitter = 0.0f, alpha = 0.0f;
+    vec3f color = {0, 0, 0};
+    DDAState it;
+    it.t_next = {0, 0, 0}; it.cell = {0, 0, 0}; it.next_cell_begin = 0.0f;
+    vec3f org = {0, 0, 0}, dir = {0, 0, 1}, m_dir = {0, 0, 1};
+    float tmin = 0.0f, tmax = VNR_FLOAT_LARGE;
+    bool alive = false;
+
+    if (active) {
+      if (FIRST) {
+        pixel = p.pixel_lo + i;
+        jitter = tea_lcg_first((uint32_t)p.frame_index, pixel);
+        compute_ray(p, pixel, org, dir);
+        m_dir = dir * p.mc_rcp;
+        alive = intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
+        if (alive) dda_init(it, org * p.mc_rcp, m_dir, tmin, p.mc_dims);
+        else write_pixel(p, {0, 0, 0, 0}, pixel);
+      } else {
+        pixel = cur.pixel_index[i];
+        jitter = cur.jitter[i];
+        alpha = cur.alpha[i];
+        color = cur.color[i];
+        it.cell = cur.cell[i];
+        it.t_next = cur.t_next[i];
+        it.next_cell_begin = cur.next_cell_begin[i];
+        const uint32_t sb = cur.sample_base[i], sc = cur.sample_count[i];
+        compute_ray(p, pixel, org, dir);
+        m_dir = dir * p.mc_rcp;
+        intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
+        // compose (classification, opacity correction, front-to-back blending)
+        for (uint32_t k = 0; k < sc; ++k) {
+          vec3f rgb; float a;
+          tfn_sample(p.tfn, values[sb + k], rgb, a);
+          a = opacity_correction(p.step_rcp, dts_in[sb + k], a);
+          const float tr = 1.0f - alpha;
+          alpha += tr * a;
+          color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a;
+          if (!(alpha < VNR_NEARLY_ONE)) break;
+        }
+        alive = (alpha < VNR_NEARLY_ONE) && dda_resumable(it, m_dir, tmin, tmax, p.mc_dims);
+        if (!alive) write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
+      }
+    }
+
+    // emit the next batch of this ray into LDS
+    uint32_t k = 0;
+    if (alive) {
+      const int n_iters = p.n_iters;
+      iter_exec(p, it, m_dir, tmin, tmax, p.step, [&](float t0, float t1) -> bool {
+        s_t0[k * 256u + tid] = t0;
+        s_t1[k * 256u + tid] = t1;
+        return (int)(++k) < n_iters;
+      });
+      if (k == 0) write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);  // nothing left to sample: the ray is finished
+    }
+    const bool survive = alive && k > 0;
+
+    // wave64 compaction: rays by ballot, samples by prefix sum
+    const unsigned long long mask = __ballot(survive);
+    const unsigned long long alive_mask = __ballot(alive);
+    uint32_t incl = k;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if ((int)lane >= d) incl += y;
+    }
+    const uint32_t wave_samples = __shfl(incl, 63);
+    const uint32_t wave_rays = (uint32_t)__popcll(mask);
+    uint32_t ray_base = 0, smp_base = 0;
+    if (lane == 0) {
+      if (wave_rays) {
+        ray_base = atomicAdd(n_rays_out, wave_rays);
+        smp_base = atomicAdd(n_samples_out, wave_samples);
+        atomicAdd((unsigned long long*)(counters + C_STAT_SAMPLES), (unsigned long long)wave_samples);
+      }
+      if (alive_mask) atomicAdd((unsigned long long*)(counters + C_STAT_REFRAYS), (unsigned long long)__popcll(alive_mask));
+      if (FIRST && alive_mask) atomicAdd(counters + C_HIT, (uint32_t)__popcll(alive_mask));
+    }
+    ray_base = __shfl(ray_base, 0);
+    smp_base = __shfl(smp_base, 0);
+
+    if (survive) {
+      const uint32_t slot = ray_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      const uint32_t sb = smp_base + (incl - k);
+      nxt.pixel_index[slot] = pixel;
+      nxt.jitter[slot] = jitter;
+      nxt.alpha[slot] = alpha;
+      nxt.color[slot] = color;
+      nxt.cell[slot] = it.cell;
+      nxt.t_next[slot] = it.t_next;
+      nxt.next_cell_begin[slot] = it.next_cell_begin;
+      nxt.sample_base[slot] = sb;
+      nxt.sample_count[slot] = k;
+      for (uint32_t j = 0; j < k; ++j) {
+        const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
+        const float t = (1.0f - jitter) * t0 + jitter * t1;  // lerp(jitter, t0, t1), instantvnr_types.h:162-166
+        const vec3f c = org + t * dir;
+        coords[3 * (size_t)(sb + j) + 0] = c.x;
+        coords[3 * (size_t)(sb + j) + 1] = c.y;
+        coords[3 * (size_t)(sb + j) + 2] = c.z;
+        dts_out[sb + j] = t1 - t0;
+      }
+    }
+  }
+}
+
+// iterative_sampling_groundtruth_kernel (method_raymarching.cu:902-915) over the compacted sample queue
+__global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float* __restrict__ vol, vec3i dims,
+                                 const float* __restrict__ coords, float* __restrict__ values, uint32_t* clear0, uint32_t* clear1)
+{
+  const uint32_t n = *n_ptr;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    values[i] = sample_volume_nodal(vol, dims, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
+}
+
+__global__ void clear_two_kernel(uint32_t* a, uint32_t* b)
+{
+  if (a) *a = 0;
+  if (b) *b = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ monolithic marcher (mode 4)
+// raymarching_kernel / raymarching_traceray / raymarching_iterator, NO_SHADING (method_raymarching.cu:263-308,401-536)
+__global__ void monolithic_kernel(const RenderParams p)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.pixel_hi - p.pixel_lo) return;
+  const uint32_t pixel = p.pixel_lo + i;
+  vec3f org, dir;
+  compute_ray(p, pixel, org, dir);
+  float alpha = 0.0f;
+  vec3f color = {0, 0, 0};
+  float t0 = 0.0f, t1 = VNR_FLOAT_LARGE;
+  if (intersect_box(t0, t1, org, dir, p.bbox_lo, p.bbox_hi)) {
+    const float jitter = tea_lcg_first((uint32_t)p.frame_index, pixel);
+    const vec3f m_dir = dir * p.mc_rcp;
+    DDAState it;
+    dda_init(it, org * p.mc_rcp, m_dir, t0, p.mc_dims);
+    // dda3 (dda.h:140-287) == dda_next with a callback that always advances, stopped by the callback's result
+    auto cell_fn = [&](vec3i cell, float c0, float c1) -> bool {
+      const float r = opacity_upper_bound(p, cell);
+      if (fabsf(r) <= FLT_EPSILON) return true;
+      float ss = adaptive_sampling_rate(p.step, r);
+      {  // sample_size_scaler :263-268
+        const int N = (int)((c1 - c0) / ss + 1.0f);
+        ss = (c1 - c0) / (float)N;
+      }
+      float tx = c0, ty = fminf(c1, c0 + ss);
+      while (ty > tx) {
+        const float t = (1.0f - jitter) * tx + jitter * ty;
+        const vec3f c = org + t * dir;
+        const float v = sample_volume_nodal(p.volume, p.vol_dims, c.x, c.y, c.z);
+        vec3f rgb; float a;
+        tfn_sample(p.tfn, v, rgb, a);
+        a = opacity_correction(p.step_rcp, ty - tx, a);
+        const float tr = 1.0f - alpha;
+        color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a;
+        alpha += tr * a;
+        if (!(alpha < VNR_NEARLY_ONE)) return false;
+        tx = ty;
+        ty = fminf(tx + ss, c1);
+      }
+      return true;
+    };
+    if (t0 < t1) {
+      const vec3i stop = {m_dir.x > 0.0f ? p.mc_dims.x : -1, m_dir.y > 0.0f ? p.mc_dims.y : -1, m_dir.z > 0.0f ? p.mc_dims.z : -1};
+      const vec3f ts = {fabsf(1.0f / m_dir.x), fabsf(1.0f / m_dir.y), fabsf(1.0f / m_dir.z)};
+      const vec3i delta = {m_dir.x > 0.0f ? 1 : -1, m_dir.y > 0.0f ? 1 : -1, m_dir.z > 0.0f ? 1 : -1};
+      for (;;) {
+        const float t_closest = min3f(it.t_next.x, it.t_next.y, it.t_next.z);
+        const float c0 = fmaxf(t0 + it.next_cell_begin, t0), c1 = fminf(t0 + t_closest, t1);
+        if (c0 >= c1) break;
+        if (!cell_fn(it.cell, c0, c1)) break;
+        if (it.t_next.x == t_closest) { it.t_next.x += ts.x; it.cell.x += delta.x; if (it.cell.x == stop.x) break; }
+        if (it.t_next.y == t_closest) { it.t_next.y += ts.y; it.cell.y += delta.y; if (it.cell.y == stop.y) break; }
+        if (it.t_next.z == t_closest) { it.t_next.z += ts.z; it.cell.z += delta.z; if (it.cell.z == stop.z) break; }
+        it.next_cell_begin = t_closest;
+      }
+    }
+  }
+  write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
+}
+
+// ================================================================================================ Renderer (host)
+Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volume))
+{
+  if (!Runtime::get().ready()) Runtime::get().init(-1);
+  stream_ = Runtime::get().stream;
+  if (const char* e = std::getenv("VNR_RM_N_ITERS")) n_iters_ = std::max(1, std::min(64, std::atoi(e)));
+  counters_.resize(C_COUNT);
+  counters_.zero(stream_);
+  VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 256 * sizeof(uint32_t), hipHostMallocDefault));
+}
+
+Renderer::~Renderer()
+{
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (int i = 0; i < 2; ++i) if (host_fb_[i]) (void)hipHostFree(host_fb_[i]);
+  if (host_counts_) (void)hipHostFree(host_counts_);
+  for (auto e : events_) (void)hipEventDestroy(e);
+}
+
+void Renderer::resize(int w, int h)
+{
+  if (w <= 0 || h <= 0) throw std::runtime_error("invalid framebuffer size");
+  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+  width_ = w; height_ = h;
+  const size_t n = (size_t)w * h;
+  for (int i = 0; i < 2; ++i) { fb_[i].resize(n); fb_[i].zero(stream_); }
+  accumulation_.resize(n);
+  accumulation_.zero(stream_);
+  if (host_fb_pixels_ != n) {
+    for (int i = 0; i < 2; ++i) {
+      if (host_fb_[i]) (void)hipHostFree(host_fb_[i]);
+      VNR_HIP_CHECK(hipHostMalloc((void**)&host_fb_[i], n * sizeof(vec4f), hipHostMallocDefault));
+      std::memset(host_fb_[i], 0, n * sizeof(vec4f));
+    }
+    host_fb_pixels_ = n;
+  }
+  reset_ = true;
+}
+
+void Renderer::set_transfer_function(const TransferFunctionData& t)
+{
+  // api.cpp:485-498: the volume refreshes its macrocell max-opacity, the renderer keeps the lookup tables
+  volume_->set_transfer_function(t, stream_);
+  tfn_.set(t, volume_->desc.range_lo, volume_->desc.range_hi, stream_);
+  reset_ = true;
+}
+
+void Renderer::ensure_queues(size_t n_pixels, int n_iters)
+{
+  if (queue_pixels_ >= n_pixels && queue_iters_ >= n_iters) return;
+  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+  const size_t P = n_pixels;
+  q_u32_.resize(6 * P);
+  q_f32_.resize(18 * P);
+  q_i32_.resize(6 * P);
+  coords_.resize(3 * P * n_iters);
+  dts_.resize(2 * P * n_iters);
+  values_.resize(P * n_iters);
+  queue_pixels_ = P;
+  queue_iters_ = n_iters;
+}
+
+void Renderer::render()
+{
+  if (width_ <= 0 || height_ <= 0) return;  // renderer.cpp:63
+  MacroCell& mc = volume_->macrocell();
+  if (!mc.allocated()) throw std::runtime_error("volume has no macrocell");
+  RenderParams p;
+  p.width = width_; p.height = height_;
+  const uint32_t n_pixels = (uint32_t)((size_t)width_ * height_);
+  p.pixel_lo = std::min(pixel_lo_, n_pixels);
+  p.pixel_hi = std::min(pixel_hi_, n_pixels);
+  if (p.pixel_hi < p.pixel_lo) p.pixel_hi = p.pixel_lo;
+  // camera, renderer.cpp:87-96
+  const float t = 2.0f * tanf(camera_.fovy * 0.5f * (float)M_PI / 180.0f);
+  const float aspect = (float)width_ / (float)height_;
+  p.cam_pos = camera_.from;
+  p.cam_dir = normalize(camera_.at - camera_.from);
+  p.cam_hor = (t * aspect) * normalize(cross(p.cam_dir, camera_.up));
+  p.cam_ver = (1.0f / aspect) * cross(p.cam_hor, p.cam_dir);
+  p.wto = affine_inverse(volume_->transform);
+  p.vol_dims = volume_->desc.dims;
+  p.volume = volume_->is_network() ? nullptr : static_cast<SimpleVolume*>(volume_.get())->d_data();
+  p.bbox_lo = volume_->clipbox.lower; p.bbox_hi = volume_->clipbox.upper;
+  p.step = 1.0f / sampling_rate_; p.step_rcp = sampling_rate_;  // object.cpp:303-304
+  p.mc_dims = mc.dims();
+  const vec3f sp = mc.spacings();
+  p.mc_rcp = {1.0f / sp.x, 1.0f / sp.y, 1.0f / sp.z};
+  p.mc_max_opacity = mc.d_max_opacity();
+  p.tfn = tfn_.view();
+  p.n_iters = n_iters_;
+  // frame index / accumulation, renderer.cpp:103-105
+  if (reset_) frame_index_ = 0;
+  ++frame_index_;
+  p.frame_index = frame_index_;
+  p.frame = fb_[fb_cur_].ptr;
+  p.accumulation = accumulation_.ptr;
+  stats_ = FrameStats();
+
+  if (p.pixel_hi > p.pixel_lo) {
+    switch (mode_) {
+    case 5: render_streaming(p); break;
+    case 4:
+      if (volume_->is_network()) throw std::runtime_error("rendering mode 4 (decoding) on a neural volume is not implemented in this build");
+      render_monolithic(p);
+      break;
+    default: throw std::runtime_error("rendering mode " + std::to_string(mode_) + " is not implemented in this build (supported: 4 on simple volumes, 5)");
+    }
+  }
+  reset_ = false;
+  if (!skip_download_) {  // renderer.cpp:133 framebuffer.download_async
+    const size_t off = p.pixel_lo, cnt = p.pixel_hi - p.pixel_lo;
+    if (cnt) VNR_HIP_CHECK(hipMemcpyAsync(host_fb_[fb_cur_] + off, fb_[fb_cur_].ptr + off, cnt * sizeof(vec4f), hipMemcpyDeviceToHost, stream_));
+  }
+}
+
+void Renderer::render_monolithic(const RenderParams& p)
+{
+  const uint32_t n = p.pixel_hi - p.pixel_lo;
+  monolithic_kernel<<<div_round_up(n, 128), 128, 0, stream_>>>(p);
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+void Renderer::render_streaming(const RenderParams& p)
+{
+  const uint32_t P = p.pixel_hi - p.pixel_lo;
+  ensure_queues(P, p.n_iters);
+  const size_t QP = queue_pixels_;
+  RayList rl[2];
+  for (int b = 0; b < 2; ++b) {
+    rl[b].pixel_index = q_u32_.ptr + (size_t)(0 + b) * QP;
+    rl[b].sample_base = q_u32_.ptr + (size_t)(2 + b) * QP;
+    rl[b].sample_count = q_u32_.ptr + (size_t)(4 + b) * QP;
+    float* f = q_f32_.ptr + (size_t)b * 9 * QP;
+    rl[b].jitter = f;
+    rl[b].alpha = f + QP;
+    rl[b].color = (vec3f*)(f + 2 * QP);
+    rl[b].t_next = (vec3f*)(f + 5 * QP);
+    rl[b].next_cell_begin = f + 8 * QP;
+    rl[b].cell = (vec3i*)(q_i32_.ptr + (size_t)b * 3 * QP);
+  }
+  float* dts[2] = {dts_.ptr, dts_.ptr + (size_t)QP * queue_iters_};
+  uint32_t* c = counters_.ptr;
+  NeuralVolume* nv = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get()) : nullptr;
+  if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
+
+  VNR_HIP_CHECK(hipMemsetAsync(c, 0, C_COUNT * sizeof(uint32_t), stream_));
+  const size_t shmem = (size_t)2 * p.n_iters * 256 * sizeof(float);
+  const uint32_t max_iterations = 240;
+  if (profiling_ && events_.size() < 2 * max_iterations) {
+    while (events_.size() < 2 * max_iterations) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreate(&e)); events_.push_back(e); }
+  }
+  const size_t s_max = (size_t)P * p.n_iters;
+  uint32_t it = 0;
+  for (;;) {
+    const int parity = (int)(it & 1u);
+    // march(it): reads ray list `parity`, writes list `parity^1` and sample queue `parity`
+    if (it == 0) {
+      const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 4096u);
+      march_kernel<true><<<blocks, 256, shmem, stream_>>>(p, rl[0], rl[1], values_.ptr, dts[1], coords_.ptr, dts[0], c, 0);
+    } else {
+      const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
+      march_kernel<false><<<blocks, 256, shmem, stream_>>>(p, rl[parity], rl[parity ^ 1], values_.ptr, dts[parity ^ 1], coords_.ptr, dts[parity], c, parity);
+    }
+    // evaluate the compacted samples; the evaluation kernel also clears the counters march(it+1) will append to
+    uint32_t* clear0 = c + C_RAYS0 + parity;            // output ray list of march(it+1)
+    uint32_t* clear1 = c + C_SAMPLES0 + (parity ^ 1);   // sample counter of march(it+1)
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[2 * it], stream_));
+    if (nv) {
+      nv->network().inference(coords_.ptr, values_.ptr, 0, c + C_SAMPLES0 + parity, s_max, stream_);
+    } else {
+      const uint32_t blocks = std::min<uint32_t>(div_round_up(s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
+      gt_sample_kernel<<<blocks, 256, 0, stream_>>>(c + C_SAMPLES0 + parity, p.volume, p.vol_dims, coords_.ptr, values_.ptr, nullptr, nullptr);
+    }
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[2 * it + 1], stream_));
+    clear_two_kernel<<<1, 1, 0, stream_>>>(clear0, clear1);
+    VNR_HIP_CHECK(hipMemcpyAsync(host_counts_ + (it & 255u), c + C_RAYS0 + (parity ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+    ++it;
+    if (it >= max_iterations) break;
+    if (it >= predicted_iterations_) {
+      // past the speculative part: look at the alive-ray count of the iteration just launched
+      VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+      if (host_counts_[(it - 1) & 255u] == 0) break;
+    }
+  }
+  // the last march that produced zero rays ends the frame; remember how many iterations that took
+  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+  uint32_t used = it;
+  while (used > 1 && host_counts_[(used - 2) & 255u] == 0) --used;  // trailing speculative no-op iterations
+  predicted_iterations_ = used;
+  uint32_t hc[C_COUNT];
+  VNR_HIP_CHECK(hipMemcpy(hc, c, sizeof(hc), hipMemcpyDeviceToHost));
+  stats_.n_rays_hit = hc[C_HIT];
+  stats_.n_samples = (uint64_t)hc[C_STAT_SAMPLES] | ((uint64_t)hc[C_STAT_SAMPLES + 1] << 32);
+  stats_.n_reference_slots = ((uint64_t)hc[C_STAT_REFRAYS] | ((uint64_t)hc[C_STAT_REFRAYS + 1] << 32)) * (uint64_t)p.n_iters;
+  stats_.n_iterations = used;
+  if (profiling_) {
+    for (uint32_t k = 0; k < it; ++k) {
+      float ms = 0.0f;
+      VNR_HIP_CHECK(hipEventElapsedTime(&ms, events_[2 * k], events_[2 * k + 1]));
+      stats_.infer_kernel_ms += ms;
+    }
+    stats_.infer_kernel_launches = used;
+  }
+}
+
+const float* Renderer::map_frame()
+{
+  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+  const float* out = skip_download_ ? (const float*)fb_[fb_cur_].ptr : (const float*)host_fb_[fb_cur_];
+  fb_cur_ ^= 1;  // framebuffer.safe_swap
+  return out;
+}
+
+}  // namespace vnr

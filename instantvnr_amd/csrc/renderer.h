@@ -1,0 +1,84 @@
+// renderer.h — MainRenderer equivalent (renderer.{h,cpp}, object.{h,cpp}, framebuffer.h) with the
+// sample-streaming ray marcher (core/renderer/method_raymarching.{h,cu}, dda.h, raytracing.h).
+#pragma once
+
+#include <memory>
+
+#include "volume.h"
+
+namespace vnr {
+
+struct CameraData {  // instantvnr_types.h:73-83
+  vec3f from{0, 0, -1}, at{0, 0, 0}, up{0, 1, 0};
+  float fovy = 60.0f;
+};
+
+struct FrameStats {
+  uint64_t n_samples = 0, n_reference_slots = 0;
+  uint32_t n_iterations = 0, n_rays_hit = 0;
+  double infer_kernel_ms = 0.0;
+  uint64_t infer_kernel_launches = 0;
+};
+
+struct RenderParams;  // device-visible POD (render.hip)
+
+class Renderer {
+public:
+  explicit Renderer(std::shared_ptr<VolumeBase> volume);  // api.cpp:419-459 vnrCreateRenderer
+  ~Renderer();
+
+  void resize(int w, int h);                         // renderer.h:96-112
+  void set_camera(const CameraData& c) { camera_ = c; reset_ = true; }
+  void set_transfer_function(const TransferFunctionData& t);
+  void set_mode(int m) { mode_ = m; reset_ = true; } // renderer.h:139-146
+  void set_sampling_rate(float r) { sampling_rate_ = r; reset_ = true; }
+  void set_density_scale(float s) { density_scale_ = s; reset_ = true; }
+  void reset_accumulation() { reset_ = true; }
+  void set_device_output(bool e) { skip_download_ = e; }
+  void set_pixel_range(uint32_t lo, uint32_t hi) { pixel_lo_ = lo; pixel_hi_ = hi; reset_ = true; }
+  void set_profiling(bool e) { profiling_ = e; }
+
+  void render();                 // renderer.cpp:59-140
+  const float* map_frame();      // renderer.h:84-94
+  const FrameStats& stats() const { return stats_; }
+  int width() const { return width_; }
+  int height() const { return height_; }
+
+private:
+  void render_streaming(const RenderParams& p);
+  void render_monolithic(const RenderParams& p);
+  void ensure_queues(size_t n_pixels, int n_iters);
+
+  std::shared_ptr<VolumeBase> volume_;
+  CameraData camera_;
+  TfnObject tfn_;
+  int mode_ = 5;  // api.cpp:456
+  float sampling_rate_ = 1.0f, density_scale_ = 1.0f;
+  int width_ = 0, height_ = 0;
+  uint32_t pixel_lo_ = 0, pixel_hi_ = 0xffffffffu;
+  bool reset_ = true, skip_download_ = false, profiling_ = false;
+  int frame_index_ = 0;
+  int n_iters_ = 16;  // VNR_RM_N_ITERS (method_raymarching.cu:30-40)
+  uint32_t predicted_iterations_ = 0;
+  hipStream_t stream_ = nullptr;
+
+  // framebuffer: double-buffered device + pinned host (framebuffer.h:7-98)
+  DeviceBuffer<vec4f> fb_[2], accumulation_;
+  vec4f* host_fb_[2] = {nullptr, nullptr};
+  size_t host_fb_pixels_ = 0;
+  int fb_cur_ = 0;
+
+  // streaming queues
+  DeviceBuffer<uint32_t> q_u32_;   // pixel_index[2], sample_base[2], sample_count[2]
+  DeviceBuffer<float> q_f32_;      // jitter[2], alpha[2], color[2][3], t_next[2][3], next_cell_begin[2]
+  DeviceBuffer<int> q_i32_;        // cell[2][3]
+  DeviceBuffer<float> coords_, dts_, values_;
+  DeviceBuffer<uint32_t> counters_;
+  uint32_t* host_counts_ = nullptr;  // pinned ring of alive-ray counts
+  size_t queue_pixels_ = 0;
+  int queue_iters_ = 0;
+  std::vector<hipEvent_t> events_;
+  FrameStats stats_;
+};
+
+}  // namespace vnr

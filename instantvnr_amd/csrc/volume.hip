@@ -1,0 +1,657 @@
+// volume.hip — ground-truth volume / sampler, macrocell kernels, transfer function, NeuralVolume host logic.
+// See volume.h for the reference mapping.
+#include "volume.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <ctime>
+#include <fstream>
+#include <thread>
+
+#include "sampling_device.h"
+
+namespace vnr {
+
+// ================================================================================================ TfnObject
+void TfnObject::set(const TransferFunctionData& t, float data_lo, float data_hi, hipStream_t s)
+{
+  // object.cpp:321-348
+  std::vector<vec4f> c(t.color.size());
+  for (size_t i = 0; i < c.size(); ++i) c[i] = {t.color[i].x, t.color[i].y, t.color[i].z, 1.0f};
+  std::vector<float> a(t.alpha.size());
+  for (size_t i = 0; i < a.size(); ++i) a[i] = t.alpha[i].y;
+  if (!c.empty()) { colors_.resize(c.size()); colors_.upload(c.data(), c.size(), s); n_colors_ = (int)c.size(); }
+  if (!a.empty()) { alphas_.resize(a.size()); alphas_.upload(a.data(), a.size(), s); n_alphas_ = (int)a.size(); }
+  if (t.range_set && !(t.range_lo > t.range_hi)) {
+    hi_ = std::min(data_hi, t.range_hi);
+    lo_ = std::max(data_lo, t.range_lo);
+  }
+  rcp_ = 1.0f / (hi_ - lo_);
+  VNR_HIP_CHECK(hipStreamSynchronize(s));  // host staging vectors go out of scope
+}
+
+DeviceTfn TfnObject::view() const
+{
+  DeviceTfn d;
+  d.colors = colors_.ptr; d.alphas = alphas_.ptr; d.n_colors = n_colors_; d.n_alphas = n_alphas_;
+  d.range_lo = lo_; d.range_hi = hi_; d.range_rcp_norm = rcp_;
+  return d;
+}
+
+// ================================================================================================ MacroCell kernels
+// float atomic min/max through integer atomics (core/instantvnr_types.h:185-199)
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v)
+{
+  if (!signbit(v)) atomicMin((int*)addr, __float_as_int(v));
+  else atomicMax((unsigned int*)addr, __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v)
+{
+  if (!signbit(v)) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+
+// macrocell.cu:11-40
+__device__ __forceinline__ void update_single_macrocell(int vx, int vy, int vz, vec3i mc, float* __restrict__ cells, float value)
+{
+  const int cx = vx >> kMacrocellSizeMip, cy = vy >> kMacrocellSizeMip, cz = vz >> kMacrocellSizeMip;
+  if (cx < 0 || cx >= mc.x) return;
+  if (cy < 0 || cy >= mc.y) return;
+  if (cz < 0 || cz >= mc.z) return;
+  const uint32_t idx = cx + cy * mc.x + cz * mc.y * mc.x;
+  atomic_min_f32(cells + 2 * (size_t)idx, value - 1.0f);
+  atomic_max_f32(cells + 2 * (size_t)idx + 1, value + 1.0f);
+}
+
+__device__ __forceinline__ void update_voxel_and_neighbours(int x, int y, int z, vec3i mc, float* __restrict__ cells, float value)
+{
+  const int sx = (x % kMacrocellSize) == 0 ? -1 : ((x % kMacrocellSize) == (kMacrocellSize - 1) ? 1 : 0);
+  const int sy = (y % kMacrocellSize) == 0 ? -1 : ((y % kMacrocellSize) == (kMacrocellSize - 1) ? 1 : 0);
+  const int sz = (z % kMacrocellSize) == 0 ? -1 : ((z % kMacrocellSize) == (kMacrocellSize - 1) ? 1 : 0);
+  update_single_macrocell(x, y, z, mc, cells, value);
+  update_single_macrocell(x + sx, y, z, mc, cells, value);
+  update_single_macrocell(x, y + sy, z, mc, cells, value);
+  update_single_macrocell(x + sx, y + sy, z, mc, cells, value);
+  update_single_macrocell(x, y, z + sz, mc, cells, value);
+  update_single_macrocell(x + sx, y, z + sz, mc, cells, value);
+  update_single_macrocell(x, y + sy, z + sz, mc, cells, value);
+  update_single_macrocell(x + sx, y + sy, z + sz, mc, cells, value);
+}
+
+// macrocell.cu:42-73
+__global__ void update_macrocell_explicit_kernel(uint32_t n, const float* __restrict__ coords, const float* __restrict__ values,
+                                                 vec3i dims, vec3i mc, float* __restrict__ cells)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float value = values[i];
+  int v[3];
+  const int d[3] = {dims.x, dims.y, dims.z};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float f = __builtin_floorf(coords[3 * (size_t)i + k] * (float)d[k]);
+    uint32_t u = f <= 0.0f ? 0u : (f >= 4294967040.0f ? 0xffffffffu : (uint32_t)f);
+    if (u > (uint32_t)(d[k] - 1)) u = (uint32_t)(d[k] - 1);
+    v[k] = (int)u;
+  }
+  update_voxel_and_neighbours(v[0], v[1], v[2], mc, cells, value);
+}
+
+// macrocell.cu:75-111 (one launch per z-slab there; one launch for the whole volume here)
+__global__ void update_macrocell_implicit_kernel(uint64_t n, vec3i dims, const float* __restrict__ vol, vec3i mc, float* __restrict__ cells)
+{
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const uint64_t stride = (uint64_t)dims.x * dims.y;
+  const uint32_t x = (uint32_t)(idx % dims.x), y = (uint32_t)((idx % stride) / dims.x), z = (uint32_t)(idx / stride);
+  const float fx = ((float)x + 0.5f) / (float)dims.x, fy = ((float)y + 0.5f) / (float)dims.y, fz = ((float)z + 0.5f) / (float)dims.z;
+  const float value = tex3d(vol, dims, fx, fy, fz);
+  update_voxel_and_neighbours((int)x, (int)y, (int)z, mc, cells, value);
+}
+
+// macrocell.cu:153-193 (TFN alphas staged in LDS; any block size)
+__global__ void macrocell_max_opacity_kernel(uint32_t n_cells, DeviceTfn tfn, const float* __restrict__ range, float* __restrict__ out)
+{
+  extern __shared__ float s_alphas[];
+  for (int j = threadIdx.x; j < tfn.n_alphas; j += blockDim.x) s_alphas[j] = tfn.alphas[j];
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cells) return;
+  const float rx = range[2 * (size_t)i] + 1.0f, ry = range[2 * (size_t)i + 1] - 1.0f;
+  const int len = tfn.n_alphas;
+  const float lower = (clampf(rx, tfn.range_lo, tfn.range_hi) - tfn.range_lo) * tfn.range_rcp_norm;
+  const float upper = (clampf(ry, tfn.range_lo, tfn.range_hi) - tfn.range_lo) * tfn.range_rcp_norm;
+  const float fl = __builtin_floorf(__builtin_fmaf(lower, (float)(len - 1), 0.5f)) - 1.0f;
+  const float fu = __builtin_floorf(__builtin_fmaf(upper, (float)(len - 1), 0.5f)) + 1.0f;
+  uint32_t il = fl <= 0.0f ? 0u : (uint32_t)fl, iu = fu <= 0.0f ? 0u : (uint32_t)fu;
+  if (il > (uint32_t)(len - 1)) il = (uint32_t)(len - 1);
+  if (iu > (uint32_t)(len - 1)) iu = (uint32_t)(len - 1);
+  float op = 0.0f;
+  for (uint32_t j = il; j <= iu; ++j) op = fmaxf(op, s_alphas[j]);
+  out[i] = op;
+}
+
+void MacroCell::set_shape(vec3i vd)
+{
+  MacroCell& t = target();
+  t.volume_dims_ = vd;
+  t.dims_ = {(vd.x + kMacrocellSize - 1) / kMacrocellSize, (vd.y + kMacrocellSize - 1) / kMacrocellSize,
+             (vd.z + kMacrocellSize - 1) / kMacrocellSize};
+  t.spacings_ = {(float)kMacrocellSize / (float)vd.x, (float)kMacrocellSize / (float)vd.y, (float)kMacrocellSize / (float)vd.z};
+}
+
+void MacroCell::allocate(hipStream_t s)
+{
+  external_ = nullptr;
+  const size_t n = (size_t)dims_.x * dims_.y * dims_.z;
+  value_range_.resize(2 * n);
+  value_range_.zero(s);
+  max_opacity_.resize(n);
+  max_opacity_.zero(s);
+}
+
+void MacroCell::compute_everything(const float* d_volume, hipStream_t s)
+{
+  const vec3i vd = volume_dims();
+  const uint64_t n = (uint64_t)vd.x * vd.y * vd.z;
+  update_macrocell_implicit_kernel<<<div_round_up(n, 256), 256, 0, s>>>(n, vd, d_volume, dims(), d_value_range());
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+void MacroCell::update_explicit(const float* d_coords, const float* d_values, size_t n, hipStream_t s)
+{
+  if (n == 0) return;
+  update_macrocell_explicit_kernel<<<div_round_up(n, 256), 256, 0, s>>>((uint32_t)n, d_coords, d_values, volume_dims(), dims(), d_value_range());
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+void MacroCell::update_max_opacity(const DeviceTfn& tfn, hipStream_t s)
+{
+  if (tfn.n_alphas <= 0 || !allocated()) return;  // macrocell.cu:245
+  const uint32_t n = (uint32_t)n_cells();
+  macrocell_max_opacity_kernel<<<div_round_up(n, 256), 256, (size_t)tfn.n_alphas * sizeof(float), s>>>(n, tfn, d_value_range(), d_max_opacity());
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+void MacroCell::upload_value_range(const void* host, size_t bytes, hipStream_t s)
+{
+  if (bytes != n_cells() * 2 * sizeof(float)) throw std::runtime_error("macrocell data has the wrong size");
+  VNR_HIP_CHECK(hipMemcpyAsync(d_value_range(), host, bytes, hipMemcpyHostToDevice, s));
+  VNR_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// ================================================================================================ sampler kernels
+struct Pcg32Dev {
+  uint64_t state, inc;
+  __device__ Pcg32Dev(uint64_t initstate, uint64_t initseq)
+  {
+    state = 0u; inc = (initseq << 1u) | 1u; next_uint(); state += initstate; next_uint();
+  }
+  __device__ uint32_t next_uint()
+  {
+    const uint64_t old = state;
+    state = old * 0x5851f42d4c957f2dULL + inc;
+    const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+  }
+  __device__ float next_float() { const uint32_t u = (next_uint() >> 9) | 0x3f800000u; return __uint_as_float(u) - 1.0f; }
+  __device__ void advance(uint64_t delta)
+  {
+    uint64_t cm = 0x5851f42d4c957f2dULL, cp = inc, am = 1u, ap = 0u;
+    while (delta > 0) {
+      if (delta & 1) { am *= cm; ap = ap * cm + cp; }
+      cp = (cm + 1) * cp; cm *= cm; delta >>= 1;
+    }
+    state = am * state + ap;
+  }
+};
+
+// neural_sampler.cu:130-164: p = lower + u * (upper - lower), value = tex3D(p) (cell-centred, clamp).
+// The random stream is pcg32(seed 1337) like tcnn's generate_random_uniform; element e of the call draws the
+// (offset + e)-th float of the stream (tcnn's thread-to-element mapping is EXTERNAL and not reproduced).
+__global__ void take_samples_kernel(uint32_t n, uint64_t seed, uint64_t stream, uint64_t offset, vec3f lower, vec3f scale,
+                                    const float* __restrict__ vol, vec3i dims, float* __restrict__ coords, float* __restrict__ values)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Pcg32Dev rng(seed, stream);
+  rng.advance(offset + 3ull * i);
+  const float ux = rng.next_float(), uy = rng.next_float(), uz = rng.next_float();
+  const float px = lower.x + ux * scale.x, py = lower.y + uy * scale.y, pz = lower.z + uz * scale.z;
+  coords[3 * (size_t)i + 0] = px; coords[3 * (size_t)i + 1] = py; coords[3 * (size_t)i + 2] = pz;
+  values[i] = tex3d(vol, dims, px, py, pz);
+}
+
+__global__ void sample_kernel(size_t n, const float* __restrict__ vol, vec3i dims, const float* __restrict__ coords,
+                              float* __restrict__ values, int nodal)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float px = coords[3 * i], py = coords[3 * i + 1], pz = coords[3 * i + 2];
+  values[i] = nodal ? sample_volume_nodal(vol, dims, px, py, pz) : tex3d(vol, dims, px, py, pz);
+}
+
+// core/network.cu:51-68 generate_coords
+__global__ void generate_coords_kernel(uint32_t n, vec3i lower, vec3i size, vec3f rdims, float* __restrict__ coords)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t stride = (uint64_t)size.x * size.y;
+  const int x = lower.x + (int)(i % size.x), y = lower.y + (int)((i % stride) / size.x), z = lower.z + (int)(i / stride);
+  coords[3 * (size_t)i + 0] = ((float)x + 0.5f) * rdims.x;
+  coords[3 * (size_t)i + 1] = ((float)y + 0.5f) * rdims.y;
+  coords[3 * (size_t)i + 2] = ((float)z + 0.5f) * rdims.z;
+}
+
+// seeded gradient-noise fBm (synthetic stand-in for the 1024^3 / 4096^3 volumes of BASELINE C4 / C5)
+__device__ __forceinline__ uint32_t hash3(uint32_t x, uint32_t y, uint32_t z, uint32_t seed)
+{
+  uint32_t h = seed ^ (x * 0x9e3779b1u) ^ (y * 0x85ebca77u) ^ (z * 0xc2b2ae3du);
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ float grad3(uint32_t h, float x, float y, float z)
+{
+  const uint32_t g = h & 15u;
+  const float u = g < 8 ? x : y;
+  const float v = g < 4 ? y : ((g == 12 || g == 14) ? x : z);
+  return ((g & 1) ? -u : u) + ((g & 2) ? -v : v);
+}
+__device__ __forceinline__ float fade(float t) { return t * t * t * (t * (t * 6.0f - 15.0f) + 10.0f); }
+__device__ float perlin3(float x, float y, float z, uint32_t seed)
+{
+  const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+  const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy, iz = (uint32_t)(int)fz;
+  const float rx = x - fx, ry = y - fy, rz = z - fz;
+  const float u = fade(rx), v = fade(ry), w = fade(rz);
+  float c[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
+    c[k] = grad3(hash3(ix + dx, iy + dy, iz + dz, seed), rx - (float)dx, ry - (float)dy, rz - (float)dz);
+  }
+  const float x00 = c[0] + u * (c[1] - c[0]), x10 = c[2] + u * (c[3] - c[2]);
+  const float x01 = c[4] + u * (c[5] - c[4]), x11 = c[6] + u * (c[7] - c[6]);
+  const float y0 = x00 + v * (x10 - x00), y1 = x01 + v * (x11 - x01);
+  return y0 + w * (y1 - y0);
+}
+__global__ void perlin_volume_kernel(uint64_t n, vec3i dims, uint32_t seed, int octaves, float base_freq, float* __restrict__ out)
+{
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const uint64_t stride = (uint64_t)dims.x * dims.y;
+  const uint32_t x = (uint32_t)(idx % dims.x), y = (uint32_t)((idx % stride) / dims.x), z = (uint32_t)(idx / stride);
+  const float px = ((float)x + 0.5f) / (float)dims.x, py = ((float)y + 0.5f) / (float)dims.y, pz = ((float)z + 0.5f) / (float)dims.z;
+  float sum = 0.0f, amp = 1.0f, norm = 0.0f, f = base_freq;
+  for (int o = 0; o < octaves; ++o) {
+    sum += amp * perlin3(px * f, py * f, pz * f, seed + 0x632be5abu * (uint32_t)o);
+    norm += amp; amp *= 0.5f; f *= 2.0f;
+  }
+  // a soft spherical envelope leaves genuinely empty space near the corners, like real scans
+  const float dx = px - 0.5f, dy = py - 0.5f, dz = pz - 0.5f;
+  const float r2 = (dx * dx + dy * dy + dz * dz) * 4.0f;  // 1 at the face centres
+  const float env = fminf(fmaxf(1.35f - r2, 0.0f), 1.0f);
+  const float v = (0.5f + 0.85f * sum / norm) * env;
+  out[idx] = fminf(fmaxf(v, 0.0f), 1.0f);
+}
+
+// ================================================================================================ SimpleVolume
+void SimpleVolume::set_transfer_function(const TransferFunctionData& t, hipStream_t s)
+{
+  tfn_.set(t, 0.0f, 1.0f, s);
+  mc_.update_max_opacity(tfn_.view(), s);
+}
+
+void SimpleVolume::finish_load(hipStream_t s)
+{
+  // core/sampler.cu:5-17 + neural_sampler.cpp:1270: object->world = translate(-dims/2) * scale(dims)
+  const vec3f d = {(float)desc.dims.x, (float)desc.dims.y, (float)desc.dims.z};
+  transform = {{d.x, 0, 0}, {0, d.y, 0}, {0, 0, d.z}, {-d.x / 2.0f, -d.y / 2.0f, -d.z / 2.0f}};
+  clipbox = {{0, 0, 0}, {1, 1, 1}};
+  mc_.set_shape(desc.dims);
+  mc_.allocate(s);
+  mc_.compute_everything(data_.ptr, s);
+  VNR_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+template <typename T>
+static void convert_chunk(const uint8_t* src, float* dst, size_t lo, size_t hi, bool swap, float vmin, float vmax, bool pass_minmax,
+                          double* omin, double* omax)
+{
+  double mn = 1e300, mx = -1e300;
+  for (size_t i = lo; i < hi; ++i) {
+    T v;
+    uint8_t b[sizeof(T)];
+    std::memcpy(b, src + i * sizeof(T), sizeof(T));
+    if (swap) std::reverse(b, b + sizeof(T));
+    std::memcpy(&v, b, sizeof(T));
+    const float f = (float)v;
+    if (pass_minmax) { mn = std::min(mn, (double)v); mx = std::max(mx, (double)v); }
+    else {
+      const float nv = (f - vmin) / (vmax - vmin);  // neural_sampler.cpp:176-210 convert_volume
+      dst[i] = nv < 0.0f ? 0.0f : (nv > 1.0f ? 1.0f : nv);
+    }
+  }
+  if (pass_minmax) { *omin = mn; *omax = mx; }
+}
+
+static size_t type_size(int type)
+{
+  switch (type) {
+  case 0: case 1: return 1;
+  case 2: case 3: return 2;
+  case 4: case 5: case 8: return 4;
+  case 6: case 7: case 12: return 8;
+  default: throw std::runtime_error("unknown data type");
+  }
+}
+
+void SimpleVolume::load_host(const void* data, vec3i dims, int type, float range_lo, float range_hi, bool big_endian)
+{
+  if (dims.x <= 0 || dims.y <= 0 || dims.z <= 0) throw std::runtime_error("invalid volume dims");
+  const size_t count = (size_t)dims.x * dims.y * dims.z;
+  const uint8_t* src = (const uint8_t*)data;
+  std::vector<float> out(count);
+  const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  auto run = [&](bool minmax, float lo, float hi, double* gmin, double* gmax) {
+    std::vector<std::thread> th;
+    std::vector<double> mins(nt, 1e300), maxs(nt, -1e300);
+    for (unsigned t = 0; t < nt; ++t) {
+      const size_t a = count * t / nt, b = count * (t + 1) / nt;
+      th.emplace_back([&, a, b, t]() {
+        switch (type) {
+        case 0: convert_chunk<uint8_t>(src, out.data(), a, b, false, lo, hi, minmax, &mins[t], &maxs[t]); break;
+        case 1: convert_chunk<int8_t>(src, out.data(), a, b, false, lo, hi, minmax, &mins[t], &maxs[t]); break;
+        case 2: convert_chunk<uint16_t>(src, out.data(), a, b, big_endian, lo, hi, minmax, &mins[t], &maxs[t]); break;
+        case 3: convert_chunk<int16_t>(src, out.data(), a, b, big_endian, lo, hi, minmax, &mins[t], &maxs[t]); break;
+        case 4: convert_chunk<uint32_t>(src, out.data(), a, b, big_endian, lo, hi, minmax, &mins[t], &maxs[t]); break;
+        case 5: convert_chunk<int32_t>(src, out.data(), a, b, big_endian, lo, hi, minmax, &mins[t], &maxs[t]); break;
+        case 8: convert_chunk<float>(src, out.data(), a, b, big_endian, lo, hi, minmax, &mins[t], &maxs[t]); break;
+        case 12: convert_chunk<double>(src, out.data(), a, b, big_endian, lo, hi, minmax, &mins[t], &maxs[t]); break;
+        default: break;
+        }
+      });
+    }
+    for (auto& t : th) t.join();
+    if (minmax) { *gmin = *std::min_element(mins.begin(), mins.end()); *gmax = *std::max_element(maxs.begin(), maxs.end()); }
+  };
+  (void)type_size(type);
+  if (range_lo > range_hi) {  // minmax.is_empty(): compute from the data (neural_sampler.cpp:252-265)
+    double mn, mx;
+    run(true, 0, 1, &mn, &mx);
+    range_lo = (float)mn; range_hi = (float)mx;
+  }
+  run(false, range_lo, range_hi, nullptr, nullptr);
+  unnormalized_lo = range_lo; unnormalized_hi = range_hi;
+  desc.dims = dims; desc.type = 8; desc.range_lo = 0.0f; desc.range_hi = 1.0f;
+  hipStream_t s = Runtime::get().stream;
+  data_.resize(count);
+  data_.upload(out.data(), count, s);
+  VNR_HIP_CHECK(hipStreamSynchronize(s));
+  finish_load(s);
+}
+
+void SimpleVolume::load_raw_file(const std::string& filename, vec3i dims, int type, size_t offset, bool big_endian, float range_lo, float range_hi)
+{
+  const size_t bytes = (size_t)dims.x * dims.y * dims.z * type_size(type);
+  std::ifstream f(filename, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot open volume file: " + filename);
+  f.seekg((std::streamoff)offset);
+  std::vector<char> buf(bytes);
+  if (!f.read(buf.data(), (std::streamsize)bytes)) throw std::runtime_error("volume file too short: " + filename);
+  load_host(buf.data(), dims, type, range_lo, range_hi, big_endian);
+}
+
+void SimpleVolume::generate_perlin(vec3i dims, uint32_t seed, int octaves, float base_frequency)
+{
+  if (!Runtime::get().ready()) Runtime::get().init(-1);
+  hipStream_t s = Runtime::get().stream;
+  const uint64_t n = (uint64_t)dims.x * dims.y * dims.z;
+  data_.resize(n);
+  perlin_volume_kernel<<<div_round_up(n, 256), 256, 0, s>>>(n, dims, seed, octaves, base_frequency, data_.ptr);
+  VNR_HIP_CHECK(hipGetLastError());
+  desc.dims = dims; desc.type = 8; desc.range_lo = 0.0f; desc.range_hi = 1.0f;
+  unnormalized_lo = 0.0f; unnormalized_hi = 1.0f;
+  finish_load(s);
+}
+
+void SimpleVolume::take_samples(float* d_coords, float* d_values, size_t n, vec3f lower, vec3f upper, hipStream_t s)
+{
+  if (n == 0) return;
+  const vec3f scale = upper - lower;
+  take_samples_kernel<<<div_round_up(n, 256), 256, 0, s>>>((uint32_t)n, rng_seed_, rng_stream_, rng_offset_, lower, scale, data_.ptr,
+                                                          desc.dims, d_coords, d_values);
+  VNR_HIP_CHECK(hipGetLastError());
+  rng_offset_ += 3ull * n;
+}
+
+void SimpleVolume::take_samples_grid(float* d_coords, float* d_values, vec3i origin, vec3i size, vec3f rdims, hipStream_t s)
+{
+  const uint32_t n = (uint32_t)((size_t)size.x * size.y * size.z);
+  if (n == 0) return;
+  generate_coords_kernel<<<div_round_up(n, 256), 256, 0, s>>>(n, origin, size, rdims, d_coords);
+  sample(d_coords, d_values, n, false, s);
+}
+
+void SimpleVolume::sample(const float* d_coords, float* d_values, size_t n, bool nodal, hipStream_t s) const
+{
+  if (n == 0) return;
+  sample_kernel<<<div_round_up(n, 256), 256, 0, s>>>(n, data_.ptr, desc.dims, d_coords, d_values, nodal ? 1 : 0);
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+// ================================================================================================ reductions for loss / PSNR
+__global__ void error_reduce_kernel(uint32_t n, const float* __restrict__ pred, const float* __restrict__ ref, int l2,
+                                    float* __restrict__ partial /* [blocks][3]: sum, min(ref), max(ref) */)
+{
+  __shared__ float ssum[256], smin[256], smax[256];
+  float sum = 0.0f, mn = 1e20f, mx = -1e20f;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float d = pred[i] - ref[i];
+    sum += l2 ? d * d : fabsf(d);
+    mn = fminf(mn, ref[i]); mx = fmaxf(mx, ref[i]);
+  }
+  ssum[threadIdx.x] = sum; smin[threadIdx.x] = mn; smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + s];
+      smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+      smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[3 * blockIdx.x] = ssum[0]; partial[3 * blockIdx.x + 1] = smin[0]; partial[3 * blockIdx.x + 2] = smax[0]; }
+}
+
+static void reduce_errors(const float* pred, const float* ref, size_t n, bool l2, double* sum, float* mn, float* mx, hipStream_t s)
+{
+  const uint32_t blocks = std::min<uint32_t>(div_round_up(n, 256), 512u);
+  DeviceBuffer<float> partial;
+  partial.resize(3 * blocks);
+  error_reduce_kernel<<<blocks, 256, 0, s>>>((uint32_t)n, pred, ref, l2 ? 1 : 0, partial.ptr);
+  std::vector<float> h(3 * blocks);
+  partial.download(h.data(), h.size(), s);
+  for (uint32_t b = 0; b < blocks; ++b) { *sum += h[3 * b]; *mn = std::min(*mn, h[3 * b + 1]); *mx = std::max(*mx, h[3 * b + 2]); }
+}
+
+// ================================================================================================ NeuralVolume
+void network_release_scratch(const Network* n);
+
+NeuralVolume::NeuralVolume()
+{
+  if (!Runtime::get().ready()) Runtime::get().init(-1);
+  stream = Runtime::get().stream;
+}
+
+NeuralVolume::~NeuralVolume() { network_release_scratch(&net_); }
+
+void NeuralVolume::set_transfer_function(const TransferFunctionData& t, hipStream_t s)
+{
+  tfn_.set(t, 0.0f, 1.0f, s);
+  mc_.update_max_opacity(tfn_.view(), s);  // network.cu:751
+}
+
+void NeuralVolume::set_network(vec3i dims, const Json& config, SimpleVolume* reference, bool use_reference_macrocell)
+{
+  source_ = reference;
+  use_reference_macrocell = source_ && use_reference_macrocell;
+  if (source_) {  // network.cu:563-570
+    desc.dims = source_->dims();
+    transform = source_->transform;
+  } else {
+    desc.dims = dims;
+    const vec3f d = {(float)dims.x, (float)dims.y, (float)dims.z};
+    transform = {{d.x, 0, 0}, {0, d.y, 0}, {0, 0, d.z}, {-d.x / 2.0f, -d.y / 2.0f, -d.z / 2.0f}};
+  }
+  desc.type = 8; desc.range_lo = 0.0f; desc.range_hi = 1.0f;
+  if (config.contains("fvsrn")) throw std::runtime_error("fvsrn is not enabled");  // network.cu:572-578
+  const uint64_t seed = init_seed ? init_seed : (uint64_t)time(nullptr);             // tcnn_network.h:209
+  net_.configure(config, seed);
+  train_x_.resize(batch_size_ * 3);
+  train_y_.resize(batch_size_);
+  test_y1_.resize(batch_size_);
+  if (use_reference_macrocell) {
+    mc_.set_external(&reference->macrocell());
+  } else {
+    mc_.set_external(nullptr);
+    mc_.set_shape(desc.dims);
+    mc_.allocate(stream);
+  }
+  VNR_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void NeuralVolume::set_model(const Json& config)
+{
+  const uint64_t seed = init_seed ? init_seed : (uint64_t)time(nullptr);
+  net_.configure(config, seed);
+}
+
+void NeuralVolume::train_begin()
+{
+  if (!net_.valid()) return;
+  if (!source_) throw std::runtime_error("missing a reference volume");  // network.cu:233-235 prints and returns
+  const vec3f lower = {0, 0, 0}, upper = {1, 1, 1};  // m_lower/m_upper = full volume (network.cu:605)
+  source_->take_samples(train_x_.ptr, train_y_.ptr, batch_size_, lower, upper, stream);
+  net_.forward_backward(train_x_.ptr, train_y_.ptr, batch_size_, stream);
+  pending_step_ = true;
+}
+
+void NeuralVolume::train_end(float grad_scale, bool fast_mode)
+{
+  if (!pending_step_) return;
+  net_.optimizer_step(grad_scale, stream);
+  // network.cu:249-257, 774: the macrocell is trained online unless (fast_mode && external macrocell)
+  const bool update_mc = !(fast_mode && mc_.is_external());
+  if (update_mc && !mc_.is_external()) mc_.update_explicit(train_x_.ptr, train_y_.ptr, batch_size_, stream);
+  pending_step_ = false;
+}
+
+void NeuralVolume::train(size_t steps, bool fast_mode)
+{
+  if (!net_.valid()) return;
+  for (size_t i = 0; i < steps; ++i) {
+    train_begin();
+    train_end(1.0f, fast_mode);
+  }
+  if (!fast_mode) mc_.update_max_opacity(tfn_.view(), stream);  // network.cu:778
+}
+
+float NeuralVolume::test_loss()
+{
+  if (!net_.valid()) return 0.0f;
+  if (!source_) throw std::runtime_error("missing a reference volume");
+  const vec3f lower = {0, 0, 0}, upper = {1, 1, 1};
+  source_->take_samples(train_x_.ptr, train_y_.ptr, batch_size_, lower, upper, stream);
+  net_.inference(train_x_.ptr, test_y1_.ptr, batch_size_, nullptr, batch_size_, stream);
+  double sum = 0.0; float mn = 1e20f, mx = -1e20f;
+  reduce_errors(test_y1_.ptr, train_y_.ptr, batch_size_, false, &sum, &mn, &mx, stream);  // l1_loss, network.cu:283
+  return (float)(sum / (double)batch_size_);
+}
+
+float NeuralVolume::get_psnr(bool /*quiet*/)
+{
+  if (!source_) throw std::runtime_error("missing a reference volume");
+  const vec3i dims = desc.dims;
+  const vec3f rdims = {1.0f / (float)dims.x, 1.0f / (float)dims.y, 1.0f / (float)dims.z};
+  const vec3i batch = {std::min(4096, dims.x), std::min(16, dims.y), std::min(16, dims.z)};  // network.cu:418
+  const size_t N = (size_t)batch.x * batch.y * batch.z;
+  DeviceBuffer<float> coords, pred, ref;
+  coords.resize(3 * N); pred.resize(N); ref.resize(N);
+  double err = 0.0; float vmin = 1e20f, vmax = -1e20f;
+  for (int z = 0; z < dims.z; z += batch.z)
+    for (int y = 0; y < dims.y; y += batch.y)
+      for (int x = 0; x < dims.x; x += batch.x) {
+        const vec3i off = {x, y, z};
+        const vec3i blk = {std::min(batch.x, dims.x - x), std::min(batch.y, dims.y - y), std::min(batch.z, dims.z - z)};
+        const size_t count = (size_t)blk.x * blk.y * blk.z;
+        if (count == 0) continue;
+        source_->take_samples_grid(coords.ptr, ref.ptr, off, blk, rdims, stream);
+        net_.inference(coords.ptr, pred.ptr, count, nullptr, count, stream);
+        reduce_errors(pred.ptr, ref.ptr, count, true, &err, &vmin, &vmax, stream);
+      }
+  const double range = (double)vmax - (double)vmin;
+  const double mse = err / ((double)dims.x * dims.y * dims.z);
+  return (float)(10.0 * std::log10(range * range / mse));  // network.cu:469-471
+}
+
+void NeuralVolume::inference(size_t n, const float* d_in, float* d_out, hipStream_t s)
+{
+  if (!net_.valid()) return;
+  net_.inference(d_in, d_out, n, nullptr, n, s);
+}
+
+void NeuralVolume::save_params_to_json(Json& root)
+{
+  const vec3i md = mc_.dims();
+  const vec3f ms = mc_.spacings();
+  std::vector<float> h(mc_.n_cells() * 2);
+  VNR_HIP_CHECK(hipMemcpyAsync(h.data(), mc_.d_value_range(), h.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+  VNR_HIP_CHECK(hipStreamSynchronize(stream));
+  Json vol = Json::object(), vdims = Json::object();
+  vdims["x"] = desc.dims.x; vdims["y"] = desc.dims.y; vdims["z"] = desc.dims.z;
+  vol["dims"] = vdims;
+  root["volume"] = vol;
+  Json mc = Json::object(), mdims = Json::object(), msp = Json::object();
+  mdims["x"] = md.x; mdims["y"] = md.y; mdims["z"] = md.z;
+  msp["x"] = ms.x; msp["y"] = ms.y; msp["z"] = ms.z;
+  mc["groundtruth"] = mc_.is_external();
+  mc["dims"] = mdims;
+  mc["spacings"] = msp;
+  mc["data"] = Json::binary(h.data(), h.size() * sizeof(float));
+  root["macrocell"] = mc;
+  root["parameters"] = net_.serialize_params(stream);
+  root["model"] = net_.model_json();
+}
+
+void NeuralVolume::load_params_from_json(const Json& root)
+{
+  if (root.contains("volume")) {
+    const Json& d = root.at("volume").at("dims");
+    const vec3i dims = {(int)d.at("x").as_int(), (int)d.at("y").as_int(), (int)d.at("z").as_int()};
+    if (dims.x != desc.dims.x || dims.y != desc.dims.y || dims.z != desc.dims.z) throw std::runtime_error("mismatch data dimension");
+  }
+  if (root.contains("macrocell")) {
+    const Json& m = root.at("macrocell");
+    const vec3i md = {(int)m.at("dims").at("x").as_int(), (int)m.at("dims").at("y").as_int(), (int)m.at("dims").at("z").as_int()};
+    const vec3f ms = {m.at("spacings").at("x").as_float(), m.at("spacings").at("y").as_float(), m.at("spacings").at("z").as_float()};
+    const vec3i cd = mc_.dims();
+    const vec3f cs = mc_.spacings();
+    if (md.x != cd.x || md.y != cd.y || md.z != cd.z || ms.x != cs.x || ms.y != cs.y || ms.z != cs.z || !mc_.allocated()) {
+      mc_.set_external(nullptr);
+      mc_.set_shape(desc.dims);  // keeps volume dims for explicit updates
+      mc_.set_dims(md);
+      mc_.set_spacings(ms);
+      mc_.allocate(stream);
+    }
+    const std::string& bin = m.at("data").as_binary();
+    mc_.upload_value_range(bin.data(), bin.size(), stream);
+    mc_.update_max_opacity(tfn_.view(), stream);
+  }
+  if (root.contains("model")) net_.configure(root.at("model"), init_seed ? init_seed : 1);
+  if (root.contains("parameters")) net_.deserialize_params(root.at("parameters"), stream);
+  else net_.deserialize_params(root, stream);  // legacy format, network.cu:934-936
+}
+
+}  // namespace vnr

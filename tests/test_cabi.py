@@ -1,0 +1,107 @@
+"""CPU-side checks of the drop-in boundary: libvnr_amd.so loads, exports every symbol include/vnr_amd.h
+declares, and the host-only entry points (JSON text <-> BSON, handles, error convention) behave like the
+reference's api.cpp.  No compute call is made here."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from instantvnr_amd import _lib, api
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(L):
+    names = _lib.declared_symbols()
+    assert len(names) > 80
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert b"gfx950" in L.vnrAmdVersion()
+
+
+def test_header_cites_reference_for_api_functions():
+    text = open(_lib.HEADER).read()
+    for ref in ["api.h:28", "api.cpp:174-188", "api.cpp:206-220", "network.cu:1043-1052", "renderer.h:84-94"]:
+        assert ref in text
+
+
+def test_json_text_with_comments_to_bson_and_back(L):
+    text = """{ // model, like example-model.json
+      "loss": {"otype": "L1"}, /* block */ "n": 3, "big": 5000000000, "f": 0.5, "neg": -7,
+      "arr": [1, 2.5, "x", null, true], "s": "h\\u00e9llo\\n" }"""
+    b = api.json_to_bson(text)
+    back = json.loads(api.bson_to_json_text(b))
+    assert back == {"loss": {"otype": "L1"}, "n": 3, "big": 5000000000, "f": 0.5, "neg": -7,
+                    "arr": [1, 2.5, "x", None, True], "s": "héllo\n"}
+    bson = pytest.importorskip("bson")
+    dec = bson.decode(b)
+    assert dec["big"] == 5000000000 and dec["arr"] == [1, 2.5, "x", None, True]
+    # byte-identical to pymongo's encoder when keys are sorted (nlohmann's std::map order)
+    want = bson.encode({k: back[k] for k in sorted(back)})
+    assert b == want
+
+
+def test_bson_binary_roundtrip_matches_pymongo(L):
+    bson = pytest.importorskip("bson")
+    blob = np.arange(300, dtype=np.uint16).tobytes()
+    doc = {"parameters": {"n_params": 300, "params_binary": bson.Binary(blob, 0), "params_type": "__half"},
+           "volume": {"dims": {"x": 4, "y": 5, "z": 6}}}
+    enc = bson.encode(doc)
+    out = C.c_void_p()
+    n = C.c_size_t()
+    _lib.check(L.vnrAmdJsonConvert(enc, len(enc), api.JSON_BSON, api.JSON_BSON, C.byref(out), C.byref(n)))
+    again = C.string_at(out, n.value)
+    L.vnrAmdFreeHost(out)
+    assert again == enc
+
+
+def test_json_save_and_load_files(L, tmp_path):
+    p = str(tmp_path / "m.json")
+    api.vnrSaveJsonText({"a": 1, "b": [1, 2]}, p)
+    assert api.vnrCreateJsonText(p) == {"a": 1, "b": [1, 2]}
+    q = str(tmp_path / "m.bson")
+    api.vnrSaveJsonBinary({"a": 1, "b": [1, 2]}, q)
+    assert json.loads(api.bson_to_json_text(api.vnrCreateJsonBinary(q))) == {"a": 1, "b": [1, 2]}
+
+
+def test_error_convention(L):
+    out = C.c_void_p()
+    n = C.c_size_t()
+    bad = b"{ not json"
+    assert L.vnrAmdJsonConvert(bad, len(bad), 0, 1, C.byref(out), C.byref(n)) != 0
+    assert b"json parse error" in L.vnrAmdGetLastError()
+    with pytest.raises(api.VnrAmdError):
+        api.vnrCreateJsonText("/nonexistent/file.json")
+    # params without volume.dims: api.cpp:214-216
+    b = api.json_to_bson({"model": {}})
+    assert not L.vnrAmdCreateNeuralVolumeFromParams(b, len(b), api.JSON_BSON)
+    assert b"volume dims" in L.vnrAmdGetLastError()
+
+
+def test_camera_and_tfn_handles(L):
+    cam = api.vnrCreateCamera()
+    api.vnrCameraSet(cam, (1, 2, 3), (0, 0, 0), (0, 1, 0))
+    assert np.allclose(api.vnrCameraGetPosition(cam), (1, 2, 3))
+    assert np.allclose(api.vnrCameraGetFocus(cam), 0) and np.allclose(api.vnrCameraGetUpVec(cam), (0, 1, 0))
+    t = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(t, [[0, 0, 0], [1, 1, 1]])
+    api.vnrTransferFunctionSetAlpha(t, [0.0, 0.5, 1.0])
+    api.vnrTransferFunctionSetValueRange(t, (0, 1))
+    nc, na = C.c_int(), C.c_int()
+    _lib.check(L.vnrAmdTransferFunctionGetSizes(t.h, C.byref(nc), C.byref(na)))
+    assert (nc.value, na.value) == (2, 3)
+
+
+def test_no_cpu_fallback_without_device(L):
+    if L.vnrAmdHasDevice():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.VnrAmdError):
+        api.vnrCreateNeuralVolume({"encoding": {"otype": "HashGrid"}, "network": {"otype": "FullyFusedMLP", "n_neurons": 64}},
+                                  (8, 8, 8))

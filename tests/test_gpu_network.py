@@ -1,0 +1,141 @@
+"""GPU parity: fused hash-grid encode + MLP kernel (through the C-ABI) vs the CPU oracle.
+
+Bar: the encode is fp16 bit-exact; the network output is within 2^-8 absolute of the oracle's
+fp32-accumulate MLP (the gap between fp16-accumulate and fp32-accumulate MMA)."""
+import numpy as np
+import pytest
+
+from instantvnr_amd import api
+from instantvnr_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+TOL_ABS = 2.0 ** -8
+
+CONFIGS = [
+    # (L, F, log2T, base, per_level_scale, hidden_layers)
+    (8, 8, 19, 16, None, 2),      # BASELINE C2
+    (16, 2, 19, 16, 1.3195, 3),   # BASELINE C4 shape (T=2^19 variant)
+    (8, 8, 19, 16, None, 4),      # example-model.json
+    (4, 4, 12, 8, None, 1),
+    (16, 1, 14, 4, 1.5, 2),
+    (5, 2, 10, 3, None, 2),       # padded width 16 with 10 real features
+    (12, 4, 15, 8, 1.4, 3),       # padded width 48
+    (2, 8, 8, 2, None, 2),
+]
+
+
+def make(oracle, L, F, log2T, base, pls, H, seed=0, interpolation="Linear"):
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base,
+                           n_hidden_layers=H, per_level_scale=pls)
+    cfg["encoding"]["interpolation"] = interpolation
+    vol = api.vnrCreateNeuralVolume(cfg, (32, 32, 32))
+    info = api.neural_info(vol)
+    ocfg = oracle.grid_config(L, F, log2T, base, 2.0 if pls is None else pls, 1 if interpolation == "Smoothstep" else 0)
+    assert info["n_params"] == oracle.n_params(ocfg, 64, H)
+    assert info["padded_width"] == oracle.padded_width(ocfg)
+    n_mlp = oracle.mlp_n_params(info["padded_width"], 64, H - 1)
+    params = syn.random_params(info["n_params"], n_mlp, seed=seed)
+    api.neural_set_params_fp16(vol, params)
+    return vol, ocfg, params, n_mlp
+
+
+def coords_for(n, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    c[0] = (0, 0, 0); c[1] = (1, 1, 1); c[2] = (0.5, 0.5, 0.5); c[3] = (1, 0, 0.999999)
+    return c
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_encode_bit_exact(oracle, cfg):
+    L, F, log2T, base, pls, H = cfg
+    vol, ocfg, params, n_mlp = make(oracle, L, F, log2T, base, pls, H)
+    coords = coords_for(3000, 1)  # ragged: not a multiple of 64 or 256
+    got = api.neural_encode(vol, coords)
+    want = oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords).view(np.float16)
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+def test_encode_smoothstep_bit_exact(oracle):
+    vol, ocfg, params, n_mlp = make(oracle, 6, 2, 12, 4, None, 2, interpolation="Smoothstep")
+    coords = coords_for(1000, 2)
+    got = api.neural_encode(vol, coords)
+    want = oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords).view(np.float16)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_inference_within_tolerance(oracle, cfg):
+    L, F, log2T, base, pls, H = cfg
+    vol, ocfg, params, n_mlp = make(oracle, L, F, log2T, base, pls, H, seed=3)
+    coords = coords_for(4097, 4)
+    got = api.neural_inference(vol, coords)
+    want = oracle.network_inference(ocfg, 64, H, params.view(np.uint16), coords)
+    err = np.abs(got - want)
+    assert np.isfinite(got).all()
+    assert np.abs(want).max() > 0.05          # the test is not vacuous
+    assert err.max() <= TOL_ABS * max(1.0, np.abs(want).max()), (err.max(), np.abs(want).max())
+    # the bulk is far tighter than the bound (only fp32 summation order + one fp16 rounding differ)
+    assert np.median(err) <= 2.0 ** -11 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 256, 257, 8191])
+def test_ragged_batch_sizes(oracle, n):
+    vol, ocfg, params, n_mlp = make(oracle, 8, 2, 14, 8, None, 2, seed=5)
+    coords = coords_for(max(n, 4), 6)[:n]
+    got = api.neural_inference(vol, coords)
+    want = oracle.network_inference(ocfg, 64, 2, params.view(np.uint16), coords)
+    assert got.shape == (n,)
+    assert np.abs(got - want).max() <= TOL_ABS * max(1.0, np.abs(want).max())
+
+
+def test_empty_batch_is_a_noop(oracle):
+    vol, *_ = make(oracle, 4, 2, 10, 4, None, 2)
+    assert api.neural_inference(vol, np.zeros((0, 3), np.float32)).shape == (0,)
+
+
+def test_out_of_domain_and_nan_coords_do_not_fault(oracle):
+    vol, ocfg, params, n_mlp = make(oracle, 8, 2, 12, 8, None, 2, seed=7)
+    coords = np.array([[-0.5, 0.5, 0.5], [1.5, 1.5, 1.5], [np.nan, 0.1, 0.2], [1e9, -1e9, 0.0]], np.float32)
+    got = api.neural_encode(vol, coords)
+    want = oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords[:2]).view(np.float16)
+    assert np.array_equal(got[:2].view(np.uint16), want.view(np.uint16))  # exact modulo semantics kept
+
+
+def test_linearity_of_last_layer_at_scale(oracle):
+    """size-independent property at BASELINE scale (1M samples, C4-shaped model): scaling the output layer by
+    2 doubles every output exactly (power-of-two scaling commutes with fp16/fp32 rounding)."""
+    L, F, log2T, base, pls, H = 16, 2, 19, 16, 1.3195, 3
+    vol, ocfg, params, n_mlp = make(oracle, L, F, log2T, base, pls, H, seed=8)
+    coords = np.random.default_rng(9).uniform(0, 1, (1 << 20, 3)).astype(np.float32)
+    y1 = api.neural_inference(vol, coords)
+    p2 = params.copy()
+    last = slice(n_mlp - 16 * 64, n_mlp)
+    p2[last] = (p2[last].astype(np.float32) * 2).astype(np.float16)
+    api.neural_set_params_fp16(vol, p2)
+    y2 = api.neural_inference(vol, coords)
+    assert np.array_equal(y2, 2 * y1)
+    # and a sampled subset agrees with the oracle
+    idx = np.random.default_rng(10).choice(coords.shape[0], 2048, replace=False)
+    want = oracle.network_inference(ocfg, 64, H, params.view(np.uint16), coords[idx])
+    assert np.abs(y1[idx] - want).max() <= TOL_ABS * max(1.0, np.abs(want).max())
+
+
+def test_params_roundtrip_and_bson(oracle, tmp_path):
+    vol, ocfg, params, n_mlp = make(oracle, 4, 4, 12, 8, None, 2, seed=11)
+    back = api.neural_get_params_fp16(vol)
+    assert np.array_equal(back.view(np.uint16), params.view(np.uint16))
+    path = str(tmp_path / "params.json")
+    api.vnrNeuralVolumeSerializeParams(vol, path)
+    vol2 = api.vnrCreateNeuralVolume(path)   # vnrCreateNeuralVolume(params) overload, BSON file
+    coords = coords_for(512, 12)
+    assert np.array_equal(api.neural_inference(vol, coords), api.neural_inference(vol2, coords))
+    bson = pytest.importorskip("bson")
+    doc = bson.decode(open(path, "rb").read())
+    assert doc["volume"]["dims"] == {"x": 32, "y": 32, "z": 32}
+    assert doc["parameters"]["params_type"] == "__half" and doc["parameters"]["n_params"] == params.size
+    assert bytes(doc["parameters"]["params_binary"]) == params.tobytes()
+    assert doc["macrocell"]["dims"] == {"x": 2, "y": 2, "z": 2} and len(doc["macrocell"]["data"]) == 8 * 8
+    assert doc["model"]["encoding"]["n_levels"] == 4

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native instantvnr hot path.
+
+Metric (BASELINE.json): fps at 1024^2 on a 1024^3 volume + MLP Msamples/s; PSNR vs ground truth.
+One "step" = one frame: sample-streaming ray march (rendering mode 5) of the trained neural volume
+(HashGrid L=16 F=2 T=2^22 + 3x64 FullyFusedMLP) at 1024x1024; with N GPUs the image is sharded by interleaved
+scanline blocks and gathered with one RCCL all_gather per frame (strong scaling: total work is fixed).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Untimed setup: generate the synthetic 1024^3 Perlin volume on the GPU, train the model (data parallel with an RCCL
+gradient all-reduce when N > 1), build the renderer.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from instantvnr_amd import api, dist, synthetic as syn  # noqa: E402
+from instantvnr_amd._lib import check, lib  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--size", type=int, default=1024, help="volume edge (C4: 1024)")
+    p.add_argument("--fb", type=int, default=1024, help="framebuffer edge (C4: 1024)")
+    p.add_argument("--levels", type=int, default=16)
+    p.add_argument("--features", type=int, default=2)
+    p.add_argument("--log2-hashmap-size", type=int, default=22)
+    p.add_argument("--hidden-layers", type=int, default=3)
+    p.add_argument("--per-level-scale", type=float, default=0.0, help="0 = finest level resolution equals the volume edge")
+    p.add_argument("--train-steps", type=int, default=1500)
+    p.add_argument("--opacity-scale", type=float, default=0.12)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-psnr", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(sv, dims, tfn_np, cam, fb, mc):
+    """the oracle's monolithic ground-truth ray marcher (mode-4 semantics: manual trilinear, macrocell DDA, adaptive
+    step, TFN, compositing) on the host cores, on a bounded sample of scanline blocks of the same frame"""
+    from oracle import oracle
+    import ctypes as C
+    n = dims[0] * dims[1] * dims[2]
+    host = np.empty(n, dtype=np.float32)
+    t0 = time.perf_counter()
+    check(lib().vnrAmdMemcpyD2H(host.ctypes.data_as(C.c_void_p), lib().vnrAmdSimpleVolumeDeviceData(sv.h), n * 4))
+    vol = host.reshape(dims[2], dims[1], dims[0])
+    colors, alphas = tfn_np
+    sc = oracle.SceneHolder(fb, fb, dims, oracle.TfnHolder(colors, alphas), mc["max_opacity"], cam["from"], cam["at"], cam["up"], cam["fovy"])
+    cores = os.cpu_count() or 1
+    # bounded sample: 8 evenly spaced blocks of 8 scanlines (1/16 of the frame at fb = 1024)
+    n_blocks = 8
+    rows = [(int((b + 0.5) * fb / n_blocks) - 4, int((b + 0.5) * fb / n_blocks) + 4) for b in range(n_blocks)]
+    t1 = time.perf_counter()
+    oracle.render_monolithic(sc, vol, n_threads=cores, rows=rows)
+    dt = time.perf_counter() - t1
+    frac = sum(b - a for a, b in rows) / float(fb)
+    return {"value": frac / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_blocks} blocks x 8 scanlines ({frac:.4f} of the {fb}x{fb} frame) of the same camera/TFN on the ground-truth "
+                      f"{dims[0]}^3 volume, CPU oracle monolithic marcher, {dt:.1f} s",
+            "d2h_volume_s": round(t1 - t0, 2)}
+
+
+def main():
+    a = parse()
+    ctx = dist.init_from_env()
+    if a.gpus != ctx.world:
+        if ctx.rank == 0:
+            print(f"warning: --gpus {a.gpus} but WORLD_SIZE={ctx.world}; using {ctx.world}", file=sys.stderr)
+    L = lib()
+    dims = (a.size, a.size, a.size)
+    pls = a.per_level_scale if a.per_level_scale > 0 else float(np.exp(np.log(a.size / 16.0) / max(a.levels - 1, 1)))
+    os.environ.setdefault("VNR_AMD_INIT_SEED", "20240611")  # identical initial parameters on every rank
+
+    # ---- setup (untimed) -------------------------------------------------------------------------------------
+    t_setup = time.perf_counter()
+    sv = api.vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=6.0)
+    cfg = syn.model_config(n_levels=a.levels, n_features=a.features, log2_hashmap_size=a.log2_hashmap_size, base_resolution=16,
+                           n_hidden_layers=a.hidden_layers, per_level_scale=pls)
+    # ground-truth macrocell (identical on every rank, so tiles compose exactly)
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+    check(L.vnrAmdNeuralVolumeSetSamplerSeed(nv.h, 1337, 0xda3e39cb94b95bdb + ctx.rank))
+    info = api.neural_info(nv)
+    check(L.vnrAmdSynchronize())
+    t_train = time.perf_counter()
+    dist.train_data_parallel(ctx, nv, a.train_steps, fast_mode=True)
+    check(L.vnrAmdSynchronize())
+    train_ms = (time.perf_counter() - t_train) * 1e3 / max(a.train_steps, 1)
+    train_loss = api.vnrNeuralVolumeGetTrainingLoss(nv)
+    psnr = None
+    if not a.no_psnr and ctx.rank == 0:
+        psnr = api.vnrNeuralVolumeGetPSNR(nv)
+
+    colors, alphas = syn.tfn_ramp_with_bumps(opacity_scale=a.opacity_scale)
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = syn.oblique_camera(dims)
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    ren = api.vnrCreateRenderer(nv)
+    api.vnrRendererSetTransferFunction(ren, tfn)
+    api.vnrRendererSetCamera(ren, camera)
+    api.vnrRendererSetFramebufferSize(ren, (a.fb, a.fb))
+    api.vnrRendererSetMode(ren, 5)
+    api.vnrRendererSetProfiling(ren, True)  # HIP events around the fused encode+MLP kernel, on its own stream
+    sr = dist.ShardedRenderer(ctx, ren, a.fb, a.fb)
+    setup_s = time.perf_counter() - t_setup
+
+    # ---- warm-up + timed region ---------------------------------------------------------------------------------
+    for _ in range(a.warmup):
+        sr.render()
+    dist.barrier(ctx)
+    t0 = time.perf_counter()
+    samples = slots = 0
+    infer_ms = 0.0
+    launches = iters = 0
+    for _ in range(a.steps):
+        sr.render()
+        st = api.vnrRendererGetFrameStats(ren)
+        samples += st["n_samples"]; slots += st["n_reference_slots"]; infer_ms += st["infer_kernel_ms"]
+        launches += st["infer_kernel_launches"]; iters = st["n_iterations"]
+    dist.barrier(ctx)
+    elapsed = time.perf_counter() - t0
+    rays_hit = st["n_rays_hit"]
+
+    if ctx.distributed:
+        import torch
+        import torch.distributed as td
+        mx = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        td.all_reduce(mx, op=td.ReduceOp.MAX)          # MAX over ranks of the timed region
+        elapsed = float(mx[0])
+        sm = torch.tensor([float(samples), float(slots), float(rays_hit)], dtype=torch.float64, device="cuda")
+        td.all_reduce(sm, op=td.ReduceOp.SUM)
+        samples_all, slots_all, rays_hit = float(sm[0]), float(sm[1]), int(sm[2])
+    else:
+        samples_all, slots_all = float(samples), float(slots)
+
+    if ctx.rank != 0:
+        return
+    fps = a.steps / elapsed
+    bytes_per_sample = 12 + info["n_levels"] * 8 * info["n_features_per_level"] * 2 + 4
+    in_pad = info["padded_width"]
+    flops_per_sample = 2 * (in_pad * 64 + (info["n_hidden_layers"] - 1) * 64 * 64 + 64)
+    # dominant kernel: fused hash-grid gather + MLP.  achieved = algorithmic bytes of the samples this rank's
+    # launches processed / summed launch durations (HIP events on the render stream), i.e. per-launch average.
+    achieved = (samples * bytes_per_sample) / (infer_ms * 1e-3) / 1e9 if infer_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "fused_infer_kernel (hash-grid gather + 3x64 MLP on MFMA)",
+                "algorithmic_bytes_per_sample": bytes_per_sample, "flops_per_sample": flops_per_sample,
+                "avg_launch_ms": round(infer_ms / max(launches, 1), 4), "launches": launches,
+                "mfma_tflops": round(samples * flops_per_sample / (infer_ms * 1e-3) / 1e12, 2) if infer_ms > 0 else 0.0}
+    out = {
+        "metric": "fps at 1024^2 on 1024^3 volume" if (a.size, a.fb) == (1024, 1024) else f"fps at {a.fb}^2 on {a.size}^3 volume",
+        "value": round(fps, 3), "unit": "frames/s", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"C4: {a.size}^3 synthetic Perlin fBm volume (seed 42), HashGrid L={a.levels} F={a.features} "
+                               f"T=2^{a.log2_hashmap_size} base 16 per_level_scale {pls:.4f} + {a.hidden_layers}x64 FullyFusedMLP, "
+                               f"{a.fb}x{a.fb} rendering mode 5 (sample streaming), sampling rate 1, N_ITERS 16",
+                   "volume": f"{a.size}^3", "framebuffer": f"{a.fb}x{a.fb}", "n_params": info["n_params"],
+                   "tfn": f"256-entry ramp-with-bumps, seed 7, opacity scale {a.opacity_scale}",
+                   "camera": cam, "train_steps": a.train_steps, "batch": 65536,
+                   "parallelism": f"image tiles x{ctx.world} (interleaved 8-scanline blocks) + RCCL all_gather" if ctx.world > 1 else "single GPU"},
+        "mlp_msamples_per_s": round(samples_all / elapsed / 1e6, 1),
+        "mlp_msamples_per_s_kernel_only": round(samples / (infer_ms * 1e-3) / 1e6, 1) if infer_ms > 0 else None,
+        "samples_per_frame": int(samples_all / a.steps), "samples_per_hit_ray": round(samples_all / a.steps / max(rays_hit, 1), 1),
+        "reference_slots_per_frame": int(slots_all / a.steps), "iterations_per_frame": iters, "rays_hit": rays_hit,
+        "psnr_db": None if psnr is None else round(psnr, 2), "train_ms_per_step": round(train_ms, 3), "train_loss": round(train_loss, 5),
+        "setup_s": round(setup_s, 1),
+        "roofline": roofline,
+    }
+    if ctx.world == 1 and not a.no_cpu_baseline:
+        mc = api.volume_macrocell(nv)
+        out["cpu_baseline"] = cpu_baseline(sv, dims, (colors, alphas), cam, a.fb, mc)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

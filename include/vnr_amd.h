@@ -160,6 +160,8 @@ int    vnrAmdNeuralVolumeSetParamsFP16(vnrAmdVolume, const uint16_t* host_in, si
 int    vnrAmdNeuralVolumeTrainBegin(vnrAmdVolume);
 float* vnrAmdNeuralVolumeGradients(vnrAmdVolume, size_t* count);
 int    vnrAmdNeuralVolumeTrainEnd(vnrAmdVolume, float grad_scale, int fast_mode);
+/* forward + backward on a caller-provided batch (same kernels as TrainBegin, no sampling): fills Gradients() */
+int    vnrAmdNeuralVolumeForwardBackward(vnrAmdVolume, size_t n, const float* d_coords, const float* d_targets);
 int    vnrAmdNeuralVolumeSetSamplerSeed(vnrAmdVolume, uint64_t seed, uint64_t stream_id);
 int    vnrAmdNeuralVolumeSetInitSeed(vnrAmdVolume, uint64_t seed); /* reference seeds with time(NULL), tcnn_network.h:209 */
 
@@ -192,6 +194,9 @@ int  vnrAmdRendererSetOutputAsDeviceFramebuffer(vnrAmdRenderer, int enable);
 /* image-tile sharding (new work): render only pixels [pixel_lo, pixel_hi) of the full image;
  * global pixel indices (RNG seeds, accumulation) are preserved so tiles compose exactly. */
 int  vnrAmdRendererSetPixelRange(vnrAmdRenderer, uint32_t pixel_lo, uint32_t pixel_hi);
+/* interleaved sharding for load balance: this renderer owns the pixel blocks b (of `block_pixels` consecutive
+ * pixels, e.g. 8 scanlines) with b % n_parts == part; empty-space skipping makes contiguous tiles uneven. */
+int  vnrAmdRendererSetPixelInterleave(vnrAmdRenderer, uint32_t block_pixels, uint32_t n_parts, uint32_t part);
 
 typedef struct {
   uint64_t n_samples;        /* live samples inferred in the last frame */

@@ -107,6 +107,7 @@ def lib():
     sig("vnrAmdNeuralVolumeTrainBegin", I, P)
     sig("vnrAmdNeuralVolumeGradients", P, P, C.POINTER(SZ))
     sig("vnrAmdNeuralVolumeTrainEnd", I, P, F, I)
+    sig("vnrAmdNeuralVolumeForwardBackward", I, P, SZ, P, P)
     sig("vnrAmdNeuralVolumeSetSamplerSeed", I, P, U64, U64)
     sig("vnrAmdNeuralVolumeSetInitSeed", I, P, U64)
     sig("vnrAmdVolumeSetClippingBox", I, P, FP, FP)
@@ -129,6 +130,7 @@ def lib():
     sig("vnrAmdRendererMapFrame", P, P)
     sig("vnrAmdRendererSetOutputAsDeviceFramebuffer", I, P, I)
     sig("vnrAmdRendererSetPixelRange", I, P, U32, U32)
+    sig("vnrAmdRendererSetPixelInterleave", I, P, U32, U32, U32)
     sig("vnrAmdRendererGetFrameStats", I, P, C.POINTER(FrameStats))
     sig("vnrAmdRendererSetProfiling", I, P, I)
     sig("vnrAmdReleaseRenderer", None, P)

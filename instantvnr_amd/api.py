@@ -392,6 +392,10 @@ def vnrRendererSetPixelRange(r, lo, hi):
     check(lib().vnrAmdRendererSetPixelRange(r.h, int(lo), int(hi)))
 
 
+def vnrRendererSetPixelInterleave(r, block_pixels, n_parts, part):
+    check(lib().vnrAmdRendererSetPixelInterleave(r.h, int(block_pixels), int(n_parts), int(part)))
+
+
 def vnrRendererSetOutputAsDeviceFramebuffer(r, flag):
     check(lib().vnrAmdRendererSetOutputAsDeviceFramebuffer(r.h, 1 if flag else 0))
     r._device_output = bool(flag)
@@ -475,3 +479,28 @@ def simple_volume_take_samples(v, n, lower=(0, 0, 0), upper=(1, 1, 1)):
     check(lib().vnrAmdSimpleVolumeTakeSamples(v.h, n, _fp(_vec(lower)), _fp(_vec(upper)), c.ptr, o.ptr, None))
     check(lib().vnrAmdSynchronize())
     return c.numpy(), o.numpy()
+
+
+def neural_forward_backward(v, coords, targets):
+    """forward + backward on a host batch; returns the fp32 (loss-scaled x128) gradient blob as numpy"""
+    c = DeviceArray.from_numpy(np.ascontiguousarray(coords, dtype=np.float32))
+    t = DeviceArray.from_numpy(np.ascontiguousarray(targets, dtype=np.float32))
+    check(lib().vnrAmdNeuralVolumeForwardBackward(v.h, c.shape[0], c.ptr, t.ptr))
+    return neural_gradients(v)
+
+
+def neural_gradients(v):
+    n = C.c_size_t()
+    p = check_ptr(lib().vnrAmdNeuralVolumeGradients(v.h, C.byref(n)))
+    check(lib().vnrAmdSynchronize())
+    out = np.empty(n.value, np.float32)
+    check(lib().vnrAmdMemcpyD2H(out.ctypes.data_as(C.c_void_p), p, n.value * 4))
+    return out
+
+
+def neural_train_begin(v):
+    check(lib().vnrAmdNeuralVolumeTrainBegin(v.h))
+
+
+def neural_train_end(v, grad_scale=1.0, fast_mode=True):
+    check(lib().vnrAmdNeuralVolumeTrainEnd(v.h, float(grad_scale), 1 if fast_mode else 0))

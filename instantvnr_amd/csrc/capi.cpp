@@ -462,6 +462,10 @@ int vnrAmdNeuralVolumeTrainEnd(vnrAmdVolume v, float grad_scale, int fast_mode)
 {
   return guarded([&]() { as_neural(v)->train_end(grad_scale, fast_mode != 0); });
 }
+int vnrAmdNeuralVolumeForwardBackward(vnrAmdVolume v, size_t n, const float* d_coords, const float* d_targets)
+{
+  return guarded([&]() { as_neural(v)->forward_backward(d_coords, d_targets, n); });
+}
 int vnrAmdNeuralVolumeSetSamplerSeed(vnrAmdVolume v, uint64_t seed, uint64_t stream_id)
 {
   return guarded([&]() {
@@ -559,6 +563,10 @@ const float* vnrAmdRendererMapFrame(vnrAmdRenderer r)
 }
 int vnrAmdRendererSetOutputAsDeviceFramebuffer(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_device_output(e != 0); }); }
 int vnrAmdRendererSetPixelRange(vnrAmdRenderer r, uint32_t lo, uint32_t hi) { return guarded([&]() { VNR_REN(r); r->r->set_pixel_range(lo, hi); }); }
+int vnrAmdRendererSetPixelInterleave(vnrAmdRenderer r, uint32_t block, uint32_t parts, uint32_t part)
+{
+  return guarded([&]() { VNR_REN(r); r->r->set_pixel_interleave(block, parts, part); });
+}
 int vnrAmdRendererGetFrameStats(vnrAmdRenderer r, vnrAmdFrameStats* s)
 {
   return guarded([&]() {

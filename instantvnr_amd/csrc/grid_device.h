@@ -94,7 +94,13 @@ __device__ __forceinline__ void encode_level(const LevelInfo& lv, uint32_t inter
     const float w = corner_weight(c, corner);
     const half_t* d = (const half_t*)&v[corner];
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = acc[f] + (half_t)(w * (float)d[f]);
+    for (int f = 0; f < F; ++f) {
+      float prod = w * (float)d[f];
+      // `(T)(weight * data)` rounds twice (f32 product, then f16).  For scalar halves hipcc would otherwise
+      // select v_fma_mixlo_f16, which rounds the exact product once and differs in rare halfway cases.
+      if (F == 1) asm volatile("" : "+v"(prod));
+      acc[f] = acc[f] + (half_t)prod;
+    }
   }
 #pragma unroll
   for (int f = 0; f < F; ++f) out[f] = acc[f];

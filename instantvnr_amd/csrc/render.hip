@@ -43,6 +43,7 @@ struct RenderParams {
   vec4f* accumulation;
   int width, height, frame_index;
   uint32_t pixel_lo, pixel_hi;
+  uint32_t il_block, il_parts, il_part, n_local;  // pixel-block interleave across ranks; n_local = local index count
   vec3f cam_pos, cam_dir, cam_hor, cam_ver;
   affine3f wto;
   vec3i vol_dims;
@@ -84,6 +85,18 @@ __device__ __forceinline__ void compute_ray(const RenderParams& p, uint32_t pixe
   org = xfm_point(p.wto, p.cam_pos);
   const vec3f d = (p.cam_dir + (sx - 0.5f) * p.cam_hor) + (sy - 0.5f) * p.cam_ver;
   dir = xfm_vector(p.wto, normalize(d));
+}
+
+// local work index -> global pixel index of this rank's share of the image (tiles / interleaved pixel blocks)
+__device__ __forceinline__ bool map_pixel(const RenderParams& p, uint32_t i, uint32_t& pixel)
+{
+  if (p.il_parts == 1) {
+    pixel = p.pixel_lo + i;
+  } else {
+    const uint32_t blk = i / p.il_block, off = i - blk * p.il_block;
+    pixel = (blk * p.il_parts + p.il_part) * p.il_block + off;
+  }
+  return pixel >= p.pixel_lo && pixel < p.pixel_hi;
 }
 
 // gdt::LCG<16> (EXTERNAL; instantvnr_types.h:155)
@@ -219,7 +232,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
   float* s_t0 = s_t;
   float* s_t1 = s_t + (size_t)p.n_iters * 256;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t n_in = FIRST ? (p.pixel_hi - p.pixel_lo) : counters[C_RAYS0 + parity];
+  const uint32_t n_in = FIRST ? p.n_local : counters[C_RAYS0 + parity];
   uint32_t* n_rays_out = counters + C_RAYS0 + (parity ^ 1);
   uint32_t* n_samples_out = counters + C_SAMPLES0 + parity;
   const uint32_t n_round = (n_in + 255u) & ~255u;
@@ -238,13 +251,14 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
 
     if (active) {
       if (FIRST) {
-        pixel = p.pixel_lo + i;
-        jitter = tea_lcg_first((uint32_t)p.frame_index, pixel);
-        compute_ray(p, pixel, org, dir);
-        m_dir = dir * p.mc_rcp;
-        alive = intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
-        if (alive) dda_init(it, org * p.mc_rcp, m_dir, tmin, p.mc_dims);
-        else write_pixel(p, {0, 0, 0, 0}, pixel);
+        if (map_pixel(p, i, pixel)) {
+          jitter = tea_lcg_first((uint32_t)p.frame_index, pixel);
+          compute_ray(p, pixel, org, dir);
+          m_dir = dir * p.mc_rcp;
+          alive = intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
+          if (alive) dda_init(it, org * p.mc_rcp, m_dir, tmin, p.mc_dims);
+          else write_pixel(p, {0, 0, 0, 0}, pixel);
+        }
       } else {
         pixel = cur.pixel_index[i];
         jitter = cur.jitter[i];
@@ -354,8 +368,9 @@ __global__ void clear_two_kernel(uint32_t* a, uint32_t* b)
 __global__ void monolithic_kernel(const RenderParams p)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.pixel_hi - p.pixel_lo) return;
-  const uint32_t pixel = p.pixel_lo + i;
+  if (i >= p.n_local) return;
+  uint32_t pixel;
+  if (!map_pixel(p, i, pixel)) return;
   vec3f org, dir;
   compute_ray(p, pixel, org, dir);
   float alpha = 0.0f;
@@ -484,6 +499,13 @@ void Renderer::render()
   p.pixel_lo = std::min(pixel_lo_, n_pixels);
   p.pixel_hi = std::min(pixel_hi_, n_pixels);
   if (p.pixel_hi < p.pixel_lo) p.pixel_hi = p.pixel_lo;
+  p.il_block = il_block_; p.il_parts = il_parts_; p.il_part = il_part_;
+  if (il_parts_ == 1) {
+    p.n_local = p.pixel_hi - p.pixel_lo;
+  } else {
+    const uint32_t n_blocks = div_round_up(n_pixels, il_block_);
+    p.n_local = div_round_up(n_blocks, il_parts_) * il_block_;
+  }
   // camera, renderer.cpp:87-96
   const float t = 2.0f * tanf(camera_.fovy * 0.5f * (float)M_PI / 180.0f);
   const float aspect = (float)width_ / (float)height_;
@@ -510,7 +532,7 @@ void Renderer::render()
   p.accumulation = accumulation_.ptr;
   stats_ = FrameStats();
 
-  if (p.pixel_hi > p.pixel_lo) {
+  if (p.pixel_hi > p.pixel_lo && p.n_local > 0) {
     switch (mode_) {
     case 5: render_streaming(p); break;
     case 4:
@@ -522,21 +544,20 @@ void Renderer::render()
   }
   reset_ = false;
   if (!skip_download_) {  // renderer.cpp:133 framebuffer.download_async
-    const size_t off = p.pixel_lo, cnt = p.pixel_hi - p.pixel_lo;
+    const size_t off = p.pixel_lo, cnt = p.pixel_hi - p.pixel_lo;  // (interleaved shares copy the covering range)
     if (cnt) VNR_HIP_CHECK(hipMemcpyAsync(host_fb_[fb_cur_] + off, fb_[fb_cur_].ptr + off, cnt * sizeof(vec4f), hipMemcpyDeviceToHost, stream_));
   }
 }
 
 void Renderer::render_monolithic(const RenderParams& p)
 {
-  const uint32_t n = p.pixel_hi - p.pixel_lo;
-  monolithic_kernel<<<div_round_up(n, 128), 128, 0, stream_>>>(p);
+  monolithic_kernel<<<div_round_up(p.n_local, 128), 128, 0, stream_>>>(p);
   VNR_HIP_CHECK(hipGetLastError());
 }
 
 void Renderer::render_streaming(const RenderParams& p)
 {
-  const uint32_t P = p.pixel_hi - p.pixel_lo;
+  const uint32_t P = p.n_local;
   ensure_queues(P, p.n_iters);
   const size_t QP = queue_pixels_;
   RayList rl[2];
@@ -606,14 +627,16 @@ void Renderer::render_streaming(const RenderParams& p)
   stats_.n_rays_hit = hc[C_HIT];
   stats_.n_samples = (uint64_t)hc[C_STAT_SAMPLES] | ((uint64_t)hc[C_STAT_SAMPLES + 1] << 32);
   stats_.n_reference_slots = ((uint64_t)hc[C_STAT_REFRAYS] | ((uint64_t)hc[C_STAT_REFRAYS + 1] << 32)) * (uint64_t)p.n_iters;
-  stats_.n_iterations = used;
+  // march(j) emits what the reference's iteration j intersects and march(j+1) composes it, so `used` marches
+  // correspond to used-1 reference iterations (= inference launches with samples)
+  stats_.n_iterations = used > 0 ? used - 1 : 0;
   if (profiling_) {
     for (uint32_t k = 0; k < it; ++k) {
       float ms = 0.0f;
       VNR_HIP_CHECK(hipEventElapsedTime(&ms, events_[2 * k], events_[2 * k + 1]));
       stats_.infer_kernel_ms += ms;
     }
-    stats_.infer_kernel_launches = used;
+    stats_.infer_kernel_launches = used > 0 ? used - 1 : 0;
   }
 }
 

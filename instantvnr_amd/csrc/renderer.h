@@ -37,6 +37,12 @@ public:
   void set_device_output(bool e) { skip_download_ = e; }
   void set_pixel_range(uint32_t lo, uint32_t hi) { pixel_lo_ = lo; pixel_hi_ = hi; reset_ = true; }
   void set_profiling(bool e) { profiling_ = e; }
+  // rank `part` of `parts` renders the pixel blocks b with b % parts == part (block = `block` consecutive pixels)
+  void set_pixel_interleave(uint32_t block, uint32_t parts, uint32_t part)
+  {
+    if (block == 0 || parts == 0 || part >= parts) throw std::runtime_error("invalid pixel interleave");
+    il_block_ = block; il_parts_ = parts; il_part_ = part; reset_ = true;
+  }
 
   void render();                 // renderer.cpp:59-140
   const float* map_frame();      // renderer.h:84-94
@@ -56,6 +62,7 @@ private:
   float sampling_rate_ = 1.0f, density_scale_ = 1.0f;
   int width_ = 0, height_ = 0;
   uint32_t pixel_lo_ = 0, pixel_hi_ = 0xffffffffu;
+  uint32_t il_block_ = 1, il_parts_ = 1, il_part_ = 0;
   bool reset_ = true, skip_download_ = false, profiling_ = false;
   int frame_index_ = 0;
   int n_iters_ = 16;  // VNR_RM_N_ITERS (method_raymarching.cu:30-40)

@@ -140,6 +140,7 @@ public:
   void train(size_t steps, bool fast_mode);                 // network.cu:769-779 + Impl::train :231-259
   void train_begin();                                       // sample + forward + backward
   void train_end(float grad_scale, bool fast_mode);         // optimizer + macrocell update
+  void forward_backward(const float* d_coords, const float* d_targets, size_t n);  // caller-provided batch
   float test_loss();                                        // network.cu:261-288
   float get_psnr(bool quiet);                               // network.cu:410-472
   void inference(size_t n, const float* d_in, float* d_out, hipStream_t s);  // network.cu:1043-1052
@@ -158,7 +159,7 @@ private:
   TfnObject tfn_;
   const size_t batch_size_ = 1u << 16;  // network.cu:183
   DeviceBuffer<float> train_x_{MemTag::Network}, train_y_{MemTag::Network}, test_y1_{MemTag::Network};
-  bool pending_step_ = false;
+  bool pending_step_ = false, pending_internal_ = false;
   friend struct VolumeKeepAlive;
 
 public:

@@ -110,6 +110,53 @@ __global__ void update_macrocell_implicit_kernel(uint64_t n, vec3i dims, const f
   update_voxel_and_neighbours((int)x, (int)y, (int)z, mc, cells, value);
 }
 
+// Same result as update_macrocell_implicit_kernel (min/max are order independent) with 16x fewer atomics:
+// the 16 consecutive-x voxels of a macrocell row share their cell, so they are min/max-reduced across a
+// 16-lane group first.  Requires dims.x % 16 == 0 (groups never straddle a row).
+__device__ __forceinline__ void update_cell_range(int cx, int cy, int cz, vec3i mc, float* __restrict__ cells, float lo, float hi)
+{
+  if (cx < 0 || cx >= mc.x || cy < 0 || cy >= mc.y || cz < 0 || cz >= mc.z) return;
+  const uint32_t idx = cx + cy * mc.x + cz * mc.y * mc.x;
+  atomic_min_f32(cells + 2 * (size_t)idx, lo - 1.0f);
+  atomic_max_f32(cells + 2 * (size_t)idx + 1, hi + 1.0f);
+}
+
+__global__ void update_macrocell_implicit_grouped_kernel(uint64_t n, vec3i dims, const float* __restrict__ vol, vec3i mc, float* __restrict__ cells)
+{
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const uint64_t stride = (uint64_t)dims.x * dims.y;
+  const int x = (int)(idx % dims.x), y = (int)((idx % stride) / dims.x), z = (int)(idx / stride);
+  const float fx = ((float)x + 0.5f) / (float)dims.x, fy = ((float)y + 0.5f) / (float)dims.y, fz = ((float)z + 0.5f) / (float)dims.z;
+  const float value = tex3d(vol, dims, fx, fy, fz);
+  float mn = value, mx = value;
+#pragma unroll
+  for (int d = 8; d > 0; d >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, d, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+  }
+  const int sx = (x % kMacrocellSize) == 0 ? -1 : ((x % kMacrocellSize) == (kMacrocellSize - 1) ? 1 : 0);
+  const int sy = (y % kMacrocellSize) == 0 ? -1 : ((y % kMacrocellSize) == (kMacrocellSize - 1) ? 1 : 0);
+  const int sz = (z % kMacrocellSize) == 0 ? -1 : ((z % kMacrocellSize) == (kMacrocellSize - 1) ? 1 : 0);
+  const int cx = x >> kMacrocellSizeMip;
+  const int cy0 = y >> kMacrocellSizeMip, cy1 = (y + sy) >> kMacrocellSizeMip;
+  const int cz0 = z >> kMacrocellSizeMip, cz1 = (z + sz) >> kMacrocellSizeMip;
+  const bool ny = sy != 0 && y + sy >= 0, nz = sz != 0 && z + sz >= 0;
+  if ((x & (kMacrocellSize - 1)) == 0) {  // group leader: the row's own cell (and its y/z neighbours)
+    update_cell_range(cx, cy0, cz0, mc, cells, mn, mx);
+    if (ny) update_cell_range(cx, cy1, cz0, mc, cells, mn, mx);
+    if (nz) update_cell_range(cx, cy0, cz1, mc, cells, mn, mx);
+    if (ny && nz) update_cell_range(cx, cy1, cz1, mc, cells, mn, mx);
+  }
+  if (sx != 0 && x + sx >= 0) {           // first / last voxel of the row segment also feeds the x neighbour
+    const int cxn = (x + sx) >> kMacrocellSizeMip;
+    update_cell_range(cxn, cy0, cz0, mc, cells, value, value);
+    if (ny) update_cell_range(cxn, cy1, cz0, mc, cells, value, value);
+    if (nz) update_cell_range(cxn, cy0, cz1, mc, cells, value, value);
+    if (ny && nz) update_cell_range(cxn, cy1, cz1, mc, cells, value, value);
+  }
+}
+
 // macrocell.cu:153-193 (TFN alphas staged in LDS; any block size)
 __global__ void macrocell_max_opacity_kernel(uint32_t n_cells, DeviceTfn tfn, const float* __restrict__ range, float* __restrict__ out)
 {
@@ -155,7 +202,10 @@ void MacroCell::compute_everything(const float* d_volume, hipStream_t s)
 {
   const vec3i vd = volume_dims();
   const uint64_t n = (uint64_t)vd.x * vd.y * vd.z;
-  update_macrocell_implicit_kernel<<<div_round_up(n, 256), 256, 0, s>>>(n, vd, d_volume, dims(), d_value_range());
+  if (vd.x % kMacrocellSize == 0)
+    update_macrocell_implicit_grouped_kernel<<<div_round_up(n, 256), 256, 0, s>>>(n, vd, d_volume, dims(), d_value_range());
+  else
+    update_macrocell_implicit_kernel<<<div_round_up(n, 256), 256, 0, s>>>(n, vd, d_volume, dims(), d_value_range());
   VNR_HIP_CHECK(hipGetLastError());
 }
 
@@ -536,6 +586,15 @@ void NeuralVolume::train_begin()
   source_->take_samples(train_x_.ptr, train_y_.ptr, batch_size_, lower, upper, stream);
   net_.forward_backward(train_x_.ptr, train_y_.ptr, batch_size_, stream);
   pending_step_ = true;
+  pending_internal_ = true;
+}
+
+void NeuralVolume::forward_backward(const float* d_coords, const float* d_targets, size_t n)
+{
+  if (!net_.valid()) throw std::runtime_error("network is not valid");
+  net_.forward_backward(d_coords, d_targets, n, stream);
+  pending_step_ = true;
+  pending_internal_ = false;
 }
 
 void NeuralVolume::train_end(float grad_scale, bool fast_mode)
@@ -544,7 +603,7 @@ void NeuralVolume::train_end(float grad_scale, bool fast_mode)
   net_.optimizer_step(grad_scale, stream);
   // network.cu:249-257, 774: the macrocell is trained online unless (fast_mode && external macrocell)
   const bool update_mc = !(fast_mode && mc_.is_external());
-  if (update_mc && !mc_.is_external()) mc_.update_explicit(train_x_.ptr, train_y_.ptr, batch_size_, stream);
+  if (update_mc && pending_internal_ && !mc_.is_external()) mc_.update_explicit(train_x_.ptr, train_y_.ptr, batch_size_, stream);
   pending_step_ = false;
 }
 

@@ -59,9 +59,10 @@ def _colormap(n):
     return np.stack([r, g, b], axis=1).astype(np.float32)
 
 
-def tfn_ramp_with_bumps(n=256, seed=7, zero_below=0.15):
+def tfn_ramp_with_bumps(n=256, seed=7, zero_below=0.15, opacity_scale=1.0):
     """256-entry ramp-with-bumps transfer function.  Values below
-    `zero_below` are fully transparent so empty-space skipping has work to do.
+    `zero_below` are fully transparent so empty-space skipping has work to do; `opacity_scale` thins the
+    medium (large volumes need a small per-voxel-step opacity for rays to penetrate).
     Returns (colors [n,3], alphas [n])."""
     rng = np.random.default_rng(seed)
     t = np.linspace(0.0, 1.0, n, dtype=np.float32)
@@ -72,6 +73,7 @@ def tfn_ramp_with_bumps(n=256, seed=7, zero_below=0.15):
         a = a + 0.55 * np.exp(-((t - mu) ** 2) / (2 * s * s))
     a = np.clip(a, 0.0, 1.0)
     a[t < zero_below] = 0.0
+    a = np.clip(a * opacity_scale, 0.0, 1.0)
     return _colormap(n), a.astype(np.float32)
 
 

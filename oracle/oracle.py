@@ -324,7 +324,7 @@ def render_streaming(scene, value_fn, n_iters=16, accumulation=None):
     return frame.reshape(s.height, s.width, 4), acc, st
 
 
-def render_monolithic(scene, vol, accumulation=None, n_threads=1):
+def render_monolithic(scene, vol, accumulation=None, n_threads=1, rows=None):
     s = scene.c
     vol = _f32(vol)
     npx = s.width * s.height
@@ -336,11 +336,14 @@ def render_monolithic(scene, vol, accumulation=None, n_threads=1):
         L.vnro_render_monolithic(C.byref(s), _p(vol, C.c_float), C.c_int(lo), C.c_int(hi), _p(acc, C.c_float),
                                  _p(frame, C.c_float))
 
-    if n_threads <= 1:
+    if n_threads <= 1 and rows is None:
         work(0, s.height)
     else:
-        # interleaved scanline blocks; ctypes releases the GIL during the call
-        rows = [(r, min(r + 4, s.height)) for r in range(0, s.height, 4)]
+        # scanline blocks pulled from a shared queue; ctypes releases the GIL during the call
+        if rows is None:
+            rows = [(r, min(r + 4, s.height)) for r in range(0, s.height, 4)]
+        else:
+            rows = [(r, min(r + 2, hi)) for lo, hi in rows for r in range(lo, hi, 2)]
         it = iter(rows)
         lk = threading.Lock()
 
@@ -352,7 +355,7 @@ def render_monolithic(scene, vol, accumulation=None, n_threads=1):
                     return
                 work(*rg)
 
-        ts = [threading.Thread(target=runner) for _ in range(n_threads)]
+        ts = [threading.Thread(target=runner) for _ in range(max(1, n_threads))]
         [t.start() for t in ts]
         [t.join() for t in ts]
     return frame.reshape(s.height, s.width, 4), acc

@@ -116,7 +116,10 @@ def test_linearity_of_last_layer_at_scale(oracle):
     p2[last] = (p2[last].astype(np.float32) * 2).astype(np.float16)
     api.neural_set_params_fp16(vol, p2)
     y2 = api.neural_inference(vol, coords)
-    assert np.array_equal(y2, 2 * y1)
+    normal = np.abs(y1) >= 2.0 ** -13          # fp16-subnormal outputs do not scale exactly
+    assert normal.mean() > 0.99
+    assert np.array_equal(y2[normal], 2 * y1[normal])
+    assert np.allclose(y2[~normal], 2 * y1[~normal], atol=2.0 ** -22)
     # and a sampled subset agrees with the oracle
     idx = np.random.default_rng(10).choice(coords.shape[0], 2048, replace=False)
     want = oracle.network_inference(ocfg, 64, H, params.view(np.uint16), coords[idx])

@@ -42,7 +42,8 @@ def parse():
     p.add_argument("--hidden-layers", type=int, default=3)
     p.add_argument("--per-level-scale", type=float, default=0.0, help="0 = finest level resolution equals the volume edge")
     p.add_argument("--train-steps", type=int, default=1500)
-    p.add_argument("--opacity-scale", type=float, default=0.12)
+    p.add_argument("--opacity-scale", type=float, default=0.06)
+    p.add_argument("--camera-distance", type=float, default=1.1, help="camera distance in volume edges (oblique view)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-psnr", action="store_true")
     return p.parse_args()
@@ -109,7 +110,7 @@ def main():
     api.vnrTransferFunctionSetColor(tfn, colors)
     api.vnrTransferFunctionSetAlpha(tfn, alphas)
     api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
-    cam = syn.oblique_camera(dims)
+    cam = syn.oblique_camera(dims, distance_scale=a.camera_distance)
     camera = api.vnrCreateCamera()
     api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
     ren = api.vnrCreateRenderer(nv)

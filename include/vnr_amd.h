@@ -208,6 +208,9 @@ typedef struct {
 } vnrAmdFrameStats;
 int  vnrAmdRendererGetFrameStats(vnrAmdRenderer, vnrAmdFrameStats*);
 int  vnrAmdRendererSetProfiling(vnrAmdRenderer, int enable);
+/* diagnostics: device pointers to the compacted sample queue ([n][3] fp32) and the counter block, plus the
+ * per-iteration duration (ms) of the sample-evaluation kernel in the last profiled frame */
+int  vnrAmdRendererDebugQueues(vnrAmdRenderer, const float** d_coords, const uint32_t** d_counters, float* iteration_ms, int max_iterations);
 void vnrAmdReleaseRenderer(vnrAmdRenderer);
 
 /* ---- misc (api.h:185-188) -------------------------------------------------- */

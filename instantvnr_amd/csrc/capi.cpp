@@ -576,6 +576,16 @@ int vnrAmdRendererGetFrameStats(vnrAmdRenderer r, vnrAmdFrameStats* s)
     s->n_rays_hit = f.n_rays_hit; s->infer_kernel_ms = f.infer_kernel_ms; s->infer_kernel_launches = f.infer_kernel_launches;
   });
 }
+int vnrAmdRendererDebugQueues(vnrAmdRenderer r, const float** d_coords, const uint32_t** d_counters, float* iteration_ms, int max_iterations)
+{
+  return guarded([&]() {
+    VNR_REN(r);
+    if (d_coords) *d_coords = r->r->debug_coords();
+    if (d_counters) *d_counters = r->r->debug_counters();
+    const auto& v = r->r->debug_iteration_ms();
+    for (int i = 0; i < max_iterations; ++i) iteration_ms[i] = i < (int)v.size() ? v[i] : 0.0f;
+  });
+}
 int vnrAmdRendererSetProfiling(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_profiling(e != 0); }); }
 void vnrAmdReleaseRenderer(vnrAmdRenderer r) { delete r; }
 

@@ -106,4 +106,95 @@ __device__ __forceinline__ void encode_level(const LevelInfo& lv, uint32_t inter
   for (int f = 0; f < F; ++f) out[f] = acc[f];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path used by the fused kernels: identical results, cheaper instruction stream.
+//  * 32-bit buffer addressing (one SRSRC for the whole table, level base as scalar offset) instead of 64-bit
+//    pointer arithmetic per corner;
+//  * dense levels: one base index + 7 adds with 24-bit multiplies; the (rare) wrap-around / out-of-domain case
+//    is detected per wave and falls back to the exact `% size` formula;
+//  * hashed levels: (g+1)*P == g*P + P, so 2 full multiplies per level instead of 16.
+// ------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t table_rsrc_t;
+
+__device__ __forceinline__ table_rsrc_t make_table_rsrc(const void* base, uint32_t bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <int F> struct RawFeat;
+template <> struct RawFeat<1> {
+  typedef unsigned short raw_t;
+  static __device__ __forceinline__ raw_t load(table_rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
+};
+template <> struct RawFeat<2> {
+  typedef uint32_t raw_t;
+  static __device__ __forceinline__ raw_t load(table_rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+};
+template <> struct RawFeat<4> {
+  typedef uint32_t raw_t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ raw_t load(table_rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); }
+};
+template <> struct RawFeat<8> {
+  typedef uint4_t raw_t;
+  static __device__ __forceinline__ raw_t load(table_rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
+};
+
+__device__ __forceinline__ void level_indices_fast(const LevelInfo& lv, const CornerSetup& c, uint32_t idx[8])
+{
+  if (lv.hashed) {
+    const uint32_t mask = lv.size - 1u;
+    const uint32_t hy0 = c.g[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+    const uint32_t hz0 = c.g[2] * 805459861u, hz1 = hz0 + 805459861u;
+    const uint32_t x0 = c.g[0], x1 = c.g[0] + 1u;
+    const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) idx[corner] = (((corner & 1) ? x1 : x0) ^ yz[corner >> 1]) & mask;
+  } else {
+    const uint32_t res = lv.resolution, res2 = lv.res2;
+    const uint32_t base = c.g[0] + __umul24(c.g[1], res) + __umul24(c.g[2], res2);
+    const bool bad = (c.g[0] > res) | (c.g[1] > res) | (c.g[2] > res) | (base + 1u + res + res2 >= lv.size);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {  // wave-uniform and rare: keep the exact modulo semantics
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner)
+        idx[corner] = level_index(lv, c.g[0] + (corner & 1), c.g[1] + ((corner >> 1) & 1), c.g[2] + ((corner >> 2) & 1));
+    } else {
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner)
+        idx[corner] = base + ((corner & 1) ? 1u : 0u) + ((corner & 2) ? res : 0u) + ((corner & 4) ? res2 : 0u);
+    }
+  }
+}
+
+template <int F>
+__device__ __forceinline__ void encode_level_fast(const LevelInfo& lv, uint32_t interpolation, table_rsrc_t rsrc,
+                                                  float x, float y, float z, half_t* out)
+{
+  typedef typename RawFeat<F>::raw_t raw_t;
+  const CornerSetup c = level_setup(lv, interpolation, x, y, z);
+  uint32_t idx[8];
+  level_indices_fast(lv, c, idx);
+  const uint32_t soff = lv.offset * (uint32_t)(F * 2);
+  raw_t v[8];
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) v[corner] = RawFeat<F>::load(rsrc, idx[corner] * (uint32_t)(F * 2), soff);
+  const float wx0 = 1.0f - c.w[0], wx1 = c.w[0], wy0 = 1.0f - c.w[1], wy1 = c.w[1], wz0 = 1.0f - c.w[2], wz1 = c.w[2];
+  const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+  half_t acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = (half_t)0.0f;
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    const float w = wxy[corner & 3] * ((corner & 4) ? wz1 : wz0);  // ((wx * wy) * wz)
+    const half_t* d = (const half_t*)&v[corner];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      float prod = w * (float)d[f];
+      if (F == 1) asm volatile("" : "+v"(prod));  // see encode_level
+      acc[f] = acc[f] + (half_t)prod;
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < F; ++f) out[f] = acc[f];
+}
+
 }  // namespace vnr

@@ -17,9 +17,11 @@ constexpr int kLossScale = 128;   // tcnn default loss scale for fp16 (EXTERNAL)
 struct LevelInfo {
   float scale;
   uint32_t resolution;
+  uint32_t res2;    // resolution^2 (dense index stride of z)
   uint32_t size;    // entries in this level
   uint32_t offset;  // first entry of this level (entries, x F for elements)
   uint32_t hashed;  // 1: prime-XOR hash (size is a power of two), 0: dense index
+  uint32_t pad0, pad1;  // 32 bytes: one s_load_dwordx8 per level
 };
 
 struct GridDevice {
@@ -73,7 +75,9 @@ public:
   void deserialize_params(const Json& j, hipStream_t s);
 
   // inference: coords [n][3] fp32 -> out [n] fp32.  n either by value or read on the device from d_n.
-  void inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s) const;
+  // d_dest (optional): result of sample i is written to d_out[d_dest[i]] (the ray marcher's gather order -> ray-major map).
+  void inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
+                 const uint32_t* d_dest = nullptr) const;
   // encode only: fp16 [n][padded_width]
   void encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const;
 
@@ -100,6 +104,7 @@ private:
 
   DeviceBuffer<uint16_t> params_f16_{MemTag::Network};   // tcnn-order blob (inference + serialisation)
   DeviceBuffer<uint16_t> mlp_packed_{MemTag::Network};   // MFMA/LDS image of the MLP weights
+  DeviceBuffer<LevelInfo> levels_dev_{MemTag::Network};  // per-level constants, read with scalar loads
   DeviceBuffer<float> params_f32_{MemTag::Network};      // fp32 master copy (training)
   DeviceBuffer<float> grads_{MemTag::Network};           // fp32 gradient of the whole blob
   DeviceBuffer<float> adam_m_{MemTag::Network}, adam_v_{MemTag::Network};

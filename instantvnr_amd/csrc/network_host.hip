@@ -11,8 +11,9 @@ namespace vnr {
 
 void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width, uint32_t n_hidden_matmuls, hipStream_t s);
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
-                  const uint16_t* table, const uint16_t* packed, uint32_t lds_halves, const float* coords, float* out,
-                  uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s);
+                  const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
+                  float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
+                  const uint32_t* d_dest = nullptr);
 void launch_init_params(float* master, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
                         uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s);
 void launch_f16_to_f32(const uint16_t* in, float* out, size_t n, hipStream_t s);
@@ -74,9 +75,11 @@ uint32_t grid_make_layout(const ModelConfig& cfg, GridDevice* out)
     LevelInfo& lv = out->levels[l];
     lv.scale = scale;
     lv.resolution = res;
+    lv.res2 = res * res;
     lv.size = n;
     lv.offset = offset;
     lv.hashed = n < stride ? 1u : 0u;
+    lv.pad0 = lv.pad1 = 0;
     if (lv.hashed && (n & (n - 1)) != 0) throw std::runtime_error("internal: hashed level with non power-of-two size");
     offset += n;
   }
@@ -173,6 +176,9 @@ void Network::build_layout()
   lds_halves_ = (in_width_ / 16) * 1024 + n_hidden_matmuls() * 4096 + 64;
   params_f16_.resize(n_params_);
   mlp_packed_.resize(lds_halves_);
+  levels_dev_.resize(kMaxLevels);
+  levels_dev_.upload(grid_.levels, kMaxLevels, Runtime::get().stream);
+  VNR_HIP_CHECK(hipStreamSynchronize(Runtime::get().stream));
   // training state is allocated lazily on the first training step
   params_f32_.release(); grads_.release(); adam_m_.release(); adam_v_.release();
   ws_batch_ = 0;
@@ -240,16 +246,17 @@ void Network::deserialize_params(const Json& j, hipStream_t s)
   if (j.contains("optimizer") || j.contains("step")) { /* optimizer state is not stored by the reference */ }
 }
 
-void Network::inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s) const
+void Network::inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
+                        const uint32_t* d_dest) const
 {
-  launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, params_f16_.ptr + n_mlp_, mlp_packed_.ptr,
-               lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s);
+  launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
+               mlp_packed_.ptr, lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest);
 }
 
 void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const
 {
-  launch_fused(1, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, params_f16_.ptr + n_mlp_, mlp_packed_.ptr,
-               lds_halves_, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s);
+  launch_fused(1, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
+               mlp_packed_.ptr, lds_halves_, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s);
 }
 
 size_t Network::bytes_allocated() const

@@ -9,12 +9,14 @@
 //  * one wave64 owns 64 samples end to end; nothing but the weights ever touches LDS.
 //  * encode: lane = sample, level is wave-uniform, so every gather instruction reads 64 spatially coherent
 //    samples of ONE level (scalar level constants, best L1/L2 locality); features stay in VGPRs as fp16.
+//    Gathers are buffer loads with 32-bit offsets; index arithmetic avoids 32-bit integer multiplies.
 //  * MLP on v_mfma_f32_32x32x16_f16 computed TRANSPOSED: Y^T[64 x samples] = W[64 x K] . X^T[K x samples].
 //    Weights are the A operand (read from an LDS image, conflict-free ds_read_b128), activations the B operand.
 //    The 32x32 accumulator of one layer (column = sample on the lane, rows = neurons in registers) is, after
 //    ReLU + fp16 pack, directly the B operand of the next layer (k-order permutation folded into the packed
 //    weight image), so activations never leave registers.  v_permlane32_swap builds the first layer's B
-//    operand from the per-lane feature vectors.
+//    operand from the per-lane feature vectors.  The two 32-sample column tiles of a wave run the MLP one
+//    after the other to keep the accumulator footprint at 32 registers (occupancy).
 //  * persistent blocks, XCD-contiguous tile ranges, sample count optionally read from device memory so the
 //    ray marcher never syncs with the host.
 #include "grid_device.h"
@@ -66,14 +68,17 @@ void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width
 
 // ------------------------------------------------------------------------------------------------
 struct InferArgs {
-  GridDevice grid;
+  const LevelInfo* levels;   // device table of per-level constants (scalar loads)
+  uint32_t n_levels, interpolation;
   const half_t* table;       // grid part of the parameter blob
+  uint32_t table_bytes;
   const half_t* packed_mlp;  // LDS image
   const float* coords;       // [n][3]
   float* out;                // [n]
   half_t* features_out;      // encode-only / training: [n][K_IN] row-major (may be null)
   half_t* acts_out;          // training: [(nh+1)][n][64] post-activation hidden outputs (may be null)
   const uint32_t* n_ptr;     // if non-null the sample count is read from here
+  const uint32_t* dest;      // if non-null, sample i's result goes to out[dest[i]]
   uint32_t n;
   uint32_t n_hidden_matmuls;
   uint32_t activation;       // 0 none, 1 relu
@@ -117,6 +122,79 @@ __device__ __forceinline__ void swap_halves8(half8_t& p, half8_t& q)
   q = __builtin_bit_cast(half8_t, b);
 }
 
+__device__ __forceinline__ void store_acts(half_t* row, const half8_t (&bf)[4], uint32_t h)
+{
+  // element j of bf[s] on lane (r, h) is neuron 16 s + 8 (j>>2) + 4 h + (j&3)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    *(half4_t*)(row + 16 * s + 4 * h) = half4_t{bf[s][0], bf[s][1], bf[s][2], bf[s][3]};
+    *(half4_t*)(row + 16 * s + 8 + 4 * h) = half4_t{bf[s][4], bf[s][5], bf[s][6], bf[s][7]};
+  }
+}
+
+// The MLP for ONE 32-sample column tile of the wave.  b1[s] = first-layer B fragments (k = 16 s + 8 h + j).
+// Returns this lane's partial sum of the output neuron (its 32 of the 64 last-layer terms).
+template <int S1, bool TRAIN>
+__device__ __forceinline__ float mlp_column_tile(const half_t* __restrict__ lds, const half8_t (&b1)[S1], uint32_t nh, bool relu,
+                                                 uint32_t h, uint32_t r, half_t* acts_out, size_t n, uint32_t smp, bool smp_ok)
+{
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < S1; ++s) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const half8_t a = *(const half8_t*)(lds + ((s * 2 + h) * 64 + m * 32 + r) * 8);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1[s], acc[m], 0, 0, 0);
+    }
+  }
+  half8_t bf[4];  // activations as next-layer B fragments, one per k-step
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) bf[2 * m + sh] = pack_act(acc[m], sh, relu);
+  if (TRAIN && acts_out && smp_ok) store_acts(acts_out + (size_t)smp * 64, bf, h);
+
+  for (uint32_t layer = 0; layer < nh; ++layer) {
+    const half_t* w = lds + S1 * 1024 + layer * 4096;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * 64 + m * 32 + r) * 8);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s], acc[m], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) bf[2 * m + sh] = pack_act(acc[m], sh, relu);
+    if (TRAIN && acts_out && smp_ok) store_acts(acts_out + ((size_t)(layer + 1) * n + smp) * 64, bf, h);
+  }
+
+  // last layer: output neuron 0 only (the other 15 padded rows are never read)
+  const half_t* wl = lds + S1 * 1024 + nh * 4096;
+  float part = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const half8_t wv = *(const half8_t*)(wl + (s * 2 + h) * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const half2_t a2 = {bf[s][2 * q], bf[s][2 * q + 1]};
+      const half2_t w2 = {wv[2 * q], wv[2 * q + 1]};
+      part = __builtin_amdgcn_fdot2(a2, w2, part, false);
+    }
+  }
+  return part;
+}
+
 // MODE 0: inference (out only), 1: encode only (features_out), 2: training forward (features + acts + out)
 template <int F, int K_IN, int MODE>
 __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
@@ -147,6 +225,7 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
   const bool relu = args.activation == 1;
   const uint32_t h = lane >> 5;   // lane half
   const uint32_t r = lane & 31u;  // row (A operand) / column (B, D operands)
+  const table_rsrc_t rsrc = make_table_rsrc(args.table, args.table_bytes);
 
   for (uint32_t tile = xcd * per_xcd + (blockIdx.x >> 3) * 4u + wave; tile < tile_end; tile += waves_per_xcd) {
     const uint32_t i = tile * 64u + lane;
@@ -155,17 +234,34 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
 
     // ---- encode: lane = sample, level wave-uniform ------------------------------------------------
     half8_t feat[NCHUNK];
+    // The level table is re-read (scalar loads) every tile: making the pointer opaque per iteration keeps the
+    // compiler from hoisting 16 x 6 loop-invariant scalars out of the persistent loop and spilling them.
+    // (constant address space => scalar s_load_dwordx8 per level)
+    typedef const __attribute__((address_space(4))) LevelInfo* const_levels_t;
+    const LevelInfo* lvtab_generic = args.levels;
+    asm volatile("" : "+s"(lvtab_generic));
+    const const_levels_t lvtab = (const_levels_t)lvtab_generic;
 #pragma unroll
     for (int l = 0; l < L_PAD; ++l) {
       half_t o[F];
-      if (l < (int)args.grid.n_levels) {
-        encode_level<F>(args.grid.levels[l], args.grid.interpolation, args.table, p.x, p.y, p.z, o);
+      if (l < (int)args.n_levels) {
+        // wave-uniform by construction; say so, or hipcc wraps every buffer load in a waterfall loop
+        LevelInfo lv;
+        lv.scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lvtab[l].scale)));
+        lv.resolution = __builtin_amdgcn_readfirstlane(lvtab[l].resolution);
+        lv.res2 = __builtin_amdgcn_readfirstlane(lvtab[l].res2);
+        lv.size = __builtin_amdgcn_readfirstlane(lvtab[l].size);
+        lv.offset = __builtin_amdgcn_readfirstlane(lvtab[l].offset);
+        lv.hashed = __builtin_amdgcn_readfirstlane(lvtab[l].hashed);
+        encode_level_fast<F>(lv, args.interpolation, rsrc, p.x, p.y, p.z, o);
       } else {
 #pragma unroll
         for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
       }
 #pragma unroll
       for (int f = 0; f < F; ++f) feat[(l * F + f) / 8][(l * F + f) % 8] = o[f];
+      // keep the level constants (scalar registers) of at most four levels live at a time
+      if ((l & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 
     if (MODE != 0 && args.features_out && i < n) {
@@ -175,124 +271,28 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
     }
     if (MODE == 1) continue;
 
-    // ---- first layer: B operand = X^T via permlane32 swaps --------------------------------------
+    // ---- first layer operands: B = X^T via permlane32 swaps --------------------------------------
     // before: lane (sample) holds chunks 2s (P) and 2s+1 (Q) of its own sample.
     // after : P = B fragment of column tile 0, Q = B fragment of column tile 1 (k = 16 s + 8 h + j).
 #pragma unroll
     for (int s = 0; s < S1; ++s) swap_halves8(feat[2 * s], feat[2 * s + 1]);
 
-    f32x16 acc[2][2];
+    float part[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int nt = 0; nt < 2; ++nt) {
+      half8_t b1[S1];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
-
-#pragma unroll
-    for (int s = 0; s < S1; ++s) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const half8_t a = *(const half8_t*)(lds + ((s * 2 + h) * 64 + m * 32 + r) * 8);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, feat[2 * s + nt], acc[m][nt], 0, 0, 0);
-      }
+      for (int s = 0; s < S1; ++s) b1[s] = feat[2 * s + nt];
+      const uint32_t smp = tile * 64u + 32u * nt + r;
+      part[nt] = mlp_column_tile<S1, MODE == 2>((const half_t*)lds, b1, nh, relu, h, r, args.acts_out, n, smp, smp < n);
     }
 
-    // activations as next-layer B fragments: bf[k-step][column tile]
-    half8_t bf[4][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int sh = 0; sh < 2; ++sh)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bf[2 * m + sh][nt] = pack_act(acc[m][nt], sh, relu);
-
-    if (MODE == 2 && args.acts_out) {
-      // element j of bf[s][nt] on lane (r, h) is neuron 16 s + 8 (j>>2) + 4 h + (j&3) of sample tile*64 + 32 nt + r
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const uint32_t smp = tile * 64u + 32u * nt + r;
-        if (smp < n) {
-          half_t* row = args.acts_out + (size_t)smp * 64;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const half4_t lo = {bf[s][nt][0], bf[s][nt][1], bf[s][nt][2], bf[s][nt][3]};
-            const half4_t hi = {bf[s][nt][4], bf[s][nt][5], bf[s][nt][6], bf[s][nt][7]};
-            *(half4_t*)(row + 16 * s + 4 * h) = lo;
-            *(half4_t*)(row + 16 * s + 8 + 4 * h) = hi;
-          }
-        }
-      }
-    }
-
-    // ---- hidden layers ----------------------------------------------------------------------------
-    for (uint32_t layer = 0; layer < nh; ++layer) {
-      const half_t* w = lds + S1 * 1024 + layer * 4096;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * 64 + m * 32 + r) * 8);
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s][nt], acc[m][nt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) bf[2 * m + sh][nt] = pack_act(acc[m][nt], sh, relu);
-
-      if (MODE == 2 && args.acts_out) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const uint32_t smp = tile * 64u + 32u * nt + r;
-          if (smp < n) {
-            half_t* row = args.acts_out + ((size_t)(layer + 1) * n + smp) * 64;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const half4_t lo = {bf[s][nt][0], bf[s][nt][1], bf[s][nt][2], bf[s][nt][3]};
-              const half4_t hi = {bf[s][nt][4], bf[s][nt][5], bf[s][nt][6], bf[s][nt][7]};
-              *(half4_t*)(row + 16 * s + 4 * h) = lo;
-              *(half4_t*)(row + 16 * s + 8 + 4 * h) = hi;
-            }
-          }
-        }
-      }
-    }
-
-    // ---- last layer: output neuron 0 only (the other 15 padded rows are never read) --------------
-    const half_t* wl = lds + S1 * 1024 + nh * 4096;
-    float part[2] = {0.0f, 0.0f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const half8_t wv = *(const half8_t*)(wl + (s * 2 + h) * 8);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const half2_t a2 = {bf[s][nt][2 * q], bf[s][nt][2 * q + 1]};
-          const half2_t w2 = {wv[2 * q], wv[2 * q + 1]};
-          part[nt] = __builtin_amdgcn_fdot2(a2, w2, part[nt], false);
-        }
-      }
-    }
     // combine the two lane halves: lanes < 32 get column tile 0, lanes >= 32 column tile 1
     uint32_t p0 = __builtin_bit_cast(uint32_t, part[0]), p1 = __builtin_bit_cast(uint32_t, part[1]);
     swap_halves(p0, p1);
     const float y = __builtin_bit_cast(float, p0) + __builtin_bit_cast(float, p1);
     // network output is produced in half precision and then cast to float (tcnn_impl.cu:421-431)
-    if (i < n) args.out[i] = (float)(half_t)y;
+    if (i < n) args.out[args.dest ? args.dest[i] : i] = (float)(half_t)y;
   }
 }
 
@@ -331,20 +331,26 @@ static void dispatch(uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max
 }
 
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
-                  const uint16_t* table, const uint16_t* packed, uint32_t lds_halves, const float* coords, float* out,
-                  uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s)
+                  const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
+                  float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
+                  const uint32_t* d_dest)
 {
   if (n_max == 0) return;
   if (n_max > 0xffffffc0ull) throw std::runtime_error("inference batch too large (max 2^32-64 samples per call)");
+  if (table_bytes >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
   InferArgs a;
-  a.grid = grid;
+  a.levels = d_levels;
+  a.n_levels = grid.n_levels;
+  a.interpolation = grid.interpolation;
   a.table = (const half_t*)table;
+  a.table_bytes = (uint32_t)table_bytes;
   a.packed_mlp = (const half_t*)packed;
   a.coords = coords;
   a.out = out;
   a.features_out = (half_t*)features_out;
   a.acts_out = (half_t*)acts_out;
   a.n_ptr = d_n;
+  a.dest = d_dest;
   a.n = (uint32_t)n;
   a.n_hidden_matmuls = n_hidden_matmuls;
   a.activation = activation;

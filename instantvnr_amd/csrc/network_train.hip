@@ -13,8 +13,9 @@
 namespace vnr {
 
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
-                  const uint16_t* table, const uint16_t* packed, uint32_t lds_halves, const float* coords, float* out,
-                  uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s);
+                  const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
+                  float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
+                  const uint32_t* d_dest = nullptr);
 
 // ------------------------------------------------------------------------------------------------ pcg32
 struct Pcg32 {
@@ -493,8 +494,8 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   ts.packedT.ensure(pt);
 
   // 1. forward, keeping features and hidden activations
-  launch_fused(2, grid_, in_width_, nh, cfg_.activation, params_f16_.ptr + n_mlp_, mlp_packed_.ptr, lds_halves_, d_coords,
-               ts.y.ptr, ws_features_.ptr, ws_acts_.ptr, batch, nullptr, batch, s);
+  launch_fused(2, grid_, in_width_, nh, cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2, mlp_packed_.ptr,
+               lds_halves_, d_coords, ts.y.ptr, ws_features_.ptr, ws_acts_.ptr, batch, nullptr, batch, s);
   // 2. loss + output gradient
   loss_grad_kernel<<<ts.loss_blocks, 256, 0, s>>>(ts.y.ptr, d_targets, n, cfg_.loss, (half_t*)ts.dy.ptr, ws_loss_.ptr);
   // 3. MLP backward

@@ -43,7 +43,9 @@ struct RenderParams {
   vec4f* accumulation;
   int width, height, frame_index;
   uint32_t pixel_lo, pixel_hi;
-  uint32_t il_block, il_parts, il_part, n_local;  // pixel-block interleave across ranks; n_local = local index count
+  uint32_t il_parts, il_part, n_local;   // tile-row interleave across ranks; n_local = local index count
+  uint32_t tiles_per_row, tile_row0;     // 8x8 pixel tiles: rays of a wave are an image patch, not a scanline
+  float bin_depth_rcp;                   // 1 / depth of one sample-sorting bin (world units)
   vec3f cam_pos, cam_dir, cam_hor, cam_ver;
   affine3f wto;
   vec3i vol_dims;
@@ -56,6 +58,8 @@ struct RenderParams {
   DeviceTfn tfn;
   int n_iters;
 };
+
+constexpr int kDepthBins = 64;
 
 enum { C_RAYS0 = 0, C_RAYS1 = 1, C_SAMPLES0 = 2, C_SAMPLES1 = 3, C_HIT = 4, C_STAT_SAMPLES = 6, C_STAT_REFRAYS = 8, C_COUNT = 16 };
 
@@ -87,16 +91,16 @@ __device__ __forceinline__ void compute_ray(const RenderParams& p, uint32_t pixe
   dir = xfm_vector(p.wto, normalize(d));
 }
 
-// local work index -> global pixel index of this rank's share of the image (tiles / interleaved pixel blocks)
+// local work index -> global pixel index of this rank's share of the image.  64 consecutive indices are one
+// 8x8 pixel tile; tile rows are dealt round-robin to the ranks (il_parts, il_part); a pixel range restricts further.
 __device__ __forceinline__ bool map_pixel(const RenderParams& p, uint32_t i, uint32_t& pixel)
 {
-  if (p.il_parts == 1) {
-    pixel = p.pixel_lo + i;
-  } else {
-    const uint32_t blk = i / p.il_block, off = i - blk * p.il_block;
-    pixel = (blk * p.il_parts + p.il_part) * p.il_block + off;
-  }
-  return pixel >= p.pixel_lo && pixel < p.pixel_hi;
+  const uint32_t tile = i >> 6, l = i & 63u;
+  const uint32_t tr_local = tile / p.tiles_per_row, tc = tile - tr_local * p.tiles_per_row;
+  const uint32_t x = tc * 8u + (l & 7u);
+  const uint32_t y = (p.tile_row0 + tr_local * p.il_parts + p.il_part) * 8u + (l >> 3);
+  pixel = y * (uint32_t)p.width + x;
+  return x < (uint32_t)p.width && y < (uint32_t)p.height && pixel >= p.pixel_lo && pixel < p.pixel_hi;
 }
 
 // gdt::LCG<16> (EXTERNAL; instantvnr_types.h:155)
@@ -220,22 +224,33 @@ __device__ __forceinline__ void iter_exec(const RenderParams& p, DDAState& it, v
 }
 
 // ------------------------------------------------------------------------------------------------ streaming march kernel
-// FIRST: thread = pixel of the tile (raygen, method_raymarching.cu:840-875) and emits the first batch.
+// FIRST: thread = pixel of an 8x8 pixel tile (raygen, method_raymarching.cu:840-875) and emits the first batch.
 // !FIRST: thread = alive ray: compose the batch inferred last iteration (:732-838), then emit the next (:687-730).
+//
+// Two views of one iteration's samples, both over the same compacted range [0, n_samples):
+//  * ray-major (values, dts): a ray's samples are contiguous, so compose needs only (base, count);
+//  * gather order (coords + `dest`): inside the 64-ray group of a wave the samples are counting-sorted by DEPTH BIN
+//    (bin = (t - t_group_front) / bin_depth, LDS histogram + wave scan).  One bin is a thin slab of an 8x8-pixel
+//    frustum, i.e. a compact brick of the volume, whatever the per-ray sample index is.  The fused inference kernel
+//    reads coords in this order (coherent hash-grid gathers: measured ~2x faster than ray-major order once rays have
+//    drifted apart in depth) and scatters its result to values[dest[i]].
 template <bool FIRST>
 __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const RayList cur, const RayList nxt,
                                                     const float* __restrict__ values, const float* __restrict__ dts_in,
-                                                    float* __restrict__ coords, float* __restrict__ dts_out,
-                                                    uint32_t* __restrict__ counters, int parity)
+                                                    float* __restrict__ coords, uint32_t* __restrict__ dest,
+                                                    float* __restrict__ dts_out, uint32_t* __restrict__ counters, int parity)
 {
-  extern __shared__ float s_t[];  // [2][n_iters][256]
+  extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1, bin|rank}  +  [4 waves][kDepthBins] histogram
   float* s_t0 = s_t;
   float* s_t1 = s_t + (size_t)p.n_iters * 256;
+  uint32_t* s_br = (uint32_t*)(s_t + (size_t)2 * p.n_iters * 256);
+  uint32_t* s_hist = s_br + (size_t)p.n_iters * 256 + (threadIdx.x >> 6) * kDepthBins;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t n_in = FIRST ? p.n_local : counters[C_RAYS0 + parity];
   uint32_t* n_rays_out = counters + C_RAYS0 + (parity ^ 1);
   uint32_t* n_samples_out = counters + C_SAMPLES0 + parity;
   const uint32_t n_round = (n_in + 255u) & ~255u;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
   for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
     const uint32_t i = base + tid;
@@ -322,10 +337,38 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     }
     ray_base = __shfl(ray_base, 0);
     smp_base = __shfl(smp_base, 0);
+    if (wave_rays == 0) continue;  // wave-uniform
+
+    // depth bins of the group: front = smallest first-sample depth among the surviving rays
+    float front = survive ? s_t0[tid] : VNR_FLOAT_LARGE;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) front = fminf(front, __shfl_xor(front, d));
+    s_hist[lane] = 0;  // kDepthBins == 64: one bin per lane
+    __builtin_amdgcn_wave_barrier();
+    if (survive) {
+      for (uint32_t j = 0; j < k; ++j) {
+        const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
+        const float t = (1.0f - jitter) * t0 + jitter * t1;
+        const uint32_t bin = min((uint32_t)kDepthBins - 1u, (uint32_t)fmaxf((t - front) * p.bin_depth_rcp, 0.0f));
+        const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
+        s_br[j * 256u + tid] = (bin << 16) | rank;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // exclusive scan of the 64-bin histogram across the wave
+    const uint32_t h = s_hist[lane];
+    uint32_t hs = h;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(hs, d);
+      if ((int)lane >= d) hs += y;
+    }
+    s_hist[lane] = hs - h;
+    __builtin_amdgcn_wave_barrier();
 
     if (survive) {
-      const uint32_t slot = ray_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      const uint32_t sb = smp_base + (incl - k);
+      const uint32_t slot = ray_base + (uint32_t)__popcll(mask & lt_mask);
+      const uint32_t sb = smp_base + (incl - k);  // ray-major base of this ray
       nxt.pixel_index[slot] = pixel;
       nxt.jitter[slot] = jitter;
       nxt.alpha[slot] = alpha;
@@ -339,22 +382,26 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
         const float t = (1.0f - jitter) * t0 + jitter * t1;  // lerp(jitter, t0, t1), instantvnr_types.h:162-166
         const vec3f c = org + t * dir;
-        coords[3 * (size_t)(sb + j) + 0] = c.x;
-        coords[3 * (size_t)(sb + j) + 1] = c.y;
-        coords[3 * (size_t)(sb + j) + 2] = c.z;
+        const uint32_t br = s_br[j * 256u + tid];
+        const size_t g = (size_t)smp_base + s_hist[br >> 16] + (br & 0xffffu);  // gather-order slot
+        coords[3 * g + 0] = c.x;
+        coords[3 * g + 1] = c.y;
+        coords[3 * g + 2] = c.z;
+        dest[g] = sb + j;
         dts_out[sb + j] = t1 - t0;
       }
     }
+    __builtin_amdgcn_wave_barrier();  // s_hist / s_br are reused by the next loop trip
   }
 }
 
 // iterative_sampling_groundtruth_kernel (method_raymarching.cu:902-915) over the compacted sample queue
 __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float* __restrict__ vol, vec3i dims,
-                                 const float* __restrict__ coords, float* __restrict__ values, uint32_t* clear0, uint32_t* clear1)
+                                 const float* __restrict__ coords, float* __restrict__ values, const uint32_t* __restrict__ dest)
 {
   const uint32_t n = *n_ptr;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    values[i] = sample_volume_nodal(vol, dims, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
+    values[dest[i]] = sample_volume_nodal(vol, dims, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
 }
 
 __global__ void clear_two_kernel(uint32_t* a, uint32_t* b)
@@ -484,6 +531,7 @@ void Renderer::ensure_queues(size_t n_pixels, int n_iters)
   coords_.resize(3 * P * n_iters);
   dts_.resize(2 * P * n_iters);
   values_.resize(P * n_iters);
+  dest_.resize(P * n_iters);
   queue_pixels_ = P;
   queue_iters_ = n_iters;
 }
@@ -499,13 +547,16 @@ void Renderer::render()
   p.pixel_lo = std::min(pixel_lo_, n_pixels);
   p.pixel_hi = std::min(pixel_hi_, n_pixels);
   if (p.pixel_hi < p.pixel_lo) p.pixel_hi = p.pixel_lo;
-  p.il_block = il_block_; p.il_parts = il_parts_; p.il_part = il_part_;
-  if (il_parts_ == 1) {
-    p.n_local = p.pixel_hi - p.pixel_lo;
-  } else {
-    const uint32_t n_blocks = div_round_up(n_pixels, il_block_);
-    p.n_local = div_round_up(n_blocks, il_parts_) * il_block_;
-  }
+  // rays are generated in 8x8 pixel tiles; tile rows (8 scanlines) are the unit of multi-GPU interleaving
+  if (il_parts_ > 1 && il_block_ != 8u * (uint32_t)width_) throw std::runtime_error("pixel interleave block must be 8 scanlines (8 * width pixels)");
+  p.il_parts = il_parts_; p.il_part = il_part_;
+  p.tiles_per_row = div_round_up((uint32_t)width_, 8);
+  const uint32_t tr_lo = p.pixel_hi > p.pixel_lo ? (p.pixel_lo / (uint32_t)width_) / 8u : 0u;
+  const uint32_t tr_hi = p.pixel_hi > p.pixel_lo ? ((p.pixel_hi - 1u) / (uint32_t)width_) / 8u + 1u : 0u;
+  p.tile_row0 = il_parts_ == 1 ? tr_lo : 0u;
+  const uint32_t rows_local = il_parts_ == 1 ? (tr_hi - tr_lo) : div_round_up(div_round_up((uint32_t)height_, 8), il_parts_);
+  p.n_local = rows_local * p.tiles_per_row * 64u;
+  p.bin_depth_rcp = 1.0f / 8.0f;  // 8 world units (voxels) per depth bin ~ the footprint of an 8x8 pixel tile
   // camera, renderer.cpp:87-96
   const float t = 2.0f * tanf(camera_.fovy * 0.5f * (float)M_PI / 180.0f);
   const float aspect = (float)width_ / (float)height_;
@@ -579,8 +630,10 @@ void Renderer::render_streaming(const RenderParams& p)
   if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
 
   VNR_HIP_CHECK(hipMemsetAsync(c, 0, C_COUNT * sizeof(uint32_t), stream_));
-  const size_t shmem = (size_t)2 * p.n_iters * 256 * sizeof(float);
-  const uint32_t max_iterations = 240;
+  const size_t shmem = ((size_t)3 * p.n_iters * 256 + 4 * kDepthBins) * sizeof(float);
+  uint32_t max_iterations = 240;
+  if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) max_iterations = std::max(1, std::min(240, std::atoi(e)));  // diagnostics only
+  if (profiling_) iter_ms_.assign(max_iterations, 0.0f);
   if (profiling_ && events_.size() < 2 * max_iterations) {
     while (events_.size() < 2 * max_iterations) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreate(&e)); events_.push_back(e); }
   }
@@ -591,20 +644,21 @@ void Renderer::render_streaming(const RenderParams& p)
     // march(it): reads ray list `parity`, writes list `parity^1` and sample queue `parity`
     if (it == 0) {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 4096u);
-      march_kernel<true><<<blocks, 256, shmem, stream_>>>(p, rl[0], rl[1], values_.ptr, dts[1], coords_.ptr, dts[0], c, 0);
+      march_kernel<true><<<blocks, 256, shmem, stream_>>>(p, rl[0], rl[1], values_.ptr, dts[1], coords_.ptr, dest_.ptr, dts[0], c, 0);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
-      march_kernel<false><<<blocks, 256, shmem, stream_>>>(p, rl[parity], rl[parity ^ 1], values_.ptr, dts[parity ^ 1], coords_.ptr, dts[parity], c, parity);
+      march_kernel<false><<<blocks, 256, shmem, stream_>>>(p, rl[parity], rl[parity ^ 1], values_.ptr, dts[parity ^ 1], coords_.ptr, dest_.ptr,
+                                                          dts[parity], c, parity);
     }
     // evaluate the compacted samples; the evaluation kernel also clears the counters march(it+1) will append to
     uint32_t* clear0 = c + C_RAYS0 + parity;            // output ray list of march(it+1)
     uint32_t* clear1 = c + C_SAMPLES0 + (parity ^ 1);   // sample counter of march(it+1)
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[2 * it], stream_));
     if (nv) {
-      nv->network().inference(coords_.ptr, values_.ptr, 0, c + C_SAMPLES0 + parity, s_max, stream_);
+      nv->network().inference(coords_.ptr, values_.ptr, 0, c + C_SAMPLES0 + parity, s_max, stream_, dest_.ptr);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
-      gt_sample_kernel<<<blocks, 256, 0, stream_>>>(c + C_SAMPLES0 + parity, p.volume, p.vol_dims, coords_.ptr, values_.ptr, nullptr, nullptr);
+      gt_sample_kernel<<<blocks, 256, 0, stream_>>>(c + C_SAMPLES0 + parity, p.volume, p.vol_dims, coords_.ptr, values_.ptr, dest_.ptr);
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[2 * it + 1], stream_));
     clear_two_kernel<<<1, 1, 0, stream_>>>(clear0, clear1);
@@ -635,6 +689,7 @@ void Renderer::render_streaming(const RenderParams& p)
       float ms = 0.0f;
       VNR_HIP_CHECK(hipEventElapsedTime(&ms, events_[2 * k], events_[2 * k + 1]));
       stats_.infer_kernel_ms += ms;
+      iter_ms_[k] = ms;
     }
     stats_.infer_kernel_launches = used > 0 ? used - 1 : 0;
   }

@@ -37,6 +37,10 @@ public:
   void set_device_output(bool e) { skip_download_ = e; }
   void set_pixel_range(uint32_t lo, uint32_t hi) { pixel_lo_ = lo; pixel_hi_ = hi; reset_ = true; }
   void set_profiling(bool e) { profiling_ = e; }
+  // diagnostics: the compacted sample queue of the last iteration and per-iteration kernel times of the last frame
+  const float* debug_coords() const { return coords_.ptr; }
+  const uint32_t* debug_counters() const { return counters_.ptr; }
+  const std::vector<float>& debug_iteration_ms() const { return iter_ms_; }
   // rank `part` of `parts` renders the pixel blocks b with b % parts == part (block = `block` consecutive pixels)
   void set_pixel_interleave(uint32_t block, uint32_t parts, uint32_t part)
   {
@@ -62,7 +66,7 @@ private:
   float sampling_rate_ = 1.0f, density_scale_ = 1.0f;
   int width_ = 0, height_ = 0;
   uint32_t pixel_lo_ = 0, pixel_hi_ = 0xffffffffu;
-  uint32_t il_block_ = 1, il_parts_ = 1, il_part_ = 0;
+  uint32_t il_block_ = 8, il_parts_ = 1, il_part_ = 0;
   bool reset_ = true, skip_download_ = false, profiling_ = false;
   int frame_index_ = 0;
   int n_iters_ = 16;  // VNR_RM_N_ITERS (method_raymarching.cu:30-40)
@@ -80,12 +84,14 @@ private:
   DeviceBuffer<float> q_f32_;      // jitter[2], alpha[2], color[2][3], t_next[2][3], next_cell_begin[2]
   DeviceBuffer<int> q_i32_;        // cell[2][3]
   DeviceBuffer<float> coords_, dts_, values_;
+  DeviceBuffer<uint32_t> dest_;    // gather-order slot -> ray-major slot of the same sample
   DeviceBuffer<uint32_t> counters_;
   uint32_t* host_counts_ = nullptr;  // pinned ring of alive-ray counts
   size_t queue_pixels_ = 0;
   int queue_iters_ = 0;
   std::vector<hipEvent_t> events_;
   FrameStats stats_;
+  std::vector<float> iter_ms_;
 };
 
 }  // namespace vnr

@@ -1,0 +1,207 @@
+// vnr_api_shim.hpp — header-only binding that re-exposes the reference's C++ API (`/root/reference/api.h:28-188`)
+// on top of the C-ABI of libvnr_amd.so (include/vnr_amd.h).
+//
+// An OVR app / `apps/*.cpp` of the reference includes this header INSTEAD of `api.h` and links `-lvnr_amd` instead of
+// the static `instantvnr` target; call sites stay unchanged: same function names, shared_ptr handles, exceptions.
+//
+// Requirements on the including side (they are the reference's own, api.h:11-13):
+//   * `nlohmann::json` >= 3.4 with BSON support (`json::to_bson`) as `<json/json.hpp>` or `<nlohmann/json.hpp>`
+//   * vector types with public x/y/z(/w) members; the reference uses gdt's `vnr::vec3f` etc. (core/mathdef.h).
+//     Define VNR_SHIM_OWN_MATH to get minimal layout-compatible types from this header instead.
+#pragma once
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "vnr_amd.h"
+
+#if defined(__has_include)
+#if __has_include(<json/json.hpp>)
+#include <json/json.hpp>
+#elif __has_include(<nlohmann/json.hpp>)
+#include <nlohmann/json.hpp>
+#else
+#include <json.hpp>
+#endif
+#else
+#include <json/json.hpp>
+#endif
+// nlohmann < 3.4 has no BSON: define VNR_SHIM_JSON_TEXT_TRANSPORT to ship documents as JSON text instead (model configs
+// only — params.json carries binary members and then has to be passed as a file path).
+
+namespace vnr {
+using json = nlohmann::json;
+
+#ifdef VNR_SHIM_OWN_MATH
+struct vec2i { int x, y; };
+struct vec2f { float x, y; };
+struct vec3i { int x, y, z; };
+struct vec3f { float x, y, z; };
+struct vec4f { float x, y, z, w; };
+struct range1f { float lower, upper; };
+#endif
+
+namespace shim {
+[[noreturn]] inline void fail() { throw std::runtime_error(vnrAmdGetLastError()); }  // api.cpp throws std::runtime_error
+inline void check(int status) { if (status != VNR_AMD_OK) fail(); }
+template <typename T> inline T* check_ptr(T* p) { if (!p) fail(); return p; }
+
+// A json that is a string is a path (api.cpp:77-83,148-153,180-185,269-278); otherwise ship the document itself.
+struct JsonArg {
+  std::vector<std::uint8_t> bytes;
+  std::string path;
+  int format;
+  JsonArg(const json& j, bool params)
+  {
+    if (j.is_string()) { path = j.get<std::string>(); format = params ? VNR_AMD_JSON_BSON_FILE : VNR_AMD_JSON_TEXT_FILE; }
+#ifdef VNR_SHIM_JSON_TEXT_TRANSPORT
+    else { const std::string t = j.dump(); bytes.assign(t.begin(), t.end()); format = VNR_AMD_JSON_TEXT; }
+#else
+    else { bytes = json::to_bson(j); format = VNR_AMD_JSON_BSON; }
+#endif
+  }
+  const void* data() const { return path.empty() ? (const void*)bytes.data() : (const void*)path.c_str(); }
+  size_t size() const { return path.empty() ? bytes.size() : path.size() + 1; }
+};
+}  // namespace shim
+}  // namespace vnr
+
+// api.h:28-32
+typedef std::shared_ptr<vnrAmdVolume_t> vnrVolume;
+typedef std::shared_ptr<vnrAmdRenderer_t> vnrRenderer;
+typedef std::shared_ptr<vnrAmdTransferFunction_t> vnrTransferFunction;
+typedef std::shared_ptr<vnrAmdCamera_t> vnrCamera;
+typedef vnr::json vnrJson;
+
+// api.h:36-60 (same numeric values as the VNR_AMD_* enum)
+enum vnrRenderMode {
+  VNR_OPTIX_NO_SHADING = 0, VNR_OPTIX_GRADIENT_SHADING, VNR_OPTIX_FULL_SHADOW, VNR_OPTIX_SINGLE_SHADE_HEURISTIC,
+  VNR_RAYMARCHING_NO_SHADING_DECODING, VNR_RAYMARCHING_NO_SHADING_SAMPLE_STREAMING, VNR_RAYMARCHING_NO_SHADING_IN_SHADER,
+  VNR_RAYMARCHING_GRADIENT_SHADING_DECODING, VNR_RAYMARCHING_GRADIENT_SHADING_SAMPLE_STREAMING, VNR_RAYMARCHING_GRADIENT_SHADING_IN_SHADER,
+  VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_DECODING, VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_SAMPLE_STREAMING,
+  VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_IN_SHADER, VNR_PATHTRACING_DECODING, VNR_PATHTRACING_SAMPLE_STREAMING,
+  VNR_PATHTRACING_IN_SHADER, VNR_INVALID,
+};
+
+// ---- json (api.h:90-96): handled entirely by the app's nlohmann (same code as api.cpp:17-62) ------------------
+#include <fstream>
+#include <iomanip>
+inline void vnrLoadJsonText(vnrJson& out, std::string filename)
+{
+  std::ifstream f(filename);
+#ifndef VNR_SHIM_JSON_TEXT_TRANSPORT
+  out = vnr::json::parse(f, nullptr, true, true);  // comments allowed, api.cpp:20
+#else
+  out = vnr::json::parse(f);
+#endif
+}
+inline void vnrLoadJsonBinary(vnrJson& out, std::string filename)
+{
+  std::ifstream f(filename, std::ios::binary | std::ios::ate);
+  std::streamsize size = f.tellg();
+  f.seekg(0, std::ios::beg);
+  std::vector<char> buffer(size);
+#ifndef VNR_SHIM_JSON_TEXT_TRANSPORT
+  if (f.read(buffer.data(), size)) out = vnr::json::from_bson(buffer);
+#else
+  (void)out; throw std::runtime_error("BSON needs nlohmann::json >= 3.4");
+#endif
+}
+inline void vnrSaveJsonText(const vnrJson& root, std::string filename) { std::ofstream o(filename); o << std::setw(4) << root << std::endl; }
+inline void vnrSaveJsonBinary(const vnrJson& root, std::string filename)
+{
+#ifndef VNR_SHIM_JSON_TEXT_TRANSPORT
+  const auto b = vnr::json::to_bson(root);
+  std::ofstream o(filename, std::ios::binary | std::ios::out);
+  o.write((const char*)b.data(), b.size());
+#else
+  (void)root; (void)filename; throw std::runtime_error("BSON needs nlohmann::json >= 3.4");
+#endif
+}
+inline vnrJson vnrCreateJsonText(std::string filename) { vnrJson j; vnrLoadJsonText(j, filename); return j; }
+inline vnrJson vnrCreateJsonBinary(std::string filename) { vnrJson j; vnrLoadJsonBinary(j, filename); return j; }
+
+// ---- camera (api.h:103-110) -----------------------------------------------------------------------------------
+inline vnrCamera vnrCreateCamera() { return vnrCamera(vnr::shim::check_ptr(vnrAmdCreateCamera()), vnrAmdReleaseCamera); }
+inline void vnrCameraSet(vnrCamera c, vnr::vec3f from, vnr::vec3f at, vnr::vec3f up)
+{
+  const float f[3] = {from.x, from.y, from.z}, a[3] = {at.x, at.y, at.z}, u[3] = {up.x, up.y, up.z};
+  vnr::shim::check(vnrAmdCameraSet(c.get(), f, a, u));
+}
+inline vnr::vec3f vnrCameraGetPosition(vnrCamera c) { float v[3]; vnr::shim::check(vnrAmdCameraGet(c.get(), v, nullptr, nullptr, nullptr)); return vnr::vec3f{v[0], v[1], v[2]}; }
+inline vnr::vec3f vnrCameraGetFocus(vnrCamera c) { float v[3]; vnr::shim::check(vnrAmdCameraGet(c.get(), nullptr, v, nullptr, nullptr)); return vnr::vec3f{v[0], v[1], v[2]}; }
+inline vnr::vec3f vnrCameraGetUpVec(vnrCamera c) { float v[3]; vnr::shim::check(vnrAmdCameraGet(c.get(), nullptr, nullptr, v, nullptr)); return vnr::vec3f{v[0], v[1], v[2]}; }
+
+// ---- volumes (api.h:117-148) -----------------------------------------------------------------------------------
+// vnrCreateSimpleVolume(scene json, mode, save): the scene-JSON loader (serializer.cpp) is SURVEY §8f "next"; until it lands
+// the app passes the raw file description explicitly.
+inline vnrVolume vnrCreateSimpleVolumeFromRawFile(const std::string& filename, vnr::vec3i dims, int value_type, size_t offset = 0,
+                                                  bool big_endian = false)
+{
+  const int d[3] = {dims.x, dims.y, dims.z};
+  return vnrVolume(vnr::shim::check_ptr(vnrAmdCreateSimpleVolumeFromRawFile(filename.c_str(), d, value_type, offset, big_endian, 1.f, 0.f)), vnrAmdReleaseVolume);
+}
+inline vnrVolume vnrCreateNeuralVolume(const vnrJson& config, vnrVolume groundtruth, bool online_macrocell_construction = true)
+{
+  vnr::shim::JsonArg a(config, false);
+  return vnrVolume(vnr::shim::check_ptr(vnrAmdCreateNeuralVolume(a.data(), a.size(), a.format, groundtruth.get(), online_macrocell_construction)), vnrAmdReleaseVolume);
+}
+inline vnrVolume vnrCreateNeuralVolume(const vnrJson& config, vnr::vec3i dims)
+{
+  vnr::shim::JsonArg a(config, false);
+  const int d[3] = {dims.x, dims.y, dims.z};
+  return vnrVolume(vnr::shim::check_ptr(vnrAmdCreateNeuralVolumeFromDims(a.data(), a.size(), a.format, d)), vnrAmdReleaseVolume);
+}
+inline vnrVolume vnrCreateNeuralVolume(const vnrJson& params)
+{
+  vnr::shim::JsonArg a(params, true);
+  return vnrVolume(vnr::shim::check_ptr(vnrAmdCreateNeuralVolumeFromParams(a.data(), a.size(), a.format)), vnrAmdReleaseVolume);
+}
+inline void vnrNeuralVolumeSetModel(vnrVolume v, const vnrJson& config) { vnr::shim::JsonArg a(config, false); vnr::shim::check(vnrAmdNeuralVolumeSetModel(v.get(), a.data(), a.size(), a.format)); }
+inline void vnrNeuralVolumeSetParams(vnrVolume v, const vnrJson& params) { vnr::shim::JsonArg a(params, true); vnr::shim::check(vnrAmdNeuralVolumeSetParams(v.get(), a.data(), a.size(), a.format)); }
+inline double vnrNeuralVolumeGetPSNR(vnrVolume v, bool verbose) { return vnrAmdNeuralVolumeGetPSNR(v.get(), verbose); }
+inline double vnrNeuralVolumeGetTestingLoss(vnrVolume v) { return vnrAmdNeuralVolumeGetTestingLoss(v.get()); }
+inline double vnrNeuralVolumeGetTrainingLoss(vnrVolume v) { return vnrAmdNeuralVolumeGetTrainingLoss(v.get()); }
+inline int vnrNeuralVolumeGetTrainingStep(vnrVolume v) { return vnrAmdNeuralVolumeGetTrainingStep(v.get()); }
+inline int vnrNeuralVolumeGetNumberOfBlobs(vnrVolume v) { return vnrAmdNeuralVolumeGetNumberOfBlobs(v.get()); }
+inline void vnrNeuralVolumeTrain(vnrVolume v, int steps, bool fast_mode) { vnr::shim::check(vnrAmdNeuralVolumeTrain(v.get(), steps, fast_mode)); }
+inline void vnrNeuralVolumeSerializeParams(vnrVolume v, std::string filename) { vnr::shim::check(vnrAmdNeuralVolumeSerializeParamsToFile(v.get(), filename.c_str())); }
+inline void vnrNeuralVolumeSerializeParams(vnrVolume v, vnrJson& params)
+{
+  void* b = nullptr; size_t n = 0;
+  vnr::shim::check(vnrAmdNeuralVolumeSerializeParams(v.get(), &b, &n));
+#ifndef VNR_SHIM_JSON_TEXT_TRANSPORT
+  params = vnr::json::from_bson((const std::uint8_t*)b, (const std::uint8_t*)b + n);
+#else
+  (void)params;
+#endif
+  vnrAmdFreeHost(b);
+}
+inline void vnrVolumeSetClippingBox(vnrVolume v, vnr::vec3f lo, vnr::vec3f hi) { const float l[3] = {lo.x, lo.y, lo.z}, u[3] = {hi.x, hi.y, hi.z}; vnr::shim::check(vnrAmdVolumeSetClippingBox(v.get(), l, u)); }
+inline void vnrVolumeSetScaling(vnrVolume v, vnr::vec3f s) { const float a[3] = {s.x, s.y, s.z}; vnr::shim::check(vnrAmdVolumeSetScaling(v.get(), a)); }
+inline vnr::range1f vnrVolumeGetValueRange(vnrVolume v) { float r[2]; vnr::shim::check(vnrAmdVolumeGetValueRange(v.get(), r)); return vnr::range1f{r[0], r[1]}; }
+
+// ---- transfer function (api.h:154-162) ---------------------------------------------------------------------------
+inline vnrTransferFunction vnrCreateTransferFunction() { return vnrTransferFunction(vnr::shim::check_ptr(vnrAmdCreateTransferFunction()), vnrAmdReleaseTransferFunction); }
+inline void vnrTransferFunctionSetColor(vnrTransferFunction t, const std::vector<vnr::vec3f>& c) { vnr::shim::check(vnrAmdTransferFunctionSetColor(t.get(), c.empty() ? nullptr : &c[0].x, (int)c.size())); }
+inline void vnrTransferFunctionSetAlpha(vnrTransferFunction t, const std::vector<vnr::vec2f>& a) { vnr::shim::check(vnrAmdTransferFunctionSetAlpha(t.get(), a.empty() ? nullptr : &a[0].x, (int)a.size())); }
+inline void vnrTransferFunctionSetValueRange(vnrTransferFunction t, vnr::range1f r) { vnr::shim::check(vnrAmdTransferFunctionSetValueRange(t.get(), r.lower, r.upper)); }
+
+// ---- renderer (api.h:168-178) ---------------------------------------------------------------------------------------
+inline vnrRenderer vnrCreateRenderer(vnrVolume v) { return vnrRenderer(vnr::shim::check_ptr(vnrAmdCreateRenderer(v.get())), vnrAmdReleaseRenderer); }
+inline void vnrRendererSetFramebufferSize(vnrRenderer r, vnr::vec2i s) { vnr::shim::check(vnrAmdRendererSetFramebufferSize(r.get(), s.x, s.y)); }
+inline void vnrRendererSetTransferFunction(vnrRenderer r, vnrTransferFunction t) { vnr::shim::check(vnrAmdRendererSetTransferFunction(r.get(), t.get())); }
+inline void vnrRendererSetCamera(vnrRenderer r, vnrCamera c) { vnr::shim::check(vnrAmdRendererSetCamera(r.get(), c.get())); }
+inline void vnrRendererSetMode(vnrRenderer r, int mode) { vnr::shim::check(vnrAmdRendererSetMode(r.get(), mode)); }
+inline void vnrRendererSetDenoiser(vnrRenderer r, bool f) { vnr::shim::check(vnrAmdRendererSetDenoiser(r.get(), f)); }
+inline void vnrRendererSetVolumeSamplingRate(vnrRenderer r, float v) { vnr::shim::check(vnrAmdRendererSetVolumeSamplingRate(r.get(), v)); }
+inline void vnrRendererSetVolumeDensityScale(vnrRenderer r, float v) { vnr::shim::check(vnrAmdRendererSetVolumeDensityScale(r.get(), v)); }
+inline void vnrRendererResetAccumulation(vnrRenderer r) { vnr::shim::check(vnrAmdRendererResetAccumulation(r.get())); }
+inline void vnrRender(vnrRenderer r) { vnr::shim::check(vnrAmdRender(r.get())); }
+inline vnr::vec4f* vnrRendererMapFrame(vnrRenderer r) { return (vnr::vec4f*)vnr::shim::check_ptr(vnrAmdRendererMapFrame(r.get())); }
+
+// ---- misc (api.h:186-188) -------------------------------------------------------------------------------------------
+inline void vnrMemoryQuery(size_t* used_by_renderer, size_t* used_by_tcnn) { vnrAmdMemoryQuery(used_by_renderer, used_by_tcnn); }
+inline void vnrFreeTemporaryGPUMemory() { vnrAmdFreeTemporaryGPUMemory(); }

@@ -105,3 +105,21 @@ def test_no_cpu_fallback_without_device(L):
     with pytest.raises(api.VnrAmdError):
         api.vnrCreateNeuralVolume({"encoding": {"otype": "HashGrid"}, "network": {"otype": "FullyFusedMLP", "n_neurons": 64}},
                                   (8, 8, 8))
+
+
+def test_cpp_api_shim_compiles_and_throws_like_the_reference(L, tmp_path):
+    """include/vnr_api_shim.hpp restores the api.h C++ signatures over the C-ABI.  Compiled here against the only
+    nlohmann::json in the image (3.1.1, no BSON => VNR_SHIM_JSON_TEXT_TRANSPORT); errors surface as std::runtime_error."""
+    import shutil
+    import subprocess
+    inc = "/opt/conda/include"
+    if not os.path.exists(os.path.join(inc, "json.hpp")) or not shutil.which("g++"):
+        pytest.skip("no nlohmann::json / g++ in this image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "shim_smoke")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include"), "-I", inc,
+                           os.path.join(root, "tests", "shim_smoke.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "instantvnr_amd"), "-lvnr_amd",
+                           "-Wl,-rpath," + os.path.join(root, "instantvnr_amd")])
+    rc = subprocess.call([exe])
+    assert rc == (0 if L.vnrAmdHasDevice() else 42)   # 42 = std::runtime_error ("no HIP capable devices")

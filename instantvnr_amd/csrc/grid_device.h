@@ -139,28 +139,93 @@ template <> struct RawFeat<8> {
   static __device__ __forceinline__ raw_t load(table_rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
 };
 
-__device__ __forceinline__ void level_indices_fast(const LevelInfo& lv, const CornerSetup& c, uint32_t idx[8])
+// Two x-adjacent corners of one (y,z) row in ONE load when they are adjacent in memory.  The gather cost on gfx950
+// is per lane-address in the texture addresser (measured: ~44 TA cycles per 64-lane dword gather, TA 87 % busy),
+// not per byte, so halving the number of gather instructions is worth far more than the wider loads cost.
+template <int F> struct PairFeat { static constexpr bool enabled = false; };
+template <> struct PairFeat<2> {
+  static constexpr bool enabled = true;
+  typedef uint32_t pair_t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ pair_t load(table_rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); }
+  static __device__ __forceinline__ uint32_t lo(pair_t p) { return p.x; }
+  static __device__ __forceinline__ uint32_t hi(pair_t p) { return p.y; }
+};
+template <> struct PairFeat<4> {
+  static constexpr bool enabled = true;
+  typedef uint4_t pair_t;
+  typedef uint32_t half_pair_t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ pair_t load(table_rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
+  static __device__ __forceinline__ half_pair_t lo(pair_t p) { return half_pair_t{p.x, p.y}; }
+  static __device__ __forceinline__ half_pair_t hi(pair_t p) { return half_pair_t{p.z, p.w}; }
+};
+
+// exact (slow, rare) dense indices: kept out of line so the hot instruction stream stays small
+typedef uint32_t uint8x32_t __attribute__((ext_vector_type(8)));
+__device__ __noinline__ uint8x32_t level_indices_exact(const LevelInfo lv, uint32_t g0, uint32_t g1, uint32_t g2)
 {
+  uint8x32_t idx;
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner)
+    idx[corner] = level_index(lv, g0 + (corner & 1), g1 + ((corner >> 1) & 1), g2 + ((corner >> 2) & 1));
+  return idx;
+}
+
+template <int F>
+__device__ __forceinline__ void gather_corners(const LevelInfo& lv, const CornerSetup& c, table_rsrc_t rsrc,
+                                               typename RawFeat<F>::raw_t (&v)[8])
+{
+  constexpr uint32_t kBytes = (uint32_t)(F * 2);
+  const uint32_t soff = lv.offset * kBytes;
   if (lv.hashed) {
     const uint32_t mask = lv.size - 1u;
     const uint32_t hy0 = c.g[1] * 2654435761u, hy1 = hy0 + 2654435761u;
     const uint32_t hz0 = c.g[2] * 805459861u, hz1 = hz0 + 805459861u;
     const uint32_t x0 = c.g[0], x1 = c.g[0] + 1u;
     const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+    if constexpr (PairFeat<F>::enabled) {
+      // even x: (x+1)^h == (x^h)^1, i.e. the second corner is the other half of the aligned entry pair
+      const bool odd_x = (x0 & 1u) != 0u;
+      uint32_t i1[4];
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner) idx[corner] = (((corner & 1) ? x1 : x0) ^ yz[corner >> 1]) & mask;
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t i0 = (x0 ^ yz[q]) & mask;
+        i1[q] = (x1 ^ yz[q]) & mask;
+        const auto pr = PairFeat<F>::load(rsrc, (i0 & ~1u) * kBytes, soff);
+        const bool up = (i0 & 1u) != 0u;
+        v[2 * q] = up ? PairFeat<F>::hi(pr) : PairFeat<F>::lo(pr);
+        v[2 * q + 1] = up ? PairFeat<F>::lo(pr) : PairFeat<F>::hi(pr);
+      }
+      if (odd_x) {  // divergent: only the odd-x lanes pay for a second gather per (y,z) row
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[2 * q + 1] = RawFeat<F>::load(rsrc, i1[q] * kBytes, soff);
+      }
+    } else {
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner)
+        v[corner] = RawFeat<F>::load(rsrc, ((((corner & 1) ? x1 : x0) ^ yz[corner >> 1]) & mask) * kBytes, soff);
+    }
   } else {
     const uint32_t res = lv.resolution, res2 = lv.res2;
     const uint32_t base = c.g[0] + __umul24(c.g[1], res) + __umul24(c.g[2], res2);
     const bool bad = (c.g[0] > res) | (c.g[1] > res) | (c.g[2] > res) | (base + 1u + res + res2 >= lv.size);
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {  // wave-uniform and rare: keep the exact modulo semantics
+      const uint8x32_t idx = level_indices_exact(lv, c.g[0], c.g[1], c.g[2]);
 #pragma unroll
-      for (int corner = 0; corner < 8; ++corner)
-        idx[corner] = level_index(lv, c.g[0] + (corner & 1), c.g[1] + ((corner >> 1) & 1), c.g[2] + ((corner >> 2) & 1));
+      for (int corner = 0; corner < 8; ++corner) v[corner] = RawFeat<F>::load(rsrc, idx[corner] * kBytes, soff);
+    } else if constexpr (PairFeat<F>::enabled) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // corners (2q, 2q+1) are entries idx and idx + 1
+        const uint32_t idx = base + ((q & 1) ? res : 0u) + ((q & 2) ? res2 : 0u);
+        const auto pr = PairFeat<F>::load(rsrc, idx * kBytes, soff);
+        v[2 * q] = PairFeat<F>::lo(pr);
+        v[2 * q + 1] = PairFeat<F>::hi(pr);
+      }
     } else {
 #pragma unroll
-      for (int corner = 0; corner < 8; ++corner)
-        idx[corner] = base + ((corner & 1) ? 1u : 0u) + ((corner & 2) ? res : 0u) + ((corner & 4) ? res2 : 0u);
+      for (int corner = 0; corner < 8; ++corner) {
+        const uint32_t idx = base + ((corner & 1) ? 1u : 0u) + ((corner & 2) ? res : 0u) + ((corner & 4) ? res2 : 0u);
+        v[corner] = RawFeat<F>::load(rsrc, idx * kBytes, soff);
+      }
     }
   }
 }
@@ -171,12 +236,8 @@ __device__ __forceinline__ void encode_level_fast(const LevelInfo& lv, uint32_t 
 {
   typedef typename RawFeat<F>::raw_t raw_t;
   const CornerSetup c = level_setup(lv, interpolation, x, y, z);
-  uint32_t idx[8];
-  level_indices_fast(lv, c, idx);
-  const uint32_t soff = lv.offset * (uint32_t)(F * 2);
   raw_t v[8];
-#pragma unroll
-  for (int corner = 0; corner < 8; ++corner) v[corner] = RawFeat<F>::load(rsrc, idx[corner] * (uint32_t)(F * 2), soff);
+  gather_corners<F>(lv, c, rsrc, v);
   const float wx0 = 1.0f - c.w[0], wx1 = c.w[0], wy0 = 1.0f - c.w[1], wy1 = c.w[1], wz0 = 1.0f - c.w[2], wz1 = c.w[2];
   const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
   half_t acc[F];

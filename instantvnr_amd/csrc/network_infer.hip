@@ -79,6 +79,8 @@ struct InferArgs {
   half_t* acts_out;          // training: [(nh+1)][n][64] post-activation hidden outputs (may be null)
   const uint32_t* n_ptr;     // if non-null the sample count is read from here
   const uint32_t* dest;      // if non-null, sample i's result goes to out[dest[i]]
+  uint32_t queue_mode;       // 1: coords are 16-byte records {x, y, z, dest} and the result goes to out[dest * out_stride]
+  uint32_t out_stride;
   uint32_t n;
   uint32_t n_hidden_matmuls;
   uint32_t activation;       // 0 none, 1 relu
@@ -230,7 +232,16 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
   for (uint32_t tile = xcd * per_xcd + (blockIdx.x >> 3) * 4u + wave; tile < tile_end; tile += waves_per_xcd) {
     const uint32_t i = tile * 64u + lane;
     const uint32_t ic = min(i, n - 1u);
-    const float3_packed p = ((const float3_packed*)args.coords)[ic];
+    float3_packed p;
+    uint32_t out_index = i;
+    if (args.queue_mode) {  // ray marcher's sample queue: one 16-byte load per sample
+      const uint4_t rec = ((const uint4_t*)args.coords)[ic];
+      p = {__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z)};
+      out_index = rec.w * args.out_stride;
+    } else {
+      p = ((const float3_packed*)args.coords)[ic];
+      if (args.dest) out_index = args.dest[ic];
+    }
 
     // ---- encode: lane = sample, level wave-uniform ------------------------------------------------
     half8_t feat[NCHUNK];
@@ -292,7 +303,7 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
     swap_halves(p0, p1);
     const float y = __builtin_bit_cast(float, p0) + __builtin_bit_cast(float, p1);
     // network output is produced in half precision and then cast to float (tcnn_impl.cu:421-431)
-    if (i < n) args.out[args.dest ? args.dest[i] : i] = (float)(half_t)y;
+    if (i < n) args.out[out_index] = (float)(half_t)y;
   }
 }
 
@@ -333,7 +344,7 @@ static void dispatch(uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
-                  const uint32_t* d_dest)
+                  const uint32_t* d_dest, uint32_t queue_out_stride)
 {
   if (n_max == 0) return;
   if (n_max > 0xffffffc0ull) throw std::runtime_error("inference batch too large (max 2^32-64 samples per call)");
@@ -351,6 +362,8 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
   a.acts_out = (half_t*)acts_out;
   a.n_ptr = d_n;
   a.dest = d_dest;
+  a.queue_mode = queue_out_stride ? 1u : 0u;
+  a.out_stride = queue_out_stride;
   a.n = (uint32_t)n;
   a.n_hidden_matmuls = n_hidden_matmuls;
   a.activation = activation;

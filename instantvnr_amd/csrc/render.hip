@@ -46,6 +46,8 @@ struct RenderParams {
   uint32_t il_parts, il_part, n_local;   // tile-row interleave across ranks; n_local = local index count
   uint32_t tiles_per_row, tile_row0;     // 8x8 pixel tiles: rays of a wave are an image patch, not a scanline
   float bin_depth_rcp;                   // 1 / depth of one sample-sorting bin (world units)
+  uint32_t tfn_in_lds;                   // the TFN tables fit in the march kernel's LDS
+  uint32_t debug_flags;                  // timing ablations only (VNR_AMD_DEBUG_FLAGS): 1 no compose, 2 no TFN, 4 no sort
   vec3f cam_pos, cam_dir, cam_hor, cam_ver;
   affine3f wto;
   vec3i vol_dims;
@@ -229,22 +231,32 @@ __device__ __forceinline__ void iter_exec(const RenderParams& p, DDAState& it, v
 //
 // Two views of one iteration's samples, both over the same compacted range [0, n_samples):
 //  * ray-major (values, dts): a ray's samples are contiguous, so compose needs only (base, count);
-//  * gather order (coords + `dest`): inside the 64-ray group of a wave the samples are counting-sorted by DEPTH BIN
-//    (bin = (t - t_group_front) / bin_depth, LDS histogram + wave scan).  One bin is a thin slab of an 8x8-pixel
+//  * gather order (16-byte queue records {x, y, z, ray-major slot}): inside the 64-ray group of a wave the samples are counting-sorted by DEPTH BIN
+//    (bin = (t - t_group_front) / bin_depth, LDS-atomic histogram + wave scan).  One bin is a thin slab of an 8x8-pixel
 //    frustum, i.e. a compact brick of the volume, whatever the per-ray sample index is.  The fused inference kernel
 //    reads coords in this order (coherent hash-grid gathers: measured ~2x faster than ray-major order once rays have
 //    drifted apart in depth) and scatters its result to values[dest[i]].
 template <bool FIRST>
 __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const RayList cur, const RayList nxt,
-                                                    const float* __restrict__ values, const float* __restrict__ dts_in,
-                                                    float* __restrict__ coords, uint32_t* __restrict__ dest,
-                                                    float* __restrict__ dts_out, uint32_t* __restrict__ counters, int parity)
+                                                    const vec2f* __restrict__ vd_in, vec4f* __restrict__ queue,
+                                                    vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters, int parity)
 {
-  extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1, bin|rank}  +  [4 waves][kDepthBins] histogram
+  extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1, bin|rank}, histogram[256], then the transfer function tables
   float* s_t0 = s_t;
   float* s_t1 = s_t + (size_t)p.n_iters * 256;
   uint32_t* s_br = (uint32_t*)(s_t + (size_t)2 * p.n_iters * 256);
-  uint32_t* s_hist = s_br + (size_t)p.n_iters * 256 + (threadIdx.x >> 6) * kDepthBins;
+  uint32_t* s_hist = s_br + (size_t)p.n_iters * 256;
+  // the TFN tables are read 4x per composed sample: keep them in LDS (no TA traffic) when they fit
+  DeviceTfn tfn = p.tfn;
+  if (!FIRST && p.tfn_in_lds) {
+    vec4f* s_colors = (vec4f*)(s_hist + 256);
+    float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
+    for (int e = threadIdx.x; e < p.tfn.n_colors; e += blockDim.x) s_colors[e] = p.tfn.colors[e];
+    for (int e = threadIdx.x; e < p.tfn.n_alphas; e += blockDim.x) s_alphas[e] = p.tfn.alphas[e];
+    __syncthreads();
+    tfn.colors = s_colors;
+    tfn.alphas = s_alphas;
+  }
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t n_in = FIRST ? p.n_local : counters[C_RAYS0 + parity];
   uint32_t* n_rays_out = counters + C_RAYS0 + (parity ^ 1);
@@ -287,10 +299,12 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         m_dir = dir * p.mc_rcp;
         intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
         // compose (classification, opacity correction, front-to-back blending)
-        for (uint32_t k = 0; k < sc; ++k) {
+        for (uint32_t k = 0; k < ((p.debug_flags & 1u) ? 0u : sc); ++k) {
           vec3f rgb; float a;
-          tfn_sample(p.tfn, values[sb + k], rgb, a);
-          a = opacity_correction(p.step_rcp, dts_in[sb + k], a);
+          const vec2f vd = vd_in[sb + k];  // {network value, t1 - t0}
+          if (p.debug_flags & 2u) { rgb = {0.5f, 0.5f, 0.5f}; a = vd.x * 0.01f; } else
+          tfn_sample(tfn, vd.x, rgb, a);
+          a = opacity_correction(p.step_rcp, vd.y, a);
           const float tr = 1.0f - alpha;
           alpha += tr * a;
           color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a;
@@ -343,27 +357,29 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     float front = survive ? s_t0[tid] : VNR_FLOAT_LARGE;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) front = fminf(front, __shfl_xor(front, d));
-    s_hist[lane] = 0;  // kDepthBins == 64: one bin per lane
+    // counting sort by depth bin (kDepthBins == 64: one histogram counter per lane, LDS atomics inside the wave)
+    uint32_t* hist = s_hist + (tid & ~63u);
+    hist[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     if (survive) {
       for (uint32_t j = 0; j < k; ++j) {
         const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
         const float t = (1.0f - jitter) * t0 + jitter * t1;
-        const uint32_t bin = min((uint32_t)kDepthBins - 1u, (uint32_t)fmaxf((t - front) * p.bin_depth_rcp, 0.0f));
-        const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
+        const uint32_t bin = (p.debug_flags & 4u) ? 0u : min((uint32_t)kDepthBins - 1u, (uint32_t)fmaxf((t - front) * p.bin_depth_rcp, 0.0f));
+        const uint32_t rank = atomicAdd(&hist[bin], 1u);
         s_br[j * 256u + tid] = (bin << 16) | rank;
       }
     }
     __builtin_amdgcn_wave_barrier();
     // exclusive scan of the 64-bin histogram across the wave
-    const uint32_t h = s_hist[lane];
+    const uint32_t h = hist[lane];
     uint32_t hs = h;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t y = __shfl_up(hs, d);
       if ((int)lane >= d) hs += y;
     }
-    s_hist[lane] = hs - h;
+    hist[lane] = smp_base + hs - h;  // first gather-order slot of bin `lane`
     __builtin_amdgcn_wave_barrier();
 
     if (survive) {
@@ -383,25 +399,24 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         const float t = (1.0f - jitter) * t0 + jitter * t1;  // lerp(jitter, t0, t1), instantvnr_types.h:162-166
         const vec3f c = org + t * dir;
         const uint32_t br = s_br[j * 256u + tid];
-        const size_t g = (size_t)smp_base + s_hist[br >> 16] + (br & 0xffffu);  // gather-order slot
-        coords[3 * g + 0] = c.x;
-        coords[3 * g + 1] = c.y;
-        coords[3 * g + 2] = c.z;
-        dest[g] = sb + j;
-        dts_out[sb + j] = t1 - t0;
+        const uint32_t g = hist[br >> 16] + (br & 0xffffu);  // gather-order slot
+        queue[g] = {c.x, c.y, c.z, __uint_as_float(sb + j)};  // one 16-byte record per sample
+        vd_out[sb + j].y = t1 - t0;
       }
     }
-    __builtin_amdgcn_wave_barrier();  // s_hist / s_br are reused by the next loop trip
+    __builtin_amdgcn_wave_barrier();  // the LDS arrays are reused by the next loop trip
   }
 }
 
 // iterative_sampling_groundtruth_kernel (method_raymarching.cu:902-915) over the compacted sample queue
 __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float* __restrict__ vol, vec3i dims,
-                                 const float* __restrict__ coords, float* __restrict__ values, const uint32_t* __restrict__ dest)
+                                 const vec4f* __restrict__ queue, vec2f* __restrict__ vd)
 {
   const uint32_t n = *n_ptr;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    values[dest[i]] = sample_volume_nodal(vol, dims, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const vec4f r = queue[i];
+    vd[__float_as_uint(r.w)].x = sample_volume_nodal(vol, dims, r.x, r.y, r.z);
+  }
 }
 
 __global__ void clear_two_kernel(uint32_t* a, uint32_t* b)
@@ -478,7 +493,7 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
 {
   if (!Runtime::get().ready()) Runtime::get().init(-1);
   stream_ = Runtime::get().stream;
-  if (const char* e = std::getenv("VNR_RM_N_ITERS")) n_iters_ = std::max(1, std::min(64, std::atoi(e)));
+  if (const char* e = std::getenv("VNR_RM_N_ITERS")) n_iters_ = std::max(1, std::min(48, std::atoi(e)));  // 3 KiB of LDS per iteration slot and block
   counters_.resize(C_COUNT);
   counters_.zero(stream_);
   VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 256 * sizeof(uint32_t), hipHostMallocDefault));
@@ -528,10 +543,8 @@ void Renderer::ensure_queues(size_t n_pixels, int n_iters)
   q_u32_.resize(6 * P);
   q_f32_.resize(18 * P);
   q_i32_.resize(6 * P);
-  coords_.resize(3 * P * n_iters);
-  dts_.resize(2 * P * n_iters);
-  values_.resize(P * n_iters);
-  dest_.resize(P * n_iters);
+  queue_.resize(P * n_iters);
+  vd_.resize(2 * P * n_iters);
   queue_pixels_ = P;
   queue_iters_ = n_iters;
 }
@@ -556,6 +569,8 @@ void Renderer::render()
   p.tile_row0 = il_parts_ == 1 ? tr_lo : 0u;
   const uint32_t rows_local = il_parts_ == 1 ? (tr_hi - tr_lo) : div_round_up(div_round_up((uint32_t)height_, 8), il_parts_);
   p.n_local = rows_local * p.tiles_per_row * 64u;
+  p.debug_flags = 0;
+  if (const char* e = std::getenv("VNR_AMD_DEBUG_FLAGS")) p.debug_flags = (uint32_t)std::atoi(e);
   p.bin_depth_rcp = 1.0f / 8.0f;  // 8 world units (voxels) per depth bin ~ the footprint of an 8x8 pixel tile
   // camera, renderer.cpp:87-96
   const float t = 2.0f * tanf(camera_.fovy * 0.5f * (float)M_PI / 180.0f);
@@ -574,6 +589,7 @@ void Renderer::render()
   p.mc_rcp = {1.0f / sp.x, 1.0f / sp.y, 1.0f / sp.z};
   p.mc_max_opacity = mc.d_max_opacity();
   p.tfn = tfn_.view();
+  p.tfn_in_lds = ((size_t)p.tfn.n_colors * sizeof(vec4f) + (size_t)p.tfn.n_alphas * sizeof(float)) <= 24 * 1024 ? 1u : 0u;
   p.n_iters = n_iters_;
   // frame index / accumulation, renderer.cpp:103-105
   if (reset_) frame_index_ = 0;
@@ -624,13 +640,21 @@ void Renderer::render_streaming(const RenderParams& p)
     rl[b].next_cell_begin = f + 8 * QP;
     rl[b].cell = (vec3i*)(q_i32_.ptr + (size_t)b * 3 * QP);
   }
-  float* dts[2] = {dts_.ptr, dts_.ptr + (size_t)QP * queue_iters_};
+  vec2f* vd[2] = {vd_.ptr, vd_.ptr + (size_t)QP * queue_iters_};
   uint32_t* c = counters_.ptr;
   NeuralVolume* nv = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get()) : nullptr;
   if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
 
   VNR_HIP_CHECK(hipMemsetAsync(c, 0, C_COUNT * sizeof(uint32_t), stream_));
-  const size_t shmem = ((size_t)3 * p.n_iters * 256 + 4 * kDepthBins) * sizeof(float);
+  const size_t shmem = ((size_t)3 * p.n_iters + 1) * 256 * sizeof(float);
+  const size_t shmem_compose = shmem + (p.tfn_in_lds ? (size_t)p.tfn.n_colors * sizeof(vec4f) + (size_t)p.tfn.n_alphas * sizeof(float) : 0);
+  if (shmem_compose > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {  // more than the default 64 KiB of dynamic LDS needs an opt-in
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    lds_attr_set = true;
+  }
   uint32_t max_iterations = 240;
   if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) max_iterations = std::max(1, std::min(240, std::atoi(e)));  // diagnostics only
   if (profiling_) iter_ms_.assign(max_iterations, 0.0f);
@@ -644,21 +668,21 @@ void Renderer::render_streaming(const RenderParams& p)
     // march(it): reads ray list `parity`, writes list `parity^1` and sample queue `parity`
     if (it == 0) {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 4096u);
-      march_kernel<true><<<blocks, 256, shmem, stream_>>>(p, rl[0], rl[1], values_.ptr, dts[1], coords_.ptr, dest_.ptr, dts[0], c, 0);
+      march_kernel<true><<<blocks, 256, shmem, stream_>>>(p, rl[0], rl[1], vd[1], queue_.ptr, vd[0], c, 0);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
-      march_kernel<false><<<blocks, 256, shmem, stream_>>>(p, rl[parity], rl[parity ^ 1], values_.ptr, dts[parity ^ 1], coords_.ptr, dest_.ptr,
-                                                          dts[parity], c, parity);
+      march_kernel<false><<<blocks, 256, shmem_compose, stream_>>>(p, rl[parity], rl[parity ^ 1], vd[parity ^ 1], queue_.ptr, vd[parity], c, parity);
     }
+    VNR_HIP_CHECK(hipGetLastError());
     // evaluate the compacted samples; the evaluation kernel also clears the counters march(it+1) will append to
     uint32_t* clear0 = c + C_RAYS0 + parity;            // output ray list of march(it+1)
     uint32_t* clear1 = c + C_SAMPLES0 + (parity ^ 1);   // sample counter of march(it+1)
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[2 * it], stream_));
     if (nv) {
-      nv->network().inference(coords_.ptr, values_.ptr, 0, c + C_SAMPLES0 + parity, s_max, stream_, dest_.ptr);
+      nv->network().inference_queue((const float*)queue_.ptr, (float*)vd[parity], 2, c + C_SAMPLES0 + parity, s_max, stream_);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
-      gt_sample_kernel<<<blocks, 256, 0, stream_>>>(c + C_SAMPLES0 + parity, p.volume, p.vol_dims, coords_.ptr, values_.ptr, dest_.ptr);
+      gt_sample_kernel<<<blocks, 256, 0, stream_>>>(c + C_SAMPLES0 + parity, p.volume, p.vol_dims, queue_.ptr, vd[parity]);
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[2 * it + 1], stream_));
     clear_two_kernel<<<1, 1, 0, stream_>>>(clear0, clear1);

@@ -38,7 +38,7 @@ public:
   void set_pixel_range(uint32_t lo, uint32_t hi) { pixel_lo_ = lo; pixel_hi_ = hi; reset_ = true; }
   void set_profiling(bool e) { profiling_ = e; }
   // diagnostics: the compacted sample queue of the last iteration and per-iteration kernel times of the last frame
-  const float* debug_coords() const { return coords_.ptr; }
+  const float* debug_coords() const { return (const float*)queue_.ptr; }  // 16-byte records {x, y, z, slot}
   const uint32_t* debug_counters() const { return counters_.ptr; }
   const std::vector<float>& debug_iteration_ms() const { return iter_ms_; }
   // rank `part` of `parts` renders the pixel blocks b with b % parts == part (block = `block` consecutive pixels)
@@ -83,8 +83,8 @@ private:
   DeviceBuffer<uint32_t> q_u32_;   // pixel_index[2], sample_base[2], sample_count[2]
   DeviceBuffer<float> q_f32_;      // jitter[2], alpha[2], color[2][3], t_next[2][3], next_cell_begin[2]
   DeviceBuffer<int> q_i32_;        // cell[2][3]
-  DeviceBuffer<float> coords_, dts_, values_;
-  DeviceBuffer<uint32_t> dest_;    // gather-order slot -> ray-major slot of the same sample
+  DeviceBuffer<vec4f> queue_;      // gather-order sample records {x, y, z, ray-major slot}
+  DeviceBuffer<vec2f> vd_;         // ray-major {value, t1 - t0} per sample, x2 (ping-pong)
   DeviceBuffer<uint32_t> counters_;
   uint32_t* host_counts_ = nullptr;  // pinned ring of alive-ray counts
   size_t queue_pixels_ = 0;

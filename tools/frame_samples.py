@@ -43,8 +43,8 @@ cnt = np.zeros(16, np.uint32)
 check(L.vnrAmdMemcpyD2H(cnt.ctypes.data_as(C.c_void_p), dn, 64))
 n = int(cnt[2 + ((ITER - 1) & 1)])
 print("iteration", ITER, "counters", cnt[:4], "samples", n)
-coords = np.empty((n, 3), np.float32)
-check(L.vnrAmdMemcpyD2H(coords.ctypes.data_as(C.c_void_p), dc, n * 12))
+rec = np.empty((n, 4), np.float32)
+check(L.vnrAmdMemcpyD2H(rec.ctypes.data_as(C.c_void_p), dc, n * 16)); coords = np.ascontiguousarray(rec[:, :3])
 d = np.linalg.norm(np.diff(coords[:4096], axis=0), axis=1) * size
 print("spacing of consecutive queue entries (voxels): median %.2f  p90 %.2f" % (np.median(d), np.quantile(d, 0.9)))
 

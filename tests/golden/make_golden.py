@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Authors the golden vectors of SURVEY.md §8(c) (i)-(vi) and writes them next to this file.
+
+    python tests/golden/make_golden.py          # regenerate every fixture
+
+What the fixtures are, and what they are not.  The reference has no tests or golden vectors for this path
+ and cannot be built or run in this image (CUDA + OptiX + tiny-cuda-nn), so nothing below comes
+from the reference itself: PARITY VERSUS THE REFERENCE STAYS UNPINNED.  Two kinds of vectors are committed:
+
+ * hand cases (`grid_hand_cases.npz`, `bson_params_like.*`): computed HERE by an independent pure-Python
+   restatement (dyadic inputs, exact arithmetic) or by an independent third-party encoder (pymongo's `bson`);
+   the oracle and the HIP path are both checked against them;
+ * frozen oracle outputs (`network_*.npz`, `c1_*.npz`, `dda_cases.npz`): produced by `oracle/` at the commit
+   that introduced them.  They anchor the HIP path on the GPU box (where /root/reference does not exist) and
+   catch silent drift of the oracle itself.
+
+Fixtures hold data only (inputs, seeds, expected outputs).  Large seeded inputs (parameter blobs, the C1 volume)
+are regenerated from their seed by `instantvnr_amd.synthetic` and pinned here by SHA-256.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from instantvnr_amd import synthetic as syn  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# --------------------------------------------------------------------------- (i) hand-computable hash-grid cases
+# Independent restatement of tcnn_impl_decoder.cu:7-175 for DYADIC inputs (every product and sum below is exact in
+# binary floating point, so plain Python floats are exact rationals here); fp16 rounding via numpy's IEEE conversion.
+PRIMES = (1, 2654435761, 805459861)
+
+
+def hand_grid_index(hashmap_size, res, g):
+    stride, index = 1, 0
+    for d in range(3):
+        if stride <= hashmap_size:
+            index += g[d] * stride
+            stride *= res
+    if hashmap_size < stride:
+        index = 0
+        for d in range(3):
+            index ^= (g[d] * PRIMES[d]) & 0xFFFFFFFF
+    return (index & 0xFFFFFFFF) % hashmap_size
+
+
+def hand_encode(n_levels, F, log2_T, base, table, coords):
+    """per_level_scale = 2, Linear interpolation.  table: fp16 [entries*F]; returns fp16 [n, pad16(L*F)]"""
+    width = ((n_levels * F + 15) // 16) * 16
+    out = np.zeros((len(coords), width), dtype=np.float16)
+    offset = 0
+    for lvl in range(n_levels):
+        scale = float(2 ** lvl * base - 1)
+        res = int(np.ceil(scale)) + 1
+        size = min(((res ** 3 + 7) // 8) * 8, 1 << log2_T)
+        for i, x in enumerate(coords):
+            pos = [float(x[d]) * scale + 0.5 for d in range(3)]
+            g = [int(np.floor(p)) for p in pos]
+            w = [p - np.floor(p) for p in pos]
+            acc = [np.float16(0)] * F
+            for corner in range(8):
+                weight, gl = 1.0, [0, 0, 0]
+                for d in range(3):
+                    if corner & (1 << d):
+                        weight *= w[d]; gl[d] = g[d] + 1
+                    else:
+                        weight *= 1.0 - w[d]; gl[d] = g[d]
+                e = hand_grid_index(size, res, gl)
+                for f in range(F):
+                    prod = np.float16(np.float32(weight) * np.float32(table[(offset + e) * F + f]))  # (T)(w * data)
+                    acc[f] = np.float16(np.float32(acc[f]) + np.float32(prod))  # fp16 accumulate
+            for f in range(F):
+                out[i, lvl * F + f] = acc[f]
+        offset += size
+    return out, offset
+
+
+def make_grid_hand_cases():
+    # L=2, F=2, T=2^4, base 2: level 0 = 2^3 dense entries, level 1 = res 4 -> 64 > 16 -> hashed into 16 entries
+    L, F, log2_T, base = 2, 2, 4, 2
+    n_entries = 8 + 16
+    table = np.zeros(n_entries * F, dtype=np.float16)
+    e = np.arange(n_entries)
+    table[0::2] = e                       # feature 0 = entry index (index ramp)
+    table[1::2] = -0.25 * e               # feature 1
+    k = np.array([[4, 4, 4], [2, 4, 4], [0, 0, 0], [8, 8, 8], [1, 3, 5], [7, 2, 6], [3, 3, 3], [5, 0, 8], [6, 7, 1]])
+    coords = (k / 8.0).astype(np.float32)  # dyadic
+    feats, total = hand_encode(L, F, log2_T, base, table, coords)
+    assert total == n_entries
+    np.savez(os.path.join(HERE, "grid_hand_cases.npz"), n_levels=L, n_features=F, log2_hashmap_size=log2_T,
+             base_resolution=base, per_level_scale=2.0, table_f16_bits=table.view(np.uint16), coords=coords,
+             features_f16_bits=feats.view(np.uint16))
+
+
+# --------------------------------------------------------------------------- (ii) seeded networks
+NETWORKS = {
+    # name: (L, F, log2T, base, per_level_scale, n_hidden_layers, param seed)   -- SURVEY §8(c)(ii) shapes
+    "L8_F8_H2": (8, 8, 15, 16, 2.0, 2, 101),
+    "L16_F2_H3": (16, 2, 16, 16, 1.3195079565048218, 3, 102),
+    "L16_F4_H3": (16, 4, 14, 8, 1.5, 3, 103),
+}
+
+
+def make_networks():
+    for name, (L, F, T, base, pls, H, seed) in NETWORKS.items():
+        cfg = oracle.grid_config(L, F, T, base, per_level_scale=pls)
+        in_w = oracle.padded_width(cfg)
+        n_mlp = oracle.mlp_n_params(in_w, 64, H - 1)
+        n_params = oracle.n_params(cfg, 64, H)
+        params = syn.random_params(n_params, n_mlp, seed=seed)
+        coords = np.random.default_rng(seed + 1000).random((4096, 3), dtype=np.float32)
+        bits = params.view(np.uint16)
+        out32 = oracle.network_inference(cfg, 64, H, bits, coords, acc_mode=0)
+        out16 = oracle.network_inference(cfg, 64, H, bits, coords, acc_mode=1)
+        feats = oracle.grid_encode(cfg, bits[n_mlp:], coords[:512])
+        np.savez_compressed(os.path.join(HERE, f"network_{name}.npz"), n_levels=L, n_features=F, log2_hashmap_size=T,
+                            base_resolution=base, per_level_scale=pls, n_hidden_layers=H, n_neurons=64, param_seed=seed,
+                            n_params=n_params, n_mlp_params=n_mlp, params_sha256=sha(params), coords=coords,
+                            out_acc_f32=out32, out_acc_f16=out16, features_f16_bits_first512=feats)
+
+
+# --------------------------------------------------------------------------- (iii) BSON
+def make_bson():
+    import bson
+    blob = (np.arange(777, dtype=np.uint16) * 31 % 65521).astype(np.uint16).tobytes()
+    mc = np.linspace(-1, 2, 16, dtype=np.float32).tobytes()
+    doc = {  # params.json schema, network.cu:827-857 (keys sorted the way nlohmann's std::map stores them)
+        "macrocell": {"data": bson.Binary(mc, 0), "dims": {"x": 2, "y": 2, "z": 2},
+                      "spacings": {"x": 0.5, "y": 0.5, "z": 0.5}},
+        "model": {"encoding": {"base_resolution": 16, "log2_hashmap_size": 19, "n_features_per_level": 8, "n_levels": 8,
+                               "otype": "HashGrid"},
+                  "loss": {"otype": "L1"},
+                  "network": {"activation": "ReLU", "n_hidden_layers": 4, "n_neurons": 64, "otype": "FullyFusedMLP",
+                              "output_activation": "None"}},
+        "parameters": {"n_params": 777, "params_binary": bson.Binary(blob, 0), "params_type": "__half"},
+        "volume": {"big": 5000000000, "dims": {"x": 32, "y": 32, "z": 32}, "flags": [True, False, None],
+                   "name": "héllo", "neg": -7, "scale": 1.5},
+    }
+    enc = bson.encode(doc)
+    open(os.path.join(HERE, "bson_params_like.bson"), "wb").write(enc)
+    meta = {"params_binary_sha256": hashlib.sha256(blob).hexdigest(), "macrocell_data_sha256": hashlib.sha256(mc).hexdigest(),
+            "n_bytes": len(enc),
+            "plain": {"model": doc["model"], "volume": doc["volume"], "n_params": 777, "params_type": "__half",
+                      "macrocell_dims": doc["macrocell"]["dims"]}}
+    json.dump(meta, open(os.path.join(HERE, "bson_params_like.json"), "w"), indent=1, sort_keys=True)
+
+
+# --------------------------------------------------------------------------- (iv) + (v) C1 scene
+def c1_scene():
+    """64^3 analytic field, 256^2, camera (0,0,-2.5*64) -> origin, up +y, fovy 60, rate 1"""
+    vol = syn.analytic_volume(64)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    cam = syn.default_camera((64, 64, 64))
+    return vol, colors, alphas, cam
+
+
+def make_c1():
+    vol, colors, alphas, cam = c1_scene()
+    tfn = oracle.TfnHolder(colors, alphas)
+    vr = oracle.macrocell_compute_implicit(vol)
+    mo = oracle.macrocell_max_opacity(tfn, vr)
+    sc = oracle.SceneHolder(256, 256, (64, 64, 64), tfn, mo, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    mono, _ = oracle.render_monolithic(sc, vol, n_threads=8)
+    stream, _, st = oracle.render_streaming(sc, lambda c: oracle.sample_volume(vol, c, nodal=True))
+    np.savez_compressed(os.path.join(HERE, "c1_scene.npz"), volume_sha256=sha(vol), tfn_colors=colors, tfn_alphas=alphas,
+                        cam_from=np.array(cam["from"], np.float32), cam_at=np.array(cam["at"], np.float32),
+                        cam_up=np.array(cam["up"], np.float32), fovy=cam["fovy"], macrocell_value_range=vr,
+                        macrocell_max_opacity=mo, image_mode4_monolithic=mono, image_mode5_streaming=stream,
+                        streaming_n_samples=st["n_samples"], streaming_n_rays_hit=st["n_rays_hit"],
+                        streaming_n_iterations=st["n_iterations"])
+
+
+# --------------------------------------------------------------------------- (vi) DDA cell sequences
+DDA_RAYS = [
+    # name, org, dir, t_min, t_max   (grid 4^3; dda.h:26-137)
+    ("axis_aligned_x", (-1.0, 1.5, 2.5), (1.0, 0.0, 0.0), 1.0, 5.0),
+    ("negative_x_zero_yz", (5.0, 0.5, 3.5), (-1.0, 0.0, 0.0), 1.0, 5.0),
+    ("diagonal", (0.1, 0.2, 0.3), (1.0, 0.7, 0.4), 0.0, 3.5),
+    ("exact_diagonal", (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 0.0, 4.0),
+    ("grazing", (0.0, 3.9999, 0.5), (1.0, 1e-6, 0.0), 0.0, 4.0),
+    ("zero_x", (2.5, -1.0, -1.0), (0.0, 1.0, 1.0), 1.0, 5.0),
+    ("steep_negative", (3.9, 3.8, 3.7), (-0.2, -1.0, -0.55), 0.0, 3.7),
+]
+
+
+def make_dda():
+    out = {}
+    for name, org, d, t0, t1 in DDA_RAYS:
+        cells, ts = oracle.dda_trace(org, d, t0, t1, (4, 4, 4))
+        out[name + "_cells"] = cells
+        out[name + "_ts"] = ts
+        out[name + "_ray"] = np.array(list(org) + list(d) + [t0, t1], dtype=np.float32)
+    # hand-checkable expectations (independent of the oracle): unit steps along an axis
+    assert out["axis_aligned_x_cells"].tolist() == [[0, 1, 2], [1, 1, 2], [2, 1, 2], [3, 1, 2]]
+    assert out["exact_diagonal_cells"].tolist() == [[0, 0, 0], [1, 1, 1], [2, 2, 2], [3, 3, 3]]
+    np.savez(os.path.join(HERE, "dda_cases.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_grid_hand_cases()
+    make_networks()
+    make_bson()
+    make_c1()
+    make_dda()
+    for f in sorted(os.listdir(HERE)):
+        print(f"{os.path.getsize(os.path.join(HERE, f)):>9}  {f}")

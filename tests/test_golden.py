@@ -1,0 +1,200 @@
+"""Golden vectors of SURVEY.md §8(c) (i)-(vi), committed under tests/golden/ (see make_golden.py for provenance).
+
+CPU half (`-m "not gpu"`): the oracle reproduces every fixture (hand cases come from an independent pure-Python
+restatement / pymongo, the rest are frozen oracle outputs).  GPU half (`-m gpu`): the HIP path, through the C-ABI,
+reproduces the same fixtures without /root/reference or a live oracle for the expected values."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from instantvnr_amd import synthetic as syn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NETWORKS = ["L8_F8_H2", "L16_F2_H3", "L16_F4_H3"]
+TOL_NET = 2.0 ** -8   # fp16-accumulate vs fp32-accumulate MMA gap, absolute, per sample
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def net_params(g):
+    p = syn.random_params(int(g["n_params"]), int(g["n_mlp_params"]), seed=int(g["param_seed"]))
+    assert sha(p) == str(g["params_sha256"]), "seeded parameter blob drifted (numpy RNG stream changed?)"
+    return p
+
+
+def c1_inputs(g):
+    vol = syn.analytic_volume(64)
+    assert sha(vol) == str(g["volume_sha256"])
+    return vol
+
+
+# =========================================================================== CPU: oracle vs fixtures
+def test_oracle_hand_grid_cases(oracle):
+    g = gold("grid_hand_cases.npz")
+    cfg = oracle.grid_config(int(g["n_levels"]), int(g["n_features"]), int(g["log2_hashmap_size"]), int(g["base_resolution"]))
+    lay = oracle.grid_layout(cfg)
+    assert lay["total_entries"] * int(g["n_features"]) == g["table_f16_bits"].size
+    got = oracle.grid_encode(cfg, g["table_f16_bits"], g["coords"])
+    assert np.array_equal(got, g["features_f16_bits"])
+    # a value that can be read off by eye: x = (.5,.5,.5) on level 0 (scale 1): pos = 1.0 -> entry 7 with weight 1
+    assert g["features_f16_bits"].view(np.float16)[0, 0] == 7 and g["features_f16_bits"].view(np.float16)[0, 1] == -1.75
+
+
+@pytest.mark.parametrize("name", NETWORKS)
+def test_oracle_network_fixtures(oracle, name):
+    g = gold(f"network_{name}.npz")
+    p = net_params(g).view(np.uint16)
+    cfg = oracle.grid_config(int(g["n_levels"]), int(g["n_features"]), int(g["log2_hashmap_size"]),
+                             int(g["base_resolution"]), per_level_scale=float(g["per_level_scale"]))
+    H = int(g["n_hidden_layers"])
+    assert oracle.n_params(cfg, 64, H) == int(g["n_params"])
+    out32 = oracle.network_inference(cfg, 64, H, p, g["coords"], acc_mode=0)
+    out16 = oracle.network_inference(cfg, 64, H, p, g["coords"], acc_mode=1)
+    assert np.array_equal(out32, g["out_acc_f32"])
+    assert np.array_equal(out16, g["out_acc_f16"])
+    feats = oracle.grid_encode(cfg, p[int(g["n_mlp_params"]):], g["coords"][:512])
+    assert np.array_equal(feats, g["features_f16_bits_first512"])
+    # the two accumulation variants bracket what a real MMA may do; their gap is what TOL_NET has to cover.  The
+    # quantile is the typical gap; rare outliers come from a hidden unit crossing the ReLU in one variant only.
+    gap = np.abs(out32 - out16)
+    assert np.quantile(gap, 0.99) <= TOL_NET, np.quantile(gap, 0.99)
+    assert np.std(out32) > 0.05   # the fixture is not degenerate
+
+
+def test_bson_fixture_roundtrips_byte_exact():
+    from instantvnr_amd import _lib, api
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    L = _lib.lib()
+    enc = open(os.path.join(GOLD, "bson_params_like.bson"), "rb").read()
+    meta = json.load(open(os.path.join(GOLD, "bson_params_like.json")))
+    assert len(enc) == meta["n_bytes"]
+    out, n = C.c_void_p(), C.c_size_t()
+    _lib.check(L.vnrAmdJsonConvert(enc, len(enc), api.JSON_BSON, api.JSON_BSON, C.byref(out), C.byref(n)))
+    again = C.string_at(out, n.value)
+    L.vnrAmdFreeHost(out)
+    assert again == enc   # pymongo-encoded document (binary subtype 0, sorted keys) survives decode + encode unchanged
+    doc = json.loads(api.bson_to_json_text(enc))
+    assert doc["model"] == meta["plain"]["model"]
+    assert doc["volume"] == meta["plain"]["volume"]
+    assert doc["parameters"]["n_params"] == 777 and doc["parameters"]["params_type"] == "__half"
+    blob = doc["parameters"]["params_binary"]
+    raw = bytes(blob["bytes"]) if isinstance(blob, dict) else None
+    assert raw is not None and hashlib.sha256(raw).hexdigest() == meta["params_binary_sha256"]
+
+
+def test_oracle_c1_scene(oracle):
+    g = gold("c1_scene.npz")
+    vol = c1_inputs(g)
+    tfn = oracle.TfnHolder(g["tfn_colors"], g["tfn_alphas"])
+    vr = oracle.macrocell_compute_implicit(vol)
+    assert np.array_equal(vr, g["macrocell_value_range"])
+    mo = oracle.macrocell_max_opacity(tfn, vr)
+    assert np.array_equal(mo, g["macrocell_max_opacity"])
+    sc = oracle.SceneHolder(256, 256, (64, 64, 64), tfn, mo, g["cam_from"], g["cam_at"], g["cam_up"], float(g["fovy"]))
+    mono, _ = oracle.render_monolithic(sc, vol, n_threads=4)
+    assert np.abs(mono - g["image_mode4_monolithic"]).max() <= 1e-6
+    stream, _, st = oracle.render_streaming(sc, lambda c: oracle.sample_volume(vol, c, nodal=True))
+    assert np.abs(stream - g["image_mode5_streaming"]).max() <= 1e-6
+    assert st["n_samples"] == int(g["streaming_n_samples"]) and st["n_rays_hit"] == int(g["streaming_n_rays_hit"])
+    # the fixture shows something: the volume covers the image centre and is neither empty nor saturated
+    a = g["image_mode5_streaming"][..., 3]
+    assert a[128, 128] > 0.5 and a[0, 0] == 0 and 0.03 < (a > 0).mean() < 0.9
+
+
+def test_oracle_dda_cases(oracle):
+    g = gold("dda_cases.npz")
+    names = sorted(k[:-4] for k in g.files if k.endswith("_ray"))
+    assert len(names) == 7
+    for n in names:
+        ray = g[n + "_ray"]
+        cells, ts = oracle.dda_trace(ray[0:3], ray[3:6], float(ray[6]), float(ray[7]), (4, 4, 4))
+        assert np.array_equal(cells, g[n + "_cells"]), n
+        assert np.array_equal(ts, g[n + "_ts"]), n
+        assert np.all((cells >= 0) & (cells < 4))
+        assert np.all(np.abs(np.diff(cells, axis=0)).sum(1) >= 1)   # every step enters a new cell
+    assert g["axis_aligned_x_cells"].tolist() == [[0, 1, 2], [1, 1, 2], [2, 1, 2], [3, 1, 2]]
+    assert g["negative_x_zero_yz_cells"].tolist() == [[3, 0, 3], [2, 0, 3], [1, 0, 3], [0, 0, 3]]
+    assert g["zero_x_cells"][:, 0].tolist() == [2] * len(g["zero_x_cells"])
+
+
+# =========================================================================== GPU: HIP path vs fixtures
+@pytest.mark.gpu
+def test_gpu_hand_grid_cases():
+    from instantvnr_amd import api
+    g = gold("grid_hand_cases.npz")
+    cfg = syn.model_config(n_levels=int(g["n_levels"]), n_features=int(g["n_features"]),
+                           log2_hashmap_size=int(g["log2_hashmap_size"]), base_resolution=int(g["base_resolution"]),
+                           n_hidden_layers=1)
+    vol = api.vnrCreateNeuralVolume(cfg, (8, 8, 8))
+    info = api.neural_info(vol)
+    table = g["table_f16_bits"].view(np.float16)
+    params = np.zeros(info["n_params"], dtype=np.float16)
+    params[info["n_params"] - table.size:] = table   # blob order: MLP weights, then the grid
+    api.neural_set_params_fp16(vol, params)
+    got = api.neural_encode(vol, g["coords"])
+    assert np.array_equal(got.view(np.uint16), g["features_f16_bits"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NETWORKS)
+def test_gpu_network_fixtures(name):
+    from instantvnr_amd import api
+    g = gold(f"network_{name}.npz")
+    cfg = syn.model_config(n_levels=int(g["n_levels"]), n_features=int(g["n_features"]),
+                           log2_hashmap_size=int(g["log2_hashmap_size"]), base_resolution=int(g["base_resolution"]),
+                           n_hidden_layers=int(g["n_hidden_layers"]), per_level_scale=float(g["per_level_scale"]))
+    vol = api.vnrCreateNeuralVolume(cfg, (32, 32, 32))
+    assert api.neural_info(vol)["n_params"] == int(g["n_params"])
+    api.neural_set_params_fp16(vol, net_params(g))
+    feats = api.neural_encode(vol, g["coords"][:512])
+    assert np.array_equal(feats.view(np.uint16), g["features_f16_bits_first512"])   # bit-exact
+    out = api.neural_inference(vol, g["coords"])
+    err = np.abs(out - g["out_acc_f32"])
+    assert err.max() <= TOL_NET, err.max()
+    # and the HIP result sits no further from the fp32-accumulate result than the fp16-accumulate oracle does (x2)
+    assert err.mean() <= 2 * np.abs(g["out_acc_f16"] - g["out_acc_f32"]).mean() + 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_c1_scene():
+    from instantvnr_amd import api
+    g = gold("c1_scene.npz")
+    vol = c1_inputs(g)
+    sv = api.vnrCreateSimpleVolume(vol)
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, g["tfn_colors"])
+    api.vnrTransferFunctionSetAlpha(tfn, g["tfn_alphas"])
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = api.vnrCreateCamera()
+    api.vnrCameraSet(cam, tuple(g["cam_from"]), tuple(g["cam_at"]), tuple(g["cam_up"]), float(g["fovy"]))
+    images = {}
+    for mode in (4, 5):
+        r = api.vnrCreateRenderer(sv)
+        api.vnrRendererSetTransferFunction(r, tfn)
+        api.vnrRendererSetCamera(r, cam)
+        api.vnrRendererSetFramebufferSize(r, (256, 256))
+        api.vnrRendererSetMode(r, mode)
+        api.vnrRender(r)
+        images[mode] = api.vnrRendererMapFrame(r).copy()
+        if mode == 5:
+            st = api.vnrRendererGetFrameStats(r)
+            assert st["n_rays_hit"] == int(g["streaming_n_rays_hit"])
+            assert st["n_iterations"] == int(g["streaming_n_iterations"])
+    mc = api.volume_macrocell(sv)
+    assert mc["dims"] == (4, 4, 4)
+    assert np.array_equal(mc["value_range"], g["macrocell_value_range"])      # bit-exact (float-as-int min/max)
+    assert np.array_equal(mc["max_opacity"], g["macrocell_max_opacity"])
+    # identical arithmetic except powf (device libm vs glibc): stated tolerance 2e-4 absolute per channel
+    assert np.abs(images[4] - g["image_mode4_monolithic"]).max() < 2e-4
+    assert np.abs(images[5] - g["image_mode5_streaming"]).max() < 2e-4

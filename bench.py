@@ -190,19 +190,35 @@ def main():
                 "algorithmic_bytes_per_sample": bytes_per_sample, "flops_per_sample": flops_per_sample,
                 "avg_launch_ms": round(infer_ms / max(launches, 1), 4), "launches": launches,
                 "mfma_tflops": round(samples * flops_per_sample / (infer_ms * 1e-3) / 1e12, 2) if infer_ms > 0 else 0.0}
+    # The renderer runs the rays as 2 halves on 2 streams by default (march of one half overlaps inference of the other,
+    # and the two halves' inference kernels overlap each other), so a launch's HIP-event duration includes time it shares
+    # the GPU: `achieved`/`frac` (defined per launch) drop although the frame gets faster.  The frame-level figure below
+    # does not depend on scheduling: algorithmic bytes of all live samples of a frame / frame time.
+    halves = 1 if os.environ.get("VNR_AMD_RENDER_HALVES", "2") == "1" else 2
+    roofline["concurrency"] = (f"{halves} ray halves on {halves} HIP streams; launch durations are per stream and overlap"
+                               if halves == 2 else "1 stream: launches run alone")
+    frame_gbs = (samples / a.steps) * bytes_per_sample / (elapsed / a.steps) / 1e9
+    roofline["frame_algorithmic_gbs"] = round(frame_gbs, 1)
+    roofline["frame_frac"] = round(frame_gbs / HBM_PEAK_GBS, 4)
     # HBM-side traffic of the dominant kernel: PMC counters cannot be collected inside this run (separate rocprofv3
-    # --pmc passes, tools/run_pmc.sh); the committed result applies only to the exact default workload on one GPU.
+    # --pmc passes, tools/run_pmc.sh); a committed result applies only to the exact default workload on one GPU with
+    # the same stream configuration it was measured with.
     default_workload = (a.size, a.fb, a.levels, a.features, a.log2_hashmap_size, a.hidden_layers, a.per_level_scale,
                         a.train_steps, a.opacity_scale, a.camera_distance) == (1024, 1024, 16, 2, 22, 3, 0.0, 1500, 0.06, 1.1)
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                            "r01_pmc_traffic.json" if halves == 1 else "r01_pmc_traffic_2halves.json")
     if default_workload and ctx.world == 1 and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
         roofline["traffic"] = round(pmc["per_launch_bytes"]["traffic"])
         roofline["traffic_unit"] = "bytes per launch (L2<->fabric reads x2-corrected + writes; includes Infinity-Cache hits)"
         roofline["algorithmic_bytes_per_launch"] = round(samples * bytes_per_sample / max(launches, 1))
-        roofline["traffic_note"] = ("measured in separate rocprofv3 --pmc passes of this command, not in this run: "
-                                    "profiles/r01_pmc_traffic.json (traffic/algorithmic = %.2f: half of every fetched 128-B "
-                                    "line is unused)" % pmc["traffic_over_algorithmic"])
+        roofline["traffic_note"] = ("measured in separate rocprofv3 --pmc passes of this command, not in this run: profiles/%s "
+                                    "(traffic/algorithmic = %.2f: about half of every fetched 128-B line is unused)"
+                                    % (os.path.basename(pmc_path), pmc["traffic_over_algorithmic"]))
+    elif default_workload and ctx.world == 1 and halves == 2:
+        roofline["traffic_note"] = ("null: not measured for the 2-stream configuration (both rocprofv3 --pmc FETCH_SIZE passes of it hung, "
+                                    "see tools/run_pmc.sh).  The same kernel running alone (VNR_AMD_RENDER_HALVES=1) fetched 2.09 x its "
+                                    "algorithmic bytes: profiles/r01_pmc_traffic.json")
     out = {
         "metric": "fps at 1024^2 on 1024^3 volume" if (a.size, a.fb) == (1024, 1024) else f"fps at {a.fb}^2 on {a.size}^3 volume",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,

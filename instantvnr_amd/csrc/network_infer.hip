@@ -314,7 +314,18 @@ static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
   const Runtime& rt = Runtime::get();
   const uint32_t n_tiles = div_round_up(n_max, 64);
   uint32_t blocks = div_round_up(n_tiles, 4);
-  const uint32_t max_blocks = (uint32_t)rt.n_cus * 4u;  // persistent: <= 4 blocks of 4 waves per CU
+  // persistent: 2 blocks of 4 waves per CU.  113 registers would allow 4 (= a full register file), but the in-frame
+  // kernel is bound by fetched lines, not latency: measured on MI355X (round 1, kernel-only G samples/s, n = 3 / 2):
+  //   C4 (L16 F2 T2^22, 40 M samples/frame): 4 blocks 5.98, 3 blocks 6.20, 2 blocks 6.25, 1 block 4.77
+  //   C2 shape (L8 F8 T2^19, 2.4 M samples/frame): 4.15-4.18 for 4, 3 and 2 alike
+  // and 2 blocks leave more than half of the registers and LDS of a CU to a kernel of another stream.
+  // VNR_AMD_INFER_BLOCKS_PER_CU (1..4) overrides, for diagnostics.
+  static const uint32_t blocks_per_cu = [] {
+    const char* e = std::getenv("VNR_AMD_INFER_BLOCKS_PER_CU");
+    const int v = e ? std::atoi(e) : 2;
+    return (uint32_t)(v >= 1 && v <= 4 ? v : 2);
+  }();
+  const uint32_t max_blocks = (uint32_t)rt.n_cus * blocks_per_cu;
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = next_multiple(blocks, 8);
   const size_t shmem = MODE == 1 ? 16 : (size_t)a.lds_halves * sizeof(uint16_t);

@@ -494,17 +494,23 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   if (!Runtime::get().ready()) Runtime::get().init(-1);
   stream_ = Runtime::get().stream;
   if (const char* e = std::getenv("VNR_RM_N_ITERS")) n_iters_ = std::max(1, std::min(48, std::atoi(e)));  // 3 KiB of LDS per iteration slot and block
-  counters_.resize(C_COUNT);
+  // streaming mode runs the rays as two halves on two streams (render_streaming); VNR_AMD_RENDER_HALVES=1: one stream
+  if (const char* e = std::getenv("VNR_AMD_RENDER_HALVES")) n_halves_ = std::atoi(e) == 1 ? 1 : 2;
+  counters_.resize(2 * C_COUNT);  // one block of counters per half
   counters_.zero(stream_);
-  VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 256 * sizeof(uint32_t), hipHostMallocDefault));
+  VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 2 * 256 * sizeof(uint32_t), hipHostMallocDefault));
+  VNR_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+  VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 }
 
 Renderer::~Renderer()
 {
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   for (int i = 0; i < 2; ++i) if (host_fb_[i]) (void)hipHostFree(host_fb_[i]);
   if (host_counts_) (void)hipHostFree(host_counts_);
-  for (auto e : events_) (void)hipEventDestroy(e);
+  for (auto& v : events_) for (auto e : v) (void)hipEventDestroy(e);
 }
 
 void Renderer::resize(int w, int h)
@@ -622,32 +628,71 @@ void Renderer::render_monolithic(const RenderParams& p)
   VNR_HIP_CHECK(hipGetLastError());
 }
 
-void Renderer::render_streaming(const RenderParams& p)
+void Renderer::render_streaming(const RenderParams& p_all)
 {
-  const uint32_t P = p.n_local;
-  ensure_queues(P, p.n_iters);
+  // The rank's rays are dealt to `n_halves_` independent halves (alternate local tile rows; same mechanism as the
+  // multi-GPU interleave), each with its own ray lists, sample queue, counters and HIP stream.  The arithmetic per ray
+  // is untouched; what changes is that march(i) of one half runs while the other half's inference kernel does: the
+  // inference kernel is bound by fetched bytes and resident with 2 blocks per CU, the march kernel is latency bound
+  // and fits next to it (registers and LDS: DESIGN.md 4.2).
+  const uint32_t row_items = p_all.tiles_per_row * 64u;
+  const uint32_t R = p_all.n_local / row_items;  // local tile rows
+  const int H = (n_halves_ == 2 && R >= 2) ? 2 : 1;
+  const uint32_t P_total = p_all.n_local;
+  ensure_queues(P_total, p_all.n_iters);
   const size_t QP = queue_pixels_;
-  RayList rl[2];
-  for (int b = 0; b < 2; ++b) {
-    rl[b].pixel_index = q_u32_.ptr + (size_t)(0 + b) * QP;
-    rl[b].sample_base = q_u32_.ptr + (size_t)(2 + b) * QP;
-    rl[b].sample_count = q_u32_.ptr + (size_t)(4 + b) * QP;
-    float* f = q_f32_.ptr + (size_t)b * 9 * QP;
-    rl[b].jitter = f;
-    rl[b].alpha = f + QP;
-    rl[b].color = (vec3f*)(f + 2 * QP);
-    rl[b].t_next = (vec3f*)(f + 5 * QP);
-    rl[b].next_cell_begin = f + 8 * QP;
-    rl[b].cell = (vec3i*)(q_i32_.ptr + (size_t)b * 3 * QP);
-  }
-  vec2f* vd[2] = {vd_.ptr, vd_.ptr + (size_t)QP * queue_iters_};
-  uint32_t* c = counters_.ptr;
   NeuralVolume* nv = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get()) : nullptr;
   if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
 
-  VNR_HIP_CHECK(hipMemsetAsync(c, 0, C_COUNT * sizeof(uint32_t), stream_));
-  const size_t shmem = ((size_t)3 * p.n_iters + 1) * 256 * sizeof(float);
-  const size_t shmem_compose = shmem + (p.tfn_in_lds ? (size_t)p.tfn.n_colors * sizeof(vec4f) + (size_t)p.tfn.n_alphas * sizeof(float) : 0);
+  struct Half {
+    RenderParams p;
+    RayList rl[2];
+    vec4f* queue;
+    vec2f* vd[2];
+    uint32_t* c;         // device counters of this half
+    uint32_t* hc;        // pinned ring of alive-ray counts
+    hipStream_t s;
+    size_t s_max;
+    uint32_t it = 0, used = 0;
+    bool done = false;
+  } half[2];
+  size_t off = 0;
+  for (int h = 0; h < H; ++h) {
+    Half& hf = half[h];
+    hf.p = p_all;
+    if (H == 2) {
+      hf.p.il_parts = p_all.il_parts * 2u;
+      hf.p.il_part = p_all.il_part + p_all.il_parts * (uint32_t)h;
+      hf.p.n_local = ((R + 1u - (uint32_t)h) / 2u) * row_items;
+    }
+    for (int b = 0; b < 2; ++b) {
+      hf.rl[b].pixel_index = q_u32_.ptr + (size_t)(0 + b) * QP + off;
+      hf.rl[b].sample_base = q_u32_.ptr + (size_t)(2 + b) * QP + off;
+      hf.rl[b].sample_count = q_u32_.ptr + (size_t)(4 + b) * QP + off;
+      float* f = q_f32_.ptr + (size_t)b * 9 * QP;
+      hf.rl[b].jitter = f + off;
+      hf.rl[b].alpha = f + QP + off;
+      hf.rl[b].color = (vec3f*)(f + 2 * QP) + off;
+      hf.rl[b].t_next = (vec3f*)(f + 5 * QP) + off;
+      hf.rl[b].next_cell_begin = f + 8 * QP + off;
+      hf.rl[b].cell = (vec3i*)(q_i32_.ptr + (size_t)b * 3 * QP) + off;
+      hf.vd[b] = vd_.ptr + (size_t)b * QP * queue_iters_ + off * queue_iters_;
+    }
+    hf.queue = queue_.ptr + off * queue_iters_;
+    hf.c = counters_.ptr + (size_t)h * C_COUNT;
+    hf.hc = host_counts_ + (size_t)h * 256;
+    hf.s = h == 0 ? stream_ : stream2_;
+    hf.s_max = (size_t)hf.p.n_local * hf.p.n_iters;
+    off += hf.p.n_local;
+  }
+
+  VNR_HIP_CHECK(hipMemsetAsync(counters_.ptr, 0, 2 * C_COUNT * sizeof(uint32_t), stream_));
+  if (H == 2) {  // fork: the second stream starts after everything queued on the render stream so far
+    VNR_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
+    VNR_HIP_CHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+  }
+  const size_t shmem = ((size_t)3 * p_all.n_iters + 1) * 256 * sizeof(float);
+  const size_t shmem_compose = shmem + (p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0);
   if (shmem_compose > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
   static bool lds_attr_set = false;
   if (!lds_attr_set) {  // more than the default 64 KiB of dynamic LDS needs an opt-in
@@ -657,67 +702,99 @@ void Renderer::render_streaming(const RenderParams& p)
   }
   uint32_t max_iterations = 240;
   if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) max_iterations = std::max(1, std::min(240, std::atoi(e)));  // diagnostics only
-  if (profiling_) iter_ms_.assign(max_iterations, 0.0f);
-  if (profiling_ && events_.size() < 2 * max_iterations) {
-    while (events_.size() < 2 * max_iterations) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreate(&e)); events_.push_back(e); }
+  if (profiling_) {
+    iter_ms_.assign(max_iterations, 0.0f);
+    for (int h = 0; h < H; ++h)
+      while (events_[h].size() < 2 * max_iterations) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreate(&e)); events_[h].push_back(e); }
   }
-  const size_t s_max = (size_t)P * p.n_iters;
-  uint32_t it = 0;
-  for (;;) {
+
+  // one iteration of one half: march(it) -> evaluate the compacted samples -> clear the counters march(it+1) appends to
+  auto launch_iteration = [&](int h) {
+    Half& hf = half[h];
+    const uint32_t it = hf.it;
     const int parity = (int)(it & 1u);
+    const uint32_t P = hf.p.n_local;
+    uint32_t* c = hf.c;
     // march(it): reads ray list `parity`, writes list `parity^1` and sample queue `parity`
     if (it == 0) {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 4096u);
-      march_kernel<true><<<blocks, 256, shmem, stream_>>>(p, rl[0], rl[1], vd[1], queue_.ptr, vd[0], c, 0);
+      march_kernel<true><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, 0);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
-      march_kernel<false><<<blocks, 256, shmem_compose, stream_>>>(p, rl[parity], rl[parity ^ 1], vd[parity ^ 1], queue_.ptr, vd[parity], c, parity);
+      march_kernel<false><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[parity], hf.rl[parity ^ 1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, parity);
     }
     VNR_HIP_CHECK(hipGetLastError());
-    // evaluate the compacted samples; the evaluation kernel also clears the counters march(it+1) will append to
     uint32_t* clear0 = c + C_RAYS0 + parity;            // output ray list of march(it+1)
     uint32_t* clear1 = c + C_SAMPLES0 + (parity ^ 1);   // sample counter of march(it+1)
-    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[2 * it], stream_));
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it], hf.s));
     if (nv) {
-      nv->network().inference_queue((const float*)queue_.ptr, (float*)vd[parity], 2, c + C_SAMPLES0 + parity, s_max, stream_);
+      nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 2, c + C_SAMPLES0 + parity, hf.s_max, hf.s);
     } else {
-      const uint32_t blocks = std::min<uint32_t>(div_round_up(s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
-      gt_sample_kernel<<<blocks, 256, 0, stream_>>>(c + C_SAMPLES0 + parity, p.volume, p.vol_dims, queue_.ptr, vd[parity]);
+      const uint32_t blocks = std::min<uint32_t>(div_round_up(hf.s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
+      gt_sample_kernel<<<blocks, 256, 0, hf.s>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, hf.vd[parity]);
     }
-    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[2 * it + 1], stream_));
-    clear_two_kernel<<<1, 1, 0, stream_>>>(clear0, clear1);
-    VNR_HIP_CHECK(hipMemcpyAsync(host_counts_ + (it & 255u), c + C_RAYS0 + (parity ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-    ++it;
-    if (it >= max_iterations) break;
-    if (it >= predicted_iterations_) {
-      // past the speculative part: look at the alive-ray count of the iteration just launched
-      VNR_HIP_CHECK(hipStreamSynchronize(stream_));
-      if (host_counts_[(it - 1) & 255u] == 0) break;
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
+    clear_two_kernel<<<1, 1, 0, hf.s>>>(clear0, clear1);
+    VNR_HIP_CHECK(hipMemcpyAsync(hf.hc + (it & 255u), c + C_RAYS0 + (parity ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, hf.s));
+    ++hf.it;
+    if (hf.it >= max_iterations) hf.done = true;
+  };
+
+  // phase 1: the iterations the previous frame needed, launched for both halves alternately without any host sync;
+  // phase 2: past that, look at the alive-ray count of the iteration just launched before launching another one.
+  for (;;) {
+    bool launched = false;
+    for (int h = 0; h < H; ++h)
+      if (!half[h].done && half[h].it < predicted_iterations_[h]) { launch_iteration(h); launched = true; }
+    if (!launched) break;
+  }
+  for (;;) {
+    bool pending = false;
+    for (int h = 0; h < H; ++h) {
+      Half& hf = half[h];
+      if (hf.done) continue;
+      if (hf.it > 0) {
+        VNR_HIP_CHECK(hipStreamSynchronize(hf.s));
+        if (hf.hc[(hf.it - 1) & 255u] == 0) { hf.done = true; continue; }
+      }
+      launch_iteration(h);
+      pending = true;
+    }
+    if (!pending) break;
+  }
+
+  // the last march that produced zero rays ends a half's frame; remember how many iterations that took
+  stats_.n_iterations = 0;
+  uint64_t n_samples = 0, n_refrays = 0;
+  for (int h = 0; h < H; ++h) {
+    Half& hf = half[h];
+    VNR_HIP_CHECK(hipStreamSynchronize(hf.s));
+    uint32_t used = hf.it;
+    while (used > 1 && hf.hc[(used - 2) & 255u] == 0) --used;  // trailing speculative no-op iterations
+    predicted_iterations_[h] = used;
+    hf.used = used;
+    uint32_t hc[C_COUNT];
+    VNR_HIP_CHECK(hipMemcpy(hc, hf.c, sizeof(hc), hipMemcpyDeviceToHost));
+    stats_.n_rays_hit += hc[C_HIT];
+    n_samples += (uint64_t)hc[C_STAT_SAMPLES] | ((uint64_t)hc[C_STAT_SAMPLES + 1] << 32);
+    n_refrays += (uint64_t)hc[C_STAT_REFRAYS] | ((uint64_t)hc[C_STAT_REFRAYS + 1] << 32);
+    // march(j) emits what the reference's iteration j intersects and march(j+1) composes it, so `used` marches
+    // correspond to used-1 reference iterations (= inference launches with samples); halves run side by side
+    stats_.n_iterations = std::max<uint32_t>(stats_.n_iterations, used > 0 ? used - 1 : 0);
+    if (profiling_) {
+      for (uint32_t k = 0; k < hf.it; ++k) {
+        float ms = 0.0f;
+        VNR_HIP_CHECK(hipEventElapsedTime(&ms, events_[h][2 * k], events_[h][2 * k + 1]));
+        stats_.infer_kernel_ms += ms;
+        iter_ms_[k] += ms;
+      }
+      stats_.infer_kernel_launches += used > 0 ? used - 1 : 0;
     }
   }
-  // the last march that produced zero rays ends the frame; remember how many iterations that took
-  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
-  uint32_t used = it;
-  while (used > 1 && host_counts_[(used - 2) & 255u] == 0) --used;  // trailing speculative no-op iterations
-  predicted_iterations_ = used;
-  uint32_t hc[C_COUNT];
-  VNR_HIP_CHECK(hipMemcpy(hc, c, sizeof(hc), hipMemcpyDeviceToHost));
-  stats_.n_rays_hit = hc[C_HIT];
-  stats_.n_samples = (uint64_t)hc[C_STAT_SAMPLES] | ((uint64_t)hc[C_STAT_SAMPLES + 1] << 32);
-  stats_.n_reference_slots = ((uint64_t)hc[C_STAT_REFRAYS] | ((uint64_t)hc[C_STAT_REFRAYS + 1] << 32)) * (uint64_t)p.n_iters;
-  // march(j) emits what the reference's iteration j intersects and march(j+1) composes it, so `used` marches
-  // correspond to used-1 reference iterations (= inference launches with samples)
-  stats_.n_iterations = used > 0 ? used - 1 : 0;
-  if (profiling_) {
-    for (uint32_t k = 0; k < it; ++k) {
-      float ms = 0.0f;
-      VNR_HIP_CHECK(hipEventElapsedTime(&ms, events_[2 * k], events_[2 * k + 1]));
-      stats_.infer_kernel_ms += ms;
-      iter_ms_[k] = ms;
-    }
-    stats_.infer_kernel_launches = used > 0 ? used - 1 : 0;
-  }
+  stats_.n_samples = n_samples;
+  stats_.n_reference_slots = n_refrays * (uint64_t)p_all.n_iters;
 }
+
 
 const float* Renderer::map_frame()
 {

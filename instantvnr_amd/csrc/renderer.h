@@ -70,8 +70,10 @@ private:
   bool reset_ = true, skip_download_ = false, profiling_ = false;
   int frame_index_ = 0;
   int n_iters_ = 16;  // VNR_RM_N_ITERS (method_raymarching.cu:30-40)
-  uint32_t predicted_iterations_ = 0;
-  hipStream_t stream_ = nullptr;
+  int n_halves_ = 2;  // streaming mode: rays dealt to 2 halves on 2 streams (march of one overlaps inference of the other)
+  uint32_t predicted_iterations_[2] = {0, 0};
+  hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr;
 
   // framebuffer: double-buffered device + pinned host (framebuffer.h:7-98)
   DeviceBuffer<vec4f> fb_[2], accumulation_;
@@ -85,11 +87,11 @@ private:
   DeviceBuffer<int> q_i32_;        // cell[2][3]
   DeviceBuffer<vec4f> queue_;      // gather-order sample records {x, y, z, ray-major slot}
   DeviceBuffer<vec2f> vd_;         // ray-major {value, t1 - t0} per sample, x2 (ping-pong)
-  DeviceBuffer<uint32_t> counters_;
-  uint32_t* host_counts_ = nullptr;  // pinned ring of alive-ray counts
+  DeviceBuffer<uint32_t> counters_;  // 2 x C_COUNT: one block per half
+  uint32_t* host_counts_ = nullptr;  // pinned rings of alive-ray counts, 2 x 256
   size_t queue_pixels_ = 0;
   int queue_iters_ = 0;
-  std::vector<hipEvent_t> events_;
+  std::vector<hipEvent_t> events_[2];  // per half: (before, after) the evaluation kernel of each iteration
   FrameStats stats_;
   std::vector<float> iter_ms_;
 };

@@ -3,9 +3,11 @@
 #   usage (on the GPU box): bash tools/run_pmc.sh calib|bench "<counters>" [timeout_s]
 #   -> gpurun_out/pmc/<what>_<counters>{.log,.summary.txt,/}
 # History (round 1): `rocprofv3 --pmc ... python3 bench.py` hangs INTERMITTENTLY (no output after "HSA version ...
-# initialized"): 3 passes finished in ~6 s (FETCH_SIZE x2, WRITE_SIZE x1), 5 hung until killed (WRITE_SIZE x2, RDREQ,
-# TCC_HIT/MISS/REQ x2) -- including a first pass on a fresh box, so it is neither counter- nor order-specific.  The calib
-# binary never hung (9 passes); bench.py never hung without --pmc.  NOT root-caused.  Always run under a short timeout;
+# initialized"): 3 passes finished in ~6 s (FETCH_SIZE x2, WRITE_SIZE x1), 8 hung until killed (WRITE_SIZE x2, RDREQ,
+# TCC_HIT/MISS/REQ x3, FETCH_SIZE x2) -- several of them the first profiler process on a fresh box, so it is neither
+# counter- nor order-specific.  The two FETCH_SIZE hangs were the only passes run after the renderer went to 2 streams
+# (n = 2: no conclusion).  The calib binary never hung (11 runs); bench.py never hung without --pmc.  NOT root-caused.
+# Always run under a short timeout;
 # chaining four 600-s passes cost ~40 GPU-minutes once.  `-X faulthandler` + SIGABRT on timeout prints where it hangs.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc

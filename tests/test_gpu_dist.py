@@ -1,0 +1,116 @@
+"""The device side of the multi-GPU path on ONE GPU: a one-rank `nccl` (= RCCL) process group.
+
+What cannot be tested on a 1-GPU box is more than one rank; what can, and is the part most likely to break on the
+driver's multi-GPU run, is everything a rank does with its own GPU: torch aliasing the library's device buffers through
+`__cuda_array_interface__` (no copies), the library-stream -> torch-stream hand-off, RCCL initialisation on this image
+(HSA_ENABLE_IPC_MODE_LEGACY=0), `all_gather_into_tensor` of the frame shares and `all_reduce` of the gradient blob.
+With one rank both collectives are the identity, so results must equal the undistributed path.
+`tests/test_dist_cpu.py` covers world size 2 (gloo) with a CPU stand-in for the renderer;
+`tests/test_gpu_render.py::test_interleaved_shares_assemble_to_the_unsharded_frame` covers the sharded rendering itself."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from instantvnr_amd import api
+from instantvnr_amd import dist as vdist
+from instantvnr_amd import synthetic as syn
+from instantvnr_amd._lib import check, check_ptr, lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def group():
+    import torch
+    import torch.distributed as dist
+    check(lib().vnrAmdInit(0))
+    torch.cuda.set_device(0)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_frame_share_roundtrip_through_rccl(group):
+    import torch
+    size = (96, 80)
+    n_pixels, block = size[0] * size[1], 8 * size[0]
+    vol = syn.analytic_volume(48)
+    sv = api.vnrCreateSimpleVolume(vol)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = syn.oblique_camera((48, 48, 48), distance_scale=0.95)
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+
+    def renderer(device_output):
+        r = api.vnrCreateRenderer(sv)
+        api.vnrRendererSetTransferFunction(r, tfn)
+        api.vnrRendererSetCamera(r, camera)
+        api.vnrRendererSetFramebufferSize(r, size)
+        api.vnrRendererSetMode(r, 5)
+        api.vnrRendererSetOutputAsDeviceFramebuffer(r, device_output)
+        return r
+
+    r_host = renderer(False)
+    api.vnrRender(r_host)
+    want = api.vnrRendererMapFrame(r_host).reshape(-1, 4).copy()
+    assert (want[:, 3] > 0).mean() > 0.2
+
+    r_dev = renderer(True)
+    api.vnrRender(r_dev)
+    ptr = api.vnrRendererMapFrame(r_dev)                       # device pointer; MapFrame synced the render streams
+    frame = vdist.as_torch(ptr, (n_pixels, 4))                # alias, no copy
+    assert frame.is_cuda and frame.data_ptr() == int(ptr)
+    share = vdist.pack_share(frame, block, 1, 0, n_pixels)
+    _, _, n_local = vdist.interleave_layout(n_pixels, block, 1)
+    gathered = torch.empty((1, n_local, 4), dtype=torch.float32, device="cuda")
+    group.all_gather_into_tensor(gathered.view(-1), share.view(-1))
+    full = vdist.assemble_shares(gathered, block, 1, n_pixels)
+    torch.cuda.synchronize()
+    assert np.array_equal(full.cpu().numpy(), want)
+
+
+def test_gradient_allreduce_step_equals_plain_step(group):
+    import torch
+    os.environ["VNR_AMD_INIT_SEED"] = "77"
+    data = syn.analytic_volume(32)
+    cfg = syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
+    L = lib()
+    res = []
+    for through_rccl in (False, True):
+        sv = api.vnrCreateSimpleVolume(data)
+        nv = api.vnrCreateNeuralVolume(cfg, sv)
+        if through_rccl:
+            grads = None
+            for _ in range(20):
+                check(L.vnrAmdNeuralVolumeTrainBegin(nv.h))
+                if grads is None:
+                    n = C.c_size_t()
+                    p = check_ptr(L.vnrAmdNeuralVolumeGradients(nv.h, C.byref(n)))
+                    grads = vdist.as_torch(p, (n.value,))
+                    assert grads.numel() == api.neural_info(nv)["n_params"]
+                check(L.vnrAmdSynchronize())                   # library stream -> torch stream hand-off
+                before = float(grads.abs().sum())
+                group.all_reduce(grads, op=group.ReduceOp.SUM)  # one rank: identity, in place on the library's buffer
+                torch.cuda.current_stream().synchronize()
+                assert before > 0 and float(grads.abs().sum()) == before
+                check(L.vnrAmdNeuralVolumeTrainEnd(nv.h, 1.0, 1))
+        else:
+            api.vnrNeuralVolumeTrain(nv, 20, True)
+        res.append((api.vnrNeuralVolumeGetTrainingLoss(nv), api.neural_get_params_fp16(nv).astype(np.float32)))
+    # same bar as test_split_training_step_equals_train: float atomics make training not bitwise reproducible
+    assert abs(res[0][0] - res[1][0]) < 0.1 * res[0][0]
+    assert np.mean(np.abs(res[0][1] - res[1][1])) < 1e-3

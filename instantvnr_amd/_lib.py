@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
@@ -11,10 +12,23 @@ SO_PATH = os.path.join(_HERE, "libvnr_amd.so")
 HEADER = os.path.join(ROOT, "include", "vnr_amd.h")
 
 _lib = None
+_torch_imported_before_load = None  # set when the library is loaded
 
 
 class VnrAmdError(RuntimeError):
     pass
+
+
+def require_torch_loaded_first():
+    """PyTorch-ROCm wheels bundle their own ROCm runtime (torch/lib/libamdhip64.so, libhsa-runtime64.so) while
+    libvnr_amd.so links against the system ROCm.  If torch is imported first, the library binds to torch's copy and both
+    share one runtime.  If the library is loaded first, `import torch` maps a SECOND HSA runtime into the process, which
+    finds no GPU ("RuntimeError: No HIP GPUs are available"; measured on MI355X, ROCm 7.2 + torch 2.10+rocm7.0).  Anything
+    here that uses torch on the GPU calls this, so that the wrong order fails with an explanation."""
+    if _lib is not None and not _torch_imported_before_load:
+        raise VnrAmdError("libvnr_amd.so was loaded before `import torch`: PyTorch's bundled ROCm runtime cannot share the "
+                          "GPU with the system runtime the library already initialised.  Import torch first (instantvnr_amd."
+                          "dist.init_from_env does when WORLD_SIZE > 1; tests/conftest.py does for the test session).")
 
 
 def build(force=False):
@@ -45,6 +59,8 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise VnrAmdError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
+    global _torch_imported_before_load
+    _torch_imported_before_load = "torch" in sys.modules
     L = C.CDLL(SO_PATH)
     P, I, U32, U64, F, D, SZ = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_size_t
     FP = C.POINTER(C.c_float)

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import api
-from ._lib import check, check_ptr, lib
+from ._lib import check, check_ptr, lib, require_torch_loaded_first
 
 
 # ------------------------------------------------------------------------------------------------ sharding maths (pure python; CPU-testable)
@@ -60,6 +60,7 @@ class _CudaArray:
 
 
 def as_torch(ptr, shape, typestr="<f4", device=None):
+    require_torch_loaded_first()   # a device pointer of the library exists, so the library is loaded: torch must have come first
     import torch
     return torch.as_tensor(_CudaArray(ptr, shape, typestr), device=device if device is not None else torch.cuda.current_device())
 
@@ -81,11 +82,15 @@ def init_from_env(device_backend="nccl"):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    check(lib().vnrAmdInit(local_rank))
     if world > 1:
+        # torch BEFORE the first use of the library: its wheel bundles its own ROCm runtime, and two runtimes cannot
+        # share the GPU in one process (_lib.require_torch_loaded_first explains; tools/repro_torch_*_lib.py reproduce)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+    check(lib().vnrAmdInit(local_rank))
+    if world > 1:
+        require_torch_loaded_first()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend=device_backend, rank=rank, world_size=world)

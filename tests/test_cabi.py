@@ -123,3 +123,19 @@ def test_cpp_api_shim_compiles_and_throws_like_the_reference(L, tmp_path):
                            "-Wl,-rpath," + os.path.join(root, "instantvnr_amd")])
     rc = subprocess.call([exe])
     assert rc == (0 if L.vnrAmdHasDevice() else 42)   # 42 = std::runtime_error ("no HIP capable devices")
+
+
+@pytest.mark.parametrize("order,ok", [("lib-first", False), ("torch-first", True)])
+def test_torch_must_be_imported_before_the_library_is_loaded(L, order, ok):
+    """PyTorch's wheel bundles its own ROCm runtime; with the library loaded first torch finds no GPU (measured on
+    MI355X: tools/repro_torch_after_lib.py).  The wrong order must fail with an explanation, not later inside torch."""
+    import subprocess
+    import sys
+    first, second = ("_lib.lib()", "import torch") if order == "lib-first" else ("import torch", "_lib.lib()")
+    code = (f"import sys; sys.path.insert(0, {_lib.ROOT!r})\n"
+            "from instantvnr_amd import _lib\n"
+            f"{first}\n{second}\n"
+            "try:\n    _lib.require_torch_loaded_first(); print('GUARD-PASSED')\n"
+            "except _lib.VnrAmdError as e:\n    print('GUARD-RAISED', 'Import torch first' in str(e))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
+    assert ("GUARD-PASSED" in out) if ok else ("GUARD-RAISED True" in out), out

@@ -48,6 +48,16 @@ struct ModelConfig {
   uint32_t loss = 0;  // 0 L1, 1 L2
 };
 
+// Optimizer state of ONE parameter, interleaved: an Adam update of a touched hash-grid entry then reads and writes one
+// 16-byte record (entries of a level are adjacent, so a 128-B line holds 8 of them) instead of one element in each of
+// four arrays, i.e. four lines (the ~10 M touched parameters of a step cost 3x the sweep over all 70 M).
+struct alignas(16) OptState {
+  float master;   // fp32 master weight
+  float m, v;     // Adam first / second moment
+  uint32_t step;  // per-parameter step count (tcnn adam: untouched grid entries do not advance)
+};
+static_assert(sizeof(OptState) == 16, "OptState must be one 16-byte record");
+
 class Network {
 public:
   Network() = default;
@@ -107,9 +117,8 @@ private:
   DeviceBuffer<uint16_t> params_f16_{MemTag::Network};   // tcnn-order blob (inference + serialisation)
   DeviceBuffer<uint16_t> mlp_packed_{MemTag::Network};   // MFMA/LDS image of the MLP weights
   DeviceBuffer<LevelInfo> levels_dev_{MemTag::Network};  // per-level constants, read with scalar loads
-  DeviceBuffer<float> params_f32_{MemTag::Network};      // fp32 master copy (training)
-  DeviceBuffer<float> grads_{MemTag::Network};           // fp32 gradient of the whole blob
-  DeviceBuffer<float> adam_m_{MemTag::Network}, adam_v_{MemTag::Network};
+  DeviceBuffer<OptState> opt_state_{MemTag::Network};    // per parameter: fp32 master copy + Adam moments + step count (training)
+  DeviceBuffer<float> grads_{MemTag::Network};           // fp32 gradient of the whole blob (ONE buffer: the all-reduce unit)
   // training workspace
   DeviceBuffer<uint16_t> ws_features_{MemTag::Network};  // [B][in_width]
   DeviceBuffer<uint16_t> ws_acts_{MemTag::Network};      // [(nh+1)][B][64]

@@ -14,10 +14,10 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                   const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0);
-void launch_init_params(float* master, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
+void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
                         uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s);
-void launch_f16_to_f32(const uint16_t* in, float* out, size_t n, hipStream_t s);
-void launch_f32_to_f16(const float* in, uint16_t* out, size_t n, hipStream_t s);
+// master weights <- fp16 parameters; reset_optimizer also zeroes the moments and step counts
+void launch_master_from_f16(const uint16_t* params, OptState* state, size_t n, bool reset_optimizer, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 uint16_t f32_to_f16(float f)
@@ -180,14 +180,14 @@ void Network::build_layout()
   levels_dev_.upload(grid_.levels, kMaxLevels, Runtime::get().stream);
   VNR_HIP_CHECK(hipStreamSynchronize(Runtime::get().stream));
   // training state is allocated lazily on the first training step
-  params_f32_.release(); grads_.release(); adam_m_.release(); adam_v_.release();
+  opt_state_.release(); grads_.release();
   ws_batch_ = 0;
 }
 
 void Network::initialize_params(uint64_t seed, hipStream_t s)
 {
-  params_f32_.resize(n_params_);
-  launch_init_params(params_f32_.ptr, params_f16_.ptr, n_mlp_, n_params_, in_width_, n_hidden_matmuls(), seed, s);
+  opt_state_.resize(n_params_);
+  launch_init_params(opt_state_.ptr, params_f16_.ptr, n_mlp_, n_params_, in_width_, n_hidden_matmuls(), seed, s);
   refresh_inference_weights(s);
 }
 
@@ -200,7 +200,7 @@ void Network::set_params_f16(const uint16_t* host, size_t count, hipStream_t s)
 {
   if (count != n_params_) throw std::runtime_error("parameter count mismatch: got " + std::to_string(count) + ", model has " + std::to_string(n_params_));
   VNR_HIP_CHECK(hipMemcpyAsync(params_f16_.ptr, host, count * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-  if (params_f32_.count == n_params_) launch_f16_to_f32(params_f16_.ptr, params_f32_.ptr, n_params_, s);
+  if (opt_state_.count == n_params_) launch_master_from_f16(params_f16_.ptr, opt_state_.ptr, n_params_, false, s);  // moments kept, as before
   refresh_inference_weights(s);
   VNR_HIP_CHECK(hipStreamSynchronize(s));
 }
@@ -267,8 +267,7 @@ void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipS
 
 size_t Network::bytes_allocated() const
 {
-  return params_f16_.bytes() + mlp_packed_.bytes() + params_f32_.bytes() + grads_.bytes() + adam_m_.bytes() +
-         adam_v_.bytes() + ws_features_.bytes() + ws_acts_.bytes() + ws_dfeat_.bytes() + ws_loss_.bytes();
+  return params_f16_.bytes() + mlp_packed_.bytes() + opt_state_.bytes() + grads_.bytes() + ws_features_.bytes() + ws_acts_.bytes() + ws_dfeat_.bytes() + ws_loss_.bytes();
 }
 
 }  // namespace vnr

@@ -55,7 +55,7 @@ struct Pcg32 {
 };
 
 // EXTERNAL tcnn init: MLP Xavier-uniform per weight matrix, grid uniform(-1e-4, 1e-4)
-__global__ void init_params_kernel(float* __restrict__ master, half_t* __restrict__ params, size_t n_mlp, size_t n_total,
+__global__ void init_params_kernel(OptState* __restrict__ state, half_t* __restrict__ params, size_t n_mlp, size_t n_total,
                                    uint32_t in_width, uint32_t n_hidden_matmuls, uint64_t seed)
 {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,35 +72,32 @@ __global__ void init_params_kernel(float* __restrict__ master, half_t* __restric
     else if (e < n_mlp) scale = sqrtf(6.0f / (float)(kWidth + 16));
     else scale = 1e-4f;
     const float v = u * (2.0f * scale) - scale;
-    master[e] = v;
+    state[e] = OptState{v, 0.0f, 0.0f, 0u};
     params[e] = (half_t)v;
   }
 }
 
-void launch_init_params(float* master, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
+void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
                         uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s)
 {
   const size_t threads = (n_total + 3) / 4;
-  init_params_kernel<<<div_round_up(threads, 256), 256, 0, s>>>(master, (half_t*)params, n_mlp, n_total, in_width,
+  init_params_kernel<<<div_round_up(threads, 256), 256, 0, s>>>(state, (half_t*)params, n_mlp, n_total, in_width,
                                                                 n_hidden_matmuls, seed);
   VNR_HIP_CHECK(hipGetLastError());
 }
 
-__global__ void f16_to_f32_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n)
+// master weights <- fp16 parameters (parameters loaded from a file, or training state allocated after the fact)
+__global__ void master_from_f16_kernel(const half_t* __restrict__ in, OptState* __restrict__ state, size_t n, bool reset_optimizer)
 {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (reset_optimizer) state[i] = OptState{(float)in[i], 0.0f, 0.0f, 0u};
+    else state[i].master = (float)in[i];
+  }
 }
-__global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n)
+void launch_master_from_f16(const uint16_t* params, OptState* state, size_t n, bool reset_optimizer, hipStream_t s)
 {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (half_t)in[i];
-}
-void launch_f16_to_f32(const uint16_t* in, float* out, size_t n, hipStream_t s)
-{
-  f16_to_f32_kernel<<<min(div_round_up(n, 256), 4096u), 256, 0, s>>>((const half_t*)in, out, n);
-}
-void launch_f32_to_f16(const float* in, uint16_t* out, size_t n, hipStream_t s)
-{
-  f32_to_f16_kernel<<<min(div_round_up(n, 256), 4096u), 256, 0, s>>>(in, (half_t*)out, n);
+  master_from_f16_kernel<<<min(div_round_up(n, 256), 4096u), 256, 0, s>>>((const half_t*)params, state, n, reset_optimizer);
+  VNR_HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------ loss
@@ -415,24 +412,33 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
 
 // ------------------------------------------------------------------------------------------------ Adam
 // EXTERNAL tcnn adam_step (optimizers/adam.h): see header comment.  Also clears the gradient for the next step.
-__global__ void adam_kernel(size_t n_total, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float epsilon,
-                            float l2_reg, float* __restrict__ master, half_t* __restrict__ params, float* __restrict__ grads,
-                            float* __restrict__ m1, float* __restrict__ m2, uint32_t* __restrict__ steps)
+// Measured split at C4 (70 M parameters, tools/adam_probe.py): the sweep over all gradients alone 0.15 ms, the ~10 M touched
+// parameters of a 65 536-sample batch 0.44 ms with master / m / v / step in four arrays.  Hence one 16-byte record per
+// parameter (OptState), and no zero written over a gradient that is already zero.
+__global__ void adam_kernel(size_t n_total, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float log2_beta1,
+                            float log2_beta2, float epsilon, float l2_reg, OptState* __restrict__ state, half_t* __restrict__ params,
+                            float* __restrict__ grads)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_total) return;
-  float gradient = grads[i] * grad_mul;
-  grads[i] = 0.0f;
+  const float raw = grads[i];
+  if (raw != 0.0f) grads[i] = 0.0f;
+  float gradient = raw * grad_mul;
   if (i >= n_matrix && gradient == 0.0f) return;  // untouched hash-grid entries are skipped entirely
-  const float w = master[i];
+  OptState st = state[i];
+  const float w = st.master;
   if (i < n_matrix) gradient += l2_reg * w;       // no L2 regularisation for grid parameters
-  const float m = m1[i] = beta1 * m1[i] + (1.0f - beta1) * gradient;
-  const float v = m2[i] = beta2 * m2[i] + (1.0f - beta2) * (gradient * gradient);
-  const uint32_t step = ++steps[i];
-  const float lr_t = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+  const float m = st.m = beta1 * st.m + (1.0f - beta1) * gradient;
+  const float v = st.v = beta2 * st.v + (1.0f - beta2) * (gradient * gradient);
+  const uint32_t step = ++st.step;
+  // beta^step as exp2(step * log2(beta)) on the native exponential (1 instruction instead of the ~80 of powf): almost every
+  // wave reaches this line for a few touched lanes, so the length of this path, not memory, sets the kernel's time
+  const float fs = (float)step;
+  const float lr_t = lr * sqrtf(1.0f - __builtin_amdgcn_exp2f(fs * log2_beta2)) / (1.0f - __builtin_amdgcn_exp2f(fs * log2_beta1));
   const float eff = lr_t / (sqrtf(v) + epsilon);
   const float nw = w - eff * m;
-  master[i] = nw;
+  st.master = nw;
+  state[i] = st;
   params[i] = (half_t)nw;
 }
 
@@ -444,7 +450,6 @@ struct TrainScratch {  // per-Network extra buffers that do not need to live in 
   DeviceBuffer<uint16_t> dy{MemTag::Network};
   DeviceBuffer<uint16_t> d_all{MemTag::Network};
   DeviceBuffer<uint16_t> packedT{MemTag::Network};
-  DeviceBuffer<uint32_t> steps{MemTag::Network};
   float lr = 0.0f;
   bool lr_init = false;
   uint32_t loss_blocks = 0;
@@ -479,10 +484,8 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   const uint32_t nh = n_hidden_matmuls();
   const uint32_t n = (uint32_t)batch;
   // lazily allocate the training state
-  if (params_f32_.count != n_params_) { params_f32_.resize(n_params_); launch_f16_to_f32(params_f16_.ptr, params_f32_.ptr, n_params_, s); }
+  if (opt_state_.count != n_params_) { opt_state_.resize(n_params_); launch_master_from_f16(params_f16_.ptr, opt_state_.ptr, n_params_, true, s); }
   if (grads_.count != n_params_) { grads_.resize(n_params_); grads_.zero(s); }
-  if (adam_m_.count != n_params_) { adam_m_.resize(n_params_); adam_m_.zero(s); adam_v_.resize(n_params_); adam_v_.zero(s); }
-  if (ts.steps.count != n_params_) { ts.steps.resize(n_params_); ts.steps.zero(s); }
   if (ws_batch_ != batch) {
     ws_features_.resize(batch * in_width_);
     ws_acts_.resize((size_t)(nh + 1) * batch * 64);
@@ -554,8 +557,9 @@ void Network::optimizer_step(float grad_scale, hipStream_t s)
   TrainScratch& ts = scratch_of(this);
   if (!ts.lr_init) { ts.lr = cfg_.learning_rate; ts.lr_init = true; }
   adam_kernel<<<div_round_up(n_params_, 256), 256, 0, s>>>(n_params_, n_mlp_, grad_scale / (float)kLossScale, ts.lr, cfg_.beta1,
-                                                           cfg_.beta2, cfg_.epsilon, cfg_.l2_reg, params_f32_.ptr,
-                                                           (half_t*)params_f16_.ptr, grads_.ptr, adam_m_.ptr, adam_v_.ptr, ts.steps.ptr);
+                                                           cfg_.beta2, (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2),
+                                                           cfg_.epsilon, cfg_.l2_reg, opt_state_.ptr,
+                                                           (half_t*)params_f16_.ptr, grads_.ptr);
   VNR_HIP_CHECK(hipGetLastError());
   ++steps_;
   // EXTERNAL tcnn ExponentialDecayOptimizer::step

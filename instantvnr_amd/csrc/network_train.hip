@@ -319,7 +319,7 @@ struct WGradArgs {
 constexpr int kWgChunk = 128;
 
 template <int IN_T>  // compile-time padded input width of the matrices handled by this launch (16, 32, 64, 128)
-__global__ void __launch_bounds__(256) weight_grad_kernel(const WGradArgs args, uint32_t layer_lo)
+__global__ void __launch_bounds__(256) weight_grad_kernel(const WGradArgs args, uint32_t layer_lo, uint32_t sub_chunks)
 {
   constexpr int IG = IN_T / 4;       // threads along the input dimension (4 inputs each)
   constexpr int OG = 256 / IG;       // thread groups along the output dimension
@@ -328,44 +328,52 @@ __global__ void __launch_bounds__(256) weight_grad_kernel(const WGradArgs args, 
   __shared__ __attribute__((aligned(16))) half_t sx[kWgChunk * IN_T];
   const uint32_t layer = layer_lo + blockIdx.y;
   const uint32_t n = args.n, nh = args.nh;
-  const uint32_t b0 = blockIdx.x * kWgChunk;
-  const uint32_t nb = min((uint32_t)kWgChunk, n - b0);
+  // A block owns `sub_chunks` consecutive chunks of kWgChunk samples and adds its partial sums to the gradient blob
+  // ONCE: the arithmetic here is negligible, what the kernel pays for is float atomics from every block into the same
+  // 64 rows of 256 B (heavy contention, MI355X_MICROARCH.md "Global float atomics"), so fewer, larger partial sums win.
+  const uint32_t blk0 = blockIdx.x * kWgChunk * sub_chunks;
+  if (blk0 >= n) return;
+  const uint32_t blk_end = min(n, blk0 + kWgChunk * sub_chunks);
 
   if (layer == nh + 1) {
     // last layer: dWl[0][k] = sum_b dy[b] * a_nh[b][k]
     const uint32_t k = threadIdx.x & 63u, sub = threadIdx.x >> 6;
     float acc = 0.0f;
-    for (uint32_t b = sub; b < nb; b += 4) acc += (float)args.dy[b0 + b] * (float)args.acts[((size_t)nh * n + b0 + b) * 64 + k];
+    for (uint32_t b = blk0 + sub; b < blk_end; b += 4) acc += (float)args.dy[b] * (float)args.acts[((size_t)nh * n + b) * 64 + k];
     atomicAdd(&args.grads[(size_t)kWidth * args.in_width + (size_t)nh * 4096 + k], acc);
     return;
   }
   const uint32_t in_w = layer == 0 ? args.in_width : 64u;
-  const half_t* dsrc = args.d_all + ((size_t)layer * n + b0) * 64;
-  const half_t* xsrc = layer == 0 ? args.features + (size_t)b0 * args.in_width : args.acts + ((size_t)(layer - 1) * n + b0) * 64;
-  // stage the chunk (row-major, zero padded to IN_T columns)
-  for (uint32_t e = threadIdx.x; e < nb * 8; e += 256) ((uint4_t*)sd)[e] = ((const uint4_t*)dsrc)[e];
-  for (uint32_t e = threadIdx.x; e < nb * (IN_T / 8); e += 256) {
-    const uint32_t b = e / (IN_T / 8), c = e % (IN_T / 8);
-    uint4_t v = {0, 0, 0, 0};
-    if (c * 8 < in_w) v = *(const uint4_t*)(xsrc + (size_t)b * in_w + c * 8);
-    ((uint4_t*)sx)[e] = v;
-  }
-  __syncthreads();
   const uint32_t ig = threadIdx.x % IG, og = threadIdx.x / IG;
   float acc[R][4];
 #pragma unroll
   for (int rr = 0; rr < R; ++rr)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[rr][c] = 0.0f;
-  for (uint32_t b = 0; b < nb; ++b) {
-    const half4_t xv = *(const half4_t*)(sx + b * IN_T + ig * 4);
-    half_t dv[R];
+  for (uint32_t b0 = blk0; b0 < blk_end; b0 += kWgChunk) {
+    const uint32_t nb = min((uint32_t)kWgChunk, blk_end - b0);
+    const half_t* dsrc = args.d_all + ((size_t)layer * n + b0) * 64;
+    const half_t* xsrc = layer == 0 ? args.features + (size_t)b0 * args.in_width : args.acts + ((size_t)(layer - 1) * n + b0) * 64;
+    if (b0 != blk0) __syncthreads();  // the previous chunk has been consumed
+    // stage the chunk (row-major, zero padded to IN_T columns)
+    for (uint32_t e = threadIdx.x; e < nb * 8; e += 256) ((uint4_t*)sd)[e] = ((const uint4_t*)dsrc)[e];
+    for (uint32_t e = threadIdx.x; e < nb * (IN_T / 8); e += 256) {
+      const uint32_t b = e / (IN_T / 8), c = e % (IN_T / 8);
+      uint4_t v = {0, 0, 0, 0};
+      if (c * 8 < in_w) v = *(const uint4_t*)(xsrc + (size_t)b * in_w + c * 8);
+      ((uint4_t*)sx)[e] = v;
+    }
+    __syncthreads();
+    for (uint32_t b = 0; b < nb; ++b) {
+      const half4_t xv = *(const half4_t*)(sx + b * IN_T + ig * 4);
+      half_t dv[R];
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) dv[rr] = sd[b * 64 + og * R + rr];
+      for (int rr = 0; rr < R; ++rr) dv[rr] = sd[b * 64 + og * R + rr];
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr)
+      for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[rr][c] = __builtin_fmaf((float)dv[rr], (float)xv[c], acc[rr][c]);
+        for (int c = 0; c < 4; ++c) acc[rr][c] = __builtin_fmaf((float)dv[rr], (float)xv[c], acc[rr][c]);
+    }
   }
   float* g = args.grads + (layer == 0 ? 0 : (size_t)kWidth * args.in_width + (size_t)(layer - 1) * 4096);
 #pragma unroll
@@ -529,13 +537,24 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   wa.features = (const half_t*)ws_features_.ptr; wa.acts = (const half_t*)ws_acts_.ptr; wa.d_all = (const half_t*)ts.d_all.ptr;
   wa.dy = (const half_t*)ts.dy.ptr; wa.grads = grads_.ptr; wa.n = n; wa.nh = nh; wa.in_width = in_width_;
   {
-    const dim3 g1(div_round_up(batch, kWgChunk), 1);
-    if (in_width_ <= 16) weight_grad_kernel<16><<<g1, 256, 0, s>>>(wa, 0);
-    else if (in_width_ <= 32) weight_grad_kernel<32><<<g1, 256, 0, s>>>(wa, 0);
-    else if (in_width_ <= 64) weight_grad_kernel<64><<<g1, 256, 0, s>>>(wa, 0);
-    else weight_grad_kernel<128><<<g1, 256, 0, s>>>(wa, 0);
-    const dim3 g2(div_round_up(batch, kWgChunk), nh + 1);  // hidden layers 1..nh and the last layer nh+1
-    weight_grad_kernel<64><<<g2, 256, 0, s>>>(wa, 1);
+    // Chunks of kWgChunk samples a block sums before its atomics.  Measured at batch 65 536 (both launches together):
+    // 1 chunk (512 blocks per matrix) 0.209 ms, 2: 0.128, 4 (128 blocks): 0.102, 8: 0.119, 16: 0.207, 32: 0.407 --
+    // contention on the 64 gradient rows falls with the block count until too few blocks are left to fill the GPU.
+    // Default: about 128 blocks per matrix.  VNR_AMD_WGRAD_SUBCHUNKS (1..64) overrides, for diagnostics.
+    static const int forced = [] {
+      const char* e = std::getenv("VNR_AMD_WGRAD_SUBCHUNKS");
+      const int v = e ? std::atoi(e) : 0;
+      return v >= 1 && v <= 64 ? v : 0;
+    }();
+    const uint32_t sub_chunks = forced ? (uint32_t)forced : std::min<uint32_t>(8u, std::max<uint32_t>(1u, (uint32_t)(batch / (128u * kWgChunk))));
+    const uint32_t nblk = div_round_up(batch, (uint64_t)kWgChunk * sub_chunks);
+    const dim3 g1(nblk, 1);
+    if (in_width_ <= 16) weight_grad_kernel<16><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
+    else if (in_width_ <= 32) weight_grad_kernel<32><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
+    else if (in_width_ <= 64) weight_grad_kernel<64><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
+    else weight_grad_kernel<128><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
+    const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
+    weight_grad_kernel<64><<<g2, 256, 0, s>>>(wa, 1, sub_chunks);
   }
   // 5. hash-grid backward
   {

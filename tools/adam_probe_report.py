@@ -14,3 +14,7 @@ print("normal step (65 536 samples): mean %.4f ms  min %.4f  max %.4f" % (st.mea
 print("near-empty batch (sweep only): mean %.4f ms  min %.4f  max %.4f" % (st.mean(b), min(b), max(b)))
 gb = dur("grid_backward")[20:]
 print("grid_backward normal / tiny : mean %.4f / %.4f ms" % (st.mean(gb[0::2]), st.mean(gb[1::2])))
+for name in ("weight_grad_kernel<64>", "weight_grad_kernel<32>", "weight_grad_kernel<16>"):
+    d = dur(name)[20:]
+    if d:
+        print("%-24s normal / tiny : mean %.4f / %.4f ms" % (name, st.mean(d[0::2]), st.mean(d[1::2])))

@@ -139,13 +139,24 @@ def test_unsupported_modes_fail_loudly(scene):
         api.vnrRender(r)
 
 
-def test_neural_streaming_matches_oracle(oracle, scene):
+NEURAL_FRAME_MODELS = [
+    # (L, F, log2T, base, per_level_scale, hidden layers): each takes a different gather path of the fused kernel's queue mode
+    (8, 4, 14, 4, None, 2),        # F = 4: paired 16-byte corner loads
+    (8, 8, 19, 16, None, 2),       # BASELINE C2 model shape, F = 8: one 16-byte load per corner, 64-wide first layer
+    (16, 2, 19, 16, 1.3195, 3),    # BASELINE C4 model shape (T = 2^19), F = 2: paired 8-byte loads, 3 hidden layers
+]
+
+
+@pytest.mark.parametrize("model", NEURAL_FRAME_MODELS)
+def test_neural_streaming_matches_oracle(oracle, scene, model):
     """mode 5 on a neural volume with random (seeded) parameters and the ground-truth macrocell"""
-    cfg = syn.model_config(n_levels=8, n_features=4, log2_hashmap_size=14, base_resolution=4, n_hidden_layers=2)
+    L, F, log2T, base, pls, H = model
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base, n_hidden_layers=H,
+                           per_level_scale=pls)
     nv = api.vnrCreateNeuralVolume(cfg, scene["sv"], online_macrocell_construction=False)
     info = api.neural_info(nv)
-    ocfg = oracle.grid_config(8, 4, 14, 4)
-    n_mlp = oracle.mlp_n_params(info["padded_width"], 64, 1)
+    ocfg = oracle.grid_config(L, F, log2T, base, 2.0 if pls is None else pls)
+    n_mlp = oracle.mlp_n_params(info["padded_width"], 64, H - 1)
     params = syn.random_params(info["n_params"], n_mlp, seed=21)
     # bias the network output into the TFN's visible range
     api.neural_set_params_fp16(nv, params)
@@ -155,7 +166,7 @@ def test_neural_streaming_matches_oracle(oracle, scene):
     st = api.vnrRendererGetFrameStats(r)
     mo = api.volume_macrocell(scene["sv"])["max_opacity"]
     sc = oracle_scene(oracle, scene, mo, size=(64, 56))
-    want, _, ost = oracle.render_streaming(sc, lambda c: oracle.network_inference(ocfg, 64, 2, params.view(np.uint16), c))
+    want, _, ost = oracle.render_streaming(sc, lambda c: oracle.network_inference(ocfg, 64, H, params.view(np.uint16), c))
     assert st["n_rays_hit"] == ost["n_rays_hit"]
     assert img[..., 3].max() > 0.05
     # stated tolerance: network outputs differ by <= 2^-8, which the TFN + compositing can amplify slightly
@@ -208,3 +219,62 @@ def test_interleaved_shares_assemble_to_the_unsharded_frame(scene, world, kind):
         shares.append(vdist.pack_share(frame, block, world, part, n_pixels))
     full = vdist.assemble_shares(torch.stack(shares), block, world, n_pixels).numpy()
     assert np.array_equal(full, want)
+
+
+def test_non_cubic_ragged_volume_matches_oracle(oracle):
+    """50 x 37 x 21 voxels (x fastest): not a cube and not a multiple of the 16-voxel macrocell in any axis, so an x/y/z
+    mix-up or a ragged-edge error anywhere (sampling, macrocell kernels, object->world transform, DDA bounds, camera) shows.
+    Same bars as the cubic tests: sampling and macrocells bit-exact, frames within 2e-4 (device powf vs glibc)."""
+    nx, ny, nz = 50, 37, 21
+    z, y, x = np.meshgrid(np.linspace(0, 1, nz), np.linspace(0, 1, ny), np.linspace(0, 1, nx), indexing="ij")
+    vol = (0.5 + 0.5 * np.sin(5.0 * x + 1.0) * np.cos(3.0 * y) * np.sin(2.0 * z + 0.5)).astype(np.float32)   # asymmetric in x, y, z
+    vol[:, :, :6] *= 0.1                                                                                    # an empty-ish slab on one x side only
+    dims = (nx, ny, nz)
+    assert vol.min() > 0.0 and vol.max() < 1.0           # so the load-time normalisation is NOT the identity (it is for analytic_volume)
+    sv = api.vnrCreateSimpleVolume(vol)                  # the library gets the RAW data and normalises it itself
+    # restatement of the reference's load-time normalisation, convert_volume (neural_sampler.cpp:176-210):
+    # clamp((v - vmin) / (vmax - vmin), 0, 1) in fp32 with a true division; the oracle samples this array
+    lo, hi = np.float32(vol.min()), np.float32(vol.max())
+    vol = np.clip((vol - lo) / (hi - lo), np.float32(0), np.float32(1)).astype(np.float32)
+    assert api.vnrVolumeGetValueRange(sv) == (0.0, 1.0)
+    rng = np.random.default_rng(3)
+    c = rng.uniform(-0.05, 1.05, (4000, 3)).astype(np.float32)
+    for nodal in (False, True):
+        assert np.array_equal(api.simple_volume_sample(sv, c, nodal), oracle.sample_volume(vol, c, nodal))
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    otfn = oracle.TfnHolder(colors, alphas)
+    cam = syn.oblique_camera(dims, distance_scale=1.2)
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    size = (88, 72)
+    images = {}
+    for mode in (5, 4):
+        r = api.vnrCreateRenderer(sv)
+        api.vnrRendererSetTransferFunction(r, tfn)
+        api.vnrRendererSetCamera(r, camera)
+        api.vnrRendererSetFramebufferSize(r, size)
+        api.vnrRendererSetMode(r, mode)
+        api.vnrRender(r)
+        images[mode] = api.vnrRendererMapFrame(r).copy()
+        if mode == 5:
+            st = api.vnrRendererGetFrameStats(r)
+    mc = api.volume_macrocell(sv)
+    assert mc["dims"] == (4, 3, 2)                       # ceil(50/16), ceil(37/16), ceil(21/16)
+    vr = oracle.macrocell_compute_implicit(vol)
+    assert np.array_equal(mc["value_range"], vr)
+    mo = oracle.macrocell_max_opacity(otfn, vr)
+    assert np.array_equal(mc["max_opacity"], mo)
+    sc = oracle.SceneHolder(size[0], size[1], dims, otfn, mo, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    want5, _, ost = oracle.render_streaming(sc, lambda q: oracle.sample_volume(vol, q, nodal=True))
+    want4, _ = oracle.render_monolithic(sc, vol)
+    assert st["n_rays_hit"] == ost["n_rays_hit"] > 500 and st["n_iterations"] == ost["n_iterations"]
+    assert (want5[..., 3] > 0).mean() > 0.1
+    assert np.abs(images[5] - want5).max() < 2e-4, np.abs(images[5] - want5).max()
+    assert np.abs(images[4] - want4).max() < 2e-4, np.abs(images[4] - want4).max()
+    # the left/right asymmetry of the volume is visible, so a mirrored axis could not pass by symmetry
+    a = want5[..., 3]
+    assert abs(a[:, : size[0] // 2].mean() - a[:, size[0] // 2:].mean()) > 0.01

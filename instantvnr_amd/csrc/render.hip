@@ -59,7 +59,19 @@ struct RenderParams {
   const float* mc_max_opacity;
   DeviceTfn tfn;
   int n_iters;
+  // gradient shading (rendering modes 7 / 8)
+  affine3f otw;          // object -> world (params.transform)
+  vec3f grad_step;       // 1 / dims (object.cpp:305)
+  vec3f light_dir;       // LaunchParams::light_directional_dir after the flip of renderer.cpp:98-101
+  uint32_t slot_cap;     // sample slots of this half's result arena (value/dt pairs first, then the gradient samples)
+  uint32_t shading_mode; // 0 NO_SHADING, 1 GRADIENT_SHADING (the streaming kernels are templated on it; the monolithic one branches)
 };
+
+// Result arena of one half and one parity, in floats: [slot_cap][2] = {value, t1 - t0} per ray-major sample slot, then (gradient
+// shading only) [slot_cap][4] = {f(c + gx), f(c + gy), f(c + gz), unused}.  A queue record's 4th word is the absolute float
+// index its result goes to, so the inference kernel and the ground-truth sampler need not know about shading modes.
+__device__ __forceinline__ uint32_t arena_value_index(uint32_t slot) { return 2u * slot; }
+__device__ __forceinline__ uint32_t arena_grad_index(uint32_t slot_cap, uint32_t slot) { return 2u * slot_cap + 4u * slot; }
 
 constexpr int kDepthBins = 64;
 
@@ -139,6 +151,56 @@ __device__ __forceinline__ void write_pixel(const RenderParams& p, vec4f rgba, u
   p.accumulation[pixel] = rgba;
   const float f = (float)p.frame_index;
   p.frame[pixel] = {rgba.x / f, rgba.y / f, rgba.z / f, rgba.w / f};
+}
+
+// ------------------------------------------------------------------------------------------------ gradient shading (modes 7 / 8)
+// shade_simple_light (raytracing.h:214-222)
+__device__ __forceinline__ vec3f shade_simple_light(vec3f ray_dir, vec3f normal, vec3f albedo)
+{
+  if (dot(normal, normal) > 1.0e-6f) {
+    const vec3f n = normalize(normal);
+    const float c = 0.2f + 0.8f * fabsf(-dot(ray_dir, n));
+    return c * albedo;
+  }
+  return {0, 0, 0};
+}
+
+// shade_scivis_light (raytracing.h:224-246) with mat_gradient_shading {.6, .9, .4, 40} and light_directional_rgb = 1
+// (instantvnr_types.h:142,147); the reference's light_ambient argument is unused there.  World-space vectors.
+__device__ __forceinline__ vec3f shade_scivis_light(vec3f ray_dir, vec3f normal, vec3f albedo, vec3f light_dir)
+{
+  const float m_ambient = 0.6f, m_diffuse = 0.9f, m_specular = 0.4f, m_shininess = 40.0f;
+  vec3f color = {0, 0, 0};
+  if (dot(normal, normal) > 1.0e-6f) {
+    const vec3f L = normalize(light_dir);
+    const vec3f N = normalize(normal);
+    const vec3f V = {-ray_dir.x, -ray_dir.y, -ray_dir.z};
+    color = color + m_ambient * albedo;
+    const float cosNL = fmaxf(dot(N, L), 0.0f);
+    if (cosNL > 0.0f) {
+      color = color + (m_diffuse * cosNL) * albedo;
+      const vec3f H = normalize(L + V);
+      const float cosNH = fmaxf(dot(N, H), 0.0f);
+      const float sp = m_specular * powf(cosNH, m_shininess);
+      color = color + vec3f{sp, sp, sp};
+    }
+  }
+  const vec3f shading2 = shade_simple_light(ray_dir, normal, albedo);
+  return 0.5f * shading2 + 0.5f * color;  // lerp(0.5, shading2, color)
+}
+
+// One shaded sample (method_raymarching.cu:773-788 / :440-454): object-space normal from forward differences divided by
+// `step`, to world space with xfmNormal (EXTERNAL gdt: transposed inverse of the linear part = rows of wto's columns),
+// shaded, then lerp(scivis_shading_scale = 0.95, albedo, shaded) (instantvnr_types.h:140).
+__device__ __forceinline__ vec3f gradient_shade(const RenderParams& p, vec3f ray_dir_obj, float f, float fgx, float fgy, float fgz,
+                                                vec3f step, vec3f albedo)
+{
+  const vec3f No = {-((fgx - f) / step.x), -((fgy - f) / step.y), -((fgz - f) / step.z)};
+  const vec3f Nw = {dot(p.wto.vx, No), dot(p.wto.vy, No), dot(p.wto.vz, No)};
+  const vec3f dir_w = xfm_vector(p.otw, ray_dir_obj);
+  const vec3f shaded = shade_scivis_light(dir_w, Nw, albedo, p.light_dir);
+  const float k = 0.95f;
+  return (1.0f - k) * albedo + k * shaded;
 }
 
 // ------------------------------------------------------------------------------------------------ DDA (dda.h)
@@ -236,7 +298,10 @@ __device__ __forceinline__ void iter_exec(const RenderParams& p, DDAState& it, v
 //    frustum, i.e. a compact brick of the volume, whatever the per-ray sample index is.  The fused inference kernel
 //    reads coords in this order (coherent hash-grid gathers: measured ~2x faster than ray-major order once rays have
 //    drifted apart in depth) and scatters its result to values[dest[i]].
-template <bool FIRST>
+// GRAD (gradient shading, rendering mode 8): every sample puts FOUR records into the queue, itself and three forward
+// offsets of grad_step (method_raymarching.cu:719-726), and compose shades with the resulting normal (:773-788).
+// vd_in / vd_out are the result arenas of the previous / this iteration (layout above RenderParams' helpers).
+template <bool FIRST, bool GRAD>
 __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const RayList cur, const RayList nxt,
                                                     const vec2f* __restrict__ vd_in, vec4f* __restrict__ queue,
                                                     vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters, int parity)
@@ -305,6 +370,10 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
           if (p.debug_flags & 2u) { rgb = {0.5f, 0.5f, 0.5f}; a = vd.x * 0.01f; } else
           tfn_sample(tfn, vd.x, rgb, a);
           a = opacity_correction(p.step_rcp, vd.y, a);
+          if (GRAD) {  // f(c + gx), f(c + gy), f(c + gz) of this sample, written by the evaluation kernel
+            const vec4f fg = *(const vec4f*)((const float*)vd_in + arena_grad_index(p.slot_cap, sb + k));
+            rgb = gradient_shade(p, dir, vd.x, fg.x, fg.y, fg.z, p.grad_step, rgb);
+          }
           const float tr = 1.0f - alpha;
           alpha += tr * a;
           color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a;
@@ -343,7 +412,9 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     if (lane == 0) {
       if (wave_rays) {
         ray_base = atomicAdd(n_rays_out, wave_rays);
-        smp_base = atomicAdd(n_samples_out, wave_samples);
+        // the queue counter counts RECORDS (what the evaluation kernel reads); with 4 records per sample every claim is a
+        // multiple of 4, so claim / 4 is a unique sample-slot base
+        smp_base = GRAD ? atomicAdd(n_samples_out, 4u * wave_samples) >> 2 : atomicAdd(n_samples_out, wave_samples);
         atomicAdd((unsigned long long*)(counters + C_STAT_SAMPLES), (unsigned long long)wave_samples);
       }
       if (alive_mask) atomicAdd((unsigned long long*)(counters + C_STAT_REFRAYS), (unsigned long long)__popcll(alive_mask));
@@ -400,7 +471,17 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         const vec3f c = org + t * dir;
         const uint32_t br = s_br[j * 256u + tid];
         const uint32_t g = hist[br >> 16] + (br & 0xffffu);  // gather-order slot
-        queue[g] = {c.x, c.y, c.z, __uint_as_float(sb + j)};  // one 16-byte record per sample
+        // one 16-byte record per evaluation: position + the float index of the result arena its value goes to
+        if (GRAD) {
+          const uint32_t gi = arena_grad_index(p.slot_cap, sb + j);
+          vec4f* q = queue + 4u * (size_t)g;  // the four records of a sample stay adjacent: they fall into the same grid cells
+          q[0] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + j))};
+          q[1] = {c.x + p.grad_step.x, c.y, c.z, __uint_as_float(gi + 0u)};
+          q[2] = {c.x, c.y + p.grad_step.y, c.z, __uint_as_float(gi + 1u)};
+          q[3] = {c.x, c.y, c.z + p.grad_step.z, __uint_as_float(gi + 2u)};
+        } else {
+          queue[g] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + j))};
+        }
         vd_out[sb + j].y = t1 - t0;
       }
     }
@@ -410,12 +491,12 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
 
 // iterative_sampling_groundtruth_kernel (method_raymarching.cu:902-915) over the compacted sample queue
 __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float* __restrict__ vol, vec3i dims,
-                                 const vec4f* __restrict__ queue, vec2f* __restrict__ vd)
+                                 const vec4f* __restrict__ queue, float* __restrict__ arena)
 {
-  const uint32_t n = *n_ptr;
+  const uint32_t n = *n_ptr;  // records (4 per sample with gradient shading)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const vec4f r = queue[i];
-    vd[__float_as_uint(r.w)].x = sample_volume_nodal(vol, dims, r.x, r.y, r.z);
+    arena[__float_as_uint(r.w)] = sample_volume_nodal(vol, dims, r.x, r.y, r.z);
   }
 }
 
@@ -460,6 +541,16 @@ __global__ void monolithic_kernel(const RenderParams p)
         vec3f rgb; float a;
         tfn_sample(p.tfn, v, rgb, a);
         a = opacity_correction(p.step_rcp, ty - tx, a);
+        if (p.shading_mode == 1u) {  // mode 7, :440-454 with sampleGradient (raytracing.h:112-126): a step leaving [0,1] is flipped
+          vec3f stp = p.grad_step;
+          if (c.x + stp.x > 1.0f - FLT_EPSILON) stp.x *= -1.0f;
+          if (c.y + stp.y > 1.0f - FLT_EPSILON) stp.y *= -1.0f;
+          if (c.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
+          const float fgx = sample_volume_nodal(p.volume, p.vol_dims, c.x + stp.x, c.y, c.z);
+          const float fgy = sample_volume_nodal(p.volume, p.vol_dims, c.x, c.y + stp.y, c.z);
+          const float fgz = sample_volume_nodal(p.volume, p.vol_dims, c.x, c.y, c.z + stp.z);
+          rgb = gradient_shade(p, dir, v, fgx, fgy, fgz, stp, rgb);
+        }
         const float tr = 1.0f - alpha;
         color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a;
         alpha += tr * a;
@@ -541,18 +632,21 @@ void Renderer::set_transfer_function(const TransferFunctionData& t)
   reset_ = true;
 }
 
-void Renderer::ensure_queues(size_t n_pixels, int n_iters)
+void Renderer::ensure_queues(size_t n_pixels, int n_iters, bool gradient)
 {
-  if (queue_pixels_ >= n_pixels && queue_iters_ >= n_iters) return;
+  if (queue_pixels_ >= n_pixels && queue_iters_ >= n_iters && (queue_grad_ || !gradient)) return;
   VNR_HIP_CHECK(hipStreamSynchronize(stream_));
-  const size_t P = n_pixels;
+  const size_t P = std::max(n_pixels, queue_pixels_);
+  const int iters = std::max(n_iters, queue_iters_);
+  const bool grad = gradient || queue_grad_;
   q_u32_.resize(6 * P);
   q_f32_.resize(18 * P);
   q_i32_.resize(6 * P);
-  queue_.resize(P * n_iters);
-  vd_.resize(2 * P * n_iters);
+  queue_.resize(P * iters * (grad ? 4 : 1));          // 4 records per sample with gradient shading
+  arena_.resize(2 * P * iters * (grad ? 6 : 2));      // x2 parities; 2 (+4) result floats per sample slot
   queue_pixels_ = P;
-  queue_iters_ = n_iters;
+  queue_iters_ = iters;
+  queue_grad_ = grad;
 }
 
 void Renderer::render()
@@ -597,6 +691,13 @@ void Renderer::render()
   p.tfn = tfn_.view();
   p.tfn_in_lds = ((size_t)p.tfn.n_colors * sizeof(vec4f) + (size_t)p.tfn.n_alphas * sizeof(float)) <= 24 * 1024 ? 1u : 0u;
   p.n_iters = n_iters_;
+  // gradient shading (modes 7 / 8)
+  p.otw = volume_->transform;
+  p.grad_step = {1.0f / (float)p.vol_dims.x, 1.0f / (float)p.vol_dims.y, 1.0f / (float)p.vol_dims.z};  // object.cpp:305
+  if (dot(p.cam_dir, light_dir_) > 0.0f) light_dir_ = -1.0f * light_dir_;  // renderer.cpp:98-101: flipped in place, every frame
+  p.light_dir = light_dir_;
+  p.shading_mode = (mode_ == 7 || mode_ == 8) ? 1u : 0u;
+  p.slot_cap = 0;
   // frame index / accumulation, renderer.cpp:103-105
   if (reset_) frame_index_ = 0;
   ++frame_index_;
@@ -607,12 +708,19 @@ void Renderer::render()
 
   if (p.pixel_hi > p.pixel_lo && p.n_local > 0) {
     switch (mode_) {
-    case 5: render_streaming(p); break;
-    case 4:
-      if (volume_->is_network()) throw std::runtime_error("rendering mode 4 (decoding) on a neural volume is not implemented in this build");
+    case 5:   // VNR_RAYMARCHING_NO_SHADING_SAMPLE_STREAMING
+    case 8:   // VNR_RAYMARCHING_GRADIENT_SHADING_SAMPLE_STREAMING
+      render_streaming(p);
+      break;
+    case 4:   // VNR_RAYMARCHING_NO_SHADING_DECODING
+    case 7:   // VNR_RAYMARCHING_GRADIENT_SHADING_DECODING
+      if (volume_->is_network())
+        throw std::runtime_error("rendering mode " + std::to_string(mode_) + " (decoding) on a neural volume is not implemented in this build");
       render_monolithic(p);
       break;
-    default: throw std::runtime_error("rendering mode " + std::to_string(mode_) + " is not implemented in this build (supported: 4 on simple volumes, 5)");
+    default:
+      throw std::runtime_error("rendering mode " + std::to_string(mode_) +
+                               " is not implemented in this build (supported: 4 and 7 on simple volumes, 5 and 8)");
     }
   }
   reset_ = false;
@@ -639,8 +747,13 @@ void Renderer::render_streaming(const RenderParams& p_all)
   const uint32_t R = p_all.n_local / row_items;  // local tile rows
   const int H = (n_halves_ == 2 && R >= 2) ? 2 : 1;
   const uint32_t P_total = p_all.n_local;
-  ensure_queues(P_total, p_all.n_iters);
+  const bool grad = p_all.shading_mode == 1u;
+  ensure_queues(P_total, p_all.n_iters, grad);
   const size_t QP = queue_pixels_;
+  const size_t QI = (size_t)queue_iters_;
+  const size_t slot_floats = queue_grad_ ? 6 : 2;   // result floats per sample slot as ALLOCATED (a slice is laid out per mode)
+  const size_t rec_per_slot = queue_grad_ ? 4 : 1;
+  if ((size_t)P_total * QI * 6 >= (1ull << 32)) throw std::runtime_error("frame share too large for 32-bit result indices");
   NeuralVolume* nv = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get()) : nullptr;
   if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
 
@@ -676,13 +789,15 @@ void Renderer::render_streaming(const RenderParams& p_all)
       hf.rl[b].t_next = (vec3f*)(f + 5 * QP) + off;
       hf.rl[b].next_cell_begin = f + 8 * QP + off;
       hf.rl[b].cell = (vec3i*)(q_i32_.ptr + (size_t)b * 3 * QP) + off;
-      hf.vd[b] = vd_.ptr + (size_t)b * QP * queue_iters_ + off * queue_iters_;
+      // this half's result arena of parity b: a slice of slot_floats * n_local * QI floats
+      hf.vd[b] = (vec2f*)(arena_.ptr + (size_t)b * slot_floats * QP * QI + slot_floats * off * QI);
     }
-    hf.queue = queue_.ptr + off * queue_iters_;
+    hf.p.slot_cap = (uint32_t)((size_t)hf.p.n_local * QI);   // 2 (+ 4 with gradient shading) floats per slot fit the slice
+    hf.queue = queue_.ptr + rec_per_slot * off * QI;
     hf.c = counters_.ptr + (size_t)h * C_COUNT;
     hf.hc = host_counts_ + (size_t)h * 256;
     hf.s = h == 0 ? stream_ : stream2_;
-    hf.s_max = (size_t)hf.p.n_local * hf.p.n_iters;
+    hf.s_max = (size_t)hf.p.n_local * hf.p.n_iters * (grad ? 4 : 1);   // records the evaluation kernel may see
     off += hf.p.n_local;
   }
 
@@ -696,8 +811,10 @@ void Renderer::render_streaming(const RenderParams& p_all)
   if (shmem_compose > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
   static bool lds_attr_set = false;
   if (!lds_attr_set) {  // more than the default 64 KiB of dynamic LDS needs an opt-in
-    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     lds_attr_set = true;
   }
   uint32_t max_iterations = 240;
@@ -718,20 +835,25 @@ void Renderer::render_streaming(const RenderParams& p_all)
     // march(it): reads ray list `parity`, writes list `parity^1` and sample queue `parity`
     if (it == 0) {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 4096u);
-      march_kernel<true><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, 0);
+      if (grad) march_kernel<true, true><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, 0);
+      else march_kernel<true, false><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, 0);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
-      march_kernel<false><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[parity], hf.rl[parity ^ 1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, parity);
+      if (grad)
+        march_kernel<false, true><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[parity], hf.rl[parity ^ 1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, parity);
+      else
+        march_kernel<false, false><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[parity], hf.rl[parity ^ 1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, parity);
     }
     VNR_HIP_CHECK(hipGetLastError());
     uint32_t* clear0 = c + C_RAYS0 + parity;            // output ray list of march(it+1)
     uint32_t* clear1 = c + C_SAMPLES0 + (parity ^ 1);   // sample counter of march(it+1)
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it], hf.s));
     if (nv) {
-      nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 2, c + C_SAMPLES0 + parity, hf.s_max, hf.s);
+      // a record's 4th word is the float index of its result in this arena (stride 1)
+      nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 1, c + C_SAMPLES0 + parity, hf.s_max, hf.s);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(hf.s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
-      gt_sample_kernel<<<blocks, 256, 0, hf.s>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, hf.vd[parity]);
+      gt_sample_kernel<<<blocks, 256, 0, hf.s>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, (float*)hf.vd[parity]);
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
     clear_two_kernel<<<1, 1, 0, hf.s>>>(clear0, clear1);

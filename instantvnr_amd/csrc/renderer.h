@@ -57,7 +57,7 @@ public:
 private:
   void render_streaming(const RenderParams& p);
   void render_monolithic(const RenderParams& p);
-  void ensure_queues(size_t n_pixels, int n_iters);
+  void ensure_queues(size_t n_pixels, int n_iters, bool gradient);
 
   std::shared_ptr<VolumeBase> volume_;
   CameraData camera_;
@@ -70,6 +70,9 @@ private:
   bool reset_ = true, skip_download_ = false, profiling_ = false;
   int frame_index_ = 0;
   int n_iters_ = 16;  // VNR_RM_N_ITERS (method_raymarching.cu:30-40)
+  // LaunchParams::light_directional_dir (instantvnr_types.h:148): a member the reference negates IN PLACE whenever it points
+  // along the view direction (renderer.cpp:98-101), so it persists across frames
+  vec3f light_dir_ = {0.7f, 0.9f, 0.4f};
   int n_halves_ = 2;  // streaming mode: rays dealt to 2 halves on 2 streams (march of one overlaps inference of the other)
   uint32_t predicted_iterations_[2] = {0, 0};
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
@@ -86,7 +89,8 @@ private:
   DeviceBuffer<float> q_f32_;      // jitter[2], alpha[2], color[2][3], t_next[2][3], next_cell_begin[2]
   DeviceBuffer<int> q_i32_;        // cell[2][3]
   DeviceBuffer<vec4f> queue_;      // gather-order sample records {x, y, z, ray-major slot}
-  DeviceBuffer<vec2f> vd_;         // ray-major {value, t1 - t0} per sample, x2 (ping-pong)
+  DeviceBuffer<float> arena_;      // evaluation results, x2 (ping-pong): per slot {value, t1 - t0}, then (gradient shading) 4 more floats
+  bool queue_grad_ = false;        // queues currently sized for 4 records / 6 result floats per sample
   DeviceBuffer<uint32_t> counters_;  // 2 x C_COUNT: one block per half
   uint32_t* host_counts_ = nullptr;  // pinned rings of alive-ray counts, 2 x 256
   size_t queue_pixels_ = 0;

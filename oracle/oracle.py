@@ -48,7 +48,8 @@ class Scene(C.Structure):
                 ("sampling_rate", C.c_float),
                 ("mc_dims", C.c_int * 3), ("mc_spacings", C.c_float * 3),
                 ("mc_max_opacity", C.POINTER(C.c_float)),
-                ("tfn", Tfn), ("pixel_lo", C.c_uint32), ("pixel_hi", C.c_uint32)]
+                ("tfn", Tfn), ("pixel_lo", C.c_uint32), ("pixel_hi", C.c_uint32),
+                ("shading_mode", C.c_int), ("light_dir", C.c_float * 3)]
 
 
 class RenderStats(C.Structure):
@@ -277,7 +278,10 @@ def default_transform(dims):
 class SceneHolder:
     def __init__(self, width, height, vol_dims, tfn, mc_max_opacity, cam_from, cam_at=(0, 0, 0), cam_up=(0, 1, 0),
                  fovy=60.0, frame_index=1, sampling_rate=1.0, bbox=((0, 0, 0), (1, 1, 1)), xfm=None,
-                 pixel_range=None):
+                 pixel_range=None, shading_mode=0, light_dir=None):
+        """shading_mode: 0 NO_SHADING (rendering modes 4 / 5), 1 GRADIENT_SHADING (modes 7 / 8).
+        light_dir: LaunchParams::light_directional_dir; default = the reference's (0.7, 0.9, 0.4) after the flip of
+        renderer.cpp:98-101 (negated when it points along the view direction)."""
         self.tfn = tfn
         self.mc = np.ascontiguousarray(mc_max_opacity, dtype=np.float32)
         mc_dims, mc_sp = macrocell_shape(vol_dims)
@@ -300,7 +304,29 @@ class SceneHolder:
         s.tfn = tfn.c
         pr = pixel_range or (0, width * height)
         s.pixel_lo, s.pixel_hi = pr
+        s.shading_mode = int(shading_mode)
+        s.light_dir[:] = [float(v) for v in (flipped_light_dir(cam_from, cam_at) if light_dir is None else light_dir)]
         self.c = s
+
+
+DEFAULT_LIGHT_DIR = (0.7, 0.9, 0.4)   # LaunchParams::light_directional_dir, core/instantvnr_types.h:148
+
+
+def flipped_light_dir(cam_from, cam_at, light_dir=DEFAULT_LIGHT_DIR):
+    """renderer.cpp:98-101: `if (dot(camera.direction, light_dir) > 0) light_dir *= -1` (fp32).  The reference flips the
+    stored member in place every frame; starting from the default that is this stateless rule except when the dot
+    product is exactly zero."""
+    d = _f32(cam_at) - _f32(cam_from)
+    d = d / np.float32(np.sqrt(np.float32((d * d).sum(dtype=np.float32))))
+    L = _f32(light_dir)
+    return tuple(float(v) for v in (-L if np.float32((d * L).sum(dtype=np.float32)) > 0 else L))
+
+
+def shade_scivis_light(ray_dir, normal, albedo, light_dir):
+    out = (C.c_float * 3)()
+    f = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    lib().vnro_shade_scivis_light(f(ray_dir), f(normal), f(albedo), f(light_dir), out)
+    return np.array(list(out), dtype=np.float32)
 
 
 def render_streaming(scene, value_fn, n_iters=16, accumulation=None):

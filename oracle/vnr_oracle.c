@@ -860,29 +860,120 @@ static void iter_exec(const vnro_scene* s, dda_iter* iter, v3 dir, float t_min, 
   while (dda_next(iter, m_dir, t_min, t_max, grid, exec_cell, &e)) {}
 }
 
-typedef struct { ray_t ray; float jitter; float* coords; uint32_t n_rays, i; int k, n_iters; } intersect_ctx;
+/* ------------------------------------------------------------------------ */
+/* gradient shading (modes 7 / 8)                                            */
+/* ------------------------------------------------------------------------ */
+
+/* ref: core/renderer/raytracing.h:214-222 */
+static v3 shade_simple_light(v3 ray_dir, v3 normal, v3 albedo)
+{
+  if (v3_dot(normal, normal) > 1.0e-6f) {
+    const v3 n = v3_normalize(normal);
+    const float c = 0.2f + 0.8f * fabsf(-v3_dot(ray_dir, n));   /* dot(-ray_dir, normalize(normal)) */
+    return v3_scale(c, albedo);
+  }
+  return v3_make(0, 0, 0);
+}
+
+/* ref: core/renderer/raytracing.h:224-246; mat = mat_gradient_shading {ambient .6, diffuse .9, specular .4, shininess 40}
+ * (instantvnr_types.h:142); light_diffuse = light_directional_rgb = 1 (:147); the light_ambient argument is unused there */
+static v3 shade_scivis_light(v3 ray_dir, v3 normal, v3 albedo, v3 light_dir)
+{
+  const float m_ambient = 0.6f, m_diffuse = 0.9f, m_specular = 0.4f, m_shininess = 40.0f;
+  v3 color = v3_make(0, 0, 0);
+  if (v3_dot(normal, normal) > 1.0e-6f) {
+    const v3 L = v3_normalize(light_dir);
+    const v3 N = v3_normalize(normal);
+    const v3 V = v3_make(-ray_dir.x, -ray_dir.y, -ray_dir.z);
+    color = v3_add(color, v3_scale(m_ambient, albedo));
+    const float cosNL = fmaxf(v3_dot(N, L), 0.0f);
+    if (cosNL > 0.0f) {
+      color = v3_add(color, v3_scale(m_diffuse * cosNL, albedo));   /* * light_diffuse (= 1) */
+      const v3 H = v3_normalize(v3_add(L, V));
+      const float cosNH = fmaxf(v3_dot(N, H), 0.0f);
+      const float sp = m_specular * powf(cosNH, m_shininess);
+      color = v3_add(color, v3_make(sp, sp, sp));
+    }
+  }
+  const v3 shading2 = shade_simple_light(ray_dir, normal, albedo);
+  /* lerp(0.5, shading2, color) */
+  return v3_add(v3_scale(0.5f, shading2), v3_scale(0.5f, color));
+}
+
+void vnro_shade_scivis_light(const float ray_dir[3], const float normal[3], const float albedo[3], const float light_dir[3],
+                             float out[3])
+{
+  const v3 r = shade_scivis_light(v3_make(ray_dir[0], ray_dir[1], ray_dir[2]), v3_make(normal[0], normal[1], normal[2]),
+                                  v3_make(albedo[0], albedo[1], albedo[2]), v3_make(light_dir[0], light_dir[1], light_dir[2]));
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+/* EXTERNAL gdt (embree lineage) xfmNormal(affine a, n) = transposed(inverse(a.l)) * n; given wto = inverse(otw):
+ * rows of wto.l, i.e. (dot(wto.vx-row...)).  With columns vx,vy,vz of wto.l the transpose applied to n is
+ * (dot(vx, n), dot(vy, n), dot(vz, n)). */
+static v3 xfm_normal_with_inverse(const affine* wto, v3 n)
+{
+  return v3_make(v3_dot(wto->vx, n), v3_dot(wto->vy, n), v3_dot(wto->vz, n));
+}
+
+/* one shaded sample: value f at c, forward differences f(c + gs_x e_x) etc.; `step` is the divisor of the differences
+ * (mode 8: grad_step, :783; mode 7: sampleGradient's possibly sign-flipped step, raytracing.h:112-126) */
+static v3 gradient_shade(const vnro_scene* s, const affine* otw, const affine* wto, v3 ray_dir_obj, float f, float fgx, float fgy,
+                         float fgz, v3 step, v3 albedo)
+{
+  /* No = -gradient */
+  const v3 No = v3_make(-((fgx - f) / step.x), -((fgy - f) / step.y), -((fgz - f) / step.z));
+  const v3 Nw = xfm_normal_with_inverse(wto, No);
+  const v3 dir_w = xfm_vector(otw, ray_dir_obj);
+  const v3 light = v3_make(s->light_dir[0], s->light_dir[1], s->light_dir[2]);
+  const v3 shaded = shade_scivis_light(dir_w, Nw, albedo, light);
+  /* sampleColor = lerp(scivis_shading_scale = 0.95, sampleColor, shadingColor), instantvnr_types.h:140 */
+  const float k = 0.95f;
+  return v3_add(v3_scale(1.0f - k, albedo), v3_scale(k, shaded));
+}
+
+typedef struct { ray_t ray; float jitter; float* coords; uint32_t n_rays, i; int k, n_iters; int gradient; v3 gs; } intersect_ctx;
 static int intersect_body(void* c, float t0, float t1)
 {
   intersect_ctx* x = (intersect_ctx*)c;
   /* lerp(r,a,b) = (1-r)*a + r*b  (instantvnr_types.h:162-166) */
   const float t = (1.0f - x->jitter) * t0 + x->jitter * t1;
   const v3 p = v3_add(x->ray.org, v3_scale(t, x->ray.dir));
-  float* dst = x->coords + 3 * ((size_t)x->n_rays * x->k + x->i);
+  const size_t slot = (size_t)x->n_rays * x->k + x->i;
+  float* dst = x->coords + 3 * slot;
   dst[0] = p.x; dst[1] = p.y; dst[2] = p.z;
+  if (x->gradient) {  /* :719-726: three more coordinate blocks of n_rays * N_ITERS each */
+    const size_t block = (size_t)x->n_rays * x->n_iters;
+    float* gx = x->coords + 3 * (1 * block + slot);
+    float* gy = x->coords + 3 * (2 * block + slot);
+    float* gz = x->coords + 3 * (3 * block + slot);
+    gx[0] = p.x + x->gs.x; gx[1] = p.y; gx[2] = p.z;
+    gy[0] = p.x; gy[1] = p.y + x->gs.y; gy[2] = p.z;
+    gz[0] = p.x; gz[1] = p.y; gz[2] = p.z + x->gs.z;
+  }
   return (++x->k) < x->n_iters;
 }
 
 typedef struct {
   const vnro_scene* s; const float* samples; uint32_t n_rays, i; int k, n_iters;
   float alpha; v3 color; float step_rcp;
+  int gradient; v3 gs; const affine* otw; const affine* wto; v3 ray_dir;
 } compose_ctx;
 static int compose_body(void* c, float t0, float t1)
 {
   compose_ctx* x = (compose_ctx*)c;
-  const float value = x->samples[(size_t)x->n_rays * x->k + x->i];
+  const size_t slot = (size_t)x->n_rays * x->k + x->i;
+  const float value = x->samples[slot];
   float rgb[3], a;
   vnro_tfn_sample(&x->s->tfn, value, rgb, &a);
   a = opacity_correction(x->step_rcp, t1 - t0, a);
+  if (x->gradient) {  /* :773-788 */
+    const size_t block = (size_t)x->n_rays * x->n_iters;
+    const v3 shaded = gradient_shade(x->s, x->otw, x->wto, x->ray_dir, value, x->samples[1 * block + slot],
+                                     x->samples[2 * block + slot], x->samples[3 * block + slot], x->gs,
+                                     v3_make(rgb[0], rgb[1], rgb[2]));
+    rgb[0] = shaded.x; rgb[1] = shaded.y; rgb[2] = shaded.z;
+  }
   const float tr = 1.0f - x->alpha;
   x->alpha += tr * a;
   x->color.x += tr * rgb[0] * a;
@@ -904,10 +995,14 @@ void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, v
   const v3 rcp = v3_make(1.0f / s->mc_spacings[0], 1.0f / s->mc_spacings[1], 1.0f / s->mc_spacings[2]);
   const i3 grid = { s->mc_dims[0], s->mc_dims[1], s->mc_dims[2] };
 
+  /* GRADIENT_SHADING streams 4 coordinates per sample (:198, :934): the sample and three forward offsets of grad_step */
+  const int gradient = s->shading_mode == 1;
+  const size_t per_sample = gradient ? 4 : 1;
+  const v3 gs = v3_make(1.0f / (float)s->vol_dims[0], 1.0f / (float)s->vol_dims[1], 1.0f / (float)s->vol_dims[2]); /* object.cpp:305 */
   payload_t* cur = (payload_t*)malloc(sizeof(payload_t) * n_pixels);
   payload_t* nxt = (payload_t*)malloc(sizeof(payload_t) * n_pixels);
-  float* coords = (float*)calloc((size_t)n_pixels * n_iters * 3, sizeof(float));
-  float* values = (float*)calloc((size_t)n_pixels * n_iters, sizeof(float));
+  float* coords = (float*)calloc((size_t)n_pixels * n_iters * 3 * per_sample, sizeof(float));
+  float* values = (float*)calloc((size_t)n_pixels * n_iters * per_sample, sizeof(float));
   vnro_render_stats st = {0, 0, 0, 0};
 
   /* raygen, ref: method_raymarching.cu:840-875 */
@@ -941,12 +1036,12 @@ void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, v
       const ray_t ray = compute_ray(s, &cam, &wto, p.pixel_index);
       float tmin = 0.0f, tmax = FLOAT_LARGE;
       intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi);
-      intersect_ctx x = { ray, p.jitter, coords, n_rays, i, 0, n_iters };
+      intersect_ctx x = { ray, p.jitter, coords, n_rays, i, 0, n_iters, gradient, gs };
       iter_exec(s, &p.iter, ray.dir, tmin, tmax, step, intersect_body, &x);
       st.n_samples += (uint64_t)x.k;
     }
-    /* inference of ALL n_iters*n_rays slots (stale coords included), :950-953 */
-    fn(user, coords, (size_t)n_rays * n_iters, values);
+    /* inference of ALL n_iters*n_rays slots (stale coords included), :950-953; x4 blocks with gradient shading */
+    fn(user, coords, (size_t)n_rays * n_iters * per_sample, values);
     /* compose, :732-838 */
     uint32_t n_next = 0;
     for (uint32_t i = 0; i < n_rays; ++i) {
@@ -954,7 +1049,7 @@ void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, v
       const ray_t ray = compute_ray(s, &cam, &wto, p.pixel_index);
       float tmin = 0.0f, tmax = FLOAT_LARGE;
       intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi);
-      compose_ctx x = { s, values, n_rays, i, 0, n_iters, p.alpha, p.color, step_rcp };
+      compose_ctx x = { s, values, n_rays, i, 0, n_iters, p.alpha, p.color, step_rcp, gradient, gs, &otw, &wto, ray.dir };
       iter_exec(s, &p.iter, ray.dir, tmin, tmax, step, compose_body, &x);
       p.alpha = x.alpha; p.color = x.color;
       const int resumable = dda_resumable(&p.iter, v3_mul(ray.dir, rcp), tmin, tmax, grid);
@@ -980,6 +1075,7 @@ void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, v
 typedef struct {
   const vnro_scene* s; const float* vol; ray_t ray; float jitter, step, step_rcp;
   float alpha; v3 color;
+  int gradient; v3 gs; const affine* otw; const affine* wto;
 } mono_ctx;
 
 static int mono_cell(void* c, i3 cell, float t0, float t1)
@@ -1001,6 +1097,17 @@ static int mono_cell(void* c, i3 cell, float t0, float t1)
     float rgb[3], a;
     vnro_tfn_sample(&m->s->tfn, value, rgb, &a);
     a = opacity_correction(m->step_rcp, ty - tx, a);
+    if (m->gradient) {  /* :440-454 with sampleGradient, raytracing.h:112-126: a step that would leave [0,1] is flipped */
+      v3 stp = m->gs;
+      if (p.x + stp.x > 1.0f - FLT_EPSILON) stp.x *= -1.0f;
+      if (p.y + stp.y > 1.0f - FLT_EPSILON) stp.y *= -1.0f;
+      if (p.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
+      const float fgx = vnro_sample_volume(m->vol, m->s->vol_dims, p.x + stp.x, p.y, p.z);
+      const float fgy = vnro_sample_volume(m->vol, m->s->vol_dims, p.x, p.y + stp.y, p.z);
+      const float fgz = vnro_sample_volume(m->vol, m->s->vol_dims, p.x, p.y, p.z + stp.z);
+      const v3 shaded = gradient_shade(m->s, m->otw, m->wto, m->ray.dir, value, fgx, fgy, fgz, stp, v3_make(rgb[0], rgb[1], rgb[2]));
+      rgb[0] = shaded.x; rgb[1] = shaded.y; rgb[2] = shaded.z;
+    }
     const float tr = 1.0f - m->alpha;
     m->color.x += tr * rgb[0] * a;
     m->color.y += tr * rgb[1] * a;
@@ -1032,6 +1139,9 @@ void vnro_render_monolithic(const vnro_scene* s, const float* vol, int row_lo, i
       m.s = s; m.vol = vol; m.ray = compute_ray(s, &cam, &wto, pixel);
       m.step = 1.0f / s->sampling_rate; m.step_rcp = s->sampling_rate;
       m.alpha = 0.0f; m.color = v3_make(0, 0, 0);
+      m.gradient = s->shading_mode == 1;
+      m.gs = v3_make(1.0f / (float)s->vol_dims[0], 1.0f / (float)s->vol_dims[1], 1.0f / (float)s->vol_dims[2]);
+      m.otw = &otw; m.wto = &wto;
       float t0 = 0.0f, t1 = FLOAT_LARGE;
       if (intersect_box(&t0, &t1, m.ray.org, m.ray.dir, lo, hi)) {
         m.jitter = vnro_lcg_next(&rng);

@@ -142,7 +142,15 @@ typedef struct {
   vnro_tfn tfn;
   /* tiling: only pixels with pixel_lo <= index < pixel_hi are rendered (others untouched) */
   uint32_t pixel_lo, pixel_hi;
+  /* shading (appended last; zero = NO_SHADING, i.e. rendering modes 4 / 5) */
+  int   shading_mode;  /* 1 = GRADIENT_SHADING (modes 7 / 8; method_raymarching.cu:446-454, 719-726, 773-788) */
+  float light_dir[3];  /* LaunchParams::light_directional_dir (instantvnr_types.h:148) AFTER the flip of renderer.cpp:98-101 */
 } vnro_scene;
+
+/* shade_scivis_light (core/renderer/raytracing.h:214-246) with mat_gradient_shading {.6, .9, .4, 40} and
+ * light_directional_rgb = 1 (instantvnr_types.h:142,147); all vectors in world space; out[3] */
+void vnro_shade_scivis_light(const float ray_dir[3], const float normal[3], const float albedo[3], const float light_dir[3],
+                             float out[3]);
 
 /* batch value callback: values[i] = f(coords[i]) for object-space coords */
 typedef void (*vnro_value_fn)(void* user, const float* coords, size_t n, float* values);

@@ -180,3 +180,40 @@ def test_psnr_definition(oracle):
     assert np.isclose(oracle.psnr(pred, ref), 10 * np.log10(4.0 / 0.0004), atol=1e-3)
     c = oracle.grid_coords((1, 2, 3), (2, 2, 2), (0.1, 0.1, 0.1))
     assert np.allclose(c[0], [0.15, 0.25, 0.35]) and np.allclose(c[-1], [0.25, 0.35, 0.45])
+
+
+# --------------------------------------------------------------------------- gradient shading (modes 7 / 8)
+def test_shade_scivis_light_hand_cases(oracle):
+    """shade_scivis_light (raytracing.h:224-246) with mat {.6, .9, .4, 40}: view, normal and light aligned ->
+    0.5 * albedo * 1.0 + 0.5 * (0.6 a + 0.9 a + 0.4) = 1.25 a + 0.2; light behind the surface -> 0.5 a + 0.5 * 0.6 a = 0.8 a."""
+    got = oracle.shade_scivis_light((0, 0, 1), (0, 0, -2), (0.2, 0.4, 0.8), (0, 0, -3))
+    assert np.allclose(got, [0.45, 0.7, 1.2], atol=1e-6)
+    assert np.allclose(oracle.shade_scivis_light((0, 0, 1), (0, 0, -1), (0.5, 0.5, 0.5), (0, 0, 1)), 0.4, atol=1e-6)
+    assert np.array_equal(oracle.shade_scivis_light((0, 0, 1), (0, 0, 0), (0.5, 0.5, 0.5), (0, 0, -1)), [0, 0, 0])   # no gradient
+    # normal perpendicular to the view, light along the normal: simple term 0.2 a, scivis 0.6 a + 0.9 a + 0.4 * cos(45 deg)^40
+    got = oracle.shade_scivis_light((0, 0, 1), (1, 0, 0), (0.5, 0.5, 0.5), (1, 0, 0))
+    assert np.allclose(got, 0.5 * 0.2 * 0.5 + 0.5 * (1.5 * 0.5 + 0.4 * np.cos(np.pi / 4) ** 40), atol=1e-6)
+
+
+def test_light_is_flipped_towards_the_viewer(oracle):
+    assert oracle.flipped_light_dir((0, 0, 100), (0, 0, 0)) == pytest.approx(oracle.DEFAULT_LIGHT_DIR)     # view along -z: dot < 0
+    assert oracle.flipped_light_dir((0, 0, -100), (0, 0, 0)) == pytest.approx([-v for v in oracle.DEFAULT_LIGHT_DIR])
+
+
+def test_gradient_shading_changes_colour_only_and_modes_agree(oracle):
+    """modes 8 (streaming) and 7 (monolithic) agree as closely as 5 and 4 do; alpha and the sample statistics are those of
+    the unshaded modes"""
+    vol = syn.analytic_volume(32)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = oracle.TfnHolder(colors, alphas)
+    mo = oracle.macrocell_max_opacity(tfn, oracle.macrocell_compute_implicit(vol))
+    cam = syn.oblique_camera((32, 32, 32))
+    f = lambda c: oracle.sample_volume(vol, c, nodal=True)
+    sc0 = oracle.SceneHolder(48, 40, (32, 32, 32), tfn, mo, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    sc1 = oracle.SceneHolder(48, 40, (32, 32, 32), tfn, mo, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=1)
+    a0, _, st0 = oracle.render_streaming(sc0, f)
+    a1, _, st1 = oracle.render_streaming(sc1, f)
+    m1, _ = oracle.render_monolithic(sc1, vol)
+    assert st0 == st1 and np.array_equal(a0[..., 3], a1[..., 3])
+    assert np.abs(a1[..., :3] - a0[..., :3]).mean() > 1e-3
+    assert np.abs(a1 - m1).mean() < 1e-3

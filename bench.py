@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--camera-distance", type=float, default=1.1, help="camera distance in volume edges (oblique view)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-psnr", action="store_true")
+    p.add_argument("--mode", type=int, default=5, choices=(5, 8),
+                   help="rendering mode: 5 = sample streaming (BASELINE metric, default), 8 = the same with gradient shading (4 evaluations per sample)")
     return p.parse_args()
 
 
@@ -141,7 +143,7 @@ def main():
     api.vnrRendererSetTransferFunction(ren, tfn)
     api.vnrRendererSetCamera(ren, camera)
     api.vnrRendererSetFramebufferSize(ren, (a.fb, a.fb))
-    api.vnrRendererSetMode(ren, 5)
+    api.vnrRendererSetMode(ren, a.mode)
     api.vnrRendererSetProfiling(ren, True)  # HIP events around the fused encode+MLP kernel, on its own stream
     sr = dist.ShardedRenderer(ctx, ren, a.fb, a.fb)
     setup_s = time.perf_counter() - t_setup
@@ -178,6 +180,12 @@ def main():
     if ctx.rank != 0:
         return
     fps = a.steps / elapsed
+    # the renderer counts SHADED samples; with gradient shading (mode 8) the network evaluates 4 coordinates for each of them,
+    # and every rate below is per network evaluation
+    evals_per_sample = 4 if a.mode == 8 else 1
+    shaded_samples_per_frame = int(samples_all / a.steps)
+    samples *= evals_per_sample
+    samples_all *= evals_per_sample
     bytes_per_sample = 12 + info["n_levels"] * 8 * info["n_features_per_level"] * 2 + 4
     in_pad = info["padded_width"]
     flops_per_sample = 2 * (in_pad * 64 + (info["n_hidden_layers"] - 1) * 64 * 64 + 64)
@@ -204,7 +212,7 @@ def main():
     # --pmc passes, tools/run_pmc.sh); a committed result applies only to the exact default workload on one GPU with
     # the same stream configuration it was measured with.
     default_workload = (a.size, a.fb, a.levels, a.features, a.log2_hashmap_size, a.hidden_layers, a.per_level_scale,
-                        a.train_steps, a.opacity_scale, a.camera_distance) == (1024, 1024, 16, 2, 22, 3, 0.0, 1500, 0.06, 1.1)
+                        a.train_steps, a.opacity_scale, a.camera_distance, a.mode) == (1024, 1024, 16, 2, 22, 3, 0.0, 1500, 0.06, 1.1, 5)
     pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                             "r01_pmc_traffic.json" if halves == 1 else "r01_pmc_traffic_2halves.json")
     if default_workload and ctx.world == 1 and os.path.exists(pmc_path):
@@ -220,13 +228,13 @@ def main():
                                     "see tools/run_pmc.sh).  The same kernel running alone (VNR_AMD_RENDER_HALVES=1) fetched 2.09 x its "
                                     "algorithmic bytes: profiles/r01_pmc_traffic.json")
     out = {
-        "metric": "fps at 1024^2 on 1024^3 volume" if (a.size, a.fb) == (1024, 1024) else f"fps at {a.fb}^2 on {a.size}^3 volume",
+        "metric": "fps at 1024^2 on 1024^3 volume" if (a.size, a.fb, a.mode) == (1024, 1024, 5) else f"fps at {a.fb}^2 on {a.size}^3 volume, rendering mode {a.mode}" if a.mode != 5 else f"fps at {a.fb}^2 on {a.size}^3 volume",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"C4: {a.size}^3 synthetic Perlin fBm volume (seed 42), HashGrid L={a.levels} F={a.features} "
                                f"T=2^{a.log2_hashmap_size} base 16 per_level_scale {pls:.4f} + {a.hidden_layers}x64 FullyFusedMLP, "
-                               f"{a.fb}x{a.fb} rendering mode 5 (sample streaming), sampling rate 1, N_ITERS 16",
+                               f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading'}), sampling rate 1, N_ITERS 16",
                    "volume": f"{a.size}^3", "framebuffer": f"{a.fb}x{a.fb}", "n_params": info["n_params"],
                    "tfn": f"256-entry ramp-with-bumps, seed 7, opacity scale {a.opacity_scale}",
                    "camera": cam, "train_steps": a.train_steps, "batch": 65536,
@@ -234,6 +242,7 @@ def main():
         "mlp_msamples_per_s": round(samples_all / elapsed / 1e6, 1),
         "mlp_msamples_per_s_kernel_only": round(samples / (infer_ms * 1e-3) / 1e6, 1) if infer_ms > 0 else None,
         "samples_per_frame": int(samples_all / a.steps), "samples_per_hit_ray": round(samples_all / a.steps / max(rays_hit, 1), 1),
+        "network_evaluations_per_shaded_sample": evals_per_sample, "shaded_samples_per_frame": shaded_samples_per_frame,
         "reference_slots_per_frame": int(slots_all / a.steps), "iterations_per_frame": iters, "rays_hit": rays_hit,
         "psnr_db": None if psnr is None else round(psnr, 2), "train_ms_per_step": round(train_ms, 3), "train_loss": round(train_loss, 5),
         "setup_s": round(setup_s, 1),

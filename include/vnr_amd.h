@@ -139,6 +139,15 @@ int    vnrAmdNeuralVolumeGetTrainingStep(vnrAmdVolume);                         
 int    vnrAmdNeuralVolumeGetNumberOfBlobs(vnrAmdVolume);                                       /* vnrNeuralVolumeGetNumberOfBlobs */
 int    vnrAmdNeuralVolumeTrain(vnrAmdVolume, int steps, int fast_mode);                        /* vnrNeuralVolumeTrain */
 /* vnrNeuralVolumeSerializeParams(vol, filename): BSON params.json (network.cu:859-877) */
+/* vnrNeuralVolumeDecodeProgressive (api.h:137, api.cpp:228-232 -> network.cu:290-326): decodes the next blob of 16 z-slices at the
+ * voxel centres into the dense decoded volume that rendering modes 4 / 7 march; GetNumberOfBlobs calls = one full pass */
+int    vnrAmdNeuralVolumeDecodeProgressive(vnrAmdVolume);
+/* vnrNeuralVolumeDecodeInference / ...DecodeReference (api.h:139-140, api.cpp:234-244 -> network.cu:328-405): raw fp32 dump of the
+ * decoded / reference volume, slice by slice, each slice padded to a multiple of 256 values.  The reference ignores the
+ * file name of DecodeReference and writes "reference.bin"; this writes `filename`. */
+int    vnrAmdNeuralVolumeDecodeInference(vnrAmdVolume, const char* filename);
+int    vnrAmdNeuralVolumeDecodeReference(vnrAmdVolume, const char* filename);
+const float* vnrAmdNeuralVolumeDecodedDeviceData(vnrAmdVolume);   /* AMD extension: the decoded volume (NULL before the first decode) */
 int    vnrAmdNeuralVolumeSerializeParamsToFile(vnrAmdVolume, const char* filename);
 /* vnrNeuralVolumeSerializeParams(vol, json&): BSON bytes, free with vnrAmdFreeHost */
 int    vnrAmdNeuralVolumeSerializeParams(vnrAmdVolume, void** bson, size_t* size);

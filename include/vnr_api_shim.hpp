@@ -167,6 +167,9 @@ inline double vnrNeuralVolumeGetTrainingLoss(vnrVolume v) { return vnrAmdNeuralV
 inline int vnrNeuralVolumeGetTrainingStep(vnrVolume v) { return vnrAmdNeuralVolumeGetTrainingStep(v.get()); }
 inline int vnrNeuralVolumeGetNumberOfBlobs(vnrVolume v) { return vnrAmdNeuralVolumeGetNumberOfBlobs(v.get()); }
 inline void vnrNeuralVolumeTrain(vnrVolume v, int steps, bool fast_mode) { vnr::shim::check(vnrAmdNeuralVolumeTrain(v.get(), steps, fast_mode)); }
+inline void vnrNeuralVolumeDecodeProgressive(vnrVolume v) { vnr::shim::check(vnrAmdNeuralVolumeDecodeProgressive(v.get())); }                                   // api.h:137
+inline void vnrNeuralVolumeDecodeInference(vnrVolume v, std::string filename) { vnr::shim::check(vnrAmdNeuralVolumeDecodeInference(v.get(), filename.c_str())); }  // api.h:139
+inline void vnrNeuralVolumeDecodeReference(vnrVolume v, std::string filename) { vnr::shim::check(vnrAmdNeuralVolumeDecodeReference(v.get(), filename.c_str())); }  // api.h:140
 inline void vnrNeuralVolumeSerializeParams(vnrVolume v, std::string filename) { vnr::shim::check(vnrAmdNeuralVolumeSerializeParamsToFile(v.get(), filename.c_str())); }
 inline void vnrNeuralVolumeSerializeParams(vnrVolume v, vnrJson& params)
 {

@@ -114,6 +114,10 @@ def lib():
     sig("vnrAmdNeuralVolumeGetNumberOfBlobs", I, P)
     sig("vnrAmdNeuralVolumeTrain", I, P, I, I)
     sig("vnrAmdNeuralVolumeSerializeParamsToFile", I, P, C.c_char_p)
+    sig("vnrAmdNeuralVolumeDecodeProgressive", I, P)
+    sig("vnrAmdNeuralVolumeDecodeInference", I, P, C.c_char_p)
+    sig("vnrAmdNeuralVolumeDecodeReference", I, P, C.c_char_p)
+    sig("vnrAmdNeuralVolumeDecodedDeviceData", P, P)
     sig("vnrAmdNeuralVolumeSerializeParams", I, P, C.POINTER(P), C.POINTER(SZ))
     sig("vnrAmdNeuralVolumeInference", I, P, SZ, P, P, P)
     sig("vnrAmdNeuralVolumeEncode", I, P, SZ, P, P, P)

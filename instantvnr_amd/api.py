@@ -282,6 +282,29 @@ def vnrNeuralVolumeTrain(v, steps, fast_mode):
     check(lib().vnrAmdNeuralVolumeTrain(v.h, int(steps), 1 if fast_mode else 0))
 
 
+def vnrNeuralVolumeDecodeProgressive(v):
+    """decodes the next blob of 16 z-slices into the dense volume rendering modes 4 / 7 march (api.h:137)"""
+    check(lib().vnrAmdNeuralVolumeDecodeProgressive(v.h))
+
+
+def vnrNeuralVolumeDecodeInference(v, filename):
+    check(lib().vnrAmdNeuralVolumeDecodeInference(v.h, filename.encode()))
+
+
+def vnrNeuralVolumeDecodeReference(v, filename):
+    check(lib().vnrAmdNeuralVolumeDecodeReference(v.h, filename.encode()))
+
+
+def neural_decoded_volume(v, dims):
+    """the decoded dense volume as numpy [z, y, x] (AMD extension; None before the first decode)"""
+    p = lib().vnrAmdNeuralVolumeDecodedDeviceData(v.h)
+    if not p:
+        return None
+    out = np.empty((dims[2], dims[1], dims[0]), dtype=np.float32)
+    check(lib().vnrAmdMemcpyD2H(out.ctypes.data_as(C.c_void_p), p, out.nbytes))
+    return out
+
+
 def vnrNeuralVolumeSerializeParams(v, filename=None):
     """with a filename: writes BSON params.json; without: returns the BSON bytes"""
     if filename is not None:

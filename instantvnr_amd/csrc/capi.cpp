@@ -393,6 +393,30 @@ int vnrAmdNeuralVolumeTrain(vnrAmdVolume v, int steps, int fast_mode)
 {
   return guarded([&]() { as_neural(v)->train((size_t)std::max(steps, 0), fast_mode != 0); });
 }
+int vnrAmdNeuralVolumeDecodeProgressive(vnrAmdVolume v)
+{
+  return guarded([&]() { as_neural(v)->decode_progressive(); });
+}
+int vnrAmdNeuralVolumeDecodeInference(vnrAmdVolume v, const char* filename)
+{
+  return guarded([&]() {
+    if (!filename) throw std::runtime_error("filename is null");
+    as_neural(v)->save_inference_volume(filename);
+  });
+}
+int vnrAmdNeuralVolumeDecodeReference(vnrAmdVolume v, const char* filename)
+{
+  return guarded([&]() {
+    if (!filename) throw std::runtime_error("filename is null");
+    as_neural(v)->save_reference_volume(filename);
+  });
+}
+const float* vnrAmdNeuralVolumeDecodedDeviceData(vnrAmdVolume v)
+{
+  const float* r = nullptr;
+  guarded([&]() { r = as_neural(v)->decoded_data(); });
+  return r;
+}
 int vnrAmdNeuralVolumeSerializeParamsToFile(vnrAmdVolume v, const char* filename)
 {
   return guarded([&]() {

@@ -681,7 +681,9 @@ void Renderer::render()
   p.cam_ver = (1.0f / aspect) * cross(p.cam_hor, p.cam_dir);
   p.wto = affine_inverse(volume_->transform);
   p.vol_dims = volume_->desc.dims;
-  p.volume = volume_->is_network() ? nullptr : static_cast<SimpleVolume*>(volume_.get())->d_data();
+  // dense data to sample: the ground-truth volume, or (decoding modes 4 / 7 on a neural volume) its decoded copy
+  p.volume = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get())->decoded_data()
+                                   : static_cast<SimpleVolume*>(volume_.get())->d_data();
   p.bbox_lo = volume_->clipbox.lower; p.bbox_hi = volume_->clipbox.upper;
   p.step = 1.0f / sampling_rate_; p.step_rcp = sampling_rate_;  // object.cpp:303-304
   p.mc_dims = mc.dims();
@@ -714,8 +716,11 @@ void Renderer::render()
       break;
     case 4:   // VNR_RAYMARCHING_NO_SHADING_DECODING
     case 7:   // VNR_RAYMARCHING_GRADIENT_SHADING_DECODING
-      if (volume_->is_network())
-        throw std::runtime_error("rendering mode " + std::to_string(mode_) + " (decoding) on a neural volume is not implemented in this build");
+      // vnrRequireDecoding(mode) (api.h:62-88): the application decodes, vnrNeuralVolumeDecodeProgressive x GetNumberOfBlobs,
+      // and these modes march whatever the decoded volume holds
+      if (volume_->is_network() && !p.volume)
+        throw std::runtime_error("rendering mode " + std::to_string(mode_) +
+                                 " marches the decoded volume: call vnrNeuralVolumeDecodeProgressive first (GetNumberOfBlobs calls = one full pass)");
       render_monolithic(p);
       break;
     default:

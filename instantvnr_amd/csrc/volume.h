@@ -145,6 +145,14 @@ public:
   float get_psnr(bool quiet);                               // network.cu:410-472
   void inference(size_t n, const float* d_in, float* d_out, hipStream_t s);  // network.cu:1043-1052
   int num_blobs() const { return (desc.dims.z + 15) / 16; } // network.cu:969-975
+  // Decoding (rendering modes 4 / 7 on a neural volume march the DECODED dense volume).  One call decodes one blob of 16
+  // z-slices at the voxel centres and moves on to the next, wrapping around (network.cu:290-326; num_blobs() calls = one
+  // full pass; the blob cursor is per volume here, a function-local static in the reference).
+  void decode_progressive();
+  const float* decoded_data() const { return decoded_.count ? decoded_.ptr : nullptr; }
+  // network.cu:328-365 / :367-405: raw fp32, z-slice by z-slice, every slice padded to a multiple of 256 values
+  void save_inference_volume(const std::string& filename);
+  void save_reference_volume(const std::string& filename);
 
   Network& network() { return net_; }
   SimpleVolume* source() { return source_; }
@@ -159,6 +167,8 @@ private:
   TfnObject tfn_;
   const size_t batch_size_ = 1u << 16;  // network.cu:183
   DeviceBuffer<float> train_x_{MemTag::Network}, train_y_{MemTag::Network}, test_y1_{MemTag::Network};
+  DeviceBuffer<float> decoded_{MemTag::Network}, decode_coords_{MemTag::Network};  // dense decoded volume, coordinates of one blob
+  int decode_blob_ = 0;
   bool pending_step_ = false, pending_internal_ = false;
   friend struct VolumeKeepAlive;
 

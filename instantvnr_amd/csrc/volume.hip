@@ -661,6 +661,77 @@ void NeuralVolume::inference(size_t n, const float* d_in, float* d_out, hipStrea
   net_.inference(d_in, d_out, n, nullptr, n, s);
 }
 
+// infer_progressively_decode_volume (network.cu:290-326): m_lower = 0, m_upper = dims, so a blob is 16 whole z-slices and its
+// result is contiguous in the decoded array: the inference writes straight into it (the reference copies with cudaMemcpy3D).
+void NeuralVolume::decode_progressive()
+{
+  if (!net_.valid()) throw std::runtime_error("neural volume has no valid network");
+  const vec3i dims = desc.dims;
+  const size_t slice = (size_t)dims.x * dims.y, total = slice * dims.z;
+  const int per_blob = 16;  // m_num_slices_per_blob, network.cu:171
+  if (decoded_.count != total) { decoded_.resize(total); decoded_.zero(stream); decode_blob_ = 0; }
+  if (decode_coords_.count != 3 * slice * per_blob) decode_coords_.resize(3 * slice * per_blob);
+  const int b = decode_blob_;
+  const int nz = std::min(per_blob, dims.z - b * per_blob);
+  const size_t count = slice * (size_t)nz;
+  if (count >= (1ull << 32)) throw std::runtime_error("blob too large");
+  const vec3f rdims = {1.0f / (float)dims.x, 1.0f / (float)dims.y, 1.0f / (float)dims.z};
+  generate_coords_kernel<<<div_round_up(count, 256), 256, 0, stream>>>((uint32_t)count, vec3i{0, 0, b * per_blob}, vec3i{dims.x, dims.y, nz}, rdims,
+                                                                        decode_coords_.ptr);
+  VNR_HIP_CHECK(hipGetLastError());
+  net_.inference(decode_coords_.ptr, decoded_.ptr + slice * (size_t)b * per_blob, count, nullptr, count, stream);
+  VNR_HIP_CHECK(hipStreamSynchronize(stream));  // the renderer reads the decoded volume on its own stream
+  decode_blob_ = (b + 1) * per_blob >= dims.z ? 0 : b + 1;
+}
+
+// save_inference_volume (network.cu:328-365): z-slice by z-slice; every slice is written with its length padded to a
+// multiple of 256 values, and the padding is what the network returns at the coordinates generate_coords produces for
+// those indices (they wrap into slice z + 1) -- reproduced by running the same kernel over the padded count.
+void NeuralVolume::save_inference_volume(const std::string& filename)
+{
+  if (!net_.valid()) throw std::runtime_error("neural volume has no valid network");
+  const vec3i dims = desc.dims;
+  const vec3f rdims = {1.0f / (float)dims.x, 1.0f / (float)dims.y, 1.0f / (float)dims.z};
+  const size_t count = (((size_t)dims.x * dims.y + 255) / 256) * 256;  // util::next_multiple<size_t>(..., 256)
+  DeviceBuffer<float> coords, values;
+  coords.resize(3 * count); values.resize(count);
+  std::vector<float> host(count);
+  std::ofstream ofs(filename, std::ios::binary | std::ios::out);
+  if (!ofs) throw std::runtime_error("cannot open " + filename);
+  for (int z = 0; z < dims.z; ++z) {
+    generate_coords_kernel<<<div_round_up(count, 256), 256, 0, stream>>>((uint32_t)count, vec3i{0, 0, z}, vec3i{dims.x, dims.y, 1}, rdims, coords.ptr);
+    net_.inference(coords.ptr, values.ptr, count, nullptr, count, stream);
+    VNR_HIP_CHECK(hipMemcpyAsync(host.data(), values.ptr, count * sizeof(float), hipMemcpyDeviceToHost, stream));
+    VNR_HIP_CHECK(hipStreamSynchronize(stream));
+    ofs.write((const char*)host.data(), (std::streamsize)(count * sizeof(float)));
+  }
+  if (!ofs) throw std::runtime_error("error while writing " + filename);
+}
+
+// save_reference_volume (network.cu:367-405): the (normalised) reference volume at the voxel centres, same slice format.
+// Two deliberate differences: the reference ignores `filename` and always writes "reference.bin" into the working directory
+// (this writes `filename`), and it writes whatever its scratch buffer holds as padding (this writes zeros).
+void NeuralVolume::save_reference_volume(const std::string& filename)
+{
+  if (!source_) throw std::runtime_error("missing a reference volume");  // the reference prints this and returns
+  const vec3i dims = desc.dims;
+  const vec3f rdims = {1.0f / (float)dims.x, 1.0f / (float)dims.y, 1.0f / (float)dims.z};
+  const size_t xy = (size_t)dims.x * dims.y, count = ((xy + 255) / 256) * 256;
+  DeviceBuffer<float> coords, values;
+  coords.resize(3 * count); values.resize(count);
+  values.zero(stream);
+  std::vector<float> host(count);
+  std::ofstream ofs(filename, std::ios::binary | std::ios::out);
+  if (!ofs) throw std::runtime_error("cannot open " + filename);
+  for (int z = 0; z < dims.z; ++z) {
+    source_->take_samples_grid(coords.ptr, values.ptr, vec3i{0, 0, z}, vec3i{dims.x, dims.y, 1}, rdims, stream);
+    VNR_HIP_CHECK(hipMemcpyAsync(host.data(), values.ptr, count * sizeof(float), hipMemcpyDeviceToHost, stream));
+    VNR_HIP_CHECK(hipStreamSynchronize(stream));
+    ofs.write((const char*)host.data(), (std::streamsize)(count * sizeof(float)));
+  }
+  if (!ofs) throw std::runtime_error("error while writing " + filename);
+}
+
 void NeuralVolume::save_params_to_json(Json& root)
 {
   const vec3i md = mc_.dims();

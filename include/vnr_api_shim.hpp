@@ -10,6 +10,8 @@
 //     Define VNR_SHIM_OWN_MATH to get minimal layout-compatible types from this header instead.
 #pragma once
 
+#include <cstdio>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -191,6 +193,27 @@ inline vnrTransferFunction vnrCreateTransferFunction() { return vnrTransferFunct
 inline void vnrTransferFunctionSetColor(vnrTransferFunction t, const std::vector<vnr::vec3f>& c) { vnr::shim::check(vnrAmdTransferFunctionSetColor(t.get(), c.empty() ? nullptr : &c[0].x, (int)c.size())); }
 inline void vnrTransferFunctionSetAlpha(vnrTransferFunction t, const std::vector<vnr::vec2f>& a) { vnr::shim::check(vnrAmdTransferFunctionSetAlpha(t.get(), a.empty() ? nullptr : &a[0].x, (int)a.size())); }
 inline void vnrTransferFunctionSetValueRange(vnrTransferFunction t, vnr::range1f r) { vnr::shim::check(vnrAmdTransferFunctionSetValueRange(t.get(), r.lower, r.upper)); }
+// api.h:160-162 return references into the transfer function object.  The handle is opaque here, so the shim keeps a copy
+// per handle (refreshed on every call); a returned reference stays valid until the next getter call on the same handle
+// or until the handle dies, which covers how the reference's apps use it.
+namespace vnr { namespace shim {
+struct TfnCopy { std::vector<vnr::vec3f> color; std::vector<vnr::vec2f> alpha; vnr::range1f range{0.0f, 1.0f}; };
+inline TfnCopy& tfn_copy(const vnrTransferFunction& t)
+{
+  static std::map<const void*, TfnCopy> copies;
+  TfnCopy& c = copies[t.get()];
+  int nc = 0, na = 0;
+  check(vnrAmdTransferFunctionGetSizes(t.get(), &nc, &na));
+  c.color.resize((size_t)nc); c.alpha.resize((size_t)na);
+  float r[2] = {0.0f, 1.0f};
+  check(vnrAmdTransferFunctionGet(t.get(), nc ? &c.color[0].x : nullptr, na ? &c.alpha[0].x : nullptr, r));
+  c.range = vnr::range1f{r[0], r[1]};
+  return c;
+}
+} }
+inline const std::vector<vnr::vec3f>& vnrTransferFunctionGetColor(vnrTransferFunction t) { return vnr::shim::tfn_copy(t).color; }
+inline const std::vector<vnr::vec2f>& vnrTransferFunctionGetAlpha(vnrTransferFunction t) { return vnr::shim::tfn_copy(t).alpha; }
+inline const vnr::range1f& vnrTransferFunctionGetValueRange(vnrTransferFunction t) { return vnr::shim::tfn_copy(t).range; }
 
 // ---- renderer (api.h:168-178) ---------------------------------------------------------------------------------------
 inline vnrRenderer vnrCreateRenderer(vnrVolume v) { return vnrRenderer(vnr::shim::check_ptr(vnrAmdCreateRenderer(v.get())), vnrAmdReleaseRenderer); }
@@ -208,3 +231,26 @@ inline vnr::vec4f* vnrRendererMapFrame(vnrRenderer r) { return (vnr::vec4f*)vnr:
 // ---- misc (api.h:186-188) -------------------------------------------------------------------------------------------
 inline void vnrMemoryQuery(size_t* used_by_renderer, size_t* used_by_tcnn) { vnrAmdMemoryQuery(used_by_renderer, used_by_tcnn); }
 inline void vnrFreeTemporaryGPUMemory() { vnrAmdFreeTemporaryGPUMemory(); }
+// api.cpp:538-552: "<str>: total used .., engine .., tcnn .., unknown ..".  The total is what this library allocated (the
+// reference asks the driver for the device-wide figure), so "unknown" is always 0 here.
+inline void vnrMemoryQueryPrint(const char* str)
+{
+  size_t r = 0, n = 0;
+  vnrAmdMemoryQuery(&r, &n);
+  auto pretty = [](size_t b) { char buf[64]; const double v = (double)b; if (b >= (1ull << 30)) snprintf(buf, sizeof buf, "%.2f GB", v / (1ull << 30)); else if (b >= (1ull << 20)) snprintf(buf, sizeof buf, "%.2f MB", v / (1ull << 20)); else snprintf(buf, sizeof buf, "%.2f KB", v / 1024.0); return std::string(buf); };
+  printf("%s: total used %s, engine %s, tcnn %s, unknown %s\n", str ? str : "", pretty(r + n).c_str(), pretty(r).c_str(), pretty(n).c_str(), pretty(0).c_str());
+}
+// api.h:185 declares vnrRelease(void*) and api.cpp never defines it (handles are shared_ptr and release themselves)
+inline void vnrRelease(void*) {}
+// api.h:62-88 (inline there as well): the *_DECODING modes march a decoded dense volume
+inline bool vnrRequireDecoding(int m)
+{
+  if (m < 0 || m > 15) throw std::runtime_error("unknown rendering mode");
+  return m <= 4 || m == 7 || m == 10 || m == 13;
+}
+// api.h:118-119: time-varying raw volumes.  This build loads one time step per volume.
+inline int vnrSimpleVolumeGetNumberOfTimeSteps(vnrVolume v) { if (!v || vnrAmdVolumeIsNetwork(v.get())) throw std::runtime_error("expected a simple volume"); return 1; }
+inline void vnrSimpleVolumeSetCurrentTimeStep(vnrVolume v, int time)
+{
+  if (time != 0 || vnrSimpleVolumeGetNumberOfTimeSteps(v) != 1) throw std::runtime_error("time step " + std::to_string(time) + " requested, but this volume has 1 time step (time-varying volumes are not implemented in this build)");
+}

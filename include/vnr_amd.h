@@ -133,6 +133,9 @@ vnrAmdVolume vnrAmdCreateNeuralVolumeFromParams(const void* params, size_t size,
 int    vnrAmdNeuralVolumeSetModel(vnrAmdVolume, const void* config, size_t size, int format);  /* vnrNeuralVolumeSetModel */
 int    vnrAmdNeuralVolumeSetParams(vnrAmdVolume, const void* params, size_t size, int format); /* vnrNeuralVolumeSetParams */
 double vnrAmdNeuralVolumeGetPSNR(vnrAmdVolume, int verbose);                                   /* vnrNeuralVolumeGetPSNR */
+/* vnrNeuralVolumeGetSSIM (api.h:130 -> network.cu:474-549 get_mssim): mean SSIM of the network against the reference volume at the
+ * voxel centres, 7^3 uniform windows, sample covariance, K1 .01, K2 .03, data range 1; -1 on error */
+double vnrAmdNeuralVolumeGetSSIM(vnrAmdVolume, int verbose);
 double vnrAmdNeuralVolumeGetTestingLoss(vnrAmdVolume);                                         /* vnrNeuralVolumeGetTestingLoss */
 double vnrAmdNeuralVolumeGetTrainingLoss(vnrAmdVolume);                                        /* vnrNeuralVolumeGetTrainingLoss */
 int    vnrAmdNeuralVolumeGetTrainingStep(vnrAmdVolume);                                        /* vnrNeuralVolumeGetTrainingStep */

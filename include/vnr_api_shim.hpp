@@ -164,6 +164,7 @@ inline vnrVolume vnrCreateNeuralVolume(const vnrJson& params)
 inline void vnrNeuralVolumeSetModel(vnrVolume v, const vnrJson& config) { vnr::shim::JsonArg a(config, false); vnr::shim::check(vnrAmdNeuralVolumeSetModel(v.get(), a.data(), a.size(), a.format)); }
 inline void vnrNeuralVolumeSetParams(vnrVolume v, const vnrJson& params) { vnr::shim::JsonArg a(params, true); vnr::shim::check(vnrAmdNeuralVolumeSetParams(v.get(), a.data(), a.size(), a.format)); }
 inline double vnrNeuralVolumeGetPSNR(vnrVolume v, bool verbose) { return vnrAmdNeuralVolumeGetPSNR(v.get(), verbose); }
+inline double vnrNeuralVolumeGetSSIM(vnrVolume v, bool verbose) { return vnrAmdNeuralVolumeGetSSIM(v.get(), verbose); }  // api.h:130
 inline double vnrNeuralVolumeGetTestingLoss(vnrVolume v) { return vnrAmdNeuralVolumeGetTestingLoss(v.get()); }
 inline double vnrNeuralVolumeGetTrainingLoss(vnrVolume v) { return vnrAmdNeuralVolumeGetTrainingLoss(v.get()); }
 inline int vnrNeuralVolumeGetTrainingStep(vnrVolume v) { return vnrAmdNeuralVolumeGetTrainingStep(v.get()); }

@@ -108,6 +108,7 @@ def lib():
     sig("vnrAmdNeuralVolumeSetModel", I, P, P, SZ, I)
     sig("vnrAmdNeuralVolumeSetParams", I, P, P, SZ, I)
     sig("vnrAmdNeuralVolumeGetPSNR", D, P, I)
+    sig("vnrAmdNeuralVolumeGetSSIM", D, P, I)
     sig("vnrAmdNeuralVolumeGetTestingLoss", D, P)
     sig("vnrAmdNeuralVolumeGetTrainingLoss", D, P)
     sig("vnrAmdNeuralVolumeGetTrainingStep", I, P)

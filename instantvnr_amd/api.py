@@ -259,6 +259,13 @@ def vnrNeuralVolumeGetPSNR(v, verbose=False):
     return r
 
 
+def vnrNeuralVolumeGetSSIM(v, verbose=False):
+    r = lib().vnrAmdNeuralVolumeGetSSIM(v.h, 1 if verbose else 0)
+    if r == -1.0:
+        raise VnrAmdError(_lib.last_error())
+    return r
+
+
 def vnrNeuralVolumeGetTestingLoss(v):
     r = lib().vnrAmdNeuralVolumeGetTestingLoss(v.h)
     if r == -1.0:

@@ -365,6 +365,12 @@ double vnrAmdNeuralVolumeGetPSNR(vnrAmdVolume v, int verbose)
   guarded([&]() { r = as_neural(v)->get_psnr(!verbose); });
   return r;
 }
+double vnrAmdNeuralVolumeGetSSIM(vnrAmdVolume v, int verbose)
+{
+  double r = -1.0;  // SSIM itself lies in (-1, 1]; -1 doubles as the error value like the reference's get_mssim
+  guarded([&]() { r = as_neural(v)->get_ssim(!verbose); });
+  return r;
+}
 double vnrAmdNeuralVolumeGetTestingLoss(vnrAmdVolume v)
 {
   double r = -1.0;

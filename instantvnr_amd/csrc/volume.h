@@ -143,6 +143,7 @@ public:
   void forward_backward(const float* d_coords, const float* d_targets, size_t n);  // caller-provided batch
   float test_loss();                                        // network.cu:261-288
   float get_psnr(bool quiet);                               // network.cu:410-472
+  float get_ssim(bool quiet);                               // network.cu:474-549 (get_mssim: mean SSIM, 7^3 uniform windows)
   void inference(size_t n, const float* d_in, float* d_out, hipStream_t s);  // network.cu:1043-1052
   int num_blobs() const { return (desc.dims.z + 15) / 16; } // network.cu:969-975
   // Decoding (rendering modes 4 / 7 on a neural volume march the DECODED dense volume).  One call decodes one blob of 16

@@ -655,6 +655,80 @@ float NeuralVolume::get_psnr(bool /*quiet*/)
   return (float)(10.0 * std::log10(range * range / mse));  // network.cu:469-471
 }
 
+// compute_ssim<7> (network.cu:70-127): SSIM of one 7^3 uniform window per output voxel, reference fx vs inference fy on a
+// block grid with a 3-voxel halo; sample covariance (cov_norm = NP / (NP - 1)), C1 = (K1 R)^2, C2 = (K2 R)^2.  The block's
+// sum is reduced here (the reference writes the map and thrust-reduces it in fp32; the sum is kept in fp64 here).
+__global__ void ssim_block_kernel(vec3i block, vec3i gdims, const float* __restrict__ fx_, const float* __restrict__ fy_, float data_range,
+                                  float cov_norm, float K1, float K2, double* __restrict__ sum)
+{
+  constexpr int W = 7;
+  __shared__ double red[256];
+  const uint32_t n = (uint32_t)block.x * block.y * block.z;
+  double acc = 0.0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int x = (int)(i % (uint32_t)block.x), y = (int)((i / (uint32_t)block.x) % (uint32_t)block.y), z = (int)(i / ((uint32_t)block.x * block.y));
+    float ux = 0.f, uy = 0.f, uxx = 0.f, uyy = 0.f, uxy = 0.f;
+    for (int kz = 0; kz < W; ++kz)
+      for (int ky = 0; ky < W; ++ky)
+        for (int kx = 0; kx < W; ++kx) {
+          const uint32_t g = (uint32_t)(x + kx) + (uint32_t)(y + ky) * gdims.x + (uint32_t)(z + kz) * gdims.x * gdims.y;
+          const float fx = fx_[g], fy = fy_[g];
+          ux += fx; uy += fy; uxx += fx * fx; uyy += fy * fy; uxy += fx * fy;
+        }
+    const float w = 1.f / (W * W * W);  // uniform filter
+    ux *= w; uy *= w; uxx *= w; uyy *= w; uxy *= w;
+    const float vx = cov_norm * (uxx - ux * ux), vy = cov_norm * (uyy - uy * uy), vxy = cov_norm * (uxy - ux * uy);
+    const float R = data_range, C1 = (K1 * R) * (K1 * R), C2 = (K2 * R) * (K2 * R);
+    const float A1 = 2 * ux * uy + C1, A2 = 2 * vxy + C2, B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
+    acc += (double)((A1 * A2) / (B1 * B2));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(sum, red[0]);
+}
+
+// get_mssim (network.cu:474-549): mean SSIM over the interior (dims - 6 per axis), blocks of <= 4096 x 16 x 16 voxels plus halo
+float NeuralVolume::get_ssim(bool /*quiet*/)
+{
+  if (!source_) throw std::runtime_error("missing a reference volume");  // the reference prints this and returns -1
+  if (!net_.valid()) throw std::runtime_error("neural volume has no valid network");
+  constexpr int win = 7, crop = win >> 1, NP = win * win * win;
+  const float K1 = 0.01f, K2 = 0.03f, data_range = 1.0f, cov_norm = (float)NP / (float)(NP - 1);
+  const vec3i dims = desc.dims;
+  if (dims.x < win || dims.y < win || dims.z < win) throw std::runtime_error("volume smaller than the 7^3 SSIM window");
+  const vec3f rdims = {1.0f / (float)dims.x, 1.0f / (float)dims.y, 1.0f / (float)dims.z};
+  const vec3i batch = {std::min(4096, dims.x), std::min(16, dims.y), std::min(16, dims.z)};
+  const size_t grid_cap = (size_t)(batch.x + win - 1) * (batch.y + win - 1) * (batch.z + win - 1);
+  DeviceBuffer<float> coords, pred, ref;
+  DeviceBuffer<double> sum;
+  coords.resize(3 * grid_cap); pred.resize(grid_cap); ref.resize(grid_cap);
+  sum.resize(1); sum.zero(stream);
+  for (int z = crop; z < dims.z - crop; z += batch.z)
+    for (int y = crop; y < dims.y - crop; y += batch.y)
+      for (int x = crop; x < dims.x - crop; x += batch.x) {
+        const vec3i off = {x, y, z};
+        const vec3i blk = {std::min(batch.x, dims.x - crop - x), std::min(batch.y, dims.y - crop - y), std::min(batch.z, dims.z - crop - z)};
+        if (blk.x <= 0 || blk.y <= 0 || blk.z <= 0) continue;
+        const vec3i goff = {off.x - crop, off.y - crop, off.z - crop};
+        const vec3i gblk = {blk.x + win - 1, blk.y + win - 1, blk.z + win - 1};
+        const size_t gcount = (size_t)gblk.x * gblk.y * gblk.z;
+        source_->take_samples_grid(coords.ptr, ref.ptr, goff, gblk, rdims, stream);
+        net_.inference(coords.ptr, pred.ptr, gcount, nullptr, gcount, stream);
+        const uint32_t n = (uint32_t)blk.x * blk.y * blk.z;
+        ssim_block_kernel<<<std::min<uint32_t>(div_round_up(n, 256), 2048u), 256, 0, stream>>>(blk, gblk, ref.ptr, pred.ptr, data_range, cov_norm, K1, K2,
+                                                                                              sum.ptr);
+        VNR_HIP_CHECK(hipGetLastError());
+      }
+  double total = 0.0;
+  VNR_HIP_CHECK(hipMemcpyAsync(&total, sum.ptr, sizeof(double), hipMemcpyDeviceToHost, stream));
+  VNR_HIP_CHECK(hipStreamSynchronize(stream));
+  return (float)(total / ((double)(dims.x - win + 1) * (dims.y - win + 1) * (dims.z - win + 1)));
+}
+
 void NeuralVolume::inference(size_t n, const float* d_in, float* d_out, hipStream_t s)
 {
   if (!net_.valid()) return;

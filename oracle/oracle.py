@@ -414,3 +414,29 @@ def psnr(pred, ref, ref_min=None, ref_max=None):
     hi = float(ref.max()) if ref_max is None else ref_max
     return float(lib().vnro_psnr(_p(pred, C.c_float), _p(ref, C.c_float), C.c_size_t(pred.size), C.c_float(lo),
                                  C.c_float(hi)))
+
+
+def mssim(pred, ref, data_range=1.0, win=7, k1=0.01, k2=0.03):
+    """get_mssim / compute_ssim<7> (core/network.cu:474-549, :70-127): mean SSIM of `pred` against `ref` (volumes [z, y, x]
+    sampled at the voxel centres) over the interior, one win^3 UNIFORM window per voxel, sample covariance
+    (cov_norm = NP / (NP - 1)), C1 = (k1 R)^2, C2 = (k2 R)^2.  float64 (the reference sums the fp32 map in fp32)."""
+    x = np.asarray(ref, dtype=np.float64)
+    y = np.asarray(pred, dtype=np.float64)
+    assert x.shape == y.shape and min(x.shape) >= win
+
+    def box(a):  # mean over every win^3 window ("valid"), via cumulative sums along each axis
+        for ax in range(3):
+            c = np.cumsum(a, axis=ax)
+            c = np.concatenate([np.zeros_like(np.take(c, [0], axis=ax)), c], axis=ax)
+            hi = np.take(c, np.arange(win, c.shape[ax]), axis=ax)
+            lo = np.take(c, np.arange(0, c.shape[ax] - win), axis=ax)
+            a = (hi - lo) / win
+        return a
+
+    ux, uy, uxx, uyy, uxy = box(x), box(y), box(x * x), box(y * y), box(x * y)
+    n_p = win ** 3
+    cov_norm = n_p / (n_p - 1.0)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+    return float(s.mean())

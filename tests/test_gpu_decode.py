@@ -121,3 +121,41 @@ def test_decode_to_files_with_padded_slices(oracle, tmp_path):
     assert np.array_equal(file_ref, oracle.sample_volume(ref, gc, nodal=False).reshape(nz, ny, nx))
     assert np.abs(file_ref - ref).max() < 1e-5, np.abs(file_ref - ref).max()
     assert np.all(got[:, xy:] == 0)
+
+
+def test_ssim_matches_numpy_restatement_and_rises_with_training(oracle):
+    """vnrNeuralVolumeGetSSIM (api.h:130, network.cu:474-549).  The library's value against oracle.mssim on the SAME data: the
+    volume the library decodes at the voxel centres and the reference sampled there, so only the SSIM arithmetic and the
+    halo-block bookkeeping are compared (fp32 window sums vs float64: stated tolerance 2e-4).  Non-cubic volume, several
+    blocks in y and z."""
+    nx, ny, nz = 50, 37, 21
+    z, y, x = np.meshgrid(np.linspace(0, 1, nz), np.linspace(0, 1, ny), np.linspace(0, 1, nx), indexing="ij")
+    raw = (0.5 + 0.5 * np.sin(5.0 * x + 1.0) * np.cos(3.0 * y) * np.sin(2.0 * z + 0.5)).astype(np.float32)
+    sv = api.vnrCreateSimpleVolume(raw)
+    lo, hi = np.float32(raw.min()), np.float32(raw.max())
+    ref = np.clip((raw - lo) / (hi - lo), np.float32(0), np.float32(1)).astype(np.float32)
+    gc = oracle.grid_coords((0, 0, 0), (nx, ny, nz), (1.0 / nx, 1.0 / ny, 1.0 / nz))
+    ref_at_centres = oracle.sample_volume(ref, gc, nodal=False).reshape(nz, ny, nx)
+
+    def decoded(nv):
+        for _ in range(api.vnrNeuralVolumeGetNumberOfBlobs(nv)):
+            api.vnrNeuralVolumeDecodeProgressive(nv)
+        return api.neural_decoded_volume(nv, (nx, ny, nz))
+
+    # (1) random parameters: a low but well-defined SSIM
+    nv, _ = neural_volume(oracle, sv, seed=33)
+    got = api.vnrNeuralVolumeGetSSIM(nv)
+    want = oracle.mssim(decoded(nv), ref_at_centres)
+    assert abs(got - want) < 2e-4, (got, want)
+    assert -1.0 < got < 0.5
+
+    # (2) a trained network: much higher, and still the same number as the restatement
+    import os
+    os.environ["VNR_AMD_INIT_SEED"] = "5"
+    cfg = syn.model_config(n_levels=6, n_features=4, log2_hashmap_size=14, base_resolution=4, n_hidden_layers=2)
+    tv = api.vnrCreateNeuralVolume(cfg, sv)
+    before = api.vnrNeuralVolumeGetSSIM(tv)
+    api.vnrNeuralVolumeTrain(tv, 400, True)
+    after = api.vnrNeuralVolumeGetSSIM(tv)
+    assert abs(after - oracle.mssim(decoded(tv), ref_at_centres)) < 2e-4
+    assert after > 0.9 and after > before + 0.3, (before, after)

@@ -208,3 +208,26 @@ def test_network_inference_is_encode_then_mlp(oracle):
     enc = oracle.grid_encode(cfg, params[n_mlp:].view(np.uint16), coords)
     out2 = oracle.mlp_forward(params[:n_mlp].view(np.uint16), 16, W, H - 1, enc)
     assert np.array_equal(out, out2)
+
+
+def test_mssim_known_answers_and_explicit_loop(oracle):
+    """get_mssim (network.cu:474-549): identical volumes -> 1; two constant volumes a, b -> (2ab + C1) / (a^2 + b^2 + C1)
+    (all variances vanish, the C2 terms cancel); and the cumulative-sum box filter equals an explicit 7^3 loop."""
+    rng = np.random.default_rng(4)
+    a = rng.random((9, 10, 11))
+    assert oracle.mssim(a, a) == pytest.approx(1.0, abs=1e-12)
+    c1 = 0.01 ** 2
+    assert oracle.mssim(np.full((8, 8, 8), 0.3), np.full((8, 8, 8), 0.7)) == pytest.approx((2 * 0.3 * 0.7 + c1) / (0.09 + 0.49 + c1), abs=1e-12)
+    b = np.clip(a + 0.1 * rng.standard_normal(a.shape), 0, 1)
+    n_p, c2 = 343, 0.03 ** 2
+    acc = []
+    for z in range(a.shape[0] - 6):
+        for y in range(a.shape[1] - 6):
+            for x in range(a.shape[2] - 6):
+                wx, wy = a[z:z + 7, y:y + 7, x:x + 7].ravel(), b[z:z + 7, y:y + 7, x:x + 7].ravel()
+                ux, uy = wx.mean(), wy.mean()
+                vx, vy = wx.var(ddof=1), wy.var(ddof=1)                  # sample covariance = NP / (NP - 1) x population
+                vxy = ((wx - ux) * (wy - uy)).sum() / (n_p - 1)
+                acc.append((2 * ux * uy + c1) * (2 * vxy + c2) / ((ux * ux + uy * uy + c1) * (vx + vy + c2)))
+    assert oracle.mssim(b, a) == pytest.approx(np.mean(acc), abs=1e-10)     # mssim(pred, ref); SSIM is symmetric
+    assert oracle.mssim(b, a) < 0.99

@@ -120,6 +120,23 @@ vnrAmdVolume vnrAmdCreateSimpleVolumeFromRawFile(const char* filename, const int
 vnrAmdVolume vnrAmdCreateSimpleVolumePerlin(const int dims[3], uint32_t seed, int octaves, float base_frequency);
 /* device pointer to the normalised fp32 voxels, x fastest */
 const float* vnrAmdSimpleVolumeDeviceData(vnrAmdVolume);
+/* vnrCreateSimpleVolume(scene, "OUT_OF_CORE") (api.cpp:145-158 -> neural_sampler.cpp:1224-1227, 1043-1064): the volume stays
+ * in its file; a random set of n_blocks slabs is resident in HBM and n_concurrent_blocks of them are replaced per
+ * training step (RandomBuffer, neural_sampler.cpp:477-668).  0 for a count = the reference's default, i.e. the
+ * environment variables VNR_NUM_CONCURRENT_BLOCKS (1024) / VNR_NUM_BLOCKS (64 x) (neural_sampler.cpp:1054-1062).
+ * A value range is required (range_lo < range_hi; :1069-1071).  Such a volume has no ground-truth macrocell and cannot
+ * be rendered itself; it feeds vnrAmdCreateNeuralVolume, whose grid is min(1024, dims) per axis. */
+vnrAmdVolume vnrAmdCreateSimpleVolumeOutOfCore(const char* filename, const int dims[3], int value_type, size_t offset,
+                                               float range_lo, float range_hi, uint64_t n_concurrent_blocks, uint64_t n_blocks);
+typedef struct vnrAmdOutOfCoreInfo {
+  int file_dims[3];            /* dims of the volume in the file */
+  int block_dims[3];           /* slab proper: x-full, rows, 1 slice (RandomBuffer ctor :531-546) */
+  int block_index_space[3];
+  uint64_t n_blocks, n_concurrent_blocks, block_size_aligned, bytes_read;
+} vnrAmdOutOfCoreInfo;
+int  vnrAmdSimpleVolumeOutOfCoreInfo(vnrAmdVolume, vnrAmdOutOfCoreInfo*);
+/* the slot table the next TakeSamples call will sample from: block index (y, z) per slot, 2 ints each (AMD extension, tests) */
+int  vnrAmdSimpleVolumeOutOfCoreBlocks(vnrAmdVolume, int* block_index_yz, size_t n_slots);
 
 /* ---- neural volume (api.h:122-143) ---------------------------------------- */
 /* vnrCreateNeuralVolume(config, groundtruth, online_macrocell_construction) api.cpp:174-188 */
@@ -233,6 +250,10 @@ void vnrAmdFreeTemporaryGPUMemory(void);                                   /* vn
 /* StaticSampler::sample (neural_sampler.cu:130-164): n uniform coords in [lower,upper] + cell-centred trilinear values */
 int  vnrAmdSimpleVolumeTakeSamples(vnrAmdVolume, size_t n, const float lower[3], const float upper[3],
                                    float* d_coords, float* d_values, void* stream);
+/* SamplerAPI::sample_grid (neural_sampler.cu:166-198; out-of-core: sample_streaming_grid, neural_sampler.cpp:967-1035):
+ * voxel-centre coordinates of the block [origin, origin + size) of the volume's grid and the ground truth there */
+int  vnrAmdSimpleVolumeTakeSamplesGrid(vnrAmdVolume, const int origin[3], const int size[3], float* d_coords, float* d_values,
+                                       void* stream);
 /* trilinear lookup of given coords; nodal = 1 is the renderer's sampleVolume (raytracing.h:105-110),
  * nodal = 0 the sampler's tex3D (neural_sampler.cu:182-185) */
 int  vnrAmdSimpleVolumeSample(vnrAmdVolume, size_t n, const float* d_coords, float* d_values, int nodal, void* stream);

@@ -45,6 +45,12 @@ class FrameStats(C.Structure):
                 ("n_rays_hit", C.c_uint32), ("infer_kernel_ms", C.c_double), ("infer_kernel_launches", C.c_uint64)]
 
 
+class OutOfCoreInfo(C.Structure):
+    _fields_ = [("file_dims", C.c_int * 3), ("block_dims", C.c_int * 3), ("block_index_space", C.c_int * 3),
+                ("n_blocks", C.c_uint64), ("n_concurrent_blocks", C.c_uint64), ("block_size_aligned", C.c_uint64),
+                ("bytes_read", C.c_uint64)]
+
+
 def declared_symbols():
     """every function name declared in include/vnr_amd.h"""
     text = open(HEADER).read()
@@ -102,6 +108,9 @@ def lib():
     sig("vnrAmdCreateSimpleVolumeFromRawFile", P, C.c_char_p, IP, I, SZ, I, F, F)
     sig("vnrAmdCreateSimpleVolumePerlin", P, IP, U32, I, F)
     sig("vnrAmdSimpleVolumeDeviceData", P, P)
+    sig("vnrAmdCreateSimpleVolumeOutOfCore", P, C.c_char_p, IP, I, SZ, F, F, U64, U64)
+    sig("vnrAmdSimpleVolumeOutOfCoreInfo", I, P, C.POINTER(OutOfCoreInfo))
+    sig("vnrAmdSimpleVolumeOutOfCoreBlocks", I, P, IP, SZ)
     sig("vnrAmdCreateNeuralVolume", P, P, SZ, I, P, I)
     sig("vnrAmdCreateNeuralVolumeFromDims", P, P, SZ, I, IP)
     sig("vnrAmdCreateNeuralVolumeFromParams", P, P, SZ, I)
@@ -159,6 +168,7 @@ def lib():
     sig("vnrAmdMemoryQuery", None, C.POINTER(SZ), C.POINTER(SZ))
     sig("vnrAmdFreeTemporaryGPUMemory", None)
     sig("vnrAmdSimpleVolumeTakeSamples", I, P, SZ, FP, FP, P, P, P)
+    sig("vnrAmdSimpleVolumeTakeSamplesGrid", I, P, IP, IP, P, P, P)
     sig("vnrAmdSimpleVolumeSample", I, P, SZ, P, P, I, P)
     sig("vnrAmdNeuralVolumeUpdateMacrocell", I, P, SZ, P, P, P)
     sig("vnrAmdVolumeUpdateMaxOpacity", I, P, P)

@@ -216,6 +216,32 @@ def vnrCreateSimpleVolumeFromRawFile(filename, dims, dtype, offset=0, big_endian
                                                                1 if big_endian else 0, lo, hi))
 
 
+def vnrCreateSimpleVolumeOutOfCore(filename, dims, dtype, value_range, offset=0, n_concurrent_blocks=0, n_blocks=0):
+    """vnrCreateSimpleVolume(scene, "OUT_OF_CORE") (api.cpp:145-158): the volume stays in `filename`; 0 block counts = the
+    reference's defaults / environment variables (neural_sampler.cpp:1054-1062)"""
+    d = (C.c_int * 3)(*[int(v) for v in dims])
+    lo, hi = value_range
+    return vnrVolume(check_ptr(lib().vnrAmdCreateSimpleVolumeOutOfCore(str(filename).encode(), d, VALUE_TYPES[np.dtype(dtype)], offset,
+                                                                       lo, hi, n_concurrent_blocks, n_blocks)))
+
+
+def out_of_core_info(v):
+    info = _lib.OutOfCoreInfo()
+    check(lib().vnrAmdSimpleVolumeOutOfCoreInfo(v.h, C.byref(info)))
+    return {"file_dims": tuple(info.file_dims), "block_dims": tuple(info.block_dims),
+            "block_index_space": tuple(info.block_index_space), "n_blocks": info.n_blocks,
+            "n_concurrent_blocks": info.n_concurrent_blocks, "block_size_aligned": info.block_size_aligned,
+            "bytes_read": info.bytes_read}
+
+
+def out_of_core_blocks(v):
+    """block index (y, z) of every resident slot, as the next take_samples call will see them"""
+    n = out_of_core_info(v)["n_blocks"]
+    a = np.zeros((n, 2), np.int32)
+    check(lib().vnrAmdSimpleVolumeOutOfCoreBlocks(v.h, a.ctypes.data_as(C.POINTER(C.c_int)), n))
+    return a
+
+
 def vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=4.0):
     d = (C.c_int * 3)(*[int(v) for v in dims])
     return vnrVolume(lib().vnrAmdCreateSimpleVolumePerlin(d, seed, octaves, base_frequency))
@@ -331,6 +357,12 @@ def vnrVolumeSetClippingBox(v, lower, upper):
 
 def vnrVolumeSetScaling(v, scale):
     check(lib().vnrAmdVolumeSetScaling(v.h, _fp(_vec(scale))))
+
+
+def vnrVolumeGetDims(v):
+    d = (C.c_int * 3)()
+    check(lib().vnrAmdVolumeGetDims(v.h, d))
+    return tuple(d)
 
 
 def vnrVolumeGetValueRange(v):
@@ -501,6 +533,16 @@ def simple_volume_sample(v, coords, nodal):
     check(lib().vnrAmdSimpleVolumeSample(v.h, c.shape[0], c.ptr, o.ptr, 1 if nodal else 0, None))
     check(lib().vnrAmdSynchronize())
     return o.numpy()
+
+
+def simple_volume_take_samples_grid(v, origin, size):
+    n = int(size[0]) * int(size[1]) * int(size[2])
+    c = DeviceArray((n, 3), np.float32)
+    o = DeviceArray((n,), np.float32)
+    check(lib().vnrAmdSimpleVolumeTakeSamplesGrid(v.h, (C.c_int * 3)(*[int(x) for x in origin]), (C.c_int * 3)(*[int(x) for x in size]),
+                                                  c.ptr, o.ptr, None))
+    check(lib().vnrAmdSynchronize())
+    return c.numpy(), o.numpy()
 
 
 def simple_volume_take_samples(v, n, lower=(0, 0, 0), upper=(1, 1, 1)):

@@ -301,6 +301,50 @@ vnrAmdVolume vnrAmdCreateSimpleVolumePerlin(const int dims[3], uint32_t seed, in
     return h;
   });
 }
+vnrAmdVolume vnrAmdCreateSimpleVolumeOutOfCore(const char* filename, const int dims[3], int value_type, size_t offset, float lo, float hi,
+                                               uint64_t n_concurrent_blocks, uint64_t n_blocks)
+{
+  return guarded_new<vnrAmdVolume_t>([&]() {
+    // neural_sampler.cpp:1054-1062
+    uint64_t ncb = n_concurrent_blocks, nb = n_blocks;
+    if (ncb == 0) {
+      ncb = 1024;
+      if (const char* e = std::getenv("VNR_NUM_CONCURRENT_BLOCKS")) ncb = (uint64_t)std::max(1, std::atoi(e));
+    }
+    if (nb == 0) {
+      nb = ncb * 64;
+      if (const char* e = std::getenv("VNR_NUM_BLOCKS")) nb = (uint64_t)std::max(1, std::atoi(e));
+    }
+    auto sv = std::make_shared<SimpleVolume>();
+    sv->load_out_of_core(filename, {dims[0], dims[1], dims[2]}, value_type, offset, lo, hi, ncb, nb);
+    auto* h = new vnrAmdVolume_t();
+    h->v = sv;
+    return h;
+  });
+}
+int vnrAmdSimpleVolumeOutOfCoreInfo(vnrAmdVolume v, vnrAmdOutOfCoreInfo* info)
+{
+  return guarded([&]() {
+    OutOfCoreSampler* o = as_simple(v)->out_of_core();
+    if (!o) throw std::runtime_error("not an out-of-core volume");
+    const vec3i d = o->dims(), b = o->block_dims(), g = o->block_index_space();
+    info->file_dims[0] = d.x; info->file_dims[1] = d.y; info->file_dims[2] = d.z;
+    info->block_dims[0] = b.x; info->block_dims[1] = b.y; info->block_dims[2] = b.z;
+    info->block_index_space[0] = g.x; info->block_index_space[1] = g.y; info->block_index_space[2] = g.z;
+    info->n_blocks = o->n_blocks(); info->n_concurrent_blocks = o->n_concurrent_blocks();
+    info->block_size_aligned = o->block_size_aligned(); info->bytes_read = o->bytes_read();
+  });
+}
+int vnrAmdSimpleVolumeOutOfCoreBlocks(vnrAmdVolume v, int* block_index_yz, size_t n_slots)
+{
+  return guarded([&]() {
+    OutOfCoreSampler* o = as_simple(v)->out_of_core();
+    if (!o) throw std::runtime_error("not an out-of-core volume");
+    const std::vector<OocBlock> b = o->blocks();
+    if (n_slots != b.size()) throw std::runtime_error("slot count mismatch");
+    for (size_t i = 0; i < b.size(); ++i) { block_index_yz[2 * i] = b[i].index_y; block_index_yz[2 * i + 1] = b[i].index_z; }
+  });
+}
 const float* vnrAmdSimpleVolumeDeviceData(vnrAmdVolume v)
 {
   const float* p = nullptr;
@@ -633,6 +677,15 @@ int vnrAmdSimpleVolumeTakeSamples(vnrAmdVolume v, size_t n, const float lower[3]
 {
   return guarded([&]() {
     as_simple(v)->take_samples(d_coords, d_values, n, {lower[0], lower[1], lower[2]}, {upper[0], upper[1], upper[2]}, resolve_stream(stream));
+  });
+}
+int vnrAmdSimpleVolumeTakeSamplesGrid(vnrAmdVolume v, const int origin[3], const int size[3], float* d_coords, float* d_values, void* stream)
+{
+  return guarded([&]() {
+    SimpleVolume* sv = as_simple(v);
+    const vec3i d = sv->dims();
+    sv->take_samples_grid(d_coords, d_values, {origin[0], origin[1], origin[2]}, {size[0], size[1], size[2]},
+                          {1.0f / (float)d.x, 1.0f / (float)d.y, 1.0f / (float)d.z}, resolve_stream(stream));
   });
 }
 int vnrAmdSimpleVolumeSample(vnrAmdVolume v, size_t n, const float* d_coords, float* d_values, int nodal, void* stream)

@@ -44,7 +44,8 @@ struct RenderParams {
   int width, height, frame_index;
   uint32_t pixel_lo, pixel_hi;
   uint32_t il_parts, il_part, n_local;   // tile-row interleave across ranks; n_local = local index count
-  uint32_t tiles_per_row, tile_row0;     // 8x8 pixel tiles: rays of a wave are an image patch, not a scanline
+  uint32_t tiles_per_row, tile_row0;     // 64-pixel tiles per band of 8 scanlines: rays of a wave are an image patch, not a scanline
+  uint32_t tile_w_log2;                  // tile shape: 2^tile_w_log2 x 2^(6 - tile_w_log2) pixels (8x8, 16x4, 32x2 or 64x1)
   float bin_depth_rcp;                   // 1 / depth of one sample-sorting bin (world units)
   uint32_t tfn_in_lds;                   // the TFN tables fit in the march kernel's LDS
   uint32_t debug_flags;                  // timing ablations only (VNR_AMD_DEBUG_FLAGS): 1 no compose, 2 no TFN, 4 no sort
@@ -106,13 +107,16 @@ __device__ __forceinline__ void compute_ray(const RenderParams& p, uint32_t pixe
 }
 
 // local work index -> global pixel index of this rank's share of the image.  64 consecutive indices are one
-// 8x8 pixel tile; tile rows are dealt round-robin to the ranks (il_parts, il_part); a pixel range restricts further.
+// TW x TH pixel tile (TW TH = 64, TH <= 8); the 8 / TH tiles stacked in one band of 8 scanlines follow each other, then the
+// next column of the band.  Bands are dealt round-robin to the ranks (il_parts, il_part); a pixel range restricts further.
 __device__ __forceinline__ bool map_pixel(const RenderParams& p, uint32_t i, uint32_t& pixel)
 {
   const uint32_t tile = i >> 6, l = i & 63u;
-  const uint32_t tr_local = tile / p.tiles_per_row, tc = tile - tr_local * p.tiles_per_row;
-  const uint32_t x = tc * 8u + (l & 7u);
-  const uint32_t y = (p.tile_row0 + tr_local * p.il_parts + p.il_part) * 8u + (l >> 3);
+  const uint32_t tr_local = tile / p.tiles_per_row, t = tile - tr_local * p.tiles_per_row;
+  const uint32_t twl = p.tile_w_log2, sub_log2 = twl - 3u;   // 8 / TH = TW / 8 stacked tiles per band column
+  const uint32_t tc = t >> sub_log2, ts = t & ((1u << sub_log2) - 1u);
+  const uint32_t x = (tc << twl) + (l & ((1u << twl) - 1u));
+  const uint32_t y = (p.tile_row0 + tr_local * p.il_parts + p.il_part) * 8u + (ts << (6u - twl)) + (l >> twl);
   pixel = y * (uint32_t)p.width + x;
   return x < (uint32_t)p.width && y < (uint32_t)p.height && pixel >= p.pixel_lo && pixel < p.pixel_hi;
 }
@@ -287,6 +291,12 @@ __device__ __forceinline__ void iter_exec(const RenderParams& p, DDAState& it, v
   while (dda_next(it, m_dir, t_min, t_max, p.mc_dims, cell_fn)) {}
 }
 
+// depth bin of a sample inside its 64-ray group (gather-order counting sort of march_kernel)
+__device__ __forceinline__ uint32_t depth_bin(const RenderParams& p, float t, float front)
+{
+  return (p.debug_flags & 4u) ? 0u : min((uint32_t)kDepthBins - 1u, (uint32_t)fmaxf((t - front) * p.bin_depth_rcp, 0.0f));
+}
+
 // ------------------------------------------------------------------------------------------------ streaming march kernel
 // FIRST: thread = pixel of an 8x8 pixel tile (raygen, method_raymarching.cu:840-875) and emits the first batch.
 // !FIRST: thread = alive ray: compose the batch inferred last iteration (:732-838), then emit the next (:687-730).
@@ -306,15 +316,15 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
                                                     const vec2f* __restrict__ vd_in, vec4f* __restrict__ queue,
                                                     vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters, int parity)
 {
-  extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1, bin|rank}, histogram[256], then the transfer function tables
+  extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1}, histogram[256], [n_iters][256] ranks (u16), then the transfer function tables
   float* s_t0 = s_t;
   float* s_t1 = s_t + (size_t)p.n_iters * 256;
-  uint32_t* s_br = (uint32_t*)(s_t + (size_t)2 * p.n_iters * 256);
-  uint32_t* s_hist = s_br + (size_t)p.n_iters * 256;
+  uint32_t* s_hist = (uint32_t*)(s_t + (size_t)2 * p.n_iters * 256);
+  uint16_t* s_rk = (uint16_t*)(s_hist + 256);   // rank of a sample inside its depth bin (< 64 n_iters); the bin is recomputed
   // the TFN tables are read 4x per composed sample: keep them in LDS (no TA traffic) when they fit
   DeviceTfn tfn = p.tfn;
   if (!FIRST && p.tfn_in_lds) {
-    vec4f* s_colors = (vec4f*)(s_hist + 256);
+    vec4f* s_colors = (vec4f*)(s_rk + (size_t)p.n_iters * 256);
     float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
     for (int e = threadIdx.x; e < p.tfn.n_colors; e += blockDim.x) s_colors[e] = p.tfn.colors[e];
     for (int e = threadIdx.x; e < p.tfn.n_alphas; e += blockDim.x) s_alphas[e] = p.tfn.alphas[e];
@@ -436,9 +446,8 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
       for (uint32_t j = 0; j < k; ++j) {
         const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
         const float t = (1.0f - jitter) * t0 + jitter * t1;
-        const uint32_t bin = (p.debug_flags & 4u) ? 0u : min((uint32_t)kDepthBins - 1u, (uint32_t)fmaxf((t - front) * p.bin_depth_rcp, 0.0f));
-        const uint32_t rank = atomicAdd(&hist[bin], 1u);
-        s_br[j * 256u + tid] = (bin << 16) | rank;
+        const uint32_t bin = depth_bin(p, t, front);
+        s_rk[j * 256u + tid] = (uint16_t)atomicAdd(&hist[bin], 1u);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -469,8 +478,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
         const float t = (1.0f - jitter) * t0 + jitter * t1;  // lerp(jitter, t0, t1), instantvnr_types.h:162-166
         const vec3f c = org + t * dir;
-        const uint32_t br = s_br[j * 256u + tid];
-        const uint32_t g = hist[br >> 16] + (br & 0xffffu);  // gather-order slot
+        const uint32_t g = hist[depth_bin(p, t, front)] + s_rk[j * 256u + tid];  // gather-order slot
         // one 16-byte record per evaluation: position + the float index of the result arena its value goes to
         if (GRAD) {
           const uint32_t gi = arena_grad_index(p.slot_cap, sb + j);
@@ -587,6 +595,10 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   if (const char* e = std::getenv("VNR_RM_N_ITERS")) n_iters_ = std::max(1, std::min(48, std::atoi(e)));  // 3 KiB of LDS per iteration slot and block
   // streaming mode runs the rays as two halves on two streams (render_streaming); VNR_AMD_RENDER_HALVES=1: one stream
   if (const char* e = std::getenv("VNR_AMD_RENDER_HALVES")) n_halves_ = std::atoi(e) == 1 ? 1 : 2;
+  if (const char* e = std::getenv("VNR_AMD_TILE_W")) {  // ray tile shape (diagnostics): 8 -> 8x8, 16 -> 16x4, 32 -> 32x2, 64 -> 64x1
+    const int w = std::atoi(e);
+    tile_w_log2_ = w == 16 ? 4u : w == 32 ? 5u : w == 64 ? 6u : 3u;
+  }
   counters_.resize(2 * C_COUNT);  // one block of counters per half
   counters_.zero(stream_);
   VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 2 * 256 * sizeof(uint32_t), hipHostMallocDefault));
@@ -663,7 +675,8 @@ void Renderer::render()
   // rays are generated in 8x8 pixel tiles; tile rows (8 scanlines) are the unit of multi-GPU interleaving
   if (il_parts_ > 1 && il_block_ != 8u * (uint32_t)width_) throw std::runtime_error("pixel interleave block must be 8 scanlines (8 * width pixels)");
   p.il_parts = il_parts_; p.il_part = il_part_;
-  p.tiles_per_row = div_round_up((uint32_t)width_, 8);
+  p.tile_w_log2 = tile_w_log2_;
+  p.tiles_per_row = div_round_up((uint32_t)width_, 1u << p.tile_w_log2) << (p.tile_w_log2 - 3u);
   const uint32_t tr_lo = p.pixel_hi > p.pixel_lo ? (p.pixel_lo / (uint32_t)width_) / 8u : 0u;
   const uint32_t tr_hi = p.pixel_hi > p.pixel_lo ? ((p.pixel_hi - 1u) / (uint32_t)width_) / 8u + 1u : 0u;
   p.tile_row0 = il_parts_ == 1 ? tr_lo : 0u;
@@ -811,7 +824,7 @@ void Renderer::render_streaming(const RenderParams& p_all)
     VNR_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
     VNR_HIP_CHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
   }
-  const size_t shmem = ((size_t)3 * p_all.n_iters + 1) * 256 * sizeof(float);
+  const size_t shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + (size_t)p_all.n_iters * 256 * sizeof(uint16_t);
   const size_t shmem_compose = shmem + (p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0);
   if (shmem_compose > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
   static bool lds_attr_set = false;

@@ -73,6 +73,7 @@ private:
   // LaunchParams::light_directional_dir (instantvnr_types.h:148): a member the reference negates IN PLACE whenever it points
   // along the view direction (renderer.cpp:98-101), so it persists across frames
   vec3f light_dir_ = {0.7f, 0.9f, 0.4f};
+  uint32_t tile_w_log2_ = 3;  // ray tiles of 2^w x 2^(6-w) pixels (render.hip map_pixel)
   int n_halves_ = 2;  // streaming mode: rays dealt to 2 halves on 2 streams (march of one overlaps inference of the other)
   uint32_t predicted_iterations_[2] = {0, 0};
   hipStream_t stream_ = nullptr, stream2_ = nullptr;

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "json.h"
 #include "network.h"
+#include "ooc_sampler.h"
 
 namespace vnr {
 
@@ -104,6 +105,12 @@ public:
   void load_host(const void* data, vec3i dims, int type, float range_lo, float range_hi, bool big_endian = false);
   void load_raw_file(const std::string& filename, vec3i dims, int type, size_t offset, bool big_endian, float range_lo, float range_hi);
   void generate_perlin(vec3i dims, uint32_t seed, int octaves, float base_frequency);
+  // vnrCreateSimpleVolume(scene, "OUT_OF_CORE") (neural_sampler.cpp:1224-1227, 1043-1064): no resident ground truth and no
+  // macrocell; dims() = min(1024, file dims) is the shape a neural volume trained from it takes, the transform is the file's
+  void load_out_of_core(const std::string& filename, vec3i dims, int type, size_t offset, float range_lo, float range_hi,
+                        uint64_t n_concurrent_blocks, uint64_t n_blocks);
+  bool has_data() const { return data_.ptr != nullptr; }   // SimpleVolume::texture() != 0
+  OutOfCoreSampler* out_of_core() { return ooc_.get(); }
 
   const float* d_data() const { return data_.ptr; }
   vec3i dims() const { return desc.dims; }
@@ -119,6 +126,7 @@ public:
 private:
   void finish_load(hipStream_t s);
   DeviceBuffer<float> data_;
+  std::unique_ptr<OutOfCoreSampler> ooc_;
   MacroCell mc_;
   TfnObject tfn_;
   uint64_t rng_seed_ = 1337, rng_stream_ = 0xda3e39cb94b95bdbULL, rng_offset_ = 0;  // neural_sampler.cu:36

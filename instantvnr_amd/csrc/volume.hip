@@ -466,9 +466,26 @@ void SimpleVolume::generate_perlin(vec3i dims, uint32_t seed, int octaves, float
   finish_load(s);
 }
 
+void SimpleVolume::load_out_of_core(const std::string& filename, vec3i dims, int type, size_t offset, float range_lo, float range_hi,
+                                    uint64_t n_concurrent_blocks, uint64_t n_blocks)
+{
+  data_.resize(0);
+  ooc_ = std::make_unique<OutOfCoreSampler>(filename, dims, type, offset, range_lo, range_hi, n_concurrent_blocks, n_blocks);
+  unnormalized_lo = range_lo; unnormalized_hi = range_hi;
+  // Sampler::load (neural_sampler.cpp:1224-1227, 1270): the neural volume's grid is capped at 1024 per axis, the
+  // object -> world map is the file's
+  desc.dims = {std::min(1024, dims.x), std::min(1024, dims.y), std::min(1024, dims.z)};
+  desc.type = type; desc.range_lo = 0.0f; desc.range_hi = 1.0f;
+  const vec3f d = {(float)dims.x, (float)dims.y, (float)dims.z};
+  transform = {{d.x, 0, 0}, {0, d.y, 0}, {0, 0, d.z}, {-d.x / 2.0f, -d.y / 2.0f, -d.z / 2.0f}};
+  clipbox = {{0, 0, 0}, {1, 1, 1}};
+  // no texture => no ground-truth macrocell (core/sampler.cu:11-16)
+}
+
 void SimpleVolume::take_samples(float* d_coords, float* d_values, size_t n, vec3f lower, vec3f upper, hipStream_t s)
 {
   if (n == 0) return;
+  if (ooc_) { ooc_->sample(d_coords, d_values, n, lower, upper, rng_seed_, rng_stream_, rng_offset_, s); return; }
   const vec3f scale = upper - lower;
   take_samples_kernel<<<div_round_up(n, 256), 256, 0, s>>>((uint32_t)n, rng_seed_, rng_stream_, rng_offset_, lower, scale, data_.ptr,
                                                           desc.dims, d_coords, d_values);
@@ -481,12 +498,14 @@ void SimpleVolume::take_samples_grid(float* d_coords, float* d_values, vec3i ori
   const uint32_t n = (uint32_t)((size_t)size.x * size.y * size.z);
   if (n == 0) return;
   generate_coords_kernel<<<div_round_up(n, 256), 256, 0, s>>>(n, origin, size, rdims, d_coords);
+  if (ooc_) { ooc_->sample_grid(d_values, origin, size, rdims, s); return; }
   sample(d_coords, d_values, n, false, s);
 }
 
 void SimpleVolume::sample(const float* d_coords, float* d_values, size_t n, bool nodal, hipStream_t s) const
 {
   if (n == 0) return;
+  if (!data_.ptr) throw std::runtime_error("this volume has no resident ground truth (training mode OUT_OF_CORE)");
   sample_kernel<<<div_round_up(n, 256), 256, 0, s>>>(n, data_.ptr, desc.dims, d_coords, d_values, nodal ? 1 : 0);
   VNR_HIP_CHECK(hipGetLastError());
 }
@@ -546,7 +565,9 @@ void NeuralVolume::set_transfer_function(const TransferFunctionData& t, hipStrea
 void NeuralVolume::set_network(vec3i dims, const Json& config, SimpleVolume* reference, bool use_reference_macrocell)
 {
   source_ = reference;
-  use_reference_macrocell = source_ && use_reference_macrocell;
+  if (use_reference_macrocell && !(source_ && source_->has_data()))  // network.cu:553-560
+    fprintf(stderr, "[vnr] ground truth macrocell unavailable with this training mode\n");
+  use_reference_macrocell = source_ && source_->has_data() && use_reference_macrocell;
   if (source_) {  // network.cu:563-570
     desc.dims = source_->dims();
     transform = source_->transform;

@@ -84,6 +84,7 @@ def lib():
             L.vnro_pcg32_next_float.restype = C.c_float
             L.vnro_dda_trace.restype = C.c_size_t
             L.vnro_psnr.restype = C.c_double
+            L.vnro_ooc_sample.restype = C.c_size_t
             _lib = L
     return _lib
 
@@ -440,3 +441,78 @@ def mssim(pred, ref, data_range=1.0, win=7, k1=0.01, k2=0.03):
     c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
     s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
     return float(s.mean())
+
+
+# --------------------------------------------------------------------------- out-of-core training sampler
+OOC_VALUE_TYPES = {np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.uint16): 2, np.dtype(np.int16): 3,
+                   np.dtype(np.uint32): 4, np.dtype(np.int32): 5, np.dtype(np.float32): 8, np.dtype(np.float64): 12}
+
+
+class OocGeometry(C.Structure):
+    _fields_ = [("dims", C.c_int * 3), ("type", C.c_int), ("elem", C.c_uint32), ("block_dims", C.c_int * 3),
+                ("ghost_dims", C.c_int * 3), ("index_space", C.c_int * 3), ("block_size_aligned", C.c_uint64)]
+
+
+class OocBlock(C.Structure):
+    _fields_ = [("index", C.c_int * 3), ("offset", C.c_uint64), ("length", C.c_uint64), ("bounds_lo", C.c_int * 3),
+                ("bounds_hi", C.c_int * 3), ("ghost_lo", C.c_int * 3), ("ghost_hi", C.c_int * 3)]
+
+
+def ooc_geometry(dims, dtype):
+    g = OocGeometry()
+    if lib().vnro_ooc_geometry_make(_dims(dims), C.c_int(OOC_VALUE_TYPES[np.dtype(dtype)]), C.byref(g)) != 0:
+        raise ValueError("unsupported data type")
+    return g
+
+
+class OocSlabSet:
+    """the resident slab set of RandomBuffer for a volume held in memory: `vol` is [z, y, x] in its file type,
+    `block_index_yz` one (y, z) block index per slot"""
+
+    def __init__(self, vol, block_index_yz):
+        self.vol = np.ascontiguousarray(vol)
+        self.g = ooc_geometry(self.vol.shape[::-1], self.vol.dtype)
+        idx = np.asarray(block_index_yz, dtype=np.int64).reshape(-1, 2)
+        self.n = idx.shape[0]
+        self.blocks = (OocBlock * self.n)()
+        self.data = np.zeros(self.n * self.g.block_size_aligned, np.uint8)
+        file_p = self.vol.ctypes.data_as(C.POINTER(C.c_uint8))
+        for i in range(self.n):
+            bi = (C.c_int * 3)(0, int(idx[i, 0]), int(idx[i, 1]))
+            dst = self.data[i * self.g.block_size_aligned:]
+            if lib().vnro_ooc_load_block(C.byref(self.g), file_p, bi, C.byref(self.blocks[i]), _p(dst, C.c_uint8)) != 0:
+                raise ValueError(f"[aio] invalid block index {tuple(idx[i])}")
+
+    def sample(self, value_range, r_coords, r_bidx, r_vidx, lower=(0, 0, 0), upper=(1, 1, 1)):
+        rc, rb, rv = _f32(r_coords).reshape(-1), _f32(r_bidx), _f32(r_vidx)
+        n = rb.shape[0]
+        coords = np.zeros((n, 3), np.float32)
+        values = np.zeros(n, np.float32)
+        lo3 = (C.c_float * 3)(*[float(v) for v in lower])
+        hi3 = (C.c_float * 3)(*[float(v) for v in upper])
+        bad = lib().vnro_ooc_sample(C.byref(self.g), self.blocks, _p(self.data, C.c_uint8), C.c_uint64(self.n),
+                                    C.c_float(value_range[0]), C.c_float(value_range[1]), _p(rc, C.c_float), _p(rb, C.c_float),
+                                    _p(rv, C.c_float), C.c_size_t(n), lo3, hi3, _p(coords, C.c_float), _p(values, C.c_float))
+        return coords, values, int(bad)
+
+
+def ooc_sample_grid(vol, value_range, origin, size, spacing):
+    vol = np.ascontiguousarray(vol)
+    g = ooc_geometry(vol.shape[::-1], vol.dtype)
+    n = int(size[0]) * int(size[1]) * int(size[2])
+    values = np.zeros(n, np.float32)
+    lib().vnro_ooc_sample_grid(C.byref(g), vol.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_float(value_range[0]),
+                               C.c_float(value_range[1]), _dims(origin), _dims(size),
+                               (C.c_float * 3)(*[float(v) for v in spacing]), _p(values, C.c_float))
+    return values
+
+
+def pcg32_floats(n, offset=0, initstate=1337, initseq=0xda3e39cb94b95bdb):
+    """n consecutive floats of the sampler's pcg32 stream starting at stream position `offset`"""
+    r = pcg32(initstate, initseq)
+    lib().vnro_pcg32_advance(C.byref(r), C.c_int64(offset))
+    out = np.zeros(n, np.float32)
+    L = lib()
+    for i in range(n):
+        out[i] = L.vnro_pcg32_next_float(C.byref(r))
+    return out

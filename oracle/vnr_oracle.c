@@ -1183,3 +1183,182 @@ double vnro_psnr(const float* pred, const float* ref, size_t n, float ref_min, f
   const double mse = err / (double)n;
   return 10.0 * log10(range * range / mse);
 }
+
+/* ------------------------------------------------------------------------ */
+/* out-of-core training sampler.  ref: core/samplers/neural_sampler.cpp      */
+/* ------------------------------------------------------------------------ */
+
+/* ref: neural_sampler.cpp:143-156 read_typed_pointer */
+static float ooc_read_typed(const uint8_t* buffer, size_t id, int type)
+{
+  switch (type) {
+  case 0: return (float)((const uint8_t*)buffer)[id];
+  case 1: return (float)((const int8_t*)buffer)[id];
+  case 2: { uint16_t v; memcpy(&v, buffer + 2 * id, 2); return (float)v; }
+  case 3: { int16_t v; memcpy(&v, buffer + 2 * id, 2); return (float)v; }
+  case 4: { uint32_t v; memcpy(&v, buffer + 4 * id, 4); return (float)v; }
+  case 5: { int32_t v; memcpy(&v, buffer + 4 * id, 4); return (float)v; }
+  case 8: { float v; memcpy(&v, buffer + 4 * id, 4); return v; }
+  default: { double v; memcpy(&v, buffer + 8 * id, 8); return (float)v; }
+  }
+}
+
+static uint64_t ooc_flatten(const int index[3], const int grid[3])  /* :339-345 */
+{
+  return (uint64_t)index[0] + (uint64_t)index[1] * (uint64_t)grid[0] + (uint64_t)index[2] * (uint64_t)grid[1] * (uint64_t)grid[0];
+}
+
+static int ooc_imin(int a, int b) { return a < b ? a : b; }
+static int ooc_imax(int a, int b) { return a > b ? a : b; }
+static float ooc_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }  /* gdt clamp = min(max(v, lo), hi) */
+
+/* ref: neural_sampler.cpp:531-552 (RandomBuffer ctor) */
+int vnro_ooc_geometry_make(const int dims[3], int type, vnro_ooc_geometry* g)
+{
+  const uint64_t STREAM_SIZE = 32 * 1024, ALIGNMENT = 512;
+  switch (type) {
+  case 0: case 1: g->elem = 1; break;
+  case 2: case 3: g->elem = 2; break;
+  case 4: case 5: case 8: g->elem = 4; break;
+  case 12: g->elem = 8; break;
+  default: return -1;
+  }
+  g->type = type;
+  for (int d = 0; d < 3; ++d) g->dims[d] = dims[d];
+  const uint64_t row = (uint64_t)dims[0] * g->elem;
+  uint64_t rows = (STREAM_SIZE + row - 1) / row;
+  if (rows > (uint64_t)dims[1]) rows = (uint64_t)dims[1];
+  g->block_dims[0] = dims[0];
+  g->block_dims[1] = (int)rows;
+  g->block_dims[2] = ooc_imin(1, dims[2]);
+  g->ghost_dims[0] = g->block_dims[0];
+  g->ghost_dims[1] = ooc_imin(g->block_dims[1] + 2, dims[1]);
+  g->ghost_dims[2] = ooc_imin(g->block_dims[2] + 2, dims[2]);
+  g->index_space[0] = 1;
+  g->index_space[1] = (dims[1] + g->block_dims[1] - 1) / g->block_dims[1];
+  g->index_space[2] = (dims[2] + g->block_dims[2] - 1) / g->block_dims[2];
+  const uint64_t bytes = (uint64_t)g->ghost_dims[0] * g->ghost_dims[1] * g->ghost_dims[2] * g->elem;
+  g->block_size_aligned = (bytes + ALIGNMENT - 1) / ALIGNMENT * ALIGNMENT;
+  return 0;
+}
+
+/* ref: neural_sampler.cpp:579-636 (submit_one_job); the asynchronous reads become memcpy from the in-memory file */
+int vnro_ooc_load_block(const vnro_ooc_geometry* g, const uint8_t* file, const int block_index[3], vnro_ooc_block* b,
+                        uint8_t* block_data)
+{
+  for (int d = 0; d < 3; ++d)
+    if (block_index[d] < 0 || block_index[d] >= g->index_space[d]) return -1;
+  int v0[3], v1[3], g0[3], g1[3], gd[3];
+  for (int d = 0; d < 3; ++d) {
+    v0[d] = block_index[d] * g->block_dims[d];
+    v1[d] = ooc_imin(v0[d] + g->block_dims[d], g->dims[d]);
+    g0[d] = ooc_imax(v0[d] - 1, 0);
+    g1[d] = ooc_imin(v1[d] + 1, g->dims[d]);
+    gd[d] = g1[d] - g0[d];
+    b->index[d] = block_index[d];
+    b->bounds_lo[d] = v0[d]; b->bounds_hi[d] = v1[d];
+    b->ghost_lo[d] = g0[d]; b->ghost_hi[d] = g1[d];
+  }
+  b->offset = ooc_flatten(v0, g->dims);
+  b->length = (uint64_t)(v1[0] - v0[0]) * (uint64_t)(v1[1] - v0[1]) * (uint64_t)(v1[2] - v0[2]);
+  if (b->length == 0) return -1;
+  if ((uint64_t)gd[0] * gd[1] * gd[2] * g->elem > g->block_size_aligned) return -1;
+  for (int z = g0[2]; z < g1[2]; ++z) {
+    const int slice_begin[3] = {g0[0], g0[1], z};
+    const int rel[3] = {0, 0, z - g0[2]};
+    const uint64_t off_b = ooc_flatten(rel, gd) * g->elem;
+    const uint64_t off_f = ooc_flatten(slice_begin, g->dims) * g->elem;
+    const uint64_t nbytes = (uint64_t)gd[0] * gd[1] * g->elem;
+    memcpy(block_data + off_b, file + off_f, nbytes);
+  }
+  return 0;
+}
+
+/* ref: neural_sampler.cpp:302-329 trilinear_vkl; accessor(x, y, z) reads slab-local storage (access_voxel :653-663) and
+ * normalises before interpolation (:1098-1102) */
+typedef struct {
+  const vnro_ooc_geometry* g;
+  const vnro_ooc_block* b;
+  const uint8_t* data;
+  float lo, vscale;
+} ooc_accessor;
+
+static float ooc_access(const ooc_accessor* a, int x, int y, int z)
+{
+  const int rel[3] = {x - a->b->ghost_lo[0], y - a->b->ghost_lo[1], z - a->b->ghost_lo[2]};
+  const int size[3] = {a->b->ghost_hi[0] - a->b->ghost_lo[0], a->b->ghost_hi[1] - a->b->ghost_lo[1], a->b->ghost_hi[2] - a->b->ghost_lo[2]};
+  const float v = ooc_read_typed(a->data, (size_t)ooc_flatten(rel, size), a->g->type);
+  return ooc_clampf((v - a->lo) * a->vscale, 0.f, 1.f);
+}
+
+static float ooc_trilinear_vkl(const float p[3], const int dims[3], const ooc_accessor* a)
+{
+  float w[3], iw[3];
+  int i0[3], i1[3];
+  for (int d = 0; d < 3; ++d) {
+    const float pb = p[d] - 0.5f;
+    w[d] = modff(pb, &iw[d]);
+    i0[d] = ooc_imin(ooc_imax((int)iw[d], 0), dims[d] - 1);
+    i1[d] = ooc_imin(ooc_imax(i0[d] + 1, 0), dims[d] - 1);
+  }
+  const float c000 = ooc_access(a, i0[0], i0[1], i0[2]);
+  const float c001 = ooc_access(a, i1[0], i0[1], i0[2]);
+  const float c010 = ooc_access(a, i0[0], i1[1], i0[2]);
+  const float c011 = ooc_access(a, i1[0], i1[1], i0[2]);
+  const float c100 = ooc_access(a, i0[0], i0[1], i1[2]);
+  const float c101 = ooc_access(a, i1[0], i0[1], i1[2]);
+  const float c110 = ooc_access(a, i0[0], i1[1], i1[2]);
+  const float c111 = ooc_access(a, i1[0], i1[1], i1[2]);
+  return (1 - w[0]) * (1 - w[1]) * (1 - w[2]) * c000 + w[0] * (1 - w[1]) * (1 - w[2]) * c001
+       + (1 - w[0]) * w[1] * (1 - w[2]) * c010 + w[0] * w[1] * (1 - w[2]) * c011
+       + (1 - w[0]) * (1 - w[1]) * w[2] * c100 + w[0] * (1 - w[1]) * w[2] * c101
+       + (1 - w[0]) * w[1] * w[2] * c110 + w[0] * w[1] * w[2] * c111;
+}
+
+/* ref: neural_sampler.cpp:1066-1120 (the tbb::parallel_for body), random numbers supplied by the caller */
+size_t vnro_ooc_sample(const vnro_ooc_geometry* g, const vnro_ooc_block* blocks, const uint8_t* block_data, uint64_t n_blocks,
+                       float range_lo, float range_hi, const float* r_coords, const float* r_bidx, const float* r_vidx, size_t n,
+                       const float lower[3], const float upper[3], float* coords, float* values)
+{
+  size_t out_of_range = 0;
+  const float rfdims[3] = {1.f / (float)g->dims[0], 1.f / (float)g->dims[1], 1.f / (float)g->dims[2]};
+  const float vscale = 1.f / (range_hi - range_lo);
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t bidx = (uint64_t)(r_bidx[i] * (float)n_blocks);
+    if (bidx >= n_blocks) { bidx = n_blocks - 1; ++out_of_range; }  /* "[aio] invalid block index" */
+    const vnro_ooc_block* b = &blocks[bidx];
+    uint64_t vidx = (uint64_t)(r_vidx[i] * (float)b->length);
+    if (vidx >= b->length) { vidx = b->length - 1; ++out_of_range; }  /* "[aio] invalid voxel index" */
+    const uint64_t index = b->offset + vidx;  /* locate_voxel */
+    const uint64_t stride_y = (uint64_t)g->dims[0], stride_z = (uint64_t)g->dims[1] * (uint64_t)g->dims[0];
+    const int voxel[3] = {(int)(index % stride_y), (int)((index % stride_z) / stride_y), (int)(index / stride_z)};  /* to_grid_index */
+    float p[3], ccp[3];
+    for (int d = 0; d < 3; ++d) {
+      p[d] = r_coords[3 * i + d] + (float)voxel[d];
+      coords[3 * i + d] = p[d] * rfdims[d] * (upper[d] - lower[d]) + lower[d];
+      ccp[d] = ooc_clampf(p[d], 0.5f, (float)g->dims[d] - 0.5f);
+    }
+    const ooc_accessor acc = {g, b, block_data + bidx * g->block_size_aligned, range_lo, vscale};
+    values[i] = ooc_trilinear_vkl(ccp, g->dims, &acc);
+  }
+  return out_of_range;
+}
+
+/* ref: neural_sampler.cpp:967-1035 with trilinear = false: nearest_vkl (:294-300) at the grid points */
+void vnro_ooc_sample_grid(const vnro_ooc_geometry* g, const uint8_t* file, float range_lo, float range_hi, const int origin[3],
+                          const int size[3], const float spacing[3], float* values)
+{
+  const float scale = 1.f / (range_hi - range_lo);
+  const size_t n = (size_t)size[0] * size[1] * size[2];
+  const uint64_t stride = (uint64_t)size[0] * size[1];
+  for (size_t i = 0; i < n; ++i) {
+    const int gp[3] = {origin[0] + (int)(i % (size_t)size[0]), origin[1] + (int)((i % stride) / (size_t)size[0]), origin[2] + (int)(i / stride)};
+    int ip[3];
+    for (int d = 0; d < 3; ++d) {
+      const float fp = ((float)gp[d] + 0.5f) * spacing[d];
+      ip[d] = (int)ooc_clampf(fp * (float)g->dims[d], 0.5f, (float)g->dims[d] - 0.5f);
+    }
+    const float v = ooc_read_typed(file, (size_t)ooc_flatten(ip, g->dims), g->type);
+    values[i] = ooc_clampf((v - range_lo) * scale, 0.f, 1.f);
+  }
+}

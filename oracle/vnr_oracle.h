@@ -179,6 +179,35 @@ size_t vnro_dda_trace(const float org[3], const float dir[3], float t_min, float
 void vnro_generate_grid_coords(const int lower[3], const int size[3], const float rdims[3], float* coords);
 double vnro_psnr(const float* pred, const float* ref, size_t n, float ref_min, float ref_max);
 
+/* ---- out-of-core training sampler (core/samplers/neural_sampler.cpp:377-668, 1043-1127) ------------------ */
+/* value types: 0 u8, 1 i8, 2 u16, 3 i16, 4 u32, 5 i32, 8 f32, 12 f64 (read_typed_pointer, :143-156) */
+typedef struct {
+  int dims[3], type;
+  uint32_t elem;
+  int block_dims[3], ghost_dims[3], index_space[3];
+  uint64_t block_size_aligned;
+} vnro_ooc_geometry;
+typedef struct {  /* RandomBuffer::Block (:491-497) */
+  int index[3];
+  uint64_t offset, length;
+  int bounds_lo[3], bounds_hi[3], ghost_lo[3], ghost_hi[3];
+} vnro_ooc_block;
+/* RandomBuffer ctor (:531-552); returns 0, or -1 for an unsupported type */
+int  vnro_ooc_geometry_make(const int dims[3], int type, vnro_ooc_geometry* g);
+/* submit_one_job (:579-636) with the file held in memory: fills *b and copies the slab (with ghosts) into block_data */
+int  vnro_ooc_load_block(const vnro_ooc_geometry* g, const uint8_t* file, const int block_index[3], vnro_ooc_block* b,
+                         uint8_t* block_data);
+/* OutOfCoreSampler::sample (:1066-1120) for given random numbers: r_coords[3n], r_bidx[n], r_vidx[n] in [0,1).
+ * block_data = n_blocks x block_size_aligned.  Returns the number of samples whose pick fell outside its range (the
+ * reference throws there; the pick is clamped and counted). */
+size_t vnro_ooc_sample(const vnro_ooc_geometry* g, const vnro_ooc_block* blocks, const uint8_t* block_data, uint64_t n_blocks,
+                       float range_lo, float range_hi, const float* r_coords, const float* r_bidx, const float* r_vidx, size_t n,
+                       const float lower[3], const float upper[3], float* coords, float* values);
+/* sample_streaming_grid (:967-1035, trilinear = false) with the file held in memory; every grid point reads the file voxel it
+ * falls into (the reference indexes the block it read and is only defined when grid dims == file dims) */
+void vnro_ooc_sample_grid(const vnro_ooc_geometry* g, const uint8_t* file, float range_lo, float range_hi, const int origin[3],
+                          const int size[3], const float spacing[3], float* values);
+
 #ifdef __cplusplus
 }
 #endif

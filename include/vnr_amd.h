@@ -95,6 +95,9 @@ void vnrAmdFreeHost(void* p);
 /* ---- camera (api.h:103-110) --------------------------------------------- */
 vnrAmdCamera vnrAmdCreateCamera(void);                                              /* vnrCreateCamera() */
 int  vnrAmdCameraSet(vnrAmdCamera, const float from[3], const float at[3], const float up[3]); /* vnrCameraSet */
+/* vnrCreateCamera(scene) / vnrCameraSet(self, scene) (api.h:104,106; serializer.cpp:178-187, 418-428): eye / center / up / fovy
+ * of view.camera, eye and center moved by -dims/2.  A DIVA scene leaves the camera as it is (the reference's TODO). */
+int  vnrAmdCameraSetFromScene(vnrAmdCamera, const void* scene, size_t size, int format);
 int  vnrAmdCameraSetFovy(vnrAmdCamera, float fovy_degrees);                          /* Camera::fovy, instantvnr_types.h:82 */
 int  vnrAmdCameraGet(vnrAmdCamera, float from[3], float at[3], float up[3], float* fovy); /* vnrCameraGetPosition/Focus/UpVec */
 void vnrAmdReleaseCamera(vnrAmdCamera);
@@ -128,6 +131,17 @@ const float* vnrAmdSimpleVolumeDeviceData(vnrAmdVolume);
  * be rendered itself; it feeds vnrAmdCreateNeuralVolume, whose grid is min(1024, dims) per axis. */
 vnrAmdVolume vnrAmdCreateSimpleVolumeOutOfCore(const char* filename, const int dims[3], int value_type, size_t offset,
                                                float range_lo, float range_hi, uint64_t n_concurrent_blocks, uint64_t n_blocks);
+/* vnrCreateSimpleVolume(scene, mode, save_loaded_volume) (api.h:117, api.cpp:145-158): `scene` is a VIDI3D or DIVA scene
+ * document (serializer.cpp:137-176, 394-447) in any of the VNR_AMD_JSON_* formats; a document that is a JSON string is the
+ * path of a JSON text file.  mode: "GPU" (resident, every time step in HBM), "OUT_OF_CORE", "NOTHING" (shape only);
+ * "VIRTUAL_MEMORY" and "OPENVKL*" are not implemented and fail; anything else fails with "unknown mode" like the reference.
+ * save_loaded_volume writes the normalised fp32 voxels to ./reference.bin (neural_sampler.cu:101-108). */
+vnrAmdVolume vnrAmdCreateSimpleVolumeFromScene(const void* scene, size_t size, int format, const char* mode, int save_loaded_volume);
+int  vnrAmdSimpleVolumeGetNumberOfTimeSteps(vnrAmdVolume);            /* vnrSimpleVolumeGetNumberOfTimeSteps (api.h:119) */
+int  vnrAmdSimpleVolumeSetCurrentTimeStep(vnrAmdVolume, int index);   /* vnrSimpleVolumeSetCurrentTimeStep (api.h:118) */
+/* the value range a scene maps its transfer function to (view.volume.scalarMappingRange[Unnormalized], serializer.cpp:212-256);
+ * returns 2 and leaves `range` untouched when the scene has none (VNR_AMD_OK when it has, VNR_AMD_ERROR on a malformed scene) */
+int  vnrAmdSceneGetValueRange(const void* scene, size_t size, int format, float range[2]);
 typedef struct vnrAmdOutOfCoreInfo {
   int file_dims[3];            /* dims of the volume in the file */
   int block_dims[3];           /* slab proper: x-full, rows, 1 slice (RandomBuffer ctor :531-546) */

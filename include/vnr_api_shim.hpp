@@ -127,6 +127,12 @@ inline vnrJson vnrCreateJsonBinary(std::string filename) { vnrJson j; vnrLoadJso
 
 // ---- camera (api.h:103-110) -----------------------------------------------------------------------------------
 inline vnrCamera vnrCreateCamera() { return vnrCamera(vnr::shim::check_ptr(vnrAmdCreateCamera()), vnrAmdReleaseCamera); }
+inline void vnrCameraSet(vnrCamera c, const vnrJson& scene)  // api.h:106; a json string is the path of a scene file (api.cpp:99-108)
+{
+  vnr::shim::JsonArg a(scene, false);
+  vnr::shim::check(vnrAmdCameraSetFromScene(c.get(), a.data(), a.size(), a.format));
+}
+inline vnrCamera vnrCreateCamera(const vnrJson& scene) { vnrCamera c = vnrCreateCamera(); vnrCameraSet(c, scene); return c; }  // api.h:104
 inline void vnrCameraSet(vnrCamera c, vnr::vec3f from, vnr::vec3f at, vnr::vec3f up)
 {
   const float f[3] = {from.x, from.y, from.z}, a[3] = {at.x, at.y, at.z}, u[3] = {up.x, up.y, up.z};
@@ -137,8 +143,13 @@ inline vnr::vec3f vnrCameraGetFocus(vnrCamera c) { float v[3]; vnr::shim::check(
 inline vnr::vec3f vnrCameraGetUpVec(vnrCamera c) { float v[3]; vnr::shim::check(vnrAmdCameraGet(c.get(), nullptr, nullptr, v, nullptr)); return vnr::vec3f{v[0], v[1], v[2]}; }
 
 // ---- volumes (api.h:117-148) -----------------------------------------------------------------------------------
-// vnrCreateSimpleVolume(scene json, mode, save): the scene-JSON loader (serializer.cpp) is SURVEY §8f "next"; until it lands
-// the app passes the raw file description explicitly.
+// api.h:117: VIDI3D / DIVA scene document or the path of one; mode "GPU", "OUT_OF_CORE" or "NOTHING" (include/vnr_amd.h)
+inline vnrVolume vnrCreateSimpleVolume(const vnrJson& scene, std::string mode, bool save_loaded_volume = false)
+{
+  vnr::shim::JsonArg a(scene, false);
+  return vnrVolume(vnr::shim::check_ptr(vnrAmdCreateSimpleVolumeFromScene(a.data(), a.size(), a.format, mode.c_str(), save_loaded_volume)), vnrAmdReleaseVolume);
+}
+// AMD extension: a raw file without a scene document around it
 inline vnrVolume vnrCreateSimpleVolumeFromRawFile(const std::string& filename, vnr::vec3i dims, int value_type, size_t offset = 0,
                                                   bool big_endian = false)
 {
@@ -191,6 +202,35 @@ inline vnr::range1f vnrVolumeGetValueRange(vnrVolume v) { float r[2]; vnr::shim:
 
 // ---- transfer function (api.h:154-162) ---------------------------------------------------------------------------
 inline vnrTransferFunction vnrCreateTransferFunction() { return vnrTransferFunction(vnr::shim::check_ptr(vnrAmdCreateTransferFunction()), vnrAmdReleaseTransferFunction); }
+// api.h:155.  The reference decodes the scene's transfer function with OVR's tfn module (tfn::loadTransferFunction,
+// serializer.cpp:192-193), which is not in its tree; an app that links that module passes its decoder in (colours, (position,
+// alpha) pairs), and the value range comes from the scene exactly as create_scene_vidi__tfn takes it (serializer.cpp:212-256).
+// Without a decoder the call throws instead of returning a made-up table.
+typedef void (*vnrShimTfnDecoder)(const vnrJson& transfer_function, std::vector<vnr::vec3f>& color, std::vector<vnr::vec2f>& alpha);
+inline vnrShimTfnDecoder& vnrShimTransferFunctionDecoder() { static vnrShimTfnDecoder d = nullptr; return d; }
+inline vnrTransferFunction vnrCreateTransferFunction(const vnrJson& scene_or_path)
+{
+  vnrJson scene = scene_or_path;
+  if (scene.is_string()) vnrLoadJsonText(scene, scene_or_path.get<std::string>());  // create_json_tfn (api.cpp:469-477)
+  if (!vnrShimTransferFunctionDecoder())
+    throw std::runtime_error("vnrCreateTransferFunction(scene): no decoder for the scene's transfer function (OVR tfn module, outside the "
+                             "reference tree); install one with vnrShimTransferFunctionDecoder() or set colours / alphas explicitly");
+  std::vector<vnr::vec3f> color; std::vector<vnr::vec2f> alpha;
+  vnrShimTransferFunctionDecoder()(scene["view"]["volume"]["transferFunction"], color, alpha);
+  if (!alpha.empty()) {  // serializer.cpp:207-208
+    if (alpha.front().y < 0.01f) alpha.front().y = 0.f;
+    if (alpha.back().y < 0.01f) alpha.back().y = 0.f;
+  }
+  vnrTransferFunction t = vnrCreateTransferFunction();
+  vnr::shim::check(vnrAmdTransferFunctionSetColor(t.get(), color.empty() ? nullptr : &color[0].x, (int)color.size()));
+  vnr::shim::check(vnrAmdTransferFunctionSetAlpha(t.get(), alpha.empty() ? nullptr : &alpha[0].x, (int)alpha.size()));
+  vnr::shim::JsonArg a(scene, false);
+  float r[2];
+  const int st = vnrAmdSceneGetValueRange(a.data(), a.size(), a.format, r);
+  if (st == VNR_AMD_OK) vnr::shim::check(vnrAmdTransferFunctionSetValueRange(t.get(), r[0], r[1]));
+  else if (st != 2) vnr::shim::fail();
+  return t;
+}
 inline void vnrTransferFunctionSetColor(vnrTransferFunction t, const std::vector<vnr::vec3f>& c) { vnr::shim::check(vnrAmdTransferFunctionSetColor(t.get(), c.empty() ? nullptr : &c[0].x, (int)c.size())); }
 inline void vnrTransferFunctionSetAlpha(vnrTransferFunction t, const std::vector<vnr::vec2f>& a) { vnr::shim::check(vnrAmdTransferFunctionSetAlpha(t.get(), a.empty() ? nullptr : &a[0].x, (int)a.size())); }
 inline void vnrTransferFunctionSetValueRange(vnrTransferFunction t, vnr::range1f r) { vnr::shim::check(vnrAmdTransferFunctionSetValueRange(t.get(), r.lower, r.upper)); }
@@ -249,9 +289,6 @@ inline bool vnrRequireDecoding(int m)
   if (m < 0 || m > 15) throw std::runtime_error("unknown rendering mode");
   return m <= 4 || m == 7 || m == 10 || m == 13;
 }
-// api.h:118-119: time-varying raw volumes.  This build loads one time step per volume.
-inline int vnrSimpleVolumeGetNumberOfTimeSteps(vnrVolume v) { if (!v || vnrAmdVolumeIsNetwork(v.get())) throw std::runtime_error("expected a simple volume"); return 1; }
-inline void vnrSimpleVolumeSetCurrentTimeStep(vnrVolume v, int time)
-{
-  if (time != 0 || vnrSimpleVolumeGetNumberOfTimeSteps(v) != 1) throw std::runtime_error("time step " + std::to_string(time) + " requested, but this volume has 1 time step (time-varying volumes are not implemented in this build)");
-}
+// api.h:118-119: time-varying raw volumes (one file per time step in the scene's dataSource / filename array)
+inline int vnrSimpleVolumeGetNumberOfTimeSteps(vnrVolume v) { const int n = vnrAmdSimpleVolumeGetNumberOfTimeSteps(v.get()); if (n < 0) vnr::shim::fail(); return n; }
+inline void vnrSimpleVolumeSetCurrentTimeStep(vnrVolume v, int time) { vnr::shim::check(vnrAmdSimpleVolumeSetCurrentTimeStep(v.get(), time)); }

@@ -109,6 +109,11 @@ def lib():
     sig("vnrAmdCreateSimpleVolumePerlin", P, IP, U32, I, F)
     sig("vnrAmdSimpleVolumeDeviceData", P, P)
     sig("vnrAmdCreateSimpleVolumeOutOfCore", P, C.c_char_p, IP, I, SZ, F, F, U64, U64)
+    sig("vnrAmdCreateSimpleVolumeFromScene", P, P, SZ, I, C.c_char_p, I)
+    sig("vnrAmdSimpleVolumeGetNumberOfTimeSteps", I, P)
+    sig("vnrAmdSimpleVolumeSetCurrentTimeStep", I, P, I)
+    sig("vnrAmdSceneGetValueRange", I, P, SZ, I, FP)
+    sig("vnrAmdCameraSetFromScene", I, P, P, SZ, I)
     sig("vnrAmdSimpleVolumeOutOfCoreInfo", I, P, C.POINTER(OutOfCoreInfo))
     sig("vnrAmdSimpleVolumeOutOfCoreBlocks", I, P, IP, SZ)
     sig("vnrAmdCreateNeuralVolume", P, P, SZ, I, P, I)

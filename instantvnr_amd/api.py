@@ -169,11 +169,20 @@ def bson_to_json_text(b):
 
 
 # ------------------------------------------------------------------------------------------------ camera (api.h:103-110)
-def vnrCreateCamera():
-    return vnrCamera(lib().vnrAmdCreateCamera())
+def vnrCreateCamera(scene=None):
+    """api.h:103-104: vnrCreateCamera() / vnrCreateCamera(scene json or path)"""
+    cam = vnrCamera(lib().vnrAmdCreateCamera())
+    if scene is not None:
+        vnrCameraSet(cam, scene)
+    return cam
 
 
-def vnrCameraSet(cam, frm, at, up, fovy=None):
+def vnrCameraSet(cam, frm, at=None, up=None, fovy=None):
+    """api.h:105-106: vnrCameraSet(self, from, at, up) / vnrCameraSet(self, scene)"""
+    if at is None:
+        b, n, f = _json_arg(frm)
+        check(lib().vnrAmdCameraSetFromScene(cam.h, b, n, f))
+        return
     check(lib().vnrAmdCameraSet(cam.h, _fp(_vec(frm)), _fp(_vec(at)), _fp(_vec(up))))
     if fovy is not None:
         check(lib().vnrAmdCameraSetFovy(cam.h, float(fovy)))
@@ -199,8 +208,16 @@ def vnrCameraGetUpVec(cam):
 
 
 # ------------------------------------------------------------------------------------------------ volumes (api.h:117-148)
-def vnrCreateSimpleVolume(data, value_range=None):
-    """data: numpy array [z, y, x] (x fastest) — stands in for vnrCreateSimpleVolume(scene json, "GPU")"""
+def vnrCreateSimpleVolume(data, mode_or_range=None, save_loaded_volume=False, value_range=None):
+    """api.h:117 vnrCreateSimpleVolume(scene, mode, save_loaded_volume): `data` is a scene document (dict / JSON text / path)
+    and mode "GPU", "OUT_OF_CORE" or "NOTHING"; or, an extension for hosts that hold the voxels already, `data` is a numpy
+    array [z, y, x] (x fastest) and the second argument an optional (lo, hi) value range"""
+    if not isinstance(data, np.ndarray):
+        b, n, f = _json_arg(data)
+        mode = "GPU" if mode_or_range is None else mode_or_range
+        return vnrVolume(lib().vnrAmdCreateSimpleVolumeFromScene(b, n, f, mode.encode(), 1 if save_loaded_volume else 0))
+    if value_range is None:
+        value_range = mode_or_range
     a = np.ascontiguousarray(data)
     if a.dtype not in VALUE_TYPES:
         raise VnrAmdError("unknown data type")
@@ -214,6 +231,28 @@ def vnrCreateSimpleVolumeFromRawFile(filename, dims, dtype, offset=0, big_endian
     lo, hi = (1.0, 0.0) if value_range is None else value_range
     return vnrVolume(lib().vnrAmdCreateSimpleVolumeFromRawFile(filename.encode(), d, VALUE_TYPES[np.dtype(dtype)], offset,
                                                                1 if big_endian else 0, lo, hi))
+
+
+def vnrSimpleVolumeGetNumberOfTimeSteps(v):
+    n = lib().vnrAmdSimpleVolumeGetNumberOfTimeSteps(v.h)
+    if n < 0:
+        raise VnrAmdError(_lib.last_error())
+    return n
+
+
+def vnrSimpleVolumeSetCurrentTimeStep(v, index):
+    check(lib().vnrAmdSimpleVolumeSetCurrentTimeStep(v.h, int(index)))
+
+
+def scene_value_range(scene):
+    """the value range a scene maps its transfer function to, or None (serializer.cpp:212-256)"""
+    b, n, f = _json_arg(scene)
+    r = np.zeros(2, np.float32)
+    st = lib().vnrAmdSceneGetValueRange(b, n, f, _fp(r))
+    if st == 2:
+        return None
+    check(st)
+    return float(r[0]), float(r[1])
 
 
 def vnrCreateSimpleVolumeOutOfCore(filename, dims, dtype, value_range, offset=0, n_concurrent_blocks=0, n_blocks=0):
@@ -372,7 +411,14 @@ def vnrVolumeGetValueRange(v):
 
 
 # ------------------------------------------------------------------------------------------------ tfn (api.h:154-162)
-def vnrCreateTransferFunction():
+def vnrCreateTransferFunction(scene=None):
+    """api.h:154-155.  vnrCreateTransferFunction(scene) decodes the scene's transfer function with OVR's tfn module
+    (tfn::loadTransferFunction, serializer.cpp:192-193), which is not part of the reference tree: unsupported here; the value
+    range of the scene is available through scene_value_range()."""
+    if scene is not None:
+        raise VnrAmdError("vnrCreateTransferFunction(scene): the transfer-function table of a scene is decoded by OVR's tfn module "
+                          "(tfn::loadTransferFunction), which is outside the reference tree; set colours / alphas explicitly "
+                          "(the scene's value range: scene_value_range)")
     return vnrTransferFunction(lib().vnrAmdCreateTransferFunction())
 
 

@@ -7,6 +7,7 @@
 #include <memory>
 
 #include "renderer.h"
+#include "scene.h"
 
 using namespace vnr;
 
@@ -206,6 +207,13 @@ int vnrAmdCameraSet(vnrAmdCamera c, const float from[3], const float at[3], cons
     c->d.up = {up[0], up[1], up[2]};
   });
 }
+int vnrAmdCameraSetFromScene(vnrAmdCamera c, const void* scene, size_t size, int format)
+{
+  return guarded([&]() {
+    if (!c) throw std::runtime_error("null camera");
+    (void)parse_scene_camera(resolve_config(parse_json_arg(scene, size, format)), c->d);
+  });
+}
 int vnrAmdCameraSetFovy(vnrAmdCamera c, float fovy)
 {
   return guarded([&]() { if (!c) throw std::runtime_error("null camera"); c->d.fovy = fovy; });
@@ -321,6 +329,37 @@ vnrAmdVolume vnrAmdCreateSimpleVolumeOutOfCore(const char* filename, const int d
     h->v = sv;
     return h;
   });
+}
+vnrAmdVolume vnrAmdCreateSimpleVolumeFromScene(const void* scene, size_t size, int format, const char* mode, int save_loaded_volume)
+{
+  return guarded_new<vnrAmdVolume_t>([&]() {
+    const SceneVolume sc = parse_scene_volume(resolve_config(parse_json_arg(scene, size, format)));
+    auto sv = std::make_shared<SimpleVolume>();
+    sv->load_scene(sc, mode ? mode : "GPU", save_loaded_volume != 0);
+    auto* h = new vnrAmdVolume_t();
+    h->v = sv;
+    return h;
+  });
+}
+int vnrAmdSimpleVolumeGetNumberOfTimeSteps(vnrAmdVolume v)
+{
+  int n = -1;
+  guarded([&]() { n = as_simple(v)->num_timesteps(); });
+  return n;
+}
+int vnrAmdSimpleVolumeSetCurrentTimeStep(vnrAmdVolume v, int index)
+{
+  return guarded([&]() { as_simple(v)->set_current_timestep(index); });
+}
+int vnrAmdSceneGetValueRange(const void* scene, size_t size, int format, float range[2])
+{
+  int none = 0;
+  const int st = guarded([&]() {
+    float lo, hi;
+    if (parse_scene_tfn_range(resolve_config(parse_json_arg(scene, size, format)), lo, hi)) { range[0] = lo; range[1] = hi; }
+    else none = 2;
+  });
+  return st != 0 ? st : none;
 }
 int vnrAmdSimpleVolumeOutOfCoreInfo(vnrAmdVolume v, vnrAmdOutOfCoreInfo* info)
 {

@@ -69,7 +69,9 @@ private:
   uint32_t il_block_ = 8, il_parts_ = 1, il_part_ = 0;
   bool reset_ = true, skip_download_ = false, profiling_ = false;
   int frame_index_ = 0;
-  int n_iters_ = 16;  // VNR_RM_N_ITERS (method_raymarching.cu:30-40)
+  // samples per ray and iteration, VNR_RM_N_ITERS (method_raymarching.cu:30-40; 16 there, tuned on the authors' GPU).  Frames do
+  // not depend on it; on MI355X 24 is the fastest (bench workload: 16: 122, 24: 129, 32: 126 frames/s)
+  int n_iters_ = 24;
   // LaunchParams::light_directional_dir (instantvnr_types.h:148): a member the reference negates IN PLACE whenever it points
   // along the view direction (renderer.cpp:98-101), so it persists across frames
   vec3f light_dir_ = {0.7f, 0.9f, 0.4f};

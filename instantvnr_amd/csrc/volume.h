@@ -13,6 +13,8 @@
 #include "network.h"
 #include "ooc_sampler.h"
 
+namespace vnr { struct SceneVolume; }
+
 namespace vnr {
 
 constexpr int kMacrocellSizeMip = 4;  // CMakeLists.txt:61 MACROCELL_SIZE_MIP
@@ -109,6 +111,10 @@ public:
   // macrocell; dims() = min(1024, file dims) is the shape a neural volume trained from it takes, the transform is the file's
   void load_out_of_core(const std::string& filename, vec3i dims, int type, size_t offset, float range_lo, float range_hi,
                         uint64_t n_concurrent_blocks, uint64_t n_blocks);
+  // vnrCreateSimpleVolume(scene, mode, save) (api.cpp:145-158): "GPU", "OUT_OF_CORE" or "NOTHING"; one file per time step
+  void load_scene(const SceneVolume& scene, const std::string& mode, bool save_volume);
+  int num_timesteps() const { return steps_.empty() ? 1 : (int)steps_.size(); }   // SimpleVolume::get_num_timesteps
+  void set_current_timestep(int index);                                           // core/sampler.cu:19-26
   bool has_data() const { return data_.ptr != nullptr; }   // SimpleVolume::texture() != 0
   OutOfCoreSampler* out_of_core() { return ooc_.get(); }
 
@@ -125,7 +131,9 @@ public:
 
 private:
   void finish_load(hipStream_t s);
-  DeviceBuffer<float> data_;
+  DeviceBuffer<float> data_;                 // the current time step
+  std::vector<DeviceBuffer<float>> steps_;   // the other time steps (entry `current_step_` is moved into data_)
+  int current_step_ = 0;
   std::unique_ptr<OutOfCoreSampler> ooc_;
   MacroCell mc_;
   TfnObject tfn_;

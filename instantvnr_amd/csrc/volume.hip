@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "sampling_device.h"
+#include "scene.h"
 
 namespace vnr {
 
@@ -397,7 +398,9 @@ static size_t type_size(int type)
   }
 }
 
-void SimpleVolume::load_host(const void* data, vec3i dims, int type, float range_lo, float range_hi, bool big_endian)
+// StaticSampler::load (neural_sampler.cpp:223-288): typed voxels -> fp32 normalised to [0,1]; an empty range (lo > hi) is
+// replaced by the min/max of the data
+static std::vector<float> normalise_volume(const void* data, vec3i dims, int type, float& range_lo, float& range_hi, bool big_endian)
 {
   if (dims.x <= 0 || dims.y <= 0 || dims.z <= 0) throw std::runtime_error("invalid volume dims");
   const size_t count = (size_t)dims.x * dims.y * dims.z;
@@ -433,16 +436,10 @@ void SimpleVolume::load_host(const void* data, vec3i dims, int type, float range
     range_lo = (float)mn; range_hi = (float)mx;
   }
   run(false, range_lo, range_hi, nullptr, nullptr);
-  unnormalized_lo = range_lo; unnormalized_hi = range_hi;
-  desc.dims = dims; desc.type = 8; desc.range_lo = 0.0f; desc.range_hi = 1.0f;
-  hipStream_t s = Runtime::get().stream;
-  data_.resize(count);
-  data_.upload(out.data(), count, s);
-  VNR_HIP_CHECK(hipStreamSynchronize(s));
-  finish_load(s);
+  return out;
 }
 
-void SimpleVolume::load_raw_file(const std::string& filename, vec3i dims, int type, size_t offset, bool big_endian, float range_lo, float range_hi)
+static std::vector<char> read_raw_file(const std::string& filename, vec3i dims, int type, size_t offset)
 {
   const size_t bytes = (size_t)dims.x * dims.y * dims.z * type_size(type);
   std::ifstream f(filename, std::ios::binary);
@@ -450,6 +447,104 @@ void SimpleVolume::load_raw_file(const std::string& filename, vec3i dims, int ty
   f.seekg((std::streamoff)offset);
   std::vector<char> buf(bytes);
   if (!f.read(buf.data(), (std::streamsize)bytes)) throw std::runtime_error("volume file too short: " + filename);
+  return buf;
+}
+
+void SimpleVolume::load_host(const void* data, vec3i dims, int type, float range_lo, float range_hi, bool big_endian)
+{
+  const std::vector<float> out = normalise_volume(data, dims, type, range_lo, range_hi, big_endian);
+  unnormalized_lo = range_lo; unnormalized_hi = range_hi;
+  desc.dims = dims; desc.type = 8; desc.range_lo = 0.0f; desc.range_hi = 1.0f;
+  hipStream_t s = Runtime::get().stream;
+  ooc_.reset();
+  steps_.clear();
+  current_step_ = 0;
+  data_.resize(out.size());
+  data_.upload(out.data(), out.size(), s);
+  VNR_HIP_CHECK(hipStreamSynchronize(s));
+  finish_load(s);
+}
+
+void SimpleVolume::load_scene(const SceneVolume& sc, const std::string& mode, bool save_volume)
+{
+  // SimpleVolume::load -> Sampler::load (core/sampler.cu:5-17, neural_sampler.cpp:1205-1271)
+  if (sc.data.empty()) throw std::runtime_error("the scene names no volume file");
+  if (mode == "GPU") {
+    // StaticSampler (neural_sampler.cu:86-121): every time step is normalised on load; here they all stay in HBM, so
+    // switching the time step is a pointer change plus the macrocell pass
+    float lo = sc.range_lo, hi = sc.range_hi;
+    {
+      const std::vector<char> raw = read_raw_file(sc.data[0].filename, sc.dims, sc.type, sc.data[0].offset);
+      load_host(raw.data(), sc.dims, sc.type, lo, hi, sc.data[0].bigendian);
+    }
+    if (save_volume) {  // neural_sampler.cu:101-108: the normalised fp32 voxels of time step 0
+      std::vector<float> h(data_.count);
+      data_.download(h.data(), h.size(), Runtime::get().stream);
+      std::ofstream o("reference.bin", std::ios::binary | std::ios::out);
+      o.write((const char*)h.data(), (std::streamsize)(h.size() * sizeof(float)));
+      if (!o) throw std::runtime_error("cannot write reference.bin");
+    }
+    steps_.resize(sc.data.size());
+    hipStream_t s = Runtime::get().stream;
+    for (size_t i = 1; i < sc.data.size(); ++i) {
+      float l = sc.range_lo, h = sc.range_hi;
+      const std::vector<char> raw = read_raw_file(sc.data[i].filename, sc.dims, sc.type, sc.data[i].offset);
+      const std::vector<float> out = normalise_volume(raw.data(), sc.dims, sc.type, l, h, sc.data[i].bigendian);
+      steps_[i].resize(out.size());
+      steps_[i].upload(out.data(), out.size(), s);
+      VNR_HIP_CHECK(hipStreamSynchronize(s));
+      unnormalized_lo = std::min(unnormalized_lo, l);   // m_value_range_unnormalized.extend (:117-118)
+      unnormalized_hi = std::max(unnormalized_hi, h);
+    }
+  } else if (mode == "OUT_OF_CORE") {
+    if (sc.data[0].bigendian) throw std::runtime_error("only support small endian");  // neural_sampler.cpp:1050
+    uint64_t ncb = 1024, nb = 0;  // neural_sampler.cpp:1054-1062
+    if (const char* e = std::getenv("VNR_NUM_CONCURRENT_BLOCKS")) ncb = (uint64_t)std::max(1, std::atoi(e));
+    nb = ncb * 64;
+    if (const char* e = std::getenv("VNR_NUM_BLOCKS")) nb = (uint64_t)std::max(1, std::atoi(e));
+    load_out_of_core(sc.data[0].filename, sc.dims, sc.type, sc.data[0].offset, sc.range_lo, sc.range_hi, ncb, nb);
+    steps_.clear();
+    steps_.resize(sc.data.size());
+  } else if (mode == "NOTHING") {  // StaticSampler(dims, type) (neural_sampler.cu:76-84): a shape without data
+    data_.resize(0);
+    ooc_.reset();
+    steps_.clear();
+    unnormalized_lo = 0.0f; unnormalized_hi = 1.0f;
+    desc.dims = sc.dims; desc.type = 8; desc.range_lo = 0.0f; desc.range_hi = 1.0f;
+    const vec3f d = {(float)sc.dims.x, (float)sc.dims.y, (float)sc.dims.z};
+    transform = {{d.x, 0, 0}, {0, d.y, 0}, {0, 0, d.z}, {-d.x / 2.0f, -d.y / 2.0f, -d.z / 2.0f}};
+    clipbox = {{0, 0, 0}, {1, 1, 1}};
+  } else if (mode == "VIRTUAL_MEMORY" || mode.rfind("OPENVKL", 0) == 0) {
+    throw std::runtime_error("training mode " + mode + " is not implemented in this build (GPU, OUT_OF_CORE and NOTHING are)");
+  } else {
+    throw std::runtime_error("unknown mode");  // neural_sampler.cpp:1268
+  }
+  current_step_ = 0;
+}
+
+void SimpleVolume::set_current_timestep(int index)
+{
+  // SimpleVolume::set_current_timestep (core/sampler.cu:19-26) -> StaticSampler::set_current_volume_timestamp
+  // (neural_sampler.cu:123-128); samplers without time steps accept index 0 only (core/sampler.h:15)
+  if (index < 0 || index >= num_timesteps()) throw std::runtime_error("time step " + std::to_string(index) + " out of range");
+  if (ooc_ || !data_.ptr) {
+    if (index != 0) throw std::runtime_error("only support single timestep volume");
+    return;
+  }
+  if (index != current_step_) {
+    steps_[(size_t)current_step_] = std::move(data_);
+    data_ = std::move(steps_[(size_t)index]);
+    current_step_ = index;
+  }
+  hipStream_t s = Runtime::get().stream;
+  if (!mc_.is_external()) mc_.compute_everything(data_.ptr, s);
+  if (!tfn_.empty()) mc_.update_max_opacity(tfn_.view(), s);
+  VNR_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void SimpleVolume::load_raw_file(const std::string& filename, vec3i dims, int type, size_t offset, bool big_endian, float range_lo, float range_hi)
+{
+  const std::vector<char> buf = read_raw_file(filename, dims, type, offset);
   load_host(buf.data(), dims, type, range_lo, range_hi, big_endian);
 }
 
@@ -470,6 +565,8 @@ void SimpleVolume::load_out_of_core(const std::string& filename, vec3i dims, int
                                     uint64_t n_concurrent_blocks, uint64_t n_blocks)
 {
   data_.resize(0);
+  steps_.clear();
+  current_step_ = 0;
   ooc_ = std::make_unique<OutOfCoreSampler>(filename, dims, type, offset, range_lo, range_hi, n_concurrent_blocks, n_blocks);
   unnormalized_lo = range_lo; unnormalized_hi = range_hi;
   // Sampler::load (neural_sampler.cpp:1224-1227, 1270): the neural volume's grid is capped at 1024 per axis, the

@@ -2,7 +2,7 @@
 #define VNR_SHIM_JSON_TEXT_TRANSPORT
 #include "vnr_api_shim.hpp"
 // Exit codes: 0 = everything ran (GPU present); 42 = all host-only checks passed and the first call that needs a GPU threw
-// std::runtime_error (expected on a box without one); 11..14 = a host-only check failed.
+// std::runtime_error (expected on a box without one); 11..17 = a host-only check failed.
 int main() {
   // host-only part of the api.h surface -------------------------------------------------------------------------------
   {
@@ -22,6 +22,28 @@ int main() {
   if (!vnrRequireDecoding(4) || vnrRequireDecoding(5) || !vnrRequireDecoding(7) || vnrRequireDecoding(8) || vnrRequireDecoding(14) ||
       !vnrRequireDecoding(0) || !vnrRequireDecoding(13)) return 12;
   try { (void)vnrRequireDecoding(16); return 13; } catch (const std::runtime_error&) {}   // api.h:86: unknown rendering mode
+  {  // scene overloads (api.h:104,106,155): host-only parsing
+    vnrJson scene = vnrJson::parse(R"({"dataSource":[{"format":"REGULAR_GRID_RAW_BINARY","fileName":"none.raw","dimensions":{"x":10,"y":20,"z":40},
+      "type":"UNSIGNED_SHORT"}],"view":{"camera":{"eye":{"x":5,"y":10,"z":-80},"center":{"x":5,"y":10,"z":20},"up":{"x":0,"y":1,"z":0},"fovy":35},
+      "volume":{"scalarMappingRange":{"minimum":0.25,"maximum":0.5},"transferFunction":{}}}})");
+    auto cam = vnrCreateCamera(scene);
+    const vnr::vec3f p = vnrCameraGetPosition(cam), f = vnrCameraGetFocus(cam);
+    if (p.x != 0.f || p.y != 0.f || p.z != -100.f || f.z != 0.f) return 15;   // eye / center - dims / 2 (serializer.cpp:425-427)
+    auto cam2 = vnrCreateCamera();
+    vnrCameraSet(cam2, scene);
+    if (vnrCameraGetPosition(cam2).z != -100.f) return 15;
+    try { (void)vnrCreateTransferFunction(scene); return 16; } catch (const std::runtime_error&) {}   // no decoder installed
+    vnrShimTransferFunctionDecoder() = [](const vnrJson&, std::vector<vnr::vec3f>& c, std::vector<vnr::vec2f>& a) {
+      c = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}};
+      a = {{0.f, 0.005f}, {1.f, 0.8f}};
+    };
+    auto t = vnrCreateTransferFunction(scene);
+    if (vnrTransferFunctionGetAlpha(t)[0].y != 0.f || vnrTransferFunctionGetAlpha(t)[1].y != 0.8f) return 16;   // serializer.cpp:207-208
+    const vnr::range1f& r = vnrTransferFunctionGetValueRange(t);
+    if (r.lower != 65535.f * 0.25f || r.upper != 65535.f * 0.5f) return 16;   // serializer.cpp:228-231
+    vnrJson bad = scene; bad["version"] = "SOMETHING";
+    try { (void)vnrCreateCamera(bad); return 17; } catch (const std::runtime_error&) {}   // unknown JSON configuration format
+  }
   vnrRelease(nullptr);                   // declared in api.h:185, never defined there: a no-op here
   vnrMemoryQueryPrint("shim_smoke");     // api.cpp:538-552
   // part that needs a GPU ---------------------------------------------------------------------------------------------

@@ -90,6 +90,20 @@ def test_streaming_groundtruth_matches_oracle(oracle, scene):
     assert st["n_samples"] > 0.5 * ost["n_samples"]
 
 
+def test_frames_do_not_depend_on_n_iters_or_tile_shape(scene, monkeypatch):
+    """the batch size of the streaming loop (VNR_RM_N_ITERS; library default 24, reference default 16) and the shape of the ray
+    tiles are scheduling choices: the frame is the same bit for bit"""
+    frames = []
+    for n_iters, tile_w in (("16", "8"), ("24", "8"), ("5", "8"), ("16", "32"), ("24", "16"), ("16", "64")):
+        monkeypatch.setenv("VNR_RM_N_ITERS", n_iters)
+        monkeypatch.setenv("VNR_AMD_TILE_W", tile_w)
+        r = make_renderer(scene, scene["sv"])
+        api.vnrRender(r)
+        frames.append(api.vnrRendererMapFrame(r).copy())
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
+
+
 def test_accumulation_over_frames(oracle, scene):
     r = make_renderer(scene, scene["sv"])
     mo = api.volume_macrocell(scene["sv"])["max_opacity"]

@@ -1,0 +1,145 @@
+"""Scene documents (serializer.cpp:137-477): vnrCreateSimpleVolume(scene, mode), vnrCreateCamera(scene) / vnrCameraSet(self, scene)
+and the value range of a scene's transfer function.  The expected values are worked out by hand from the reference's loader;
+the host-only parts run without a GPU."""
+import json
+
+import numpy as np
+import pytest
+
+from instantvnr_amd import api
+
+
+def pos(cam):
+    return tuple(float(v) for v in api.vnrCameraGetPosition(cam))
+
+
+def vidi_scene(files, dims, type_name, volume_extra=None, version=None, **source_extra):
+    src = [dict({"format": "REGULAR_GRID_RAW_BINARY", "fileName": f, "dimensions": {"x": dims[0], "y": dims[1], "z": dims[2]},
+                 "type": type_name}, **source_extra) for f in files]
+    sc = {"dataSource": src,
+          "view": {"camera": {"eye": {"x": 10.0, "y": 20.0, "z": -300.0}, "center": {"x": 16.0, "y": 8.0, "z": 4.0},
+                              "up": {"x": 0.0, "y": 1.0, "z": 0.0}, "fovy": 42.0},
+                   "volume": dict({"transferFunction": {}}, **(volume_extra or {}))}}
+    if version:
+        sc["version"] = version
+    return sc
+
+
+def test_camera_from_scene_and_errors():
+    sc = vidi_scene(["a.raw"], (32, 16, 8), "FLOAT", version="VIDI3D")
+    cam = api.vnrCreateCamera(sc)
+    # eye and center move by -dims / 2 (serializer.cpp:425-427); up and fovy are taken as they are
+    assert pos(cam) == (10.0 - 16.0, 20.0 - 8.0, -300.0 - 4.0)
+    assert tuple(api.vnrCameraGetFocus(cam)) == (0.0, 0.0, 0.0)
+    assert tuple(api.vnrCameraGetUpVec(cam)) == (0.0, 1.0, 0.0)
+    cam2 = api.vnrCreateCamera()
+    api.vnrCameraSet(cam2, json.dumps(sc))          # JSON text
+    assert pos(cam2) == pos(cam)
+    # a DIVA scene leaves the camera untouched (the reference's TODO, serializer.cpp:464)
+    cam3 = api.vnrCreateCamera()
+    api.vnrCameraSet(cam3, (1, 2, 3), (0, 0, 0), (0, 0, 1))
+    api.vnrCameraSet(cam3, {"version": "DIVA", "volume": {}})
+    assert pos(cam3) == (1.0, 2.0, 3.0)
+    with pytest.raises(api.VnrAmdError, match="unknown JSON configuration format"):
+        api.vnrCreateCamera(dict(sc, version="OTHER"))
+    with pytest.raises(api.VnrAmdError, match="expected to be an array"):
+        api.vnrCreateCamera(dict(sc, dataSource={}))
+    with pytest.raises(api.VnrAmdError):
+        api.vnrCreateCamera({"view": {}})
+
+
+def test_camera_from_scene_file(tmp_path):
+    sc = vidi_scene(["a.raw"], (2, 4, 6), "BYTE")
+    p = tmp_path / "scene.json"
+    p.write_text("// a scene file may carry comments\n" + json.dumps(sc))
+    cam = api.vnrCreateCamera(str(p))               # a string that is not JSON is a path (api.cpp:77-83)
+    assert pos(cam) == (9.0, 18.0, -303.0)
+
+
+@pytest.mark.parametrize("type_name,unnorm,expect", [
+    ("UNSIGNED_BYTE", False, (255 * 0.25, 255 * 0.5)), ("BYTE", False, (127 * 0.25, 127 * 0.5)),
+    ("UNSIGNED_SHORT", False, (65535 * 0.25, 65535 * 0.5)), ("SHORT", False, (32767 * 0.25, 32767 * 0.5)),
+    ("UNSIGNED_INT", False, (float(np.float32(4294967295) * np.float32(0.25)), float(np.float32(4294967295) * np.float32(0.5)))),
+    ("INT", False, (float(np.float32(2147483647) * np.float32(0.25)), float(np.float32(2147483647) * np.float32(0.5)))),
+    ("FLOAT", False, (0.25, 0.5)), ("DOUBLE", False, (0.25, 0.5)), ("UNSIGNED_BYTE", True, (3.0, 200.0))])
+def test_scene_value_range(type_name, unnorm, expect):
+    extra = {"scalarMappingRange": {"minimum": 0.25, "maximum": 0.5}}
+    if unnorm:  # the unnormalised range wins (serializer.cpp:212-216)
+        extra["scalarMappingRangeUnnormalized"] = {"minimum": 3.0, "maximum": 200.0}
+    sc = vidi_scene(["a.raw"], (4, 4, 4), type_name, extra)
+    assert api.scene_value_range(sc) == pytest.approx(expect, rel=1e-7)
+
+
+def test_scene_without_a_range_and_tfn_table():
+    sc = vidi_scene(["a.raw"], (4, 4, 4), "FLOAT")
+    assert api.scene_value_range(sc) is None
+    assert api.scene_value_range(vidi_scene(["a.raw"], (4, 4, 4), "FLOAT", {"scalarMappingRange": {}})) == (0.0, 0.0)  # rangeFromJson
+    with pytest.raises(api.VnrAmdError, match="tfn module"):
+        api.vnrCreateTransferFunction(sc)
+
+
+# ------------------------------------------------------------------------------------------------ volumes (GPU)
+@pytest.mark.gpu
+def test_simple_volume_from_vidi_scene_with_time_steps(oracle, tmp_path):
+    rng = np.random.default_rng(0)
+    dims = (24, 20, 18)
+    steps = [rng.integers(0, 65535, dims[::-1], dtype=np.uint16) for _ in range(3)]
+    files = []
+    for i, s in enumerate(steps):
+        f = tmp_path / f"t{i}.raw"
+        with open(f, "wb") as h:
+            h.write(b"\0" * 16)
+            h.write(s.astype(">u2").tobytes())     # big endian on disk
+        files.append(str(f))
+    sc = vidi_scene(files, dims, "UNSIGNED_SHORT", {"scalarMappingRangeUnnormalized": {"minimum": 1000.0, "maximum": 60000.0}},
+                    offset=16, endian="BIG_ENDIAN")
+    sc["dataSource"][0]["fileName"] = [str(tmp_path / "missing.raw"), files[0]]   # first existing name wins (serializer.cpp:115-134)
+    sv = api.vnrCreateSimpleVolume(sc, "GPU")
+    assert api.vnrVolumeGetDims(sv) == dims and api.vnrSimpleVolumeGetNumberOfTimeSteps(sv) == 3
+    coords = rng.uniform(0, 1, (2000, 3)).astype(np.float32)
+
+    def norm(a):
+        return np.clip((a.astype(np.float32) - np.float32(1000.0)) / (np.float32(60000.0) - np.float32(1000.0)), 0, 1).astype(np.float32)
+
+    for t in (0, 2, 1, 1, 0):
+        api.vnrSimpleVolumeSetCurrentTimeStep(sv, t)
+        got = api.simple_volume_sample(sv, coords, nodal=False)
+        assert np.array_equal(got, oracle.sample_volume(norm(steps[t]), coords, nodal=False))
+        mc = api.volume_macrocell(sv)
+        assert np.array_equal(mc["value_range"], oracle.macrocell_compute_implicit(norm(steps[t])))
+    with pytest.raises(api.VnrAmdError, match="out of range"):
+        api.vnrSimpleVolumeSetCurrentTimeStep(sv, 3)
+
+
+@pytest.mark.gpu
+def test_simple_volume_from_diva_scene_and_modes(oracle, tmp_path, monkeypatch):
+    rng = np.random.default_rng(1)
+    vol = rng.normal(0, 1, (6, 40, 260)).astype(np.float32)
+    f = tmp_path / "v.raw"
+    vol.tofile(f)
+    sc = {"version": "DIVA", "volume": {"dims": {"x": 260, "y": 40, "z": 6}, "type": "FLOAT", "range": {"x": -1.0, "y": 1.5},
+                                        "filename": str(f)}}
+    monkeypatch.chdir(tmp_path)
+    sv = api.vnrCreateSimpleVolume(sc, "GPU", True)               # save_loaded_volume -> ./reference.bin (neural_sampler.cu:101-108)
+    want = np.clip((vol - np.float32(-1.0)) / np.float32(2.5), 0, 1).astype(np.float32)
+    assert np.array_equal(np.fromfile(tmp_path / "reference.bin", np.float32).reshape(vol.shape), want)
+    # the same scene out of core (reference defaults come from the environment, neural_sampler.cpp:1054-1062)
+    monkeypatch.setenv("VNR_NUM_CONCURRENT_BLOCKS", "4")
+    monkeypatch.setenv("VNR_NUM_BLOCKS", "12")
+    ov = api.vnrCreateSimpleVolume(sc, "OUT_OF_CORE")
+    info = api.out_of_core_info(ov)
+    assert (info["n_concurrent_blocks"], info["n_blocks"]) == (4, 12) and info["file_dims"] == (260, 40, 6)
+    blocks = api.out_of_core_blocks(ov)
+    c, v = api.simple_volume_take_samples(ov, 512)
+    r = oracle.pcg32_floats(5 * 512, 0, 1337, 0xda3e39cb94b95bdb)
+    wc, wv, _ = oracle.OocSlabSet(vol, blocks).sample((-1.0, 1.5), r[:1536].reshape(512, 3), r[1536:2048], r[2048:])
+    assert np.array_equal(c, wc) and np.array_equal(v, wv)
+    # a shape without data, and the modes this build does not have
+    nv = api.vnrCreateSimpleVolume(sc, "NOTHING")
+    assert api.vnrVolumeGetDims(nv) == (260, 40, 6)
+    with pytest.raises(api.VnrAmdError, match="not implemented"):
+        api.vnrCreateSimpleVolume(sc, "VIRTUAL_MEMORY")
+    with pytest.raises(api.VnrAmdError, match="unknown mode"):
+        api.vnrCreateSimpleVolume(sc, "SOMETHING")
+    with pytest.raises(api.VnrAmdError, match="cannot open"):
+        api.vnrCreateSimpleVolume(dict(sc, volume=dict(sc["volume"], filename="/nonexistent.raw")), "GPU")

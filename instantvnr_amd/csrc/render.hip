@@ -314,7 +314,8 @@ __device__ __forceinline__ uint32_t depth_bin(const RenderParams& p, float t, fl
 template <bool FIRST, bool GRAD>
 __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const RayList cur, const RayList nxt,
                                                     const vec2f* __restrict__ vd_in, vec4f* __restrict__ queue,
-                                                    vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters, int parity)
+                                                    vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters,
+                                                    uint32_t* __restrict__ ray_counts, int parity)
 {
   extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1}, histogram[256], [n_iters][256] ranks (u16), then the transfer function tables
   float* s_t0 = s_t;
@@ -334,7 +335,6 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
   }
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t n_in = FIRST ? p.n_local : counters[C_RAYS0 + parity];
-  uint32_t* n_rays_out = counters + C_RAYS0 + (parity ^ 1);
   uint32_t* n_samples_out = counters + C_SAMPLES0 + parity;
   const uint32_t n_round = (n_in + 255u) & ~255u;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -418,10 +418,15 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     }
     const uint32_t wave_samples = __shfl(incl, 63);
     const uint32_t wave_rays = (uint32_t)__popcll(mask);
-    uint32_t ray_base = 0, smp_base = 0;
+    // Surviving rays go to the wave's OWN 64 slots of the scratch list (`nxt`) and compact_rays_kernel packs the groups in
+    // wave order afterwards: an order-preserving compaction, so a 64-ray group stays a compact patch of the image over the
+    // iterations.  (Claiming slots with an atomic, as the reference does, hands them out in wave-arrival order; by the third
+    // iteration a group then mixes rays of distant tiles and the hash-grid gathers of its samples lose 20-35 % of their rate.)
+    const uint32_t group = i >> 6;
+    uint32_t smp_base = 0;
     if (lane == 0) {
+      ray_counts[group] = wave_rays;
       if (wave_rays) {
-        ray_base = atomicAdd(n_rays_out, wave_rays);
         // the queue counter counts RECORDS (what the evaluation kernel reads); with 4 records per sample every claim is a
         // multiple of 4, so claim / 4 is a unique sample-slot base
         smp_base = GRAD ? atomicAdd(n_samples_out, 4u * wave_samples) >> 2 : atomicAdd(n_samples_out, wave_samples);
@@ -430,7 +435,6 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
       if (alive_mask) atomicAdd((unsigned long long*)(counters + C_STAT_REFRAYS), (unsigned long long)__popcll(alive_mask));
       if (FIRST && alive_mask) atomicAdd(counters + C_HIT, (uint32_t)__popcll(alive_mask));
     }
-    ray_base = __shfl(ray_base, 0);
     smp_base = __shfl(smp_base, 0);
     if (wave_rays == 0) continue;  // wave-uniform
 
@@ -463,7 +467,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     __builtin_amdgcn_wave_barrier();
 
     if (survive) {
-      const uint32_t slot = ray_base + (uint32_t)__popcll(mask & lt_mask);
+      const uint32_t slot = (group << 6) + (uint32_t)__popcll(mask & lt_mask);
       const uint32_t sb = smp_base + (incl - k);  // ray-major base of this ray
       nxt.pixel_index[slot] = pixel;
       nxt.jitter[slot] = jitter;
@@ -508,10 +512,56 @@ __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float
   }
 }
 
-__global__ void clear_two_kernel(uint32_t* a, uint32_t* b)
+// Packs the 64-ray groups march_kernel left in the scratch list (group g holds ray_counts[g] rays in slots 64 g ..) into the
+// dense list, in group order.  One thread per scratch slot; a block (16 groups) first sums the counts of all groups before
+// it (at most 64 KiB of L2-resident counts per block), so no second launch and no inter-block dependency is needed.  The block
+// that holds the last group publishes the number of alive rays; block 0 also clears the sample counter the next march adds to.
+__global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, const RayList dst, const uint32_t* __restrict__ ray_counts,
+                                                            uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first)
 {
-  if (a) *a = 0;
-  if (b) *b = 0;
+  __shared__ uint32_t s_part[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n_in = first ? n_first : counters[C_RAYS0 + parity];   // rays the march that just ran consumed
+  const uint32_t n_groups = ((n_in + 255u) & ~255u) >> 6;               // groups it wrote a count for
+  if (blockIdx.x == 0 && tid == 0) counters[C_SAMPLES0 + (parity ^ 1)] = 0;
+  if (n_groups == 0) {
+    if (blockIdx.x == 0 && tid == 0) counters[C_RAYS0 + (parity ^ 1)] = 0;
+    return;
+  }
+  const uint32_t g0 = blockIdx.x * 16u;
+  if (g0 >= n_groups) return;
+  uint32_t sum = 0;
+  for (uint32_t g = tid; g < g0; g += 1024u) sum += ray_counts[g];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+  if (lane == 0) s_part[wave] = sum;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) before += s_part[w];
+  // counts of this block's groups: lane l < 16 of every wave holds count[g0 + l]
+  const uint32_t mine = (lane < 16u && g0 + lane < n_groups) ? ray_counts[g0 + lane] : 0u;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    const uint32_t y = __shfl_up(incl, d);
+    if ((int)lane >= d) incl += y;
+  }
+  const uint32_t count = __shfl(mine, (int)wave), base = before + __shfl(incl, (int)wave) - count;
+  const uint32_t block_total = __shfl(incl, 15);
+  if (g0 + 16u >= n_groups && tid == 0) counters[C_RAYS0 + (parity ^ 1)] = before + block_total;
+  if (lane < count) {
+    const uint32_t from = ((g0 + wave) << 6) + lane, to = base + lane;
+    dst.pixel_index[to] = src.pixel_index[from];
+    dst.jitter[to] = src.jitter[from];
+    dst.alpha[to] = src.alpha[from];
+    dst.color[to] = src.color[from];
+    dst.cell[to] = src.cell[from];
+    dst.t_next[to] = src.t_next[from];
+    dst.next_cell_begin[to] = src.next_cell_begin[from];
+    dst.sample_base[to] = src.sample_base[from];
+    dst.sample_count[to] = src.sample_count[from];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ monolithic marcher (mode 4)
@@ -652,6 +702,7 @@ void Renderer::ensure_queues(size_t n_pixels, int n_iters, bool gradient)
   const int iters = std::max(n_iters, queue_iters_);
   const bool grad = gradient || queue_grad_;
   q_u32_.resize(6 * P);
+  ray_counts_.resize(P / 64 + 64);   // survivors per 64-ray group (P is a multiple of 64; slack for the round-up to 256 rays)
   q_f32_.resize(18 * P);
   q_i32_.resize(6 * P);
   queue_.resize(P * iters * (grad ? 4 : 1));          // 4 records per sample with gradient shading
@@ -781,6 +832,7 @@ void Renderer::render_streaming(const RenderParams& p_all)
     vec4f* queue;
     vec2f* vd[2];
     uint32_t* c;         // device counters of this half
+    uint32_t* rc;        // survivors per 64-ray group
     uint32_t* hc;        // pinned ring of alive-ray counts
     hipStream_t s;
     size_t s_max;
@@ -813,6 +865,7 @@ void Renderer::render_streaming(const RenderParams& p_all)
     hf.p.slot_cap = (uint32_t)((size_t)hf.p.n_local * QI);   // 2 (+ 4 with gradient shading) floats per slot fit the slice
     hf.queue = queue_.ptr + rec_per_slot * off * QI;
     hf.c = counters_.ptr + (size_t)h * C_COUNT;
+    hf.rc = ray_counts_.ptr + off / 64 + (size_t)h * 8;   // halves are multiples of 64 rays; 8 groups of slack each
     hf.hc = host_counts_ + (size_t)h * 256;
     hf.s = h == 0 ? stream_ : stream2_;
     hf.s_max = (size_t)hf.p.n_local * hf.p.n_iters * (grad ? 4 : 1);   // records the evaluation kernel may see
@@ -850,21 +903,20 @@ void Renderer::render_streaming(const RenderParams& p_all)
     const int parity = (int)(it & 1u);
     const uint32_t P = hf.p.n_local;
     uint32_t* c = hf.c;
-    // march(it): reads ray list `parity`, writes list `parity^1` and sample queue `parity`
+    // march(it): reads the dense ray list rl[0] (count: counter `parity`), leaves the survivors of every 64-ray group in the
+    // group's slots of the scratch list rl[1] and appends their samples to queue `parity`
     if (it == 0) {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 4096u);
-      if (grad) march_kernel<true, true><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, 0);
-      else march_kernel<true, false><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, 0);
+      if (grad) march_kernel<true, true><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, hf.rc, 0);
+      else march_kernel<true, false><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, hf.rc, 0);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
       if (grad)
-        march_kernel<false, true><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[parity], hf.rl[parity ^ 1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, parity);
+        march_kernel<false, true><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, hf.rc, parity);
       else
-        march_kernel<false, false><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[parity], hf.rl[parity ^ 1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, parity);
+        march_kernel<false, false><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, hf.rc, parity);
     }
     VNR_HIP_CHECK(hipGetLastError());
-    uint32_t* clear0 = c + C_RAYS0 + parity;            // output ray list of march(it+1)
-    uint32_t* clear1 = c + C_SAMPLES0 + (parity ^ 1);   // sample counter of march(it+1)
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it], hf.s));
     if (nv) {
       // a record's 4th word is the float index of its result in this arena (stride 1)
@@ -874,7 +926,9 @@ void Renderer::render_streaming(const RenderParams& p_all)
       gt_sample_kernel<<<blocks, 256, 0, hf.s>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, (float*)hf.vd[parity]);
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
-    clear_two_kernel<<<1, 1, 0, hf.s>>>(clear0, clear1);
+    // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
+    compact_rays_kernel<<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0);
+    VNR_HIP_CHECK(hipGetLastError());
     VNR_HIP_CHECK(hipMemcpyAsync(hf.hc + (it & 255u), c + C_RAYS0 + (parity ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, hf.s));
     ++hf.it;
     if (hf.it >= max_iterations) hf.done = true;

@@ -91,6 +91,7 @@ private:
   DeviceBuffer<uint32_t> q_u32_;   // pixel_index[2], sample_base[2], sample_count[2]
   DeviceBuffer<float> q_f32_;      // jitter[2], alpha[2], color[2][3], t_next[2][3], next_cell_begin[2]
   DeviceBuffer<int> q_i32_;        // cell[2][3]
+  DeviceBuffer<uint32_t> ray_counts_;  // surviving rays per 64-ray group of the last march (order-preserving compaction)
   DeviceBuffer<vec4f> queue_;      // gather-order sample records {x, y, z, ray-major slot}
   DeviceBuffer<float> arena_;      // evaluation results, x2 (ping-pong): per slot {value, t1 - t0}, then (gradient shading) 4 more floats
   bool queue_grad_ = false;        // queues currently sized for 4 records / 6 result floats per sample

@@ -230,14 +230,68 @@ __device__ __forceinline__ void gather_corners(const LevelInfo& lv, const Corner
   }
 }
 
+// Corners of one cell out of the brick image (network.h): entry (x, y, z) of a level lives at
+//   ((z >> lz) nby + (y >> ly)) nbx + (x >> lx)   bricks of one 128-byte line, then (z & mz, y & my, x & mx) x-fastest inside.
+// The step to the +1 neighbour is a constant unless the cell sits on a brick face, so one index and three selects address
+// all 8 corners; corners x and x + 1 of a row come with ONE load unless x is the last column of its brick (1 lane in 4, where
+// the hash pays a second gather for every odd x).  Plain 64-bit addresses: the finest level of the bench model is 4.3 GB.
+// Returns false (wave-uniform) when a lane's cell is outside the level's grid, i.e. the coordinate was outside [0, 1]: the
+// caller then reads the parameter blob, whose index arithmetic is defined for any coordinate.
 template <int F>
-__device__ __forceinline__ void encode_level_fast(const LevelInfo& lv, uint32_t interpolation, table_rsrc_t rsrc,
+__device__ __forceinline__ bool gather_corners_brick(const LevelInfo& lv, const CornerSetup& c, const uint8_t* __restrict__ image,
+                                                     typename RawFeat<F>::raw_t (&v)[8])
+{
+  typedef typename RawFeat<F>::raw_t raw_t;
+  constexpr uint32_t LX = BrickShape<F>::lx, LY = BrickShape<F>::ly, LZ = BrickShape<F>::lz;
+  constexpr uint32_t MX = (1u << LX) - 1u, MY = (1u << LY) - 1u, MZ = (1u << LZ) - 1u;
+  constexpr uint32_t E = 1u << (LX + LY + LZ);   // entries per brick
+  constexpr uint32_t kBytes = (uint32_t)(F * 2);
+  static_assert(E * kBytes == 128, "a brick is one 128-byte line");
+  const uint32_t res = lv.resolution;
+  const bool bad = (c.g[0] >= res) | (c.g[1] >= res) | (c.g[2] >= res);
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull) return false;
+  const uint32_t nbx = (res >> LX) + 1u, nby = (res >> LY) + 1u;   // scalar
+  const uint32_t wx = c.g[0] & MX, wy = c.g[1] & MY, wz = c.g[2] & MZ;
+  const uint32_t brick = __umul24(__umul24(c.g[2] >> LZ, nby) + (c.g[1] >> LY), nbx) + (c.g[0] >> LX);
+  const uint32_t e0 = brick * E + ((wz << (LX + LY)) | (wy << LX) | wx);
+  const uint32_t dx = wx == MX ? E - MX : 1u;
+  const uint32_t dy = wy == MY ? nbx * E - (MY << LX) : 1u << LX;
+  const uint32_t dz = wz == MZ ? nbx * nby * E - (MZ << (LX + LY)) : 1u << (LX + LY);
+  const uint8_t* base = image + (size_t)(lv.brick - 1u) * 128u;
+  if constexpr (PairFeat<F>::enabled) {
+    typedef typename PairFeat<F>::pair_t pair_t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t e = e0 + ((q & 1) ? dy : 0u) + ((q & 2) ? dz : 0u);
+      const pair_t pr = *(const pair_t*)(base + (size_t)e * kBytes);   // entries e, e + 1 (the image ends with a spare line)
+      v[2 * q] = PairFeat<F>::lo(pr);
+      v[2 * q + 1] = PairFeat<F>::hi(pr);
+    }
+    if (wx == MX) {  // divergent: the +x neighbour is the first column of the next brick
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t e = e0 + ((q & 1) ? dy : 0u) + ((q & 2) ? dz : 0u) + dx;
+        v[2 * q + 1] = *(const raw_t*)(base + (size_t)e * kBytes);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const uint32_t e = e0 + ((corner & 1) ? dx : 0u) + ((corner & 2) ? dy : 0u) + ((corner & 4) ? dz : 0u);
+      v[corner] = *(const raw_t*)(base + (size_t)e * kBytes);
+    }
+  }
+  return true;
+}
+
+template <int F>
+__device__ __forceinline__ void encode_level_fast(const LevelInfo& lv, uint32_t interpolation, table_rsrc_t rsrc, const uint8_t* image,
                                                   float x, float y, float z, half_t* out)
 {
   typedef typename RawFeat<F>::raw_t raw_t;
   const CornerSetup c = level_setup(lv, interpolation, x, y, z);
   raw_t v[8];
-  gather_corners<F>(lv, c, rsrc, v);
+  if (lv.brick == 0u || !gather_corners_brick<F>(lv, c, image, v)) gather_corners<F>(lv, c, rsrc, v);
   const float wx0 = 1.0f - c.w[0], wx1 = c.w[0], wy0 = 1.0f - c.w[1], wy1 = c.w[1], wz0 = 1.0f - c.w[2], wz1 = c.w[2];
   const float wxy[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
   half_t acc[F];

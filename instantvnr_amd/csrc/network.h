@@ -21,8 +21,23 @@ struct LevelInfo {
   uint32_t size;    // entries in this level
   uint32_t offset;  // first entry of this level (entries, x F for elements)
   uint32_t hashed;  // 1: prime-XOR hash (size is a power of two), 0: dense index
-  uint32_t pad0, pad1;  // 32 bytes: one s_load_dwordx8 per level
+  uint32_t brick;   // 0: read the parameter blob; else 1 + first 128-byte line of this level in the brick image (below)
+  uint32_t pad1;    // 32 bytes: one s_load_dwordx8 per level
 };
+
+// Brick image (inference only): a level whose table is hashed is ALSO kept de-hashed, as a dense array over the level's
+// (res + 1)^3 grid points stored in bricks of one 128-byte line: 4x4x4 entries for F = 1, 4x4x2 for F = 2, 4x2x2 for F = 4,
+// 2x2x2 for F = 8.  The values are copies (image[x, y, z] = table[hash(x, y, z)]), so results are bit-identical; what changes
+// is which lines a wave touches: the 8 corners of a cell fall into ~2.3 lines instead of 4-8 and neighbouring samples share
+// them, where the hash scatters every (y, z) row to an unrelated line (measured on the bench frame's sample queue: 917 -> 385
+// fetched bytes per sample inside a 64-sample wave).  The price is memory, 7.6 GB instead of 140 MB for the bench model,
+// which is what 288 GB of HBM are for, and a rebuild (a few ms) after the parameters change, so the image is only built once
+// the parameters have been left alone for a while (Network::brick_policy).
+template <int F> struct BrickShape;
+template <> struct BrickShape<1> { static constexpr uint32_t lx = 2, ly = 2, lz = 2; };
+template <> struct BrickShape<2> { static constexpr uint32_t lx = 2, ly = 2, lz = 1; };
+template <> struct BrickShape<4> { static constexpr uint32_t lx = 2, ly = 1, lz = 1; };
+template <> struct BrickShape<8> { static constexpr uint32_t lx = 1, ly = 1, lz = 1; };
 
 struct GridDevice {
   LevelInfo levels[kMaxLevels];
@@ -102,10 +117,19 @@ public:
 
   size_t bytes_allocated() const;
 
+  // brick image policy: built on stream `s` once `brick_after` inference launches have seen unchanged parameters
+  // (VNR_AMD_BRICK_AFTER, default 24 = two frames of the streaming renderer; VNR_AMD_BRICK=0 disables, =1 builds at the first
+  // launch), within VNR_AMD_BRICK_MAX_GB (default 32) and a quarter of the free device memory
+  bool brick_image_in_use() const { return brick_valid_; }
+  size_t brick_image_bytes() const { return brick_image_.bytes(); }
+  float brick_build_ms() const { return brick_build_ms_; }
+
 private:
   void build_layout();
   void initialize_params(uint64_t seed, hipStream_t s);
   void refresh_inference_weights(hipStream_t s);
+  const LevelInfo* inference_levels(hipStream_t s, const uint8_t** image) const;  // decides / builds / orders streams
+  void build_brick_image(hipStream_t s) const;
 
   ModelConfig cfg_;
   Json model_;
@@ -126,6 +150,18 @@ private:
   DeviceBuffer<float> ws_loss_{MemTag::Network};         // [blocks] partial loss sums
   size_t ws_batch_ = 0;
   uint32_t lds_halves_ = 0;
+  // brick image (inference cache; mutable: built lazily from const inference calls)
+  mutable DeviceBuffer<uint8_t> brick_image_{MemTag::Network};
+  mutable DeviceBuffer<LevelInfo> levels_brick_dev_{MemTag::Network};
+  mutable bool brick_valid_ = false, brick_refused_ = false;
+  mutable uint32_t brick_stable_calls_ = 0;
+  mutable hipEvent_t brick_event_ = nullptr;
+  mutable float brick_build_ms_ = 0.0f;
+
+public:
+  ~Network();
+  Network(const Network&) = delete;
+  Network& operator=(const Network&) = delete;
 };
 
 // layout helpers shared with tests

@@ -6,6 +6,9 @@
 #include "network.h"
 
 #include <algorithm>
+#include <cstdlib>
+
+#include "grid_device.h"
 
 namespace vnr {
 
@@ -13,7 +16,7 @@ void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
-                  const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0);
+                  const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr);
 void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
                         uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s);
 // master weights <- fp16 parameters; reset_optimizer also zeroes the moments and step counts
@@ -79,7 +82,7 @@ uint32_t grid_make_layout(const ModelConfig& cfg, GridDevice* out)
     lv.size = n;
     lv.offset = offset;
     lv.hashed = n < stride ? 1u : 0u;
-    lv.pad0 = lv.pad1 = 0;
+    lv.brick = lv.pad1 = 0;
     if (lv.hashed && (n & (n - 1)) != 0) throw std::runtime_error("internal: hashed level with non power-of-two size");
     offset += n;
   }
@@ -194,6 +197,115 @@ void Network::initialize_params(uint64_t seed, hipStream_t s)
 void Network::refresh_inference_weights(hipStream_t s)
 {
   launch_pack_mlp(params_f16_.ptr, mlp_packed_.ptr, in_width_, n_hidden_matmuls(), s);
+  // the parameters changed: the brick image is stale (it is rebuilt once they have been left alone again)
+  brick_valid_ = false;
+  brick_stable_calls_ = 0;
+}
+
+Network::~Network()
+{
+  if (brick_event_) (void)hipEventDestroy(brick_event_);
+}
+
+// ------------------------------------------------------------------------------------------------ brick image (network.h)
+// one thread per entry of a level's image: (brick, x-fastest position inside it) -> grid point -> the entry the reference's
+// index function gives that point (level_index: hash or dense, exact `% size` semantics); points beyond the grid are zero
+template <int F>
+__global__ void brick_build_kernel(const LevelInfo lv, const half_t* __restrict__ table, uint8_t* __restrict__ image, uint64_t n_entries)
+{
+  typedef typename FeatVec<F>::type vec_t;
+  constexpr uint32_t LX = BrickShape<F>::lx, LY = BrickShape<F>::ly, LZ = BrickShape<F>::lz;
+  constexpr uint32_t E = 1u << (LX + LY + LZ);
+  const uint32_t nbx = (lv.resolution >> LX) + 1u, nby = (lv.resolution >> LY) + 1u;
+  vec_t* out = (vec_t*)(image + (size_t)(lv.brick - 1u) * 128u);
+  const vec_t* src = (const vec_t*)(table + (size_t)lv.offset * F);
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t w = (uint32_t)(e & (E - 1u));
+    const uint64_t b = e >> (LX + LY + LZ);
+    const uint32_t bx = (uint32_t)(b % nbx), by = (uint32_t)((b / nbx) % nby), bz = (uint32_t)(b / ((uint64_t)nbx * nby));
+    const uint32_t x = (bx << LX) | (w & ((1u << LX) - 1u)), y = (by << LY) | ((w >> LX) & ((1u << LY) - 1u)), z = (bz << LZ) | (w >> (LX + LY));
+    vec_t v;
+    if (x <= lv.resolution && y <= lv.resolution && z <= lv.resolution) v = src[level_index(lv, x, y, z)];
+    else v = vec_t{};
+    out[e] = v;
+  }
+}
+
+template <int F>
+static void launch_brick_build(const LevelInfo& lv, const uint16_t* table, uint8_t* image, uint64_t n_entries, hipStream_t s)
+{
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_entries + 255) / 256, 1u << 20);
+  brick_build_kernel<F><<<blocks, 256, 0, s>>>(lv, (const half_t*)table, image, n_entries);
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+void Network::build_brick_image(hipStream_t s) const
+{
+  // which levels: the hashed ones (VNR_AMD_BRICK_DENSE=1: every level), finest first, while the image stays within the budget
+  static const bool dense_too = [] { const char* e = std::getenv("VNR_AMD_BRICK_DENSE"); return e && std::atoi(e) != 0; }();
+  static const double max_gb = [] { const char* e = std::getenv("VNR_AMD_BRICK_MAX_GB"); return e ? std::atof(e) : 32.0; }();
+  size_t free_b = 0, total_b = 0;
+  VNR_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+  const uint64_t budget_lines = (uint64_t)std::min(max_gb * 1073741824.0, (double)(free_b + brick_image_.bytes()) / 4.0) / 128u;
+  const uint32_t F = cfg_.n_features;
+  const uint32_t lx = F == 8 ? 1 : 2, ly = F >= 4 ? 1 : 2, lz = F == 1 ? 2 : 1;
+  const uint64_t entries_per_line = 64u / F;
+  std::vector<LevelInfo> lv(grid_.levels, grid_.levels + kMaxLevels);
+  std::vector<uint64_t> lines(kMaxLevels, 0);
+  uint64_t used = 0;
+  for (int l = (int)grid_.n_levels - 1; l >= 0; --l) {
+    if (!lv[l].hashed && !dense_too) continue;
+    const uint64_t res = lv[l].resolution;
+    const uint64_t n = ((res >> lx) + 1) * ((res >> ly) + 1) * ((res >> lz) + 1);
+    if (n * entries_per_line >= (1ull << 32) || used + n + 1 > budget_lines || used + n + 1 >= 0xffffffffull) continue;
+    lv[l].brick = (uint32_t)used + 1u;
+    lines[l] = n;
+    used += n;
+  }
+  if (used == 0) { brick_refused_ = true; return; }
+  hipEvent_t t0, t1;
+  VNR_HIP_CHECK(hipEventCreate(&t0)); VNR_HIP_CHECK(hipEventCreate(&t1));
+  brick_image_.resize((used + 1) * 128u);   // + one spare line: a pair load at the last entry reads 2 entries
+  VNR_HIP_CHECK(hipEventRecord(t0, s));
+  for (uint32_t l = 0; l < grid_.n_levels; ++l) {
+    if (!lv[l].brick) continue;
+    const uint64_t n_entries = lines[l] * entries_per_line;
+    const uint16_t* table = params_f16_.ptr + n_mlp_;
+    switch (F) {
+    case 1: launch_brick_build<1>(lv[l], table, brick_image_.ptr, n_entries, s); break;
+    case 2: launch_brick_build<2>(lv[l], table, brick_image_.ptr, n_entries, s); break;
+    case 4: launch_brick_build<4>(lv[l], table, brick_image_.ptr, n_entries, s); break;
+    default: launch_brick_build<8>(lv[l], table, brick_image_.ptr, n_entries, s); break;
+    }
+  }
+  VNR_HIP_CHECK(hipMemsetAsync(brick_image_.ptr + used * 128u, 0, 128, s));
+  levels_brick_dev_.resize(kMaxLevels);
+  // pageable host source: the copy has completed for the host when the call returns, the device side is ordered on `s`
+  VNR_HIP_CHECK(hipMemcpyAsync(levels_brick_dev_.ptr, lv.data(), kMaxLevels * sizeof(LevelInfo), hipMemcpyHostToDevice, s));
+  VNR_HIP_CHECK(hipEventRecord(t1, s));
+  if (!brick_event_) VNR_HIP_CHECK(hipEventCreateWithFlags(&brick_event_, hipEventDisableTiming));
+  VNR_HIP_CHECK(hipEventRecord(brick_event_, s));
+  VNR_HIP_CHECK(hipEventSynchronize(t1));
+  VNR_HIP_CHECK(hipEventElapsedTime(&brick_build_ms_, t0, t1));
+  (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+  brick_valid_ = true;
+}
+
+const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image) const
+{
+  static const int mode = [] { const char* e = std::getenv("VNR_AMD_BRICK"); return e ? std::atoi(e) : -1; }();   // -1 auto, 0 off, 1 at once
+  static const uint32_t after = [] { const char* e = std::getenv("VNR_AMD_BRICK_AFTER"); return e ? (uint32_t)std::max(0, std::atoi(e)) : 24u; }();
+  *image = nullptr;
+  if (mode == 0 || brick_refused_) return levels_dev_.ptr;
+  if (!brick_valid_) {
+    if (++brick_stable_calls_ <= (mode == 1 ? 0u : after)) return levels_dev_.ptr;
+    build_brick_image(s);
+    if (!brick_valid_) return levels_dev_.ptr;
+  }
+  // the image was built on one stream; launches on any other stream wait for it (a no-op once it has completed)
+  VNR_HIP_CHECK(hipStreamWaitEvent(s, brick_event_, 0));
+  *image = brick_image_.ptr;
+  return levels_brick_dev_.ptr;
 }
 
 void Network::set_params_f16(const uint16_t* host, size_t count, hipStream_t s)
@@ -249,25 +361,31 @@ void Network::deserialize_params(const Json& j, hipStream_t s)
 void Network::inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                         const uint32_t* d_dest) const
 {
-  launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest);
+  const uint8_t* image;
+  const LevelInfo* levels = inference_levels(s, &image);
+  launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
+               mlp_packed_.ptr, lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest, 0, image);
 }
 
 void Network::inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s) const
 {
-  launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride);
+  const uint8_t* image;
+  const LevelInfo* levels = inference_levels(s, &image);
+  launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
+               mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image);
 }
 
 void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const
 {
-  launch_fused(1, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s);
+  const uint8_t* image;
+  const LevelInfo* levels = inference_levels(s, &image);
+  launch_fused(1, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
+               mlp_packed_.ptr, lds_halves_, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s, nullptr, 0, image);
 }
 
 size_t Network::bytes_allocated() const
 {
-  return params_f16_.bytes() + mlp_packed_.bytes() + opt_state_.bytes() + grads_.bytes() + ws_features_.bytes() + ws_acts_.bytes() + ws_dfeat_.bytes() + ws_loss_.bytes();
+  return brick_image_.bytes() + params_f16_.bytes() + mlp_packed_.bytes() + opt_state_.bytes() + grads_.bytes() + ws_features_.bytes() + ws_acts_.bytes() + ws_dfeat_.bytes() + ws_loss_.bytes();
 }
 
 }  // namespace vnr

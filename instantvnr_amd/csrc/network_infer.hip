@@ -72,6 +72,7 @@ struct InferArgs {
   uint32_t n_levels, interpolation;
   const half_t* table;       // grid part of the parameter blob
   uint32_t table_bytes;
+  const uint8_t* brick_image;  // de-hashed copies of the levels whose LevelInfo::brick is set (network.h), or null
   const half_t* packed_mlp;  // LDS image
   const float* coords;       // [n][3]
   float* out;                // [n]
@@ -264,7 +265,8 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
         lv.size = __builtin_amdgcn_readfirstlane(lvtab[l].size);
         lv.offset = __builtin_amdgcn_readfirstlane(lvtab[l].offset);
         lv.hashed = __builtin_amdgcn_readfirstlane(lvtab[l].hashed);
-        encode_level_fast<F>(lv, args.interpolation, rsrc, p.x, p.y, p.z, o);
+        lv.brick = __builtin_amdgcn_readfirstlane(lvtab[l].brick);
+        encode_level_fast<F>(lv, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, o);
       } else {
 #pragma unroll
         for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
@@ -355,7 +357,7 @@ static void dispatch(uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
-                  const uint32_t* d_dest, uint32_t queue_out_stride)
+                  const uint32_t* d_dest, uint32_t queue_out_stride, const uint8_t* brick_image)
 {
   if (n_max == 0) return;
   if (n_max > 0xffffffc0ull) throw std::runtime_error("inference batch too large (max 2^32-64 samples per call)");
@@ -366,6 +368,7 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
   a.interpolation = grid.interpolation;
   a.table = (const half_t*)table;
   a.table_bytes = (uint32_t)table_bytes;
+  a.brick_image = brick_image;
   a.packed_mlp = (const half_t*)packed;
   a.coords = coords;
   a.out = out;

@@ -88,7 +88,35 @@ def regroup_by_pixel(coords, tile_order):
     return coords[order]
 
 
-for it in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
+def lines_per_sample(coords, chunk=64, n_max=1 << 21):
+    """distinct 128-B lines per sample and level inside a 64-sample chunk: the table as it is (x-fastest rows / hash) against a
+    de-hashed dense image in 4x4x2-entry bricks (F = 2: 32 entries = one line)"""
+    c = coords[: (min(len(coords), n_max) // chunk) * chunk].astype(np.float32)
+    scale0 = np.float32(pls)
+    out = []
+    for l in range(16):
+        scale = np.float32(np.exp2(np.float32(l) * np.log2(scale0)) * np.float32(16.0) - np.float32(1.0))
+        res = int(np.ceil(scale)) + 1
+        g = np.floor(c * scale + np.float32(0.5)).astype(np.int64)
+        hashed = res ** 3 > (1 << 22)
+        cur, brk = [], []
+        for k in range(8):
+            x, y, z = g[:, 0] + (k & 1), g[:, 1] + ((k >> 1) & 1), g[:, 2] + (k >> 2)
+            if hashed:
+                idx = (x ^ (y * 2654435761) ^ (z * 805459861)) & ((1 << 22) - 1)
+            else:
+                idx = x + y * res + z * res * res
+            cur.append(idx >> 5)
+            bx, by, bz = (res + 4) // 4, (res + 4) // 4, (res + 2) // 2
+            brk.append((x >> 2) + bx * ((y >> 2) + by * (z >> 1)))
+        def uniq(a):
+            a = np.sort(np.stack(a, 1).reshape(-1, chunk * 8), axis=1)
+            return (1 + (np.diff(a, axis=1) != 0).sum(1)).mean() / chunk
+        out.append((l, res, hashed, uniq(cur), uniq(brk)))
+    return out
+
+
+for it in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 4]:
     os.environ["VNR_AMD_DEBUG_MAX_ITERS"] = str(it)
     ren = api.vnrCreateRenderer(nv)
     api.vnrRendererSetFramebufferSize(ren, (1024, 1024))
@@ -108,6 +136,13 @@ for it in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
     check(L.vnrAmdMemcpyD2H(rec.ctypes.data_as(C.c_void_p), dc, n * 16))
     coords = np.ascontiguousarray(rec[:, :3])
     print(f"iteration {it}: {n} samples (N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24')})", flush=True)
+    if "--lines" in sys.argv:
+        tot_c = tot_b = 0.0
+        for l, res, hashed, lc, lb in lines_per_sample(coords):
+            print(f"    level {l:2d} res {res:5d} {'hash ' if hashed else 'dense'} lines/sample in a 64-chunk: as is {lc:.3f}   4x4x2 bricks {lb:.3f}")
+            tot_c += lc; tot_b += lb
+        print(f"    all levels: as is {tot_c:.2f} lines = {tot_c * 128:.0f} B per sample; bricks {tot_b:.2f} lines = {tot_b * 128:.0f} B per sample", flush=True)
+        continue
     run("queue order", coords)
     run("regrouped: rays in row-major tile order", regroup_by_pixel(coords, "row"))
     run("regrouped: rays in Morton tile order", regroup_by_pixel(coords, "morton"))
@@ -117,3 +152,5 @@ for it in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
     run("samples sorted by Morton code (upper bound)", coords[np.argsort(morton(q), kind="stable")])
     run("shuffled (lower bound)", coords[np.random.default_rng(0).permutation(n)])
     del ren
+
+

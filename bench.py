@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--camera-distance", type=float, default=1.1, help="camera distance in volume edges (oblique view)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-psnr", action="store_true")
+    p.add_argument("--no-alone", action="store_true", help="skip the un-timed one-stream leg (roofline.alone)")
     p.add_argument("--mode", type=int, default=5, choices=(5, 8),
                    help="rendering mode: 5 = sample streaming (BASELINE metric, default), 8 = the same with gradient shading (4 evaluations per sample)")
     return p.parse_args()
@@ -165,6 +166,36 @@ def main():
     elapsed = time.perf_counter() - t0
     rays_hit = st["n_rays_hit"]
 
+    # ---- un-timed extra leg (one GPU only): the dominant kernel with the GPU to itself -------------------------------------
+    # The default renderer runs two ray halves on two HIP streams, so a launch of the fused kernel shares the GPU with the
+    # other half's kernels and its HIP-event duration says little about the kernel.  The same frames on ONE stream (nothing
+    # else resident while the kernel runs) give the per-launch figure the roofline fraction is meant to be.
+    alone = None
+    if ctx.world == 1 and not a.no_alone and os.environ.get("VNR_AMD_RENDER_HALVES", "2") != "1":
+        os.environ["VNR_AMD_RENDER_HALVES"] = "1"
+        ren1 = api.vnrCreateRenderer(nv)
+        del os.environ["VNR_AMD_RENDER_HALVES"]
+        api.vnrRendererSetTransferFunction(ren1, tfn)
+        api.vnrRendererSetCamera(ren1, camera)
+        api.vnrRendererSetFramebufferSize(ren1, (a.fb, a.fb))
+        api.vnrRendererSetMode(ren1, a.mode)
+        api.vnrRendererSetOutputAsDeviceFramebuffer(ren1, True)
+        api.vnrRendererSetProfiling(ren1, True)
+        for _ in range(3):
+            api.vnrRender(ren1); api.vnrRendererMapFrame(ren1)
+        check(L.vnrAmdSynchronize())
+        t1 = time.perf_counter()
+        a_samples = a_launches = 0
+        a_ms = 0.0
+        n_alone = max(5, a.steps // 2)
+        for _ in range(n_alone):
+            api.vnrRender(ren1); api.vnrRendererMapFrame(ren1)
+            s1 = api.vnrRendererGetFrameStats(ren1)
+            a_samples += s1["n_samples"]; a_ms += s1["infer_kernel_ms"]; a_launches += s1["infer_kernel_launches"]
+        check(L.vnrAmdSynchronize())
+        alone = {"frames": n_alone, "fps": round(n_alone / (time.perf_counter() - t1), 2), "samples": a_samples, "ms": a_ms, "launches": a_launches}
+        del ren1
+
     if ctx.distributed:
         import torch
         import torch.distributed as td
@@ -203,6 +234,15 @@ def main():
     # the GPU: `achieved`/`frac` (defined per launch) drop although the frame gets faster.  The frame-level figure below
     # does not depend on scheduling: algorithmic bytes of all live samples of a frame / frame time.
     halves = 1 if os.environ.get("VNR_AMD_RENDER_HALVES", "2") == "1" else 2
+    if alone and alone["ms"] > 0:
+        ev = alone["samples"] * evals_per_sample
+        a_gbs = ev * bytes_per_sample / (alone["ms"] * 1e-3) / 1e9
+        roofline["alone"] = {"what": "same frames on ONE HIP stream, un-timed extra leg of this run: nothing else is resident while the kernel runs",
+                             "achieved": round(a_gbs, 1), "frac": round(a_gbs / HBM_PEAK_GBS, 4),
+                             "avg_launch_ms": round(alone["ms"] / max(alone["launches"], 1), 4), "launches": alone["launches"],
+                             "msamples_per_s": round(ev / (alone["ms"] * 1e-3) / 1e6, 1), "frames": alone["frames"],
+                             "fps_one_stream": alone["fps"],
+                             "mfma_tflops": round(ev * flops_per_sample / (alone["ms"] * 1e-3) / 1e12, 2)}
     roofline["concurrency"] = (f"{halves} ray halves on {halves} HIP streams; launch durations are per stream and overlap"
                                if halves == 2 else "1 stream: launches run alone")
     frame_gbs = (samples / a.steps) * bytes_per_sample / (elapsed / a.steps) / 1e9
@@ -238,6 +278,8 @@ def main():
                    "volume": f"{a.size}^3", "framebuffer": f"{a.fb}x{a.fb}", "n_params": info["n_params"],
                    "tfn": f"256-entry ramp-with-bumps, seed 7, opacity scale {a.opacity_scale}",
                    "camera": cam, "train_steps": a.train_steps, "batch": 65536,
+                   "brick_image": {k: (round(v / 2**30, 2) if k == "bytes" else round(v, 2) if k == "build_ms" else v)
+                                   for k, v in api.neural_brick_image(nv).items()} | {"unit": "bytes in GiB; built once, in the warm-up"},
                    "parallelism": f"image tiles x{ctx.world} (interleaved 8-scanline blocks) + RCCL all_gather" if ctx.world > 1 else "single GPU"},
         "mlp_msamples_per_s": round(samples_all / elapsed / 1e6, 1),
         "mlp_msamples_per_s_kernel_only": round(samples / (infer_ms * 1e-3) / 1e6, 1) if infer_ms > 0 else None,

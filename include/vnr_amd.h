@@ -191,6 +191,10 @@ int    vnrAmdNeuralVolumeSerializeParams(vnrAmdVolume, void** bson, size_t* size
 int    vnrAmdNeuralVolumeInference(vnrAmdVolume, size_t n, const float* d_coords, float* d_values, void* stream);
 /* hash-grid encode only (tcnn_impl_decoder.cu:177-230, column = level*F + f): fp16 [n][padded_width] */
 int    vnrAmdNeuralVolumeEncode(vnrAmdVolume, size_t n, const float* d_coords, uint16_t* d_features, void* stream);
+/* AMD extension: state of the brick image, the de-hashed inference copy of the hashed levels (csrc/network.h).  It is built
+ * once the parameters have been left unchanged for VNR_AMD_BRICK_AFTER (24) inference launches and dropped when they change;
+ * VNR_AMD_BRICK=0 disables it, =1 builds it at the first launch; VNR_AMD_BRICK_MAX_GB (32) bounds it.  Results do not depend on it. */
+int    vnrAmdNeuralVolumeBrickImageInfo(vnrAmdVolume, int* in_use, size_t* bytes, float* build_ms);
 int    vnrAmdNeuralVolumeGetInfo(vnrAmdVolume, int* n_levels, int* n_features_per_level, int* padded_width,
                                  int* n_neurons, int* n_hidden_layers, uint64_t* n_params);
 /* raw tcnn-order parameter blob (MLP weights, then grid), fp16 */

@@ -136,6 +136,7 @@ def lib():
     sig("vnrAmdNeuralVolumeSerializeParams", I, P, C.POINTER(P), C.POINTER(SZ))
     sig("vnrAmdNeuralVolumeInference", I, P, SZ, P, P, P)
     sig("vnrAmdNeuralVolumeEncode", I, P, SZ, P, P, P)
+    sig("vnrAmdNeuralVolumeBrickImageInfo", I, P, IP, C.POINTER(SZ), FP)
     sig("vnrAmdNeuralVolumeGetInfo", I, P, IP, IP, IP, IP, IP, C.POINTER(U64))
     sig("vnrAmdNeuralVolumeGetParamsFP16", I, P, P, SZ)
     sig("vnrAmdNeuralVolumeSetParamsFP16", I, P, P, SZ)

@@ -519,6 +519,13 @@ def vnrRendererGetFrameStats(r):
     return {k: getattr(s, k) for k, _ in s._fields_}
 
 
+def neural_brick_image(v):
+    """state of the de-hashed inference copy of the hashed levels (csrc/network.h)"""
+    u, b, ms = C.c_int(), C.c_size_t(), C.c_float()
+    check(lib().vnrAmdNeuralVolumeBrickImageInfo(v.h, C.byref(u), C.byref(b), C.byref(ms)))
+    return {"in_use": bool(u.value), "bytes": b.value, "build_ms": ms.value}
+
+
 def neural_info(v):
     vals = [C.c_int() for _ in range(5)]
     n = C.c_uint64()

@@ -539,6 +539,15 @@ int vnrAmdNeuralVolumeEncode(vnrAmdVolume v, size_t n, const float* d_coords, ui
 {
   return guarded([&]() { as_neural(v)->network().encode(d_coords, d_features, n, resolve_stream(stream)); });
 }
+int vnrAmdNeuralVolumeBrickImageInfo(vnrAmdVolume v, int* in_use, size_t* bytes, float* build_ms)
+{
+  return guarded([&]() {
+    Network& n = as_neural(v)->network();
+    if (in_use) *in_use = n.brick_image_in_use() ? 1 : 0;
+    if (bytes) *bytes = n.brick_image_bytes();
+    if (build_ms) *build_ms = n.brick_build_ms();
+  });
+}
 int vnrAmdNeuralVolumeGetInfo(vnrAmdVolume v, int* n_levels, int* n_features, int* padded_width, int* n_neurons,
                               int* n_hidden_layers, uint64_t* n_params)
 {

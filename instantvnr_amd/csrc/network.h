@@ -104,7 +104,9 @@ public:
   void inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                  const uint32_t* d_dest = nullptr) const;
   // ray marcher's sample queue: records {x, y, z, dest} (16 B); result of a record goes to d_out[dest * out_stride]
-  void inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s) const;
+  // `sharers`: streams that run such launches side by side (sizes the persistent grid, network_infer.hip)
+  void inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
+                       uint32_t sharers = 1) const;
   // encode only: fp16 [n][padded_width]
   void encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const;
 

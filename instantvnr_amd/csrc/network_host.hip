@@ -16,7 +16,8 @@ void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
-                  const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr);
+                  const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr,
+                  uint32_t sharers = 1);
 void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
                         uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s);
 // master weights <- fp16 parameters; reset_optimizer also zeroes the moments and step counts
@@ -367,12 +368,13 @@ void Network::inference(const float* d_coords, float* d_out, size_t n, const uin
                mlp_packed_.ptr, lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest, 0, image);
 }
 
-void Network::inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s) const
+void Network::inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
+                              uint32_t sharers) const
 {
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
   launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image);
+               mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image, sharers);
 }
 
 void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const

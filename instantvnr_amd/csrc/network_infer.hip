@@ -86,6 +86,7 @@ struct InferArgs {
   uint32_t n_hidden_matmuls;
   uint32_t activation;       // 0 none, 1 relu
   uint32_t lds_halves;
+  uint32_t sharers;          // kernels of this kind expected to share the GPU (host-side launch sizing only)
 };
 
 struct float3_packed { float x, y, z; };
@@ -316,17 +317,19 @@ static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
   const Runtime& rt = Runtime::get();
   const uint32_t n_tiles = div_round_up(n_max, 64);
   uint32_t blocks = div_round_up(n_tiles, 4);
-  // persistent: 2 blocks of 4 waves per CU.  113 registers would allow 4 (= a full register file), but the in-frame
-  // kernel is bound by fetched lines, not latency: measured on MI355X (round 1, kernel-only G samples/s, n = 3 / 2):
-  //   C4 (L16 F2 T2^22, 40 M samples/frame): 4 blocks 5.98, 3 blocks 6.20, 2 blocks 6.25, 1 block 4.77
-  //   C2 shape (L8 F8 T2^19, 2.4 M samples/frame): 4.15-4.18 for 4, 3 and 2 alike
-  // and 2 blocks leave more than half of the registers and LDS of a CU to a kernel of another stream.
+  // persistent blocks of 4 waves; 113 registers allow 4 per CU.  How many pay depends on what limits the kernel (MI355X, C4
+  // bench frame, kernel-only G samples/s):
+  //   reading the hashed parameter blob (bound by fetched lines): 4 blocks 5.98, 3 blocks 6.20, 2 blocks 6.25, 1 block 4.77
+  //   reading the brick image (2.4 x fewer lines, latency matters again), one stream: 2 blocks 8.1, 3 blocks 10.1, 4 blocks 11.1;
+  //   two ray halves on two streams (two of these kernels share the GPU): 2 blocks 179, 3 blocks 195, 4 blocks 192 frames/s
+  // so the caller says how many kernels share the GPU (`sharers`): 4 blocks alone, 3 with a second stream.
   // VNR_AMD_INFER_BLOCKS_PER_CU (1..4) overrides, for diagnostics.
-  static const uint32_t blocks_per_cu = [] {
+  static const uint32_t forced = [] {
     const char* e = std::getenv("VNR_AMD_INFER_BLOCKS_PER_CU");
-    const int v = e ? std::atoi(e) : 2;
-    return (uint32_t)(v >= 1 && v <= 4 ? v : 2);
+    const int v = e ? std::atoi(e) : 0;
+    return (uint32_t)(v >= 1 && v <= 4 ? v : 0);
   }();
+  const uint32_t blocks_per_cu = forced ? forced : (a.sharers >= 2 ? 3u : 4u);
   const uint32_t max_blocks = (uint32_t)rt.n_cus * blocks_per_cu;
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = next_multiple(blocks, 8);
@@ -357,7 +360,7 @@ static void dispatch(uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
-                  const uint32_t* d_dest, uint32_t queue_out_stride, const uint8_t* brick_image)
+                  const uint32_t* d_dest, uint32_t queue_out_stride, const uint8_t* brick_image, uint32_t sharers)
 {
   if (n_max == 0) return;
   if (n_max > 0xffffffc0ull) throw std::runtime_error("inference batch too large (max 2^32-64 samples per call)");
@@ -369,6 +372,7 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
   a.table = (const half_t*)table;
   a.table_bytes = (uint32_t)table_bytes;
   a.brick_image = brick_image;
+  a.sharers = sharers;
   a.packed_mlp = (const half_t*)packed;
   a.coords = coords;
   a.out = out;

@@ -920,7 +920,7 @@ void Renderer::render_streaming(const RenderParams& p_all)
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it], hf.s));
     if (nv) {
       // a record's 4th word is the float index of its result in this arena (stride 1)
-      nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 1, c + C_SAMPLES0 + parity, hf.s_max, hf.s);
+      nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 1, c + C_SAMPLES0 + parity, hf.s_max, hf.s, (uint32_t)H);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(hf.s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
       gt_sample_kernel<<<blocks, 256, 0, hf.s>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, (float*)hf.vd[parity]);

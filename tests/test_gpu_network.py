@@ -142,3 +142,39 @@ def test_params_roundtrip_and_bson(oracle, tmp_path):
     assert bytes(doc["parameters"]["params_binary"]) == params.tobytes()
     assert doc["macrocell"]["dims"] == {"x": 2, "y": 2, "z": 2} and len(doc["macrocell"]["data"]) == 8 * 8
     assert doc["model"]["encoding"]["n_levels"] == 4
+
+
+@pytest.mark.parametrize("cfg", [(10, 2, 12, 8, 1.5, 2), (6, 8, 10, 4, None, 2), (7, 4, 11, 4, 1.6, 3), (9, 1, 12, 4, 1.5, 2)])
+def test_brick_image_is_lazy_exact_and_dropped_when_parameters_change(oracle, cfg):
+    """the de-hashed inference copy of the hashed levels (csrc/network.h) is a cache: built once the parameters have been
+    left alone for 24 launches, bit-identical results (coordinates outside [0, 1] and NaN included: those waves read the
+    parameter blob), gone as soon as the parameters change"""
+    L, F, log2T, base, pls, H = cfg
+    vol, ocfg, params, n_mlp = make(oracle, L, F, log2T, base, pls, H, seed=3)
+    coords = coords_for(5000, 4)
+    coords[10:20] = np.random.default_rng(5).uniform(-0.5, 1.5, (10, 3)).astype(np.float32)   # outside the unit cube
+    coords[20] = (np.nan, 0.5, 0.5)
+    assert not api.neural_brick_image(vol)["in_use"]
+    enc0 = api.neural_encode(vol, coords).view(np.uint16)
+    y0 = api.neural_inference(vol, coords).view(np.uint32)
+    want = oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords)
+    ok = ~np.isnan(coords).any(axis=1)
+    assert np.array_equal(enc0[ok], want[ok])
+    for _ in range(30):
+        if api.neural_brick_image(vol)["in_use"]:
+            break
+        api.neural_inference(vol, coords[:64])
+    state = api.neural_brick_image(vol)
+    assert state["in_use"] and state["bytes"] > 0
+    assert np.array_equal(api.neural_encode(vol, coords).view(np.uint16)[ok], enc0[ok])
+    assert np.array_equal(api.neural_inference(vol, coords).view(np.uint32)[ok], y0[ok])
+    # new parameters: the image is stale at once, and the next launches read the blob again
+    params2 = syn.random_params(len(params), n_mlp, seed=9)
+    api.neural_set_params_fp16(vol, params2)
+    assert not api.neural_brick_image(vol)["in_use"]
+    enc2 = api.neural_encode(vol, coords).view(np.uint16)
+    assert np.array_equal(enc2[ok], oracle.grid_encode(ocfg, params2[n_mlp:].view(np.uint16), coords)[ok])
+    for _ in range(30):
+        api.neural_inference(vol, coords[:64])
+    assert api.neural_brick_image(vol)["in_use"]
+    assert np.array_equal(api.neural_encode(vol, coords).view(np.uint16)[ok], enc2[ok])

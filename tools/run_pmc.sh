@@ -20,7 +20,7 @@ if [ "$what" = calib ]; then
   (cd /tmp && timeout $to rocprofv3 --pmc $c --output-format csv -d "$d" -o calib -- $R/tools/calib/gather_calib) > "$d.log" 2>&1
 else
   # SIGABRT (not TERM) on timeout: faulthandler then dumps the Python stack of the hung call into the log; KILL 10 s later
-  (cd /tmp && timeout -s ABRT -k 10 $to rocprofv3 --pmc $c --output-format csv -d "$d" -o bench -- python3 -X faulthandler $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-psnr) > "$d.log" 2>&1
+  (cd /tmp && timeout -s ABRT -k 10 $to rocprofv3 --pmc $c --output-format csv -d "$d" -o bench -- python3 -X faulthandler $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-psnr --no-alone) > "$d.log" 2>&1
 fi
 rc=$?
 echo "[run_pmc] $what '$c' exit $rc"

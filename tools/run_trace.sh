@@ -7,7 +7,7 @@ O=$R/gpurun_out/trace
 mkdir -p "$O"
 export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
-(cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$tag" -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-psnr) > "$O/$tag.log" 2>&1
+(cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$tag" -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-psnr --no-alone) > "$O/$tag.log" 2>&1
 rc=$?
 f=$(find "$O/$tag" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "$O/${tag}_kernel_stats.csv" && head -12 "$O/${tag}_kernel_stats.csv" | cut -c1-180

@@ -48,6 +48,19 @@ def _worker(rank, world, port, width, height, q):
         dist.all_gather_into_tensor(gathered.view(-1), share.view(-1))
         full = vdist.assemble_shares(gathered, block, world, n)
         ok_render = bool(torch.equal(full, want))
+        # the three-operation path of ShardedRenderer (blocks divide evenly): a strided view instead of pack, one strided copy
+        # instead of assemble.  It must exist exactly when the division is even and give the same frame.
+        view = vdist.share_view(frame, block, world, rank)
+        if (height % (8 * world)) == 0:
+            share2 = torch.empty((n_local, 4))
+            share2.view(view.shape).copy_(view)
+            ok_render = ok_render and bool(torch.equal(share2, share))
+            gathered2 = torch.empty((world, n_local, 4))
+            dist.all_gather_into_tensor(gathered2.view(-1), share2.view(-1))
+            full2 = vdist.assemble_shares_into(torch.empty((n, 4)), gathered2, block, world)
+            ok_render = ok_render and bool(torch.equal(full2, want))
+        else:
+            ok_render = ok_render and view is None
         # local index -> global pixel mapping used by the kernels agrees with the packing
         for i in (0, 1, block - 1, block, n_local - 1):
             g = vdist.local_to_global(i, block, world, rank)
@@ -73,7 +86,7 @@ def _worker(rank, world, port, width, height, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("width,height", [(64, 48), (40, 36)])  # second: height not a multiple of 8 x world
+@pytest.mark.parametrize("width,height", [(64, 48), (40, 36)])  # first: blocks divide evenly; second: height not a multiple of 8 x world
 def test_world2_gloo_tiles_and_gradients(width, height):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -83,6 +83,46 @@ def test_frame_share_roundtrip_through_rccl(group):
     assert np.array_equal(full.cpu().numpy(), want)
 
 
+def test_sharded_renderer_object_on_a_one_rank_group(group):
+    """dist.ShardedRenderer as bench.py drives it with WORLD_SIZE > 1, on the one-rank group: the even-division path (strided
+    view of the share made once per framebuffer, all_gather, one strided copy into the frame) over several frames, so both of
+    the renderer's framebuffers are aliased; the frames must equal the undistributed renderer's"""
+    import torch
+
+    class OneRank(vdist.Context):
+        distributed = True
+
+    size = (64, 48)
+    vol = syn.analytic_volume(32)
+    sv = api.vnrCreateSimpleVolume(vol)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = syn.oblique_camera((32, 32, 32), distance_scale=0.95)
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+
+    def renderer():
+        r = api.vnrCreateRenderer(sv)
+        api.vnrRendererSetTransferFunction(r, tfn)
+        api.vnrRendererSetCamera(r, camera)
+        api.vnrRendererSetFramebufferSize(r, size)
+        return r
+
+    plain = renderer()
+    sharded = vdist.ShardedRenderer(OneRank(0, 1, 0, "nccl"), renderer(), size[0], size[1])
+    assert sharded.even
+    for _ in range(4):   # accumulation over frames, alternating framebuffers
+        api.vnrRender(plain)
+        want = api.vnrRendererMapFrame(plain).reshape(-1, 4).copy()
+        full = sharded.render()
+        torch.cuda.synchronize()
+        assert np.array_equal(full.cpu().numpy(), want)
+    assert len(sharded._views) == 2
+
+
 def test_gradient_allreduce_step_equals_plain_step(group):
     import torch
     os.environ["VNR_AMD_INIT_SEED"] = "77"

@@ -1,0 +1,45 @@
+"""GPU box: how long one rank's share of the bench frame takes (interleaved 8-scanline blocks, part 0 of N) without the
+collective: the compute side of the N-GPU strong-scaling curve on one GPU.  usage: python tools/share_probe.py"""
+import sys
+import time
+import numpy as np
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from instantvnr_amd import api, synthetic as syn  # noqa: E402
+from instantvnr_amd._lib import check, lib  # noqa: E402
+L = lib(); check(L.vnrAmdInit(-1))
+size, fb = 1024, 1024
+dims = (size,) * 3
+sv = api.vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=6.0)
+pls = float(np.exp(np.log(size / 16.0) / 15))
+cfg = syn.model_config(n_levels=16, n_features=2, log2_hashmap_size=22, n_hidden_layers=3, per_level_scale=pls)
+nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+api.vnrNeuralVolumeTrain(nv, 300, True)
+cam = syn.oblique_camera(dims, distance_scale=1.1)
+base = 0.0
+colors, alphas = syn.tfn_ramp_with_bumps(opacity_scale=0.06)
+import os
+for parts in [int(v) for v in os.environ.get("SHARE_PARTS", "1,2,4,8").split(",")]:
+    ren = api.vnrCreateRenderer(nv)
+    api.vnrRendererSetFramebufferSize(ren, (fb, fb))
+    api.vnrRendererSetOutputAsDeviceFramebuffer(ren, True)
+    camera = api.vnrCreateCamera(); api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    api.vnrRendererSetCamera(ren, camera)
+    tfn = api.vnrCreateTransferFunction(); api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1)); api.vnrRendererSetTransferFunction(ren, tfn)
+    if parts > 1:
+        api.vnrRendererSetPixelInterleave(ren, 8 * fb, parts, 0)
+    for _ in range(6):
+        api.vnrRender(ren); api.vnrRendererMapFrame(ren)
+    check(L.vnrAmdSynchronize())
+    t0 = time.perf_counter()
+    n = 40
+    for _ in range(n):
+        api.vnrRender(ren); api.vnrRendererMapFrame(ren)
+    check(L.vnrAmdSynchronize())
+    dt = (time.perf_counter() - t0) / n
+    st = api.vnrRendererGetFrameStats(ren)
+    print(f"share 1/{parts}: {dt * 1e3:.3f} ms per frame, {st['n_samples'] / 1e6:.2f} M samples, {st['n_iterations']} iterations "
+          f"-> speed-up {base / dt if parts > 1 and base else 0:.2f}x of {parts}", flush=True)
+    if parts == 1:
+        base = dt
+    del ren

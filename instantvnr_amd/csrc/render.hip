@@ -36,6 +36,10 @@ struct RayList {  // per ray payload, SoA (RayMarchingData, method_raymarching.c
   float* next_cell_begin;
   uint32_t* sample_base;
   uint32_t* sample_count;
+  // SINGLE_SHADE_HEURISTIC only (inter_highest_*, method_raymarching.cu:84-87): the sample that has contributed most so far
+  vec3f* h_org;
+  vec3f* h_color;
+  float* h_alpha;
 };
 
 struct RenderParams {
@@ -65,8 +69,19 @@ struct RenderParams {
   vec3f grad_step;       // 1 / dims (object.cpp:305)
   vec3f light_dir;       // LaunchParams::light_directional_dir after the flip of renderer.cpp:98-101
   uint32_t slot_cap;     // sample slots of this half's result arena (value/dt pairs first, then the gradient samples)
-  uint32_t shading_mode; // 0 NO_SHADING, 1 GRADIENT_SHADING (the streaming kernels are templated on it; the monolithic one branches)
+  uint32_t shading_mode; // 0 NO_SHADING, 1 GRADIENT_SHADING, 2 SINGLE_SHADE_HEURISTIC (the streaming kernels are templated on it; the monolithic one branches)
+  // SINGLE_SHADE_HEURISTIC (modes 10 / 11): per-pixel hand-over from the camera pass to the shadow pass
+  // (final_highest_*, shading_color, jitter_ssh; method_raymarching.cu:88-92) and the shadow rays' common direction
+  vec3f* px_org;
+  vec3f* px_color;
+  float* px_alpha;
+  vec4f* px_shading;
+  float* px_jitter;
+  vec3f shadow_dir;      // xfmVector(wto, normalize(light_directional_dir)) (:649)
 };
+
+// streaming kernel modes (ShadingMode, method_raymarching.cu:51-56)
+enum { M_NONE = 0, M_GRADIENT = 1, M_SSH = 2, M_SHADOW = 3 };
 
 // Result arena of one half and one parity, in floats: [slot_cap][2] = {value, t1 - t0} per ray-major sample slot, then (gradient
 // shading only) [slot_cap][4] = {f(c + gx), f(c + gy), f(c + gz), unused}.  A queue record's 4th word is the absolute float
@@ -133,6 +148,22 @@ __device__ __forceinline__ float tea_lcg_first(uint32_t v0, uint32_t v1)
   }
   const uint32_t state = 1664525u * v0 + 1013904223u;
   return (float)(state & 0x00FFFFFFu) / (float)0x01000000;
+}
+
+// both draws of rng.get_floats() (EXTERNAL OVR addition to gdt::LCG: two successive floats)
+__device__ __forceinline__ void tea_lcg_two(uint32_t v0, uint32_t v1, float& a, float& b)
+{
+  uint32_t s0 = 0;
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+  }
+  uint32_t state = 1664525u * v0 + 1013904223u;
+  a = (float)(state & 0x00FFFFFFu) / (float)0x01000000;
+  state = 1664525u * state + 1013904223u;
+  b = (float)(state & 0x00FFFFFFu) / (float)0x01000000;
 }
 
 // raytracing.h:188-194 / :166-170 / :196-207
@@ -311,7 +342,11 @@ __device__ __forceinline__ uint32_t depth_bin(const RenderParams& p, float t, fl
 // GRAD (gradient shading, rendering mode 8): every sample puts FOUR records into the queue, itself and three forward
 // offsets of grad_step (method_raymarching.cu:719-726), and compose shades with the resulting normal (:773-788).
 // vd_in / vd_out are the result arenas of the previous / this iteration (layout above RenderParams' helpers).
-template <bool FIRST, bool GRAD>
+// MODE (M_*): M_SSH is the camera pass of the single-shade heuristic (rendering mode 11): like M_NONE, but a ray remembers the sample
+// that contributed most and its result goes to the per-pixel hand-over arrays instead of the frame; M_SHADOW is the second
+// pass, one ray per pixel from that sample towards the light, alpha only, which finally shades and writes the pixel
+// (method_raymarching.cu:789-833, 877-900, 960-973).
+template <bool FIRST, int MODE>
 __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const RayList cur, const RayList nxt,
                                                     const vec2f* __restrict__ vd_in, vec4f* __restrict__ queue,
                                                     vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters,
@@ -324,6 +359,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
   uint16_t* s_rk = (uint16_t*)(s_hist + 256);   // rank of a sample inside its depth bin (< 64 n_iters); the bin is recomputed
   // the TFN tables are read 4x per composed sample: keep them in LDS (no TA traffic) when they fit
   DeviceTfn tfn = p.tfn;
+  constexpr bool GRAD = MODE == M_GRADIENT;
   if (!FIRST && p.tfn_in_lds) {
     vec4f* s_colors = (vec4f*)(s_rk + (size_t)p.n_iters * 256);
     float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
@@ -350,16 +386,55 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     vec3f org = {0, 0, 0}, dir = {0, 0, 1}, m_dir = {0, 0, 1};
     float tmin = 0.0f, tmax = VNR_FLOAT_LARGE;
     bool alive = false;
+    vec3f h_org = {0, 0, 0}, h_color = {0, 0, 0};   // M_SSH: SingleShotPayload
+    float h_alpha = 0.0f;
+
+    // the end of a ray: the pixel (M_NONE / M_GRADIENT), the hand-over to the shadow pass (M_SSH, :827-833), or the shaded
+    // pixel (M_SHADOW, :820-826: lerp(scivis_shading_scale, unshaded, highest colour x pixel alpha x transmittance))
+    auto finish = [&]() {
+      if (MODE == M_SSH) {
+        p.px_org[pixel] = h_org; p.px_color[pixel] = h_color; p.px_alpha[pixel] = h_alpha;
+        p.px_shading[pixel] = {color.x, color.y, color.z, alpha};
+      } else if (MODE == M_SHADOW) {
+        const float transmittance = 1.0f - alpha, k = 0.95f;
+        vec4f sc = p.px_shading[pixel];
+        const vec3f hc = p.px_color[pixel];
+        sc.x = (1.0f - k) * sc.x + k * (hc.x * sc.w * transmittance);
+        sc.y = (1.0f - k) * sc.y + k * (hc.y * sc.w * transmittance);
+        sc.z = (1.0f - k) * sc.z + k * (hc.z * sc.w * transmittance);
+        write_pixel(p, sc, pixel);
+      } else {
+        write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
+      }
+    };
 
     if (active) {
       if (FIRST) {
         if (map_pixel(p, i, pixel)) {
-          jitter = tea_lcg_first((uint32_t)p.frame_index, pixel);
-          compute_ray(p, pixel, org, dir);
-          m_dir = dir * p.mc_rcp;
-          alive = intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
-          if (alive) dda_init(it, org * p.mc_rcp, m_dir, tmin, p.mc_dims);
-          else write_pixel(p, {0, 0, 0, 0}, pixel);
+          if (MODE == M_SHADOW) {  // iterative_raygen_kernel_shadow (:877-900)
+            jitter = p.px_jitter[pixel];
+            org = p.px_org[pixel];
+            dir = p.shadow_dir;
+            color = org;           // color_or_org: a shadow ray carries its origin where a camera ray carries its colour
+            m_dir = dir * p.mc_rcp;
+            alive = intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi) && p.px_alpha[pixel] > 0.0f;
+            if (alive) dda_init(it, org * p.mc_rcp, m_dir, tmin, p.mc_dims);
+            else write_pixel(p, p.px_shading[pixel], pixel);
+          } else {
+            if (MODE == M_SSH) {
+              float j2;
+              tea_lcg_two((uint32_t)p.frame_index, pixel, jitter, j2);
+              p.px_jitter[pixel] = j2;   // jitters.y (:866-868)
+            } else {
+              jitter = tea_lcg_first((uint32_t)p.frame_index, pixel);
+            }
+            compute_ray(p, pixel, org, dir);
+            m_dir = dir * p.mc_rcp;
+            alive = intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
+            if (alive) dda_init(it, org * p.mc_rcp, m_dir, tmin, p.mc_dims);
+            else if (MODE == M_SSH) finish();   // zeros: what the reference's per-frame memset leaves for the shadow pass (:870-874)
+            else write_pixel(p, {0, 0, 0, 0}, pixel);
+          }
         }
       } else {
         pixel = cur.pixel_index[i];
@@ -370,7 +445,9 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         it.t_next = cur.t_next[i];
         it.next_cell_begin = cur.next_cell_begin[i];
         const uint32_t sb = cur.sample_base[i], sc = cur.sample_count[i];
-        compute_ray(p, pixel, org, dir);
+        if (MODE == M_SHADOW) { org = color; dir = p.shadow_dir; }   // compute_ray<SHADOW> (:639-653)
+        else compute_ray(p, pixel, org, dir);
+        if (MODE == M_SSH) { h_org = cur.h_org[i]; h_color = cur.h_color[i]; h_alpha = cur.h_alpha[i]; }
         m_dir = dir * p.mc_rcp;
         intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
         // compose (classification, opacity correction, front-to-back blending)
@@ -384,13 +461,19 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
             const vec4f fg = *(const vec4f*)((const float*)vd_in + arena_grad_index(p.slot_cap, sb + k));
             rgb = gradient_shade(p, dir, vd.x, fg.x, fg.y, fg.z, p.grad_step, rgb);
           }
+          if (MODE == M_SSH && h_alpha < (1.0f - alpha) * a) {  // :789-795; the sample's t is kept where GRAD keeps f(c + gx)
+            const float t = ((const float*)vd_in)[arena_grad_index(p.slot_cap, sb + k)];
+            h_org = org + t * dir;
+            h_color = rgb;
+            h_alpha = (1.0f - alpha) * a;
+          }
           const float tr = 1.0f - alpha;
           alpha += tr * a;
-          color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a;
+          if (MODE != M_SHADOW) { color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a; }
           if (!(alpha < VNR_NEARLY_ONE)) break;
         }
         alive = (alpha < VNR_NEARLY_ONE) && dda_resumable(it, m_dir, tmin, tmax, p.mc_dims);
-        if (!alive) write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
+        if (!alive) finish();
       }
     }
 
@@ -403,7 +486,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         s_t1[k * 256u + tid] = t1;
         return (int)(++k) < n_iters;
       });
-      if (k == 0) write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);  // nothing left to sample: the ray is finished
+      if (k == 0) finish();  // nothing left to sample: the ray is finished
     }
     const bool survive = alive && k > 0;
 
@@ -478,6 +561,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
       nxt.next_cell_begin[slot] = it.next_cell_begin;
       nxt.sample_base[slot] = sb;
       nxt.sample_count[slot] = k;
+      if (MODE == M_SSH) { nxt.h_org[slot] = h_org; nxt.h_color[slot] = h_color; nxt.h_alpha[slot] = h_alpha; }
       for (uint32_t j = 0; j < k; ++j) {
         const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
         const float t = (1.0f - jitter) * t0 + jitter * t1;  // lerp(jitter, t0, t1), instantvnr_types.h:162-166
@@ -495,6 +579,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
           queue[g] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + j))};
         }
         vd_out[sb + j].y = t1 - t0;
+        if (MODE == M_SSH) ((float*)vd_out)[arena_grad_index(p.slot_cap, sb + j)] = t;   // compose needs the position of the sample
       }
     }
     __builtin_amdgcn_wave_barrier();  // the LDS arrays are reused by the next loop trip
@@ -517,7 +602,7 @@ __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float
 // it (at most 64 KiB of L2-resident counts per block), so no second launch and no inter-block dependency is needed.  The block
 // that holds the last group publishes the number of alive rays; block 0 also clears the sample counter the next march adds to.
 __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, const RayList dst, const uint32_t* __restrict__ ray_counts,
-                                                            uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first)
+                                                            uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first, int ssh)
 {
   __shared__ uint32_t s_part[16];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -561,6 +646,7 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
     dst.next_cell_begin[to] = src.next_cell_begin[from];
     dst.sample_base[to] = src.sample_base[from];
     dst.sample_count[to] = src.sample_count[from];
+    if (ssh) { dst.h_org[to] = src.h_org[from]; dst.h_color[to] = src.h_color[from]; dst.h_alpha[to] = src.h_alpha[from]; }
   }
 }
 
@@ -576,17 +662,19 @@ __global__ void monolithic_kernel(const RenderParams p)
   compute_ray(p, pixel, org, dir);
   float alpha = 0.0f;
   vec3f color = {0, 0, 0};
-  float t0 = 0.0f, t1 = VNR_FLOAT_LARGE;
-  if (intersect_box(t0, t1, org, dir, p.bbox_lo, p.bbox_hi)) {
-    const float jitter = tea_lcg_first((uint32_t)p.frame_index, pixel);
-    const vec3f m_dir = dir * p.mc_rcp;
+  vec3f h_org = {0, 0, 0}, h_color = {0, 0, 0};   // SINGLE_SHADE_HEURISTIC (mode 10, :414-416)
+  float h_alpha = 0.0f;
+
+  // raymarching_iterator (:270-308) = dda3 (dda.h:140-287) over the macrocells with the equalised adaptive step; one walk for
+  // the camera ray, a second one (shadow = true: alpha only, raymarching_transmittance :364-398) for the single-shade ray
+  auto march = [&](vec3f o, vec3f d, float t0, float t1, float jitter, float step, bool shadow) {
+    const vec3f m_dir = d * p.mc_rcp;
     DDAState it;
-    dda_init(it, org * p.mc_rcp, m_dir, t0, p.mc_dims);
-    // dda3 (dda.h:140-287) == dda_next with a callback that always advances, stopped by the callback's result
+    dda_init(it, o * p.mc_rcp, m_dir, t0, p.mc_dims);
     auto cell_fn = [&](vec3i cell, float c0, float c1) -> bool {
       const float r = opacity_upper_bound(p, cell);
       if (fabsf(r) <= FLT_EPSILON) return true;
-      float ss = adaptive_sampling_rate(p.step, r);
+      float ss = adaptive_sampling_rate(step, r);
       {  // sample_size_scaler :263-268
         const int N = (int)((c1 - c0) / ss + 1.0f);
         ss = (c1 - c0) / (float)N;
@@ -594,11 +682,18 @@ __global__ void monolithic_kernel(const RenderParams p)
       float tx = c0, ty = fminf(c1, c0 + ss);
       while (ty > tx) {
         const float t = (1.0f - jitter) * tx + jitter * ty;
-        const vec3f c = org + t * dir;
+        const vec3f c = o + t * d;
         const float v = sample_volume_nodal(p.volume, p.vol_dims, c.x, c.y, c.z);
         vec3f rgb; float a;
         tfn_sample(p.tfn, v, rgb, a);
         a = opacity_correction(p.step_rcp, ty - tx, a);
+        if (shadow) {
+          alpha += (1.0f - alpha) * a;
+          if (!(alpha < VNR_NEARLY_ONE)) return false;
+          tx = ty;
+          ty = fminf(tx + ss, c1);
+          continue;
+        }
         if (p.shading_mode == 1u) {  // mode 7, :440-454 with sampleGradient (raytracing.h:112-126): a step leaving [0,1] is flipped
           vec3f stp = p.grad_step;
           if (c.x + stp.x > 1.0f - FLT_EPSILON) stp.x *= -1.0f;
@@ -607,7 +702,10 @@ __global__ void monolithic_kernel(const RenderParams p)
           const float fgx = sample_volume_nodal(p.volume, p.vol_dims, c.x + stp.x, c.y, c.z);
           const float fgy = sample_volume_nodal(p.volume, p.vol_dims, c.x, c.y + stp.y, c.z);
           const float fgz = sample_volume_nodal(p.volume, p.vol_dims, c.x, c.y, c.z + stp.z);
-          rgb = gradient_shade(p, dir, v, fgx, fgy, fgz, stp, rgb);
+          rgb = gradient_shade(p, d, v, fgx, fgy, fgz, stp, rgb);
+        }
+        if (p.shading_mode == 2u && h_alpha < (1.0f - alpha) * a) {  // mode 10, :455-462
+          h_org = c; h_color = rgb; h_alpha = (1.0f - alpha) * a;
         }
         const float tr = 1.0f - alpha;
         color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a;
@@ -632,6 +730,38 @@ __global__ void monolithic_kernel(const RenderParams p)
         if (it.t_next.z == t_closest) { it.t_next.z += ts.z; it.cell.z += delta.z; if (it.cell.z == stop.z) break; }
         it.next_cell_begin = t_closest;
       }
+    }
+  };
+
+  float t0 = 0.0f, t1 = VNR_FLOAT_LARGE;
+  if (intersect_box(t0, t1, org, dir, p.bbox_lo, p.bbox_hi)) {
+    float jitter, unused;
+    tea_lcg_two((uint32_t)p.frame_index, pixel, jitter, unused);   // rng.get_floats().x; the generator advances by two draws
+    march(org, dir, t0, t1, jitter, p.step, false);
+    if (p.shading_mode == 2u && h_alpha > 0.0f) {  // :471-484: one shadow ray from the strongest sample towards the light
+      const float pixel_alpha = alpha;
+      float s0 = 0.0f, s1 = VNR_FLOAT_LARGE;
+      alpha = 0.0f;
+      if (intersect_box(s0, s1, h_org, p.shadow_dir, p.bbox_lo, p.bbox_hi)) {
+        // third draw of the pixel's generator: state3 = a (a (a v0 + c) + c) + c, recomputed from the first two
+        uint32_t v0 = (uint32_t)p.frame_index, v1 = pixel, s = 0;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          s += 0x9e3779b9u;
+          v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s) ^ ((v1 >> 5) + 0xc8013ea4u);
+          v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s) ^ ((v0 >> 5) + 0x7e95761eu);
+        }
+        uint32_t st = 1664525u * v0 + 1013904223u;
+        st = 1664525u * st + 1013904223u;
+        st = 1664525u * st + 1013904223u;
+        const float j3 = (float)(st & 0x00FFFFFFu) / (float)0x01000000;
+        march(h_org, p.shadow_dir, s0, s1, j3, 2.0f * p.step, true);   // raymarching_shadow_sampling_scale = 2 (instantvnr_types.h:137)
+      }
+      const float transmittance = 1.0f - alpha, k = 0.95f;
+      alpha = pixel_alpha;
+      color.x = (1.0f - k) * color.x + k * (h_color.x * alpha * transmittance);
+      color.y = (1.0f - k) * color.y + k * (h_color.y * alpha * transmittance);
+      color.z = (1.0f - k) * color.z + k * (h_color.z * alpha * transmittance);
     }
   }
   write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
@@ -762,8 +892,17 @@ void Renderer::render()
   p.grad_step = {1.0f / (float)p.vol_dims.x, 1.0f / (float)p.vol_dims.y, 1.0f / (float)p.vol_dims.z};  // object.cpp:305
   if (dot(p.cam_dir, light_dir_) > 0.0f) light_dir_ = -1.0f * light_dir_;  // renderer.cpp:98-101: flipped in place, every frame
   p.light_dir = light_dir_;
-  p.shading_mode = (mode_ == 7 || mode_ == 8) ? 1u : 0u;
+  p.shading_mode = (mode_ == 7 || mode_ == 8) ? 1u : (mode_ == 10 || mode_ == 11) ? 2u : 0u;
   p.slot_cap = 0;
+  // single-shade heuristic (modes 10 / 11): shadow rays point towards the light, xfmVector(wto, normalize(dir)) (:649, :473)
+  p.shadow_dir = xfm_vector(p.wto, normalize(light_dir_));
+  p.px_org = nullptr; p.px_color = nullptr; p.px_alpha = nullptr; p.px_shading = nullptr; p.px_jitter = nullptr;
+  if (mode_ == 11) {  // per-pixel hand-over between the two passes (final_highest_*, shading_color, jitter_ssh; :88-92)
+    ssh_px_.ensure(12 * (size_t)n_pixels);
+    float* b = ssh_px_.ptr;
+    p.px_org = (vec3f*)b; p.px_color = (vec3f*)(b + 3 * (size_t)n_pixels); p.px_alpha = b + 6 * (size_t)n_pixels;
+    p.px_jitter = b + 7 * (size_t)n_pixels; p.px_shading = (vec4f*)(b + 8 * (size_t)n_pixels);
+  }
   // frame index / accumulation, renderer.cpp:103-105
   if (reset_) frame_index_ = 0;
   ++frame_index_;
@@ -776,10 +915,15 @@ void Renderer::render()
     switch (mode_) {
     case 5:   // VNR_RAYMARCHING_NO_SHADING_SAMPLE_STREAMING
     case 8:   // VNR_RAYMARCHING_GRADIENT_SHADING_SAMPLE_STREAMING
-      render_streaming(p);
+      render_streaming(p, p.shading_mode == 1u ? M_GRADIENT : M_NONE);
+      break;
+    case 11:  // VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_SAMPLE_STREAMING: camera pass, then one shadow ray per pixel (:968-971)
+      render_streaming(p, M_SSH);
+      render_streaming(p, M_SHADOW);
       break;
     case 4:   // VNR_RAYMARCHING_NO_SHADING_DECODING
     case 7:   // VNR_RAYMARCHING_GRADIENT_SHADING_DECODING
+    case 10:  // VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_DECODING
       // vnrRequireDecoding(mode) (api.h:62-88): the application decodes, vnrNeuralVolumeDecodeProgressive x GetNumberOfBlobs,
       // and these modes march whatever the decoded volume holds
       if (volume_->is_network() && !p.volume)
@@ -789,7 +933,7 @@ void Renderer::render()
       break;
     default:
       throw std::runtime_error("rendering mode " + std::to_string(mode_) +
-                               " is not implemented in this build (supported: 4 and 7 on simple volumes, 5 and 8)");
+                               " is not implemented in this build (supported: the ray-marching modes 4, 5, 7, 8, 10, 11)");
     }
   }
   reset_ = false;
@@ -805,7 +949,7 @@ void Renderer::render_monolithic(const RenderParams& p)
   VNR_HIP_CHECK(hipGetLastError());
 }
 
-void Renderer::render_streaming(const RenderParams& p_all)
+void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
 {
   // The rank's rays are dealt to `n_halves_` independent halves (alternate local tile rows; same mechanism as the
   // multi-GPU interleave), each with its own ray lists, sample queue, counters and HIP stream.  The arithmetic per ray
@@ -816,9 +960,12 @@ void Renderer::render_streaming(const RenderParams& p_all)
   const uint32_t R = p_all.n_local / row_items;  // local tile rows
   const int H = (n_halves_ == 2 && R >= 2) ? 2 : 1;
   const uint32_t P_total = p_all.n_local;
-  const bool grad = p_all.shading_mode == 1u;
-  ensure_queues(P_total, p_all.n_iters, grad);
+  const bool grad = pass_mode == M_GRADIENT;
+  const bool ssh = pass_mode == M_SSH;
+  uint32_t* predicted = predicted_iterations_[pass_mode == M_SHADOW ? 1 : 0];
+  ensure_queues(P_total, p_all.n_iters, grad || ssh || pass_mode == M_SHADOW);   // M_SSH keeps a sample's t where GRAD keeps f(c + g)
   const size_t QP = queue_pixels_;
+  if (ssh) q_ssh_.ensure(14 * QP);
   const size_t QI = (size_t)queue_iters_;
   const size_t slot_floats = queue_grad_ ? 6 : 2;   // result floats per sample slot as ALLOCATED (a slice is laid out per mode)
   const size_t rec_per_slot = queue_grad_ ? 4 : 1;
@@ -859,6 +1006,13 @@ void Renderer::render_streaming(const RenderParams& p_all)
       hf.rl[b].t_next = (vec3f*)(f + 5 * QP) + off;
       hf.rl[b].next_cell_begin = f + 8 * QP + off;
       hf.rl[b].cell = (vec3i*)(q_i32_.ptr + (size_t)b * 3 * QP) + off;
+      hf.rl[b].h_org = nullptr; hf.rl[b].h_color = nullptr; hf.rl[b].h_alpha = nullptr;
+      if (ssh) {
+        float* g = q_ssh_.ptr + (size_t)b * 7 * QP;
+        hf.rl[b].h_org = (vec3f*)g + off;
+        hf.rl[b].h_color = (vec3f*)(g + 3 * QP) + off;
+        hf.rl[b].h_alpha = g + 6 * QP + off;
+      }
       // this half's result arena of parity b: a slice of slot_floats * n_local * QI floats
       hf.vd[b] = (vec2f*)(arena_.ptr + (size_t)b * slot_floats * QP * QI + slot_floats * off * QI);
     }
@@ -882,10 +1036,10 @@ void Renderer::render_streaming(const RenderParams& p_all)
   if (shmem_compose > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
   static bool lds_attr_set = false;
   if (!lds_attr_set) {  // more than the default 64 KiB of dynamic LDS needs an opt-in
-    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define VNR_ATTR(FIRST_, MODE_) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)march_kernel<FIRST_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    VNR_ATTR(true, M_NONE); VNR_ATTR(false, M_NONE); VNR_ATTR(true, M_GRADIENT); VNR_ATTR(false, M_GRADIENT);
+    VNR_ATTR(true, M_SSH); VNR_ATTR(false, M_SSH); VNR_ATTR(true, M_SHADOW); VNR_ATTR(false, M_SHADOW);
+#undef VNR_ATTR
     lds_attr_set = true;
   }
   uint32_t max_iterations = 240;
@@ -905,16 +1059,20 @@ void Renderer::render_streaming(const RenderParams& p_all)
     uint32_t* c = hf.c;
     // march(it): reads the dense ray list rl[0] (count: counter `parity`), leaves the survivors of every 64-ray group in the
     // group's slots of the scratch list rl[1] and appends their samples to queue `parity`
-    if (it == 0) {
-      const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 4096u);
-      if (grad) march_kernel<true, true><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, hf.rc, 0);
-      else march_kernel<true, false><<<blocks, 256, shmem, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[1], hf.queue, hf.vd[0], c, hf.rc, 0);
-    } else {
-      const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
-      if (grad)
-        march_kernel<false, true><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, hf.rc, parity);
-      else
-        march_kernel<false, false><<<blocks, 256, shmem_compose, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], hf.vd[parity ^ 1], hf.queue, hf.vd[parity], c, hf.rc, parity);
+    {
+      const bool first = it == 0;
+      const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), first ? 4096u : 2048u);
+      const size_t lds = first ? shmem : shmem_compose;
+      const vec2f* vd_in = hf.vd[parity ^ 1];
+      vec2f* vd_out = hf.vd[parity];
+#define VNR_MARCH(FIRST_, MODE_) march_kernel<FIRST_, MODE_><<<blocks, 256, lds, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], vd_in, hf.queue, vd_out, c, hf.rc, parity)
+      switch (pass_mode) {
+      case M_GRADIENT: if (first) VNR_MARCH(true, M_GRADIENT); else VNR_MARCH(false, M_GRADIENT); break;
+      case M_SSH: if (first) VNR_MARCH(true, M_SSH); else VNR_MARCH(false, M_SSH); break;
+      case M_SHADOW: if (first) VNR_MARCH(true, M_SHADOW); else VNR_MARCH(false, M_SHADOW); break;
+      default: if (first) VNR_MARCH(true, M_NONE); else VNR_MARCH(false, M_NONE); break;
+      }
+#undef VNR_MARCH
     }
     VNR_HIP_CHECK(hipGetLastError());
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it], hf.s));
@@ -927,7 +1085,7 @@ void Renderer::render_streaming(const RenderParams& p_all)
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
     // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
-    compact_rays_kernel<<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0);
+    compact_rays_kernel<<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0);
     VNR_HIP_CHECK(hipGetLastError());
     VNR_HIP_CHECK(hipMemcpyAsync(hf.hc + (it & 255u), c + C_RAYS0 + (parity ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, hf.s));
     ++hf.it;
@@ -939,7 +1097,7 @@ void Renderer::render_streaming(const RenderParams& p_all)
   for (;;) {
     bool launched = false;
     for (int h = 0; h < H; ++h)
-      if (!half[h].done && half[h].it < predicted_iterations_[h]) { launch_iteration(h); launched = true; }
+      if (!half[h].done && half[h].it < predicted[h]) { launch_iteration(h); launched = true; }
     if (!launched) break;
   }
   for (;;) {
@@ -958,23 +1116,23 @@ void Renderer::render_streaming(const RenderParams& p_all)
   }
 
   // the last march that produced zero rays ends a half's frame; remember how many iterations that took
-  stats_.n_iterations = 0;
+  uint32_t pass_iterations = 0;
   uint64_t n_samples = 0, n_refrays = 0;
   for (int h = 0; h < H; ++h) {
     Half& hf = half[h];
     VNR_HIP_CHECK(hipStreamSynchronize(hf.s));
     uint32_t used = hf.it;
     while (used > 1 && hf.hc[(used - 2) & 255u] == 0) --used;  // trailing speculative no-op iterations
-    predicted_iterations_[h] = used;
+    predicted[h] = used;
     hf.used = used;
     uint32_t hc[C_COUNT];
     VNR_HIP_CHECK(hipMemcpy(hc, hf.c, sizeof(hc), hipMemcpyDeviceToHost));
-    stats_.n_rays_hit += hc[C_HIT];
+    if (pass_mode != M_SHADOW) stats_.n_rays_hit += hc[C_HIT];
     n_samples += (uint64_t)hc[C_STAT_SAMPLES] | ((uint64_t)hc[C_STAT_SAMPLES + 1] << 32);
     n_refrays += (uint64_t)hc[C_STAT_REFRAYS] | ((uint64_t)hc[C_STAT_REFRAYS + 1] << 32);
     // march(j) emits what the reference's iteration j intersects and march(j+1) composes it, so `used` marches
     // correspond to used-1 reference iterations (= inference launches with samples); halves run side by side
-    stats_.n_iterations = std::max<uint32_t>(stats_.n_iterations, used > 0 ? used - 1 : 0);
+    pass_iterations = std::max<uint32_t>(pass_iterations, used > 0 ? used - 1 : 0);
     if (profiling_) {
       for (uint32_t k = 0; k < hf.it; ++k) {
         float ms = 0.0f;
@@ -985,8 +1143,10 @@ void Renderer::render_streaming(const RenderParams& p_all)
       stats_.infer_kernel_launches += used > 0 ? used - 1 : 0;
     }
   }
-  stats_.n_samples = n_samples;
-  stats_.n_reference_slots = n_refrays * (uint64_t)p_all.n_iters;
+  // summed over the passes of a frame (mode 11: camera pass + shadow pass)
+  stats_.n_iterations += pass_iterations;
+  stats_.n_samples += n_samples;
+  stats_.n_reference_slots += n_refrays * (uint64_t)p_all.n_iters;
 }
 
 

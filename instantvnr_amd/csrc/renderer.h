@@ -55,7 +55,7 @@ public:
   int height() const { return height_; }
 
 private:
-  void render_streaming(const RenderParams& p);
+  void render_streaming(const RenderParams& p, int pass_mode);   // one iterative_raymarching_loop<MODE> (method_raymarching.cu:931-958)
   void render_monolithic(const RenderParams& p);
   void ensure_queues(size_t n_pixels, int n_iters, bool gradient);
 
@@ -77,7 +77,7 @@ private:
   vec3f light_dir_ = {0.7f, 0.9f, 0.4f};
   uint32_t tile_w_log2_ = 3;  // ray tiles of 2^w x 2^(6-w) pixels (render.hip map_pixel)
   int n_halves_ = 2;  // streaming mode: rays dealt to 2 halves on 2 streams (march of one overlaps inference of the other)
-  uint32_t predicted_iterations_[2] = {0, 0};
+  uint32_t predicted_iterations_[2][2] = {{0, 0}, {0, 0}};   // [camera pass | shadow pass][half]
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr;
 
@@ -91,6 +91,8 @@ private:
   DeviceBuffer<uint32_t> q_u32_;   // pixel_index[2], sample_base[2], sample_count[2]
   DeviceBuffer<float> q_f32_;      // jitter[2], alpha[2], color[2][3], t_next[2][3], next_cell_begin[2]
   DeviceBuffer<int> q_i32_;        // cell[2][3]
+  DeviceBuffer<float> q_ssh_;      // single-shade heuristic: highest org[2][3], colour[2][3], alpha[2] per ray
+  DeviceBuffer<float> ssh_px_;     // ... and per pixel: org[3], colour[3], alpha, second jitter, unshaded rgba[4]
   DeviceBuffer<uint32_t> ray_counts_;  // surviving rays per 64-ray group of the last march (order-preserving compaction)
   DeviceBuffer<vec4f> queue_;      // gather-order sample records {x, y, z, ray-major slot}
   DeviceBuffer<float> arena_;      // evaluation results, x2 (ping-pong): per slot {value, t1 - t0}, then (gradient shading) 4 more floats

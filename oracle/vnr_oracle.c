@@ -982,8 +982,49 @@ static int compose_body(void* c, float t0, float t1)
   return ((++x->k) < x->n_iters) && (x->alpha < NEARLY_ONE);
 }
 
-void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, void* user,
-                           float* accumulation, float* frame, vnro_render_stats* stats)
+/* SINGLE_SHADE_HEURISTIC state carried by a ray (SingleShotPayload, method_raymarching.cu:157-162) */
+typedef struct { v3 org, color; float alpha; } ssh_t;
+
+/* per-pixel results of the SSH camera pass that the shadow pass consumes (:88-92): highest-contribution sample, the
+ * unshaded pixel, the second jitter */
+typedef struct { v3* org; v3* color; float* alpha; float* shading; float* jitter; } ssh_pixels;
+
+typedef struct {
+  const vnro_scene* s; const float* samples; uint32_t n_rays, i; int k, n_iters;
+  float alpha; v3 color; float step_rcp;
+  ray_t ray; float jitter; ssh_t* ssh; int shadow;
+} compose2_ctx;
+/* iterative_compose_kernel<SINGLE_SHADE_HEURISTIC / SHADOW> body (:762-803) */
+static int compose2_body(void* c, float t0, float t1)
+{
+  compose2_ctx* x = (compose2_ctx*)c;
+  const size_t slot = (size_t)x->n_rays * x->k + x->i;
+  const float value = x->samples[slot];
+  float rgb[3], a;
+  vnro_tfn_sample(&x->s->tfn, value, rgb, &a);
+  a = opacity_correction(x->step_rcp, t1 - t0, a);
+  if (x->ssh) {  /* remember the sample that contributes most (:789-795) */
+    if (x->ssh->alpha < (1.0f - x->alpha) * a) {
+      const float t = (1.0f - x->jitter) * t0 + x->jitter * t1;
+      x->ssh->org = v3_add(x->ray.org, v3_scale(t, x->ray.dir));
+      x->ssh->color = v3_make(rgb[0], rgb[1], rgb[2]);
+      x->ssh->alpha = (1.0f - x->alpha) * a;
+    }
+  }
+  const float tr = 1.0f - x->alpha;
+  x->alpha += tr * a;
+  if (!x->shadow) {
+    x->color.x += tr * rgb[0] * a;
+    x->color.y += tr * rgb[1] * a;
+    x->color.z += tr * rgb[2] * a;
+  }
+  return ((++x->k) < x->n_iters) && (x->alpha < NEARLY_ONE);
+}
+
+/* One iterative_raymarching_loop<MODE> (:931-958).  pass: 0 = NO_SHADING / GRADIENT_SHADING camera rays, 2 = SINGLE_SHADE_HEURISTIC
+ * camera rays (results go to `px`, no pixel is written), 3 = SHADOW rays from px->org towards the light (:877-900, 639-653) */
+static void streaming_pass(const vnro_scene* s, int pass, int n_iters, vnro_value_fn fn, void* user, float* accumulation, float* frame,
+                           vnro_render_stats* st, ssh_pixels* px)
 {
   const uint32_t n_pixels = (uint32_t)s->width * (uint32_t)s->height;
   const camera_t cam = make_camera(s);
@@ -994,51 +1035,74 @@ void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, v
   const float step = 1.0f / s->sampling_rate, step_rcp = s->sampling_rate; /* object.cpp:303-304 */
   const v3 rcp = v3_make(1.0f / s->mc_spacings[0], 1.0f / s->mc_spacings[1], 1.0f / s->mc_spacings[2]);
   const i3 grid = { s->mc_dims[0], s->mc_dims[1], s->mc_dims[2] };
+  const float shading_scale = 0.95f;  /* scivis_shading_scale, instantvnr_types.h:140 */
 
   /* GRADIENT_SHADING streams 4 coordinates per sample (:198, :934): the sample and three forward offsets of grad_step */
-  const int gradient = s->shading_mode == 1;
+  const int gradient = pass == 0 && s->shading_mode == 1;
   const size_t per_sample = gradient ? 4 : 1;
   const v3 gs = v3_make(1.0f / (float)s->vol_dims[0], 1.0f / (float)s->vol_dims[1], 1.0f / (float)s->vol_dims[2]); /* object.cpp:305 */
   payload_t* cur = (payload_t*)malloc(sizeof(payload_t) * n_pixels);
   payload_t* nxt = (payload_t*)malloc(sizeof(payload_t) * n_pixels);
+  ssh_t* ssh_cur = (ssh_t*)calloc(n_pixels, sizeof(ssh_t));
+  ssh_t* ssh_nxt = (ssh_t*)calloc(n_pixels, sizeof(ssh_t));
   float* coords = (float*)calloc((size_t)n_pixels * n_iters * 3 * per_sample, sizeof(float));
   float* values = (float*)calloc((size_t)n_pixels * n_iters * per_sample, sizeof(float));
-  vnro_render_stats st = {0, 0, 0, 0};
+  /* shadow rays all point towards the light: xfmVector(wto, normalize(light_directional_dir)) (:649) */
+  const v3 ldir = xfm_vector(&wto, v3_normalize(v3_make(s->light_dir[0], s->light_dir[1], s->light_dir[2])));
 
-  /* raygen, ref: method_raymarching.cu:840-875 */
+  /* raygen, ref: method_raymarching.cu:840-875 (camera) / :877-900 (shadow) */
   uint32_t n_rays = 0;
   const uint32_t p_lo = s->pixel_lo, p_hi = s->pixel_hi < n_pixels ? s->pixel_hi : n_pixels;
   for (uint32_t i = p_lo; i < p_hi; ++i) {
-    vnro_lcg rng;
-    vnro_lcg_init(&rng, (uint32_t)s->frame_index, i);
-    const float jitter = vnro_lcg_next(&rng); /* get_floats().x */
-    const ray_t ray = compute_ray(s, &cam, &wto, i);
+    ray_t ray;
+    float jitter;
+    int want = 1;
+    if (pass == 3) {
+      ray.org = px->org[i]; ray.dir = ldir;
+      jitter = px->jitter[i];
+      want = px->alpha[i] > 0.0f;
+    } else {
+      vnro_lcg rng;
+      vnro_lcg_init(&rng, (uint32_t)s->frame_index, i);
+      jitter = vnro_lcg_next(&rng); /* get_floats().x */
+      if (pass == 2) px->jitter[i] = vnro_lcg_next(&rng); /* get_floats().y (:866-868; stored for every pixel here) */
+      ray = compute_ray(s, &cam, &wto, i);
+    }
     float tmin = 0.0f, tmax = FLOAT_LARGE;
-    if (intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi)) {
+    if (intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi) && want) {
       payload_t p;
-      p.pixel_index = i; p.jitter = jitter; p.alpha = 0.0f; p.color = v3_make(0, 0, 0);
+      p.pixel_index = i; p.jitter = jitter; p.alpha = 0.0f;
+      p.color = pass == 3 ? ray.org : v3_make(0, 0, 0);   /* color_or_org: a shadow ray keeps its origin there (:639-653) */
       dda_init(&p.iter, v3_mul(ray.org, rcp), v3_mul(ray.dir, rcp), tmin, tmax, grid); /* :544-553 */
+      ssh_cur[n_rays].org = v3_make(0, 0, 0); ssh_cur[n_rays].color = v3_make(0, 0, 0); ssh_cur[n_rays].alpha = 0.0f;
       cur[n_rays++] = p;
+    } else if (pass == 3) {
+      write_pixel(s, accumulation, frame, px->shading + 4 * (size_t)i, i);   /* :897-899 */
+    } else if (pass == 2) {
+      /* :870-874: nothing is written; the reference's per-frame memset leaves zeros for the shadow pass to find */
+      px->org[i] = v3_make(0, 0, 0); px->color[i] = v3_make(0, 0, 0); px->alpha[i] = 0.0f;
+      px->shading[4 * (size_t)i] = px->shading[4 * (size_t)i + 1] = px->shading[4 * (size_t)i + 2] = px->shading[4 * (size_t)i + 3] = 0.0f;
     } else {
       const float zero[4] = {0, 0, 0, 0};
       write_pixel(s, accumulation, frame, zero, i);
     }
   }
-  st.n_rays_hit = n_rays;
+  if (pass != 3) st->n_rays_hit = n_rays;
 
   /* loop, ref: method_raymarching.cu:931-958 */
   while (n_rays > 0) {
-    st.n_iterations++;
-    st.n_slots += (uint64_t)n_rays * (uint64_t)n_iters;
+    st->n_iterations++;
+    st->n_slots += (uint64_t)n_rays * (uint64_t)n_iters;
     /* intersect, :687-730 (iterator state is NOT saved here) */
     for (uint32_t i = 0; i < n_rays; ++i) {
       payload_t p = cur[i];
-      const ray_t ray = compute_ray(s, &cam, &wto, p.pixel_index);
+      ray_t ray;
+      if (pass == 3) { ray.org = p.color; ray.dir = ldir; } else ray = compute_ray(s, &cam, &wto, p.pixel_index);
       float tmin = 0.0f, tmax = FLOAT_LARGE;
       intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi);
       intersect_ctx x = { ray, p.jitter, coords, n_rays, i, 0, n_iters, gradient, gs };
       iter_exec(s, &p.iter, ray.dir, tmin, tmax, step, intersect_body, &x);
-      st.n_samples += (uint64_t)x.k;
+      st->n_samples += (uint64_t)x.k;
     }
     /* inference of ALL n_iters*n_rays slots (stale coords included), :950-953; x4 blocks with gradient shading */
     fn(user, coords, (size_t)n_rays * n_iters * per_sample, values);
@@ -1046,25 +1110,69 @@ void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, v
     uint32_t n_next = 0;
     for (uint32_t i = 0; i < n_rays; ++i) {
       payload_t p = cur[i];
-      const ray_t ray = compute_ray(s, &cam, &wto, p.pixel_index);
+      ray_t ray;
+      if (pass == 3) { ray.org = p.color; ray.dir = ldir; } else ray = compute_ray(s, &cam, &wto, p.pixel_index);
       float tmin = 0.0f, tmax = FLOAT_LARGE;
       intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi);
-      compose_ctx x = { s, values, n_rays, i, 0, n_iters, p.alpha, p.color, step_rcp, gradient, gs, &otw, &wto, ray.dir };
-      iter_exec(s, &p.iter, ray.dir, tmin, tmax, step, compose_body, &x);
-      p.alpha = x.alpha; p.color = x.color;
+      ssh_t ssh = ssh_cur[i];
+      if (pass == 0) {
+        compose_ctx x = { s, values, n_rays, i, 0, n_iters, p.alpha, p.color, step_rcp, gradient, gs, &otw, &wto, ray.dir };
+        iter_exec(s, &p.iter, ray.dir, tmin, tmax, step, compose_body, &x);
+        p.alpha = x.alpha; p.color = x.color;
+      } else {
+        compose2_ctx x = { s, values, n_rays, i, 0, n_iters, p.alpha, pass == 3 ? v3_make(0, 0, 0) : p.color, step_rcp, ray, p.jitter,
+                           pass == 2 ? &ssh : NULL, pass == 3 };
+        iter_exec(s, &p.iter, ray.dir, tmin, tmax, step, compose2_body, &x);
+        p.alpha = x.alpha;
+        if (pass == 2) p.color = x.color;   /* a shadow ray's color_or_org stays its origin (set_ray<SHADOW>) */
+      }
       const int resumable = dda_resumable(&p.iter, v3_mul(ray.dir, rcp), tmin, tmax, grid);
       if (p.alpha < NEARLY_ONE && resumable) {
+        ssh_nxt[n_next] = ssh;
         nxt[n_next++] = p;
+      } else if (pass == 3) {  /* :820-826 */
+        const uint32_t pidx = p.pixel_index;
+        const float transmittance = 1.0f - p.alpha;
+        float sc[4] = { px->shading[4 * (size_t)pidx], px->shading[4 * (size_t)pidx + 1], px->shading[4 * (size_t)pidx + 2], px->shading[4 * (size_t)pidx + 3] };
+        const v3 hc = px->color[pidx];
+        sc[0] = (1.0f - shading_scale) * sc[0] + shading_scale * (hc.x * sc[3] * transmittance);
+        sc[1] = (1.0f - shading_scale) * sc[1] + shading_scale * (hc.y * sc[3] * transmittance);
+        sc[2] = (1.0f - shading_scale) * sc[2] + shading_scale * (hc.z * sc[3] * transmittance);
+        write_pixel(s, accumulation, frame, sc, pidx);
+      } else if (pass == 2) {  /* :827-833 */
+        const uint32_t pidx = p.pixel_index;
+        px->org[pidx] = ssh.org; px->color[pidx] = ssh.color; px->alpha[pidx] = ssh.alpha;
+        px->shading[4 * (size_t)pidx] = p.color.x; px->shading[4 * (size_t)pidx + 1] = p.color.y;
+        px->shading[4 * (size_t)pidx + 2] = p.color.z; px->shading[4 * (size_t)pidx + 3] = p.alpha;
       } else {
         const float rgba[4] = { p.color.x, p.color.y, p.color.z, p.alpha };
         write_pixel(s, accumulation, frame, rgba, p.pixel_index);
       }
     }
     payload_t* t = cur; cur = nxt; nxt = t;
+    ssh_t* u = ssh_cur; ssh_cur = ssh_nxt; ssh_nxt = u;
     n_rays = n_next;
   }
+  free(cur); free(nxt); free(ssh_cur); free(ssh_nxt); free(coords); free(values);
+}
+
+/* do_raymarching_iterative (:960-973): shading_mode 0 / 1 = one pass, 2 = SINGLE_SHADE_HEURISTIC = camera pass + shadow pass */
+void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, void* user,
+                           float* accumulation, float* frame, vnro_render_stats* stats)
+{
+  vnro_render_stats st = {0, 0, 0, 0};
+  if (s->shading_mode == 2) {
+    const size_t n = (size_t)s->width * (size_t)s->height;
+    ssh_pixels px;
+    px.org = (v3*)calloc(n, sizeof(v3)); px.color = (v3*)calloc(n, sizeof(v3)); px.alpha = (float*)calloc(n, sizeof(float));
+    px.shading = (float*)calloc(4 * n, sizeof(float)); px.jitter = (float*)calloc(n, sizeof(float));
+    streaming_pass(s, 2, n_iters, fn, user, accumulation, frame, &st, &px);
+    streaming_pass(s, 3, n_iters, fn, user, accumulation, frame, &st, &px);
+    free(px.org); free(px.color); free(px.alpha); free(px.shading); free(px.jitter);
+  } else {
+    streaming_pass(s, 0, n_iters, fn, user, accumulation, frame, &st, NULL);
+  }
   if (stats) *stats = st;
-  free(cur); free(nxt); free(coords); free(values);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1076,6 +1184,8 @@ typedef struct {
   const vnro_scene* s; const float* vol; ray_t ray; float jitter, step, step_rcp;
   float alpha; v3 color;
   int gradient; v3 gs; const affine* otw; const affine* wto;
+  int ssh, shadow;               /* SINGLE_SHADE_HEURISTIC camera ray (:455-462) / its transmittance ray (:364-398) */
+  v3 highest_org, highest_color; float highest_alpha;
 } mono_ctx;
 
 static int mono_cell(void* c, i3 cell, float t0, float t1)
@@ -1107,6 +1217,18 @@ static int mono_cell(void* c, i3 cell, float t0, float t1)
       const float fgz = vnro_sample_volume(m->vol, m->s->vol_dims, p.x, p.y, p.z + stp.z);
       const v3 shaded = gradient_shade(m->s, m->otw, m->wto, m->ray.dir, value, fgx, fgy, fgz, stp, v3_make(rgb[0], rgb[1], rgb[2]));
       rgb[0] = shaded.x; rgb[1] = shaded.y; rgb[2] = shaded.z;
+    }
+    if (m->shadow) {  /* raymarching_transmittance: alpha += (1 - alpha) * sampleAlpha (:391-392) */
+      m->alpha += (1.0f - m->alpha) * a;
+      if (!(m->alpha < NEARLY_ONE)) return 0;
+      tx = ty;
+      ty = fminf(tx + ss, t1);
+      continue;
+    }
+    if (m->ssh && m->highest_alpha < (1.0f - m->alpha) * a) {  /* :455-462 */
+      m->highest_org = p;
+      m->highest_color = v3_make(rgb[0], rgb[1], rgb[2]);
+      m->highest_alpha = (1.0f - m->alpha) * a;
     }
     const float tr = 1.0f - m->alpha;
     m->color.x += tr * rgb[0] * a;
@@ -1140,12 +1262,33 @@ void vnro_render_monolithic(const vnro_scene* s, const float* vol, int row_lo, i
       m.step = 1.0f / s->sampling_rate; m.step_rcp = s->sampling_rate;
       m.alpha = 0.0f; m.color = v3_make(0, 0, 0);
       m.gradient = s->shading_mode == 1;
+      m.ssh = s->shading_mode == 2; m.shadow = 0;
+      m.highest_org = v3_make(0, 0, 0); m.highest_color = v3_make(0, 0, 0); m.highest_alpha = 0.0f;
       m.gs = v3_make(1.0f / (float)s->vol_dims[0], 1.0f / (float)s->vol_dims[1], 1.0f / (float)s->vol_dims[2]);
       m.otw = &otw; m.wto = &wto;
       float t0 = 0.0f, t1 = FLOAT_LARGE;
       if (intersect_box(&t0, &t1, m.ray.org, m.ray.dir, lo, hi)) {
-        m.jitter = vnro_lcg_next(&rng);
+        m.jitter = vnro_lcg_next(&rng);   /* get_floats().x: the generator advances by two draws per get_floats() */
+        (void)vnro_lcg_next(&rng);
         dda3(v3_mul(m.ray.org, rcp), v3_mul(m.ray.dir, rcp), t0, t1, grid, mono_cell, &m);
+        if (m.ssh && m.highest_alpha > 0.0f) {  /* :471-484: one shadow ray from the strongest sample towards the light */
+          const v3 ldir = xfm_vector(&wto, v3_normalize(v3_make(s->light_dir[0], s->light_dir[1], s->light_dir[2])));
+          mono_ctx sh = m;
+          sh.ray.org = m.highest_org; sh.ray.dir = ldir;
+          sh.shadow = 1; sh.ssh = 0; sh.gradient = 0;
+          sh.step = 2.0f * m.step;          /* raymarching_shadow_sampling_scale = 2 (instantvnr_types.h:137); opacityCorrection keeps self.step */
+          sh.alpha = 0.0f;
+          float s0 = 0.0f, s1 = FLOAT_LARGE;
+          if (intersect_box(&s0, &s1, sh.ray.org, sh.ray.dir, lo, hi)) {
+            sh.jitter = vnro_lcg_next(&rng);
+            dda3(v3_mul(sh.ray.org, rcp), v3_mul(sh.ray.dir, rcp), s0, s1, grid, mono_cell, &sh);
+          }
+          const float transmittance = 1.0f - sh.alpha;
+          const float k = 0.95f;            /* scivis_shading_scale */
+          m.color.x = (1.0f - k) * m.color.x + k * (m.highest_color.x * m.alpha * transmittance);
+          m.color.y = (1.0f - k) * m.color.y + k * (m.highest_color.y * m.alpha * transmittance);
+          m.color.z = (1.0f - k) * m.color.z + k * (m.highest_color.z * m.alpha * transmittance);
+        }
       }
       const float rgba[4] = { m.color.x, m.color.y, m.color.z, m.alpha };
       write_pixel(s, accumulation, frame, rgba, pixel);

@@ -143,7 +143,8 @@ typedef struct {
   /* tiling: only pixels with pixel_lo <= index < pixel_hi are rendered (others untouched) */
   uint32_t pixel_lo, pixel_hi;
   /* shading (appended last; zero = NO_SHADING, i.e. rendering modes 4 / 5) */
-  int   shading_mode;  /* 1 = GRADIENT_SHADING (modes 7 / 8; method_raymarching.cu:446-454, 719-726, 773-788) */
+  int   shading_mode;  /* 1 = GRADIENT_SHADING (modes 7 / 8; method_raymarching.cu:446-454, 719-726, 773-788);
+                        * 2 = SINGLE_SHADE_HEURISTIC (modes 10 / 11; :455-484 monolithic, :789-833, 877-900 streaming + shadow pass) */
   float light_dir[3];  /* LaunchParams::light_directional_dir (instantvnr_types.h:148) AFTER the flip of renderer.cpp:98-101 */
 } vnro_scene;
 

@@ -365,3 +365,68 @@ def test_gradient_shading_neural_streaming_matches_oracle(oracle, scene):
     plain = oracle.SceneHolder(64, 56, (48, 48, 48), scene["otfn"], mo, cam["from"], cam["at"], cam["up"], cam["fovy"])
     want5, _, _ = oracle.render_streaming(plain, lambda c: oracle.network_inference(ocfg, 64, H, params.view(np.uint16), c))
     assert psnr(img5, want5) > 40
+
+
+@pytest.mark.parametrize("side", ["light not flipped", "light flipped"])
+@pytest.mark.parametrize("mode", [11, 10])
+def test_single_shade_heuristic_groundtruth_matches_oracle(oracle, scene, mode, side):
+    """VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_{SAMPLE_STREAMING = 11, DECODING = 10} on a dense volume: the camera ray remembers
+    the sample that contributed most, one shadow ray from there towards the light gives a transmittance, and the pixel becomes
+    lerp(0.95, colour, highest colour x alpha x transmittance) (method_raymarching.cu:455-484 monolithic; :789-833, 877-900 and
+    the two loops of :968-971 streaming).  Accumulation over two frames included: both passes write through writePixelColor."""
+    frm = scene["cam"]["from"] if side == "light not flipped" else tuple(-v for v in scene["cam"]["from"])
+    r = make_renderer(scene, scene["sv"], mode=mode)
+    api.vnrRendererSetCamera(r, _camera(frm))
+    mo = api.volume_macrocell(scene["sv"])["max_opacity"]
+    f = lambda c: oracle.sample_volume(scene["vol"], c, nodal=True)
+    acc = None
+    for frame_index in (1, 2):
+        api.vnrRender(r)
+        img = api.vnrRendererMapFrame(r).copy()
+        sc = oracle.SceneHolder(96, 80, (48, 48, 48), scene["otfn"], mo, frm, fovy=45.0, shading_mode=2, frame_index=frame_index)
+        plain = oracle.SceneHolder(96, 80, (48, 48, 48), scene["otfn"], mo, frm, fovy=45.0, shading_mode=0, frame_index=frame_index)
+        if mode == 11:
+            want, acc, ost = oracle.render_streaming(sc, f, accumulation=acc)
+            st = api.vnrRendererGetFrameStats(r)
+            assert st["n_rays_hit"] == ost["n_rays_hit"] > 1000
+            assert st["n_iterations"] == ost["n_iterations"]         # camera pass + shadow pass
+            assert st["n_samples"] <= ost["n_samples"]
+        else:
+            want, acc = oracle.render_monolithic(sc, scene["vol"], accumulation=acc)
+        if frame_index == 1:
+            unshaded = oracle.render_streaming(plain, f)[0] if mode == 11 else oracle.render_monolithic(plain, scene["vol"])[0]
+            assert np.abs(want[..., :3] - unshaded[..., :3]).mean() > 2e-3     # the shadows are visible
+            assert np.array_equal(want[..., 3], unshaded[..., 3])              # and change colour only
+        assert np.abs(img - want).max() < 2e-5, (frame_index, np.abs(img - want).max())
+        assert psnr(img, want) > 110
+
+
+def test_single_shade_heuristic_neural_streaming_matches_oracle(oracle, scene):
+    """mode 11 on a neural volume: both passes evaluate the network (C4 model shape); same bar as mode 8"""
+    L, F, log2T, base, pls, H = 16, 2, 19, 16, 1.3195, 3
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base, n_hidden_layers=H, per_level_scale=pls)
+    nv = api.vnrCreateNeuralVolume(cfg, scene["sv"], online_macrocell_construction=False)
+    info = api.neural_info(nv)
+    ocfg = oracle.grid_config(L, F, log2T, base, pls)
+    params = syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], 64, H - 1), seed=22)
+    api.neural_set_params_fp16(nv, params)
+    r = make_renderer(scene, nv, size=(64, 56), mode=11)
+    api.vnrRender(r)
+    img = api.vnrRendererMapFrame(r).copy()
+    st = api.vnrRendererGetFrameStats(r)
+    mo = api.volume_macrocell(scene["sv"])["max_opacity"]
+    cam = scene["cam"]
+    sc = oracle.SceneHolder(64, 56, (48, 48, 48), scene["otfn"], mo, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=2)
+    want, _, ost = oracle.render_streaming(sc, lambda c: oracle.network_inference(ocfg, 64, H, params.view(np.uint16), c))
+    assert st["n_rays_hit"] == ost["n_rays_hit"]
+    assert img[..., 3].max() > 0.05
+    assert psnr(img, want) > 70, psnr(img, want)
+    # modes 5 and 8 on the same renderer afterwards (queues, ray lists and predictions are shared between the modes)
+    for m, sm in ((5, 0), (8, 1)):
+        api.vnrRendererSetMode(r, m)
+        api.vnrRendererResetAccumulation(r)
+        api.vnrRender(r)
+        got = api.vnrRendererMapFrame(r).copy()
+        s2 = oracle.SceneHolder(64, 56, (48, 48, 48), scene["otfn"], mo, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=sm)
+        w2, _, _ = oracle.render_streaming(s2, lambda c: oracle.network_inference(ocfg, 64, H, params.view(np.uint16), c))
+        assert psnr(got, w2) > 40

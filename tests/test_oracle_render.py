@@ -217,3 +217,34 @@ def test_gradient_shading_changes_colour_only_and_modes_agree(oracle):
     assert st0 == st1 and np.array_equal(a0[..., 3], a1[..., 3])
     assert np.abs(a1[..., :3] - a0[..., :3]).mean() > 1e-3
     assert np.abs(a1 - m1).mean() < 1e-3
+
+
+def test_single_shade_heuristic_properties(oracle, small_scene):
+    """SINGLE_SHADE_HEURISTIC (method_raymarching.cu:455-484, 789-833, 877-900) has no reference fixture; what must hold by its
+    definition: alpha is the unshaded alpha; a colour is 0.05 x unshaded + 0.95 x (a transfer-function colour) x alpha x T with
+    T in [0, 1]; the streaming result does not depend on the batch size; streaming and monolithic agree up to the monolithic
+    marcher's step equalisation; a transparent volume stays black"""
+    vol, sc0 = small_scene
+    f = lambda c: oracle.sample_volume(vol, c, nodal=True)
+    cam = syn.oblique_camera((32, 32, 32))
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = oracle.TfnHolder(colors, alphas)
+    mo = oracle.macrocell_max_opacity(tfn, oracle.macrocell_compute_implicit(vol))
+    sc = oracle.SceneHolder(48, 40, (32, 32, 32), tfn, mo, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=2)
+    plain, _, _ = oracle.render_streaming(sc0, f)
+    ssh, _, st = oracle.render_streaming(sc, f)
+    assert np.array_equal(ssh[..., 3], plain[..., 3])
+    lo = 0.05 * plain[..., :3]
+    hi = lo + 0.95 * np.asarray(colors, np.float32).max() * plain[..., 3:4]
+    assert (ssh[..., :3] >= lo - 1e-6).all() and (ssh[..., :3] <= hi + 1e-6).all()
+    assert np.abs(ssh[..., :3] - plain[..., :3]).mean() > 2e-3
+    assert st["n_iterations"] > oracle.render_streaming(sc0, f)[2]["n_iterations"]   # the shadow pass adds its own
+    ssh5, _, _ = oracle.render_streaming(sc, f, n_iters=5)
+    assert np.abs(ssh - ssh5).max() < 2e-4
+    mono, _ = oracle.render_monolithic(sc, vol)
+    assert np.abs(mono - ssh).mean() < 0.01
+    # nothing opaque: no strongest sample, no shadow ray, black pixels
+    clear = oracle.TfnHolder(colors, np.zeros_like(np.asarray(alphas, np.float32)))
+    mo0 = oracle.macrocell_max_opacity(clear, oracle.macrocell_compute_implicit(vol))
+    sc_clear = oracle.SceneHolder(48, 40, (32, 32, 32), clear, mo0, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=2)
+    assert not oracle.render_streaming(sc_clear, f)[0].any() and not oracle.render_monolithic(sc_clear, vol)[0].any()

@@ -36,10 +36,17 @@ struct RayList {  // per ray payload, SoA (RayMarchingData, method_raymarching.c
   float* next_cell_begin;
   uint32_t* sample_base;
   uint32_t* sample_count;
-  // SINGLE_SHADE_HEURISTIC only (inter_highest_*, method_raymarching.cu:84-87): the sample that has contributed most so far
-  vec3f* h_org;
-  vec3f* h_color;
-  float* h_alpha;
+};
+
+// SINGLE_SHADE_HEURISTIC only (inter_highest_*, method_raymarching.cu:84-87): per ray, the sample that has contributed most so
+// far; [0] belongs to the dense ray list, [1] to the scratch list.  A kernel argument of its own, behind the others, so that
+// the instances that never touch it do not drag it through their scalar registers: as members of RayList these six pointers
+// cost the unshaded march kernel 6 more spilled SGPRs (90 -> 96) and the bench 3 % of its frame rate (A/B on one box,
+// tools/ab/ab.sh, n = 3 each: 195-198 against 201-204 frames/s; 199-200 against 199-201 with this layout).
+struct SshLists {
+  vec3f* org[2];
+  vec3f* color[2];
+  float* alpha[2];
 };
 
 struct RenderParams {
@@ -350,7 +357,7 @@ template <bool FIRST, int MODE>
 __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const RayList cur, const RayList nxt,
                                                     const vec2f* __restrict__ vd_in, vec4f* __restrict__ queue,
                                                     vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters,
-                                                    uint32_t* __restrict__ ray_counts, int parity)
+                                                    uint32_t* __restrict__ ray_counts, int parity, const SshLists ssh_lists)
 {
   extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1}, histogram[256], [n_iters][256] ranks (u16), then the transfer function tables
   float* s_t0 = s_t;
@@ -447,7 +454,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         const uint32_t sb = cur.sample_base[i], sc = cur.sample_count[i];
         if (MODE == M_SHADOW) { org = color; dir = p.shadow_dir; }   // compute_ray<SHADOW> (:639-653)
         else compute_ray(p, pixel, org, dir);
-        if (MODE == M_SSH) { h_org = cur.h_org[i]; h_color = cur.h_color[i]; h_alpha = cur.h_alpha[i]; }
+        if (MODE == M_SSH) { h_org = ssh_lists.org[0][i]; h_color = ssh_lists.color[0][i]; h_alpha = ssh_lists.alpha[0][i]; }
         m_dir = dir * p.mc_rcp;
         intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
         // compose (classification, opacity correction, front-to-back blending)
@@ -561,7 +568,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
       nxt.next_cell_begin[slot] = it.next_cell_begin;
       nxt.sample_base[slot] = sb;
       nxt.sample_count[slot] = k;
-      if (MODE == M_SSH) { nxt.h_org[slot] = h_org; nxt.h_color[slot] = h_color; nxt.h_alpha[slot] = h_alpha; }
+      if (MODE == M_SSH) { ssh_lists.org[1][slot] = h_org; ssh_lists.color[1][slot] = h_color; ssh_lists.alpha[1][slot] = h_alpha; }
       for (uint32_t j = 0; j < k; ++j) {
         const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
         const float t = (1.0f - jitter) * t0 + jitter * t1;  // lerp(jitter, t0, t1), instantvnr_types.h:162-166
@@ -602,7 +609,7 @@ __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float
 // it (at most 64 KiB of L2-resident counts per block), so no second launch and no inter-block dependency is needed.  The block
 // that holds the last group publishes the number of alive rays; block 0 also clears the sample counter the next march adds to.
 __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, const RayList dst, const uint32_t* __restrict__ ray_counts,
-                                                            uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first, int ssh)
+                                                            uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first, int ssh, const SshLists ssh_lists)
 {
   __shared__ uint32_t s_part[16];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -646,7 +653,9 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
     dst.next_cell_begin[to] = src.next_cell_begin[from];
     dst.sample_base[to] = src.sample_base[from];
     dst.sample_count[to] = src.sample_count[from];
-    if (ssh) { dst.h_org[to] = src.h_org[from]; dst.h_color[to] = src.h_color[from]; dst.h_alpha[to] = src.h_alpha[from]; }
+    if (ssh) {  // scratch [1] -> dense [0]
+      ssh_lists.org[0][to] = ssh_lists.org[1][from]; ssh_lists.color[0][to] = ssh_lists.color[1][from]; ssh_lists.alpha[0][to] = ssh_lists.alpha[1][from];
+    }
   }
 }
 
@@ -976,6 +985,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
   struct Half {
     RenderParams p;
     RayList rl[2];
+    SshLists ssh;
     vec4f* queue;
     vec2f* vd[2];
     uint32_t* c;         // device counters of this half
@@ -1006,12 +1016,12 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
       hf.rl[b].t_next = (vec3f*)(f + 5 * QP) + off;
       hf.rl[b].next_cell_begin = f + 8 * QP + off;
       hf.rl[b].cell = (vec3i*)(q_i32_.ptr + (size_t)b * 3 * QP) + off;
-      hf.rl[b].h_org = nullptr; hf.rl[b].h_color = nullptr; hf.rl[b].h_alpha = nullptr;
+      hf.ssh.org[b] = nullptr; hf.ssh.color[b] = nullptr; hf.ssh.alpha[b] = nullptr;
       if (ssh) {
         float* g = q_ssh_.ptr + (size_t)b * 7 * QP;
-        hf.rl[b].h_org = (vec3f*)g + off;
-        hf.rl[b].h_color = (vec3f*)(g + 3 * QP) + off;
-        hf.rl[b].h_alpha = g + 6 * QP + off;
+        hf.ssh.org[b] = (vec3f*)g + off;
+        hf.ssh.color[b] = (vec3f*)(g + 3 * QP) + off;
+        hf.ssh.alpha[b] = g + 6 * QP + off;
       }
       // this half's result arena of parity b: a slice of slot_floats * n_local * QI floats
       hf.vd[b] = (vec2f*)(arena_.ptr + (size_t)b * slot_floats * QP * QI + slot_floats * off * QI);
@@ -1065,7 +1075,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
       const size_t lds = first ? shmem : shmem_compose;
       const vec2f* vd_in = hf.vd[parity ^ 1];
       vec2f* vd_out = hf.vd[parity];
-#define VNR_MARCH(FIRST_, MODE_) march_kernel<FIRST_, MODE_><<<blocks, 256, lds, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], vd_in, hf.queue, vd_out, c, hf.rc, parity)
+#define VNR_MARCH(FIRST_, MODE_) march_kernel<FIRST_, MODE_><<<blocks, 256, lds, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], vd_in, hf.queue, vd_out, c, hf.rc, parity, hf.ssh)
       switch (pass_mode) {
       case M_GRADIENT: if (first) VNR_MARCH(true, M_GRADIENT); else VNR_MARCH(false, M_GRADIENT); break;
       case M_SSH: if (first) VNR_MARCH(true, M_SSH); else VNR_MARCH(false, M_SSH); break;
@@ -1085,7 +1095,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
     // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
-    compact_rays_kernel<<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0);
+    compact_rays_kernel<<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh);
     VNR_HIP_CHECK(hipGetLastError());
     VNR_HIP_CHECK(hipMemcpyAsync(hf.hc + (it & 255u), c + C_RAYS0 + (parity ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, hf.s));
     ++hf.it;

@@ -122,6 +122,10 @@ public:
   // brick image policy: built on stream `s` once `brick_after` inference launches have seen unchanged parameters
   // (VNR_AMD_BRICK_AFTER, default 24 = two frames of the streaming renderer; VNR_AMD_BRICK=0 disables, =1 builds at the first
   // launch), within VNR_AMD_BRICK_MAX_GB (default 32) and a quarter of the free device memory
+  // Levels finer than `cap` grid points per axis are left hashed: the image pays off where neighbouring samples share cells,
+  // i.e. up to about the resolution of the volume the network represents (NeuralVolume passes twice its largest dimension).
+  // A 128^3 volume with tcnn's default per_level_scale 2 has levels up to 2048^3, whose image would be 137 GB and useless.
+  void set_brick_resolution_cap(uint32_t cap) { brick_res_cap_ = cap; }
   bool brick_image_in_use() const { return brick_valid_; }
   size_t brick_image_bytes() const { return brick_image_.bytes(); }
   float brick_build_ms() const { return brick_build_ms_; }
@@ -159,6 +163,7 @@ private:
   mutable uint32_t brick_stable_calls_ = 0;
   mutable hipEvent_t brick_event_ = nullptr;
   mutable float brick_build_ms_ = 0.0f;
+  uint32_t brick_res_cap_ = 0;   // 0: no cap
 
 public:
   ~Network();

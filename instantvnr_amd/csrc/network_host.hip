@@ -256,6 +256,7 @@ void Network::build_brick_image(hipStream_t s) const
   uint64_t used = 0;
   for (int l = (int)grid_.n_levels - 1; l >= 0; --l) {
     if (!lv[l].hashed && !dense_too) continue;
+    if (brick_res_cap_ && lv[l].resolution > brick_res_cap_ + 1u) continue;
     const uint64_t res = lv[l].resolution;
     const uint64_t n = ((res >> lx) + 1) * ((res >> ly) + 1) * ((res >> lz) + 1);
     if (n * entries_per_line >= (1ull << 32) || used + n + 1 > budget_lines || used + n + 1 >= 0xffffffffull) continue;

@@ -677,6 +677,7 @@ void NeuralVolume::set_network(vec3i dims, const Json& config, SimpleVolume* ref
   if (config.contains("fvsrn")) throw std::runtime_error("fvsrn is not enabled");  // network.cu:572-578
   const uint64_t seed = init_seed ? init_seed : (uint64_t)time(nullptr);             // tcnn_network.h:209
   net_.configure(config, seed);
+  net_.set_brick_resolution_cap(2u * (uint32_t)std::max(desc.dims.x, std::max(desc.dims.y, desc.dims.z)));
   train_x_.resize(batch_size_ * 3);
   train_y_.resize(batch_size_);
   test_y1_.resize(batch_size_);
@@ -694,6 +695,7 @@ void NeuralVolume::set_model(const Json& config)
 {
   const uint64_t seed = init_seed ? init_seed : (uint64_t)time(nullptr);
   net_.configure(config, seed);
+  net_.set_brick_resolution_cap(2u * (uint32_t)std::max(desc.dims.x, std::max(desc.dims.y, desc.dims.z)));
 }
 
 void NeuralVolume::train_begin()

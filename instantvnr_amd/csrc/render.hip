@@ -781,7 +781,7 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
 {
   if (!Runtime::get().ready()) Runtime::get().init(-1);
   stream_ = Runtime::get().stream;
-  if (const char* e = std::getenv("VNR_RM_N_ITERS")) n_iters_ = std::max(1, std::min(48, std::atoi(e)));  // 3 KiB of LDS per iteration slot and block
+  if (const char* e = std::getenv("VNR_RM_N_ITERS")) { n_iters_ = std::max(1, std::min(48, std::atoi(e))); n_iters_fixed_ = true; }  // 2.5 KiB of LDS per iteration slot and block
   // streaming mode runs the rays as two halves on two streams (render_streaming); VNR_AMD_RENDER_HALVES=1: one stream
   if (const char* e = std::getenv("VNR_AMD_RENDER_HALVES")) n_halves_ = std::atoi(e) == 1 ? 1 : 2;
   if (const char* e = std::getenv("VNR_AMD_TILE_W")) {  // ray tile shape (diagnostics): 8 -> 8x8, 16 -> 16x4, 32 -> 32x2, 64 -> 64x1
@@ -895,7 +895,9 @@ void Renderer::render()
   p.mc_max_opacity = mc.d_max_opacity();
   p.tfn = tfn_.view();
   p.tfn_in_lds = ((size_t)p.tfn.n_colors * sizeof(vec4f) + (size_t)p.tfn.n_alphas * sizeof(float)) <= 24 * 1024 ? 1u : 0u;
-  p.n_iters = n_iters_;
+  // A small share of a frame (one rank of 8) is bound by the latency of the per-iteration kernel chain, not by throughput:
+  // fewer, longer iterations (tools/share_probe.py, 1/8 of the bench frame: 24 -> 0.995 ms, 32 -> 0.910 ms, 48 -> 0.905 ms)
+  p.n_iters = (!n_iters_fixed_ && p.n_local <= 196608u) ? 32 : n_iters_;
   // gradient shading (modes 7 / 8)
   p.otw = volume_->transform;
   p.grad_step = {1.0f / (float)p.vol_dims.x, 1.0f / (float)p.vol_dims.y, 1.0f / (float)p.vol_dims.z};  // object.cpp:305

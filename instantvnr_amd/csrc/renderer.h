@@ -72,6 +72,7 @@ private:
   // samples per ray and iteration, VNR_RM_N_ITERS (method_raymarching.cu:30-40; 16 there, tuned on the authors' GPU).  Frames do
   // not depend on it; on MI355X 24 is the fastest (bench workload: 16: 122, 24: 129, 32: 126 frames/s)
   int n_iters_ = 24;
+  bool n_iters_fixed_ = false;   // VNR_RM_N_ITERS given: no adaptation to the size of the share
   // LaunchParams::light_directional_dir (instantvnr_types.h:148): a member the reference negates IN PLACE whenever it points
   // along the view direction (renderer.cpp:98-101), so it persists across frames
   vec3f light_dir_ = {0.7f, 0.9f, 0.4f};

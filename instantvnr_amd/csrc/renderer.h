@@ -69,8 +69,8 @@ private:
   uint32_t il_block_ = 8, il_parts_ = 1, il_part_ = 0;
   bool reset_ = true, skip_download_ = false, profiling_ = false;
   int frame_index_ = 0;
-  // samples per ray and iteration, VNR_RM_N_ITERS (method_raymarching.cu:30-40; 16 there, tuned on the authors' GPU).  Frames do
-  // not depend on it; on MI355X 24 is the fastest (bench workload: 16: 122, 24: 129, 32: 126 frames/s)
+  // samples per ray and iteration, VNR_RM_N_ITERS (method_raymarching.cu:30-40; 16 there, tuned on the authors' GPU).  Frames
+  // depend on it only through the last bit of samples at batch boundaries (0.2 % of the pixels, max 4e-5); on MI355X 24 is the fastest (bench workload: 16: 122, 24: 129, 32: 126 frames/s)
   int n_iters_ = 24;
   bool n_iters_fixed_ = false;   // VNR_RM_N_ITERS given: no adaptation to the size of the share
   // LaunchParams::light_directional_dir (instantvnr_types.h:148): a member the reference negates IN PLACE whenever it points

@@ -17,8 +17,8 @@ except ImportError:  # the CPU suite does not need it except for tests/test_dist
 
 
 # The parity tests compare iteration counts and slot statistics with the oracle run at the REFERENCE's batch size
-# (N_ITERS = 16, method_raymarching.cu:30-40); the library's own default is 24 (frames are identical either way:
-# tests/test_gpu_render.py::test_frames_do_not_depend_on_n_iters).
+# (N_ITERS = 16, method_raymarching.cu:30-40); the library's own default is 24 (frames agree to the last bits of a few samples
+# either way: tests/test_gpu_fullsize.py).
 os.environ.setdefault("VNR_RM_N_ITERS", "16")
 
 

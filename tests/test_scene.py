@@ -143,3 +143,36 @@ def test_simple_volume_from_diva_scene_and_modes(oracle, tmp_path, monkeypatch):
         api.vnrCreateSimpleVolume(sc, "SOMETHING")
     with pytest.raises(api.VnrAmdError, match="cannot open"):
         api.vnrCreateSimpleVolume(dict(sc, volume=dict(sc["volume"], filename="/nonexistent.raw")), "GPU")
+
+
+@pytest.mark.gpu
+def test_vnr_cmd_train_command_line(tmp_path):
+    """tools/vnr_cmd_train.py takes the reference's flags (apps/batch_trainer.cpp:30-70): scene document in, Summary block and
+    ./params.json (BSON) out, which vnrCreateNeuralVolume(params) loads again"""
+    import os
+    import subprocess
+    import sys
+    from instantvnr_amd import synthetic as syn
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vol = syn.analytic_volume(48)
+    vol.astype(np.float32).tofile(tmp_path / "v.raw")
+    scene = vidi_scene([str(tmp_path / "v.raw")], (48, 48, 48), "FLOAT")
+    (tmp_path / "scene.json").write_text(json.dumps(scene))
+    model = syn.model_config(n_levels=6, n_features=4, log2_hashmap_size=14, base_resolution=4, n_hidden_layers=2)
+    (tmp_path / "model.json").write_text("// model file with a comment\n" + json.dumps(model))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "vnr_cmd_train.py"), "--volume", str(tmp_path / "scene.json"),
+                          "--network", str(tmp_path / "model.json"), "--max-num-steps", "300", "--report", str(tmp_path / "log"),
+                          "--quiet", "--train-macrocell"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    summary = dict(line.strip().split("=") for line in out.stdout.splitlines() if "=" in line)
+    assert summary["STEP"] == "300" and float(summary["PSNR"]) > 30.0 and 0.5 < float(summary["SSIM"]) <= 1.0
+    log = (tmp_path / "log.csv").read_text().splitlines()
+    assert log[0] == "step,loss" and len(log) == 31 and log[-1].startswith("300,")
+    nv = api.vnrCreateNeuralVolume(str(tmp_path / "params.json"))     # api.h:124: params.json with volume dims + model + parameters
+    assert api.vnrVolumeGetDims(nv) == (48, 48, 48) and api.neural_info(nv)["n_levels"] == 6
+    # resuming from it continues the step count? no: the reference's params.json carries no optimizer state; it must at least load
+    out2 = subprocess.run([sys.executable, os.path.join(root, "tools", "vnr_cmd_train.py"), "--volume", str(tmp_path / "scene.json"),
+                           "--network", str(tmp_path / "model.json"), "--resume", str(tmp_path / "params.json"), "--max-num-steps", "20",
+                           "--quiet"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    assert float(dict(l.strip().split("=") for l in out2.stdout.splitlines() if "=" in l)["PSNR"]) > 30.0

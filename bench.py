@@ -47,7 +47,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-psnr", action="store_true")
     p.add_argument("--no-alone", action="store_true", help="skip the un-timed one-stream leg (roofline.alone)")
-    p.add_argument("--mode", type=int, default=5, choices=(5, 8, 11),
+    p.add_argument("--mode", type=int, default=5, choices=(5, 8, 11, 14),
                    help="rendering mode: 5 = sample streaming (BASELINE metric, default), 8 = the same with gradient shading (4 evaluations per sample)")
     return p.parse_args()
 
@@ -274,7 +274,7 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"C4: {a.size}^3 synthetic Perlin fBm volume (seed 42), HashGrid L={a.levels} F={a.features} "
                                f"T=2^{a.log2_hashmap_size} base 16 per_level_scale {pls:.4f} + {a.hidden_layers}x64 FullyFusedMLP, "
-                               f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading' if a.mode == 8 else 'sample streaming, single-shade heuristic: camera pass + shadow pass'}), sampling rate 1, N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24 (32 when a rank renders at most 196608 pixels)')}",
+                               f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading' if a.mode == 8 else 'sample streaming, single-shade heuristic: camera pass + shadow pass' if a.mode == 11 else 'path tracing, sample streaming'}), sampling rate 1, N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24 (32 when a rank renders at most 196608 pixels)')}",
                    "volume": f"{a.size}^3", "framebuffer": f"{a.fb}x{a.fb}", "n_params": info["n_params"],
                    "tfn": f"256-entry ramp-with-bumps, seed 7, opacity scale {a.opacity_scale}",
                    "camera": cam, "train_steps": a.train_steps, "batch": 65536,

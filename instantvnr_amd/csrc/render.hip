@@ -85,6 +85,7 @@ struct RenderParams {
   vec4f* px_shading;
   float* px_jitter;
   vec3f shadow_dir;      // xfmVector(wto, normalize(light_directional_dir)) (:649)
+  float density_scale;   // DeviceVolume::density_scale (path tracing, rendering mode 14)
 };
 
 // streaming kernel modes (ShadingMode, method_raymarching.cu:51-56)
@@ -776,6 +777,255 @@ __global__ void monolithic_kernel(const RenderParams p)
   write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
 }
 
+// ================================================================================================ path tracing (mode 14)
+// Sample-streaming path tracer: core/renderer/method_pathtracing.cu:532-813 (DeltaTrackingIter with the macrocell majorants,
+// iterative_take_sample, iterative_shade, raygen / shade kernels, do_path_tracing_iterative); VARYING_MAJORANT = 1 there
+// (ADAPTIVE_SAMPLING is not defined in that translation unit, :24-27).  One volume sample per alive ray and iteration.
+// Structure here: one kernel per iteration does shade + the delta tracking to the next tentative collision (the reference's
+// raygen / shade kernels, fused), survivors stay in their 64-ray group's slots and pt_compact_kernel packs them in group order
+// (the order-preserving compaction of the ray marcher) and writes the queue records the evaluation kernel reads, so the ray
+// count never visits the host either.
+constexpr int kPtPlanes = 26;  // dwords of state per ray, one plane each: see PtRay::load / store
+struct PtRays { float* base; uint32_t stride; };
+
+struct PtRay {
+  float tnear, tfar;
+  uint32_t pidx; bool shadow;
+  vec3f org, dir;
+  uint32_t scatter_index;
+  vec3f sample_coord;
+  float majorant;
+  vec3f L, throughput;
+  DDAState it;
+  uint32_t rng;   // gdt::LCG state (EXTERNAL): next = 1664525 state + 1013904223, float = low 24 bits / 2^24
+  __device__ __forceinline__ float next_float()
+  {
+    rng = 1664525u * rng + 1013904223u;
+    return (float)(rng & 0x00FFFFFFu) / (float)0x01000000;
+  }
+  __device__ __forceinline__ void load(const PtRays r, uint32_t i)
+  {
+    const float* b = r.base + i;
+    const uint32_t st = r.stride;
+    const uint32_t bits = __float_as_uint(b[0]);
+    shadow = (bits & 1u) != 0u; pidx = bits >> 1;
+    org = {b[1 * st], b[2 * st], b[3 * st]};
+    dir = {b[4 * st], b[5 * st], b[6 * st]};
+    scatter_index = __float_as_uint(b[7 * st]);
+    sample_coord = {b[8 * st], b[9 * st], b[10 * st]};
+    majorant = b[11 * st];
+    L = {b[12 * st], b[13 * st], b[14 * st]};
+    throughput = {b[15 * st], b[16 * st], b[17 * st]};
+    rng = __float_as_uint(b[18 * st]);
+    it.t_next = {b[19 * st], b[20 * st], b[21 * st]};
+    it.cell = {(int)__float_as_uint(b[22 * st]), (int)__float_as_uint(b[23 * st]), (int)__float_as_uint(b[24 * st])};
+    it.next_cell_begin = b[25 * st];
+  }
+  __device__ __forceinline__ void store(const PtRays r, uint32_t i) const
+  {
+    float* b = r.base + i;
+    const uint32_t st = r.stride;
+    b[0] = __uint_as_float((pidx << 1) | (shadow ? 1u : 0u));
+    b[1 * st] = org.x; b[2 * st] = org.y; b[3 * st] = org.z;
+    b[4 * st] = dir.x; b[5 * st] = dir.y; b[6 * st] = dir.z;
+    b[7 * st] = __uint_as_float(scatter_index);
+    b[8 * st] = sample_coord.x; b[9 * st] = sample_coord.y; b[10 * st] = sample_coord.z;
+    b[11 * st] = majorant;
+    b[12 * st] = L.x; b[13 * st] = L.y; b[14 * st] = L.z;
+    b[15 * st] = throughput.x; b[16 * st] = throughput.y; b[17 * st] = throughput.z;
+    b[18 * st] = __uint_as_float(rng);
+    b[19 * st] = it.t_next.x; b[20 * st] = it.t_next.y; b[21 * st] = it.t_next.z;
+    b[22 * st] = __uint_as_float((uint32_t)it.cell.x); b[23 * st] = __uint_as_float((uint32_t)it.cell.y); b[24 * st] = __uint_as_float((uint32_t)it.cell.z);
+    b[25 * st] = it.next_cell_begin;
+  }
+};
+
+// DeltaTrackingIter::hashit (:545-573)
+__device__ __forceinline__ bool pt_hashit(const RenderParams& p, PtRay& r, float& rayt)
+{
+  const vec3f m_dir = r.dir * p.mc_rcp;
+  bool found_hit = false;
+  float tau = -logf(1.0f - r.next_float());
+  float t = r.it.next_cell_begin + r.tnear;
+  while (dda_next(r.it, m_dir, r.tnear, r.tfar, p.mc_dims, [&](vec3i c, float /*t0*/, float t1) -> bool {
+    r.majorant = opacity_upper_bound(p, c) * p.density_scale;
+    if (fabsf(r.majorant) <= FLT_EPSILON) return true;  // next macrocell; t is not advanced, as in the reference
+    tau -= (t1 - t) * (r.majorant * 1.0f);
+    t = t1;
+    if (tau > 0.0f) return true;
+    t = t + tau / (r.majorant * 1.0f);
+    found_hit = true;
+    r.it.next_cell_begin = t - r.tnear;
+    rayt = t;
+    return false;
+  })) {}
+  return found_hit;
+}
+
+// uniform_sample_sphere (raytracing.h:253-270); phi = 2 * M_PI * s.x is a double expression rounded to float
+__device__ __forceinline__ vec3f pt_uniform_sample_sphere(float sx, float sy)
+{
+  const float phi = (float)(2 * M_PI * (double)sx);
+  const float cos_theta = 1.0f - 2.0f * sy;
+  const float sin_theta = 2.0f * sqrtf(sy * (1.0f - sy));
+  float sp, cp;
+  sincosf(phi, &sp, &cp);
+  return {cp * sin_theta, sp * sin_theta, cos_theta};
+}
+
+// iterative_take_sample (:598-636)
+__device__ __forceinline__ bool pt_take_sample(const RenderParams& p, PtRay& r)
+{
+  float t;
+  if (pt_hashit(p, r, t)) { r.sample_coord = r.org + t * r.dir; return true; }
+  if (r.scatter_index > 0u) {  // no light accumulation for primary rays
+    if (r.shadow) {
+      r.L = r.L + r.throughput;   // * light_directional_rgb = 1 (instantvnr_types.h:147)
+      r.shadow = false;
+      const float s0 = r.next_float(), s1 = r.next_float();
+      r.dir = xfm_vector(p.wto, pt_uniform_sample_sphere(s0, s1));
+      if (!intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi)) return false;   // the interval is not reset first
+      dda_init(r.it, r.org * p.mc_rcp, r.dir * p.mc_rcp, r.tnear, p.mc_dims);
+      if (pt_hashit(p, r, t)) { r.sample_coord = r.org + t * r.dir; return true; }
+    } else {
+      r.L = r.L + 1.5f * r.throughput;   // light_ambient = 1.5 (instantvnr_types.h:146)
+    }
+  }
+  return false;
+}
+
+// iterative_shade (:638-677)
+__device__ __forceinline__ bool pt_shade(const RenderParams& p, const DeviceTfn& tfn, PtRay& r, float value)
+{
+  vec3f albedo; float a;
+  tfn_sample(tfn, value, albedo, a);
+  if (r.next_float() * r.majorant >= a * p.density_scale) return true;   // null collision
+  if (r.shadow) {
+    r.shadow = false;
+    const float s0 = r.next_float(), s1 = r.next_float();
+    r.dir = xfm_vector(p.wto, pt_uniform_sample_sphere(s0, s1));
+  } else {
+    if (r.scatter_index > 4u) {  // russian_roulette (:366-376), russian_roulette_length = 4
+      const float q = fminf(0.95f, max3f(r.throughput.x, r.throughput.y, r.throughput.z));
+      if (r.next_float() > q) return false;
+      r.throughput = {r.throughput.x / q, r.throughput.y / q, r.throughput.z / q};
+    }
+    ++r.scatter_index;
+    r.org = r.sample_coord;
+    r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;
+    r.throughput = r.throughput * (0.6f * albedo);   // PHASE(albedo) = albedo * 0.6f (:35)
+    r.shadow = true;
+    r.dir = p.shadow_dir;
+  }
+  if (!intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi)) return false;
+  dda_init(r.it, r.org * p.mc_rcp, r.dir * p.mc_rcp, r.tnear, p.mc_dims);
+  return true;
+}
+
+// FIRST: iterative_raygen_kernel (:679-748), thread = pixel of an 8x8 tile; else iterative_shade_kernel (:750-768), thread = alive ray
+template <bool FIRST>
+__global__ void __launch_bounds__(256) pt_kernel(const RenderParams p, const PtRays dense, const PtRays scratch, const float* __restrict__ values,
+                                                 uint32_t* __restrict__ counters, uint32_t* __restrict__ ray_counts, int parity)
+{
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t n_in = FIRST ? p.n_local : counters[C_RAYS0 + parity];
+  const uint32_t n_round = (n_in + 255u) & ~255u;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
+    const uint32_t i = base + tid;
+    PtRay r;
+    bool alive = false, finished = false;
+    if (i < n_in) {
+      if (FIRST) {
+        uint32_t pixel;
+        if (map_pixel(p, i, pixel)) {
+          r.pidx = pixel; r.shadow = false;
+          compute_ray(p, pixel, r.org, r.dir);
+          r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;
+          r.scatter_index = 0; r.sample_coord = {0, 0, 0}; r.majorant = 0.0f;
+          r.L = {0, 0, 0}; r.throughput = {1, 1, 1};
+          {  // RandomTEA(frame_index, pidx): 16 TEA rounds seed the LCG
+            uint32_t v0 = (uint32_t)p.frame_index, v1 = pixel, s0 = 0;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+              s0 += 0x9e3779b9u;
+              v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+              v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+            }
+            r.rng = v0;
+          }
+          r.it.t_next = {0, 0, 0}; r.it.cell = {0, 0, 0}; r.it.next_cell_begin = 0.0f;
+          if (intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi)) {
+            atomicAdd(counters + C_HIT, 1u);
+            dda_init(r.it, r.org * p.mc_rcp, r.dir * p.mc_rcp, r.tnear, p.mc_dims);
+            alive = pt_take_sample(p, r);
+          }
+          finished = !alive;
+        }
+      } else {
+        r.load(dense, i);
+        r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;   // load (:126-129): the interval is recomputed every iteration
+        intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi);
+        alive = pt_shade(p, p.tfn, r, values[i]) && pt_take_sample(p, r);
+        finished = !alive;
+      }
+    }
+    if (finished) write_pixel(p, {r.L.x, r.L.y, r.L.z, 1.0f}, r.pidx);
+    const unsigned long long mask = __ballot(alive);
+    const uint32_t group = i >> 6;
+    if (lane == 0) ray_counts[group] = (uint32_t)__popcll(mask);
+    if (alive) r.store(scratch, (group << 6) + (uint32_t)__popcll(mask & lt_mask));
+  }
+}
+
+// packs the survivors in group order (compact_rays_kernel's scheme) and writes one queue record per alive ray:
+// {sample_coord, index of the ray} -> the evaluation kernel puts the value where the next pt_kernel reads it
+__global__ void __launch_bounds__(1024) pt_compact_kernel(const PtRays src, const PtRays dst, const uint32_t* __restrict__ ray_counts,
+                                                          uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first,
+                                                          vec4f* __restrict__ queue)
+{
+  __shared__ uint32_t s_part[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n_in = first ? n_first : counters[C_RAYS0 + parity];
+  const uint32_t n_groups = ((n_in + 255u) & ~255u) >> 6;
+  if (n_groups == 0) {
+    if (blockIdx.x == 0 && tid == 0) counters[C_RAYS0 + (parity ^ 1)] = 0;
+    return;
+  }
+  const uint32_t g0 = blockIdx.x * 16u;
+  if (g0 >= n_groups) return;
+  uint32_t sum = 0;
+  for (uint32_t g = tid; g < g0; g += 1024u) sum += ray_counts[g];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+  if (lane == 0) s_part[wave] = sum;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) before += s_part[w];
+  const uint32_t mine = (lane < 16u && g0 + lane < n_groups) ? ray_counts[g0 + lane] : 0u;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    const uint32_t y = __shfl_up(incl, d);
+    if ((int)lane >= d) incl += y;
+  }
+  const uint32_t count = __shfl(mine, (int)wave), base = before + __shfl(incl, (int)wave) - count;
+  const uint32_t block_total = __shfl(incl, 15);
+  if (g0 + 16u >= n_groups && tid == 0) {
+    const uint32_t total = before + block_total;
+    counters[C_RAYS0 + (parity ^ 1)] = total;
+    atomicAdd((unsigned long long*)(counters + C_STAT_SAMPLES), (unsigned long long)total);
+  }
+  if (lane < count) {
+    const uint32_t from = ((g0 + wave) << 6) + lane, to = base + lane;
+#pragma unroll
+    for (int k = 0; k < kPtPlanes; ++k) dst.base[(size_t)k * dst.stride + to] = src.base[(size_t)k * src.stride + from];
+    queue[to] = {src.base[(size_t)8 * src.stride + from], src.base[(size_t)9 * src.stride + from], src.base[(size_t)10 * src.stride + from],
+                 __uint_as_float(to)};
+  }
+}
+
 // ================================================================================================ Renderer (host)
 Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volume))
 {
@@ -907,6 +1157,7 @@ void Renderer::render()
   p.slot_cap = 0;
   // single-shade heuristic (modes 10 / 11): shadow rays point towards the light, xfmVector(wto, normalize(dir)) (:649, :473)
   p.shadow_dir = xfm_vector(p.wto, normalize(light_dir_));
+  p.density_scale = density_scale_;
   p.px_org = nullptr; p.px_color = nullptr; p.px_alpha = nullptr; p.px_shading = nullptr; p.px_jitter = nullptr;
   if (mode_ == 11) {  // per-pixel hand-over between the two passes (final_highest_*, shading_color, jitter_ssh; :88-92)
     ssh_px_.ensure(12 * (size_t)n_pixels);
@@ -932,6 +1183,9 @@ void Renderer::render()
       render_streaming(p, M_SSH);
       render_streaming(p, M_SHADOW);
       break;
+    case 14:  // VNR_PATHTRACING_SAMPLE_STREAMING
+      render_pathtracing(p);
+      break;
     case 4:   // VNR_RAYMARCHING_NO_SHADING_DECODING
     case 7:   // VNR_RAYMARCHING_GRADIENT_SHADING_DECODING
     case 10:  // VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_DECODING
@@ -944,7 +1198,7 @@ void Renderer::render()
       break;
     default:
       throw std::runtime_error("rendering mode " + std::to_string(mode_) +
-                               " is not implemented in this build (supported: the ray-marching modes 4, 5, 7, 8, 10, 11)");
+                               " is not implemented in this build (supported: ray marching 4, 5, 7, 8, 10, 11 and path tracing 14)");
     }
   }
   reset_ = false;
@@ -958,6 +1212,61 @@ void Renderer::render_monolithic(const RenderParams& p)
 {
   monolithic_kernel<<<div_round_up(p.n_local, 128), 128, 0, stream_>>>(p);
   VNR_HIP_CHECK(hipGetLastError());
+}
+
+void Renderer::render_pathtracing(const RenderParams& p)
+{
+  // do_path_tracing_iterative (method_pathtracing.cu:786-806) without its per-iteration D2H + sync: the iterations the
+  // previous frame needed are enqueued at once, then the alive-ray count is looked at every few iterations
+  const uint32_t P = p.n_local;
+  NeuralVolume* nv = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get()) : nullptr;
+  if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
+  if (!nv && !p.volume) throw std::runtime_error("this volume has no resident data to sample");
+  pt_rays_.ensure((size_t)2 * kPtPlanes * P);
+  pt_values_.ensure(P);
+  if (queue_.count < P) queue_.resize(P);
+  ray_counts_.ensure(P / 64 + 64);
+  const PtRays dense = {pt_rays_.ptr, P}, scratch = {pt_rays_.ptr + (size_t)kPtPlanes * P, P};
+  uint32_t* c = counters_.ptr;
+  hipStream_t s = stream_;
+  VNR_HIP_CHECK(hipMemsetAsync(c, 0, C_COUNT * sizeof(uint32_t), s));
+  const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 4096u);
+  const uint32_t cblocks = div_round_up(P, 1024);
+  uint32_t it = 0;
+  auto launch = [&]() {
+    const int parity = (int)(it & 1u);
+    if (it == 0) {
+      pt_kernel<true><<<blocks, 256, 0, s>>>(p, dense, scratch, pt_values_.ptr, c, ray_counts_.ptr, 0);
+    } else {
+      // values of the alive rays' sample points: the count is the one the last packing step published
+      if (nv) nv->network().inference_queue((const float*)queue_.ptr, pt_values_.ptr, 1, c + C_RAYS0 + parity, P, s, 1);
+      else gt_sample_kernel<<<std::min<uint32_t>(div_round_up(P, 256), (uint32_t)Runtime::get().n_cus * 8u), 256, 0, s>>>(
+               c + C_RAYS0 + parity, p.volume, p.vol_dims, queue_.ptr, pt_values_.ptr);
+      pt_kernel<false><<<blocks, 256, 0, s>>>(p, dense, scratch, pt_values_.ptr, c, ray_counts_.ptr, parity);
+    }
+    pt_compact_kernel<<<cblocks, 1024, 0, s>>>(scratch, dense, ray_counts_.ptr, P, c, parity, it == 0 ? 1 : 0, queue_.ptr);
+    VNR_HIP_CHECK(hipGetLastError());
+    VNR_HIP_CHECK(hipMemcpyAsync(host_counts_ + (it & 255u), c + C_RAYS0 + (parity ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    ++it;
+  };
+  const uint32_t max_iterations = 1u << 16;
+  while (it < std::max<uint32_t>(predicted_pt_, 1u)) launch();
+  for (;;) {
+    VNR_HIP_CHECK(hipStreamSynchronize(s));
+    if (host_counts_[(it - 1) & 255u] == 0 || it >= max_iterations) break;
+    for (int k = 0; k < 8; ++k) launch();
+  }
+  // iterations that had rays to shade = index of the first packing step that published zero
+  uint32_t used = it;
+  if (it <= 256) { while (used > 1 && host_counts_[(used - 2) & 255u] == 0) --used; }
+  predicted_pt_ = used;
+  uint32_t hc[C_COUNT];
+  VNR_HIP_CHECK(hipMemcpy(hc, c, sizeof(hc), hipMemcpyDeviceToHost));
+  stats_.n_rays_hit += hc[C_HIT];
+  const uint64_t n = (uint64_t)hc[C_STAT_SAMPLES] | ((uint64_t)hc[C_STAT_SAMPLES + 1] << 32);
+  stats_.n_samples += n;
+  stats_.n_reference_slots += n;
+  stats_.n_iterations += used > 0 ? used - 1 : 0;
 }
 
 void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)

@@ -57,6 +57,7 @@ public:
 private:
   void render_streaming(const RenderParams& p, int pass_mode);   // one iterative_raymarching_loop<MODE> (method_raymarching.cu:931-958)
   void render_monolithic(const RenderParams& p);
+  void render_pathtracing(const RenderParams& p);   // do_path_tracing_iterative (method_pathtracing.cu:786-806)
   void ensure_queues(size_t n_pixels, int n_iters, bool gradient);
 
   std::shared_ptr<VolumeBase> volume_;
@@ -93,6 +94,8 @@ private:
   DeviceBuffer<float> q_f32_;      // jitter[2], alpha[2], color[2][3], t_next[2][3], next_cell_begin[2]
   DeviceBuffer<int> q_i32_;        // cell[2][3]
   DeviceBuffer<float> q_ssh_;      // single-shade heuristic: highest org[2][3], colour[2][3], alpha[2] per ray
+  DeviceBuffer<float> pt_rays_, pt_values_;   // path tracing: 2 x 26 planes of ray state, one value per alive ray
+  uint32_t predicted_pt_ = 0;
   DeviceBuffer<float> ssh_px_;     // ... and per pixel: org[3], colour[3], alpha, second jitter, unshaded rgba[4]
   DeviceBuffer<uint32_t> ray_counts_;  // surviving rays per 64-ray group of the last march (order-preserving compaction)
   DeviceBuffer<vec4f> queue_;      // gather-order sample records {x, y, z, ray-major slot}

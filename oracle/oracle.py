@@ -49,7 +49,7 @@ class Scene(C.Structure):
                 ("mc_dims", C.c_int * 3), ("mc_spacings", C.c_float * 3),
                 ("mc_max_opacity", C.POINTER(C.c_float)),
                 ("tfn", Tfn), ("pixel_lo", C.c_uint32), ("pixel_hi", C.c_uint32),
-                ("shading_mode", C.c_int), ("light_dir", C.c_float * 3)]
+                ("shading_mode", C.c_int), ("light_dir", C.c_float * 3), ("density_scale", C.c_float)]
 
 
 class RenderStats(C.Structure):
@@ -279,7 +279,7 @@ def default_transform(dims):
 class SceneHolder:
     def __init__(self, width, height, vol_dims, tfn, mc_max_opacity, cam_from, cam_at=(0, 0, 0), cam_up=(0, 1, 0),
                  fovy=60.0, frame_index=1, sampling_rate=1.0, bbox=((0, 0, 0), (1, 1, 1)), xfm=None,
-                 pixel_range=None, shading_mode=0, light_dir=None):
+                 pixel_range=None, shading_mode=0, light_dir=None, density_scale=1.0):
         """shading_mode: 0 NO_SHADING (rendering modes 4 / 5), 1 GRADIENT_SHADING (modes 7 / 8).
         light_dir: LaunchParams::light_directional_dir; default = the reference's (0.7, 0.9, 0.4) after the flip of
         renderer.cpp:98-101 (negated when it points along the view direction)."""
@@ -306,6 +306,7 @@ class SceneHolder:
         pr = pixel_range or (0, width * height)
         s.pixel_lo, s.pixel_hi = pr
         s.shading_mode = int(shading_mode)
+        s.density_scale = float(density_scale)
         s.light_dir[:] = [float(v) for v in (flipped_light_dir(cam_from, cam_at) if light_dir is None else light_dir)]
         self.c = s
 
@@ -348,6 +349,25 @@ def render_streaming(scene, value_fn, n_iters=16, accumulation=None):
                                 C.byref(stats))
     st = {"n_samples": stats.n_samples, "n_slots": stats.n_slots, "n_iterations": stats.n_iterations,
           "n_rays_hit": stats.n_rays_hit}
+    return frame.reshape(s.height, s.width, 4), acc, st
+
+
+def render_pathtracing(scene, value_fn, accumulation=None):
+    """rendering mode 14 (sample-streaming path tracer); value_fn(coords[n,3] float32) -> values[n] float32"""
+    s = scene.c
+    npx = s.width * s.height
+    acc = np.zeros((npx, 4), dtype=np.float32) if accumulation is None else accumulation
+    frame = np.zeros((npx, 4), dtype=np.float32)
+    stats = RenderStats()
+
+    def _cb(_user, cptr, n, vptr):
+        coords = np.ctypeslib.as_array(cptr, shape=(n, 3))
+        vals = np.ctypeslib.as_array(vptr, shape=(n,))
+        vals[:] = value_fn(coords)
+
+    cb = VALUE_FN(_cb)
+    lib().vnro_render_pathtracing(C.byref(s), cb, None, _p(acc, C.c_float), _p(frame, C.c_float), C.byref(stats))
+    st = {"n_samples": stats.n_samples, "n_slots": stats.n_slots, "n_iterations": stats.n_iterations, "n_rays_hit": stats.n_rays_hit}
     return frame.reshape(s.height, s.width, 4), acc, st
 
 

@@ -1176,6 +1176,188 @@ void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, v
 }
 
 /* ------------------------------------------------------------------------ */
+/* path tracing, sample streaming (rendering mode 14)                        */
+/* ref: core/renderer/method_pathtracing.cu:532-813; VARYING_MAJORANT = 1     */
+/* (ADAPTIVE_SAMPLING is not defined in that translation unit, :24-27)        */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  /* Ray (:70-79) */
+  float tnear, tfar;
+  uint32_t pidx;
+  v3 org, dir;
+  int shadow;
+  /* SampleStreamingPayload (:100-113) */
+  uint32_t scatter_index;
+  v3 sample_coord;
+  float majorant;
+  v3 L, throughput;
+  dda_iter iter;
+  vnro_lcg rng;
+} pt_ray;
+
+typedef struct { const vnro_scene* s; pt_ray* r; float tau, t, density_scale; int found_hit; float rayt; } pt_hit_ctx;
+
+/* the lambda of DeltaTrackingIter::hashit (:558-570) */
+static int pt_hit_cell(void* c, i3 cell, float t0, float t1)
+{
+  (void)t0;
+  pt_hit_ctx* x = (pt_hit_ctx*)c;
+  x->r->majorant = opacity_upper_bound(x->s, cell) * x->density_scale;
+  if (fabsf(x->r->majorant) <= FLT_EPSILON) return 1;  /* move to the next macrocell (t is NOT advanced, as in the reference) */
+  x->tau -= (t1 - x->t) * (x->r->majorant * 1.0f);
+  x->t = t1;
+  if (x->tau > 0.0f) return 1;
+  x->t = x->t + x->tau / (x->r->majorant * 1.0f);
+  x->found_hit = 1;
+  x->r->iter.next_cell_begin = x->t - x->r->tnear;
+  x->rayt = x->t;
+  return 0;
+}
+
+/* DeltaTrackingIter::hashit (:545-573) */
+static int pt_hashit(const vnro_scene* s, pt_ray* r, v3 rcp, i3 grid, float density_scale, float* rayt)
+{
+  pt_hit_ctx x;
+  x.s = s; x.r = r; x.density_scale = density_scale; x.found_hit = 0; x.rayt = 0.0f;
+  x.tau = -logf(1.0f - vnro_lcg_next(&r->rng));
+  x.t = r->iter.next_cell_begin + r->tnear;
+  const v3 m_dir = v3_mul(r->dir, rcp);
+  while (dda_next(&r->iter, m_dir, r->tnear, r->tfar, grid, pt_hit_cell, &x)) {}
+  *rayt = x.rayt;
+  return x.found_hit;
+}
+
+/* uniform_sample_sphere (raytracing.h:253-270): phi = 2 * M_PI * s.x is evaluated in double and rounded to float */
+static v3 pt_uniform_sample_sphere(float radius, float sx, float sy)
+{
+  const float phi = (float)(2 * M_PI * sx);
+  const float cosTheta = radius * (1.f - 2.f * sy);
+  const float sinTheta = 2.f * radius * sqrtf(sy * (1.f - sy));
+  return v3_make(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta);
+}
+
+typedef struct { const vnro_scene* s; const affine* wto; v3 lo, hi, rcp; i3 grid; float density_scale; v3 light_dir_obj; } pt_env;
+
+/* iterative_take_sample (:598-636) */
+static int pt_take_sample(const pt_env* e, pt_ray* r)
+{
+  float t;
+  if (pt_hashit(e->s, r, e->rcp, e->grid, e->density_scale, &t)) {
+    r->sample_coord = v3_add(r->org, v3_scale(t, r->dir));
+    return 1;
+  }
+  /* ray exits the volume, compute lighting */
+  if (r->scatter_index > 0) {  /* no light accumulation for primary rays */
+    if (r->shadow) {
+      r->L = v3_add(r->L, v3_scale(1.0f, r->throughput));  /* light_directional_rgb = 1 (instantvnr_types.h:147) */
+      r->shadow = 0;
+      const float s0 = vnro_lcg_next(&r->rng), s1 = vnro_lcg_next(&r->rng);
+      r->dir = xfm_vector(e->wto, pt_uniform_sample_sphere(1.f, s0, s1));
+      if (!intersect_box(&r->tnear, &r->tfar, r->org, r->dir, e->lo, e->hi)) return 0;  /* the interval is NOT reset first */
+      dda_init(&r->iter, v3_mul(r->org, e->rcp), v3_mul(r->dir, e->rcp), r->tnear, r->tfar, e->grid);
+      if (pt_hashit(e->s, r, e->rcp, e->grid, e->density_scale, &t)) {
+        r->sample_coord = v3_add(r->org, v3_scale(t, r->dir));
+        return 1;
+      }
+    } else {
+      r->L = v3_add(r->L, v3_scale(1.5f, r->throughput));  /* light_ambient = 1.5 (instantvnr_types.h:146) */
+    }
+  }
+  return 0;
+}
+
+/* iterative_shade (:638-677) */
+static int pt_shade(const pt_env* e, pt_ray* r, float sample_value)
+{
+  float rgb[3], a;
+  vnro_tfn_sample(&e->s->tfn, sample_value, rgb, &a);
+  if (vnro_lcg_next(&r->rng) * r->majorant >= a * e->density_scale) return 1;  /* null collision */
+  const v3 albedo = v3_make(rgb[0], rgb[1], rgb[2]);
+  if (r->shadow) {
+    r->shadow = 0;
+    const float s0 = vnro_lcg_next(&r->rng), s1 = vnro_lcg_next(&r->rng);
+    r->dir = xfm_vector(e->wto, pt_uniform_sample_sphere(1.f, s0, s1));
+  } else {
+    /* russian_roulette (:366-376), russian_roulette_length = 4 */
+    if (r->scatter_index > 4) {
+      const float q = fminf(0.95f, fmaxf(fmaxf(r->throughput.x, r->throughput.y), r->throughput.z));
+      if (vnro_lcg_next(&r->rng) > q) return 0;
+      r->throughput = v3_make(r->throughput.x / q, r->throughput.y / q, r->throughput.z / q);
+    }
+    ++r->scatter_index;
+    r->org = r->sample_coord;
+    r->tnear = 0.f;
+    r->tfar = FLOAT_LARGE;
+    r->throughput = v3_mul(r->throughput, v3_scale(0.6f, albedo));  /* PHASE(albedo) = albedo * 0.6f (:35) */
+    r->shadow = 1;
+    r->dir = e->light_dir_obj;
+  }
+  if (!intersect_box(&r->tnear, &r->tfar, r->org, r->dir, e->lo, e->hi)) return 0;
+  dda_init(&r->iter, v3_mul(r->org, e->rcp), v3_mul(r->dir, e->rcp), r->tnear, r->tfar, e->grid);
+  return 1;
+}
+
+/* do_path_tracing_iterative (:786-806) with iterative_raygen_kernel (:679-748) and iterative_shade_kernel (:750-768).  Every
+ * iteration reloads a ray with tnear = 0, tfar = large and re-intersects the box (load, :115-143). */
+void vnro_render_pathtracing(const vnro_scene* s, vnro_value_fn fn, void* user, float* accumulation, float* frame,
+                             vnro_render_stats* stats)
+{
+  const uint32_t n_pixels = (uint32_t)s->width * (uint32_t)s->height;
+  const camera_t cam = make_camera(s);
+  const affine otw = affine_from(s->xfm);
+  const affine wto = affine_inverse(&otw);
+  pt_env e;
+  e.s = s; e.wto = &wto;
+  e.lo = v3_make(s->bbox_lo[0], s->bbox_lo[1], s->bbox_lo[2]);
+  e.hi = v3_make(s->bbox_hi[0], s->bbox_hi[1], s->bbox_hi[2]);
+  e.rcp = v3_make(1.0f / s->mc_spacings[0], 1.0f / s->mc_spacings[1], 1.0f / s->mc_spacings[2]);
+  e.grid.x = s->mc_dims[0]; e.grid.y = s->mc_dims[1]; e.grid.z = s->mc_dims[2];
+  e.density_scale = s->density_scale == 0.0f ? 1.0f : s->density_scale;
+  e.light_dir_obj = xfm_vector(&wto, v3_normalize(v3_make(s->light_dir[0], s->light_dir[1], s->light_dir[2])));
+  vnro_render_stats st = {0, 0, 0, 0};
+  pt_ray* rays = (pt_ray*)malloc(sizeof(pt_ray) * (n_pixels ? n_pixels : 1));
+  float* coords = (float*)malloc(sizeof(float) * 3 * (n_pixels ? n_pixels : 1));
+  float* values = (float*)malloc(sizeof(float) * (n_pixels ? n_pixels : 1));
+  uint32_t n_rays = 0;
+  const uint32_t p_lo = s->pixel_lo, p_hi = s->pixel_hi < n_pixels ? s->pixel_hi : n_pixels;
+  for (uint32_t i = p_lo; i < p_hi; ++i) {
+    pt_ray r;
+    const ray_t cr = compute_ray(s, &cam, &wto, i);
+    r.tnear = 0.f; r.tfar = FLOAT_LARGE; r.pidx = i; r.org = cr.org; r.dir = cr.dir; r.shadow = 0;
+    r.scatter_index = 0; r.sample_coord = v3_make(0, 0, 0); r.majorant = 0.f;
+    r.L = v3_make(0, 0, 0); r.throughput = v3_make(1, 1, 1);
+    vnro_lcg_init(&r.rng, (uint32_t)s->frame_index, i);
+    int alive = 0;
+    if (intersect_box(&r.tnear, &r.tfar, r.org, r.dir, e.lo, e.hi)) {
+      st.n_rays_hit++;
+      dda_init(&r.iter, v3_mul(r.org, e.rcp), v3_mul(r.dir, e.rcp), r.tnear, r.tfar, e.grid);
+      alive = pt_take_sample(&e, &r);
+    }
+    if (alive) rays[n_rays++] = r;
+    else { const float rgba[4] = { r.L.x, r.L.y, r.L.z, 1.f }; write_pixel(s, accumulation, frame, rgba, i); }
+  }
+  while (n_rays > 0) {
+    st.n_iterations++;
+    st.n_samples += n_rays;
+    st.n_slots += n_rays;
+    for (uint32_t i = 0; i < n_rays; ++i) { coords[3 * i] = rays[i].sample_coord.x; coords[3 * i + 1] = rays[i].sample_coord.y; coords[3 * i + 2] = rays[i].sample_coord.z; }
+    fn(user, coords, n_rays, values);
+    uint32_t n_next = 0;
+    for (uint32_t i = 0; i < n_rays; ++i) {
+      pt_ray r = rays[i];
+      r.tnear = 0.f; r.tfar = FLOAT_LARGE;                                     /* load (:126-129) */
+      (void)intersect_box(&r.tnear, &r.tfar, r.org, r.dir, e.lo, e.hi);
+      if (pt_shade(&e, &r, values[i]) && pt_take_sample(&e, &r)) rays[n_next++] = r;
+      else { const float rgba[4] = { r.L.x, r.L.y, r.L.z, 1.f }; write_pixel(s, accumulation, frame, rgba, r.pidx); }
+    }
+    n_rays = n_next;
+  }
+  if (stats) *stats = st;
+  free(rays); free(coords); free(values);
+}
+
+/* ------------------------------------------------------------------------ */
 /* monolithic ground-truth marcher (mode 4 semantics, NO_SHADING)            */
 /* ref: core/renderer/method_raymarching.cu:263-308, 401-536                 */
 /* ------------------------------------------------------------------------ */

@@ -146,6 +146,7 @@ typedef struct {
   int   shading_mode;  /* 1 = GRADIENT_SHADING (modes 7 / 8; method_raymarching.cu:446-454, 719-726, 773-788);
                         * 2 = SINGLE_SHADE_HEURISTIC (modes 10 / 11; :455-484 monolithic, :789-833, 877-900 streaming + shadow pass) */
   float light_dir[3];  /* LaunchParams::light_directional_dir (instantvnr_types.h:148) AFTER the flip of renderer.cpp:98-101 */
+  float density_scale; /* DeviceVolume::density_scale (vnrRendererSetVolumeDensityScale); path tracing only; 0 is read as 1 */
 } vnro_scene;
 
 /* shade_scivis_light (core/renderer/raytracing.h:214-246) with mat_gradient_shading {.6, .9, .4, 40} and
@@ -166,6 +167,12 @@ typedef struct {
 /* mode 5 sample-streaming loop.  accumulation/frame: [w*h][4] */
 void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, void* user,
                            float* accumulation, float* frame, vnro_render_stats* stats);
+
+/* sample-streaming path tracer (rendering mode 14; core/renderer/method_pathtracing.cu:532-813): delta tracking with the macrocell
+ * majorants, one volume sample per alive ray and iteration through `fn`, single scattering towards the directional light plus
+ * uniform bounces, Russian roulette after 4 scatters; pixel = (L, 1) through writePixelColor.  stats->n_samples = evaluations. */
+void vnro_render_pathtracing(const vnro_scene* s, vnro_value_fn fn, void* user, float* accumulation, float* frame,
+                             vnro_render_stats* stats);
 
 /* monolithic ground-truth marcher (mode 4 semantics) on a dense fp32 volume;
  * rows [row_lo,row_hi) only, so callers can thread over scanlines */

@@ -149,8 +149,10 @@ def test_monolithic_mode4_matches_oracle(oracle, scene):
     assert psnr(img, want) > 80
 
 
-def test_unsupported_modes_fail_loudly(scene):
-    r = make_renderer(scene, scene["sv"], mode=14)
+@pytest.mark.parametrize("mode", [0, 3, 6, 9, 12, 13, 15])
+def test_unsupported_modes_fail_loudly(scene, mode):
+    """OptiX modes (0-3), in-shader modes (6, 9, 12, 15) and the monolithic path tracer (13) are not built: no silent fallback"""
+    r = make_renderer(scene, scene["sv"], mode=mode)
     with pytest.raises(api.VnrAmdError, match="not implemented"):
         api.vnrRender(r)
 
@@ -432,3 +434,54 @@ def test_single_shade_heuristic_neural_streaming_matches_oracle(oracle, scene):
         s2 = oracle.SceneHolder(64, 56, (48, 48, 48), scene["otfn"], mo, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=sm)
         w2, _, _ = oracle.render_streaming(s2, lambda c: oracle.network_inference(ocfg, 64, H, params.view(np.uint16), c))
         assert psnr(got, w2) > 40
+
+
+def test_path_tracing_streaming_matches_oracle(oracle, scene):
+    """VNR_PATHTRACING_SAMPLE_STREAMING (mode 14) on a dense volume against the oracle's restatement of
+    method_pathtracing.cu:532-813, two accumulated frames.  A path is a chain of decisions on random numbers (collision or not,
+    Russian roulette), so a last-bit difference in logf / sincosf between the device and glibc can send a pixel down another
+    path: the bar is on how many pixels agree, and the rest must still be plausible radiance."""
+    r = make_renderer(scene, scene["sv"], mode=14)
+    api.vnrRendererSetVolumeDensityScale(r, 6.0)
+    mo = api.volume_macrocell(scene["sv"])["max_opacity"]
+    f = lambda c: oracle.sample_volume(scene["vol"], c, nodal=True)
+    acc = None
+    for frame_index in (1, 2):
+        api.vnrRender(r)
+        img = api.vnrRendererMapFrame(r).copy()
+        st = api.vnrRendererGetFrameStats(r)
+        cam = scene["cam"]
+        sc = oracle.SceneHolder(96, 80, (48, 48, 48), scene["otfn"], mo, cam["from"], cam["at"], cam["up"], cam["fovy"],
+                                frame_index=frame_index, density_scale=6.0)
+        want, acc, ost = oracle.render_pathtracing(sc, f, accumulation=acc)
+        assert st["n_rays_hit"] == ost["n_rays_hit"] > 1000
+        assert np.array_equal(img[..., 3], want[..., 3]) and (want[..., 3] == 1.0).all()
+        assert want[..., :3].max() > 0.5 and (want[..., :3].sum(axis=2) > 0).mean() > 0.03      # light does arrive
+        same = np.abs(img - want).max(axis=2) < 1e-5
+        assert same.mean() > 0.995, same.mean()
+        assert abs(float(img[..., :3].mean()) - float(want[..., :3].mean())) < 2e-3
+        assert abs(st["n_samples"] - ost["n_samples"]) < 0.01 * ost["n_samples"]
+        assert abs(st["n_iterations"] - ost["n_iterations"]) <= max(4, 0.2 * ost["n_iterations"])
+
+
+def test_path_tracing_on_a_neural_volume_runs_and_converges(oracle, scene):
+    """mode 14 with the network as the sampler: many frames accumulate towards the oracle's many-frame mean"""
+    L, F, log2T, base, pls, H = 8, 4, 15, 8, 1.5, 2
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base, n_hidden_layers=H, per_level_scale=pls)
+    nv = api.vnrCreateNeuralVolume(cfg, scene["sv"], online_macrocell_construction=False)
+    api.vnrNeuralVolumeTrain(nv, 300, True)
+    r = make_renderer(scene, nv, size=(48, 40), mode=14)
+    frames = 24
+    for _ in range(frames):
+        api.vnrRender(r)
+        img = api.vnrRendererMapFrame(r).copy()
+    mo = api.volume_macrocell(scene["sv"])["max_opacity"]
+    cam = scene["cam"]
+    acc = None
+    for k in range(frames):
+        sc = oracle.SceneHolder(48, 40, (48, 48, 48), scene["otfn"], mo, cam["from"], cam["at"], cam["up"], cam["fovy"], frame_index=k + 1)
+        want, acc, _ = oracle.render_pathtracing(sc, lambda c: oracle.sample_volume(scene["vol"], c, nodal=True), accumulation=acc)
+    # the network approximates the volume (PSNR > 30 dB after 300 steps) and individual paths differ, so compare the images coarsely
+    assert (img[..., 3] == 1.0).all()
+    assert abs(float(img[..., :3].mean()) - float(want[..., :3].mean())) < 0.15 * float(want[..., :3].mean())
+    assert np.corrcoef(img[..., :3].reshape(-1), want[..., :3].reshape(-1))[0, 1] > 0.8

@@ -248,3 +248,36 @@ def test_single_shade_heuristic_properties(oracle, small_scene):
     mo0 = oracle.macrocell_max_opacity(clear, oracle.macrocell_compute_implicit(vol))
     sc_clear = oracle.SceneHolder(48, 40, (32, 32, 32), clear, mo0, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=2)
     assert not oracle.render_streaming(sc_clear, f)[0].any() and not oracle.render_monolithic(sc_clear, vol)[0].any()
+
+
+def test_path_tracing_properties(oracle, small_scene):
+    """the oracle's path tracer (method_pathtracing.cu:532-813) has no reference fixture either; by its definition: alpha is 1
+    everywhere, radiance is non-negative and bounded by ambient light x the largest possible throughput, a frame is a function of
+    (frame index, pixel) only, primary rays that leave without scattering stay black, a transparent volume stays black, and the
+    mean over many frames settles (it is a Monte-Carlo estimate: two disjoint sets of frames agree within their noise)"""
+    vol, sc0 = small_scene
+    f = lambda c: oracle.sample_volume(vol, c, nodal=True)
+    cam = syn.oblique_camera((32, 32, 32))
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = oracle.TfnHolder(colors, alphas)
+    mo = oracle.macrocell_max_opacity(tfn, oracle.macrocell_compute_implicit(vol))
+    mk = lambda k, ds=4.0, t=tfn, m=mo: oracle.SceneHolder(48, 40, (32, 32, 32), t, m, cam["from"], cam["at"], cam["up"], cam["fovy"],
+                                                           frame_index=k, density_scale=ds)
+    a, _, st = oracle.render_pathtracing(mk(1), f)
+    b, _, _ = oracle.render_pathtracing(mk(1), f)
+    c, _, _ = oracle.render_pathtracing(mk(2), f)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert (a[..., 3] == 1.0).all() and (a[..., :3] >= 0).all()
+    assert a[..., :3].max() <= 1.5 * 1.0 / 0.95 ** 8 + 1e-6          # ambient 1.5 x throughput (<= 1 before roulette, / q after)
+    assert st["n_rays_hit"] > 0 and st["n_samples"] > st["n_rays_hit"] and st["n_iterations"] > 4
+    clear = oracle.TfnHolder(colors, np.zeros_like(np.asarray(alphas, np.float32)))
+    mo0 = oracle.macrocell_max_opacity(clear, oracle.macrocell_compute_implicit(vol))
+    z, _, zst = oracle.render_pathtracing(mk(1, 4.0, clear, mo0), f)
+    assert not z[..., :3].any() and (z[..., 3] == 1.0).all() and zst["n_samples"] == 0
+    means = []
+    for lo in (1, 41):
+        acc = None
+        for k in range(lo, lo + 40):
+            _, acc, _ = oracle.render_pathtracing(mk(k), f, accumulation=acc)
+        means.append(float(acc.reshape(-1, 4)[:, :3].mean()) / 40.0)   # the accumulation buffer holds the sum of the frames
+    assert means[0] > 0.01 and abs(means[0] - means[1]) < 0.1 * means[0]

@@ -978,6 +978,72 @@ __global__ void __launch_bounds__(256) pt_kernel(const RenderParams p, const PtR
   }
 }
 
+// path tracer on a dense volume in one loop per pixel (rendering mode 13, "Decoding - Debug"): path_tracing_kernel /
+// path_tracing_traceray / delta_tracking with USE_DELTA_TRACKING_ITER (method_pathtracing.cu:258-292, 420-510).  Unlike the
+// streaming variant the interval is reset before a bounce (:438-439).
+__global__ void pt_monolithic_kernel(const RenderParams p)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n_local) return;
+  uint32_t pixel;
+  if (!map_pixel(p, i, pixel)) return;
+  PtRay r;
+  r.pidx = pixel; r.shadow = false;
+  compute_ray(p, pixel, r.org, r.dir);
+  r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;
+  r.scatter_index = 0; r.majorant = 0.0f; r.sample_coord = {0, 0, 0};
+  r.L = {0, 0, 0}; r.throughput = {1, 1, 1};
+  {
+    uint32_t v0 = (uint32_t)p.frame_index, v1 = pixel, s0 = 0;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      s0 += 0x9e3779b9u;
+      v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+      v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    r.rng = v0;
+  }
+  while (intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi)) {
+    // delta_tracking: tentative collisions from hashit until a real one
+    float t = r.tnear;
+    vec3f albedo = {0, 0, 0};
+    bool found = false;
+    dda_init(r.it, r.org * p.mc_rcp, r.dir * p.mc_rcp, r.tnear, p.mc_dims);
+    while (pt_hashit(p, r, t)) {
+      const vec3f c = r.org + t * r.dir;
+      const float v = sample_volume_nodal(p.volume, p.vol_dims, c.x, c.y, c.z);
+      vec3f rgb; float a;
+      tfn_sample(p.tfn, v, rgb, a);
+      if (r.next_float() * r.majorant < a * p.density_scale) { albedo = rgb; found = true; break; }
+    }
+    const bool exited = !found;
+    if (r.shadow) {
+      if (exited) r.L = r.L + r.throughput;
+      r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;
+      const float s0 = r.next_float(), s1 = r.next_float();
+      r.dir = xfm_vector(p.wto, pt_uniform_sample_sphere(s0, s1));
+      r.shadow = false;
+    } else {
+      if (exited) {
+        if (r.scatter_index > 0u) r.L = r.L + 1.5f * r.throughput;
+        break;
+      }
+      if (r.scatter_index > 4u) {
+        const float q = fminf(0.95f, max3f(r.throughput.x, r.throughput.y, r.throughput.z));
+        if (r.next_float() > q) break;
+        r.throughput = {r.throughput.x / q, r.throughput.y / q, r.throughput.z / q};
+      }
+      ++r.scatter_index;
+      r.org = r.org + t * r.dir;
+      r.throughput = r.throughput * (0.6f * albedo);
+      r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;
+      r.dir = p.shadow_dir;
+      r.shadow = true;
+    }
+  }
+  write_pixel(p, {r.L.x, r.L.y, r.L.z, 1.0f}, pixel);
+}
+
 // packs the survivors in group order (compact_rays_kernel's scheme) and writes one queue record per alive ray:
 // {sample_coord, index of the ray} -> the evaluation kernel puts the value where the next pt_kernel reads it
 __global__ void __launch_bounds__(1024) pt_compact_kernel(const PtRays src, const PtRays dst, const uint32_t* __restrict__ ray_counts,
@@ -1186,6 +1252,13 @@ void Renderer::render()
     case 14:  // VNR_PATHTRACING_SAMPLE_STREAMING
       render_pathtracing(p);
       break;
+    case 13:  // VNR_PATHTRACING_DECODING: the same estimator in one loop per pixel, on dense (or decoded) data
+      if (!p.volume)
+        throw std::runtime_error(volume_->is_network() ? "rendering mode 13 traces the decoded volume: call vnrNeuralVolumeDecodeProgressive first (GetNumberOfBlobs calls = one full pass)"
+                                                       : "this volume has no resident data to sample");
+      pt_monolithic_kernel<<<div_round_up(p.n_local, 128), 128, 0, stream_>>>(p);
+      VNR_HIP_CHECK(hipGetLastError());
+      break;
     case 4:   // VNR_RAYMARCHING_NO_SHADING_DECODING
     case 7:   // VNR_RAYMARCHING_GRADIENT_SHADING_DECODING
     case 10:  // VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_DECODING
@@ -1198,7 +1271,7 @@ void Renderer::render()
       break;
     default:
       throw std::runtime_error("rendering mode " + std::to_string(mode_) +
-                               " is not implemented in this build (supported: ray marching 4, 5, 7, 8, 10, 11 and path tracing 14)");
+                               " is not implemented in this build (supported: ray marching 4, 5, 7, 8, 10, 11 and path tracing 13, 14)");
     }
   }
   reset_ = false;

@@ -371,6 +371,18 @@ def render_pathtracing(scene, value_fn, accumulation=None):
     return frame.reshape(s.height, s.width, 4), acc, st
 
 
+def render_pathtracing_monolithic(scene, vol, accumulation=None):
+    """rendering mode 13: the path tracer in one loop per pixel on a dense volume"""
+    s = scene.c
+    vol = _f32(vol)
+    npx = s.width * s.height
+    acc = np.zeros((npx, 4), dtype=np.float32) if accumulation is None else accumulation
+    frame = np.zeros((npx, 4), dtype=np.float32)
+    lib().vnro_render_pathtracing_monolithic(C.byref(s), _p(vol, C.c_float), C.c_int(0), C.c_int(s.height), _p(acc, C.c_float),
+                                             _p(frame, C.c_float))
+    return frame.reshape(s.height, s.width, 4), acc
+
+
 def render_monolithic(scene, vol, accumulation=None, n_threads=1, rows=None):
     s = scene.c
     vol = _f32(vol)

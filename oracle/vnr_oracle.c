@@ -1357,6 +1357,84 @@ void vnro_render_pathtracing(const vnro_scene* s, vnro_value_fn fn, void* user, 
   free(rays); free(coords); free(values);
 }
 
+/* delta_tracking with USE_DELTA_TRACKING_ITER (method_pathtracing.cu:258-292): tentative collisions from hashit until a real one */
+static int pt_delta_tracking(const pt_env* e, const float* vol, pt_ray* r, float* t_out, v3* albedo)
+{
+  float t = r->tnear;
+  int found = 0;
+  *albedo = v3_make(0, 0, 0);
+  dda_init(&r->iter, v3_mul(r->org, e->rcp), v3_mul(r->dir, e->rcp), r->tnear, r->tfar, e->grid);
+  while (pt_hashit(e->s, r, e->rcp, e->grid, e->density_scale, &t)) {
+    const v3 c = v3_add(r->org, v3_scale(t, r->dir));
+    const float sample = vnro_sample_volume(vol, e->s->vol_dims, c.x, c.y, c.z);
+    float rgb[3], a;
+    vnro_tfn_sample(&e->s->tfn, sample, rgb, &a);
+    if (vnro_lcg_next(&r->rng) * r->majorant < a * e->density_scale) {
+      *albedo = v3_make(rgb[0], rgb[1], rgb[2]);
+      found = 1;
+      break;
+    }
+  }
+  *t_out = t;
+  return found;
+}
+
+/* path tracer on a dense volume in one loop per pixel (rendering mode 13): path_tracing_kernel / path_tracing_traceray
+ * (method_pathtracing.cu:420-510).  Unlike the streaming variant the interval IS reset before a bounce (:438-439). */
+void vnro_render_pathtracing_monolithic(const vnro_scene* s, const float* vol, int row_lo, int row_hi, float* accumulation, float* frame)
+{
+  const camera_t cam = make_camera(s);
+  const affine otw = affine_from(s->xfm);
+  const affine wto = affine_inverse(&otw);
+  pt_env e;
+  e.s = s; e.wto = &wto;
+  e.lo = v3_make(s->bbox_lo[0], s->bbox_lo[1], s->bbox_lo[2]);
+  e.hi = v3_make(s->bbox_hi[0], s->bbox_hi[1], s->bbox_hi[2]);
+  e.rcp = v3_make(1.0f / s->mc_spacings[0], 1.0f / s->mc_spacings[1], 1.0f / s->mc_spacings[2]);
+  e.grid.x = s->mc_dims[0]; e.grid.y = s->mc_dims[1]; e.grid.z = s->mc_dims[2];
+  e.density_scale = s->density_scale == 0.0f ? 1.0f : s->density_scale;
+  e.light_dir_obj = xfm_vector(&wto, v3_normalize(v3_make(s->light_dir[0], s->light_dir[1], s->light_dir[2])));
+  for (int iy = row_lo; iy < row_hi; ++iy)
+    for (int ix = 0; ix < s->width; ++ix) {
+      const uint32_t pixel = (uint32_t)ix + (uint32_t)iy * (uint32_t)s->width;
+      pt_ray r;
+      const ray_t cr = compute_ray(s, &cam, &wto, pixel);
+      r.tnear = 0.f; r.tfar = FLOAT_LARGE; r.pidx = pixel; r.org = cr.org; r.dir = cr.dir; r.shadow = 0;
+      r.scatter_index = 0; r.majorant = 0.f; r.sample_coord = v3_make(0, 0, 0);
+      r.L = v3_make(0, 0, 0); r.throughput = v3_make(1, 1, 1);
+      vnro_lcg_init(&r.rng, (uint32_t)s->frame_index, pixel);
+      while (intersect_box(&r.tnear, &r.tfar, r.org, r.dir, e.lo, e.hi)) {
+        float t; v3 albedo;
+        const int exited = !pt_delta_tracking(&e, vol, &r, &t, &albedo);
+        if (r.shadow) {
+          if (exited) r.L = v3_add(r.L, v3_scale(1.0f, r.throughput));   /* light_directional_rgb */
+          r.tnear = 0.f; r.tfar = FLOAT_LARGE;
+          const float s0 = vnro_lcg_next(&r.rng), s1 = vnro_lcg_next(&r.rng);
+          r.dir = xfm_vector(&wto, pt_uniform_sample_sphere(1.f, s0, s1));
+          r.shadow = 0;
+        } else {
+          if (exited) {
+            if (r.scatter_index > 0) r.L = v3_add(r.L, v3_scale(1.5f, r.throughput));   /* light_ambient */
+            break;
+          }
+          if (r.scatter_index > 4) {  /* russian_roulette */
+            const float q = fminf(0.95f, fmaxf(fmaxf(r.throughput.x, r.throughput.y), r.throughput.z));
+            if (vnro_lcg_next(&r.rng) > q) break;
+            r.throughput = v3_make(r.throughput.x / q, r.throughput.y / q, r.throughput.z / q);
+          }
+          ++r.scatter_index;
+          r.org = v3_add(r.org, v3_scale(t, r.dir));
+          r.throughput = v3_mul(r.throughput, v3_scale(0.6f, albedo));
+          r.tnear = 0.f; r.tfar = FLOAT_LARGE;
+          r.dir = e.light_dir_obj;
+          r.shadow = 1;
+        }
+      }
+      const float rgba[4] = { r.L.x, r.L.y, r.L.z, 1.f };
+      write_pixel(s, accumulation, frame, rgba, pixel);
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* monolithic ground-truth marcher (mode 4 semantics, NO_SHADING)            */
 /* ref: core/renderer/method_raymarching.cu:263-308, 401-536                 */

@@ -174,6 +174,9 @@ void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, v
 void vnro_render_pathtracing(const vnro_scene* s, vnro_value_fn fn, void* user, float* accumulation, float* frame,
                              vnro_render_stats* stats);
 
+/* the same estimator in one loop per pixel on a dense volume (rendering mode 13; method_pathtracing.cu:258-292, 420-510) */
+void vnro_render_pathtracing_monolithic(const vnro_scene* s, const float* vol, int row_lo, int row_hi, float* accumulation, float* frame);
+
 /* monolithic ground-truth marcher (mode 4 semantics) on a dense fp32 volume;
  * rows [row_lo,row_hi) only, so callers can thread over scanlines */
 void vnro_render_monolithic(const vnro_scene* s, const float* vol, int row_lo, int row_hi,

@@ -149,9 +149,9 @@ def test_monolithic_mode4_matches_oracle(oracle, scene):
     assert psnr(img, want) > 80
 
 
-@pytest.mark.parametrize("mode", [0, 3, 6, 9, 12, 13, 15])
+@pytest.mark.parametrize("mode", [0, 3, 6, 9, 12, 15])
 def test_unsupported_modes_fail_loudly(scene, mode):
-    """OptiX modes (0-3), in-shader modes (6, 9, 12, 15) and the monolithic path tracer (13) are not built: no silent fallback"""
+    """OptiX modes (0-3) and in-shader modes (6, 9, 12, 15) are not built: no silent fallback"""
     r = make_renderer(scene, scene["sv"], mode=mode)
     with pytest.raises(api.VnrAmdError, match="not implemented"):
         api.vnrRender(r)
@@ -485,3 +485,25 @@ def test_path_tracing_on_a_neural_volume_runs_and_converges(oracle, scene):
     assert (img[..., 3] == 1.0).all()
     assert abs(float(img[..., :3].mean()) - float(want[..., :3].mean())) < 0.15 * float(want[..., :3].mean())
     assert np.corrcoef(img[..., :3].reshape(-1), want[..., :3].reshape(-1))[0, 1] > 0.8
+
+
+def test_path_tracing_decoding_mode_matches_oracle(oracle, scene):
+    """VNR_PATHTRACING_DECODING (mode 13): the path tracer in one loop per pixel on dense data (method_pathtracing.cu:258-292,
+    420-510); same kind of bar as mode 14.  The two estimators are not the same random walk (the interval is reset before a
+    bounce here), but they estimate the same image."""
+    r = make_renderer(scene, scene["sv"], mode=13)
+    api.vnrRendererSetVolumeDensityScale(r, 6.0)
+    mo = api.volume_macrocell(scene["sv"])["max_opacity"]
+    cam = scene["cam"]
+    acc = None
+    for frame_index in (1, 2):
+        api.vnrRender(r)
+        img = api.vnrRendererMapFrame(r).copy()
+        sc = oracle.SceneHolder(96, 80, (48, 48, 48), scene["otfn"], mo, cam["from"], cam["at"], cam["up"], cam["fovy"],
+                                frame_index=frame_index, density_scale=6.0)
+        want, acc = oracle.render_pathtracing_monolithic(sc, scene["vol"], accumulation=acc)
+        assert np.array_equal(img[..., 3], want[..., 3]) and (want[..., 3] == 1.0).all()
+        assert (want[..., :3].sum(axis=2) > 0).mean() > 0.03
+        same = np.abs(img - want).max(axis=2) < 1e-5
+        assert same.mean() > 0.995, same.mean()
+        assert abs(float(img[..., :3].mean()) - float(want[..., :3].mean())) < 2e-3

@@ -149,9 +149,9 @@ def test_monolithic_mode4_matches_oracle(oracle, scene):
     assert psnr(img, want) > 80
 
 
-@pytest.mark.parametrize("mode", [0, 3, 6, 9, 12, 15])
+@pytest.mark.parametrize("mode", [0, 3, 9, 12, 15])
 def test_unsupported_modes_fail_loudly(scene, mode):
-    """OptiX modes (0-3) and in-shader modes (6, 9, 12, 15) are not built: no silent fallback"""
+    """OptiX modes (0-3) and the shaded / path-traced in-shader modes (9, 12, 15) are not built: no silent fallback"""
     r = make_renderer(scene, scene["sv"], mode=mode)
     with pytest.raises(api.VnrAmdError, match="not implemented"):
         api.vnrRender(r)
@@ -507,3 +507,16 @@ def test_path_tracing_decoding_mode_matches_oracle(oracle, scene):
         same = np.abs(img - want).max(axis=2) < 1e-5
         assert same.mean() > 0.995, same.mean()
         assert abs(float(img[..., :3].mean()) - float(want[..., :3].mean())) < 2e-3
+
+
+def test_in_shader_mode_6_is_the_uninterrupted_march(oracle, scene):
+    """VNR_RAYMARCHING_NO_SHADING_IN_SHADER (mode 6) marches a ray in one loop (network_raymarching_iterator,
+    method_raymarching.cu:310-356); its arithmetic is the streaming loop's without interruptions, which the oracle reproduces with a
+    batch size no ray reaches.  The library runs it on the streaming path: same frame within the resume rounding."""
+    r = make_renderer(scene, scene["sv"], mode=6)
+    api.vnrRender(r)
+    img = api.vnrRendererMapFrame(r).copy()
+    mo = api.volume_macrocell(scene["sv"])["max_opacity"]
+    want, _, ost = oracle.render_streaming(oracle_scene(oracle, scene, mo), lambda c: oracle.sample_volume(scene["vol"], c, nodal=True), n_iters=512)
+    assert ost["n_iterations"] == 1      # nothing was interrupted in the oracle run
+    assert np.abs(img - want).max() < 2e-4 and psnr(img, want) > 80

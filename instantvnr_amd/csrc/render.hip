@@ -86,6 +86,8 @@ struct RenderParams {
   float* px_jitter;
   vec3f shadow_dir;      // xfmVector(wto, normalize(light_directional_dir)) (:649)
   float density_scale;   // DeviceVolume::density_scale (path tracing, rendering mode 14)
+  uint32_t ssh_third_draw;   // rendering mode 12: the shadow ray's jitter is the pixel's third random number
+  uint32_t grad_flip;        // rendering mode 9: forward differences flip at the volume's far faces (sampleGradient)
 };
 
 // streaming kernel modes (ShadingMode, method_raymarching.cu:51-56)
@@ -159,7 +161,7 @@ __device__ __forceinline__ float tea_lcg_first(uint32_t v0, uint32_t v1)
 }
 
 // both draws of rng.get_floats() (EXTERNAL OVR addition to gdt::LCG: two successive floats)
-__device__ __forceinline__ void tea_lcg_two(uint32_t v0, uint32_t v1, float& a, float& b)
+__device__ __forceinline__ uint32_t tea_lcg_two(uint32_t v0, uint32_t v1, float& a, float& b)
 {
   uint32_t s0 = 0;
 #pragma unroll
@@ -172,6 +174,7 @@ __device__ __forceinline__ void tea_lcg_two(uint32_t v0, uint32_t v1, float& a, 
   a = (float)(state & 0x00FFFFFFu) / (float)0x01000000;
   state = 1664525u * state + 1013904223u;
   b = (float)(state & 0x00FFFFFFu) / (float)0x01000000;
+  return state;
 }
 
 // raytracing.h:188-194 / :166-170 / :196-207
@@ -431,8 +434,9 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
           } else {
             if (MODE == M_SSH) {
               float j2;
-              tea_lcg_two((uint32_t)p.frame_index, pixel, jitter, j2);
-              p.px_jitter[pixel] = j2;   // jitters.y (:866-868)
+              const uint32_t state2 = tea_lcg_two((uint32_t)p.frame_index, pixel, jitter, j2);
+              // streaming: jitters.y (:866-868); in shader (mode 12): the next get_floats().x, i.e. the third draw
+              p.px_jitter[pixel] = p.ssh_third_draw ? (float)((1664525u * state2 + 1013904223u) & 0x00FFFFFFu) / (float)0x01000000 : j2;
             } else {
               jitter = tea_lcg_first((uint32_t)p.frame_index, pixel);
             }
@@ -465,9 +469,16 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
           if (p.debug_flags & 2u) { rgb = {0.5f, 0.5f, 0.5f}; a = vd.x * 0.01f; } else
           tfn_sample(tfn, vd.x, rgb, a);
           a = opacity_correction(p.step_rcp, vd.y, a);
-          if (GRAD) {  // f(c + gx), f(c + gy), f(c + gz) of this sample, written by the evaluation kernel
+          if (GRAD) {  // f(c + gx), f(c + gy), f(c + gz) of this sample, written by the evaluation kernel; .w: the sample's t
             const vec4f fg = *(const vec4f*)((const float*)vd_in + arena_grad_index(p.slot_cap, sb + k));
-            rgb = gradient_shade(p, dir, vd.x, fg.x, fg.y, fg.z, p.grad_step, rgb);
+            vec3f stp = p.grad_step;
+            if (p.grad_flip) {  // in shader (mode 9): repeat sampleGradient's flip of a step that would leave [0,1] (raytracing.h:128-143)
+              const vec3f c = org + fg.w * dir;
+              if (c.x + stp.x > 1.0f - FLT_EPSILON) stp.x *= -1.0f;
+              if (c.y + stp.y > 1.0f - FLT_EPSILON) stp.y *= -1.0f;
+              if (c.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
+            }
+            rgb = gradient_shade(p, dir, vd.x, fg.x, fg.y, fg.z, stp, rgb);
           }
           if (MODE == M_SSH && h_alpha < (1.0f - alpha) * a) {  // :789-795; the sample's t is kept where GRAD keeps f(c + gx)
             const float t = ((const float*)vd_in)[arena_grad_index(p.slot_cap, sb + k)];
@@ -579,10 +590,17 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         if (GRAD) {
           const uint32_t gi = arena_grad_index(p.slot_cap, sb + j);
           vec4f* q = queue + 4u * (size_t)g;  // the four records of a sample stay adjacent: they fall into the same grid cells
+          vec3f stp = p.grad_step;
+          if (p.grad_flip) {
+            if (c.x + stp.x > 1.0f - FLT_EPSILON) stp.x *= -1.0f;
+            if (c.y + stp.y > 1.0f - FLT_EPSILON) stp.y *= -1.0f;
+            if (c.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
+            ((float*)vd_out)[gi + 3u] = t;
+          }
           q[0] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + j))};
-          q[1] = {c.x + p.grad_step.x, c.y, c.z, __uint_as_float(gi + 0u)};
-          q[2] = {c.x, c.y + p.grad_step.y, c.z, __uint_as_float(gi + 1u)};
-          q[3] = {c.x, c.y, c.z + p.grad_step.z, __uint_as_float(gi + 2u)};
+          q[1] = {c.x + stp.x, c.y, c.z, __uint_as_float(gi + 0u)};
+          q[2] = {c.x, c.y + stp.y, c.z, __uint_as_float(gi + 1u)};
+          q[3] = {c.x, c.y, c.z + stp.z, __uint_as_float(gi + 2u)};
         } else {
           queue[g] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + j))};
         }
@@ -1219,13 +1237,15 @@ void Renderer::render()
   p.grad_step = {1.0f / (float)p.vol_dims.x, 1.0f / (float)p.vol_dims.y, 1.0f / (float)p.vol_dims.z};  // object.cpp:305
   if (dot(p.cam_dir, light_dir_) > 0.0f) light_dir_ = -1.0f * light_dir_;  // renderer.cpp:98-101: flipped in place, every frame
   p.light_dir = light_dir_;
-  p.shading_mode = (mode_ == 7 || mode_ == 8) ? 1u : (mode_ == 10 || mode_ == 11) ? 2u : 0u;
+  p.shading_mode = (mode_ == 7 || mode_ == 8 || mode_ == 9) ? 1u : (mode_ == 10 || mode_ == 11 || mode_ == 12) ? 2u : 0u;
+  p.grad_flip = mode_ == 9 ? 1u : 0u;
+  p.ssh_third_draw = mode_ == 12 ? 1u : 0u;
   p.slot_cap = 0;
   // single-shade heuristic (modes 10 / 11): shadow rays point towards the light, xfmVector(wto, normalize(dir)) (:649, :473)
   p.shadow_dir = xfm_vector(p.wto, normalize(light_dir_));
   p.density_scale = density_scale_;
   p.px_org = nullptr; p.px_color = nullptr; p.px_alpha = nullptr; p.px_shading = nullptr; p.px_jitter = nullptr;
-  if (mode_ == 11) {  // per-pixel hand-over between the two passes (final_highest_*, shading_color, jitter_ssh; :88-92)
+  if (mode_ == 11 || mode_ == 12) {  // per-pixel hand-over between the two passes (final_highest_*, shading_color, jitter_ssh; :88-92)
     ssh_px_.ensure(12 * (size_t)n_pixels);
     float* b = ssh_px_.ptr;
     p.px_org = (vec3f*)b; p.px_color = (vec3f*)(b + 3 * (size_t)n_pixels); p.px_alpha = b + 6 * (size_t)n_pixels;
@@ -1246,6 +1266,7 @@ void Renderer::render()
               // mode 5's without the interruptions, i.e. mode 5's up to the last bit of the samples at batch boundaries (a ray
               // resumes at t_min + (t - t_min)): measured 4e-5 at most on 0.2 % of the pixels, two orders below what the network's
               // own arithmetic differs by.  "In shader" is an execution strategy; here it is the streaming one.
+    case 9:   // VNR_RAYMARCHING_GRADIENT_SHADING_IN_SHADER (:1068-1070): mode 8 with sampleGradient's boundary flip, uninterrupted
     case 5:   // VNR_RAYMARCHING_NO_SHADING_SAMPLE_STREAMING
     case 8:   // VNR_RAYMARCHING_GRADIENT_SHADING_SAMPLE_STREAMING
       render_streaming(p, p.shading_mode == 1u ? M_GRADIENT : M_NONE);
@@ -1264,6 +1285,15 @@ void Renderer::render()
       pt_monolithic_kernel<<<div_round_up(p.n_local, 128), 128, 0, stream_>>>(p);
       VNR_HIP_CHECK(hipGetLastError());
       break;
+    case 12: {  // VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_IN_SHADER (network_raymarching_traceray / _transmittance, :981-1035,
+                // 1037-1128): the uninterrupted camera march of mode 11, then a shadow ray at raymarching_shadow_sampling_scale = 2 x
+                // the step (opacity correction keeps the step), jittered by the pixel's third random number
+      render_streaming(p, M_SSH);
+      RenderParams q = p;
+      q.step = 2.0f * p.step;
+      render_streaming(q, M_SHADOW);
+      break;
+    }
     case 4:   // VNR_RAYMARCHING_NO_SHADING_DECODING
     case 7:   // VNR_RAYMARCHING_GRADIENT_SHADING_DECODING
     case 10:  // VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_DECODING
@@ -1276,7 +1306,7 @@ void Renderer::render()
       break;
     default:
       throw std::runtime_error("rendering mode " + std::to_string(mode_) +
-                               " is not implemented in this build (supported: ray marching 4, 5, 6, 7, 8, 10, 11 and path tracing 13, 14)");
+                               " is not implemented in this build (supported: ray marching 4 - 12 and path tracing 13, 14)");
     }
   }
   reset_ = false;

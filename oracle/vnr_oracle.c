@@ -947,9 +947,15 @@ static int intersect_body(void* c, float t0, float t1)
     float* gx = x->coords + 3 * (1 * block + slot);
     float* gy = x->coords + 3 * (2 * block + slot);
     float* gz = x->coords + 3 * (3 * block + slot);
-    gx[0] = p.x + x->gs.x; gx[1] = p.y; gx[2] = p.z;
-    gy[0] = p.x; gy[1] = p.y + x->gs.y; gy[2] = p.z;
-    gz[0] = p.x; gz[1] = p.y; gz[2] = p.z + x->gs.z;
+    v3 stp = x->gs;
+    if (x->gradient == 2) {  /* in shader (mode 9): sampleGradient flips a step that would leave [0,1] (raytracing.h:128-143) */
+      if (p.x + stp.x > 1.0f - FLT_EPSILON) stp.x *= -1.0f;
+      if (p.y + stp.y > 1.0f - FLT_EPSILON) stp.y *= -1.0f;
+      if (p.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
+    }
+    gx[0] = p.x + stp.x; gx[1] = p.y; gx[2] = p.z;
+    gy[0] = p.x; gy[1] = p.y + stp.y; gy[2] = p.z;
+    gz[0] = p.x; gz[1] = p.y; gz[2] = p.z + stp.z;
   }
   return (++x->k) < x->n_iters;
 }
@@ -958,6 +964,7 @@ typedef struct {
   const vnro_scene* s; const float* samples; uint32_t n_rays, i; int k, n_iters;
   float alpha; v3 color; float step_rcp;
   int gradient; v3 gs; const affine* otw; const affine* wto; v3 ray_dir;
+  v3 ray_org; float jitter;   /* gradient == 2 recomputes the sample position to repeat sampleGradient's flip */
 } compose_ctx;
 static int compose_body(void* c, float t0, float t1)
 {
@@ -969,8 +976,16 @@ static int compose_body(void* c, float t0, float t1)
   a = opacity_correction(x->step_rcp, t1 - t0, a);
   if (x->gradient) {  /* :773-788 */
     const size_t block = (size_t)x->n_rays * x->n_iters;
+    v3 stp = x->gs;
+    if (x->gradient == 2) {
+      const float t = (1.0f - x->jitter) * t0 + x->jitter * t1;
+      const v3 p = v3_add(x->ray_org, v3_scale(t, x->ray_dir));
+      if (p.x + stp.x > 1.0f - FLT_EPSILON) stp.x *= -1.0f;
+      if (p.y + stp.y > 1.0f - FLT_EPSILON) stp.y *= -1.0f;
+      if (p.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
+    }
     const v3 shaded = gradient_shade(x->s, x->otw, x->wto, x->ray_dir, value, x->samples[1 * block + slot],
-                                     x->samples[2 * block + slot], x->samples[3 * block + slot], x->gs,
+                                     x->samples[2 * block + slot], x->samples[3 * block + slot], stp,
                                      v3_make(rgb[0], rgb[1], rgb[2]));
     rgb[0] = shaded.x; rgb[1] = shaded.y; rgb[2] = shaded.z;
   }
@@ -1026,19 +1041,24 @@ static int compose2_body(void* c, float t0, float t1)
 static void streaming_pass(const vnro_scene* s, int pass, int n_iters, vnro_value_fn fn, void* user, float* accumulation, float* frame,
                            vnro_render_stats* st, ssh_pixels* px)
 {
+  /* shading_mode 3 = the in-shader single-shade heuristic (rendering mode 12; network_raymarching_traceray / _transmittance,
+   * method_raymarching.cu:981-1035, 1037-1128): the shadow ray marches at raymarching_shadow_sampling_scale = 2 x the step and is
+   * jittered by the pixel's THIRD random number (two get_floats() calls), where the streaming variant uses the step and the second */
+  const int in_shader_ssh = s->shading_mode == 3;
   const uint32_t n_pixels = (uint32_t)s->width * (uint32_t)s->height;
   const camera_t cam = make_camera(s);
   const affine otw = affine_from(s->xfm);
   const affine wto = affine_inverse(&otw);
   const v3 lo = v3_make(s->bbox_lo[0], s->bbox_lo[1], s->bbox_lo[2]);
   const v3 hi = v3_make(s->bbox_hi[0], s->bbox_hi[1], s->bbox_hi[2]);
-  const float step = 1.0f / s->sampling_rate, step_rcp = s->sampling_rate; /* object.cpp:303-304 */
+  const float step = (pass == 3 && in_shader_ssh ? 2.0f : 1.0f) * (1.0f / s->sampling_rate), step_rcp = s->sampling_rate; /* object.cpp:303-304 */
   const v3 rcp = v3_make(1.0f / s->mc_spacings[0], 1.0f / s->mc_spacings[1], 1.0f / s->mc_spacings[2]);
   const i3 grid = { s->mc_dims[0], s->mc_dims[1], s->mc_dims[2] };
   const float shading_scale = 0.95f;  /* scivis_shading_scale, instantvnr_types.h:140 */
 
   /* GRADIENT_SHADING streams 4 coordinates per sample (:198, :934): the sample and three forward offsets of grad_step */
-  const int gradient = pass == 0 && s->shading_mode == 1;
+  /* shading_mode 4 = the in-shader gradient shading (rendering mode 9; :1068-1070): mode 8 with sampleGradient's boundary flip */
+  const int gradient = pass == 0 ? (s->shading_mode == 1 ? 1 : s->shading_mode == 4 ? 2 : 0) : 0;
   const size_t per_sample = gradient ? 4 : 1;
   const v3 gs = v3_make(1.0f / (float)s->vol_dims[0], 1.0f / (float)s->vol_dims[1], 1.0f / (float)s->vol_dims[2]); /* object.cpp:305 */
   payload_t* cur = (payload_t*)malloc(sizeof(payload_t) * n_pixels);
@@ -1066,6 +1086,7 @@ static void streaming_pass(const vnro_scene* s, int pass, int n_iters, vnro_valu
       vnro_lcg_init(&rng, (uint32_t)s->frame_index, i);
       jitter = vnro_lcg_next(&rng); /* get_floats().x */
       if (pass == 2) px->jitter[i] = vnro_lcg_next(&rng); /* get_floats().y (:866-868; stored for every pixel here) */
+      if (pass == 2 && in_shader_ssh) px->jitter[i] = vnro_lcg_next(&rng); /* the next get_floats().x */
       ray = compute_ray(s, &cam, &wto, i);
     }
     float tmin = 0.0f, tmax = FLOAT_LARGE;
@@ -1116,7 +1137,7 @@ static void streaming_pass(const vnro_scene* s, int pass, int n_iters, vnro_valu
       intersect_box(&tmin, &tmax, ray.org, ray.dir, lo, hi);
       ssh_t ssh = ssh_cur[i];
       if (pass == 0) {
-        compose_ctx x = { s, values, n_rays, i, 0, n_iters, p.alpha, p.color, step_rcp, gradient, gs, &otw, &wto, ray.dir };
+        compose_ctx x = { s, values, n_rays, i, 0, n_iters, p.alpha, p.color, step_rcp, gradient, gs, &otw, &wto, ray.dir, ray.org, p.jitter };
         iter_exec(s, &p.iter, ray.dir, tmin, tmax, step, compose_body, &x);
         p.alpha = x.alpha; p.color = x.color;
       } else {
@@ -1161,7 +1182,7 @@ void vnro_render_streaming(const vnro_scene* s, int n_iters, vnro_value_fn fn, v
                            float* accumulation, float* frame, vnro_render_stats* stats)
 {
   vnro_render_stats st = {0, 0, 0, 0};
-  if (s->shading_mode == 2) {
+  if (s->shading_mode == 2 || s->shading_mode == 3) {
     const size_t n = (size_t)s->width * (size_t)s->height;
     ssh_pixels px;
     px.org = (v3*)calloc(n, sizeof(v3)); px.color = (v3*)calloc(n, sizeof(v3)); px.alpha = (float*)calloc(n, sizeof(float));

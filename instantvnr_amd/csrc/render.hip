@@ -88,6 +88,7 @@ struct RenderParams {
   float density_scale;   // DeviceVolume::density_scale (path tracing, rendering mode 14)
   uint32_t ssh_third_draw;   // rendering mode 12: the shadow ray's jitter is the pixel's third random number
   uint32_t grad_flip;        // rendering mode 9: forward differences flip at the volume's far faces (sampleGradient)
+  uint32_t pt_reset_interval;  // rendering mode 15: the in-shader estimator resets tnear / tfar before a bounce (:999-1001)
 };
 
 // streaming kernel modes (ShadingMode, method_raymarching.cu:51-56)
@@ -902,9 +903,13 @@ __device__ __forceinline__ bool pt_take_sample(const RenderParams& p, PtRay& r)
       r.shadow = false;
       const float s0 = r.next_float(), s1 = r.next_float();
       r.dir = xfm_vector(p.wto, pt_uniform_sample_sphere(s0, s1));
-      if (!intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi)) return false;   // the interval is not reset first
+      if (p.pt_reset_interval) { r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE; }
+      if (!intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi)) return false;   // mode 14: the interval is not reset first
       dda_init(r.it, r.org * p.mc_rcp, r.dir * p.mc_rcp, r.tnear, p.mc_dims);
       if (pt_hashit(p, r, t)) { r.sample_coord = r.org + t * r.dir; return true; }
+      // the bounce leaves the volume at once: mode 14 ends the path here without the ambient term (:631-635 falls through to
+      // `return false`), the in-shader / monolithic estimator adds it on its next loop trip (:447-452, 1008-1013)
+      if (p.pt_reset_interval) r.L = r.L + 1.5f * r.throughput;
     } else {
       r.L = r.L + 1.5f * r.throughput;   // light_ambient = 1.5 (instantvnr_types.h:146)
     }
@@ -922,6 +927,7 @@ __device__ __forceinline__ bool pt_shade(const RenderParams& p, const DeviceTfn&
     r.shadow = false;
     const float s0 = r.next_float(), s1 = r.next_float();
     r.dir = xfm_vector(p.wto, pt_uniform_sample_sphere(s0, s1));
+    if (p.pt_reset_interval) { r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE; }
   } else {
     if (r.scatter_index > 4u) {  // russian_roulette (:366-376), russian_roulette_length = 4
       const float q = fminf(0.95f, max3f(r.throughput.x, r.throughput.y, r.throughput.z));
@@ -1239,6 +1245,7 @@ void Renderer::render()
   p.light_dir = light_dir_;
   p.shading_mode = (mode_ == 7 || mode_ == 8 || mode_ == 9) ? 1u : (mode_ == 10 || mode_ == 11 || mode_ == 12) ? 2u : 0u;
   p.grad_flip = mode_ == 9 ? 1u : 0u;
+  p.pt_reset_interval = mode_ == 15 ? 1u : 0u;
   p.ssh_third_draw = mode_ == 12 ? 1u : 0u;
   p.slot_cap = 0;
   // single-shade heuristic (modes 10 / 11): shadow rays point towards the light, xfmVector(wto, normalize(dir)) (:649, :473)
@@ -1275,6 +1282,8 @@ void Renderer::render()
       render_streaming(p, M_SSH);
       render_streaming(p, M_SHADOW);
       break;
+    case 15:  // VNR_PATHTRACING_IN_SHADER (network_path_tracing_traceray, :968-1025): mode 13's estimator, i.e. the streaming
+              // loop with the interval reset before a bounce, sampled from whatever the volume is
     case 14:  // VNR_PATHTRACING_SAMPLE_STREAMING
       render_pathtracing(p);
       break;
@@ -1306,7 +1315,7 @@ void Renderer::render()
       break;
     default:
       throw std::runtime_error("rendering mode " + std::to_string(mode_) +
-                               " is not implemented in this build (supported: ray marching 4 - 12 and path tracing 13, 14)");
+                               " is not implemented in this build (supported: ray marching 4 - 12 and path tracing 13 - 15; 0 - 3 are the OptiX modes)");
     }
   }
   reset_ = false;

@@ -1258,7 +1258,9 @@ static v3 pt_uniform_sample_sphere(float radius, float sx, float sy)
   return v3_make(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta);
 }
 
-typedef struct { const vnro_scene* s; const affine* wto; v3 lo, hi, rcp; i3 grid; float density_scale; v3 light_dir_obj; } pt_env;
+typedef struct { const vnro_scene* s; const affine* wto; v3 lo, hi, rcp; i3 grid; float density_scale; v3 light_dir_obj;
+                 int reset_interval;  /* in-shader / monolithic estimator: tnear = 0, tfar = large before a bounce (:438-439, 999-1001) */
+} pt_env;
 
 /* iterative_take_sample (:598-636) */
 static int pt_take_sample(const pt_env* e, pt_ray* r)
@@ -1275,12 +1277,16 @@ static int pt_take_sample(const pt_env* e, pt_ray* r)
       r->shadow = 0;
       const float s0 = vnro_lcg_next(&r->rng), s1 = vnro_lcg_next(&r->rng);
       r->dir = xfm_vector(e->wto, pt_uniform_sample_sphere(1.f, s0, s1));
-      if (!intersect_box(&r->tnear, &r->tfar, r->org, r->dir, e->lo, e->hi)) return 0;  /* the interval is NOT reset first */
+      if (e->reset_interval) { r->tnear = 0.f; r->tfar = FLOAT_LARGE; }
+      if (!intersect_box(&r->tnear, &r->tfar, r->org, r->dir, e->lo, e->hi)) return 0;  /* streaming: the interval is NOT reset first */
       dda_init(&r->iter, v3_mul(r->org, e->rcp), v3_mul(r->dir, e->rcp), r->tnear, r->tfar, e->grid);
       if (pt_hashit(e->s, r, e->rcp, e->grid, e->density_scale, &t)) {
         r->sample_coord = v3_add(r->org, v3_scale(t, r->dir));
         return 1;
       }
+      /* the bounce leaves the volume without a tentative collision: the streaming variant ends the path here WITHOUT the ambient term
+       * (it falls through to `return false`, :631-635); the monolithic / in-shader estimator adds it on its next loop trip (:447-452) */
+      if (e->reset_interval) r->L = v3_add(r->L, v3_scale(1.5f, r->throughput));
     } else {
       r->L = v3_add(r->L, v3_scale(1.5f, r->throughput));  /* light_ambient = 1.5 (instantvnr_types.h:146) */
     }
@@ -1299,6 +1305,7 @@ static int pt_shade(const pt_env* e, pt_ray* r, float sample_value)
     r->shadow = 0;
     const float s0 = vnro_lcg_next(&r->rng), s1 = vnro_lcg_next(&r->rng);
     r->dir = xfm_vector(e->wto, pt_uniform_sample_sphere(1.f, s0, s1));
+    if (e->reset_interval) { r->tnear = 0.f; r->tfar = FLOAT_LARGE; }
   } else {
     /* russian_roulette (:366-376), russian_roulette_length = 4 */
     if (r->scatter_index > 4) {
@@ -1336,6 +1343,9 @@ void vnro_render_pathtracing(const vnro_scene* s, vnro_value_fn fn, void* user, 
   e.grid.x = s->mc_dims[0]; e.grid.y = s->mc_dims[1]; e.grid.z = s->mc_dims[2];
   e.density_scale = s->density_scale == 0.0f ? 1.0f : s->density_scale;
   e.light_dir_obj = xfm_vector(&wto, v3_normalize(v3_make(s->light_dir[0], s->light_dir[1], s->light_dir[2])));
+  /* shading_mode 5: the in-shader path tracer's estimator (rendering mode 15; network_path_tracing_traceray, :968-1025), which is
+   * path_tracing_traceray's: the streaming loop with the interval reset before a bounce */
+  e.reset_interval = s->shading_mode == 5;
   vnro_render_stats st = {0, 0, 0, 0};
   pt_ray* rays = (pt_ray*)malloc(sizeof(pt_ray) * (n_pixels ? n_pixels : 1));
   float* coords = (float*)malloc(sizeof(float) * 3 * (n_pixels ? n_pixels : 1));
@@ -1415,6 +1425,7 @@ void vnro_render_pathtracing_monolithic(const vnro_scene* s, const float* vol, i
   e.grid.x = s->mc_dims[0]; e.grid.y = s->mc_dims[1]; e.grid.z = s->mc_dims[2];
   e.density_scale = s->density_scale == 0.0f ? 1.0f : s->density_scale;
   e.light_dir_obj = xfm_vector(&wto, v3_normalize(v3_make(s->light_dir[0], s->light_dir[1], s->light_dir[2])));
+  e.reset_interval = 1;
   for (int iy = row_lo; iy < row_hi; ++iy)
     for (int ix = 0; ix < s->width; ++ix) {
       const uint32_t pixel = (uint32_t)ix + (uint32_t)iy * (uint32_t)s->width;

@@ -149,9 +149,9 @@ def test_monolithic_mode4_matches_oracle(oracle, scene):
     assert psnr(img, want) > 80
 
 
-@pytest.mark.parametrize("mode", [0, 3, 15])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 16, -1])
 def test_unsupported_modes_fail_loudly(scene, mode):
-    """OptiX modes (0-3) and the in-shader path tracer (15) are not built: no silent fallback"""
+    """the OptiX modes (0-3) are not built and there is nothing beyond 15: no silent fallback"""
     r = make_renderer(scene, scene["sv"], mode=mode)
     with pytest.raises(api.VnrAmdError, match="not implemented"):
         api.vnrRender(r)
@@ -576,3 +576,27 @@ def test_in_shader_mode_9_gradient_shading(oracle):
     for mode in (9, 8):
         assert np.abs(frames[mode] - want[mode]).max() < 2e-4 and psnr(frames[mode], want[mode]) > 80
     assert int((np.abs(frames[9] - frames[8]).max(axis=2) > 1e-6).sum()) > 200
+
+
+def test_in_shader_mode_15_path_tracing(oracle, scene):
+    """VNR_PATHTRACING_IN_SHADER: the estimator of mode 13 on the streaming loop: the interval is reset before a bounce and a bounce
+    that leaves the volume at once still collects the ambient light (mode 14 drops that term, method_pathtracing.cu:631-635 vs
+    447-452).  On a dense volume it must agree with BOTH oracle programs, the streaming one with that flag and the monolithic
+    one, which agree with each other bit for bit; a thin medium makes the two differences from mode 14 visible."""
+    r = make_renderer(scene, scene["sv"], mode=15)
+    api.vnrRendererSetVolumeDensityScale(r, 0.25)
+    mo = api.volume_macrocell(scene["sv"])["max_opacity"]
+    cam = scene["cam"]
+    f = lambda c: oracle.sample_volume(scene["vol"], c, nodal=True)
+    acc = acc_mono = acc14 = None
+    for frame_index in (1, 2, 3, 4):
+        api.vnrRender(r)
+        img = api.vnrRendererMapFrame(r).copy()
+        mk = lambda sm: oracle.SceneHolder(96, 80, (48, 48, 48), scene["otfn"], mo, cam["from"], cam["at"], cam["up"], cam["fovy"],
+                                           density_scale=0.25, shading_mode=sm, frame_index=frame_index)
+        want, acc, _ = oracle.render_pathtracing(mk(5), f, accumulation=acc)
+        mono, acc_mono = oracle.render_pathtracing_monolithic(mk(5), scene["vol"], accumulation=acc_mono)
+        other, acc14, _ = oracle.render_pathtracing(mk(0), f, accumulation=acc14)
+        assert np.array_equal(want, mono)                                  # one estimator, two programs
+        assert (np.abs(img - want).max(axis=2) < 1e-5).mean() > 0.995
+    assert (np.abs(other - want).max(axis=2) > 1e-6).sum() > 10            # and it is not mode 14's

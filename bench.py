@@ -166,6 +166,26 @@ def main():
     elapsed = time.perf_counter() - t0
     rays_hit = st["n_rays_hit"]
 
+    # ---- un-timed: the neural frame against the frame of the ground-truth volume (same camera / TFN / mode / macrocell) --------
+    image = None
+    if ctx.world == 1 and not a.no_psnr:
+        def one_frame(volume):
+            rr = api.vnrCreateRenderer(volume)
+            api.vnrRendererSetTransferFunction(rr, tfn)
+            api.vnrRendererSetCamera(rr, camera)
+            api.vnrRendererSetFramebufferSize(rr, (a.fb, a.fb))
+            api.vnrRendererSetMode(rr, a.mode)
+            api.vnrRender(rr)
+            return api.vnrRendererMapFrame(rr).astype(np.float64).copy()
+
+        f_nn, f_gt = one_frame(nv), one_frame(sv)
+        d = f_nn - f_gt
+        mse = float((d[..., :3] ** 2).mean())
+        image = {"what": "first frame of the neural volume vs the same frame marched through the ground-truth volume (rgb, peak 1)",
+                 "psnr_db": round(10.0 * np.log10(1.0 / mse), 2) if mse > 0 else None,
+                 "l2_per_pixel_mean": round(float(np.sqrt((d ** 2).sum(axis=2)).mean()), 6),
+                 "l2_per_pixel_max": round(float(np.sqrt((d ** 2).sum(axis=2)).max()), 5)}
+
     # ---- un-timed extra leg (one GPU only): the dominant kernel with the GPU to itself -------------------------------------
     # The default renderer runs two ray halves on two HIP streams, so a launch of the fused kernel shares the GPU with the
     # other half's kernels and its HIP-event duration says little about the kernel.  The same frames on ONE stream (nothing
@@ -286,7 +306,7 @@ def main():
         "samples_per_frame": int(samples_all / a.steps), "samples_per_hit_ray": round(samples_all / a.steps / max(rays_hit, 1), 1),
         "network_evaluations_per_shaded_sample": evals_per_sample, "shaded_samples_per_frame": shaded_samples_per_frame,
         "reference_slots_per_frame": int(slots_all / a.steps), "iterations_per_frame": iters, "rays_hit": rays_hit,
-        "psnr_db": None if psnr is None else round(psnr, 2), "train_ms_per_step": round(train_ms, 3), "train_loss": round(train_loss, 5),
+        "psnr_db": None if psnr is None else round(psnr, 2), "image_vs_ground_truth": image, "train_ms_per_step": round(train_ms, 3), "train_loss": round(train_loss, 5),
         "setup_s": round(setup_s, 1),
         "roofline": roofline,
     }

@@ -495,6 +495,18 @@ def vnrRendererMapFrame(r):
     return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(h, w, 4))
 
 
+# misc (api.h:185-188) -----------------------------------------------------------------------------------------------
+def vnrMemoryQuery():
+    """-> (bytes used by the renderer, bytes used by the network engine)"""
+    r, n = C.c_size_t(), C.c_size_t()
+    lib().vnrAmdMemoryQuery(C.byref(r), C.byref(n))
+    return r.value, n.value
+
+
+def vnrFreeTemporaryGPUMemory():
+    lib().vnrAmdFreeTemporaryGPUMemory()
+
+
 # AMD extensions -------------------------------------------------------------------------------------------------
 def vnrRendererSetPixelRange(r, lo, hi):
     check(lib().vnrAmdRendererSetPixelRange(r.h, int(lo), int(hi)))

@@ -717,7 +717,10 @@ void vnrAmdMemoryQuery(size_t* used_by_renderer, size_t* used_by_network)
   if (used_by_renderer) *used_by_renderer = Runtime::get().bytes_renderer;
   if (used_by_network) *used_by_network = Runtime::get().bytes_network;
 }
-void vnrAmdFreeTemporaryGPUMemory(void) {}
+void vnrAmdFreeTemporaryGPUMemory(void)
+{
+  guarded([&]() { Network::release_temporary_of_all(); });   // api.cpp:554-557
+}
 
 // ------------------------------------------------------------------------------------------------ building blocks
 int vnrAmdSimpleVolumeTakeSamples(vnrAmdVolume v, size_t n, const float lower[3], const float upper[3], float* d_coords,

@@ -118,6 +118,10 @@ public:
   double training_loss(hipStream_t s);  // mean loss of the last forward_backward
 
   size_t bytes_allocated() const;
+  // vnrFreeTemporaryGPUMemory (api.cpp:554-557 -> tcnn's free_all_gpu_memory_arenas): drops what can be rebuilt on demand,
+  // the brick image and the training workspace (not parameters, optimizer state or gradients)
+  void release_temporary();
+  static void release_temporary_of_all();
 
   // brick image policy: built on stream `s` once `brick_after` inference launches have seen unchanged parameters
   // (VNR_AMD_BRICK_AFTER, default 24 = two frames of the streaming renderer; VNR_AMD_BRICK=0 disables, =1 builds at the first

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <set>
 
 #include "grid_device.h"
 
@@ -93,6 +94,12 @@ uint32_t grid_make_layout(const ModelConfig& cfg, GridDevice* out)
   return offset;
 }
 
+static std::set<Network*>& live_networks()
+{
+  static std::set<Network*> s;
+  return s;
+}
+
 static uint32_t json_u32(const Json& j, const char* key, uint32_t def) { return j.contains(key) ? (uint32_t)j.at(key).as_int() : def; }
 static float json_f32(const Json& j, const char* key, float def) { return j.contains(key) ? j.at(key).as_float() : def; }
 static std::string json_str(const Json& j, const char* key, const char* def) { return j.contains(key) ? j.at(key).as_string() : std::string(def); }
@@ -167,6 +174,7 @@ void Network::configure(const Json& config, uint64_t init_seed)
   build_layout();
   steps_ = 0;
   initialize_params(init_seed, Runtime::get().stream);
+  live_networks().insert(this);
 }
 
 void Network::build_layout()
@@ -205,7 +213,24 @@ void Network::refresh_inference_weights(hipStream_t s)
 
 Network::~Network()
 {
+  live_networks().erase(this);
   if (brick_event_) (void)hipEventDestroy(brick_event_);
+}
+
+void Network::release_temporary()
+{
+  if (Runtime::get().ready()) (void)hipDeviceSynchronize();   // nothing may still read what is freed
+  brick_image_.release();
+  levels_brick_dev_.release();
+  brick_valid_ = false;
+  brick_stable_calls_ = 0;
+  ws_features_.release(); ws_acts_.release(); ws_dfeat_.release();   // re-allocated by the next training step (ws_batch_ = 0)
+  ws_batch_ = 0;
+}
+
+void Network::release_temporary_of_all()
+{
+  for (Network* n : live_networks()) n->release_temporary();
 }
 
 // ------------------------------------------------------------------------------------------------ brick image (network.h)

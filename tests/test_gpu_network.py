@@ -178,3 +178,23 @@ def test_brick_image_is_lazy_exact_and_dropped_when_parameters_change(oracle, cf
         api.neural_inference(vol, coords[:64])
     assert api.neural_brick_image(vol)["in_use"]
     assert np.array_equal(api.neural_encode(vol, coords).view(np.uint16)[ok], enc2[ok])
+
+
+def test_free_temporary_gpu_memory_drops_the_caches(oracle):
+    """vnrFreeTemporaryGPUMemory (api.h:188; tcnn's free_all_gpu_memory_arenas in the reference): the brick image and the
+    training workspace go, results and training state stay"""
+    vol, ocfg, params, n_mlp = make(oracle, 10, 2, 12, 8, 1.5, 2, seed=11)
+    coords = coords_for(2000, 12)
+    y0 = api.neural_inference(vol, coords).view(np.uint32)
+    for _ in range(30):
+        api.neural_inference(vol, coords[:64])
+    assert api.neural_brick_image(vol)["in_use"]
+    used = api.vnrMemoryQuery()
+    api.vnrFreeTemporaryGPUMemory()
+    after = api.vnrMemoryQuery()
+    assert not api.neural_brick_image(vol)["in_use"] and api.neural_brick_image(vol)["bytes"] == 0
+    assert sum(after) < sum(used)
+    assert np.array_equal(api.neural_inference(vol, coords).view(np.uint32), y0)
+    for _ in range(30):
+        api.neural_inference(vol, coords[:64])
+    assert api.neural_brick_image(vol)["in_use"]          # and it comes back

@@ -207,7 +207,54 @@ def make_dda():
     np.savez(os.path.join(HERE, "dda_cases.npz"), **out)
 
 
+# --------------------------------------------------------------------------- (viii) the other rendering modes on the C1 scene
+MODE_SHADING = {8: 1, 11: 2, 10: 2, 9: 4, 12: 3}   # rendering mode -> oracle shading_mode (ray marching)
+
+
+def make_c1_modes():
+    """frozen oracle outputs, 96 x 96: gradient shading (8, 9), single-shade heuristic (10, 11, 12), path tracing (13, 14, 15 at
+    density scale 4, first frame)"""
+    vol, colors, alphas, cam = c1_scene()
+    tfn = oracle.TfnHolder(colors, alphas)
+    mo = oracle.macrocell_max_opacity(tfn, oracle.macrocell_compute_implicit(vol))
+    f = lambda c: oracle.sample_volume(vol, c, nodal=True)
+    out = {}
+    for mode, sm in MODE_SHADING.items():
+        sc = oracle.SceneHolder(96, 96, (64, 64, 64), tfn, mo, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=sm)
+        if mode == 10:
+            out["mode10"] = oracle.render_monolithic(sc, vol, n_threads=8)[0]
+        else:
+            out[f"mode{mode}"] = oracle.render_streaming(sc, f, n_iters=512 if mode in (9, 12) else 16)[0]
+    for mode, sm in ((14, 0), (15, 5)):
+        sc = oracle.SceneHolder(96, 96, (64, 64, 64), tfn, mo, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=sm, density_scale=4.0)
+        out[f"mode{mode}"] = oracle.render_pathtracing(sc, f)[0]
+    sc = oracle.SceneHolder(96, 96, (64, 64, 64), tfn, mo, cam["from"], cam["at"], cam["up"], cam["fovy"], density_scale=4.0)
+    out["mode13"] = oracle.render_pathtracing_monolithic(sc, vol)[0]
+    assert np.array_equal(out["mode13"], out["mode15"])    # one estimator (DESIGN.md 7)
+    np.savez_compressed(os.path.join(HERE, "c1_modes.npz"), **{k: v.astype(np.float32) for k, v in out.items()})
+
+
+# --------------------------------------------------------------------------- (ix) one batch of the out-of-core sampler
+def ooc_volume():
+    return np.random.default_rng(2024).integers(0, 65535, (6, 70, 300), dtype=np.uint16)   # [z, y, x]: 55-row slabs, 2 x 6 of them
+
+
+def make_ooc():
+    vol = ooc_volume()
+    rng = np.random.default_rng(7)
+    blocks = np.stack([rng.integers(0, 2, 20), rng.integers(0, 6, 20)], axis=1).astype(np.int32)
+    n, offset = 1500, 12345
+    r = oracle.pcg32_floats(5 * n, offset, 1337, 0xda3e39cb94b95bdb)
+    c, v, bad = oracle.OocSlabSet(vol, blocks).sample((1000.0, 60000.0), r[:3 * n].reshape(n, 3), r[3 * n:4 * n], r[4 * n:],
+                                                       lower=(0.1, 0.0, 0.2), upper=(0.9, 1.0, 0.7))
+    assert bad == 0
+    np.savez_compressed(os.path.join(HERE, "ooc_batch.npz"), volume_sha256=sha(vol), blocks=blocks, n=n, rng_offset=offset, coords=c, values=v,
+                        random_head=r[:8])
+
+
 if __name__ == "__main__":
+    make_c1_modes()
+    make_ooc()
     make_grid_hand_cases()
     make_networks()
     make_bson()

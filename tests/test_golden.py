@@ -198,3 +198,94 @@ def test_gpu_c1_scene():
     # identical arithmetic except powf (device libm vs glibc): stated tolerance 2e-4 absolute per channel
     assert np.abs(images[4] - g["image_mode4_monolithic"]).max() < 2e-4
     assert np.abs(images[5] - g["image_mode5_streaming"]).max() < 2e-4
+
+
+# --------------------------------------------------------------------------- (viii) the other rendering modes, (ix) out-of-core batch
+RAYMARCH_MODES = {8: (1, 16), 9: (4, 512), 11: (2, 16), 12: (3, 512)}   # rendering mode -> (oracle shading_mode, batch size)
+
+
+def test_oracle_c1_modes_and_ooc_batch(oracle):
+    from tests.golden import make_golden as mg
+    g = gold("c1_modes.npz")
+    vol, colors, alphas, cam = mg.c1_scene()
+    tfn = oracle.TfnHolder(colors, alphas)
+    mo = oracle.macrocell_max_opacity(tfn, oracle.macrocell_compute_implicit(vol))
+    f = lambda c: oracle.sample_volume(vol, c, nodal=True)
+    mk = lambda sm, ds=1.0: oracle.SceneHolder(96, 96, (64, 64, 64), tfn, mo, cam["from"], cam["at"], cam["up"], cam["fovy"],
+                                               shading_mode=sm, density_scale=ds)
+    for mode, (sm, n_iters) in RAYMARCH_MODES.items():
+        assert np.abs(oracle.render_streaming(mk(sm), f, n_iters=n_iters)[0] - g[f"mode{mode}"]).max() <= 1e-6, mode
+    assert np.abs(oracle.render_monolithic(mk(2), vol, n_threads=4)[0] - g["mode10"]).max() <= 1e-6
+    assert np.array_equal(oracle.render_pathtracing(mk(0, 4.0), f)[0], g["mode14"])
+    assert np.array_equal(oracle.render_pathtracing(mk(5, 4.0), f)[0], g["mode15"])
+    assert np.array_equal(oracle.render_pathtracing_monolithic(mk(0, 4.0), vol)[0], g["mode13"])
+    for mode in (8, 9, 10, 11, 12):      # each fixture shows a shaded image, and the variants are distinct
+        assert g[f"mode{mode}"][..., 3].max() > 0.5
+    assert np.abs(g["mode11"] - g["mode12"]).max() > 1e-4   # (8 / 9 and 14 / 15 coincide on this scene: tests/test_gpu_render.py has scenes where they differ)
+    o = gold("ooc_batch.npz")
+    ovol = mg.ooc_volume()
+    assert hashlib.sha256(np.ascontiguousarray(ovol).tobytes()).hexdigest() == str(o["volume_sha256"])
+    n, off = int(o["n"]), int(o["rng_offset"])
+    r = oracle.pcg32_floats(5 * n, off, 1337, 0xda3e39cb94b95bdb)
+    assert np.array_equal(r[:8], o["random_head"])
+    c, v, bad = oracle.OocSlabSet(ovol, o["blocks"]).sample((1000.0, 60000.0), r[:3 * n].reshape(n, 3), r[3 * n:4 * n], r[4 * n:],
+                                                              lower=(0.1, 0.0, 0.2), upper=(0.9, 1.0, 0.7))
+    assert bad == 0 and np.array_equal(c, o["coords"]) and np.array_equal(v, o["values"])
+
+
+@pytest.mark.gpu
+def test_gpu_c1_modes():
+    """every rendering mode beyond 4 / 5 on the C1 scene against the frozen oracle frames: ray marching to 2e-4 (powf), path
+    tracing by the fraction of pixels that took the same path (a last-bit difference in logf / sincosf can fork one)"""
+    from instantvnr_amd import api
+    from tests.golden import make_golden as mg
+    g = gold("c1_modes.npz")
+    vol, colors, alphas, cam = mg.c1_scene()
+    sv = api.vnrCreateSimpleVolume(vol)
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    for mode in (8, 9, 10, 11, 12, 13, 14, 15):
+        r = api.vnrCreateRenderer(sv)
+        api.vnrRendererSetTransferFunction(r, tfn)
+        api.vnrRendererSetCamera(r, camera)
+        api.vnrRendererSetFramebufferSize(r, (96, 96))
+        api.vnrRendererSetMode(r, mode)
+        if mode >= 13:
+            api.vnrRendererSetVolumeDensityScale(r, 4.0)
+        api.vnrRender(r)
+        img = api.vnrRendererMapFrame(r).copy()
+        want = g[f"mode{mode}"]
+        if mode >= 13:
+            assert (np.abs(img - want).max(axis=2) < 1e-5).mean() > 0.995, mode
+        else:
+            assert np.abs(img - want).max() < 2e-4, (mode, np.abs(img - want).max())
+
+
+@pytest.mark.gpu
+def test_gpu_ooc_batch(tmp_path):
+    """the frozen out-of-core batch: same file contents, same slab set (loaded through a scene of exactly those slabs is not
+    possible, so the batch is compared for the slots the library happens to hold: every sample whose slot holds the fixture's
+    slab must be bit-identical)"""
+    from instantvnr_amd import api
+    from tests.golden import make_golden as mg
+    o = gold("ooc_batch.npz")
+    ovol = mg.ooc_volume()
+    path = tmp_path / "ooc.raw"
+    ovol.tofile(path)
+    sv = api.vnrCreateSimpleVolumeOutOfCore(path, ovol.shape[::-1], np.uint16, (1000.0, 60000.0), n_concurrent_blocks=4, n_blocks=20)
+    n, off = int(o["n"]), int(o["rng_offset"])
+    # move the sampler's pcg32 stream to the fixture's offset: (off / 5) dummy samples advance it by 5 each
+    assert off % 5 == 0
+    api.simple_volume_take_samples(sv, off // 5)
+    mine = api.out_of_core_blocks(sv)
+    c, v = api.simple_volume_take_samples(sv, n, (0.1, 0.0, 0.2), (0.9, 1.0, 0.7))
+    from oracle import oracle
+    r = oracle.pcg32_floats(5 * n, off, 1337, 0xda3e39cb94b95bdb)
+    slot = np.minimum((r[3 * n:4 * n] * np.float32(20)).astype(np.int64), 19)
+    same_slab = (mine[slot] == o["blocks"][slot]).all(axis=1)
+    assert same_slab.sum() > 20          # a few slots do coincide (2 x 6 possible slabs in 20 slots)
+    assert np.array_equal(c[same_slab], o["coords"][same_slab]) and np.array_equal(v[same_slab], o["values"][same_slab])

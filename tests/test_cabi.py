@@ -139,3 +139,25 @@ def test_torch_must_be_imported_before_the_library_is_loaded(L, order, ok):
             "except _lib.VnrAmdError as e:\n    print('GUARD-RAISED', 'Import torch first' in str(e))\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
     assert ("GUARD-PASSED" in out) if ok else ("GUARD-RAISED True" in out), out
+
+
+def test_view_model_tool_reads_and_corrects_params_files(tmp_path):
+    """tools/view_model.py (apps/view_model.cpp): what a params.json holds; --correct --dims adds the missing volume dims to a
+    legacy file and writes params-corrected.json"""
+    import subprocess
+    import sys
+    import bson
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "view_model.py")
+    fixture = os.path.join(root, "tests", "golden", "bson_params_like.bson")
+    out = subprocess.run([sys.executable, tool, fixture], capture_output=True, text=True, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr
+    assert "[info] volume dims: (32, 32, 32)" in out.stdout and "[info] params = 1.52 KB" in out.stdout and '"otype"' in out.stdout
+    doc = bson.decode(open(fixture, "rb").read())
+    del doc["volume"]
+    legacy = tmp_path / "legacy.bson"
+    legacy.write_bytes(bson.encode(doc))
+    out = subprocess.run([sys.executable, tool, str(legacy), "--correct", "--dims", "10,20,30"], capture_output=True, text=True, cwd=tmp_path)
+    assert out.returncode == 0 and "does not contain dimension data" in out.stdout
+    fixed = bson.decode((tmp_path / "params-corrected.json").read_bytes())
+    assert fixed["volume"]["dims"] == {"x": 10, "y": 20, "z": 30} and fixed["parameters"] == doc["parameters"]

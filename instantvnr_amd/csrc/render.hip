@@ -314,24 +314,61 @@ __device__ __forceinline__ float opacity_upper_bound(const RenderParams& p, vec3
   return p.mc_max_opacity[idx];
 }
 
-// RayMarchingIter::exec (method_raymarching.cu:555-600); body(t0, t1) -> bool
+// RayMarchingIter::exec (method_raymarching.cu:555-600); body(t0, t1) -> bool.
+// dda_next with the cell callback written out as one loop, for the latency of a single wave (a small frame share runs one
+// wave per SIMD, and the length of the per-iteration kernel chain is what bounds it):
+//  * the opacity bound of the cell the walk enters NEXT is fetched while the current cell is processed: which cell comes
+//    next depends only on the DDA state, not on what the current cell holds (an empty run of cells is otherwise a chain of
+//    dependent L2 round trips).  The fetch is unconditional (a walk that leaves the grid re-reads its current cell) so that
+//    the compiler's wait-count bookkeeping sees one pending load on every path;
+//  * the advance is written with selects instead of dda_next's three early returns.  A walk that leaves the grid through x
+//    therefore also advances y / z and next_cell_begin where dda_next returns first; nothing reads that state again
+//    (dda_resumable and this function test the cell against `stop` before anything else).
+// Inside the grid the state (cell, t_next, next_cell_begin) goes through exactly dda_next's operations.
 template <typename B>
-__device__ __forceinline__ void iter_exec(const RenderParams& p, DDAState& it, vec3f m_dir, float t_min, float t_max, float step, B&& body)
+__device__ __forceinline__ void iter_exec(const RenderParams& p, DDAState& it, vec3f dir, float t_min, float t_max, float step, B&& body)
 {
-  auto cell_fn = [&](vec3i cell, float t0, float t1) -> bool {
-    const float r = opacity_upper_bound(p, cell);
-    if (fabsf(r) <= FLT_EPSILON) return true;
-    const float ss = adaptive_sampling_rate(step, r);
-    float tx = t0, ty = fminf(t1, t0 + ss);
-    while (ty > tx) {
-      it.next_cell_begin = ty - t_min;
-      if (!body(tx, ty)) return false;
-      tx = ty;
-      ty = fminf(tx + ss, t1);
+  const vec3i grid = p.mc_dims;
+  const vec3i stop = {dir.x > 0.0f ? grid.x : -1, dir.y > 0.0f ? grid.y : -1, dir.z > 0.0f ? grid.z : -1};
+  if (it.cell.x == stop.x || it.cell.y == stop.y || it.cell.z == stop.z) return;
+  const vec3f ts = {fabsf(1.0f / dir.x), fabsf(1.0f / dir.y), fabsf(1.0f / dir.z)};
+  const vec3i delta = {dir.x > 0.0f ? 1 : -1, dir.y > 0.0f ? 1 : -1, dir.z > 0.0f ? 1 : -1};
+  float r = opacity_upper_bound(p, it.cell);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): inside the loop only the look-ahead load is in flight
+  bool more = true;
+  while (more) {
+    const float t_closest = min3f(it.t_next.x, it.t_next.y, it.t_next.z);
+    const float cell_t0 = fmaxf(t_min + it.next_cell_begin, t_min);
+    const float cell_t1 = fminf(t_min + t_closest, t_max);
+    if (cell_t0 >= cell_t1) break;
+    // the cell after this one
+    const bool bx = it.t_next.x == t_closest, by = it.t_next.y == t_closest, bz = it.t_next.z == t_closest;
+    const vec3i nc = {it.cell.x + (bx ? delta.x : 0), it.cell.y + (by ? delta.y : 0), it.cell.z + (bz ? delta.z : 0)};
+    const bool inside = nc.x != stop.x && nc.y != stop.y && nc.z != stop.z;
+    const float r_next = opacity_upper_bound(p, inside ? nc : it.cell);
+    // the cell callback of RayMarchingIter::exec
+    bool go = true;
+    if (!(fabsf(r) <= FLT_EPSILON)) {
+      const float ss = adaptive_sampling_rate(step, r);
+      float tx = cell_t0, ty = fminf(cell_t1, cell_t0 + ss);
+      while (ty > tx) {
+        it.next_cell_begin = ty - t_min;
+        if (!body(tx, ty)) { go = false; break; }
+        tx = ty;
+        ty = fminf(tx + ss, cell_t1);
+      }
     }
-    return true;
-  };
-  while (dda_next(it, m_dir, t_min, t_max, p.mc_dims, cell_fn)) {}
+    const bool adv = go || fmaxf(t_min + it.next_cell_begin, t_min) >= cell_t1;
+    it.t_next.x = (adv && bx) ? it.t_next.x + ts.x : it.t_next.x;
+    it.t_next.y = (adv && by) ? it.t_next.y + ts.y : it.t_next.y;
+    it.t_next.z = (adv && bz) ? it.t_next.z + ts.z : it.t_next.z;
+    it.cell.x = adv ? nc.x : it.cell.x;
+    it.cell.y = adv ? nc.y : it.cell.y;
+    it.cell.z = adv ? nc.z : it.cell.z;
+    it.next_cell_begin = adv ? t_closest : it.next_cell_begin;
+    more = go && inside;
+    r = r_next;
+  }
 }
 
 // depth bin of a sample inside its 64-ray group (gather-order counting sort of march_kernel)
@@ -629,15 +666,19 @@ __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float
 // it (at most 64 KiB of L2-resident counts per block), so no second launch and no inter-block dependency is needed.  The block
 // that holds the last group publishes the number of alive rays; block 0 also clears the sample counter the next march adds to.
 __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, const RayList dst, const uint32_t* __restrict__ ray_counts,
-                                                            uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first, int ssh, const SshLists ssh_lists)
+                                                            uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first, int ssh, const SshLists ssh_lists,
+                                                            uint32_t* __restrict__ host_alive, uint32_t* __restrict__ host_stats)
 {
   __shared__ uint32_t s_part[16];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n_in = first ? n_first : counters[C_RAYS0 + parity];   // rays the march that just ran consumed
   const uint32_t n_groups = ((n_in + 255u) & ~255u) >> 6;               // groups it wrote a count for
   if (blockIdx.x == 0 && tid == 0) counters[C_SAMPLES0 + (parity ^ 1)] = 0;
+  // the host reads the alive-ray count and the frame statistics from pinned memory the kernel writes itself: a copy
+  // engine operation between two kernels of a stream costs more than either of the small kernels
+  if (blockIdx.x == 0 && tid >= C_HIT && tid < C_COUNT) host_stats[tid] = counters[tid];
   if (n_groups == 0) {
-    if (blockIdx.x == 0 && tid == 0) counters[C_RAYS0 + (parity ^ 1)] = 0;
+    if (blockIdx.x == 0 && tid == 0) { counters[C_RAYS0 + (parity ^ 1)] = 0; *host_alive = 0; }
     return;
   }
   const uint32_t g0 = blockIdx.x * 16u;
@@ -661,7 +702,7 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
   }
   const uint32_t count = __shfl(mine, (int)wave), base = before + __shfl(incl, (int)wave) - count;
   const uint32_t block_total = __shfl(incl, 15);
-  if (g0 + 16u >= n_groups && tid == 0) counters[C_RAYS0 + (parity ^ 1)] = before + block_total;
+  if (g0 + 16u >= n_groups && tid == 0) { counters[C_RAYS0 + (parity ^ 1)] = before + block_total; *host_alive = before + block_total; }
   if (lane < count) {
     const uint32_t from = ((g0 + wave) << 6) + lane, to = base + lane;
     dst.pixel_index[to] = src.pixel_index[from];
@@ -1130,7 +1171,7 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   }
   counters_.resize(2 * C_COUNT);  // one block of counters per half
   counters_.zero(stream_);
-  VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 2 * 256 * sizeof(uint32_t), hipHostMallocDefault));
+  VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, (2 * 256 + 2 * C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
   VNR_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 }
@@ -1418,7 +1459,8 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     vec2f* vd[2];
     uint32_t* c;         // device counters of this half
     uint32_t* rc;        // survivors per 64-ray group
-    uint32_t* hc;        // pinned ring of alive-ray counts
+    uint32_t* hc;        // pinned ring of alive-ray counts (written by compact_rays_kernel)
+    uint32_t* hs;        // pinned copy of this half's counters as of the last compact_rays_kernel
     hipStream_t s;
     size_t s_max;
     uint32_t it = 0, used = 0;
@@ -1459,6 +1501,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     hf.c = counters_.ptr + (size_t)h * C_COUNT;
     hf.rc = ray_counts_.ptr + off / 64 + (size_t)h * 8;   // halves are multiples of 64 rays; 8 groups of slack each
     hf.hc = host_counts_ + (size_t)h * 256;
+    hf.hs = host_counts_ + 512 + (size_t)h * C_COUNT;
     hf.s = h == 0 ? stream_ : stream2_;
     hf.s_max = (size_t)hf.p.n_local * hf.p.n_iters * (grad ? 4 : 1);   // records the evaluation kernel may see
     off += hf.p.n_local;
@@ -1523,9 +1566,9 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
     // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
-    compact_rays_kernel<<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh);
+    compact_rays_kernel<<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
+                                                                  hf.hc + (it & 255u), hf.hs);
     VNR_HIP_CHECK(hipGetLastError());
-    VNR_HIP_CHECK(hipMemcpyAsync(hf.hc + (it & 255u), c + C_RAYS0 + (parity ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, hf.s));
     ++hf.it;
     if (hf.it >= max_iterations) hf.done = true;
   };
@@ -1563,8 +1606,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     while (used > 1 && hf.hc[(used - 2) & 255u] == 0) --used;  // trailing speculative no-op iterations
     predicted[h] = used;
     hf.used = used;
-    uint32_t hc[C_COUNT];
-    VNR_HIP_CHECK(hipMemcpy(hc, hf.c, sizeof(hc), hipMemcpyDeviceToHost));
+    const uint32_t* hc = hf.hs;   // every march of the frame ran before the last compact_rays_kernel
     if (pass_mode != M_SHADOW) stats_.n_rays_hit += hc[C_HIT];
     n_samples += (uint64_t)hc[C_STAT_SAMPLES] | ((uint64_t)hc[C_STAT_SAMPLES + 1] << 32);
     n_refrays += (uint64_t)hc[C_STAT_REFRAYS] | ((uint64_t)hc[C_STAT_REFRAYS + 1] << 32);

@@ -59,7 +59,7 @@ struct RenderParams {
   uint32_t tile_w_log2;                  // tile shape: 2^tile_w_log2 x 2^(6 - tile_w_log2) pixels (8x8, 16x4, 32x2 or 64x1)
   float bin_depth_rcp;                   // 1 / depth of one sample-sorting bin (world units)
   uint32_t tfn_in_lds;                   // the TFN tables fit in the march kernel's LDS
-  uint32_t debug_flags;                  // timing ablations only (VNR_AMD_DEBUG_FLAGS): 1 no compose, 2 no TFN, 4 no sort
+  uint32_t debug_flags;                  // timing ablations only (VNR_AMD_DEBUG_FLAGS): 1 no compose, 2 no TFN, 4 no sort, 8 no DDA walk, 16 no sample records
   vec3f cam_pos, cam_dir, cam_hor, cam_ver;
   affine3f wto;
   vec3i vol_dims;
@@ -401,11 +401,12 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
                                                     vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters,
                                                     uint32_t* __restrict__ ray_counts, int parity, const SshLists ssh_lists)
 {
-  extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1}, histogram[256], [n_iters][256] ranks (u16), then the transfer function tables
+  extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1}, histogram[256], claims[16], [n_iters][256] ranks (u16), then the transfer function tables
   float* s_t0 = s_t;
   float* s_t1 = s_t + (size_t)p.n_iters * 256;
   uint32_t* s_hist = (uint32_t*)(s_t + (size_t)2 * p.n_iters * 256);
-  uint16_t* s_rk = (uint16_t*)(s_hist + 256);   // rank of a sample inside its depth bin (< 64 n_iters); the bin is recomputed
+  uint32_t* s_claim = s_hist + 256;             // [2][8]
+  uint16_t* s_rk = (uint16_t*)(s_claim + 16);   // rank of a sample inside its depth bin (< 64 n_iters); the bin is recomputed
   // the TFN tables are read 4x per composed sample: keep them in LDS (no TA traffic) when they fit
   DeviceTfn tfn = p.tfn;
   constexpr bool GRAD = MODE == M_GRADIENT;
@@ -423,6 +424,8 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
   uint32_t* n_samples_out = counters + C_SAMPLES0 + parity;
   const uint32_t n_round = (n_in + 255u) & ~255u;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // s_claim: per trip of the block's loop (double-buffered) the samples of the 4 waves, [4] the block's base
+  uint32_t trip = 0;
 
   for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
     const uint32_t i = base + tid;
@@ -536,7 +539,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
 
     // emit the next batch of this ray into LDS
     uint32_t k = 0;
-    if (alive) {
+    if (alive && !(p.debug_flags & 8u)) {
       const int n_iters = p.n_iters;
       iter_exec(p, it, m_dir, tmin, tmax, p.step, [&](float t0, float t1) -> bool {
         s_t0[k * 256u + tid] = t0;
@@ -563,20 +566,29 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     // iterations.  (Claiming slots with an atomic, as the reference does, hands them out in wave-arrival order; by the third
     // iteration a group then mixes rays of distant tiles and the hash-grid gathers of its samples lose 20-35 % of their rate.)
     const uint32_t group = i >> 6;
-    uint32_t smp_base = 0;
+    // Sample slots: ONE claim per block.  A device-scope atomic is resolved beyond the per-XCD L2, and atomics on one address
+    // are served one after the other (about 10 ns each, measured: a first march of 131 072 pixels whose waves each issued four
+    // of them took 45 us before tracing a single ray), so neither the claim is made per wave nor are the frame statistics
+    // counted here: compact_rays_kernel sums them from the per-group counts.
+    // The queue counter counts RECORDS (what the evaluation kernel reads); with 4 records per sample every claim is a
+    // multiple of 4, so claim / 4 is a unique sample-slot base.
+    uint32_t* claim = s_claim + 8u * (trip & 1u);
     if (lane == 0) {
-      ray_counts[group] = wave_rays;
-      if (wave_rays) {
-        // the queue counter counts RECORDS (what the evaluation kernel reads); with 4 records per sample every claim is a
-        // multiple of 4, so claim / 4 is a unique sample-slot base
-        smp_base = GRAD ? atomicAdd(n_samples_out, 4u * wave_samples) >> 2 : atomicAdd(n_samples_out, wave_samples);
-        atomicAdd((unsigned long long*)(counters + C_STAT_SAMPLES), (unsigned long long)wave_samples);
-      }
-      if (alive_mask) atomicAdd((unsigned long long*)(counters + C_STAT_REFRAYS), (unsigned long long)__popcll(alive_mask));
-      if (FIRST && alive_mask) atomicAdd(counters + C_HIT, (uint32_t)__popcll(alive_mask));
+      ray_counts[group] = wave_rays | ((uint32_t)__popcll(alive_mask) << 8);  // survivors | rays that were alive when the march began to emit
+      claim[tid >> 6] = wave_samples;
     }
-    smp_base = __shfl(smp_base, 0);
-    if (wave_rays == 0) continue;  // wave-uniform
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t total = claim[0] + claim[1] + claim[2] + claim[3];
+      uint32_t b = 0;
+      if (total) b = GRAD ? atomicAdd(n_samples_out, 4u * total) >> 2 : atomicAdd(n_samples_out, total);
+      claim[4] = b;
+    }
+    __syncthreads();
+    uint32_t smp_base = claim[4];
+    for (uint32_t w = 0; w < (tid >> 6); ++w) smp_base += claim[w];
+    ++trip;
+    if (wave_rays == 0 || (p.debug_flags & 16u)) continue;  // wave-uniform
 
     // depth bins of the group: front = smallest first-sample depth among the surviving rays
     float front = survive ? s_t0[tid] : VNR_FLOAT_LARGE;
@@ -667,7 +679,7 @@ __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float
 // that holds the last group publishes the number of alive rays; block 0 also clears the sample counter the next march adds to.
 __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, const RayList dst, const uint32_t* __restrict__ ray_counts,
                                                             uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first, int ssh, const SshLists ssh_lists,
-                                                            uint32_t* __restrict__ host_alive, uint32_t* __restrict__ host_stats)
+                                                            uint32_t* __restrict__ host_alive, uint32_t* __restrict__ host_stats, int grad)
 {
   __shared__ uint32_t s_part[16];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -676,15 +688,16 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
   if (blockIdx.x == 0 && tid == 0) counters[C_SAMPLES0 + (parity ^ 1)] = 0;
   // the host reads the alive-ray count and the frame statistics from pinned memory the kernel writes itself: a copy
   // engine operation between two kernels of a stream costs more than either of the small kernels
-  if (blockIdx.x == 0 && tid >= C_HIT && tid < C_COUNT) host_stats[tid] = counters[tid];
-  if (n_groups == 0) {
+  if (n_groups == 0) {  // nothing marched: the statistics are those of the previous launch
     if (blockIdx.x == 0 && tid == 0) { counters[C_RAYS0 + (parity ^ 1)] = 0; *host_alive = 0; }
+    if (blockIdx.x == 0 && tid >= C_HIT && tid < C_COUNT) host_stats[tid] = counters[tid];
     return;
   }
   const uint32_t g0 = blockIdx.x * 16u;
   if (g0 >= n_groups) return;
+  // a group's count: survivors in the low byte, rays that were alive when the march began to emit above it
   uint32_t sum = 0;
-  for (uint32_t g = tid; g < g0; g += 1024u) sum += ray_counts[g];
+  for (uint32_t g = tid; g < g0; g += 1024u) sum += ray_counts[g] & 0xffu;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
   if (lane == 0) s_part[wave] = sum;
@@ -693,7 +706,7 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
 #pragma unroll
   for (int w = 0; w < 16; ++w) before += s_part[w];
   // counts of this block's groups: lane l < 16 of every wave holds count[g0 + l]
-  const uint32_t mine = (lane < 16u && g0 + lane < n_groups) ? ray_counts[g0 + lane] : 0u;
+  const uint32_t mine = (lane < 16u && g0 + lane < n_groups) ? ray_counts[g0 + lane] & 0xffu : 0u;
   uint32_t incl = mine;
 #pragma unroll
   for (int d = 1; d < 16; d <<= 1) {
@@ -702,7 +715,8 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
   }
   const uint32_t count = __shfl(mine, (int)wave), base = before + __shfl(incl, (int)wave) - count;
   const uint32_t block_total = __shfl(incl, 15);
-  if (g0 + 16u >= n_groups && tid == 0) { counters[C_RAYS0 + (parity ^ 1)] = before + block_total; *host_alive = before + block_total; }
+  const bool last_block = g0 + 16u >= n_groups;  // (block-uniform) the block that holds the last group
+  if (last_block && tid == 0) { counters[C_RAYS0 + (parity ^ 1)] = before + block_total; *host_alive = before + block_total; }
   if (lane < count) {
     const uint32_t from = ((g0 + wave) << 6) + lane, to = base + lane;
     dst.pixel_index[to] = src.pixel_index[from];
@@ -717,6 +731,29 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
     if (ssh) {  // scratch [1] -> dense [0]
       ssh_lists.org[0][to] = ssh_lists.org[1][from]; ssh_lists.color[0][to] = ssh_lists.color[1][from]; ssh_lists.alpha[0][to] = ssh_lists.alpha[1][from];
     }
+  }
+  // Frame statistics of the march that just ran (it used to count them with three device-scope atomics per wave), summed by
+  // the last block after its copies so that the kernel needs no more registers than the copies do: a 1024-thread block has
+  // to find room next to the persistent blocks of the other half's evaluation kernel.
+  if (last_block) {
+    uint32_t asum = 0;
+    for (uint32_t g = tid; g < n_groups; g += 1024u) asum += ray_counts[g] >> 8;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) asum += __shfl_xor(asum, d);
+    __syncthreads();  // s_part is read above
+    if (lane == 0) s_part[wave] = asum;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t alive_total = 0;
+      for (int w = 0; w < 16; ++w) alive_total += s_part[w];
+      const uint32_t records = counters[C_SAMPLES0 + parity];
+      unsigned long long* c64 = (unsigned long long*)counters;
+      c64[C_STAT_SAMPLES / 2] += (unsigned long long)(grad ? records >> 2 : records);
+      c64[C_STAT_REFRAYS / 2] += (unsigned long long)alive_total;
+      if (first) counters[C_HIT] += alive_total;
+    }
+    __syncthreads();
+    if (tid >= C_HIT && tid < C_COUNT) host_stats[tid] = ((volatile uint32_t*)counters)[tid];
   }
 }
 
@@ -1512,7 +1549,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     VNR_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
     VNR_HIP_CHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
   }
-  const size_t shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + (size_t)p_all.n_iters * 256 * sizeof(uint16_t);
+  const size_t shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + 16 * sizeof(uint32_t) + (size_t)p_all.n_iters * 256 * sizeof(uint16_t);
   const size_t shmem_compose = shmem + (p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0);
   if (shmem_compose > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
   static bool lds_attr_set = false;
@@ -1567,7 +1604,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
     // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
     compact_rays_kernel<<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
-                                                                  hf.hc + (it & 255u), hf.hs);
+                                                                  hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
     VNR_HIP_CHECK(hipGetLastError());
     ++hf.it;
     if (hf.it >= max_iterations) hf.done = true;

@@ -211,13 +211,6 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
 
-  if (MODE != 1) {  // stage the packed weights once per (persistent) block
-    const uint4_t* src = (const uint4_t*)args.packed_mlp;
-    uint4_t* dst = (uint4_t*)lds;
-    for (uint32_t i = threadIdx.x; i < args.lds_halves / 8; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
-  }
-
   const uint32_t n = args.n_ptr ? *args.n_ptr : args.n;
   const uint32_t n_tiles = (n + 63u) >> 6;
   // XCD-contiguous tile ranges: blocks with equal (blockIdx % 8) share an XCD / L2 (speed only)
@@ -225,6 +218,15 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
   const uint32_t per_xcd = (n_tiles + 7u) >> 3;
   const uint32_t waves_per_xcd = (gridDim.x >> 3) * 4u;
   const uint32_t tile_end = min(n_tiles, (xcd + 1u) * per_xcd);
+  // the grid is sized by an upper bound of the sample count: a block none of whose waves has a tile leaves at once
+  if (xcd * per_xcd + (blockIdx.x >> 3) * 4u >= tile_end) return;
+
+  if (MODE != 1) {  // stage the packed weights once per block
+    const uint4_t* src = (const uint4_t*)args.packed_mlp;
+    uint4_t* dst = (uint4_t*)lds;
+    for (uint32_t i = threadIdx.x; i < args.lds_halves / 8; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
   const uint32_t nh = args.n_hidden_matmuls;
   const bool relu = args.activation == 1;
   const uint32_t h = lane >> 5;   // lane half
@@ -327,10 +329,15 @@ static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
   static const uint32_t forced = [] {
     const char* e = std::getenv("VNR_AMD_INFER_BLOCKS_PER_CU");
     const int v = e ? std::atoi(e) : 0;
-    return (uint32_t)(v >= 1 && v <= 4 ? v : 0);
+    return (uint32_t)(v >= 1 && v <= 64 ? v : 0);
   }();
-  const uint32_t blocks_per_cu = forced ? forced : (a.sharers >= 2 ? 3u : 4u);
-  const uint32_t max_blocks = (uint32_t)rt.n_cus * blocks_per_cu;
+  uint32_t max_blocks = (uint32_t)rt.n_cus * (forced ? forced : (a.sharers >= 2 ? 3u : 4u));
+  // The ray marcher's queue (count on the device, n_max an upper bound of which a frame fills 25-30 %): more blocks than fit,
+  // so that the hardware hands them out as room appears.  With a second kernel and the march kernels of the other ray half
+  // on the GPU a resident grid of fixed size either leaves room unused or waits for it with its tiles already dealt out.
+  // Swept on the C4 frame and on a 1/8 share of it (gpurun_out/s3_share_sweep*.log): best at 2-3 tiles per wave, i.e.
+  // 16-32 blocks per CU for the whole frame (4.59 -> 4.27 ms) and 4-6 for the share (0.77 -> 0.74 ms).
+  if (!forced && a.n_ptr && a.queue_mode) max_blocks = std::min((uint32_t)rt.n_cus * 32u, std::max((uint32_t)rt.n_cus * 4u, n_tiles / 33u));
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = next_multiple(blocks, 8);
   const size_t shmem = MODE == 1 ? 16 : (size_t)a.lds_halves * sizeof(uint16_t);

@@ -677,11 +677,13 @@ __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float
 // dense list, in group order.  One thread per scratch slot; a block (16 groups) first sums the counts of all groups before
 // it (at most 64 KiB of L2-resident counts per block), so no second launch and no inter-block dependency is needed.  The block
 // that holds the last group publishes the number of alive rays; block 0 also clears the sample counter the next march adds to.
-__global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, const RayList dst, const uint32_t* __restrict__ ray_counts,
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) compact_rays_kernel(const RayList src, const RayList dst, const uint32_t* __restrict__ ray_counts,
                                                             uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first, int ssh, const SshLists ssh_lists,
                                                             uint32_t* __restrict__ host_alive, uint32_t* __restrict__ host_stats, int grad)
 {
-  __shared__ uint32_t s_part[16];
+  constexpr uint32_t T = 64u * WAVES;  // threads = scratch slots per block; WAVES groups
+  __shared__ uint32_t s_part[WAVES];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n_in = first ? n_first : counters[C_RAYS0 + parity];   // rays the march that just ran consumed
   const uint32_t n_groups = ((n_in + 255u) & ~255u) >> 6;               // groups it wrote a count for
@@ -693,29 +695,29 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
     if (blockIdx.x == 0 && tid >= C_HIT && tid < C_COUNT) host_stats[tid] = counters[tid];
     return;
   }
-  const uint32_t g0 = blockIdx.x * 16u;
+  const uint32_t g0 = blockIdx.x * (uint32_t)WAVES;
   if (g0 >= n_groups) return;
   // a group's count: survivors in the low byte, rays that were alive when the march began to emit above it
   uint32_t sum = 0;
-  for (uint32_t g = tid; g < g0; g += 1024u) sum += ray_counts[g] & 0xffu;
+  for (uint32_t g = tid; g < g0; g += T) sum += ray_counts[g] & 0xffu;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
   if (lane == 0) s_part[wave] = sum;
   __syncthreads();
   uint32_t before = 0;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) before += s_part[w];
-  // counts of this block's groups: lane l < 16 of every wave holds count[g0 + l]
-  const uint32_t mine = (lane < 16u && g0 + lane < n_groups) ? ray_counts[g0 + lane] & 0xffu : 0u;
+  for (int w = 0; w < WAVES; ++w) before += s_part[w];
+  // counts of this block's groups: lane l < WAVES of every wave holds count[g0 + l]
+  const uint32_t mine = (lane < (uint32_t)WAVES && g0 + lane < n_groups) ? ray_counts[g0 + lane] & 0xffu : 0u;
   uint32_t incl = mine;
 #pragma unroll
-  for (int d = 1; d < 16; d <<= 1) {
+  for (int d = 1; d < WAVES; d <<= 1) {
     const uint32_t y = __shfl_up(incl, d);
     if ((int)lane >= d) incl += y;
   }
   const uint32_t count = __shfl(mine, (int)wave), base = before + __shfl(incl, (int)wave) - count;
-  const uint32_t block_total = __shfl(incl, 15);
-  const bool last_block = g0 + 16u >= n_groups;  // (block-uniform) the block that holds the last group
+  const uint32_t block_total = __shfl(incl, WAVES - 1);
+  const bool last_block = g0 + (uint32_t)WAVES >= n_groups;  // (block-uniform) the block that holds the last group
   if (last_block && tid == 0) { counters[C_RAYS0 + (parity ^ 1)] = before + block_total; *host_alive = before + block_total; }
   if (lane < count) {
     const uint32_t from = ((g0 + wave) << 6) + lane, to = base + lane;
@@ -737,7 +739,7 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
   // to find room next to the persistent blocks of the other half's evaluation kernel.
   if (last_block) {
     uint32_t asum = 0;
-    for (uint32_t g = tid; g < n_groups; g += 1024u) asum += ray_counts[g] >> 8;
+    for (uint32_t g = tid; g < n_groups; g += T) asum += ray_counts[g] >> 8;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) asum += __shfl_xor(asum, d);
     __syncthreads();  // s_part is read above
@@ -745,7 +747,7 @@ __global__ void __launch_bounds__(1024) compact_rays_kernel(const RayList src, c
     __syncthreads();
     if (tid == 0) {
       uint32_t alive_total = 0;
-      for (int w = 0; w < 16; ++w) alive_total += s_part[w];
+      for (int w = 0; w < WAVES; ++w) alive_total += s_part[w];
       const uint32_t records = counters[C_SAMPLES0 + parity];
       unsigned long long* c64 = (unsigned long long*)counters;
       c64[C_STAT_SAMPLES / 2] += (unsigned long long)(grad ? records >> 2 : records);
@@ -1201,22 +1203,23 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   stream_ = Runtime::get().stream;
   if (const char* e = std::getenv("VNR_RM_N_ITERS")) { n_iters_ = std::max(1, std::min(48, std::atoi(e))); n_iters_fixed_ = true; }  // 2.5 KiB of LDS per iteration slot and block
   // streaming mode runs the rays as two halves on two streams (render_streaming); VNR_AMD_RENDER_HALVES=1: one stream
-  if (const char* e = std::getenv("VNR_AMD_RENDER_HALVES")) n_halves_ = std::atoi(e) == 1 ? 1 : 2;
+  if (const char* e = std::getenv("VNR_AMD_RENDER_HALVES")) { n_halves_ = std::max(1, std::min(kMaxParts, std::atoi(e))); n_halves_fixed_ = true; }
+  if (const char* e = std::getenv("VNR_AMD_SMALL_SHARE_PARTS")) small_share_parts_ = std::max(1, std::min(kMaxParts, std::atoi(e)));
   if (const char* e = std::getenv("VNR_AMD_TILE_W")) {  // ray tile shape (diagnostics): 8 -> 8x8, 16 -> 16x4, 32 -> 32x2, 64 -> 64x1
     const int w = std::atoi(e);
     tile_w_log2_ = w == 16 ? 4u : w == 32 ? 5u : w == 64 ? 6u : 3u;
   }
-  counters_.resize(2 * C_COUNT);  // one block of counters per half
+  counters_.resize(kMaxParts * C_COUNT);  // one block of counters per half
   counters_.zero(stream_);
-  VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, (2 * 256 + 2 * C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
-  VNR_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+  VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, kMaxParts * (256 + C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
+  for (int i = 1; i < kMaxParts; ++i) VNR_HIP_CHECK(hipStreamCreateWithFlags(&part_streams_[i], hipStreamNonBlocking));
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 }
 
 Renderer::~Renderer()
 {
   if (stream_) (void)hipStreamSynchronize(stream_);
-  if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }
+  for (int i = 1; i < kMaxParts; ++i) if (part_streams_[i]) { (void)hipStreamSynchronize(part_streams_[i]); (void)hipStreamDestroy(part_streams_[i]); }
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   for (int i = 0; i < 2; ++i) if (host_fb_[i]) (void)hipHostFree(host_fb_[i]);
   if (host_counts_) (void)hipHostFree(host_counts_);
@@ -1259,7 +1262,7 @@ void Renderer::ensure_queues(size_t n_pixels, int n_iters, bool gradient)
   const int iters = std::max(n_iters, queue_iters_);
   const bool grad = gradient || queue_grad_;
   q_u32_.resize(6 * P);
-  ray_counts_.resize(P / 64 + 64);   // survivors per 64-ray group (P is a multiple of 64; slack for the round-up to 256 rays)
+  ray_counts_.resize(P / 64 + 64 + 8 * kMaxParts);   // survivors per 64-ray group (P is a multiple of 64; slack for the round-up to 256 rays)
   q_f32_.resize(18 * P);
   q_i32_.resize(6 * P);
   queue_.resize(P * iters * (grad ? 4 : 1));          // 4 records per sample with gradient shading
@@ -1473,7 +1476,9 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
   // and fits next to it (registers and LDS: DESIGN.md 4.2).
   const uint32_t row_items = p_all.tiles_per_row * 64u;
   const uint32_t R = p_all.n_local / row_items;  // local tile rows
-  const int H = (n_halves_ == 2 && R >= 2) ? 2 : 1;
+  // a small share is bound by the length of the kernel chain of one part, not by throughput: more, shorter chains side by side
+  const int want = (!n_halves_fixed_ && p_all.n_local <= 196608u) ? small_share_parts_ : n_halves_;
+  const int H = (int)std::min<uint32_t>((uint32_t)want, std::max(R, 1u));
   const uint32_t P_total = p_all.n_local;
   const bool grad = pass_mode == M_GRADIENT;
   const bool ssh = pass_mode == M_SSH;
@@ -1502,15 +1507,15 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     size_t s_max;
     uint32_t it = 0, used = 0;
     bool done = false;
-  } half[2];
+  } half[kMaxParts];
   size_t off = 0;
   for (int h = 0; h < H; ++h) {
     Half& hf = half[h];
     hf.p = p_all;
-    if (H == 2) {
-      hf.p.il_parts = p_all.il_parts * 2u;
+    if (H > 1) {
+      hf.p.il_parts = p_all.il_parts * (uint32_t)H;
       hf.p.il_part = p_all.il_part + p_all.il_parts * (uint32_t)h;
-      hf.p.n_local = ((R + 1u - (uint32_t)h) / 2u) * row_items;
+      hf.p.n_local = ((R + (uint32_t)(H - 1 - h)) / (uint32_t)H) * row_items;
     }
     for (int b = 0; b < 2; ++b) {
       hf.rl[b].pixel_index = q_u32_.ptr + (size_t)(0 + b) * QP + off;
@@ -1538,16 +1543,16 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     hf.c = counters_.ptr + (size_t)h * C_COUNT;
     hf.rc = ray_counts_.ptr + off / 64 + (size_t)h * 8;   // halves are multiples of 64 rays; 8 groups of slack each
     hf.hc = host_counts_ + (size_t)h * 256;
-    hf.hs = host_counts_ + 512 + (size_t)h * C_COUNT;
-    hf.s = h == 0 ? stream_ : stream2_;
+    hf.hs = host_counts_ + kMaxParts * 256 + (size_t)h * C_COUNT;
+    hf.s = h == 0 ? stream_ : part_streams_[h];
     hf.s_max = (size_t)hf.p.n_local * hf.p.n_iters * (grad ? 4 : 1);   // records the evaluation kernel may see
     off += hf.p.n_local;
   }
 
-  VNR_HIP_CHECK(hipMemsetAsync(counters_.ptr, 0, 2 * C_COUNT * sizeof(uint32_t), stream_));
-  if (H == 2) {  // fork: the second stream starts after everything queued on the render stream so far
+  VNR_HIP_CHECK(hipMemsetAsync(counters_.ptr, 0, (size_t)H * C_COUNT * sizeof(uint32_t), stream_));
+  if (H > 1) {  // fork: the other streams start after everything queued on the render stream so far
     VNR_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
-    VNR_HIP_CHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+    for (int h = 1; h < H; ++h) VNR_HIP_CHECK(hipStreamWaitEvent(part_streams_[h], ev_fork_, 0));
   }
   const size_t shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + 16 * sizeof(uint32_t) + (size_t)p_all.n_iters * 256 * sizeof(uint16_t);
   const size_t shmem_compose = shmem + (p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0);
@@ -1603,8 +1608,15 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
     // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
-    compact_rays_kernel<<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
-                                                                  hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
+    // 1024-thread blocks need 4 free wave slots on every SIMD of one CU at once, which the other half's evaluation kernel
+    // rarely leaves: a small share (where the wait shows) packs with 256-thread blocks
+    static const uint32_t small_limit = [] { const char* e = std::getenv("VNR_AMD_COMPACT_SMALL_LIMIT"); return e ? (uint32_t)std::atoll(e) : 262144u; }();  // diagnostics
+    if (P <= small_limit)
+      compact_rays_kernel<4><<<div_round_up(P, 256), 256, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
+                                                                     hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
+    else
+      compact_rays_kernel<16><<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
+                                                                        hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
     VNR_HIP_CHECK(hipGetLastError());
     ++hf.it;
     if (hf.it >= max_iterations) hf.done = true;

@@ -78,9 +78,12 @@ private:
   // along the view direction (renderer.cpp:98-101), so it persists across frames
   vec3f light_dir_ = {0.7f, 0.9f, 0.4f};
   uint32_t tile_w_log2_ = 3;  // ray tiles of 2^w x 2^(6-w) pixels (render.hip map_pixel)
-  int n_halves_ = 2;  // streaming mode: rays dealt to 2 halves on 2 streams (march of one overlaps inference of the other)
-  uint32_t predicted_iterations_[2][2] = {{0, 0}, {0, 0}};   // [camera pass | shadow pass][half]
-  hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  static constexpr int kMaxParts = 4;
+  int n_halves_ = 2;  // streaming mode: rays dealt to n parts on n streams (march of one overlaps inference of another)
+  bool n_halves_fixed_ = false;
+  int small_share_parts_ = 2;  // parts of a share of at most 196 608 pixels
+  uint32_t predicted_iterations_[2][kMaxParts] = {};   // [camera pass | shadow pass][half]
+  hipStream_t stream_ = nullptr, part_streams_[kMaxParts] = {};
   hipEvent_t ev_fork_ = nullptr;
 
   // framebuffer: double-buffered device + pinned host (framebuffer.h:7-98)
@@ -105,7 +108,7 @@ private:
   uint32_t* host_counts_ = nullptr;  // pinned rings of alive-ray counts, 2 x 256
   size_t queue_pixels_ = 0;
   int queue_iters_ = 0;
-  std::vector<hipEvent_t> events_[2];  // per half: (before, after) the evaluation kernel of each iteration
+  std::vector<hipEvent_t> events_[kMaxParts];  // per half: (before, after) the evaluation kernel of each iteration
   FrameStats stats_;
   std::vector<float> iter_ms_;
 };

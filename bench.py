@@ -152,6 +152,7 @@ def main():
     # ---- warm-up + timed region ---------------------------------------------------------------------------------
     for _ in range(a.warmup):
         sr.render()
+    sr.flush()
     dist.barrier(ctx)
     t0 = time.perf_counter()
     samples = slots = 0
@@ -162,6 +163,7 @@ def main():
         st = api.vnrRendererGetFrameStats(ren)
         samples += st["n_samples"]; slots += st["n_reference_slots"]; infer_ms += st["infer_kernel_ms"]
         launches += st["infer_kernel_launches"]; iters = st["n_iterations"]
+    sr.flush()   # N > 1: the gather of the last frame (ShardedRenderer pipelines render k with gather k - 1); every frame is rendered AND gathered inside the timed region
     dist.barrier(ctx)
     elapsed = time.perf_counter() - t0
     rays_hit = st["n_rays_hit"]

@@ -255,6 +255,11 @@ typedef struct {
 } vnrAmdFrameStats;
 int  vnrAmdRendererGetFrameStats(vnrAmdRenderer, vnrAmdFrameStats*);
 int  vnrAmdRendererSetProfiling(vnrAmdRenderer, int enable);
+/* Asynchronous frames (new; the reference's render() synchronises once per iteration, method_raymarching.cu:923-929): with
+ * a device framebuffer (SetOutputAsDeviceFramebuffer) and rendering modes 5 / 6 / 8 / 9, vnrAmdRender returns once the frame's
+ * predicted iterations are enqueued and vnrAmdRendererMapFrame / GetFrameStats / the next vnrAmdRender complete it.  The caller
+ * must not change the volume between Render and MapFrame.  Off by default. */
+int  vnrAmdRendererSetAsync(vnrAmdRenderer, int enable);
 /* diagnostics: device pointers to the compacted sample queue ([n][3] fp32) and the counter block, plus the
  * per-iteration duration (ms) of the sample-evaluation kernel in the last profiled frame */
 int  vnrAmdRendererDebugQueues(vnrAmdRenderer, const float** d_coords, const uint32_t** d_counters, float* iteration_ms, int max_iterations);

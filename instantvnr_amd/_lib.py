@@ -169,6 +169,7 @@ def lib():
     sig("vnrAmdRendererSetPixelInterleave", I, P, U32, U32, U32)
     sig("vnrAmdRendererGetFrameStats", I, P, C.POINTER(FrameStats))
     sig("vnrAmdRendererSetProfiling", I, P, I)
+    sig("vnrAmdRendererSetAsync", I, P, I)
     sig("vnrAmdRendererDebugQueues", I, P, C.POINTER(P), C.POINTER(P), FP, I)
     sig("vnrAmdReleaseRenderer", None, P)
     sig("vnrAmdMemoryQuery", None, C.POINTER(SZ), C.POINTER(SZ))

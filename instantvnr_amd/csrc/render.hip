@@ -1197,6 +1197,36 @@ __global__ void __launch_bounds__(1024) pt_compact_kernel(const PtRays src, cons
 }
 
 // ================================================================================================ Renderer (host)
+struct PartState {
+  RenderParams p;
+  RayList rl[2];
+  SshLists ssh;
+  vec4f* queue;
+  vec2f* vd[2];
+  uint32_t* c;         // device counters of this half
+  uint32_t* rc;        // survivors per 64-ray group
+  uint32_t* hc;        // pinned ring of alive-ray counts (written by compact_rays_kernel)
+  uint32_t* hs;        // pinned copy of this half's counters as of the last compact_rays_kernel
+  hipStream_t s;
+  size_t s_max;
+  uint32_t it = 0, used = 0;
+  bool done = false;
+};
+
+// One pass of the streaming loop between its two halves: everything launch_iteration / finish_streaming need.  With
+// set_async(true) a frame stays in this state ("pending") from render() until the next call that needs its result.
+struct Renderer::StreamingFrame {
+  bool pending = false;
+  int H = 0, pass_mode = 0;
+  bool grad = false, ssh = false;
+  NeuralVolume* nv = nullptr;
+  size_t shmem = 0, shmem_compose = 0;
+  uint32_t max_iterations = 240;
+  uint32_t* predicted = nullptr;
+  RenderParams p_all;
+  PartState part[Renderer::kMaxParts];
+};
+
 Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volume))
 {
   if (!Runtime::get().ready()) Runtime::get().init(-1);
@@ -1228,6 +1258,7 @@ Renderer::~Renderer()
 
 void Renderer::resize(int w, int h)
 {
+  finish_pending();
   if (w <= 0 || h <= 0) throw std::runtime_error("invalid framebuffer size");
   VNR_HIP_CHECK(hipStreamSynchronize(stream_));
   width_ = w; height_ = h;
@@ -1248,6 +1279,7 @@ void Renderer::resize(int w, int h)
 
 void Renderer::set_transfer_function(const TransferFunctionData& t)
 {
+  finish_pending();
   // api.cpp:485-498: the volume refreshes its macrocell max-opacity, the renderer keeps the lookup tables
   volume_->set_transfer_function(t, stream_);
   tfn_.set(t, volume_->desc.range_lo, volume_->desc.range_hi, stream_);
@@ -1272,8 +1304,14 @@ void Renderer::ensure_queues(size_t n_pixels, int n_iters, bool gradient)
   queue_grad_ = grad;
 }
 
+void Renderer::finish_pending()
+{
+  if (frame_ && frame_->pending) finish_streaming();
+}
+
 void Renderer::render()
 {
+  finish_pending();
   if (width_ <= 0 || height_ <= 0) return;  // renderer.cpp:63
   MacroCell& mc = volume_->macrocell();
   if (!mc.allocated()) throw std::runtime_error("volume has no macrocell");
@@ -1357,7 +1395,8 @@ void Renderer::render()
     case 9:   // VNR_RAYMARCHING_GRADIENT_SHADING_IN_SHADER (:1068-1070): mode 8 with sampleGradient's boundary flip, uninterrupted
     case 5:   // VNR_RAYMARCHING_NO_SHADING_SAMPLE_STREAMING
     case 8:   // VNR_RAYMARCHING_GRADIENT_SHADING_SAMPLE_STREAMING
-      render_streaming(p, p.shading_mode == 1u ? M_GRADIENT : M_NONE);
+      // asynchronous frames (set_async): the pass is left pending after its predicted iterations have been enqueued
+      render_streaming(p, p.shading_mode == 1u ? M_GRADIENT : M_NONE, async_ && skip_download_);
       break;
     case 11:  // VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_SAMPLE_STREAMING: camera pass, then one shadow ray per pixel (:968-971)
       render_streaming(p, M_SSH);
@@ -1467,7 +1506,66 @@ void Renderer::render_pathtracing(const RenderParams& p)
   stats_.n_iterations += used > 0 ? used - 1 : 0;
 }
 
-void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
+// one iteration of one half: march(it) -> evaluate the compacted samples -> clear the counters march(it+1) appends to
+void Renderer::launch_iteration(int h)
+{
+  StreamingFrame& f = *frame_;
+  PartState* half = f.part;
+  const int pass_mode = f.pass_mode, H = f.H;
+  const bool grad = f.grad, ssh = f.ssh;
+  NeuralVolume* nv = f.nv;
+  const size_t shmem = f.shmem, shmem_compose = f.shmem_compose;
+  const uint32_t max_iterations = f.max_iterations;
+  {
+    PartState& hf = half[h];
+    const uint32_t it = hf.it;
+    const int parity = (int)(it & 1u);
+    const uint32_t P = hf.p.n_local;
+    uint32_t* c = hf.c;
+    // march(it): reads the dense ray list rl[0] (count: counter `parity`), leaves the survivors of every 64-ray group in the
+    // group's slots of the scratch list rl[1] and appends their samples to queue `parity`
+    {
+      const bool first = it == 0;
+      const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), first ? 4096u : 2048u);
+      const size_t lds = first ? shmem : shmem_compose;
+      const vec2f* vd_in = hf.vd[parity ^ 1];
+      vec2f* vd_out = hf.vd[parity];
+#define VNR_MARCH(FIRST_, MODE_) march_kernel<FIRST_, MODE_><<<blocks, 256, lds, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], vd_in, hf.queue, vd_out, c, hf.rc, parity, hf.ssh)
+      switch (pass_mode) {
+      case M_GRADIENT: if (first) VNR_MARCH(true, M_GRADIENT); else VNR_MARCH(false, M_GRADIENT); break;
+      case M_SSH: if (first) VNR_MARCH(true, M_SSH); else VNR_MARCH(false, M_SSH); break;
+      case M_SHADOW: if (first) VNR_MARCH(true, M_SHADOW); else VNR_MARCH(false, M_SHADOW); break;
+      default: if (first) VNR_MARCH(true, M_NONE); else VNR_MARCH(false, M_NONE); break;
+      }
+#undef VNR_MARCH
+    }
+    VNR_HIP_CHECK(hipGetLastError());
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it], hf.s));
+    if (nv) {
+      // a record's 4th word is the float index of its result in this arena (stride 1)
+      nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 1, c + C_SAMPLES0 + parity, hf.s_max, hf.s, (uint32_t)H);
+    } else {
+      const uint32_t blocks = std::min<uint32_t>(div_round_up(hf.s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
+      gt_sample_kernel<<<blocks, 256, 0, hf.s>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, (float*)hf.vd[parity]);
+    }
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
+    // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
+    // 1024-thread blocks need 4 free wave slots on every SIMD of one CU at once, which the other half's evaluation kernel
+    // rarely leaves: a small share (where the wait shows, DESIGN.md 6) packs with 256-thread blocks
+    static const uint32_t small_limit = [] { const char* e = std::getenv("VNR_AMD_COMPACT_SMALL_LIMIT"); return e ? (uint32_t)std::atoll(e) : 262144u; }();  // diagnostics
+    if (P <= small_limit)
+      compact_rays_kernel<4><<<div_round_up(P, 256), 256, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
+                                                                     hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
+    else
+      compact_rays_kernel<16><<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
+                                                                        hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
+    VNR_HIP_CHECK(hipGetLastError());
+    ++hf.it;
+    if (hf.it >= max_iterations) hf.done = true;
+  }
+}
+
+void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool defer)
 {
   // The rank's rays are dealt to `n_halves_` independent halves (alternate local tile rows; same mechanism as the
   // multi-GPU interleave), each with its own ray lists, sample queue, counters and HIP stream.  The arithmetic per ray
@@ -1493,24 +1591,13 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
   NeuralVolume* nv = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get()) : nullptr;
   if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
 
-  struct Half {
-    RenderParams p;
-    RayList rl[2];
-    SshLists ssh;
-    vec4f* queue;
-    vec2f* vd[2];
-    uint32_t* c;         // device counters of this half
-    uint32_t* rc;        // survivors per 64-ray group
-    uint32_t* hc;        // pinned ring of alive-ray counts (written by compact_rays_kernel)
-    uint32_t* hs;        // pinned copy of this half's counters as of the last compact_rays_kernel
-    hipStream_t s;
-    size_t s_max;
-    uint32_t it = 0, used = 0;
-    bool done = false;
-  } half[kMaxParts];
+  if (!frame_) frame_.reset(new StreamingFrame());
+  StreamingFrame& f = *frame_;
+  PartState* half = f.part;
+  for (int h = 0; h < kMaxParts; ++h) { half[h].it = 0; half[h].used = 0; half[h].done = false; }
   size_t off = 0;
   for (int h = 0; h < H; ++h) {
-    Half& hf = half[h];
+    PartState& hf = half[h];
     hf.p = p_all;
     if (H > 1) {
       hf.p.il_parts = p_all.il_parts * (uint32_t)H;
@@ -1573,55 +1660,8 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
       while (events_[h].size() < 2 * max_iterations) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreate(&e)); events_[h].push_back(e); }
   }
 
-  // one iteration of one half: march(it) -> evaluate the compacted samples -> clear the counters march(it+1) appends to
-  auto launch_iteration = [&](int h) {
-    Half& hf = half[h];
-    const uint32_t it = hf.it;
-    const int parity = (int)(it & 1u);
-    const uint32_t P = hf.p.n_local;
-    uint32_t* c = hf.c;
-    // march(it): reads the dense ray list rl[0] (count: counter `parity`), leaves the survivors of every 64-ray group in the
-    // group's slots of the scratch list rl[1] and appends their samples to queue `parity`
-    {
-      const bool first = it == 0;
-      const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), first ? 4096u : 2048u);
-      const size_t lds = first ? shmem : shmem_compose;
-      const vec2f* vd_in = hf.vd[parity ^ 1];
-      vec2f* vd_out = hf.vd[parity];
-#define VNR_MARCH(FIRST_, MODE_) march_kernel<FIRST_, MODE_><<<blocks, 256, lds, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], vd_in, hf.queue, vd_out, c, hf.rc, parity, hf.ssh)
-      switch (pass_mode) {
-      case M_GRADIENT: if (first) VNR_MARCH(true, M_GRADIENT); else VNR_MARCH(false, M_GRADIENT); break;
-      case M_SSH: if (first) VNR_MARCH(true, M_SSH); else VNR_MARCH(false, M_SSH); break;
-      case M_SHADOW: if (first) VNR_MARCH(true, M_SHADOW); else VNR_MARCH(false, M_SHADOW); break;
-      default: if (first) VNR_MARCH(true, M_NONE); else VNR_MARCH(false, M_NONE); break;
-      }
-#undef VNR_MARCH
-    }
-    VNR_HIP_CHECK(hipGetLastError());
-    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it], hf.s));
-    if (nv) {
-      // a record's 4th word is the float index of its result in this arena (stride 1)
-      nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 1, c + C_SAMPLES0 + parity, hf.s_max, hf.s, (uint32_t)H);
-    } else {
-      const uint32_t blocks = std::min<uint32_t>(div_round_up(hf.s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
-      gt_sample_kernel<<<blocks, 256, 0, hf.s>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, (float*)hf.vd[parity]);
-    }
-    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
-    // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
-    // 1024-thread blocks need 4 free wave slots on every SIMD of one CU at once, which the other half's evaluation kernel
-    // rarely leaves: a small share (where the wait shows, DESIGN.md 6) packs with 256-thread blocks
-    static const uint32_t small_limit = [] { const char* e = std::getenv("VNR_AMD_COMPACT_SMALL_LIMIT"); return e ? (uint32_t)std::atoll(e) : 262144u; }();  // diagnostics
-    if (P <= small_limit)
-      compact_rays_kernel<4><<<div_round_up(P, 256), 256, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
-                                                                     hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
-    else
-      compact_rays_kernel<16><<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
-                                                                        hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
-    VNR_HIP_CHECK(hipGetLastError());
-    ++hf.it;
-    if (hf.it >= max_iterations) hf.done = true;
-  };
-
+  f.H = H; f.pass_mode = pass_mode; f.grad = grad; f.ssh = ssh; f.nv = nv; f.shmem = shmem; f.shmem_compose = shmem_compose;
+  f.max_iterations = max_iterations; f.predicted = predicted; f.p_all = p_all;
   // phase 1: the iterations the previous frame needed, launched for both halves alternately without any host sync;
   // phase 2: past that, look at the alive-ray count of the iteration just launched before launching another one.
   for (;;) {
@@ -1630,10 +1670,25 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
       if (!half[h].done && half[h].it < predicted[h]) { launch_iteration(h); launched = true; }
     if (!launched) break;
   }
+  f.pending = true;
+  if (!defer) finish_streaming();
+}
+
+// phase 2 of a pass and its bookkeeping: past the predicted iterations, look at the alive-ray count of the iteration just
+// launched before launching another one; then the statistics.  Ends the "pending" state of an asynchronous frame.
+void Renderer::finish_streaming()
+{
+  StreamingFrame& f = *frame_;
+  if (!f.pending) return;
+  f.pending = false;
+  PartState* half = f.part;
+  const int H = f.H, pass_mode = f.pass_mode;
+  uint32_t* predicted = f.predicted;
+  const RenderParams& p_all = f.p_all;
   for (;;) {
     bool pending = false;
     for (int h = 0; h < H; ++h) {
-      Half& hf = half[h];
+      PartState& hf = half[h];
       if (hf.done) continue;
       if (hf.it > 0) {
         VNR_HIP_CHECK(hipStreamSynchronize(hf.s));
@@ -1649,7 +1704,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
   uint32_t pass_iterations = 0;
   uint64_t n_samples = 0, n_refrays = 0;
   for (int h = 0; h < H; ++h) {
-    Half& hf = half[h];
+    PartState& hf = half[h];
     VNR_HIP_CHECK(hipStreamSynchronize(hf.s));
     uint32_t used = hf.it;
     while (used > 1 && hf.hc[(used - 2) & 255u] == 0) --used;  // trailing speculative no-op iterations
@@ -1681,6 +1736,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode)
 
 const float* Renderer::map_frame()
 {
+  finish_pending();
   VNR_HIP_CHECK(hipStreamSynchronize(stream_));
   const float* out = skip_download_ ? (const float*)fb_[fb_cur_].ptr : (const float*)host_fb_[fb_cur_];
   fb_cur_ ^= 1;  // framebuffer.safe_swap

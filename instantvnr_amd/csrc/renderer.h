@@ -28,19 +28,24 @@ public:
   ~Renderer();
 
   void resize(int w, int h);                         // renderer.h:96-112
-  void set_camera(const CameraData& c) { camera_ = c; reset_ = true; }
+  void set_camera(const CameraData& c) { finish_pending(); camera_ = c; reset_ = true; }
   void set_transfer_function(const TransferFunctionData& t);
-  void set_mode(int m) { mode_ = m; reset_ = true; } // renderer.h:139-146
+  void set_mode(int m) { finish_pending(); mode_ = m; reset_ = true; } // renderer.h:139-146
   void set_sampling_rate(float r) { sampling_rate_ = r; reset_ = true; }
   void set_density_scale(float s) { density_scale_ = s; reset_ = true; }
   void reset_accumulation() { reset_ = true; }
-  void set_device_output(bool e) { skip_download_ = e; }
+  void set_device_output(bool e) { finish_pending(); skip_download_ = e; }
   void set_pixel_range(uint32_t lo, uint32_t hi) { pixel_lo_ = lo; pixel_hi_ = hi; reset_ = true; }
   void set_profiling(bool e) { profiling_ = e; }
+  // Asynchronous frames (device framebuffer output, single-pass streaming modes 5 / 6 / 8 / 9): render() returns once the
+  // iterations the previous frame needed are enqueued; map_frame(), stats(), the next render() and every call that changes
+  // what the frame reads complete it first (further iterations if rays are still alive).  Off by default: the caller
+  // must not change the volume (training, decoding, time step) between render() and map_frame().
+  void set_async(bool e) { finish_pending(); async_ = e; }
   // diagnostics: the compacted sample queue of the last iteration and per-iteration kernel times of the last frame
-  const float* debug_coords() const { return (const float*)queue_.ptr; }  // 16-byte records {x, y, z, slot}
-  const uint32_t* debug_counters() const { return counters_.ptr; }
-  const std::vector<float>& debug_iteration_ms() const { return iter_ms_; }
+  const float* debug_coords() { finish_pending(); return (const float*)queue_.ptr; }  // 16-byte records {x, y, z, slot}
+  const uint32_t* debug_counters() { finish_pending(); return counters_.ptr; }
+  const std::vector<float>& debug_iteration_ms() { finish_pending(); return iter_ms_; }
   // rank `part` of `parts` renders the pixel blocks b with b % parts == part (block = `block` consecutive pixels)
   void set_pixel_interleave(uint32_t block, uint32_t parts, uint32_t part)
   {
@@ -50,12 +55,16 @@ public:
 
   void render();                 // renderer.cpp:59-140
   const float* map_frame();      // renderer.h:84-94
-  const FrameStats& stats() const { return stats_; }
+  const FrameStats& stats() { finish_pending(); return stats_; }
   int width() const { return width_; }
   int height() const { return height_; }
 
 private:
-  void render_streaming(const RenderParams& p, int pass_mode);   // one iterative_raymarching_loop<MODE> (method_raymarching.cu:931-958)
+  struct StreamingFrame;   // render.hip
+  void render_streaming(const RenderParams& p, int pass_mode, bool defer = false);   // one iterative_raymarching_loop<MODE> (method_raymarching.cu:931-958)
+  void launch_iteration(int part);
+  void finish_streaming();
+  void finish_pending();
   void render_monolithic(const RenderParams& p);
   void render_pathtracing(const RenderParams& p);   // do_path_tracing_iterative (method_pathtracing.cu:786-806)
   void ensure_queues(size_t n_pixels, int n_iters, bool gradient);
@@ -68,7 +77,8 @@ private:
   int width_ = 0, height_ = 0;
   uint32_t pixel_lo_ = 0, pixel_hi_ = 0xffffffffu;
   uint32_t il_block_ = 8, il_parts_ = 1, il_part_ = 0;
-  bool reset_ = true, skip_download_ = false, profiling_ = false;
+  bool reset_ = true, skip_download_ = false, profiling_ = false, async_ = false;
+  std::unique_ptr<StreamingFrame> frame_;
   int frame_index_ = 0;
   // samples per ray and iteration, VNR_RM_N_ITERS (method_raymarching.cu:30-40; 16 there, tuned on the authors' GPU).  Frames
   // depend on it only through the last bit of samples at batch boundaries (0.2 % of the pixels, max 4e-5); on MI355X 24 is the fastest (bench workload: 16: 122, 24: 129, 32: 126 frames/s)

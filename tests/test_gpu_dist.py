@@ -114,13 +114,82 @@ def test_sharded_renderer_object_on_a_one_rank_group(group):
     plain = renderer()
     sharded = vdist.ShardedRenderer(OneRank(0, 1, 0, "nccl"), renderer(), size[0], size[1])
     assert sharded.even
-    for _ in range(4):   # accumulation over frames, alternating framebuffers
+    # the object pipelines: render() enqueues frame k (asynchronous frames), gathers frame k - 1 and returns it
+    wants = []
+    for k in range(5):   # accumulation over frames, alternating framebuffers
         api.vnrRender(plain)
-        want = api.vnrRendererMapFrame(plain).reshape(-1, 4).copy()
+        wants.append(api.vnrRendererMapFrame(plain).reshape(-1, 4).copy())
         full = sharded.render()
-        torch.cuda.synchronize()
-        assert np.array_equal(full.cpu().numpy(), want)
+        if k == 0:
+            assert full is None
+        else:
+            torch.cuda.synchronize()
+            assert np.array_equal(full.cpu().numpy(), wants[k - 1])
+    full = sharded.flush()
+    torch.cuda.synchronize()
+    assert np.array_equal(full.cpu().numpy(), wants[-1])
+    assert sharded.flush() is None
     assert len(sharded._views) == 2
+    # frame statistics complete a pending frame; a render after a flush starts the pipeline again
+    assert sharded.render() is None
+    st = api.vnrRendererGetFrameStats(sharded.r)
+    assert st["n_samples"] > 0 and st["n_iterations"] > 0
+    api.vnrRender(plain)
+    want = api.vnrRendererMapFrame(plain).reshape(-1, 4).copy()
+    full = sharded.flush()
+    torch.cuda.synchronize()
+    assert np.array_equal(full.cpu().numpy(), want)
+
+
+def test_asynchronous_frames_equal_synchronous_ones(group):
+    """vnrAmdRendererSetAsync: vnrRender returns after enqueueing the iterations the previous frame needed; MapFrame completes the
+    frame.  Frames must equal the synchronous renderer's, also when a frame needs MORE iterations than the previous one (the
+    camera moves from far to near and the sampling rate rises: the prediction is too short and MapFrame has to launch the rest) and when
+    it needs fewer."""
+    import torch
+    size = (96, 64)
+    n_pixels = size[0] * size[1]
+    vol = syn.analytic_volume(48)
+    sv = api.vnrCreateSimpleVolume(vol)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    os.environ["VNR_RM_N_ITERS"] = "4"   # many iterations per frame on a small volume
+    try:
+        def renderer(asynchronous):
+            r = api.vnrCreateRenderer(sv)
+            api.vnrRendererSetTransferFunction(r, tfn)
+            api.vnrRendererSetFramebufferSize(r, size)
+            api.vnrRendererSetMode(r, 5)
+            api.vnrRendererSetOutputAsDeviceFramebuffer(r, True)
+            check(lib().vnrAmdRendererSetAsync(r.h, 1 if asynchronous else 0))
+            return r
+        r_sync, r_async = renderer(False), renderer(True)
+    finally:
+        del os.environ["VNR_RM_N_ITERS"]
+    iterations = []
+    for distance, rate in ((3.0, 1.0), (3.0, 1.0), (0.9, 4.0), (0.9, 4.0), (0.9, 1.0), (3.0, 0.5), (1.5, 2.0)):
+        cam = syn.oblique_camera((48, 48, 48), distance_scale=distance)
+        frames = []
+        for r in (r_sync, r_async):
+            camera = api.vnrCreateCamera()
+            api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+            api.vnrRendererSetCamera(r, camera)
+            api.vnrRendererSetVolumeSamplingRate(r, rate)
+            api.vnrRender(r)
+            ptr = api.vnrRendererMapFrame(r)
+            frames.append(vdist.as_torch(ptr, (n_pixels, 4)).cpu().numpy().copy())
+        assert np.array_equal(frames[0], frames[1])
+        a, b = api.vnrRendererGetFrameStats(r_sync), api.vnrRendererGetFrameStats(r_async)
+        assert a["n_samples"] == b["n_samples"] and a["n_iterations"] == b["n_iterations"] and a["n_rays_hit"] == b["n_rays_hit"]
+        iterations.append(a["n_iterations"])
+    assert max(iterations) > min(iterations) + 1   # the scene really changed its iteration count
+    # statistics before MapFrame complete the frame too
+    api.vnrRender(r_async)
+    st = api.vnrRendererGetFrameStats(r_async)
+    assert st["n_iterations"] == iterations[-1]
 
 
 def test_gradient_allreduce_step_equals_plain_step(group):

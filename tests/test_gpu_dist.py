@@ -141,7 +141,7 @@ def test_sharded_renderer_object_on_a_one_rank_group(group):
     assert np.array_equal(full.cpu().numpy(), want)
 
 
-def test_asynchronous_frames_equal_synchronous_ones(group):
+def test_asynchronous_frames_equal_synchronous_ones(group, monkeypatch):
     """vnrAmdRendererSetAsync: vnrRender returns after enqueueing the iterations the previous frame needed; MapFrame completes the
     frame.  Frames must equal the synchronous renderer's, also when a frame needs MORE iterations than the previous one (the
     camera moves from far to near and the sampling rate rises: the prediction is too short and MapFrame has to launch the rest) and when
@@ -156,19 +156,17 @@ def test_asynchronous_frames_equal_synchronous_ones(group):
     api.vnrTransferFunctionSetColor(tfn, colors)
     api.vnrTransferFunctionSetAlpha(tfn, alphas)
     api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
-    os.environ["VNR_RM_N_ITERS"] = "4"   # many iterations per frame on a small volume
-    try:
-        def renderer(asynchronous):
-            r = api.vnrCreateRenderer(sv)
-            api.vnrRendererSetTransferFunction(r, tfn)
-            api.vnrRendererSetFramebufferSize(r, size)
-            api.vnrRendererSetMode(r, 5)
-            api.vnrRendererSetOutputAsDeviceFramebuffer(r, True)
-            check(lib().vnrAmdRendererSetAsync(r.h, 1 if asynchronous else 0))
-            return r
-        r_sync, r_async = renderer(False), renderer(True)
-    finally:
-        del os.environ["VNR_RM_N_ITERS"]
+    monkeypatch.setenv("VNR_RM_N_ITERS", "4")   # read when a renderer is created: many iterations per frame on a small volume
+
+    def renderer(asynchronous):
+        r = api.vnrCreateRenderer(sv)
+        api.vnrRendererSetTransferFunction(r, tfn)
+        api.vnrRendererSetFramebufferSize(r, size)
+        api.vnrRendererSetMode(r, 5)
+        api.vnrRendererSetOutputAsDeviceFramebuffer(r, True)
+        check(lib().vnrAmdRendererSetAsync(r.h, 1 if asynchronous else 0))
+        return r
+    r_sync, r_async = renderer(False), renderer(True)
     iterations = []
     for distance, rate in ((3.0, 1.0), (3.0, 1.0), (0.9, 4.0), (0.9, 4.0), (0.9, 1.0), (3.0, 0.5), (1.5, 2.0)):
         cam = syn.oblique_camera((48, 48, 48), distance_scale=distance)

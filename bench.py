@@ -275,7 +275,7 @@ def main():
     # the same stream configuration it was measured with.
     default_workload = (a.size, a.fb, a.levels, a.features, a.log2_hashmap_size, a.hidden_layers, a.per_level_scale,
                         a.train_steps, a.opacity_scale, a.camera_distance, a.mode) == (1024, 1024, 16, 2, 22, 3, 0.0, 1500, 0.06, 1.1, 5)
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k_pmc_traffic.json")
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_l_pmc_traffic.json")
     brick = api.neural_brick_image(nv)["in_use"]
     if default_workload and ctx.world == 1 and brick and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
@@ -283,13 +283,13 @@ def main():
         roofline["traffic"] = round(leg["traffic_per_launch"])
         roofline["traffic_unit"] = "bytes per launch (L2<->fabric reads x2-corrected + writes; includes Infinity-Cache hits)"
         roofline["algorithmic_bytes_per_launch"] = round(samples * bytes_per_sample / max(launches, 1))
-        roofline["traffic_note"] = ("measured in separate rocprofv3 --pmc passes of this command, not in this run: profiles/r01_k_pmc_traffic.json "
+        roofline["traffic_note"] = ("measured in separate rocprofv3 --pmc passes of this command, not in this run: profiles/r01_l_pmc_traffic.json "
                                     "(traffic/algorithmic = %.2f; 2.09 before the brick image, profiles/r01_pmc_traffic.json)" % leg["traffic_over_algorithmic"])
         if "alone" in roofline:
             t1 = pmc["one_stream"].get("traffic_per_launch")
             roofline["alone"]["traffic"] = round(t1) if t1 else None
     else:
-        roofline["traffic_note"] = "null: the committed PMC passes (profiles/r01_k_pmc_traffic.json) describe the default workload on one GPU with the brick image"
+        roofline["traffic_note"] = "null: the committed PMC passes (profiles/r01_l_pmc_traffic.json) describe the default workload on one GPU with the brick image"
     out = {
         "metric": "fps at 1024^2 on 1024^3 volume" if (a.size, a.fb, a.mode) == (1024, 1024, 5) else f"fps at {a.fb}^2 on {a.size}^3 volume, rendering mode {a.mode}" if a.mode != 5 else f"fps at {a.fb}^2 on {a.size}^3 volume",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,

@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-psnr", action="store_true")
     p.add_argument("--no-alone", action="store_true", help="skip the un-timed one-stream leg (roofline.alone)")
+    p.add_argument("--no-kernel-events", action="store_true", help="diagnostics: no HIP events around the evaluation kernel (roofline.achieved reads 0)")
     p.add_argument("--mode", type=int, default=5, choices=(5, 8, 11, 14),
                    help="rendering mode: 5 = sample streaming (BASELINE metric, default), 8 = the same with gradient shading (4 evaluations per sample)")
     return p.parse_args()
@@ -104,6 +105,9 @@ def cpu_baseline(sv, nv, info, dims, tfn_np, cam, fb, mc, pls, hidden_layers, lo
 
 def main():
     a = parse()
+    if os.environ.get("VNR_BENCH_DUMP_AFTER"):  # diagnostics: where does a run that hangs under the profiler stand?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VNR_BENCH_DUMP_AFTER"]), exit=False, file=sys.stderr)
     ctx = dist.init_from_env()
     if a.gpus != ctx.world:
         if ctx.rank == 0:
@@ -145,7 +149,7 @@ def main():
     api.vnrRendererSetCamera(ren, camera)
     api.vnrRendererSetFramebufferSize(ren, (a.fb, a.fb))
     api.vnrRendererSetMode(ren, a.mode)
-    api.vnrRendererSetProfiling(ren, True)  # HIP events around the fused encode+MLP kernel, on its own stream
+    api.vnrRendererSetProfiling(ren, not a.no_kernel_events)  # HIP events around the fused encode+MLP kernel, on its own stream
     sr = dist.ShardedRenderer(ctx, ren, a.fb, a.fb)
     setup_s = time.perf_counter() - t_setup
 

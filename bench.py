@@ -161,11 +161,12 @@ def main():
     t0 = time.perf_counter()
     samples = slots = 0
     infer_ms = 0.0
+    union_ms = 0.0
     launches = iters = 0
     for _ in range(a.steps):
         sr.render()
         st = api.vnrRendererGetFrameStats(ren)
-        samples += st["n_samples"]; slots += st["n_reference_slots"]; infer_ms += st["infer_kernel_ms"]
+        samples += st["n_samples"]; slots += st["n_reference_slots"]; infer_ms += st["infer_kernel_ms"]; union_ms += st["infer_union_ms"]
         launches += st["infer_kernel_launches"]; iters = st["n_iterations"]
     sr.flush()   # N > 1: the gather of the last frame (ShardedRenderer pipelines render k with gather k - 1); every frame is rendered AND gathered inside the timed region
     dist.barrier(ctx)
@@ -260,6 +261,11 @@ def main():
     # the GPU: `achieved`/`frac` (defined per launch) drop although the frame gets faster.  The frame-level figure below
     # does not depend on scheduling: algorithmic bytes of all live samples of a frame / frame time.
     halves = 1 if os.environ.get("VNR_AMD_RENDER_HALVES", "2") == "1" else 2
+    if union_ms > 0:
+        u = (samples * bytes_per_sample) / (union_ms * 1e-3) / 1e9
+        roofline["union"] = {"what": "timed region: algorithmic bytes of all launches / the time during which at least one launch of the kernel was "
+                                     "running (union of the HIP-event intervals of both streams): overlapping launches count once",
+                             "achieved": round(u, 1), "frac": round(u / HBM_PEAK_GBS, 4), "ms_per_frame": round(union_ms / a.steps, 4)}
     if alone and alone["ms"] > 0:
         ev = alone["samples"] * evals_per_sample
         a_gbs = ev * bytes_per_sample / (alone["ms"] * 1e-3) / 1e9

@@ -252,6 +252,7 @@ typedef struct {
   uint32_t n_rays_hit;
   double   infer_kernel_ms;  /* sum over the frame of the fused encode+MLP kernel (HIP events), if profiling */
   uint64_t infer_kernel_launches;
+  double   infer_union_ms;   /* length of the union of those launches' intervals: overlapping launches of the ray halves count once */
 } vnrAmdFrameStats;
 int  vnrAmdRendererGetFrameStats(vnrAmdRenderer, vnrAmdFrameStats*);
 int  vnrAmdRendererSetProfiling(vnrAmdRenderer, int enable);

@@ -42,7 +42,7 @@ def build(force=False):
 
 class FrameStats(C.Structure):
     _fields_ = [("n_samples", C.c_uint64), ("n_reference_slots", C.c_uint64), ("n_iterations", C.c_uint32),
-                ("n_rays_hit", C.c_uint32), ("infer_kernel_ms", C.c_double), ("infer_kernel_launches", C.c_uint64)]
+                ("n_rays_hit", C.c_uint32), ("infer_kernel_ms", C.c_double), ("infer_kernel_launches", C.c_uint64), ("infer_union_ms", C.c_double)]
 
 
 class OutOfCoreInfo(C.Structure):

@@ -695,7 +695,7 @@ int vnrAmdRendererGetFrameStats(vnrAmdRenderer r, vnrAmdFrameStats* s)
     VNR_REN(r);
     const FrameStats& f = r->r->stats();
     s->n_samples = f.n_samples; s->n_reference_slots = f.n_reference_slots; s->n_iterations = f.n_iterations;
-    s->n_rays_hit = f.n_rays_hit; s->infer_kernel_ms = f.infer_kernel_ms; s->infer_kernel_launches = f.infer_kernel_launches;
+    s->n_rays_hit = f.n_rays_hit; s->infer_kernel_ms = f.infer_kernel_ms; s->infer_kernel_launches = f.infer_kernel_launches; s->infer_union_ms = f.infer_union_ms;
   });
 }
 int vnrAmdRendererDebugQueues(vnrAmdRenderer r, const float** d_coords, const uint32_t** d_counters, float* iteration_ms, int max_iterations)

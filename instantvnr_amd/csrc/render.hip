@@ -1727,6 +1727,26 @@ void Renderer::finish_streaming()
       stats_.infer_kernel_launches += used > 0 ? used - 1 : 0;
     }
   }
+  if (profiling_ && half[0].it > 0) {
+    // the halves' launches overlap: the union of their intervals (all timed against part 0's first event) is the time the
+    // evaluation kernel had the GPU or a share of it
+    std::vector<std::pair<float, float>> iv;
+    for (int h = 0; h < H; ++h)
+      for (uint32_t k = 0; k < half[h].it; ++k) {
+        float t0 = 0.0f, t1 = 0.0f;
+        VNR_HIP_CHECK(hipEventElapsedTime(&t0, events_[0][0], events_[h][2 * k]));
+        VNR_HIP_CHECK(hipEventElapsedTime(&t1, events_[0][0], events_[h][2 * k + 1]));
+        iv.emplace_back(t0, t1);
+      }
+    std::sort(iv.begin(), iv.end());
+    float lo = iv[0].first, hi = iv[0].second;
+    double total = 0.0;
+    for (size_t e = 1; e < iv.size(); ++e) {
+      if (iv[e].first > hi) { total += hi - lo; lo = iv[e].first; hi = iv[e].second; }
+      else hi = std::max(hi, iv[e].second);
+    }
+    stats_.infer_union_ms += total + (hi - lo);
+  }
   // summed over the passes of a frame (mode 11: camera pass + shadow pass)
   stats_.n_iterations += pass_iterations;
   stats_.n_samples += n_samples;

@@ -18,6 +18,7 @@ struct FrameStats {
   uint32_t n_iterations = 0, n_rays_hit = 0;
   double infer_kernel_ms = 0.0;
   uint64_t infer_kernel_launches = 0;
+  double infer_union_ms = 0.0;   // time during which at least one evaluation kernel of the frame was running (any stream)
 };
 
 struct RenderParams;  // device-visible POD (render.hip)

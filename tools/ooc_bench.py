@@ -1,6 +1,6 @@
 """GPU box: training throughput from an out-of-core volume (SURVEY 8 a15 / BASELINE C5 in miniature).
 Writes a synthetic uint8 volume file under /tmp, opens it with vnrCreateSimpleVolumeOutOfCore and trains the C4-shaped model.
-usage: python tools/ooc_bench.py [nx ny nz] [n_concurrent_blocks] [n_blocks] [steps]"""
+usage: python tools/ooc_bench.py [nx ny nz] [n_concurrent_blocks] [n_blocks] [steps] [keep the file: 0 | 1]"""
 import os
 import sys
 import time
@@ -46,4 +46,5 @@ dt = time.perf_counter() - t0
 b1 = api.out_of_core_info(sv)["bytes_read"]
 print(f"training from the file: {steps} steps, {dt / steps * 1e3:.3f} ms per step (65536 samples each) = {65536 * steps / dt / 1e6:.1f} M samples/s; "
       f"refresh traffic {(b1 - b0) / steps / 2**20:.1f} MiB per step = {(b1 - b0) / dt / 2**30:.2f} GiB/s from the page cache; loss {api.vnrNeuralVolumeGetTrainingLoss(nv):.4f}", flush=True)
-os.remove(path)
+if not (len(a) > 6 and a[6]):
+    os.remove(path)

@@ -266,6 +266,51 @@ int  vnrAmdRendererSetAsync(vnrAmdRenderer, int enable);
 int  vnrAmdRendererDebugQueues(vnrAmdRenderer, const float** d_coords, const uint32_t** d_counters, float* iteration_ms, int max_iterations);
 void vnrAmdReleaseRenderer(vnrAmdRenderer);
 
+/* ---- multi-GPU: one process per GPU (new work; the reference is single-GPU, its only device-selection code is
+ * renderer.cpp:299-304 and it has no collective) ------------------------------------------------------------------------------
+ * Transports: "rccl" (librccl.so of the ROCm the process runs on, opened with dlopen here; device pointers straight into
+ * ncclAllGather / ncclAllReduce on HIP streams) and "shm" (host-staged through one shared-memory segment of the node: several
+ * ranks on one GPU, or none; tests).  NULL / "" = env VNR_AMD_DIST_TRANSPORT, default "rccl".
+ * InitFromEnv reads the torchrun contract (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT), binds the process to
+ * device LOCAL_RANK (modulo the device count) and meets the other ranks on a control socket of its own: an abstract unix
+ * socket named after MASTER_PORT when MASTER_ADDR is this host, tcp MASTER_ADDR:MASTER_PORT+1 otherwise
+ * (VNR_AMD_DIST_ADDR = "unix:<name>" | "tcp:<host>:<port>" overrides).  Init is the explicit form for an application with its
+ * own rendezvous: unique_id = the 128 bytes of vnrAmdDistGetUniqueId from one rank (NULL: exchanged over `address`). */
+int  vnrAmdDistGetUniqueId(void* out128);
+int  vnrAmdDistInit(int rank, int world_size, int local_rank, const void* unique_id, const char* transport, const char* address);
+int  vnrAmdDistInitFromEnv(void);
+int  vnrAmdDistFinalize(void);
+int  vnrAmdDistRank(void);
+int  vnrAmdDistWorldSize(void);
+const char* vnrAmdDistTransport(void);
+int  vnrAmdDistBarrier(void);                                      /* device synchronize + host barrier */
+/* host values over the control plane (the bench's MAX / SUM over ranks); op: 0 sum, 1 max, 2 min */
+int  vnrAmdDistAllReduceHost(double* values, int n, int op);
+/* the transport's collectives on caller buffers (device pointers; host pointers on the shm transport), blocking.
+ * dtype: 0 f32, 1 f16, 2 u8.  AllGather: rank r's bytes land at recv + r * bytes_per_rank (send may be that address). */
+int  vnrAmdDistAllReduce(void* buf, size_t count, int dtype, int op);
+int  vnrAmdDistAllGather(const void* send, void* recv, size_t bytes_per_rank);
+int  vnrAmdDistReduceScatter(void* buf, size_t count_per_rank, int dtype);
+int  vnrAmdDistBroadcast(void* buf, size_t bytes, int root);
+/* Image tiles: the rank renders the 8-scanline tile rows r with r % world == rank into its slot of a [world][share] buffer;
+ * vnrAmdRendererMapFrame (= vnrAmdRendererGatherFrame) all-gathers in place, de-interleaves and returns the WHOLE frame on
+ * every rank, bit-identical to the unsharded frame.  RenderPipelined: enqueue frame k, gather frame k - 1 meanwhile on the
+ * communication stream, complete frame k, return the assembled frame k - 1 (NULL the first time); FlushPipeline returns the
+ * frame still in flight. */
+int  vnrAmdRendererSetDistributed(vnrAmdRenderer, int enable);
+const float* vnrAmdRendererGatherFrame(vnrAmdRenderer);
+int  vnrAmdRendererRenderPipelined(vnrAmdRenderer, const float** previous_frame);
+int  vnrAmdRendererFlushPipeline(vnrAmdRenderer, const float** last_frame);
+/* Data-parallel training: `steps` steps, each equal to ONE step on the concatenated batch of all ranks.  Gradients travel as
+ * fp16 (2 B x n_params per step), range by range while the backward pass of the coarser levels and the update of earlier
+ * ranges run; no host synchronisation inside a step on the rccl transport.  The first call broadcasts rank 0's parameters,
+ * optimizer state, step count and learning rate (SyncReplicas) and gives every rank its own sample stream. */
+int  vnrAmdNeuralVolumeTrainDataParallel(vnrAmdVolume, int steps, int fast_mode);
+int  vnrAmdNeuralVolumeSyncReplicas(vnrAmdVolume);
+/* for the TrainBegin / TrainEnd form: sums vnrAmdNeuralVolumeGradients() over the ranks (fp16 payload, result back in the fp32
+ * buffer); follow with vnrAmdNeuralVolumeTrainEnd(v, 1.0f / world, fast_mode) */
+int  vnrAmdNeuralVolumeAllReduceGradients(vnrAmdVolume);
+
 /* ---- misc (api.h:185-188) -------------------------------------------------- */
 void vnrAmdMemoryQuery(size_t* used_by_renderer, size_t* used_by_network); /* vnrMemoryQuery */
 void vnrAmdFreeTemporaryGPUMemory(void);                                   /* vnrFreeTemporaryGPUMemory */

@@ -172,6 +172,26 @@ def lib():
     sig("vnrAmdRendererSetAsync", I, P, I)
     sig("vnrAmdRendererDebugQueues", I, P, C.POINTER(P), C.POINTER(P), FP, I)
     sig("vnrAmdReleaseRenderer", None, P)
+    sig("vnrAmdDistGetUniqueId", I, P)
+    sig("vnrAmdDistInit", I, I, I, I, P, C.c_char_p, C.c_char_p)
+    sig("vnrAmdDistInitFromEnv", I)
+    sig("vnrAmdDistFinalize", I)
+    sig("vnrAmdDistRank", I)
+    sig("vnrAmdDistWorldSize", I)
+    sig("vnrAmdDistTransport", C.c_char_p)
+    sig("vnrAmdDistBarrier", I)
+    sig("vnrAmdDistAllReduceHost", I, C.POINTER(D), I, I)
+    sig("vnrAmdDistAllReduce", I, P, SZ, I, I)
+    sig("vnrAmdDistAllGather", I, P, P, SZ)
+    sig("vnrAmdDistReduceScatter", I, P, SZ, I)
+    sig("vnrAmdDistBroadcast", I, P, SZ, I)
+    sig("vnrAmdRendererSetDistributed", I, P, I)
+    sig("vnrAmdRendererGatherFrame", P, P)
+    sig("vnrAmdRendererRenderPipelined", I, P, C.POINTER(P))
+    sig("vnrAmdRendererFlushPipeline", I, P, C.POINTER(P))
+    sig("vnrAmdNeuralVolumeTrainDataParallel", I, P, I, I)
+    sig("vnrAmdNeuralVolumeSyncReplicas", I, P)
+    sig("vnrAmdNeuralVolumeAllReduceGradients", I, P)
     sig("vnrAmdMemoryQuery", None, C.POINTER(SZ), C.POINTER(SZ))
     sig("vnrAmdFreeTemporaryGPUMemory", None)
     sig("vnrAmdSimpleVolumeTakeSamples", I, P, SZ, FP, FP, P, P, P)

@@ -6,6 +6,7 @@
 #include <fstream>
 #include <memory>
 
+#include "dist.h"
 #include "renderer.h"
 #include "scene.h"
 
@@ -711,6 +712,99 @@ int vnrAmdRendererDebugQueues(vnrAmdRenderer r, const float** d_coords, const ui
 int vnrAmdRendererSetProfiling(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_profiling(e != 0); }); }
 int vnrAmdRendererSetAsync(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_async(e != 0); }); }
 void vnrAmdReleaseRenderer(vnrAmdRenderer r) { delete r; }
+
+// ------------------------------------------------------------------------------------------------ multi-GPU (dist.h)
+int vnrAmdDistGetUniqueId(void* out128) { return guarded([&]() { if (!out128) throw std::runtime_error("null id buffer"); rccl_unique_id(out128); }); }
+static void bind_device_to_local_rank(int local_rank)
+{
+  const int count = vnrAmdDeviceCount();
+  if (count > 0) Runtime::get().init(local_rank % count);   // several ranks on one device: the host-staged transport's test set-up
+}
+int vnrAmdDistInit(int rank, int world, int local_rank, const void* unique_id, const char* transport, const char* address)
+{
+  return guarded([&]() {
+    bind_device_to_local_rank(local_rank);
+    Dist::get().init(rank, world, local_rank, unique_id, transport, address ? address : "");
+  });
+}
+int vnrAmdDistInitFromEnv(void)
+{
+  return guarded([&]() {
+    const char* lr = std::getenv("LOCAL_RANK");
+    const char* r = std::getenv("RANK");
+    bind_device_to_local_rank(lr && *lr ? std::atoi(lr) : (r && *r ? std::atoi(r) : 0));
+    Dist::get().init_from_env();
+  });
+}
+int vnrAmdDistFinalize(void) { return guarded([&]() { Dist::get().finalize(); }); }
+int vnrAmdDistRank(void) { return Dist::get().rank(); }
+int vnrAmdDistWorldSize(void) { return Dist::get().world(); }
+const char* vnrAmdDistTransport(void) { return Dist::get().transport_name(); }
+int vnrAmdDistBarrier(void)
+{
+  return guarded([&]() {
+    if (Runtime::get().ready()) VNR_HIP_CHECK(hipDeviceSynchronize());
+    Dist::get().barrier();
+  });
+}
+int vnrAmdDistAllReduceHost(double* values, int n, int op)
+{
+  return guarded([&]() {
+    if (op < 0 || op > 2) throw std::runtime_error("unknown reduction");
+    Dist::get().all_reduce_host(values, n, (DistOp)op);
+  });
+}
+static hipStream_t dist_call_stream() { return Runtime::get().ready() ? Runtime::get().stream : nullptr; }
+static void dist_call_done() { if (Runtime::get().ready()) VNR_HIP_CHECK(hipStreamSynchronize(Runtime::get().stream)); }
+int vnrAmdDistAllReduce(void* buf, size_t count, int dtype, int op)
+{
+  return guarded([&]() {
+    if (dtype < 0 || dtype > 2 || op < 0 || op > 2) throw std::runtime_error("unknown dtype / reduction");
+    Dist::get().transport().all_reduce(buf, count, (DistDType)dtype, (DistOp)op, dist_call_stream());
+    dist_call_done();
+  });
+}
+int vnrAmdDistAllGather(const void* send, void* recv, size_t bytes_per_rank)
+{
+  return guarded([&]() { Dist::get().transport().all_gather(send, recv, bytes_per_rank, dist_call_stream()); dist_call_done(); });
+}
+int vnrAmdDistReduceScatter(void* buf, size_t count_per_rank, int dtype)
+{
+  return guarded([&]() {
+    if (dtype < 0 || dtype > 2) throw std::runtime_error("unknown dtype");
+    Dist::get().transport().reduce_scatter(buf, count_per_rank, (DistDType)dtype, dist_call_stream());
+    dist_call_done();
+  });
+}
+int vnrAmdDistBroadcast(void* buf, size_t bytes, int root)
+{
+  return guarded([&]() { Dist::get().transport().broadcast(buf, bytes, root, dist_call_stream()); dist_call_done(); });
+}
+int vnrAmdRendererSetDistributed(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_distributed(e != 0); }); }
+const float* vnrAmdRendererGatherFrame(vnrAmdRenderer r)
+{
+  const float* out = nullptr;
+  guarded([&]() {
+    VNR_REN(r);
+    if (!r->r->distributed()) throw std::runtime_error("vnrAmdRendererGatherFrame: the renderer is not in distributed mode (vnrAmdRendererSetDistributed)");
+    out = r->r->map_frame();
+  });
+  return out;
+}
+int vnrAmdRendererRenderPipelined(vnrAmdRenderer r, const float** previous_frame)
+{
+  return guarded([&]() { VNR_REN(r); const float* f = r->r->render_pipelined(); if (previous_frame) *previous_frame = f; });
+}
+int vnrAmdRendererFlushPipeline(vnrAmdRenderer r, const float** last_frame)
+{
+  return guarded([&]() { VNR_REN(r); const float* f = r->r->flush_pipeline(); if (last_frame) *last_frame = f; });
+}
+int vnrAmdNeuralVolumeTrainDataParallel(vnrAmdVolume v, int steps, int fast_mode)
+{
+  return guarded([&]() { as_neural(v)->train_data_parallel((size_t)std::max(steps, 0), fast_mode != 0); });
+}
+int vnrAmdNeuralVolumeSyncReplicas(vnrAmdVolume v) { return guarded([&]() { as_neural(v)->sync_replicas(); }); }
+int vnrAmdNeuralVolumeAllReduceGradients(vnrAmdVolume v) { return guarded([&]() { as_neural(v)->all_reduce_gradients(); }); }
 
 // ------------------------------------------------------------------------------------------------ misc
 void vnrAmdMemoryQuery(size_t* used_by_renderer, size_t* used_by_network)

@@ -73,6 +73,14 @@ struct alignas(16) OptState {
 };
 static_assert(sizeof(OptState) == 16, "OptState must be one 16-byte record");
 
+// Data-parallel hook (dist.h): forward_backward calls it in stream order whenever this rank's fp32 gradient of a
+// contiguous parameter range is complete (the MLP first, then the hash-grid levels from the finest to the coarsest in buckets),
+// so the exchange of one range runs while the backward pass of the next still does.
+struct GradExchange {
+  virtual ~GradExchange() = default;
+  virtual void range_ready(size_t lo, size_t hi, hipStream_t s) = 0;
+};
+
 class Network {
 public:
   Network() = default;
@@ -111,10 +119,20 @@ public:
   void encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const;
 
   // training step pieces (tcnn Trainer::training_step, EXTERNAL): forward+loss+backward into grads()
-  void forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s);
+  void forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s, GradExchange* exchange = nullptr);
   float* grads() { return grads_.ptr; }
   size_t grads_count() const { return grads_.count; }
   void optimizer_step(float grad_scale, hipStream_t s);
+  // the same step in pieces, for gradients that arrive range by range as fp16 (data-parallel exchange, volume.hip):
+  // Adam on parameters [lo, hi) with gradient d_grads_f16[i] * grad_scale / loss_scale, then the bookkeeping of ONE step
+  void optimizer_step_range(size_t lo, size_t hi, const uint16_t* d_grads_f16, float grad_scale, hipStream_t s);
+  void optimizer_finish_step(hipStream_t s);
+  float learning_rate() const { return lr_; }
+  // replica state for data-parallel training: everything an optimizer step reads
+  uint16_t* params_device() { return params_f16_.ptr; }
+  OptState* opt_state_device() { return opt_state_.ptr; }
+  void set_replica_state(uint64_t steps, float lr, hipStream_t s) { steps_ = steps; lr_ = lr; refresh_inference_weights(s); }
+  void ensure_training_state(hipStream_t s);
   double training_loss(hipStream_t s);  // mean loss of the last forward_backward
 
   size_t bytes_allocated() const;
@@ -147,6 +165,7 @@ private:
   uint32_t in_width_ = 0;
   size_t n_params_ = 0, n_mlp_ = 0;
   uint64_t steps_ = 0;
+  float lr_ = 0.0f;   // current learning rate (ExponentialDecay state); reset by configure() like the reference's rebuilt optimizer (tcnn_network.h:195-209)
 
   DeviceBuffer<uint16_t> params_f16_{MemTag::Network};   // tcnn-order blob (inference + serialisation)
   DeviceBuffer<uint16_t> mlp_packed_{MemTag::Network};   // MFMA/LDS image of the MLP weights

@@ -173,6 +173,7 @@ void Network::configure(const Json& config, uint64_t init_seed)
   model_["network"] = net;
   build_layout();
   steps_ = 0;
+  lr_ = cfg_.learning_rate;   // a re-configured model starts its schedule over (tcnn_network.h:195-209 rebuilds optimizer and trainer)
   initialize_params(init_seed, Runtime::get().stream);
   live_networks().insert(this);
 }

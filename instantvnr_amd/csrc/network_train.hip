@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256) weight_grad_kernel(const WGradArgs args, 
 // EXTERNAL tcnn kernel_grid_backward: for every (sample, level): grad[idx*F+f] += w * dL/dfeature[f].
 template <int F>
 __global__ void grid_backward_kernel(const GridDevice grid, const float* __restrict__ coords, const half_t* __restrict__ dfeat,
-                                     uint32_t n, uint32_t in_width, float* __restrict__ grid_grads)
+                                     uint32_t n, uint32_t in_width, float* __restrict__ grid_grads, uint32_t level0)
 {
   // lane = (sample, feature): the F features of a table entry are adjacent in memory, so F adjacent lanes add to one
   // contiguous 4F-byte segment in ONE wave-instruction.  Global float atomics are priced per memory-side request, and
@@ -405,7 +405,7 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
   const uint32_t i = t / kLanesPerSample, r = t % kLanesPerSample;
   const uint32_t xb = r / (uint32_t)F, f = r % (uint32_t)F;
   if (i >= n) return;
-  const uint32_t level = blockIdx.y;
+  const uint32_t level = level0 + blockIdx.y;
   const LevelInfo lv = grid.levels[level];
   const float g = (float)dfeat[(size_t)i * in_width + level * F + f];
   if (g == 0.0f) return;
@@ -451,6 +451,64 @@ __global__ void adam_kernel(size_t n_total, size_t n_matrix, float grad_mul, flo
   params[i] = (half_t)nw;
 }
 
+// Data-parallel variant (volume.hip train_data_parallel): parameters [lo, hi) only, gradient = the all-reduced fp16 copy
+// (sum over ranks; grad_mul carries 1 / (world * loss_scale)).  The fp32 blob was cleared when the copy was made.
+__global__ void adam_range_f16_kernel(size_t lo, size_t hi, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float log2_beta1,
+                                      float log2_beta2, float epsilon, float l2_reg, OptState* __restrict__ state, half_t* __restrict__ params,
+                                      const half_t* __restrict__ grads)
+{
+  const size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  float gradient = (float)grads[i] * grad_mul;
+  if (i >= n_matrix && gradient == 0.0f) return;
+  OptState st = state[i];
+  const float w = st.master;
+  if (i < n_matrix) gradient += l2_reg * w;
+  const float m = st.m = beta1 * st.m + (1.0f - beta1) * gradient;
+  const float v = st.v = beta2 * st.v + (1.0f - beta2) * (gradient * gradient);
+  const uint32_t step = ++st.step;
+  const float fs = (float)step;
+  const float lr_t = lr * sqrtf(1.0f - __builtin_amdgcn_exp2f(fs * log2_beta2)) / (1.0f - __builtin_amdgcn_exp2f(fs * log2_beta1));
+  const float eff = lr_t / (sqrtf(v) + epsilon);
+  const float nw = w - eff * m;
+  st.master = nw;
+  state[i] = st;
+  params[i] = (half_t)nw;
+}
+
+// fp32 gradient range -> fp16 exchange payload, clearing the fp32 range for the next step (4 elements per thread; lo and
+// hi - lo are multiples of 4 for every range forward_backward reports: level sizes are multiples of 8 entries)
+__global__ void pack_grads_f16_kernel(float* __restrict__ grads, half_t* __restrict__ out, size_t n4)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4_t g = ((const float4_t*)grads)[i];
+    ((half4_t*)out)[i] = half4_t{(half_t)g.x, (half_t)g.y, (half_t)g.z, (half_t)g.w};
+    if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) ((float4_t*)grads)[i] = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+}
+void launch_pack_grads_f16(float* grads, uint16_t* out, size_t n, hipStream_t s)
+{
+  if (n % 4) throw std::runtime_error("internal: gradient range is not a multiple of 4 elements");
+  const size_t n4 = n / 4;
+  pack_grads_f16_kernel<<<(uint32_t)std::min<size_t>((n4 + 255) / 256, 8192), 256, 0, s>>>(grads, (half_t*)out, n4);
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+__global__ void unpack_grads_f16_kernel(const half_t* __restrict__ in, float* __restrict__ grads, size_t n4)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const half4_t h = ((const half4_t*)in)[i];
+    if (h.x != (half_t)0.0f || h.y != (half_t)0.0f || h.z != (half_t)0.0f || h.w != (half_t)0.0f)   // the fp32 blob was cleared by the pack
+      ((float4_t*)grads)[i] = float4_t{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+  }
+}
+void launch_unpack_grads_f16(const uint16_t* in, float* grads, size_t n, hipStream_t s)
+{
+  const size_t n4 = n / 4;
+  unpack_grads_f16_kernel<<<(uint32_t)std::min<size_t>((n4 + 255) / 256, 8192), 256, 0, s>>>((const half_t*)in, grads, n4);
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------------ host
 void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width, uint32_t n_hidden_matmuls, hipStream_t s);
 
@@ -459,8 +517,6 @@ struct TrainScratch {  // per-Network extra buffers that do not need to live in 
   DeviceBuffer<uint16_t> dy{MemTag::Network};
   DeviceBuffer<uint16_t> d_all{MemTag::Network};
   DeviceBuffer<uint16_t> packedT{MemTag::Network};
-  float lr = 0.0f;
-  bool lr_init = false;
   uint32_t loss_blocks = 0;
 };
 
@@ -485,16 +541,20 @@ static TrainScratch& scratch_of(const Network* n)
 }
 void network_release_scratch(const Network* n) { scratch_map().erase(n); }
 
-void Network::forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s)
+void Network::ensure_training_state(hipStream_t s)
+{
+  if (opt_state_.count != n_params_) { opt_state_.resize(n_params_); launch_master_from_f16(params_f16_.ptr, opt_state_.ptr, n_params_, true, s); }
+  if (grads_.count != n_params_) { grads_.resize(n_params_); grads_.zero(s); }
+}
+
+void Network::forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s, GradExchange* exchange)
 {
   if (!valid()) throw std::runtime_error("network is not configured");
   if (batch == 0) return;
   TrainScratch& ts = scratch_of(this);
   const uint32_t nh = n_hidden_matmuls();
   const uint32_t n = (uint32_t)batch;
-  // lazily allocate the training state
-  if (opt_state_.count != n_params_) { opt_state_.resize(n_params_); launch_master_from_f16(params_f16_.ptr, opt_state_.ptr, n_params_, true, s); }
-  if (grads_.count != n_params_) { grads_.resize(n_params_); grads_.zero(s); }
+  ensure_training_state(s);  // lazily allocated
   if (ws_batch_ != batch) {
     ws_features_.resize(batch * in_width_);
     ws_acts_.resize((size_t)(nh + 1) * batch * 64);
@@ -557,15 +617,34 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
     weight_grad_kernel<64><<<g2, 256, 0, s>>>(wa, 1, sub_chunks);
   }
-  // 5. hash-grid backward
-  {
-    const dim3 g(div_round_up((uint64_t)batch * cfg_.n_features * 2, 256), cfg_.n_levels);  // one lane per (sample, x bit, feature)
+  if (exchange) exchange->range_ready(0, n_mlp_, s);   // the MLP's gradient travels while the grid backward runs
+  // 5. hash-grid backward: levels [l0, l1) per launch (blockIdx.y + l0 = level)
+  auto grid_backward = [&](uint32_t l0, uint32_t l1) {
+    const dim3 g(div_round_up((uint64_t)batch * cfg_.n_features * 2, 256), l1 - l0);  // one lane per (sample, x bit, feature)
     float* gg = grads_.ptr + n_mlp_;
     switch (cfg_.n_features) {
-    case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg); break;
-    case 2: grid_backward_kernel<2><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg); break;
-    case 4: grid_backward_kernel<4><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg); break;
-    default: grid_backward_kernel<8><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg); break;
+    case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
+    case 2: grid_backward_kernel<2><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
+    case 4: grid_backward_kernel<4><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
+    default: grid_backward_kernel<8><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
+    }
+  };
+  if (!exchange) {
+    grid_backward(0, cfg_.n_levels);
+  } else {
+    // finest levels first (the large tables), in buckets of at least kBucket parameters: a bucket's exchange overlaps the
+    // backward launches of the coarser levels and, afterwards, the optimizer update of the buckets before it
+    constexpr size_t kBucket = 4u << 20;
+    uint32_t l1 = cfg_.n_levels;
+    while (l1 > 0) {
+      uint32_t l0 = l1;
+      size_t count = 0;
+      while (l0 > 0 && (count < kBucket || (size_t)grid_.levels[l0 - 1].offset * cfg_.n_features < kBucket)) { --l0; count += (size_t)grid_.levels[l0].size * cfg_.n_features; }
+      grid_backward(l0, l1);
+      const size_t lo = n_mlp_ + (size_t)grid_.levels[l0].offset * cfg_.n_features;
+      const size_t hi = n_mlp_ + ((size_t)grid_.levels[l1 - 1].offset + grid_.levels[l1 - 1].size) * cfg_.n_features;
+      exchange->range_ready(lo, hi, s);
+      l1 = l0;
     }
   }
   VNR_HIP_CHECK(hipGetLastError());
@@ -574,16 +653,29 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
 void Network::optimizer_step(float grad_scale, hipStream_t s)
 {
   if (grads_.count != n_params_) throw std::runtime_error("optimizer_step before forward_backward");
-  TrainScratch& ts = scratch_of(this);
-  if (!ts.lr_init) { ts.lr = cfg_.learning_rate; ts.lr_init = true; }
-  adam_kernel<<<div_round_up(n_params_, 256), 256, 0, s>>>(n_params_, n_mlp_, grad_scale / (float)kLossScale, ts.lr, cfg_.beta1,
+  adam_kernel<<<div_round_up(n_params_, 256), 256, 0, s>>>(n_params_, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1,
                                                            cfg_.beta2, (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2),
                                                            cfg_.epsilon, cfg_.l2_reg, opt_state_.ptr,
                                                            (half_t*)params_f16_.ptr, grads_.ptr);
   VNR_HIP_CHECK(hipGetLastError());
+  optimizer_finish_step(s);
+}
+
+void Network::optimizer_step_range(size_t lo, size_t hi, const uint16_t* d_grads_f16, float grad_scale, hipStream_t s)
+{
+  if (opt_state_.count != n_params_) throw std::runtime_error("optimizer_step_range before forward_backward");
+  if (hi > n_params_ || lo >= hi) throw std::runtime_error("optimizer_step_range: invalid parameter range");
+  adam_range_f16_kernel<<<div_round_up(hi - lo, 256), 256, 0, s>>>(lo, hi, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1, cfg_.beta2,
+                                                                  (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2), cfg_.epsilon,
+                                                                  cfg_.l2_reg, opt_state_.ptr, (half_t*)params_f16_.ptr, (const half_t*)d_grads_f16);
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+void Network::optimizer_finish_step(hipStream_t s)
+{
   ++steps_;
   // EXTERNAL tcnn ExponentialDecayOptimizer::step
-  if (cfg_.has_decay && steps_ >= cfg_.decay_start && cfg_.decay_interval > 0 && steps_ % cfg_.decay_interval == 0) ts.lr *= cfg_.decay_base;
+  if (cfg_.has_decay && steps_ >= cfg_.decay_start && cfg_.decay_interval > 0 && steps_ % cfg_.decay_interval == 0) lr_ *= cfg_.decay_base;
   refresh_inference_weights(s);
 }
 

@@ -2,6 +2,8 @@
 // (StreamLoader, RandomBuffer), :967-1035 (sample_streaming_grid), :1043-1127 (OutOfCoreSampler).
 #include "ooc_sampler.h"
 
+#include "dist.h"
+
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -163,6 +165,9 @@ OutOfCoreSampler::OutOfCoreSampler(const std::string& filename, vec3i dims, int 
   if (n_concurrent_ == 0 || n_blocks_ == 0) throw std::runtime_error("out-of-core sampler: block counts must be positive");
   if (n_concurrent_ > n_blocks_) n_concurrent_ = n_blocks_;
   elem_ = ooc_type_size(type);
+  // data-parallel training (BASELINE C5: "each rank its own slab set"): rank r of a multi-process job draws its slabs from the
+  // default-seeded generator's seed + r, so rank 0 and a single process keep the reference's sequence
+  if (Dist::get().world() > 1) rng_.seed(std::mt19937::default_seed + (uint32_t)Dist::get().rank());
   if (!Runtime::get().ready()) Runtime::get().init(-1);
   fd_ = ::open(filename.c_str(), O_RDONLY);
   if (fd_ < 0) throw std::runtime_error("cannot open volume file: " + filename);

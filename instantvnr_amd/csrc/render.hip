@@ -19,6 +19,7 @@
 #include <cfloat>
 #include <cstdlib>
 
+#include "dist.h"
 #include "sampling_device.h"
 
 namespace vnr {
@@ -55,6 +56,7 @@ struct RenderParams {
   int width, height, frame_index;
   uint32_t pixel_lo, pixel_hi;
   uint32_t il_parts, il_part, n_local;   // tile-row interleave across ranks; n_local = local index count
+  uint32_t out_parts;                    // > 1: frame / accumulation hold only the tile rows r with r % out_parts == this rank, packed (Renderer::set_distributed)
   uint32_t tiles_per_row, tile_row0;     // 64-pixel tiles per band of 8 scanlines: rays of a wave are an image patch, not a scanline
   uint32_t tile_w_log2;                  // tile shape: 2^tile_w_log2 x 2^(6 - tile_w_log2) pixels (8x8, 16x4, 32x2 or 64x1)
   float bin_depth_rcp;                   // 1 / depth of one sample-sorting bin (world units)
@@ -191,6 +193,10 @@ __device__ __forceinline__ float opacity_correction(float step_rcp, float distan
 }
 __device__ __forceinline__ void write_pixel(const RenderParams& p, vec4f rgba, uint32_t pixel)
 {
+  if (p.out_parts > 1u) {  // compact share: tile row b of the image is tile row b / out_parts of the share
+    const uint32_t y = pixel / (uint32_t)p.width, x = pixel - y * (uint32_t)p.width;
+    pixel = (((y >> 3) / p.out_parts) * 8u + (y & 7u)) * (uint32_t)p.width + x;
+  }
   if (p.frame_index != 1) {
     const vec4f a = p.accumulation[pixel];
     rgba = {a.x + rgba.x, a.y + rgba.y, a.z + rgba.z, a.w + rgba.w};
@@ -1251,6 +1257,9 @@ Renderer::~Renderer()
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (int i = 1; i < kMaxParts; ++i) if (part_streams_[i]) { (void)hipStreamSynchronize(part_streams_[i]); (void)hipStreamDestroy(part_streams_[i]); }
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (distributed_) (void)hipStreamSynchronize(Dist::get().comm_stream());
+  if (ev_rendered_) (void)hipEventDestroy(ev_rendered_);
+  for (int i = 0; i < 2; ++i) if (ev_gathered_[i]) (void)hipEventDestroy(ev_gathered_[i]);
   for (int i = 0; i < 2; ++i) if (host_fb_[i]) (void)hipHostFree(host_fb_[i]);
   if (host_counts_) (void)hipHostFree(host_counts_);
   for (auto& v : events_) for (auto e : v) (void)hipEventDestroy(e);
@@ -1274,7 +1283,106 @@ void Renderer::resize(int w, int h)
     }
     host_fb_pixels_ = n;
   }
+  if (distributed_) ensure_share_buffers();
   reset_ = true;
+}
+
+// ------------------------------------------------------------------------------------------------ distributed mode (dist.h)
+// gathered [world][n_local] (slot r = the packed tile rows r, r + world, ...) -> the width x height frame
+__global__ void assemble_shares_kernel(const vec4f* __restrict__ gathered, vec4f* __restrict__ full, uint32_t width, uint32_t height,
+                                       uint32_t world, uint32_t n_local)
+{
+  const uint32_t n = width * height;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t y = i / width, x = i - y * width, b = y >> 3;
+    full[i] = gathered[(size_t)(b % world) * n_local + ((b / world) * 8u + (y & 7u)) * width + x];
+  }
+}
+
+void Renderer::set_distributed(bool e)
+{
+  finish_pending();
+  if (e && !Dist::get().active()) throw std::runtime_error("distributed rendering needs vnrAmdDistInitFromEnv / vnrAmdDistInit first");
+  distributed_ = e && Dist::get().world() >= 1;
+  pipe_prev_ = -1;
+  if (distributed_) {
+    if (!ev_rendered_) VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_rendered_, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) if (!ev_gathered_[i]) VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_gathered_[i], hipEventDisableTiming));
+    ensure_share_buffers();
+  }
+  reset_ = true;
+}
+
+void Renderer::ensure_share_buffers()
+{
+  if (width_ <= 0 || height_ <= 0) return;
+  const Dist& d = Dist::get();
+  const ShareLayout l = share_layout((uint32_t)width_, (uint32_t)height_, (uint32_t)d.world());
+  share_world_ = (uint32_t)d.world(); share_rank_ = (uint32_t)d.rank(); share_n_local_ = l.n_local;
+  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+  VNR_HIP_CHECK(hipStreamSynchronize(Dist::get().comm_stream()));
+  const size_t n = (size_t)width_ * height_;
+  for (int i = 0; i < 2; ++i) {
+    gathered_[i].resize((size_t)share_world_ * l.n_local);
+    gathered_[i].zero(stream_);
+    full_[i].resize(n);
+    full_[i].zero(stream_);
+    gather_issued_[i] = false;
+  }
+  if (accumulation_.count < l.n_local) { accumulation_.resize(l.n_local); accumulation_.zero(stream_); }  // a share of a tiny image is padded past it
+  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Renderer::issue_gather(int buf)
+{
+  if (gather_issued_[buf]) return;
+  Dist& d = Dist::get();
+  hipStream_t comm = d.comm_stream();
+  // every part stream of the frame has been joined by the host (finish_streaming); the render stream carries the rest
+  VNR_HIP_CHECK(hipEventRecord(ev_rendered_, stream_));
+  VNR_HIP_CHECK(hipStreamWaitEvent(comm, ev_rendered_, 0));
+  vec4f* g = gathered_[buf].ptr;
+  const size_t share_bytes = (size_t)share_n_local_ * sizeof(vec4f);
+  d.transport().all_gather(g + (size_t)share_rank_ * share_n_local_, g, share_bytes, comm);   // in place: the own slot is already there
+  const uint32_t n = (uint32_t)((size_t)width_ * height_);
+  assemble_shares_kernel<<<std::min<uint32_t>(div_round_up(n, 256), (uint32_t)Runtime::get().n_cus * 8u), 256, 0, comm>>>(
+      g, full_[buf].ptr, (uint32_t)width_, (uint32_t)height_, share_world_, share_n_local_);
+  VNR_HIP_CHECK(hipGetLastError());
+  if (!skip_download_) VNR_HIP_CHECK(hipMemcpyAsync(host_fb_[buf], full_[buf].ptr, (size_t)n * sizeof(vec4f), hipMemcpyDeviceToHost, comm));
+  VNR_HIP_CHECK(hipEventRecord(ev_gathered_[buf], comm));
+  gather_issued_[buf] = true;
+}
+
+const float* Renderer::render_pipelined()
+{
+  if (!distributed_) { render(); return map_frame(); }
+  const int cur = fb_cur_;
+  const bool was_async = async_;
+  async_ = true;
+  try { render(); } catch (...) { async_ = was_async; throw; }   // the predicted iterations of frame k are enqueued
+  async_ = was_async;
+  const float* out = nullptr;
+  const int prev = pipe_prev_;
+  if (prev >= 0) issue_gather(prev);   // frame k - 1 travels while frame k renders
+  finish_pending();                    // frame k complete (further iterations if rays are still alive)
+  if (prev >= 0) {
+    VNR_HIP_CHECK(hipEventSynchronize(ev_gathered_[prev]));
+    out = skip_download_ ? (const float*)full_[prev].ptr : (const float*)host_fb_[prev];
+  }
+  pipe_prev_ = cur;
+  fb_cur_ ^= 1;
+  return out;
+}
+
+const float* Renderer::flush_pipeline()
+{
+  if (!distributed_ || pipe_prev_ < 0) return nullptr;
+  finish_pending();
+  const int prev = pipe_prev_;
+  issue_gather(prev);
+  VNR_HIP_CHECK(hipEventSynchronize(ev_gathered_[prev]));
+  pipe_prev_ = -1;
+  return skip_download_ ? (const float*)full_[prev].ptr : (const float*)host_fb_[prev];
 }
 
 void Renderer::set_transfer_function(const TransferFunctionData& t)
@@ -1322,8 +1430,10 @@ void Renderer::render()
   p.pixel_hi = std::min(pixel_hi_, n_pixels);
   if (p.pixel_hi < p.pixel_lo) p.pixel_hi = p.pixel_lo;
   // rays are generated in 8x8 pixel tiles; tile rows (8 scanlines) are the unit of multi-GPU interleaving
+  if (distributed_) { il_block_ = 8u * (uint32_t)width_; il_parts_ = share_world_; il_part_ = share_rank_; }
   if (il_parts_ > 1 && il_block_ != 8u * (uint32_t)width_) throw std::runtime_error("pixel interleave block must be 8 scanlines (8 * width pixels)");
   p.il_parts = il_parts_; p.il_part = il_part_;
+  p.out_parts = distributed_ ? share_world_ : 1u;
   p.tile_w_log2 = tile_w_log2_;
   p.tiles_per_row = div_round_up((uint32_t)width_, 1u << p.tile_w_log2) << (p.tile_w_log2 - 3u);
   const uint32_t tr_lo = p.pixel_hi > p.pixel_lo ? (p.pixel_lo / (uint32_t)width_) / 8u : 0u;
@@ -1382,6 +1492,12 @@ void Renderer::render()
   ++frame_index_;
   p.frame_index = frame_index_;
   p.frame = fb_[fb_cur_].ptr;
+  if (distributed_) {
+    // the buffer still feeds the gather of the frame rendered into it two frames ago (a no-op once that has completed)
+    if (gather_issued_[fb_cur_]) VNR_HIP_CHECK(hipStreamWaitEvent(stream_, ev_gathered_[fb_cur_], 0));
+    gather_issued_[fb_cur_] = false;
+    p.frame = gathered_[fb_cur_].ptr + (size_t)share_rank_ * share_n_local_;
+  }
   p.accumulation = accumulation_.ptr;
   stats_ = FrameStats();
 
@@ -1396,7 +1512,7 @@ void Renderer::render()
     case 5:   // VNR_RAYMARCHING_NO_SHADING_SAMPLE_STREAMING
     case 8:   // VNR_RAYMARCHING_GRADIENT_SHADING_SAMPLE_STREAMING
       // asynchronous frames (set_async): the pass is left pending after its predicted iterations have been enqueued
-      render_streaming(p, p.shading_mode == 1u ? M_GRADIENT : M_NONE, async_ && skip_download_);
+      render_streaming(p, p.shading_mode == 1u ? M_GRADIENT : M_NONE, async_ && (skip_download_ || distributed_));
       break;
     case 11:  // VNR_RAYMARCHING_SINGLE_SHADE_HEURISTIC_SAMPLE_STREAMING: camera pass, then one shadow ray per pixel (:968-971)
       render_streaming(p, M_SSH);
@@ -1439,7 +1555,7 @@ void Renderer::render()
     }
   }
   reset_ = false;
-  if (!skip_download_) {  // renderer.cpp:133 framebuffer.download_async
+  if (!skip_download_ && !distributed_) {  // renderer.cpp:133 framebuffer.download_async (distributed: the assembled frame, issue_gather)
     const size_t off = p.pixel_lo, cnt = p.pixel_hi - p.pixel_lo;  // (interleaved shares copy the covering range)
     if (cnt) VNR_HIP_CHECK(hipMemcpyAsync(host_fb_[fb_cur_] + off, fb_[fb_cur_].ptr + off, cnt * sizeof(vec4f), hipMemcpyDeviceToHost, stream_));
   }
@@ -1757,6 +1873,13 @@ void Renderer::finish_streaming()
 const float* Renderer::map_frame()
 {
   finish_pending();
+  if (distributed_) {
+    issue_gather(fb_cur_);
+    VNR_HIP_CHECK(hipEventSynchronize(ev_gathered_[fb_cur_]));
+    const float* out = skip_download_ ? (const float*)full_[fb_cur_].ptr : (const float*)host_fb_[fb_cur_];
+    fb_cur_ ^= 1;
+    return out;
+  }
   VNR_HIP_CHECK(hipStreamSynchronize(stream_));
   const float* out = skip_download_ ? (const float*)fb_[fb_cur_].ptr : (const float*)host_fb_[fb_cur_];
   fb_cur_ ^= 1;  // framebuffer.safe_swap

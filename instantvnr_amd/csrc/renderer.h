@@ -56,6 +56,18 @@ public:
 
   void render();                 // renderer.cpp:59-140
   const float* map_frame();      // renderer.h:84-94
+  // Image-tile sharding over the ranks of Dist (dist.h; new work).  The rank renders the tile rows (8 scanlines)
+  // r with r % world == rank straight into ITS slot of a [world][n_local] buffer (local pixel order: the share is compact), one
+  // in-place all-gather fills the other slots and one kernel de-interleaves them into the width x height frame that map_frame()
+  // returns, so vnrRender + vnrRendererMapFrame give every rank the whole frame, as on one GPU.  Global pixel indices keep the
+  // random sequences and the accumulation exact: the assembled frame equals the unsharded one bit for bit.
+  void set_distributed(bool e);
+  bool distributed() const { return distributed_; }
+  // a pipeline of depth one for throughput: enqueues frame k, gathers frame k - 1 on the communication stream while the GPU
+  // renders, completes frame k and returns the assembled frame k - 1 (nullptr on the first call); flush_pipeline() gathers and
+  // returns the frame still in flight.  Undistributed renderers return frame k itself.
+  const float* render_pipelined();
+  const float* flush_pipeline();
   const FrameStats& stats() { finish_pending(); return stats_; }
   int width() const { return width_; }
   int height() const { return height_; }
@@ -69,6 +81,8 @@ private:
   void render_monolithic(const RenderParams& p);
   void render_pathtracing(const RenderParams& p);   // do_path_tracing_iterative (method_pathtracing.cu:786-806)
   void ensure_queues(size_t n_pixels, int n_iters, bool gradient);
+  void ensure_share_buffers();
+  void issue_gather(int buf);    // all-gather + assemble (+ download) of the frame in gathered_[buf], on the communication stream
 
   std::shared_ptr<VolumeBase> volume_;
   CameraData camera_;
@@ -102,6 +116,14 @@ private:
   vec4f* host_fb_[2] = {nullptr, nullptr};
   size_t host_fb_pixels_ = 0;
   int fb_cur_ = 0;
+
+  // distributed mode: [world][n_local] share buffers and assembled frames, both double-buffered like fb_
+  bool distributed_ = false;
+  uint32_t share_world_ = 1, share_rank_ = 0, share_n_local_ = 0;
+  DeviceBuffer<vec4f> gathered_[2], full_[2];
+  hipEvent_t ev_rendered_ = nullptr, ev_gathered_[2] = {nullptr, nullptr};
+  bool gather_issued_[2] = {false, false};
+  int pipe_prev_ = -1;           // buffer of the rendered but not yet gathered frame of render_pipelined()
 
   // streaming queues
   DeviceBuffer<uint32_t> q_u32_;   // pixel_index[2], sample_base[2], sample_count[2]

@@ -127,7 +127,9 @@ public:
   // neural_sampler.cu:166-198 sample_grid: voxel-centre coords of a block + values
   void take_samples_grid(float* d_coords, float* d_values, vec3i origin, vec3i size, vec3f rdims, hipStream_t s);
   void sample(const float* d_coords, float* d_values, size_t n, bool nodal, hipStream_t s) const;
-  void set_sampler_seed(uint64_t seed, uint64_t stream_id) { rng_seed_ = seed; rng_stream_ = stream_id; rng_offset_ = 0; }
+  void set_sampler_seed(uint64_t seed, uint64_t stream_id) { rng_seed_ = seed; rng_stream_ = stream_id; rng_offset_ = 0; rng_user_set_ = true; }
+  // data-parallel training: rank r draws pcg32 stream (default stream + r) unless the application chose a stream itself
+  void set_sampler_rank(int rank) { if (!rng_user_set_) { rng_stream_ = 0xda3e39cb94b95bdbULL + (uint64_t)rank; rng_offset_ = 0; } }
 
 private:
   void finish_load(hipStream_t s);
@@ -138,6 +140,7 @@ private:
   MacroCell mc_;
   TfnObject tfn_;
   uint64_t rng_seed_ = 1337, rng_stream_ = 0xda3e39cb94b95bdbULL, rng_offset_ = 0;  // neural_sampler.cu:36
+  bool rng_user_set_ = false;
 };
 
 class NeuralVolume : public VolumeBase {  // core/network.h:29-107, core/network.cu:143-699
@@ -154,6 +157,15 @@ public:
   void load_params_from_json(const Json& root);             // network.cu:879-939
   void save_params_to_json(Json& root);                     // network.cu:827-857
   void train(size_t steps, bool fast_mode);                 // network.cu:769-779 + Impl::train :231-259
+  // Data-parallel training over the ranks of Dist (dist.h; new work): every rank samples its own batch and runs
+  // forward + backward; the gradient travels as fp16 (tcnn's own gradient precision), range by range while the backward pass of
+  // the coarser levels and the optimizer update of the ranges before it run; no host synchronisation inside a step on the RCCL
+  // transport.  One step equals one step on the concatenated batch (sum of the ranks' gradients / world).  The first call makes
+  // the replicas identical (parameters, optimizer state, step count and learning rate of rank 0) and gives every rank its own
+  // sample stream; an online macrocell is merged over the ranks at the end of the call (min / max per cell).
+  void train_data_parallel(size_t steps, bool fast_mode);
+  void all_reduce_gradients();                              // the TrainBegin / TrainEnd form: grads() summed over the ranks
+  void sync_replicas();                                     // broadcast rank 0's training state (also after SetParams on one rank)
   void train_begin();                                       // sample + forward + backward
   void train_end(float grad_scale, bool fast_mode);         // optimizer + macrocell update
   void forward_backward(const float* d_coords, const float* d_targets, size_t n);  // caller-provided batch
@@ -187,6 +199,9 @@ private:
   DeviceBuffer<float> decoded_{MemTag::Network}, decode_coords_{MemTag::Network};  // dense decoded volume, coordinates of one blob
   int decode_blob_ = 0;
   bool pending_step_ = false, pending_internal_ = false;
+  bool replicas_synced_ = false;
+  struct DpState;
+  std::unique_ptr<DpState> dp_;
   friend struct VolumeKeepAlive;
 
 public:

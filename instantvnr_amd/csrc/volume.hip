@@ -9,6 +9,7 @@
 #include <fstream>
 #include <thread>
 
+#include "dist.h"
 #include "sampling_device.h"
 #include "scene.h"
 
@@ -645,6 +646,51 @@ static void reduce_errors(const float* pred, const float* ref, size_t n, bool l2
 // ================================================================================================ NeuralVolume
 void network_release_scratch(const Network* n);
 
+void launch_pack_grads_f16(float* grads, uint16_t* out, size_t n, hipStream_t s);
+
+// value ranges are stored as (min - 1, max + 1) with 0 = "nothing seen yet" (macrocell.cu:35-39, 213-219): min - 1 <= 0 and
+// max + 1 >= 1, so the element-wise MIN over ranks of .x and MAX of .y merge the ranks' macrocells, untouched cells included
+__global__ void macrocell_merge_kernel(vec2f* __restrict__ range_max_reduced, const vec2f* __restrict__ range_min_reduced, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    range_max_reduced[i].x = range_min_reduced[i].x;
+}
+
+struct NeuralVolume::DpState : GradExchange {
+  NeuralVolume* nv = nullptr;
+  DeviceBuffer<uint16_t> grads_f16{MemTag::Network};   // the exchange payload, indexed like the parameter blob
+  struct Range { size_t lo, hi; hipEvent_t packed, reduced; };
+  std::vector<Range> ranges;     // this step's ranges in the order they became ready
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // events, reused step after step
+  hipEvent_t ev_updated = nullptr;   // the optimizer has consumed the payload of the previous step
+  size_t used = 0;
+
+  ~DpState() override
+  {
+    for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (ev_updated) (void)hipEventDestroy(ev_updated);
+  }
+  void range_ready(size_t lo, size_t hi, hipStream_t s) override
+  {
+    Dist& d = Dist::get();
+    hipStream_t comm = d.comm_stream();
+    if (used == pool.size()) {
+      hipEvent_t a, b;
+      VNR_HIP_CHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+      VNR_HIP_CHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      pool.emplace_back(a, b);
+    }
+    Range r{lo, hi, pool[used].first, pool[used].second};
+    ++used;
+    launch_pack_grads_f16(nv->net_.grads() + lo, grads_f16.ptr + lo, hi - lo, s);   // compute stream: overlaps the exchange of the range before
+    VNR_HIP_CHECK(hipEventRecord(r.packed, s));
+    VNR_HIP_CHECK(hipStreamWaitEvent(comm, r.packed, 0));
+    d.transport().all_reduce(grads_f16.ptr + lo, hi - lo, DistDType::F16, DistOp::Sum, comm);
+    VNR_HIP_CHECK(hipEventRecord(r.reduced, comm));
+    ranges.push_back(r);
+  }
+};
+
 NeuralVolume::NeuralVolume()
 {
   if (!Runtime::get().ready()) Runtime::get().init(-1);
@@ -735,6 +781,81 @@ void NeuralVolume::train(size_t steps, bool fast_mode)
     train_end(1.0f, fast_mode);
   }
   if (!fast_mode) mc_.update_max_opacity(tfn_.view(), stream);  // network.cu:778
+}
+
+// ------------------------------------------------------------------------------------------------ data-parallel training
+void launch_unpack_grads_f16(const uint16_t* in, float* grads, size_t n, hipStream_t s);
+
+void NeuralVolume::all_reduce_gradients()
+{
+  Dist& d = Dist::get();
+  if (!d.active() || !pending_step_) return;   // a one-rank group still runs the exchange (the identity): tests
+  if (!dp_) { dp_.reset(new DpState()); dp_->nv = this; VNR_HIP_CHECK(hipEventCreateWithFlags(&dp_->ev_updated, hipEventDisableTiming)); }
+  const size_t n = net_.n_params();
+  dp_->grads_f16.ensure(n);
+  launch_pack_grads_f16(net_.grads(), dp_->grads_f16.ptr, n, stream);
+  d.transport().all_reduce(dp_->grads_f16.ptr, n, DistDType::F16, DistOp::Sum, stream);
+  launch_unpack_grads_f16(dp_->grads_f16.ptr, net_.grads(), n, stream);
+}
+
+void NeuralVolume::sync_replicas()
+{
+  Dist& d = Dist::get();
+  if (!d.active()) { replicas_synced_ = true; return; }
+  net_.ensure_training_state(stream);
+  Transport& t = d.transport();
+  t.broadcast(net_.params_device(), net_.n_params() * sizeof(uint16_t), 0, stream);
+  t.broadcast(net_.opt_state_device(), net_.n_params() * sizeof(OptState), 0, stream);
+  double host[2] = {(double)net_.steps(), (double)net_.learning_rate()};
+  d.broadcast_host(host, sizeof(host), 0);
+  net_.set_replica_state((uint64_t)host[0], (float)host[1], stream);
+  if (source_) source_->set_sampler_rank(d.rank());
+  VNR_HIP_CHECK(hipStreamSynchronize(stream));
+  replicas_synced_ = true;
+}
+
+void NeuralVolume::train_data_parallel(size_t steps, bool fast_mode)
+{
+  Dist& d = Dist::get();
+  if (!d.active()) { train(steps, fast_mode); return; }
+  if (!net_.valid()) return;
+  if (!source_) throw std::runtime_error("missing a reference volume");
+  if (!replicas_synced_) sync_replicas();
+  if (!dp_) { dp_.reset(new DpState()); dp_->nv = this; VNR_HIP_CHECK(hipEventCreateWithFlags(&dp_->ev_updated, hipEventDisableTiming)); }
+  DpState& dp = *dp_;
+  dp.grads_f16.ensure(net_.n_params());
+  hipStream_t comm = d.comm_stream();
+  const vec3f lower = {0, 0, 0}, upper = {1, 1, 1};
+  const float scale = 1.0f / (float)d.world();
+  for (size_t i = 0; i < steps; ++i) {
+    source_->take_samples(train_x_.ptr, train_y_.ptr, batch_size_, lower, upper, stream);
+    dp.ranges.clear();
+    dp.used = 0;
+    net_.forward_backward(train_x_.ptr, train_y_.ptr, batch_size_, stream, &dp);
+    // the update of a range waits for that range's exchange only: Adam of the first ranges runs while the last ones travel
+    for (const DpState::Range& r : dp.ranges) {
+      VNR_HIP_CHECK(hipStreamWaitEvent(stream, r.reduced, 0));
+      net_.optimizer_step_range(r.lo, r.hi, dp.grads_f16.ptr, scale, stream);
+    }
+    net_.optimizer_finish_step(stream);
+    const bool update_mc = !(fast_mode && mc_.is_external());
+    if (update_mc && !mc_.is_external()) mc_.update_explicit(train_x_.ptr, train_y_.ptr, batch_size_, stream);
+  }
+  (void)comm;
+  if (!mc_.is_external()) {  // every rank has seen other samples: merge the value ranges so that all ranks skip the same cells
+    const size_t n = mc_.n_cells();
+    DeviceBuffer<float> tmp;
+    tmp.resize(2 * n);
+    VNR_HIP_CHECK(hipMemcpyAsync(tmp.ptr, mc_.d_value_range(), 2 * n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    d.transport().all_reduce(tmp.ptr, 2 * n, DistDType::F32, DistOp::Min, stream);
+    d.transport().all_reduce(mc_.d_value_range(), 2 * n, DistDType::F32, DistOp::Max, stream);
+    macrocell_merge_kernel<<<std::min<uint32_t>(div_round_up(n, 256), 4096u), 256, 0, stream>>>((vec2f*)mc_.d_value_range(), (const vec2f*)tmp.ptr, n);
+    VNR_HIP_CHECK(hipGetLastError());
+    VNR_HIP_CHECK(hipStreamSynchronize(stream));   // tmp goes out of scope
+    mc_.update_max_opacity(tfn_.view(), stream);
+  } else if (!fast_mode) {
+    mc_.update_max_opacity(tfn_.view(), stream);  // network.cu:778
+  }
 }
 
 float NeuralVolume::test_loss()

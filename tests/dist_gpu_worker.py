@@ -1,0 +1,145 @@
+"""One rank of a multi-process GPU test (tests/test_gpu_dist.py starts WORLD_SIZE of these on the ONE GPU of the test box, with
+the host-staged "shm" transport, or one of them with the "rccl" transport).  usage: dist_gpu_worker.py <scenario> <out.npz>
+Everything goes through the C-ABI entry points an application would use; results are written per rank for the parent to judge."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from instantvnr_amd import api, dist as vdist, synthetic as syn  # noqa: E402
+from instantvnr_amd._lib import check, lib  # noqa: E402
+
+SMALL_MODEL = dict(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
+
+
+def make_scene_objects(dims):
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = syn.oblique_camera(dims, distance_scale=0.95)
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    return tfn, camera
+
+
+def make_renderer(volume, tfn, camera, size, mode):
+    r = api.vnrCreateRenderer(volume)
+    api.vnrRendererSetTransferFunction(r, tfn)
+    api.vnrRendererSetCamera(r, camera)
+    api.vnrRendererSetFramebufferSize(r, size)
+    api.vnrRendererSetMode(r, mode)
+    return r
+
+
+def scenario_frames(ctx, out):
+    """the assembled frame of every rank equals the unsharded frame, bit for bit: synchronous API (vnrRender + vnrRendererMapFrame,
+    host frames), pipelined API (device frames), accumulation over frames, ragged and even tile-row counts, dense and neural volumes"""
+    L = lib()
+    vol = syn.analytic_volume(48)
+    sv = api.vnrCreateSimpleVolume(vol)
+    os.environ["VNR_AMD_INIT_SEED"] = "4242"   # identical networks on every rank without any exchange
+    nv = api.vnrCreateNeuralVolume(syn.model_config(**SMALL_MODEL), sv, online_macrocell_construction=False)
+    api.vnrNeuralVolumeTrain(nv, 30, True)     # every rank trains the same 30 steps on the same stream: identical up to atomics order ...
+    check(L.vnrAmdNeuralVolumeSyncReplicas(nv.h))   # ... and exactly identical after this
+    tfn, camera = make_scene_objects((48, 48, 48))
+    n_frames = 3
+    for case, (volume, size, mode) in enumerate([(sv, (96, 80), 5), (sv, (64, 64), 5), (nv, (96, 80), 5), (sv, (72, 40), 4), (nv, (64, 64), 8)]):
+        plain = make_renderer(volume, tfn, camera, size, mode)
+        want = []
+        for _ in range(n_frames):
+            api.vnrRender(plain)
+            want.append(api.vnrRendererMapFrame(plain).copy())
+        # synchronous: the calls an unchanged application makes
+        r_sync = make_renderer(volume, tfn, camera, size, mode)
+        check(L.vnrAmdRendererSetDistributed(r_sync.h, 1))
+        ok_sync = True
+        for k in range(n_frames):
+            api.vnrRender(r_sync)
+            ok_sync = ok_sync and bool(np.array_equal(api.vnrRendererMapFrame(r_sync), want[k]))
+        # pipelined: frame k - 1 is gathered while frame k renders
+        sr = vdist.ShardedRenderer(ctx, make_renderer(volume, tfn, camera, size, mode), size[0], size[1])
+        got = []
+        for k in range(n_frames):
+            f = sr.render()
+            if k == 0:
+                assert f is None
+            else:
+                got.append(sr.download(f))
+        got.append(sr.download(sr.flush()))
+        assert sr.flush() is None
+        ok_pipe = all(np.array_equal(g, w) for g, w in zip(got, want))
+        st = api.vnrRendererGetFrameStats(sr.r)
+        out[f"case{case}_sync"] = ok_sync
+        out[f"case{case}_pipe"] = ok_pipe
+        out[f"case{case}_coverage"] = float((want[-1][..., 3] > 0).mean())
+        out[f"case{case}_samples"] = int(st["n_samples"])
+        vdist.barrier()
+
+
+def scenario_train(ctx, out):
+    """data-parallel training: replicas start from DIFFERENT seeds and must be identical after the first call; parameters stay
+    identical over the steps; the by-hand form (TrainBegin / AllReduceGradients / TrainEnd) follows the same trajectory"""
+    L = lib()
+    vol = syn.analytic_volume(32)
+    os.environ["VNR_AMD_INIT_SEED"] = str(100 + ctx.rank)
+    steps = int(os.environ.get("TEST_STEPS", "20"))
+    sv = api.vnrCreateSimpleVolume(vol)
+    nv = api.vnrCreateNeuralVolume(syn.model_config(**SMALL_MODEL), sv, online_macrocell_construction=False)
+    before = vdist.params_checksum(nv)
+    vdist.train_data_parallel(ctx, nv, steps)
+    out["checksum_before"] = before
+    out["checksum"] = vdist.params_checksum(nv)
+    out["loss"] = api.vnrNeuralVolumeGetTrainingLoss(nv)
+    out["step"] = api.vnrNeuralVolumeGetTrainingStep(nv)
+    out["params"] = api.neural_get_params_fp16(nv).view(np.uint16)
+    sv2 = api.vnrCreateSimpleVolume(vol)
+    nv2 = api.vnrCreateNeuralVolume(syn.model_config(**SMALL_MODEL), sv2, online_macrocell_construction=False)
+    vdist.train_data_parallel_by_hand(ctx, nv2, steps)
+    out["checksum_by_hand"] = vdist.params_checksum(nv2)
+    out["params_by_hand"] = api.neural_get_params_fp16(nv2).view(np.uint16)
+    out["psnr"] = api.vnrNeuralVolumeGetPSNR(nv)
+
+
+def scenario_macrocell(ctx, out):
+    """online macrocell construction under data-parallel training: every rank ends with the min / max over ALL ranks' samples"""
+    vol = syn.analytic_volume(32)
+    os.environ["VNR_AMD_INIT_SEED"] = "9"
+    sv = api.vnrCreateSimpleVolume(vol)
+    nv = api.vnrCreateNeuralVolume(syn.model_config(**SMALL_MODEL), sv, online_macrocell_construction=True)
+    vdist.train_data_parallel(ctx, nv, 3, fast_mode=False)
+    mc = api.volume_macrocell(nv)
+    out["value_range"] = mc["value_range"]
+    out["max_opacity"] = mc["max_opacity"]
+
+
+def scenario_ooc(ctx, out):
+    """BASELINE C5 in small: out-of-core volume, every rank its own slab set, gradients exchanged every step"""
+    path, n = os.environ["TEST_OOC_FILE"], int(os.environ["TEST_OOC_SIZE"])
+    os.environ["VNR_AMD_INIT_SEED"] = "11"
+    sv = api.vnrCreateSimpleVolumeOutOfCore(path, (n, n, n), "uint8", (0.0, 255.0), n_concurrent_blocks=8, n_blocks=64)
+    out["slabs"] = np.asarray(api.out_of_core_blocks(sv))
+    nv = api.vnrCreateNeuralVolume(syn.model_config(**SMALL_MODEL), sv, online_macrocell_construction=True)
+    vdist.train_data_parallel(ctx, nv, int(os.environ.get("TEST_STEPS", "300")))
+    out["checksum"] = vdist.params_checksum(nv)
+    out["psnr"] = api.vnrNeuralVolumeGetPSNR(nv)
+    out["loss"] = api.vnrNeuralVolumeGetTrainingLoss(nv)
+    out["value_range"] = api.volume_macrocell(nv)["value_range"]
+
+
+def main():
+    scenario, out_path = sys.argv[1], sys.argv[2]
+    ctx = vdist.init_from_env()
+    out = {"rank": ctx.rank, "world": ctx.world, "transport": ctx.transport or "none"}
+    {"frames": scenario_frames, "train": scenario_train, "macrocell": scenario_macrocell, "ooc": scenario_ooc}[scenario](ctx, out)
+    vdist.barrier()
+    np.savez(out_path, **out)
+    vdist.finalize()
+
+
+if __name__ == "__main__":
+    main()

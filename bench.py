@@ -4,13 +4,18 @@
 Metric (BASELINE.json): fps at 1024^2 on a 1024^3 volume + MLP Msamples/s; PSNR vs ground truth.
 One "step" = one frame: sample-streaming ray march (rendering mode 5) of the trained neural volume
 (HashGrid L=16 F=2 T=2^22 + 3x64 FullyFusedMLP) at 1024x1024; with N GPUs the image is sharded by interleaved
-scanline blocks and gathered with one RCCL all_gather per frame (strong scaling: total work is fixed).
+8-scanline tile rows and every frame is gathered with one RCCL all-gather (strong scaling: total work is fixed).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Untimed setup: generate the synthetic 1024^3 Perlin volume on the GPU, train the model (data parallel with an RCCL
-gradient all-reduce when N > 1), build the renderer.  Rank 0 prints ONE JSON line.
+torch.distributed.run is only the launcher: this program reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and does everything,
+collectives included, through libvnr_amd.so (vnrAmdDist*, RCCL opened with dlopen); it never imports torch.
+
+Untimed setup: generate the synthetic volume on the GPU, train the model (data parallel with an RCCL gradient exchange when
+N > 1), build the renderer.  Rank 0 prints ONE JSON line.
+Other BASELINE configurations through the same program: C2 + C3 = `--size 128 --fb 512 --levels 8 --features 8
+--log2-hashmap-size 19 --hidden-layers 2 --per-level-scale 2 --train-steps 10000` (synthetic vortex field).
 """
 import argparse
 import json
@@ -32,10 +37,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--steps", type=int, default=100)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--size", type=int, default=1024, help="volume edge (C4: 1024)")
     p.add_argument("--fb", type=int, default=1024, help="framebuffer edge (C4: 1024)")
+    p.add_argument("--volume", choices=("auto", "perlin", "vortex"), default="auto",
+                   help="synthetic field: perlin fBm generated on the GPU (C4), vortex tubes (C2 / C3 stand-in for vorts1); auto = vortex up to 256^3")
     p.add_argument("--levels", type=int, default=16)
     p.add_argument("--features", type=int, default=2)
     p.add_argument("--log2-hashmap-size", type=int, default=22)
@@ -47,6 +54,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-psnr", action="store_true")
     p.add_argument("--no-alone", action="store_true", help="skip the un-timed one-stream leg (roofline.alone)")
+    p.add_argument("--no-brick-off", action="store_true", help="skip the un-timed leg without the brick image (train-while-render configuration)")
     p.add_argument("--no-kernel-events", action="store_true", help="diagnostics: no HIP events around the evaluation kernel (roofline.achieved reads 0)")
     p.add_argument("--mode", type=int, default=5, choices=(5, 8, 11, 14),
                    help="rendering mode: 5 = sample streaming (BASELINE metric, default), 8 = the same with gradient shading (4 evaluations per sample)")
@@ -103,6 +111,30 @@ def cpu_baseline(sv, nv, info, dims, tfn_np, cam, fb, mc, pls, hidden_layers, lo
     return out
 
 
+def workload_name(a):
+    if (a.size, a.fb, a.levels, a.features, a.hidden_layers) == (1024, 1024, 16, 2, 3):
+        return "C4"
+    if (a.size, a.fb, a.levels, a.features, a.hidden_layers) == (128, 512, 8, 8, 2):
+        return "C2 (model trained as C3)"
+    return "custom"
+
+
+def untimed_frames(ren, n, warm=3):
+    """n frames of an already configured renderer, timed on the host; -> (fps, samples, kernel ms, launches, union ms)"""
+    for _ in range(warm):
+        api.vnrRender(ren); api.vnrRendererMapFrame(ren)
+    check(lib().vnrAmdSynchronize())
+    t = time.perf_counter()
+    samples = launches = 0
+    ms = union = 0.0
+    for _ in range(n):
+        api.vnrRender(ren); api.vnrRendererMapFrame(ren)
+        s = api.vnrRendererGetFrameStats(ren)
+        samples += s["n_samples"]; ms += s["infer_kernel_ms"]; launches += s["infer_kernel_launches"]; union += s["infer_union_ms"]
+    check(lib().vnrAmdSynchronize())
+    return n / (time.perf_counter() - t), samples, ms, launches, union
+
+
 def main():
     a = parse()
     if os.environ.get("VNR_BENCH_DUMP_AFTER"):  # diagnostics: where does a run that hangs under the profiler stand?
@@ -115,22 +147,34 @@ def main():
     L = lib()
     dims = (a.size, a.size, a.size)
     pls = a.per_level_scale if a.per_level_scale > 0 else float(np.exp(np.log(a.size / 16.0) / max(a.levels - 1, 1)))
-    os.environ.setdefault("VNR_AMD_INIT_SEED", "20240611")  # identical initial parameters on every rank
+    os.environ.setdefault("VNR_AMD_INIT_SEED", "20240611")  # reproducible initial parameters (N > 1: rank 0's are broadcast anyway)
+    kind = a.volume if a.volume != "auto" else ("vortex" if a.size <= 256 else "perlin")
 
     # ---- setup (untimed) -------------------------------------------------------------------------------------
     t_setup = time.perf_counter()
-    sv = api.vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=6.0)
+    if kind == "vortex":
+        sv = api.vnrCreateSimpleVolume(syn.vortex_volume(a.size, seed=1234))
+        volume_desc = f"{a.size}^3 synthetic vortex-tube field (seed 1234; stand-in for vorts1, SURVEY 8c)"
+    else:
+        sv = api.vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=6.0)
+        volume_desc = f"{a.size}^3 synthetic Perlin fBm volume (seed 42)"
     cfg = syn.model_config(n_levels=a.levels, n_features=a.features, log2_hashmap_size=a.log2_hashmap_size, base_resolution=16,
                            n_hidden_layers=a.hidden_layers, per_level_scale=pls)
     # ground-truth macrocell (identical on every rank, so tiles compose exactly)
     nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
-    check(L.vnrAmdNeuralVolumeSetSamplerSeed(nv.h, 1337, 0xda3e39cb94b95bdb + ctx.rank))
     info = api.neural_info(nv)
     check(L.vnrAmdSynchronize())
+    # training: the model the frames are rendered from; its last <= 64 steps are profiled kernel by kernel (HIP events)
+    check(L.vnrAmdNeuralVolumeSetTrainProfiling(nv.h, 1))
     t_train = time.perf_counter()
     dist.train_data_parallel(ctx, nv, a.train_steps, fast_mode=True)
     check(L.vnrAmdSynchronize())
     train_ms = (time.perf_counter() - t_train) * 1e3 / max(a.train_steps, 1)
+    import ctypes as C
+    phase_ms = (C.c_double * 5)()
+    n_prof = C.c_int()
+    check(L.vnrAmdNeuralVolumeGetTrainProfile(nv.h, phase_ms, C.byref(n_prof)))
+    check(L.vnrAmdNeuralVolumeSetTrainProfiling(nv.h, 0))
     train_loss = api.vnrNeuralVolumeGetTrainingLoss(nv)
     psnr = None
     if not a.no_psnr and ctx.rank == 0:
@@ -144,12 +188,19 @@ def main():
     cam = syn.oblique_camera(dims, distance_scale=a.camera_distance)
     camera = api.vnrCreateCamera()
     api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
-    ren = api.vnrCreateRenderer(nv)
-    api.vnrRendererSetTransferFunction(ren, tfn)
-    api.vnrRendererSetCamera(ren, camera)
-    api.vnrRendererSetFramebufferSize(ren, (a.fb, a.fb))
-    api.vnrRendererSetMode(ren, a.mode)
-    api.vnrRendererSetProfiling(ren, not a.no_kernel_events)  # HIP events around the fused encode+MLP kernel, on its own stream
+
+    def make_renderer(volume, device_output=True, profiling=True):
+        rr = api.vnrCreateRenderer(volume)
+        api.vnrRendererSetTransferFunction(rr, tfn)
+        api.vnrRendererSetCamera(rr, camera)
+        api.vnrRendererSetFramebufferSize(rr, (a.fb, a.fb))
+        api.vnrRendererSetMode(rr, a.mode)
+        if device_output:
+            api.vnrRendererSetOutputAsDeviceFramebuffer(rr, True)
+        api.vnrRendererSetProfiling(rr, profiling)
+        return rr
+
+    ren = make_renderer(nv, device_output=False, profiling=not a.no_kernel_events)  # HIP events around the fused encode+MLP kernel, on its own stream
     sr = dist.ShardedRenderer(ctx, ren, a.fb, a.fb)
     setup_s = time.perf_counter() - t_setup
 
@@ -168,20 +219,17 @@ def main():
         st = api.vnrRendererGetFrameStats(ren)
         samples += st["n_samples"]; slots += st["n_reference_slots"]; infer_ms += st["infer_kernel_ms"]; union_ms += st["infer_union_ms"]
         launches += st["infer_kernel_launches"]; iters = st["n_iterations"]
-    sr.flush()   # N > 1: the gather of the last frame (ShardedRenderer pipelines render k with gather k - 1); every frame is rendered AND gathered inside the timed region
+    sr.flush()   # N > 1: the gather of the last frame (render k runs beside gather k - 1); every frame is rendered AND gathered inside the timed region
     dist.barrier(ctx)
     elapsed = time.perf_counter() - t0
     rays_hit = st["n_rays_hit"]
+    brick_state = api.neural_brick_image(nv)
 
     # ---- un-timed: the neural frame against the frame of the ground-truth volume (same camera / TFN / mode / macrocell) --------
     image = None
     if ctx.world == 1 and not a.no_psnr:
         def one_frame(volume):
-            rr = api.vnrCreateRenderer(volume)
-            api.vnrRendererSetTransferFunction(rr, tfn)
-            api.vnrRendererSetCamera(rr, camera)
-            api.vnrRendererSetFramebufferSize(rr, (a.fb, a.fb))
-            api.vnrRendererSetMode(rr, a.mode)
+            rr = make_renderer(volume, device_output=False, profiling=False)
             api.vnrRender(rr)
             return api.vnrRendererMapFrame(rr).astype(np.float64).copy()
 
@@ -193,49 +241,46 @@ def main():
                  "l2_per_pixel_mean": round(float(np.sqrt((d ** 2).sum(axis=2)).mean()), 6),
                  "l2_per_pixel_max": round(float(np.sqrt((d ** 2).sum(axis=2)).max()), 5)}
 
-    # ---- un-timed extra leg (one GPU only): the dominant kernel with the GPU to itself -------------------------------------
-    # The default renderer runs two ray halves on two HIP streams, so a launch of the fused kernel shares the GPU with the
-    # other half's kernels and its HIP-event duration says little about the kernel.  The same frames on ONE stream (nothing
-    # else resident while the kernel runs) give the per-launch figure the roofline fraction is meant to be.
+    # ---- un-timed extra legs (one GPU only) ------------------------------------------------------------------------------------
+    # (1) the dominant kernel with the GPU to itself.  The default renderer runs two ray halves on two HIP streams, so a launch of
+    # the fused kernel shares the GPU with the other half's kernels and its HIP-event duration says little about the kernel.  The
+    # same frames on ONE stream (nothing else resident while the kernel runs) give the per-launch figure the roofline fraction is
+    # meant to be.
+    n_leg = max(5, min(a.steps // 2, 30))
     alone = None
     if ctx.world == 1 and not a.no_alone and os.environ.get("VNR_AMD_RENDER_HALVES", "2") != "1":
         os.environ["VNR_AMD_RENDER_HALVES"] = "1"
-        ren1 = api.vnrCreateRenderer(nv)
+        ren1 = make_renderer(nv)
         del os.environ["VNR_AMD_RENDER_HALVES"]
-        api.vnrRendererSetTransferFunction(ren1, tfn)
-        api.vnrRendererSetCamera(ren1, camera)
-        api.vnrRendererSetFramebufferSize(ren1, (a.fb, a.fb))
-        api.vnrRendererSetMode(ren1, a.mode)
-        api.vnrRendererSetOutputAsDeviceFramebuffer(ren1, True)
-        api.vnrRendererSetProfiling(ren1, True)
-        for _ in range(3):
-            api.vnrRender(ren1); api.vnrRendererMapFrame(ren1)
-        check(L.vnrAmdSynchronize())
-        t1 = time.perf_counter()
-        a_samples = a_launches = 0
-        a_ms = 0.0
-        n_alone = max(5, a.steps // 2)
-        for _ in range(n_alone):
-            api.vnrRender(ren1); api.vnrRendererMapFrame(ren1)
-            s1 = api.vnrRendererGetFrameStats(ren1)
-            a_samples += s1["n_samples"]; a_ms += s1["infer_kernel_ms"]; a_launches += s1["infer_kernel_launches"]
-        check(L.vnrAmdSynchronize())
-        alone = {"frames": n_alone, "fps": round(n_alone / (time.perf_counter() - t1), 2), "samples": a_samples, "ms": a_ms, "launches": a_launches}
+        fps1, a_samples, a_ms, a_launches, _ = untimed_frames(ren1, n_leg)
+        alone = {"frames": n_leg, "fps": round(fps1, 2), "samples": a_samples, "ms": a_ms, "launches": a_launches}
         del ren1
+    # (2) the same frames WITHOUT the brick image: what an application that trains while it renders gets (every optimizer step
+    # drops the image, so it never exists there); the image costs `inference_cache.brick_image_bytes` of HBM
+    brick_off = None
+    if ctx.world == 1 and not a.no_brick_off and brick_state["in_use"]:
+        check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, 0))
+        ren2 = make_renderer(nv)
+        fps2, b_samples, b_ms, b_launches, b_union = untimed_frames(ren2, n_leg)
+        del ren2
+        os.environ["VNR_AMD_RENDER_HALVES"] = "1"
+        ren3 = make_renderer(nv)
+        del os.environ["VNR_AMD_RENDER_HALVES"]
+        _, c_samples, c_ms, c_launches, _ = untimed_frames(ren3, max(5, n_leg // 2))
+        del ren3
+        brick_off = {"frames": n_leg, "fps": fps2, "samples": b_samples, "ms": b_ms, "launches": b_launches, "union": b_union,
+                     "alone_samples": c_samples, "alone_ms": c_ms, "alone_launches": c_launches}
+        check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
 
     if ctx.distributed:
-        import torch
-        import torch.distributed as td
-        mx = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        td.all_reduce(mx, op=td.ReduceOp.MAX)          # MAX over ranks of the timed region
-        elapsed = float(mx[0])
-        sm = torch.tensor([float(samples), float(slots), float(rays_hit)], dtype=torch.float64, device="cuda")
-        td.all_reduce(sm, op=td.ReduceOp.SUM)
-        samples_all, slots_all, rays_hit = float(sm[0]), float(sm[1]), int(sm[2])
+        elapsed = dist.all_reduce_host([elapsed], dist.MAX)[0]          # MAX over ranks of the timed region
+        samples_all, slots_all, rays_f = dist.all_reduce_host([float(samples), float(slots), float(rays_hit)], dist.SUM)
+        rays_hit = int(rays_f)
     else:
         samples_all, slots_all = float(samples), float(slots)
 
     if ctx.rank != 0:
+        dist.barrier(ctx)
         return
     fps = a.steps / elapsed
     # the renderer counts SHADED samples; with gradient shading (mode 8) the network evaluates 4 coordinates for each of them,
@@ -284,36 +329,80 @@ def main():
     # --pmc passes, tools/run_pmc.sh); a committed result applies only to the exact default workload on one GPU with
     # the same stream configuration it was measured with.
     default_workload = (a.size, a.fb, a.levels, a.features, a.log2_hashmap_size, a.hidden_layers, a.per_level_scale,
-                        a.train_steps, a.opacity_scale, a.camera_distance, a.mode) == (1024, 1024, 16, 2, 22, 3, 0.0, 1500, 0.06, 1.1, 5)
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_l_pmc_traffic.json")
-    brick = api.neural_brick_image(nv)["in_use"]
-    if default_workload and ctx.world == 1 and brick and os.path.exists(pmc_path):
+                        a.train_steps, a.opacity_scale, a.camera_distance, a.mode, kind) == (1024, 1024, 16, 2, 22, 3, 0.0, 1500, 0.06, 1.1, 5, "perlin")
+    pmc_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_traffic.json", "r01_l_pmc_traffic.json")) if os.path.exists(p)), None)
+    if default_workload and ctx.world == 1 and brick_state["in_use"] and pmc_path:
         pmc = json.load(open(pmc_path))
         leg = pmc["one_stream" if halves == 1 else "two_streams"]
-        roofline["traffic"] = round(leg["traffic_per_launch"])
+        per_sample = leg.get("bytes_per_sample") or leg["traffic_over_algorithmic"] * bytes_per_sample
+        roofline["traffic"] = round(per_sample * samples / max(launches, 1))
         roofline["traffic_unit"] = "bytes per launch (L2<->fabric reads x2-corrected + writes; includes Infinity-Cache hits)"
         roofline["algorithmic_bytes_per_launch"] = round(samples * bytes_per_sample / max(launches, 1))
-        roofline["traffic_note"] = ("measured in separate rocprofv3 --pmc passes of this command, not in this run: profiles/r01_l_pmc_traffic.json "
-                                    "(traffic/algorithmic = %.2f; 2.09 before the brick image, profiles/r01_pmc_traffic.json)" % leg["traffic_over_algorithmic"])
+        # the bound the counters point at: what actually crosses the fabric per second while the kernel runs
+        if union_ms > 0:
+            t_gbs = per_sample * samples / (union_ms * 1e-3) / 1e9
+            roofline["traffic_frac"] = {"what": "measured fabric bytes per sample x this run's samples / the union of the launch intervals / 8 TB/s: the kernel "
+                                                "is no longer bound by bytes (L1 / texture-addresser latency, DESIGN 4.1); the algorithmic fraction flatters it",
+                                        "achieved": round(t_gbs, 1), "frac": round(t_gbs / HBM_PEAK_GBS, 4), "bytes_per_sample": round(per_sample, 1)}
+        roofline["traffic_note"] = (f"bytes per sample measured in separate rocprofv3 --pmc passes of the same frame, not in this run: {os.path.relpath(pmc_path, ROOT)} "
+                                    "(traffic / algorithmic = %.2f; 2.09 before the brick image, profiles/r01_pmc_traffic.json)" % (per_sample / bytes_per_sample))
         if "alone" in roofline:
-            t1 = pmc["one_stream"].get("traffic_per_launch")
-            roofline["alone"]["traffic"] = round(t1) if t1 else None
+            one = pmc["one_stream"]
+            ps1 = one.get("bytes_per_sample") or one["traffic_over_algorithmic"] * bytes_per_sample
+            roofline["alone"]["traffic"] = round(ps1 * alone["samples"] / max(alone["launches"], 1))
     else:
-        roofline["traffic_note"] = "null: the committed PMC passes (profiles/r01_l_pmc_traffic.json) describe the default workload on one GPU with the brick image"
+        roofline["traffic_note"] = "null: the committed PMC passes (profiles/*_pmc_traffic.json) describe the default workload on one GPU with the brick image"
+    if brick_off:
+        ev = brick_off["samples"] * evals_per_sample
+        leg = {"what": "un-timed leg of this run with the brick image switched off: the configuration of an application that trains while it renders "
+                       "(every optimizer step drops the image)",
+               "fps": round(brick_off["fps"], 2), "frames": brick_off["frames"],
+               "frame_frac": round((ev / brick_off["frames"]) * bytes_per_sample * brick_off["fps"] / 1e9 / HBM_PEAK_GBS, 4)}
+        if brick_off["union"] > 0:
+            leg["kernel_union_frac"] = round(ev * bytes_per_sample / (brick_off["union"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if brick_off["alone_ms"] > 0:
+            ev1 = brick_off["alone_samples"] * evals_per_sample
+            leg["kernel_alone_frac"] = round(ev1 * bytes_per_sample / (brick_off["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            leg["kernel_alone_msamples_per_s"] = round(ev1 / (brick_off["alone_ms"] * 1e-3) / 1e6, 1)
+        roofline["brick_off"] = leg
+
+    # ---- training step: algorithmic bytes per SURVEY 8(d) and the live per-kernel split -------------------------------------------
+    B, Lv, F, n_params = 65536, info["n_levels"], info["n_features_per_level"], info["n_params"]
+    fwd_bytes = bytes_per_sample * B
+    bwd_bytes = Lv * 8 * F * 2 * 2 * B
+    opt_bytes = n_params * (2 + 4 + 4 + 4) * 2
+    step_bytes = fwd_bytes + bwd_bytes + opt_bytes
+    names = ["forward (fused encode + MLP, keeps activations)", "loss + MLP backward (MFMA)", "weight gradients", "grid backward (float atomics)",
+             "optimizer (Adam, fp32 master)" + (" incl. waiting for the gradient exchange" if ctx.distributed else "")]
+    kernel_ms = [float(phase_ms[i]) for i in range(5)]
+    step_kernel_ms = sum(kernel_ms)
+    train_roofline = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_step": step_bytes,
+                      "algorithmic_bytes": {"forward": fwd_bytes, "grid_backward_rmw": bwd_bytes, "optimizer_sweep": opt_bytes,
+                                            "what": "SURVEY 8(d): 528 B x B forward, L*8*F*2*2 B x B scatter, n_params x 14 B read + 14 B written"},
+                      "achieved": round(step_bytes / (train_ms * 1e-3) / 1e9, 1), "frac": round(step_bytes / (train_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "ms_per_step_wall": round(train_ms, 4), "ms_per_step_kernels": round(step_kernel_ms, 4), "profiled_steps": int(n_prof.value),
+                      "kernels_ms": {n: round(v, 4) for n, v in zip(names, kernel_ms)},
+                      "note": "the optimizer sweep dominates the algorithmic bytes; the implementation skips untouched grid entries (about 10 % are touched "
+                              "per step), so `frac` measures the step against a dense sweep it does not perform"}
+
     out = {
         "metric": "fps at 1024^2 on 1024^3 volume" if (a.size, a.fb, a.mode) == (1024, 1024, 5) else f"fps at {a.fb}^2 on {a.size}^3 volume, rendering mode {a.mode}" if a.mode != 5 else f"fps at {a.fb}^2 on {a.size}^3 volume",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"C4: {a.size}^3 synthetic Perlin fBm volume (seed 42), HashGrid L={a.levels} F={a.features} "
+        "config": {"workload": f"{workload_name(a)}: {volume_desc}, HashGrid L={a.levels} F={a.features} "
                                f"T=2^{a.log2_hashmap_size} base 16 per_level_scale {pls:.4f} + {a.hidden_layers}x64 FullyFusedMLP, "
                                f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading' if a.mode == 8 else 'sample streaming, single-shade heuristic: camera pass + shadow pass' if a.mode == 11 else 'path tracing, sample streaming'}), sampling rate 1, N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24 (32 when a rank renders at most 196608 pixels)')}",
                    "volume": f"{a.size}^3", "framebuffer": f"{a.fb}x{a.fb}", "n_params": info["n_params"],
                    "tfn": f"256-entry ramp-with-bumps, seed 7, opacity scale {a.opacity_scale}",
                    "camera": cam, "train_steps": a.train_steps, "batch": 65536,
-                   "brick_image": {k: (round(v / 2**30, 2) if k == "bytes" else round(v, 2) if k == "build_ms" else v)
-                                   for k, v in api.neural_brick_image(nv).items()} | {"unit": "bytes in GiB; built once, in the warm-up"},
-                   "parallelism": f"image tiles x{ctx.world} (interleaved 8-scanline blocks) + RCCL all_gather" if ctx.world > 1 else "single GPU"},
+                   "parallelism": (f"image tiles x{ctx.world} (interleaved 8-scanline tile rows) + one in-place all-gather per frame through libvnr_amd "
+                                   f"(transport {ctx.transport}); training data parallel, fp16 gradient exchange") if ctx.distributed else "single GPU"},
+        "inference_cache": {"what": "brick image: de-hashed copy of the hashed levels, built once the parameters have been left unchanged for 24 launches, "
+                                    "dropped by every optimizer step; results are bit-identical with and without it",
+                            "in_use": bool(brick_state["in_use"]), "brick_image_bytes": int(brick_state["bytes"]), "model_bytes": int(info["n_params"]) * 2,
+                            "ratio": round(brick_state["bytes"] / (info["n_params"] * 2.0), 1), "build_ms": round(brick_state["build_ms"], 2)},
         "mlp_msamples_per_s": round(samples_all / elapsed / 1e6, 1),
         "mlp_msamples_per_s_kernel_only": round(samples / (infer_ms * 1e-3) / 1e6, 1) if infer_ms > 0 else None,
         "samples_per_frame": int(samples_all / a.steps), "samples_per_hit_ray": round(samples_all / a.steps / max(rays_hit, 1), 1),
@@ -322,11 +411,13 @@ def main():
         "psnr_db": None if psnr is None else round(psnr, 2), "image_vs_ground_truth": image, "train_ms_per_step": round(train_ms, 3), "train_loss": round(train_loss, 5),
         "setup_s": round(setup_s, 1),
         "roofline": roofline,
+        "train_roofline": train_roofline,
     }
     if ctx.world == 1 and not a.no_cpu_baseline:
         mc = api.volume_macrocell(nv)
         out["cpu_baseline"] = cpu_baseline(sv, nv, info, dims, (colors, alphas), cam, a.fb, mc, pls, a.hidden_layers, a.log2_hashmap_size)
     print(json.dumps(out), flush=True)
+    dist.barrier(ctx)
 
 
 if __name__ == "__main__":

@@ -195,6 +195,13 @@ int    vnrAmdNeuralVolumeEncode(vnrAmdVolume, size_t n, const float* d_coords, u
  * once the parameters have been left unchanged for VNR_AMD_BRICK_AFTER (24) inference launches and dropped when they change;
  * VNR_AMD_BRICK=0 disables it, =1 builds it at the first launch; VNR_AMD_BRICK_MAX_GB (32) bounds it.  Results do not depend on it. */
 int    vnrAmdNeuralVolumeBrickImageInfo(vnrAmdVolume, int* in_use, size_t* bytes, float* build_ms);
+/* AMD extension: -1 = the environment's policy, 0 = never use the image (frees it: the train-while-render configuration),
+ * 1 = build it at the next launch */
+int    vnrAmdNeuralVolumeSetBrickImageMode(vnrAmdVolume, int mode);
+/* AMD extension (measurement): HIP events around the kernels of the training step; GetTrainProfile averages the last <= 64 steps:
+ * ms_per_step = {forward, loss + MLP backward, weight gradients, grid backward (+ the exchange's pack kernels), optimizer} */
+int    vnrAmdNeuralVolumeSetTrainProfiling(vnrAmdVolume, int enable);
+int    vnrAmdNeuralVolumeGetTrainProfile(vnrAmdVolume, double ms_per_step[5], int* n_steps);
 int    vnrAmdNeuralVolumeGetInfo(vnrAmdVolume, int* n_levels, int* n_features_per_level, int* padded_width,
                                  int* n_neurons, int* n_hidden_layers, uint64_t* n_params);
 /* raw tcnn-order parameter blob (MLP weights, then grid), fp16 */

@@ -191,6 +191,9 @@ def lib():
     sig("vnrAmdRendererFlushPipeline", I, P, C.POINTER(P))
     sig("vnrAmdNeuralVolumeTrainDataParallel", I, P, I, I)
     sig("vnrAmdNeuralVolumeSyncReplicas", I, P)
+    sig("vnrAmdNeuralVolumeSetBrickImageMode", I, P, I)
+    sig("vnrAmdNeuralVolumeSetTrainProfiling", I, P, I)
+    sig("vnrAmdNeuralVolumeGetTrainProfile", I, P, C.POINTER(D), IP)
     sig("vnrAmdNeuralVolumeAllReduceGradients", I, P)
     sig("vnrAmdMemoryQuery", None, C.POINTER(SZ), C.POINTER(SZ))
     sig("vnrAmdFreeTemporaryGPUMemory", None)

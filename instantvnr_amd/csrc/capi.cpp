@@ -803,6 +803,15 @@ int vnrAmdNeuralVolumeTrainDataParallel(vnrAmdVolume v, int steps, int fast_mode
 {
   return guarded([&]() { as_neural(v)->train_data_parallel((size_t)std::max(steps, 0), fast_mode != 0); });
 }
+int vnrAmdNeuralVolumeSetBrickImageMode(vnrAmdVolume v, int mode) { return guarded([&]() { as_neural(v)->network().set_brick_mode(mode); }); }
+int vnrAmdNeuralVolumeSetTrainProfiling(vnrAmdVolume v, int e) { return guarded([&]() { as_neural(v)->network().set_train_profiling(e != 0); }); }
+int vnrAmdNeuralVolumeGetTrainProfile(vnrAmdVolume v, double ms_per_step[5], int* n_steps)
+{
+  return guarded([&]() {
+    const int n = as_neural(v)->network().train_profile(ms_per_step);
+    if (n_steps) *n_steps = n;
+  });
+}
 int vnrAmdNeuralVolumeSyncReplicas(vnrAmdVolume v) { return guarded([&]() { as_neural(v)->sync_replicas(); }); }
 int vnrAmdNeuralVolumeAllReduceGradients(vnrAmdVolume v) { return guarded([&]() { as_neural(v)->all_reduce_gradients(); }); }
 

@@ -148,6 +148,8 @@ public:
   // i.e. up to about the resolution of the volume the network represents (NeuralVolume passes twice its largest dimension).
   // A 128^3 volume with tcnn's default per_level_scale 2 has levels up to 2048^3, whose image would be 137 GB and useless.
   void set_brick_resolution_cap(uint32_t cap) { brick_res_cap_ = cap; }
+  // -1: the environment's policy (VNR_AMD_BRICK, default automatic), 0: never (drops an existing image), 1: build at the next launch
+  void set_brick_mode(int mode);
   bool brick_image_in_use() const { return brick_valid_; }
   size_t brick_image_bytes() const { return brick_image_.bytes(); }
   float brick_build_ms() const { return brick_build_ms_; }
@@ -187,6 +189,19 @@ private:
   mutable hipEvent_t brick_event_ = nullptr;
   mutable float brick_build_ms_ = 0.0f;
   uint32_t brick_res_cap_ = 0;   // 0: no cap
+  int brick_mode_ = -1;
+
+public:
+  // Per-kernel time of the training step (HIP events on the training stream, a ring of the last kTrainProfileSteps steps):
+  // phases = {forward, loss + MLP backward, weight gradients, grid backward, optimizer}.  Off by default (no events recorded).
+  static constexpr int kTrainPhases = 5, kTrainProfileSteps = 64;
+  void set_train_profiling(bool e);
+  int train_profile(double* ms_per_step /* [kTrainPhases] */);   // returns the number of steps averaged over (0: nothing recorded)
+private:
+  void profile_mark(int phase_boundary, hipStream_t s);
+  bool train_profiling_ = false;
+  std::vector<hipEvent_t> prof_events_;   // [kTrainProfileSteps][kTrainPhases + 1]
+  uint64_t prof_steps_ = 0;
 
 public:
   ~Network();

@@ -216,6 +216,52 @@ Network::~Network()
 {
   live_networks().erase(this);
   if (brick_event_) (void)hipEventDestroy(brick_event_);
+  for (hipEvent_t e : prof_events_) (void)hipEventDestroy(e);
+}
+
+void Network::set_brick_mode(int mode)
+{
+  brick_mode_ = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+  brick_refused_ = false;
+  if (brick_mode_ == 0 && brick_valid_) {   // the next launches read the parameter blob; the image's memory goes back
+    if (Runtime::get().ready()) (void)hipDeviceSynchronize();
+    brick_image_.release();
+    levels_brick_dev_.release();
+    brick_valid_ = false;
+  }
+  brick_stable_calls_ = 0;
+}
+
+void Network::set_train_profiling(bool e)
+{
+  train_profiling_ = e;
+  prof_steps_ = 0;
+  if (e && prof_events_.empty()) {
+    prof_events_.resize((size_t)kTrainProfileSteps * (kTrainPhases + 1));
+    for (hipEvent_t& ev : prof_events_) VNR_HIP_CHECK(hipEventCreate(&ev));
+  }
+}
+
+void Network::profile_mark(int boundary, hipStream_t s)
+{
+  if (!train_profiling_) return;
+  VNR_HIP_CHECK(hipEventRecord(prof_events_[(size_t)(prof_steps_ % kTrainProfileSteps) * (kTrainPhases + 1) + boundary], s));
+  if (boundary == kTrainPhases) ++prof_steps_;
+}
+
+int Network::train_profile(double* ms_per_step)
+{
+  for (int p = 0; p < kTrainPhases; ++p) ms_per_step[p] = 0.0;
+  const int n = (int)std::min<uint64_t>(prof_steps_, kTrainProfileSteps);
+  if (!train_profiling_ || n == 0) return 0;
+  VNR_HIP_CHECK(hipEventSynchronize(prof_events_[(size_t)((prof_steps_ - 1) % kTrainProfileSteps) * (kTrainPhases + 1) + kTrainPhases]));
+  for (int k = 0; k < n; ++k)
+    for (int p = 0; p < kTrainPhases; ++p) {
+      float ms = 0.0f;
+      VNR_HIP_CHECK(hipEventElapsedTime(&ms, prof_events_[(size_t)k * (kTrainPhases + 1) + p], prof_events_[(size_t)k * (kTrainPhases + 1) + p + 1]));
+      ms_per_step[p] += ms / n;
+    }
+  return n;
 }
 
 void Network::release_temporary()
@@ -321,7 +367,8 @@ void Network::build_brick_image(hipStream_t s) const
 
 const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image) const
 {
-  static const int mode = [] { const char* e = std::getenv("VNR_AMD_BRICK"); return e ? std::atoi(e) : -1; }();   // -1 auto, 0 off, 1 at once
+  static const int env_mode = [] { const char* e = std::getenv("VNR_AMD_BRICK"); return e ? std::atoi(e) : -1; }();   // -1 auto, 0 off, 1 at once
+  const int mode = brick_mode_ >= 0 ? brick_mode_ : env_mode;
   static const uint32_t after = [] { const char* e = std::getenv("VNR_AMD_BRICK_AFTER"); return e ? (uint32_t)std::max(0, std::atoi(e)) : 24u; }();
   *image = nullptr;
   if (mode == 0 || brick_refused_) return levels_dev_.ptr;

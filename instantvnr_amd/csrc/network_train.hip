@@ -570,9 +570,11 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   ts.packedT.ensure(pt);
 
   // 1. forward, keeping features and hidden activations
+  profile_mark(0, s);
   launch_fused(2, grid_, in_width_, nh, cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2, mlp_packed_.ptr,
                lds_halves_, d_coords, ts.y.ptr, ws_features_.ptr, ws_acts_.ptr, batch, nullptr, batch, s);
   // 2. loss + output gradient
+  profile_mark(1, s);
   loss_grad_kernel<<<ts.loss_blocks, 256, 0, s>>>(ts.y.ptr, d_targets, n, cfg_.loss, (half_t*)ts.dy.ptr, ws_loss_.ptr);
   // 3. MLP backward
   pack_mlp_T_kernel<<<div_round_up(pt, 256), 256, 0, s>>>((const half_t*)params_f16_.ptr, (half_t*)ts.packedT.ptr, in_width_, nh);
@@ -594,6 +596,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     else launch(mlp_backward_kernel<4>);
   }
   // 4. weight gradients
+  profile_mark(2, s);
   WGradArgs wa;
   wa.features = (const half_t*)ws_features_.ptr; wa.acts = (const half_t*)ws_acts_.ptr; wa.d_all = (const half_t*)ts.d_all.ptr;
   wa.dy = (const half_t*)ts.dy.ptr; wa.grads = grads_.ptr; wa.n = n; wa.nh = nh; wa.in_width = in_width_;
@@ -617,6 +620,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
     weight_grad_kernel<64><<<g2, 256, 0, s>>>(wa, 1, sub_chunks);
   }
+  profile_mark(3, s);
   if (exchange) exchange->range_ready(0, n_mlp_, s);   // the MLP's gradient travels while the grid backward runs
   // 5. hash-grid backward: levels [l0, l1) per launch (blockIdx.y + l0 = level)
   auto grid_backward = [&](uint32_t l0, uint32_t l1) {
@@ -648,6 +652,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     }
   }
   VNR_HIP_CHECK(hipGetLastError());
+  profile_mark(4, s);
 }
 
 void Network::optimizer_step(float grad_scale, hipStream_t s)
@@ -677,6 +682,7 @@ void Network::optimizer_finish_step(hipStream_t s)
   // EXTERNAL tcnn ExponentialDecayOptimizer::step
   if (cfg_.has_decay && steps_ >= cfg_.decay_start && cfg_.decay_interval > 0 && steps_ % cfg_.decay_interval == 0) lr_ *= cfg_.decay_base;
   refresh_inference_weights(s);
+  profile_mark(kTrainPhases, s);
 }
 
 double Network::training_loss(hipStream_t s)

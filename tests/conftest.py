@@ -7,13 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# PyTorch BEFORE anything loads libvnr_amd.so: the torch wheel bundles its own ROCm runtime, and if the library (linked
-# against the system ROCm) is loaded first, torch finds no GPU afterwards (instantvnr_amd/_lib.require_torch_loaded_first).
-# tests/test_gpu_dist.py uses torch on the GPU next to the library, and test order must not decide whether it works.
-try:
-    import torch  # noqa: F401,E402
-except ImportError:  # the CPU suite does not need it except for tests/test_dist_cpu.py, which imports it itself
-    pass
+# No torch in this process: since round 2 the multi-GPU path runs behind the C-ABI (csrc/dist.cpp), so the test session uses the
+# system ROCm runtime exactly like bench.py and an application do.  (Only the gloo cross-check of tests/test_dist_cpu.py imports
+# torch, in child processes of its own; the import-order hazard for applications that DO mix torch and the library stays guarded
+# by instantvnr_amd/_lib.require_torch_loaded_first and its test in tests/test_cabi.py.)
 
 
 # The parity tests compare iteration counts and slot statistics with the oracle run at the REFERENCE's batch size
@@ -24,6 +21,27 @@ os.environ.setdefault("VNR_RM_N_ITERS", "16")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _device_present():
+    """probed in a child process: the test session itself must not initialise a HIP runtime just to find out"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\nfrom instantvnr_amd import _lib\nprint('DEVICES', _lib.lib().vnrAmdDeviceCount())" % ROOT)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
+        return "DEVICES 0" not in out and "DEVICES" in out
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """a plain `pytest tests` on a box without a GPU skips the gpu-marked tests instead of failing them one by one"""
+    gpu_items = [it for it in items if it.get_closest_marker("gpu")]
+    if not gpu_items or _device_present():
+        return
+    skip = pytest.mark.skip(reason="no HIP device on this box (the MI355X path has no CPU fallback)")
+    for it in gpu_items:
+        it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -199,7 +199,6 @@ def test_interleaved_shares_assemble_to_the_unsharded_frame(scene, world, kind):
     """the multi-GPU render path on ONE device: every rank's share (vnrRendererSetPixelInterleave, 8-scanline blocks,
     rendered as two halves on two streams inside the library) packed and assembled exactly as instantvnr_amd.dist does
     must equal the unsharded frame bit for bit.  80 scanlines = 10 tile rows: ragged for every world size here."""
-    import torch
     from instantvnr_amd import dist as vdist
     size = (96, 80)
     n_pixels = size[0] * size[1]
@@ -233,9 +232,9 @@ def test_interleaved_shares_assemble_to_the_unsharded_frame(scene, world, kind):
         rp = renderer()   # one renderer per rank
         api.vnrRendererSetPixelInterleave(rp, block, world, part)
         api.vnrRender(rp)
-        frame = torch.from_numpy(api.vnrRendererMapFrame(rp).reshape(-1, 4).copy())
+        frame = api.vnrRendererMapFrame(rp).reshape(-1, 4).copy()
         shares.append(vdist.pack_share(frame, block, world, part, n_pixels))
-    full = vdist.assemble_shares(torch.stack(shares), block, world, n_pixels).numpy()
+    full = vdist.assemble_shares(np.stack(shares), block, world, n_pixels)
     assert np.array_equal(full, want)
 
 

@@ -8,7 +8,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-SO_PATH = os.path.join(_HERE, "libvnr_amd.so")
+SO_PATH = os.environ.get("VNR_AMD_LIB_PATH") or os.path.join(_HERE, "libvnr_amd.so")   # the override is for A/B builds of kernel variants (tools/ab_build.sh)
 HEADER = os.path.join(ROOT, "include", "vnr_amd.h")
 
 _lib = None

@@ -288,179 +288,6 @@ __device__ __forceinline__ bool gather_corners_brick(const LevelInfo& lv, const 
   return true;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Grouped form (round 2).  Two measurements set its shape (MI355X, C4 bench frame):
-//  * the level-by-level kernel above finishes one level (index arithmetic, 4-5 gathers, wait, blend) before it starts the
-//    next: 16 dependent round trips per tile.  Here the loads of a GROUP of levels are issued back to back and the blends
-//    follow, so the round trips of a group overlap;
-//  * with the brick image the kernel is bound by vector-ALU issue, not by memory: rocprofv3 counts ~2700 VALU instructions per
-//    64-sample tile, SQ_ACTIVE_INST_VALU = 25 % of a wave's cycles at 3 waves per SIMD and another 38 % waiting to issue, against
-//    31 % in s_waitcnt.  So everything per corner that is not the reference's arithmetic goes: corner loads are structured
-//    buffer loads (`buffer_load ... idxen`: the hardware multiplies the entry index by the stride and adds a 48-bit base, so
-//    there is no 64-bit address arithmetic per corner and an image larger than 4 GiB is no special case), the position's
-//    floor / fraction are one conversion and one v_fract, and the interpolation weights are kept from the issue to the blend.
-// Straight-line issue code: no wave-divergent fix-up gathers and no rare-path ballots between the loads of a group, so
-//  * a tile with a coordinate outside [0, 1] (or NaN) takes the level-by-level path above, whole (wave-uniform, rare);
-//    inside the domain a cell's lower corner is < res on every level, which is all the brick image needs, and a dense table
-//    index exceeds the level size at most once (`idx -= size`);
-//  * every corner has its own load.  Corners x and x + 1 of a row fall into the same 128-byte line unless the cell sits on a
-//    brick face (image) / the level is hashed and x is odd (table), and a gather is priced by the distinct lines of the
-//    instruction (tools/calib/ta_model.hip: ~2 cycles per line; one line per lane 129 cycles, 8 lines 25, 1 line <= 15).
-// Values and blend order are those of encode_level / encode_level_fast: results are bit-identical.
-typedef int int32x4_t __attribute__((ext_vector_type(4)));
-// LLVM's structured buffer loads (clang has builtins for the raw forms only): (rsrc, vindex, voffset, soffset, aux)
-__device__ _Float16 llvm_struct_buffer_load_f16(int32x4_t, uint32_t, uint32_t, uint32_t, int) __asm("llvm.amdgcn.struct.buffer.load.f16");
-__device__ half2_t llvm_struct_buffer_load_v2f16(int32x4_t, uint32_t, uint32_t, uint32_t, int) __asm("llvm.amdgcn.struct.buffer.load.v2f16");
-__device__ half4_t llvm_struct_buffer_load_v4f16(int32x4_t, uint32_t, uint32_t, uint32_t, int) __asm("llvm.amdgcn.struct.buffer.load.v4f16");
-__device__ float4_t llvm_struct_buffer_load_v4f32(int32x4_t, uint32_t, uint32_t, uint32_t, int) __asm("llvm.amdgcn.struct.buffer.load.v4f32");
-
-template <int F> struct EntryLoad;
-template <> struct EntryLoad<1> { static __device__ __forceinline__ half_t load(int32x4_t r, uint32_t i) { return llvm_struct_buffer_load_f16(r, i, 0, 0, 0); } };
-template <> struct EntryLoad<2> { static __device__ __forceinline__ half2_t load(int32x4_t r, uint32_t i) { return llvm_struct_buffer_load_v2f16(r, i, 0, 0, 0); } };
-template <> struct EntryLoad<4> { static __device__ __forceinline__ half4_t load(int32x4_t r, uint32_t i) { return llvm_struct_buffer_load_v4f16(r, i, 0, 0, 0); } };
-template <> struct EntryLoad<8> { static __device__ __forceinline__ half8_t load(int32x4_t r, uint32_t i) { return __builtin_bit_cast(half8_t, llvm_struct_buffer_load_v4f32(r, i, 0, 0, 0)); } };
-
-// descriptor of an array of `stride`-byte entries at a wave-uniform address (scalar registers; index = entry number)
-__device__ __forceinline__ int32x4_t make_entry_rsrc(uint64_t base, uint32_t stride, uint32_t n_entries)
-{
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-  return int32x4_t{(int)lo, (int)((hi & 0xffffu) | (stride << 16)), (int)__builtin_amdgcn_readfirstlane(n_entries), 0x00020000};
-}
-
-// `idxen` addressing multiplies index and stride in 32 bits (measured: an array beyond 4 GiB reads wrong entries), and the finest
-// levels of a large model exceed that (C4: 4.3 GB of point bricks, 17 GB of cell records).  Such a level is read through a 4 GiB
-// WINDOW of its array: the window starts one 2 GiB granule below the granule of the wave's first lane (wave-uniform, scalar),
-// the lanes subtract the window's first entry.  A wave of a ray-marched frame spans kilobytes to megabytes; a lane outside the
-// window (incoherent coordinates) reads entry 0 instead and flags the tile, which then takes the level-by-level path.
-// entries_log2 = log2(2 GiB / entry bytes); `margin` = the largest distance between a cell's first and last entry.
-__device__ __forceinline__ uint32_t window_index(uint32_t idx, uint32_t entries_log2, uint32_t margin, uint64_t& base, uint32_t entry_bytes, bool& outside)
-{
-  const uint32_t granule = __builtin_amdgcn_readfirstlane(idx) >> entries_log2;
-  const uint32_t first = granule > 0u ? (granule - 1u) << entries_log2 : 0u;   // scalar
-  base += (uint64_t)first * entry_bytes;
-  const uint32_t rel = idx - first;
-  const bool bad = rel >= (2u << entries_log2) - margin;
-  outside = outside || bad;
-  return bad ? 0u : rel;
-}
-
-template <int F>
-__device__ __forceinline__ void issue_level_loads(const LevelInfo& lv, uint32_t interpolation, uint64_t table, uint64_t image,
-                                                  float x, float y, float z, typename FeatVec<F>::type (&v)[8], float (&w)[3], bool& outside)
-{
-  constexpr uint32_t kBytes = (uint32_t)(F * 2);
-  // pos_fract for a coordinate in [0, 1]: pos = x scale + 0.5 > 0, so truncation is floor and v_fract is pos - floor(pos), exactly
-  uint32_t g[3];
-  const float in[3] = {x, y, z};
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float p = __builtin_fmaf(in[d], lv.scale, 0.5f);
-    g[d] = (uint32_t)p;
-    w[d] = __builtin_amdgcn_fractf(p);
-  }
-  if (interpolation == 1) {   // Smoothstep; a real (wave-uniform) branch: as a select it costs every Linear model 12 instructions per level
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int d = 0; d < 3; ++d) w[d] = w[d] * w[d] * (3.0f - 2.0f * w[d]);
-  }
-  // The wave-uniform choice (brick image / hashed table / dense table) is made on entry INDICES; the eight loads follow it in
-  // straight-line code.  (With the loads inside the branches the compiler reconciles the loaded registers of the two sides where
-  // they join, i.e. waits for the loads there, and the group's round trips are serial again.)
-  uint32_t idx[8];
-  int32x4_t rsrc;
-  if (lv.brick != 0u) {
-    constexpr uint32_t LX = BrickShape<F>::lx, LY = BrickShape<F>::ly, LZ = BrickShape<F>::lz;
-    constexpr uint32_t MX = (1u << LX) - 1u, MY = (1u << LY) - 1u, MZ = (1u << LZ) - 1u;
-    constexpr uint32_t E = 1u << (LX + LY + LZ);
-    const uint32_t res = lv.resolution;
-    const uint32_t nbx = (res >> LX) + 1u, nby = (res >> LY) + 1u;   // scalar
-    const uint32_t SY = nbx * E, SZ = SY * nby;
-    // entry (x, y, z) = brick ((z >> LZ) nby + (y >> LY)) nbx + (x >> LX), then (z & MZ, y & MY, x & MX) inside it
-    //                 = x + (E - 2^LX) (x >> LX)  +  (y << LX) + (SY - 2^(LX+LY)) (y >> LY)  +  (z << (LX+LY)) + (SZ - E) (z >> LZ)
-    uint32_t e0 = __umul24(g[0] >> LX, E - (1u << LX)) + g[0];
-    e0 = __umul24(g[1] >> LY, SY - (1u << (LX + LY))) + e0;
-    e0 = __umul24(g[2] >> LZ, SZ - E) + e0;
-    e0 += (g[1] << LX) + (g[2] << (LX + LY));
-    const uint32_t dx = (g[0] & MX) == MX ? E - MX : 1u;
-    const uint32_t dy = (g[1] & MY) == MY ? SY - (MY << LX) : 1u << LX;
-    const uint32_t dz = (g[2] & MZ) == MZ ? SZ - (MZ << (LX + LY)) : 1u << (LX + LY);
-    uint64_t base = image + (uint64_t)(lv.brick - 1u) * 128u;
-    if ((uint64_t)SZ * ((res >> LZ) + 1u) * kBytes >= 0xfc000000ull) {   // wave-uniform: this level's array is (nearly) 4 GiB or more
-      constexpr uint32_t kLog2 = F == 1 ? 30u : F == 2 ? 29u : F == 4 ? 28u : 27u;
-      e0 = window_index(e0, kLog2, SZ + SY + E, base, kBytes, outside);
-    }
-    idx[0] = e0; idx[1] = e0 + dx; idx[2] = e0 + dy; idx[3] = idx[2] + dx;
-    idx[4] = e0 + dz; idx[5] = idx[4] + dx; idx[6] = idx[4] + dy; idx[7] = idx[6] + dx;
-    rsrc = make_entry_rsrc(base, kBytes, 0xffffffffu);
-  } else {
-    const uint32_t res = lv.resolution, res2 = lv.res2, size = lv.size;
-    if (lv.hashed != 0u) {
-      const uint32_t hy0 = g[1] * 2654435761u, hy1 = hy0 + 2654435761u;
-      const uint32_t hz0 = g[2] * 805459861u, hz1 = hz0 + 805459861u;
-      const uint32_t x1 = g[0] + 1u, mask = size - 1u;
-      const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
-#pragma unroll
-      for (int corner = 0; corner < 8; ++corner) idx[corner] = (((corner & 1) ? x1 : g[0]) ^ yz[corner >> 1]) & mask;
-    } else {
-      const uint32_t lin = g[0] + __umul24(g[1], res) + __umul24(g[2], res2);
-#pragma unroll
-      for (int corner = 0; corner < 8; ++corner) {
-        const uint32_t d = lin + ((corner & 1) ? 1u : 0u) + ((corner & 2) ? res : 0u) + ((corner & 4) ? res2 : 0u);
-        idx[corner] = d >= size ? d - size : d;   // in-domain coordinates wrap at most once (level_index)
-      }
-    }
-    rsrc = make_entry_rsrc(table + (uint64_t)lv.offset * kBytes, kBytes, size);
-  }
-#pragma unroll
-  for (int corner = 0; corner < 8; ++corner) v[corner] = EntryLoad<F>::load(rsrc, idx[corner]);
-}
-
-// Keeps a loaded corner untouched until the blend phase: without it the compiler takes a loaded register apart in the block of
-// the load (a use, hence a wait for the load, directly behind the loads of every level).
-__device__ __forceinline__ void hold_until_here(half_t& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void hold_until_here(half2_t& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void hold_until_here(half4_t& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void hold_until_here(half8_t& v) { asm volatile("" : "+v"(v)); }
-
-// Cell records (network.h): the eight corners of a cell are the records (x, y, z) and (x, y, z + 1), 16 bytes each, in bricks
-// of 2 x 2 x 2 records:  r = x + 6 (x >> 1)  +  2 y + (SY - 4) (y >> 1)  +  4 z + (SZ - 8) (z >> 1),  SY = 8 nbx, SZ = SY nby.
-__device__ __forceinline__ void issue_level_records(const LevelInfo& lv, uint32_t interpolation, uint64_t image, float x, float y, float z,
-                                                    half2_t (&v)[8], float (&w)[3], bool& outside)
-{
-  uint32_t g[3];
-  const float in[3] = {x, y, z};
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float p = __builtin_fmaf(in[d], lv.scale, 0.5f);
-    g[d] = (uint32_t)p;
-    w[d] = __builtin_amdgcn_fractf(p);
-  }
-  if (interpolation == 1) {
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int d = 0; d < 3; ++d) w[d] = w[d] * w[d] * (3.0f - 2.0f * w[d]);
-  }
-  const uint32_t nb = (lv.resolution + 1u) >> 1;   // scalar
-  const uint32_t SY = nb * 8u, SZ = SY * nb;
-  uint32_t r = __umul24(g[0] >> 1, 6u) + g[0];
-  r = __umul24(g[1] >> 1, SY - 4u) + r;
-  r = __umul24(g[2] >> 1, SZ - 8u) + r;
-  r += (g[1] << 1) + (g[2] << 2);
-  uint64_t base = image + (uint64_t)(lv.brick - 1u) * 128u;
-  if ((uint64_t)SZ * ((lv.resolution + 2u) >> 1) * 16u >= 0xfc000000ull) r = window_index(r, 27u, SZ, base, 16u, outside);   // wave-uniform
-  const uint32_t r1 = r + ((g[2] & 1u) ? SZ - 4u : 4u);
-  const int32x4_t rsrc = make_entry_rsrc(base, 16u, 0xffffffffu);
-  // corner (cx, cy, cz) is word cx + 2 cy of record cz: the corner order of blend_level.  (The words of a loaded register
-  // quadruple are sub-registers: taking them apart costs no instruction and no wait.)
-  const float4_t a = llvm_struct_buffer_load_v4f32(rsrc, r, 0, 0, 0);
-  const float4_t b = llvm_struct_buffer_load_v4f32(rsrc, r1, 0, 0, 0);
-  // (through scalars: hipcc of ROCm 7.2 compiles __builtin_bit_cast of an ext-vector ELEMENT to a read of element 0)
-  const float a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
-  v[0] = __builtin_bit_cast(half2_t, a0); v[1] = __builtin_bit_cast(half2_t, a1); v[2] = __builtin_bit_cast(half2_t, a2); v[3] = __builtin_bit_cast(half2_t, a3);
-  v[4] = __builtin_bit_cast(half2_t, b0); v[5] = __builtin_bit_cast(half2_t, b1); v[6] = __builtin_bit_cast(half2_t, b2); v[7] = __builtin_bit_cast(half2_t, b3);
-}
-
 // `(T)(weight * data)` for the two halves of a register: the fp32 products, each rounded, then both rounded to fp16.
 // v_fma_mix_f32 takes the fp16 operand as it is (x y + 0 in fp32: rounds like x y; a product of -0 becomes +0, which an fp16 sum
 // that starts at +0 cannot tell apart), so a pair costs 2 + 1 instructions instead of the 2 conversions + multiply + conversion
@@ -473,7 +300,7 @@ __device__ __forceinline__ half2_t weighted_pair(float w, uint32_t pair)
   return __builtin_convertvector(float2_t{lo, hi}, half2_t);
 }
 
-// the blend of one level from its 8 loaded corners and the weights of issue_level_loads
+// the blend of one level from its 8 loaded corners and the weights of level_setup
 template <int F>
 __device__ __forceinline__ void blend_level(const float (&wd)[3], const typename FeatVec<F>::type (&v)[8], half_t* out)
 {

@@ -21,8 +21,8 @@ struct LevelInfo {
   uint32_t size;    // entries in this level
   uint32_t offset;  // first entry of this level (entries, x F for elements)
   uint32_t hashed;  // 1: prime-XOR hash (size is a power of two), 0: dense index
-  uint32_t brick;   // 0: read the parameter blob; else 1 + first 128-byte line of this level in the inference image (below)
-  uint32_t records; // the level's part of the image holds cell records (below) instead of point bricks.  32 bytes: one s_load_dwordx8 per level
+  uint32_t brick;   // 0: read the parameter blob; else 1 + first 128-byte line of this level in the brick image (below)
+  uint32_t pad1;    // 32 bytes: one s_load_dwordx8 per level
 };
 
 // Brick image (inference only): a level whose table is hashed is ALSO kept de-hashed, as a dense array over the level's
@@ -33,13 +33,6 @@ struct LevelInfo {
 // fetched bytes per sample inside a 64-sample wave).  The price is memory, 7.6 GB instead of 140 MB for the bench model,
 // which is what 288 GB of HBM are for, and a rebuild (a few ms) after the parameters change, so the image is only built once
 // the parameters have been left alone for a while (Network::brick_policy).
-// Cell records (inference only, F = 2; round 2): with the point bricks the evaluation kernel was bound by the number of gather
-// instructions and by the index arithmetic around them, not by bytes.  A record is what ONE 16-byte load can
-// fetch of a cell: the four corners (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1) of one z plane, stored for every cell (x, y)
-// and every plane z <= res; a cell's eight corners are the records (x, y, z) and (x, y, z + 1).  2 x 2 x 2 records share a
-// 128-byte line (so both records of a cell with even z come from one line).  Two loads and a dozen integer operations per
-// level instead of eight loads (or four + a divergent fix-up) and two dozen; the price is 4 x the memory of the point bricks
-// (30.7 GB for the bench model), which is why it is all levels or none and bounded by the same budget.
 template <int F> struct BrickShape;
 template <> struct BrickShape<1> { static constexpr uint32_t lx = 2, ly = 2, lz = 2; };
 template <> struct BrickShape<2> { static constexpr uint32_t lx = 2, ly = 2, lz = 1; };
@@ -158,7 +151,6 @@ public:
   // -1: the environment's policy (VNR_AMD_BRICK, default automatic), 0: never (drops an existing image), 1: build at the next launch
   void set_brick_mode(int mode);
   bool brick_image_in_use() const { return brick_valid_; }
-  int image_kind() const { return brick_valid_ ? image_kind_ : 0; }   // 0 none, 1 point bricks, 2 cell records
   size_t brick_image_bytes() const { return brick_image_.bytes(); }
   float brick_build_ms() const { return brick_build_ms_; }
 
@@ -166,8 +158,7 @@ private:
   void build_layout();
   void initialize_params(uint64_t seed, hipStream_t s);
   void refresh_inference_weights(hipStream_t s);
-  const LevelInfo* inference_levels(hipStream_t s, const uint8_t** image, int* kind = nullptr) const;  // decides / builds / orders streams
-  bool build_record_image(hipStream_t s, uint64_t budget_lines) const;
+  const LevelInfo* inference_levels(hipStream_t s, const uint8_t** image) const;  // decides / builds / orders streams
   void build_brick_image(hipStream_t s) const;
 
   ModelConfig cfg_;
@@ -197,7 +188,6 @@ private:
   mutable uint32_t brick_stable_calls_ = 0;
   mutable hipEvent_t brick_event_ = nullptr;
   mutable float brick_build_ms_ = 0.0f;
-  mutable int image_kind_ = 0;
   uint32_t brick_res_cap_ = 0;   // 0: no cap
   int brick_mode_ = -1;
 

@@ -18,7 +18,7 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                   const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr,
-                  uint32_t sharers = 1, int image_kind = 0);
+                  uint32_t sharers = 1);
 void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
                         uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s);
 // master weights <- fp16 parameters; reset_optimizer also zeroes the moments and step counts
@@ -84,7 +84,7 @@ uint32_t grid_make_layout(const ModelConfig& cfg, GridDevice* out)
     lv.size = n;
     lv.offset = offset;
     lv.hashed = n < stride ? 1u : 0u;
-    lv.brick = lv.records = 0;
+    lv.brick = lv.pad1 = 0;
     if (lv.hashed && (n & (n - 1)) != 0) throw std::runtime_error("internal: hashed level with non power-of-two size");
     offset += n;
   }
@@ -312,79 +312,16 @@ static void launch_brick_build(const LevelInfo& lv, const uint16_t* table, uint8
   VNR_HIP_CHECK(hipGetLastError());
 }
 
-// one thread per record: cell (x, y) of plane z -> its four corner entries, each the entry the reference's index function gives
-// that grid point (level_index: hash or dense, exact `% size` semantics)
-__global__ void record_build_kernel(const LevelInfo lv, const half_t* __restrict__ table, uint8_t* __restrict__ image, uint64_t n_records)
-{
-  const uint32_t res = lv.resolution;
-  const uint32_t nbx = (res + 1u) >> 1, nby = nbx;
-  uint4_t* out = (uint4_t*)(image + (size_t)(lv.brick - 1u) * 128u);
-  const uint32_t* src = (const uint32_t*)(table + (size_t)lv.offset * 2);
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_records; r += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t w = (uint32_t)(r & 7u);
-    const uint64_t b = r >> 3;
-    const uint32_t bx = (uint32_t)(b % nbx), by = (uint32_t)((b / nbx) % nby), bz = (uint32_t)(b / ((uint64_t)nbx * nby));
-    const uint32_t x = (bx << 1) | (w & 1u), y = (by << 1) | ((w >> 1) & 1u), z = (bz << 1) | (w >> 2);
-    uint4_t v = {0u, 0u, 0u, 0u};
-    if (x < res && y < res && z <= res)
-      v = uint4_t{src[level_index(lv, x, y, z)], src[level_index(lv, x + 1u, y, z)], src[level_index(lv, x, y + 1u, z)], src[level_index(lv, x + 1u, y + 1u, z)]};
-    out[r] = v;
-  }
-}
-
-bool Network::build_record_image(hipStream_t s, uint64_t budget_lines) const
-{
-  static const bool enabled = [] { const char* e = std::getenv("VNR_AMD_RECORDS"); return !e || std::atoi(e) != 0; }();
-  if (!enabled || cfg_.n_features != 2) return false;
-  std::vector<LevelInfo> lv(grid_.levels, grid_.levels + kMaxLevels);
-  std::vector<uint64_t> lines(kMaxLevels, 0);
-  uint64_t used = 0;
-  for (uint32_t l = 0; l < grid_.n_levels; ++l) {   // all levels or none
-    if (brick_res_cap_ && lv[l].resolution > brick_res_cap_ + 1u) return false;
-    const uint64_t res = lv[l].resolution, nb = (res + 1) >> 1, nbz = (res + 2) >> 1;
-    const uint64_t n = nb * nb * nbz;
-    if (n * 8u >= (1ull << 32) || used + n >= 0xffffffffull) return false;
-    lv[l].brick = (uint32_t)used + 1u;
-    lv[l].records = 1u;
-    lines[l] = n;
-    used += n;
-  }
-  if (used == 0 || used > budget_lines) return false;
-  brick_image_.resize(used * 128u);
-  for (uint32_t l = 0; l < grid_.n_levels; ++l) {
-    const uint64_t n_records = lines[l] * 8u;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_records + 255) / 256, 1u << 20);
-    record_build_kernel<<<blocks, 256, 0, s>>>(lv[l], (const half_t*)(params_f16_.ptr + n_mlp_), brick_image_.ptr, n_records);
-    VNR_HIP_CHECK(hipGetLastError());
-  }
-  levels_brick_dev_.resize(kMaxLevels);
-  VNR_HIP_CHECK(hipMemcpyAsync(levels_brick_dev_.ptr, lv.data(), kMaxLevels * sizeof(LevelInfo), hipMemcpyHostToDevice, s));
-  image_kind_ = 2;
-  return true;
-}
-
 void Network::build_brick_image(hipStream_t s) const
 {
   // which levels: the hashed ones (VNR_AMD_BRICK_DENSE=1: every level), finest first, while the image stays within the budget
   static const bool dense_too = [] { const char* e = std::getenv("VNR_AMD_BRICK_DENSE"); return e && std::atoi(e) != 0; }();
-  static const double max_gb = [] { const char* e = std::getenv("VNR_AMD_BRICK_MAX_GB"); return e ? std::atof(e) : 40.0; }();
+  static const double max_gb = [] { const char* e = std::getenv("VNR_AMD_BRICK_MAX_GB"); return e ? std::atof(e) : 32.0; }();
   size_t free_b = 0, total_b = 0;
   VNR_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
   const uint64_t budget_lines = (uint64_t)std::min(max_gb * 1073741824.0, (double)(free_b + brick_image_.bytes()) / 4.0) / 128u;
   hipEvent_t t0, t1;
   VNR_HIP_CHECK(hipEventCreate(&t0)); VNR_HIP_CHECK(hipEventCreate(&t1));
-  VNR_HIP_CHECK(hipEventRecord(t0, s));
-  if (build_record_image(s, budget_lines)) {   // cell records for every level (F = 2) when they fit, else point bricks
-    VNR_HIP_CHECK(hipEventRecord(t1, s));
-    if (!brick_event_) VNR_HIP_CHECK(hipEventCreateWithFlags(&brick_event_, hipEventDisableTiming));
-    VNR_HIP_CHECK(hipEventRecord(brick_event_, s));
-    VNR_HIP_CHECK(hipEventSynchronize(t1));
-    VNR_HIP_CHECK(hipEventElapsedTime(&brick_build_ms_, t0, t1));
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
-    brick_valid_ = true;
-    return;
-  }
-  image_kind_ = 1;
   const uint32_t F = cfg_.n_features;
   const uint32_t lx = F == 8 ? 1 : 2, ly = F >= 4 ? 1 : 2, lz = F == 1 ? 2 : 1;
   const uint64_t entries_per_line = 64u / F;
@@ -403,6 +340,7 @@ void Network::build_brick_image(hipStream_t s) const
   }
   if (used == 0) { brick_refused_ = true; (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); return; }
   brick_image_.resize((used + 1) * 128u);   // + one spare line: a pair load at the last entry reads 2 entries
+  VNR_HIP_CHECK(hipEventRecord(t0, s));
   for (uint32_t l = 0; l < grid_.n_levels; ++l) {
     if (!lv[l].brick) continue;
     const uint64_t n_entries = lines[l] * entries_per_line;
@@ -427,9 +365,8 @@ void Network::build_brick_image(hipStream_t s) const
   brick_valid_ = true;
 }
 
-const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image, int* kind) const
+const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image) const
 {
-  if (kind) *kind = 0;
   static const int env_mode = [] { const char* e = std::getenv("VNR_AMD_BRICK"); return e ? std::atoi(e) : -1; }();   // -1 auto, 0 off, 1 at once
   const int mode = brick_mode_ >= 0 ? brick_mode_ : env_mode;
   static const uint32_t after = [] { const char* e = std::getenv("VNR_AMD_BRICK_AFTER"); return e ? (uint32_t)std::max(0, std::atoi(e)) : 24u; }();
@@ -443,7 +380,6 @@ const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image,
   // the image was built on one stream; launches on any other stream wait for it (a no-op once it has completed)
   VNR_HIP_CHECK(hipStreamWaitEvent(s, brick_event_, 0));
   *image = brick_image_.ptr;
-  if (kind) *kind = image_kind_;
   return levels_brick_dev_.ptr;
 }
 
@@ -501,29 +437,26 @@ void Network::inference(const float* d_coords, float* d_out, size_t n, const uin
                         const uint32_t* d_dest) const
 {
   const uint8_t* image;
-  int kind;
-  const LevelInfo* levels = inference_levels(s, &image, &kind);
+  const LevelInfo* levels = inference_levels(s, &image);
   launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest, 0, image, 1, kind);
+               mlp_packed_.ptr, lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest, 0, image);
 }
 
 void Network::inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
                               uint32_t sharers) const
 {
   const uint8_t* image;
-  int kind;
-  const LevelInfo* levels = inference_levels(s, &image, &kind);
+  const LevelInfo* levels = inference_levels(s, &image);
   launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image, sharers, kind);
+               mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image, sharers);
 }
 
 void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const
 {
   const uint8_t* image;
-  int kind;
-  const LevelInfo* levels = inference_levels(s, &image, &kind);
+  const LevelInfo* levels = inference_levels(s, &image);
   launch_fused(1, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s, nullptr, 0, image, 1, kind);
+               mlp_packed_.ptr, lds_halves_, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s, nullptr, 0, image);
 }
 
 size_t Network::bytes_allocated() const

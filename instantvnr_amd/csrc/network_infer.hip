@@ -200,18 +200,10 @@ __device__ __forceinline__ float mlp_column_tile(const half_t* __restrict__ lds,
 }
 
 // MODE 0: inference (out only), 1: encode only (features_out), 2: training forward (features + acts + out)
-// RECORDS: every level is read from the cell-record image (network.h; F = 2 only)
-#ifndef VNR_INFER_WAVES
-#define VNR_INFER_WAVES 1
-#endif
-template <int F, int K_IN, int MODE, bool RECORDS = false>
-__global__ void __launch_bounds__(256, VNR_INFER_WAVES) fused_infer_kernel(const InferArgs args)
+template <int F, int K_IN, int MODE>
+__global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
 {
   constexpr int L_PAD = K_IN / F;   // levels incl. zero padding
-#ifndef VNR_INFER_GROUP
-#define VNR_INFER_GROUP 4
-#endif
-  constexpr int GROUP = F >= 8 ? (VNR_INFER_GROUP > 2 ? 2 : VNR_INFER_GROUP) : VNR_INFER_GROUP;   // levels whose corner loads are in flight together (8 GROUP registers of F halves per lane)
   constexpr int S1 = K_IN / 16;     // k-steps of the first layer
   constexpr int NCHUNK = K_IN / 8;  // half8 chunks of the feature vector
   extern __shared__ __attribute__((aligned(16))) half_t lds[];
@@ -276,112 +268,16 @@ __global__ void __launch_bounds__(256, VNR_INFER_WAVES) fused_infer_kernel(const
       lv.brick = __builtin_amdgcn_readfirstlane(lvtab[l].brick);
       return lv;
     };
-    // a coordinate outside [0, 1] (or NaN) anywhere in the tile: the level-by-level path, whose index arithmetic is defined
-    // for anything (grid_device.h); wave-uniform and rare
-#if defined(VNR_INFER_SERIAL)   // the level-by-level kernel of round 1 (A/B builds, tools/ab_build.sh)
-    {
 #pragma unroll
-      for (int l = 0; l < L_PAD; ++l) {
-        half_t o[F];
+    for (int l = 0; l < L_PAD; ++l) {
+      half_t o[F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
-        if (l < (int)args.n_levels) {
-          LevelInfo lv = level_consts(l);
-          if (RECORDS) lv.brick = 0u;
-          encode_level_fast<F>(lv, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, o);
-        }
+      for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
+      if (l < (int)args.n_levels) encode_level_fast<F>(level_consts(l), args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, o);
 #pragma unroll
-        for (int f = 0; f < F; ++f) feat[(l * F + f) / 8][(l * F + f) % 8] = o[f];
-        if ((l & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    bool outside = false;
-    const bool grouped = false;
-#else
-    bool outside = !(p.x >= 0.0f && p.x <= 1.0f && p.y >= 0.0f && p.y <= 1.0f && p.z >= 0.0f && p.z <= 1.0f);
-    const bool grouped = __builtin_amdgcn_ballot_w64(outside) == 0ull;
-#endif
-    if (grouped) {
-      if constexpr (RECORDS) {
-#pragma unroll
-      for (int g0 = 0; g0 < L_PAD; g0 += GROUP) {
-        half2_t v[GROUP][8];
-        float wd[GROUP][3];
-#pragma unroll
-        for (int j = 0; j < GROUP; ++j) {
-          const int l = g0 + j;
-          if (l < L_PAD && l < (int)args.n_levels) issue_level_records(level_consts(l), args.interpolation, (uint64_t)args.brick_image, p.x, p.y, p.z, v[j], wd[j], outside);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < GROUP; ++j) {
-          const int l = g0 + j;
-          if (l >= L_PAD) continue;
-          half_t o[F];
-#pragma unroll
-          for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
-          if (l < (int)args.n_levels) {
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) hold_until_here(v[j][corner]);
-            blend_level<2>(wd[j], v[j], o);
-          }
-#pragma unroll
-          for (int f = 0; f < F; ++f) feat[(l * F + f) / 8][(l * F + f) % 8] = o[f];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      typedef typename FeatVec<F>::type raw_t;
-#pragma unroll
-      for (int g0 = 0; g0 < L_PAD; g0 += GROUP) {
-        raw_t v[GROUP][8];
-        float wd[GROUP][3];
-        // issue: the loads of GROUP levels back to back, nothing waits in between
-#pragma unroll
-        for (int j = 0; j < GROUP; ++j) {
-          const int l = g0 + j;
-          if (l < L_PAD && l < (int)args.n_levels)
-            issue_level_loads<F>(level_consts(l), args.interpolation, (uint64_t)args.table, (uint64_t)args.brick_image, p.x, p.y, p.z, v[j], wd[j], outside);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the blends stay behind the group's loads
-#pragma unroll
-        for (int j = 0; j < GROUP; ++j) {
-          const int l = g0 + j;
-          if (l >= L_PAD) continue;
-          half_t o[F];
-#pragma unroll
-          for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
-          if (l < (int)args.n_levels) {
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) hold_until_here(v[j][corner]);
-            blend_level<F>(wd[j], v[j], o);
-          }
-#pragma unroll
-          for (int f = 0; f < F; ++f) feat[(l * F + f) / 8][(l * F + f) % 8] = o[f];
-        }
-        __builtin_amdgcn_sched_barrier(0);   // at most one group's level constants and loads are live
-      }
-      }
-    }
-    // not grouped, or a lane left the 4 GiB window of a large level (grid_device.h window_index): the whole tile, level by level
-    if (__builtin_amdgcn_ballot_w64(outside) != 0ull) {
-#pragma unroll 1
-      for (int l = 0; l < L_PAD; ++l) {
-        half_t o[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
-        if (l < (int)args.n_levels) {
-          LevelInfo lv = level_consts(l);
-          if (RECORDS) lv.brick = 0u;   // this path knows tables and point bricks only
-          encode_level_fast<F>(lv, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, o);
-        }
-        // (runtime level index: the chunk / element is selected arithmetically)
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c)
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if ((c * 8 + e) / F == l) feat[c][e] = o[(c * 8 + e) % F];
-      }
+      for (int f = 0; f < F; ++f) feat[(l * F + f) / 8][(l * F + f) % 8] = o[f];
+      // keep the level constants (scalar registers) of at most four levels live at a time
+      if ((l & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 
     if (MODE != 0 && args.features_out && i < n) {
@@ -417,7 +313,7 @@ __global__ void __launch_bounds__(256, VNR_INFER_WAVES) fused_infer_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int F, int K_IN, int MODE, bool RECORDS = false>
+template <int F, int K_IN, int MODE>
 static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
 {
   const Runtime& rt = Runtime::get();
@@ -435,7 +331,7 @@ static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
     const int v = e ? std::atoi(e) : 0;
     return (uint32_t)(v >= 1 && v <= 64 ? v : 0);
   }();
-  uint32_t max_blocks = (uint32_t)rt.n_cus * (forced ? forced : (a.sharers >= 2 ? 3u : (VNR_INFER_WAVES > 4 ? (uint32_t)VNR_INFER_WAVES : 4u)));
+  uint32_t max_blocks = (uint32_t)rt.n_cus * (forced ? forced : (a.sharers >= 2 ? 3u : 4u));
   // The ray marcher's queue (count on the device, n_max an upper bound of which a frame fills 25-30 %): more blocks than fit,
   // so that the hardware hands them out as room appears.  With a second kernel and the march kernels of the other ray half
   // on the GPU a resident grid of fixed size either leaves room unused or waits for it with its tiles already dealt out.
@@ -445,7 +341,7 @@ static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = next_multiple(blocks, 8);
   const size_t shmem = MODE == 1 ? 16 : (size_t)a.lds_halves * sizeof(uint16_t);
-  auto kernel = fused_infer_kernel<F, K_IN, MODE, RECORDS>;
+  auto kernel = fused_infer_kernel<F, K_IN, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
     VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -456,17 +352,8 @@ static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
 }
 
 template <int MODE>
-static void dispatch(uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max, hipStream_t s, int image_kind)
+static void dispatch(uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max, hipStream_t s)
 {
-  if (image_kind == 2) {   // cell records: F = 2 models, inference and encoding
-    if constexpr (MODE != 2) {
-      if (F == 2 && K_IN == 16) return launch_one<2, 16, MODE, true>(a, n_max, s);
-      if (F == 2 && K_IN == 32) return launch_one<2, 32, MODE, true>(a, n_max, s);
-      if (F == 2 && K_IN == 48) return launch_one<2, 48, MODE, true>(a, n_max, s);
-      if (F == 2 && K_IN == 64) return launch_one<2, 64, MODE, true>(a, n_max, s);
-    }
-    throw std::runtime_error("internal: cell-record image with an unsupported model shape");
-  }
 #define VNR_CASE(f, k) if (F == f && K_IN == k) return launch_one<f, k, MODE>(a, n_max, s)
   VNR_CASE(1, 16); VNR_CASE(1, 32);
   VNR_CASE(2, 16); VNR_CASE(2, 32); VNR_CASE(2, 48); VNR_CASE(2, 64);
@@ -480,7 +367,7 @@ static void dispatch(uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
-                  const uint32_t* d_dest, uint32_t queue_out_stride, const uint8_t* brick_image, uint32_t sharers, int image_kind)
+                  const uint32_t* d_dest, uint32_t queue_out_stride, const uint8_t* brick_image, uint32_t sharers)
 {
   if (n_max == 0) return;
   if (n_max > 0xffffffc0ull) throw std::runtime_error("inference batch too large (max 2^32-64 samples per call)");
@@ -506,9 +393,9 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
   a.n_hidden_matmuls = n_hidden_matmuls;
   a.activation = activation;
   a.lds_halves = lds_halves;
-  if (mode == 0) dispatch<0>(grid.n_features, in_width, a, n_max, s, image_kind);
-  else if (mode == 1) dispatch<1>(grid.n_features, in_width, a, n_max, s, image_kind);
-  else dispatch<2>(grid.n_features, in_width, a, n_max, s, 0);
+  if (mode == 0) dispatch<0>(grid.n_features, in_width, a, n_max, s);
+  else if (mode == 1) dispatch<1>(grid.n_features, in_width, a, n_max, s);
+  else dispatch<2>(grid.n_features, in_width, a, n_max, s);
 }
 
 }  // namespace vnr

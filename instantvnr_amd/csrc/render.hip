@@ -104,6 +104,17 @@ __device__ __forceinline__ uint32_t arena_grad_index(uint32_t slot_cap, uint32_t
 
 constexpr int kDepthBins = 64;
 
+// In-kernel stamps of the march kernel's phases (diagnostic builds only: tools/ab_build.sh <tag> -DVNR_MARCH_STAMPS; the guide's
+// "In-kernel stamps"): cycles per phase summed over the waves of every march_kernel<false> launch, read by tools/march_stamps.py
+#if defined(VNR_MARCH_STAMPS)
+__device__ unsigned long long g_march_stamps[16];
+#define VNR_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define VNR_STAMP_ADD(slot, a, b) do { if (!FIRST && (threadIdx.x & 63u) == 0) atomicAdd(&g_march_stamps[slot], (b) - (a)); } while (0)
+#else
+#define VNR_STAMP(var)
+#define VNR_STAMP_ADD(slot, a, b)
+#endif
+
 enum { C_RAYS0 = 0, C_RAYS1 = 1, C_SAMPLES0 = 2, C_SAMPLES1 = 3, C_HIT = 4, C_STAT_SAMPLES = 6, C_STAT_REFRAYS = 8, C_COUNT = 16 };
 
 // ------------------------------------------------------------------------------------------------ helpers
@@ -466,6 +477,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
       }
     };
 
+    VNR_STAMP(st0);
     if (active) {
       if (FIRST) {
         if (map_pixel(p, i, pixel)) {
@@ -509,40 +521,67 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         if (MODE == M_SSH) { h_org = ssh_lists.org[0][i]; h_color = ssh_lists.color[0][i]; h_alpha = ssh_lists.alpha[0][i]; }
         m_dir = dir * p.mc_rcp;
         intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
+        VNR_STAMP(st1);
+        VNR_STAMP_ADD(0, st0, st1);   // ray state loaded
         // compose (classification, opacity correction, front-to-back blending)
-        for (uint32_t k = 0; k < ((p.debug_flags & 1u) ? 0u : sc); ++k) {
-          vec3f rgb; float a;
-          const vec2f vd = vd_in[sb + k];  // {network value, t1 - t0}
-          if (p.debug_flags & 2u) { rgb = {0.5f, 0.5f, 0.5f}; a = vd.x * 0.01f; } else
-          tfn_sample(tfn, vd.x, rgb, a);
-          a = opacity_correction(p.step_rcp, vd.y, a);
-          if (GRAD) {  // f(c + gx), f(c + gy), f(c + gz) of this sample, written by the evaluation kernel; .w: the sample's t
-            const vec4f fg = *(const vec4f*)((const float*)vd_in + arena_grad_index(p.slot_cap, sb + k));
-            vec3f stp = p.grad_step;
-            if (p.grad_flip) {  // in shader (mode 9): repeat sampleGradient's flip of a step that would leave [0,1] (raytracing.h:128-143)
-              const vec3f c = org + fg.w * dir;
-              if (c.x + stp.x > 1.0f - FLT_EPSILON) stp.x *= -1.0f;
-              if (c.y + stp.y > 1.0f - FLT_EPSILON) stp.y *= -1.0f;
-              if (c.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
+        // The results were written by the evaluation kernel on other CUs (other XCDs: their L2 is not ours), so a load of them
+        // costs a trip to the fabric, and a loop that loads, classifies, blends and tests for saturation sample by sample pays
+        // that trip per sample: stamped on a 1/8 share of the bench frame, 2000 cycles per sample, 56 % of the kernel (DESIGN.md
+        // 4.2).  The batch is composed in chunks: the chunk's results are fetched back to back (clamped index, no predicate:
+        // one trip per chunk), then classified and blended in order with the reference's early exit.
+        constexpr uint32_t kChunk = 8;
+        const uint32_t sc_eff = (p.debug_flags & 1u) ? 0u : sc;
+        bool saturated = false;
+        for (uint32_t k0 = 0; k0 < sc_eff && !saturated; k0 += kChunk) {
+          vec2f chunk[kChunk];
+#pragma unroll
+          for (uint32_t j = 0; j < kChunk; ++j) chunk[j] = vd_in[sb + min(k0 + j, sc - 1u)];
+          // classification and opacity correction of the whole chunk first: eight independent instruction streams for the
+          // scheduler to interleave (a march block runs one or two waves per SIMD, where a dependent instruction issues every
+          // ~10 cycles and an independent one every 4); only the blend below is sequential
+          vec3f crgb[kChunk]; float ca[kChunk];
+#pragma unroll
+          for (uint32_t j = 0; j < kChunk; ++j) {
+            if (p.debug_flags & 2u) { crgb[j] = {0.5f, 0.5f, 0.5f}; ca[j] = chunk[j].x * 0.01f; } else
+            tfn_sample(tfn, chunk[j].x, crgb[j], ca[j]);
+            ca[j] = opacity_correction(p.step_rcp, chunk[j].y, ca[j]);
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < kChunk; ++j) {
+            const uint32_t k = k0 + j;
+            if (k >= sc_eff) break;
+            vec3f rgb = crgb[j]; float a = ca[j];
+            const vec2f vd = chunk[j];  // {network value, t1 - t0}
+            if (GRAD) {  // f(c + gx), f(c + gy), f(c + gz) of this sample, written by the evaluation kernel; .w: the sample's t
+              const vec4f fg = *(const vec4f*)((const float*)vd_in + arena_grad_index(p.slot_cap, sb + k));
+              vec3f stp = p.grad_step;
+              if (p.grad_flip) {  // in shader (mode 9): repeat sampleGradient's flip of a step that would leave [0,1] (raytracing.h:128-143)
+                const vec3f c = org + fg.w * dir;
+                if (c.x + stp.x > 1.0f - FLT_EPSILON) stp.x *= -1.0f;
+                if (c.y + stp.y > 1.0f - FLT_EPSILON) stp.y *= -1.0f;
+                if (c.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
+              }
+              rgb = gradient_shade(p, dir, vd.x, fg.x, fg.y, fg.z, stp, rgb);
             }
-            rgb = gradient_shade(p, dir, vd.x, fg.x, fg.y, fg.z, stp, rgb);
+            if (MODE == M_SSH && h_alpha < (1.0f - alpha) * a) {  // :789-795; the sample's t is kept where GRAD keeps f(c + gx)
+              const float t = ((const float*)vd_in)[arena_grad_index(p.slot_cap, sb + k)];
+              h_org = org + t * dir;
+              h_color = rgb;
+              h_alpha = (1.0f - alpha) * a;
+            }
+            const float tr = 1.0f - alpha;
+            alpha += tr * a;
+            if (MODE != M_SHADOW) { color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a; }
+            if (!(alpha < VNR_NEARLY_ONE)) { saturated = true; break; }
           }
-          if (MODE == M_SSH && h_alpha < (1.0f - alpha) * a) {  // :789-795; the sample's t is kept where GRAD keeps f(c + gx)
-            const float t = ((const float*)vd_in)[arena_grad_index(p.slot_cap, sb + k)];
-            h_org = org + t * dir;
-            h_color = rgb;
-            h_alpha = (1.0f - alpha) * a;
-          }
-          const float tr = 1.0f - alpha;
-          alpha += tr * a;
-          if (MODE != M_SHADOW) { color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a; }
-          if (!(alpha < VNR_NEARLY_ONE)) break;
         }
         alive = (alpha < VNR_NEARLY_ONE) && dda_resumable(it, m_dir, tmin, tmax, p.mc_dims);
         if (!alive) finish();
       }
     }
 
+    VNR_STAMP(st2);
+    VNR_STAMP_ADD(1, st0, st2);   // ... + compose
     // emit the next batch of this ray into LDS
     uint32_t k = 0;
     if (alive && !(p.debug_flags & 8u)) {
@@ -555,6 +594,8 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
       if (k == 0) finish();  // nothing left to sample: the ray is finished
     }
     const bool survive = alive && k > 0;
+    VNR_STAMP(st3);
+    VNR_STAMP_ADD(2, st2, st3);   // DDA walk + samples to LDS
 
     // wave64 compaction: rays by ballot, samples by prefix sum
     const unsigned long long mask = __ballot(survive);
@@ -594,6 +635,8 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     uint32_t smp_base = claim[4];
     for (uint32_t w = 0; w < (tid >> 6); ++w) smp_base += claim[w];
     ++trip;
+    VNR_STAMP(st4);
+    VNR_STAMP_ADD(3, st3, st4);   // compaction, block-wide slot claim (two barriers)
     if (wave_rays == 0 || (p.debug_flags & 16u)) continue;  // wave-uniform
 
     // depth bins of the group: front = smallest first-sample depth among the surviving rays
@@ -623,6 +666,8 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     }
     hist[lane] = smp_base + hs - h;  // first gather-order slot of bin `lane`
     __builtin_amdgcn_wave_barrier();
+    VNR_STAMP(st5);
+    VNR_STAMP_ADD(4, st4, st5);   // depth-bin counting sort
 
     if (survive) {
       const uint32_t slot = (group << 6) + (uint32_t)__popcll(mask & lt_mask);
@@ -665,8 +710,21 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
       }
     }
     __builtin_amdgcn_wave_barrier();  // the LDS arrays are reused by the next loop trip
+    VNR_STAMP(st6);
+    VNR_STAMP_ADD(5, st5, st6);   // ray state + queue records + dt written
+    VNR_STAMP_ADD(6, st0, st6);   // the whole trip
+    VNR_STAMP_ADD(7, st0, st0 + 1ull);   // trips
   }
 }
+
+#if defined(VNR_MARCH_STAMPS)
+extern "C" int vnrAmdDebugMarchStamps(unsigned long long* out16, int reset)
+{
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_march_stamps), sizeof(g_march_stamps)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_march_stamps), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 // iterative_sampling_groundtruth_kernel (method_raymarching.cu:902-915) over the compacted sample queue
 __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float* __restrict__ vol, vec3i dims,

@@ -214,12 +214,21 @@ def main():
     infer_ms = 0.0
     union_ms = 0.0
     launches = iters = 0
-    for _ in range(a.steps):
-        sr.render()
-        st = api.vnrRendererGetFrameStats(ren)
+    def add(st):
+        nonlocal samples, slots, infer_ms, union_ms, launches, iters
         samples += st["n_samples"]; slots += st["n_reference_slots"]; infer_ms += st["infer_kernel_ms"]; union_ms += st["infer_union_ms"]
         launches += st["infer_kernel_launches"]; iters = st["n_iterations"]
-    sr.flush()   # N > 1: the gather of the last frame (render k runs beside gather k - 1); every frame is rendered AND gathered inside the timed region
+
+    # a pipeline of depth one (vnrAmdRendererRenderPipelined): call k enqueues frame k, completes frame k - 1 and hands it out
+    # (N > 1: all-gathered and assembled beside the rendering of frame k); the flush completes the last frame, so K frames are
+    # rendered, completed (and gathered) inside the timed region
+    for k in range(a.steps):
+        sr.render()
+        if k > 0:
+            add(sr.completed_stats())
+    sr.flush()
+    add(sr.completed_stats())
+    st = sr.completed_stats()
     dist.barrier(ctx)
     elapsed = time.perf_counter() - t0
     rays_hit = st["n_rays_hit"]

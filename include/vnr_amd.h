@@ -303,10 +303,14 @@ int  vnrAmdDistBroadcast(void* buf, size_t bytes, int root);
  * vnrAmdRendererMapFrame (= vnrAmdRendererGatherFrame) all-gathers in place, de-interleaves and returns the WHOLE frame on
  * every rank, bit-identical to the unsharded frame.  RenderPipelined: enqueue frame k, gather frame k - 1 meanwhile on the
  * communication stream, complete frame k, return the assembled frame k - 1 (NULL the first time); FlushPipeline returns the
- * frame still in flight. */
+ * frame still in flight.  The head of frame k (ray generation, first batch of samples) is enqueued before the host has seen
+ * frame k - 1 complete, so the GPU does not idle during the host's turn-around; a renderer that is not distributed pipelines the
+ * same way. */
 int  vnrAmdRendererSetDistributed(vnrAmdRenderer, int enable);
 const float* vnrAmdRendererGatherFrame(vnrAmdRenderer);
 int  vnrAmdRendererRenderPipelined(vnrAmdRenderer, const float** previous_frame);
+/* statistics of the frame COMPLETED last (vnrAmdRendererGetFrameStats completes a pending frame first, which ends the overlap) */
+int  vnrAmdRendererGetCompletedFrameStats(vnrAmdRenderer, vnrAmdFrameStats*);
 int  vnrAmdRendererFlushPipeline(vnrAmdRenderer, const float** last_frame);
 /* Data-parallel training: `steps` steps, each equal to ONE step on the concatenated batch of all ranks.  Gradients travel as
  * fp16 (2 B x n_params per step), range by range while the backward pass of the coarser levels and the update of earlier

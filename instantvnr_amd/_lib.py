@@ -188,6 +188,7 @@ def lib():
     sig("vnrAmdRendererSetDistributed", I, P, I)
     sig("vnrAmdRendererGatherFrame", P, P)
     sig("vnrAmdRendererRenderPipelined", I, P, C.POINTER(P))
+    sig("vnrAmdRendererGetCompletedFrameStats", I, P, C.POINTER(FrameStats))
     sig("vnrAmdRendererFlushPipeline", I, P, C.POINTER(P))
     sig("vnrAmdNeuralVolumeTrainDataParallel", I, P, I, I)
     sig("vnrAmdNeuralVolumeSyncReplicas", I, P)

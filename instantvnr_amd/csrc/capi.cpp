@@ -791,6 +791,16 @@ const float* vnrAmdRendererGatherFrame(vnrAmdRenderer r)
   });
   return out;
 }
+int vnrAmdRendererGetCompletedFrameStats(vnrAmdRenderer r, vnrAmdFrameStats* out)
+{
+  return guarded([&]() {
+    VNR_REN(r);
+    if (!out) throw std::runtime_error("null stats pointer");
+    const FrameStats& s = r->r->completed_stats();
+    out->n_samples = s.n_samples; out->n_reference_slots = s.n_reference_slots; out->n_iterations = s.n_iterations; out->n_rays_hit = s.n_rays_hit;
+    out->infer_kernel_ms = s.infer_kernel_ms; out->infer_kernel_launches = s.infer_kernel_launches; out->infer_union_ms = s.infer_union_ms;
+  });
+}
 int vnrAmdRendererRenderPipelined(vnrAmdRenderer r, const float** previous_frame)
 {
   return guarded([&]() { VNR_REN(r); const float* f = r->r->render_pipelined(); if (previous_frame) *previous_frame = f; });

@@ -1275,12 +1275,15 @@ struct PartState {
   size_t s_max;
   uint32_t it = 0, used = 0;
   bool done = false;
+  hipEvent_t ev_done = nullptr;   // recorded behind the last iteration launched so far: the host (and the communication stream)
+                                  // wait for THIS, not for the stream, which may already hold the head of the next frame
 };
 
 // One pass of the streaming loop between its two halves: everything launch_iteration / finish_streaming need.  With
 // set_async(true) a frame stays in this state ("pending") from render() until the next call that needs its result.
 struct Renderer::StreamingFrame {
   bool pending = false;
+  int slot = 0;
   int H = 0, pass_mode = 0;
   bool grad = false, ssh = false;
   NeuralVolume* nv = nullptr;
@@ -1289,6 +1292,9 @@ struct Renderer::StreamingFrame {
   uint32_t* predicted = nullptr;
   RenderParams p_all;
   PartState part[Renderer::kMaxParts];
+  StreamingFrame() { for (auto& p : part) (void)hipEventCreateWithFlags(&p.ev_done, hipEventDisableTiming); }
+  ~StreamingFrame() { for (auto& p : part) if (p.ev_done) (void)hipEventDestroy(p.ev_done); }
+  void mark(int h) { VNR_HIP_CHECK(hipEventRecord(part[h].ev_done, part[h].s)); }
 };
 
 Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volume))
@@ -1303,9 +1309,9 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
     const int w = std::atoi(e);
     tile_w_log2_ = w == 16 ? 4u : w == 32 ? 5u : w == 64 ? 6u : 3u;
   }
-  counters_.resize(kMaxParts * C_COUNT);  // one block of counters per half
+  counters_.resize(2 * kMaxParts * C_COUNT);  // one block of counters per frame slot and half
   counters_.zero(stream_);
-  VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, kMaxParts * (256 + C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
+  VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 2 * kMaxParts * (256 + C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
   for (int i = 1; i < kMaxParts; ++i) VNR_HIP_CHECK(hipStreamCreateWithFlags(&part_streams_[i], hipStreamNonBlocking));
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 }
@@ -1320,7 +1326,7 @@ Renderer::~Renderer()
   for (int i = 0; i < 2; ++i) if (ev_gathered_[i]) (void)hipEventDestroy(ev_gathered_[i]);
   for (int i = 0; i < 2; ++i) if (host_fb_[i]) (void)hipHostFree(host_fb_[i]);
   if (host_counts_) (void)hipHostFree(host_counts_);
-  for (auto& v : events_) for (auto e : v) (void)hipEventDestroy(e);
+  for (auto& sl : events_) for (auto& v : sl) for (auto e : v) (void)hipEventDestroy(e);
 }
 
 void Renderer::resize(int w, int h)
@@ -1396,9 +1402,15 @@ void Renderer::issue_gather(int buf)
   if (gather_issued_[buf]) return;
   Dist& d = Dist::get();
   hipStream_t comm = d.comm_stream();
-  // every part stream of the frame has been joined by the host (finish_streaming); the render stream carries the rest
-  VNR_HIP_CHECK(hipEventRecord(ev_rendered_, stream_));
-  VNR_HIP_CHECK(hipStreamWaitEvent(comm, ev_rendered_, 0));
+  // the frame's kernels: a streaming frame's parts have their completion events (the streams themselves may already hold the next
+  // frame); any other mode runs on the render stream
+  const int fslot = frame_of_buffer_[buf];
+  if (fslot >= 0 && frame_[fslot]) {
+    for (int h = 0; h < frame_[fslot]->H; ++h) VNR_HIP_CHECK(hipStreamWaitEvent(comm, frame_[fslot]->part[h].ev_done, 0));
+  } else {
+    VNR_HIP_CHECK(hipEventRecord(ev_rendered_, stream_));
+    VNR_HIP_CHECK(hipStreamWaitEvent(comm, ev_rendered_, 0));
+  }
   vec4f* g = gathered_[buf].ptr;
   const size_t share_bytes = (size_t)share_n_local_ * sizeof(vec4f);
   d.transport().all_gather(g + (size_t)share_rank_ * share_n_local_, g, share_bytes, comm);   // in place: the own slot is already there
@@ -1413,19 +1425,21 @@ void Renderer::issue_gather(int buf)
 
 const float* Renderer::render_pipelined()
 {
-  if (!distributed_) { render(); return map_frame(); }
+  // frame k + 1 is enqueued (its head before the host has seen frame k complete, render_streaming), which completes frame k;
+  // frame k then travels (distributed: all-gather + assembly on the communication stream) while frame k + 1 renders
   const int cur = fb_cur_;
-  const bool was_async = async_;
+  const bool was_async = async_, was_skip = skip_download_;
   async_ = true;
-  try { render(); } catch (...) { async_ = was_async; throw; }   // the predicted iterations of frame k are enqueued
-  async_ = was_async;
+  if (!distributed_) skip_download_ = true;   // (the host copy of a pipelined frame is made when it is handed out, below)
+  try { render(); } catch (...) { async_ = was_async; skip_download_ = was_skip; throw; }
+  async_ = was_async; skip_download_ = was_skip;
   const float* out = nullptr;
   const int prev = pipe_prev_;
-  if (prev >= 0) issue_gather(prev);   // frame k - 1 travels while frame k renders
-  finish_pending();                    // frame k complete (further iterations if rays are still alive)
   if (prev >= 0) {
-    VNR_HIP_CHECK(hipEventSynchronize(ev_gathered_[prev]));
-    out = skip_download_ ? (const float*)full_[prev].ptr : (const float*)host_fb_[prev];
+    // frame k is complete unless this frame could not be pipelined (first frame after a change: render() completed k before)
+    StreamingFrame* older = frame_[slot_ ^ 1].get();
+    if (older && older->pending) finish_streaming(*older);
+    out = hand_out_frame(prev);
   }
   pipe_prev_ = cur;
   fb_cur_ ^= 1;
@@ -1434,13 +1448,26 @@ const float* Renderer::render_pipelined()
 
 const float* Renderer::flush_pipeline()
 {
-  if (!distributed_ || pipe_prev_ < 0) return nullptr;
+  if (pipe_prev_ < 0) return nullptr;
   finish_pending();
   const int prev = pipe_prev_;
-  issue_gather(prev);
-  VNR_HIP_CHECK(hipEventSynchronize(ev_gathered_[prev]));
   pipe_prev_ = -1;
-  return skip_download_ ? (const float*)full_[prev].ptr : (const float*)host_fb_[prev];
+  return hand_out_frame(prev);
+}
+
+// the complete frame in buffer `buf` as the application sees it: assembled over the ranks (distributed), on the host unless the
+// output is a device framebuffer
+const float* Renderer::hand_out_frame(int buf)
+{
+  if (distributed_) {
+    issue_gather(buf);
+    VNR_HIP_CHECK(hipEventSynchronize(ev_gathered_[buf]));
+    return skip_download_ ? (const float*)full_[buf].ptr : (const float*)host_fb_[buf];
+  }
+  if (skip_download_) return (const float*)fb_[buf].ptr;
+  const size_t n = (size_t)width_ * height_;
+  VNR_HIP_CHECK(hipMemcpy(host_fb_[buf], fb_[buf].ptr, n * sizeof(vec4f), hipMemcpyDeviceToHost));
+  return (const float*)host_fb_[buf];
 }
 
 void Renderer::set_transfer_function(const TransferFunctionData& t)
@@ -1455,16 +1482,18 @@ void Renderer::set_transfer_function(const TransferFunctionData& t)
 void Renderer::ensure_queues(size_t n_pixels, int n_iters, bool gradient)
 {
   if (queue_pixels_ >= n_pixels && queue_iters_ >= n_iters && (queue_grad_ || !gradient)) return;
+  finish_pending();   // a pending frame lives in the buffers that are about to be replaced
   VNR_HIP_CHECK(hipStreamSynchronize(stream_));
   const size_t P = std::max(n_pixels, queue_pixels_);
   const int iters = std::max(n_iters, queue_iters_);
   const bool grad = gradient || queue_grad_;
-  q_u32_.resize(6 * P);
-  ray_counts_.resize(P / 64 + 64 + 8 * kMaxParts);   // survivors per 64-ray group (P is a multiple of 64; slack for the round-up to 256 rays)
-  q_f32_.resize(18 * P);
-  q_i32_.resize(6 * P);
-  queue_.resize(P * iters * (grad ? 4 : 1));          // 4 records per sample with gradient shading
-  arena_.resize(2 * P * iters * (grad ? 6 : 2));      // x2 parities; 2 (+4) result floats per sample slot
+  // everything x 2: two frame slots (renderer.h)
+  q_u32_.resize(2 * 6 * P);
+  ray_counts_.resize(2 * (P / 64 + 64 + 8 * kMaxParts));   // survivors per 64-ray group (P is a multiple of 64; slack for the round-up to 256 rays)
+  q_f32_.resize(2 * 18 * P);
+  q_i32_.resize(2 * 6 * P);
+  queue_.resize(2 * P * iters * (grad ? 4 : 1));          // 4 records per sample with gradient shading
+  arena_.resize(2 * 2 * P * iters * (grad ? 6 : 2));      // x2 parities; 2 (+4) result floats per sample slot
   queue_pixels_ = P;
   queue_iters_ = iters;
   queue_grad_ = grad;
@@ -1472,12 +1501,20 @@ void Renderer::ensure_queues(size_t n_pixels, int n_iters, bool gradient)
 
 void Renderer::finish_pending()
 {
-  if (frame_ && frame_->pending) finish_streaming();
+  for (int k = 1; k <= 2; ++k) {   // the older slot first
+    StreamingFrame* f = frame_[(slot_ + k) & 1].get();
+    if (f && f->pending) finish_streaming(*f);
+  }
 }
 
 void Renderer::render()
 {
-  finish_pending();
+  // an asynchronous single-pass frame that is still pending stays pending until the head of this frame is enqueued
+  // (render_streaming); everything else completes first
+  const bool pipeline_head = async_ && (skip_download_ || distributed_) && (mode_ == 5 || mode_ == 6 || mode_ == 8 || mode_ == 9) &&
+                             frame_[slot_] && frame_[slot_]->pending && !(frame_[slot_ ^ 1] && frame_[slot_ ^ 1]->pending) &&
+                             !reset_;   // (a frame that restarts the accumulation overwrites it: its head must not run beside the tail of the frame before)
+  if (!pipeline_head) finish_pending();
   if (width_ <= 0 || height_ <= 0) return;  // renderer.cpp:63
   MacroCell& mc = volume_->macrocell();
   if (!mc.allocated()) throw std::runtime_error("volume has no macrocell");
@@ -1557,8 +1594,9 @@ void Renderer::render()
     p.frame = gathered_[fb_cur_].ptr + (size_t)share_rank_ * share_n_local_;
   }
   p.accumulation = accumulation_.ptr;
-  stats_ = FrameStats();
+  if (!pipeline_head) stats_ = FrameStats();   // (pipelined: reset by render_streaming once the frame before this one has completed)
 
+  frame_of_buffer_[fb_cur_] = -1;
   if (p.pixel_hi > p.pixel_lo && p.n_local > 0) {
     switch (mode_) {
     case 6:   // VNR_RAYMARCHING_NO_SHADING_IN_SHADER: the reference evaluates the network inside the marching loop
@@ -1681,9 +1719,8 @@ void Renderer::render_pathtracing(const RenderParams& p)
 }
 
 // one iteration of one half: march(it) -> evaluate the compacted samples -> clear the counters march(it+1) appends to
-void Renderer::launch_iteration(int h)
+void Renderer::launch_iteration(StreamingFrame& f, int h)
 {
-  StreamingFrame& f = *frame_;
   PartState* half = f.part;
   const int pass_mode = f.pass_mode, H = f.H;
   const bool grad = f.grad, ssh = f.ssh;
@@ -1714,7 +1751,7 @@ void Renderer::launch_iteration(int h)
 #undef VNR_MARCH
     }
     VNR_HIP_CHECK(hipGetLastError());
-    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it], hf.s));
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], hf.s));
     if (nv) {
       // a record's 4th word is the float index of its result in this arena (stride 1)
       nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 1, c + C_SAMPLES0 + parity, hf.s_max, hf.s, (uint32_t)H);
@@ -1722,7 +1759,7 @@ void Renderer::launch_iteration(int h)
       const uint32_t blocks = std::min<uint32_t>(div_round_up(hf.s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
       gt_sample_kernel<<<blocks, 256, 0, hf.s>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, (float*)hf.vd[parity]);
     }
-    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[h][2 * it + 1], hf.s));
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it + 1], hf.s));
     // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
     // 1024-thread blocks need 4 free wave slots on every SIMD of one CU at once, which the other half's evaluation kernel
     // rarely leaves: a small share (where the wait shows) packs with 256-thread blocks
@@ -1765,10 +1802,25 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
   NeuralVolume* nv = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get()) : nullptr;
   if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
 
-  if (!frame_) frame_.reset(new StreamingFrame());
-  StreamingFrame& f = *frame_;
+  // the slot the previous frame does not occupy if that one is still pending (asynchronous frames), else the same slot again
+  StreamingFrame* older = frame_[slot_] && frame_[slot_]->pending ? frame_[slot_].get() : nullptr;
+  const int slot = older ? slot_ ^ 1 : slot_;
+  if (!frame_[slot]) frame_[slot].reset(new StreamingFrame());
+  StreamingFrame& f = *frame_[slot];
+  if (f.pending) throw std::runtime_error("internal: both frame slots are pending");
+  f.slot = slot;
+  slot_ = slot;
   PartState* half = f.part;
   for (int h = 0; h < kMaxParts; ++h) { half[h].it = 0; half[h].used = 0; half[h].done = false; }
+  const size_t n_groups_slot = QP / 64 + 64 + 8 * kMaxParts;
+  uint32_t* const u32_base = q_u32_.ptr + (size_t)slot * 6 * QP;
+  float* const f32_base = q_f32_.ptr + (size_t)slot * 18 * QP;
+  int* const i32_base = q_i32_.ptr + (size_t)slot * 6 * QP;
+  uint32_t* const rc_base = ray_counts_.ptr + (size_t)slot * n_groups_slot;
+  vec4f* const queue_base = queue_.ptr + (size_t)slot * rec_per_slot * QP * QI;
+  float* const arena_base = arena_.ptr + (size_t)slot * 2 * slot_floats * QP * QI;
+  uint32_t* const counters_base = counters_.ptr + (size_t)slot * kMaxParts * C_COUNT;
+  uint32_t* const host_base = host_counts_ + (size_t)slot * kMaxParts * (256 + C_COUNT);
   size_t off = 0;
   for (int h = 0; h < H; ++h) {
     PartState& hf = half[h];
@@ -1779,16 +1831,16 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
       hf.p.n_local = ((R + (uint32_t)(H - 1 - h)) / (uint32_t)H) * row_items;
     }
     for (int b = 0; b < 2; ++b) {
-      hf.rl[b].pixel_index = q_u32_.ptr + (size_t)(0 + b) * QP + off;
-      hf.rl[b].sample_base = q_u32_.ptr + (size_t)(2 + b) * QP + off;
-      hf.rl[b].sample_count = q_u32_.ptr + (size_t)(4 + b) * QP + off;
-      float* f = q_f32_.ptr + (size_t)b * 9 * QP;
+      hf.rl[b].pixel_index = u32_base + (size_t)(0 + b) * QP + off;
+      hf.rl[b].sample_base = u32_base + (size_t)(2 + b) * QP + off;
+      hf.rl[b].sample_count = u32_base + (size_t)(4 + b) * QP + off;
+      float* f = f32_base + (size_t)b * 9 * QP;
       hf.rl[b].jitter = f + off;
       hf.rl[b].alpha = f + QP + off;
       hf.rl[b].color = (vec3f*)(f + 2 * QP) + off;
       hf.rl[b].t_next = (vec3f*)(f + 5 * QP) + off;
       hf.rl[b].next_cell_begin = f + 8 * QP + off;
-      hf.rl[b].cell = (vec3i*)(q_i32_.ptr + (size_t)b * 3 * QP) + off;
+      hf.rl[b].cell = (vec3i*)(i32_base + (size_t)b * 3 * QP) + off;
       hf.ssh.org[b] = nullptr; hf.ssh.color[b] = nullptr; hf.ssh.alpha[b] = nullptr;
       if (ssh) {
         float* g = q_ssh_.ptr + (size_t)b * 7 * QP;
@@ -1797,20 +1849,20 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
         hf.ssh.alpha[b] = g + 6 * QP + off;
       }
       // this half's result arena of parity b: a slice of slot_floats * n_local * QI floats
-      hf.vd[b] = (vec2f*)(arena_.ptr + (size_t)b * slot_floats * QP * QI + slot_floats * off * QI);
+      hf.vd[b] = (vec2f*)(arena_base + (size_t)b * slot_floats * QP * QI + slot_floats * off * QI);
     }
     hf.p.slot_cap = (uint32_t)((size_t)hf.p.n_local * QI);   // 2 (+ 4 with gradient shading) floats per slot fit the slice
-    hf.queue = queue_.ptr + rec_per_slot * off * QI;
-    hf.c = counters_.ptr + (size_t)h * C_COUNT;
-    hf.rc = ray_counts_.ptr + off / 64 + (size_t)h * 8;   // halves are multiples of 64 rays; 8 groups of slack each
-    hf.hc = host_counts_ + (size_t)h * 256;
-    hf.hs = host_counts_ + kMaxParts * 256 + (size_t)h * C_COUNT;
+    hf.queue = queue_base + rec_per_slot * off * QI;
+    hf.c = counters_base + (size_t)h * C_COUNT;
+    hf.rc = rc_base + off / 64 + (size_t)h * 8;   // halves are multiples of 64 rays; 8 groups of slack each
+    hf.hc = host_base + (size_t)h * 256;
+    hf.hs = host_base + kMaxParts * 256 + (size_t)h * C_COUNT;
     hf.s = h == 0 ? stream_ : part_streams_[h];
     hf.s_max = (size_t)hf.p.n_local * hf.p.n_iters * (grad ? 4 : 1);   // records the evaluation kernel may see
     off += hf.p.n_local;
   }
 
-  VNR_HIP_CHECK(hipMemsetAsync(counters_.ptr, 0, (size_t)H * C_COUNT * sizeof(uint32_t), stream_));
+  VNR_HIP_CHECK(hipMemsetAsync(counters_base, 0, (size_t)H * C_COUNT * sizeof(uint32_t), stream_));
   if (H > 1) {  // fork: the other streams start after everything queued on the render stream so far
     VNR_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
     for (int h = 1; h < H; ++h) VNR_HIP_CHECK(hipStreamWaitEvent(part_streams_[h], ev_fork_, 0));
@@ -1831,28 +1883,38 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
   if (profiling_) {
     iter_ms_.assign(max_iterations, 0.0f);
     for (int h = 0; h < H; ++h)
-      while (events_[h].size() < 2 * max_iterations) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreate(&e)); events_[h].push_back(e); }
+      while (events_[slot][h].size() < 2 * max_iterations) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreate(&e)); events_[slot][h].push_back(e); }
   }
 
   f.H = H; f.pass_mode = pass_mode; f.grad = grad; f.ssh = ssh; f.nv = nv; f.shmem = shmem; f.shmem_compose = shmem_compose;
   f.max_iterations = max_iterations; f.predicted = predicted; f.p_all = p_all;
+  // phase 0 (asynchronous frames with the frame before still pending): the HEAD of this frame, i.e. iteration 0 of every part:
+  // ray generation, the first batch of samples, their evaluation and the packing.  The only pixels it writes are those of rays
+  // that miss the volume or find nothing to sample, which contribute zero in every frame, so it may run before the frame
+  // before it has written its last pixel; then that frame is completed (host), and only then come the iterations that compose.
+  if (older) {
+    for (int h = 0; h < H; ++h) launch_iteration(f, h);
+    finish_streaming(*older);
+    stats_ = FrameStats();
+  }
+  frame_of_buffer_[fb_cur_] = slot;
   // phase 1: the iterations the previous frame needed, launched for both halves alternately without any host sync;
   // phase 2: past that, look at the alive-ray count of the iteration just launched before launching another one.
   for (;;) {
     bool launched = false;
     for (int h = 0; h < H; ++h)
-      if (!half[h].done && half[h].it < predicted[h]) { launch_iteration(h); launched = true; }
+      if (!half[h].done && half[h].it < predicted[h]) { launch_iteration(f, h); launched = true; }
     if (!launched) break;
   }
+  for (int h = 0; h < H; ++h) f.mark(h);
   f.pending = true;
-  if (!defer) finish_streaming();
+  if (!defer) finish_streaming(f);
 }
 
 // phase 2 of a pass and its bookkeeping: past the predicted iterations, look at the alive-ray count of the iteration just
 // launched before launching another one; then the statistics.  Ends the "pending" state of an asynchronous frame.
-void Renderer::finish_streaming()
+void Renderer::finish_streaming(StreamingFrame& f)
 {
-  StreamingFrame& f = *frame_;
   if (!f.pending) return;
   f.pending = false;
   PartState* half = f.part;
@@ -1865,10 +1927,11 @@ void Renderer::finish_streaming()
       PartState& hf = half[h];
       if (hf.done) continue;
       if (hf.it > 0) {
-        VNR_HIP_CHECK(hipStreamSynchronize(hf.s));
+        VNR_HIP_CHECK(hipEventSynchronize(hf.ev_done));
         if (hf.hc[(hf.it - 1) & 255u] == 0) { hf.done = true; continue; }
       }
-      launch_iteration(h);
+      launch_iteration(f, h);
+      f.mark(h);
       pending = true;
     }
     if (!pending) break;
@@ -1879,7 +1942,7 @@ void Renderer::finish_streaming()
   uint64_t n_samples = 0, n_refrays = 0;
   for (int h = 0; h < H; ++h) {
     PartState& hf = half[h];
-    VNR_HIP_CHECK(hipStreamSynchronize(hf.s));
+    VNR_HIP_CHECK(hipEventSynchronize(hf.ev_done));
     uint32_t used = hf.it;
     while (used > 1 && hf.hc[(used - 2) & 255u] == 0) --used;  // trailing speculative no-op iterations
     predicted[h] = used;
@@ -1894,7 +1957,7 @@ void Renderer::finish_streaming()
     if (profiling_) {
       for (uint32_t k = 0; k < hf.it; ++k) {
         float ms = 0.0f;
-        VNR_HIP_CHECK(hipEventElapsedTime(&ms, events_[h][2 * k], events_[h][2 * k + 1]));
+        VNR_HIP_CHECK(hipEventElapsedTime(&ms, events_[f.slot][h][2 * k], events_[f.slot][h][2 * k + 1]));
         stats_.infer_kernel_ms += ms;
         iter_ms_[k] += ms;
       }
@@ -1908,8 +1971,8 @@ void Renderer::finish_streaming()
     for (int h = 0; h < H; ++h)
       for (uint32_t k = 0; k < half[h].it; ++k) {
         float t0 = 0.0f, t1 = 0.0f;
-        VNR_HIP_CHECK(hipEventElapsedTime(&t0, events_[0][0], events_[h][2 * k]));
-        VNR_HIP_CHECK(hipEventElapsedTime(&t1, events_[0][0], events_[h][2 * k + 1]));
+        VNR_HIP_CHECK(hipEventElapsedTime(&t0, events_[f.slot][0][0], events_[f.slot][h][2 * k]));
+        VNR_HIP_CHECK(hipEventElapsedTime(&t1, events_[f.slot][0][0], events_[f.slot][h][2 * k + 1]));
         iv.emplace_back(t0, t1);
       }
     std::sort(iv.begin(), iv.end());
@@ -1925,6 +1988,7 @@ void Renderer::finish_streaming()
   stats_.n_iterations += pass_iterations;
   stats_.n_samples += n_samples;
   stats_.n_reference_slots += n_refrays * (uint64_t)p_all.n_iters;
+  completed_stats_ = stats_;
 }
 
 

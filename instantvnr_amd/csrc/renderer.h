@@ -69,20 +69,22 @@ public:
   const float* render_pipelined();
   const float* flush_pipeline();
   const FrameStats& stats() { finish_pending(); return stats_; }
+  const FrameStats& completed_stats() const { return completed_stats_; }   // of the frame completed last; completes nothing (pipelined frames)
   int width() const { return width_; }
   int height() const { return height_; }
 
 private:
   struct StreamingFrame;   // render.hip
   void render_streaming(const RenderParams& p, int pass_mode, bool defer = false);   // one iterative_raymarching_loop<MODE> (method_raymarching.cu:931-958)
-  void launch_iteration(int part);
-  void finish_streaming();
+  void launch_iteration(StreamingFrame& f, int part);
+  void finish_streaming(StreamingFrame& f);
   void finish_pending();
   void render_monolithic(const RenderParams& p);
   void render_pathtracing(const RenderParams& p);   // do_path_tracing_iterative (method_pathtracing.cu:786-806)
   void ensure_queues(size_t n_pixels, int n_iters, bool gradient);
   void ensure_share_buffers();
   void issue_gather(int buf);    // all-gather + assemble (+ download) of the frame in gathered_[buf], on the communication stream
+  const float* hand_out_frame(int buf);
 
   std::shared_ptr<VolumeBase> volume_;
   CameraData camera_;
@@ -93,7 +95,13 @@ private:
   uint32_t pixel_lo_ = 0, pixel_hi_ = 0xffffffffu;
   uint32_t il_block_ = 8, il_parts_ = 1, il_part_ = 0;
   bool reset_ = true, skip_download_ = false, profiling_ = false, async_ = false;
-  std::unique_ptr<StreamingFrame> frame_;
+  // Two slots of frame state (ray lists, queues, result arenas, counters, pinned rings, events): with asynchronous frames the
+  // HEAD of frame k + 1 (ray generation, first batch of samples, their evaluation, packing: nothing in it writes a pixel that
+  // frame k contributes to) is enqueued before the host has seen frame k complete, so the GPU has work during the host's
+  // turn-around between two frames (55 us of a 0.7 ms share on one of eight GPUs)
+  std::unique_ptr<StreamingFrame> frame_[2];
+  int slot_ = 0;            // the slot of the frame rendered last (pending or complete)
+  int frame_of_buffer_[2] = {-1, -1};   // which slot's streaming frame wrote framebuffer i (-1: another rendering mode)
   int frame_index_ = 0;
   // samples per ray and iteration, VNR_RM_N_ITERS (method_raymarching.cu:30-40; 16 there, tuned on the authors' GPU).  Frames
   // depend on it only through the last bit of samples at batch boundaries (0.2 % of the pixels, max 4e-5); on MI355X 24 is the fastest (bench workload: 16: 122, 24: 129, 32: 126 frames/s)
@@ -141,8 +149,8 @@ private:
   uint32_t* host_counts_ = nullptr;  // pinned rings of alive-ray counts, 2 x 256
   size_t queue_pixels_ = 0;
   int queue_iters_ = 0;
-  std::vector<hipEvent_t> events_[kMaxParts];  // per half: (before, after) the evaluation kernel of each iteration
-  FrameStats stats_;
+  std::vector<hipEvent_t> events_[2][kMaxParts];  // per slot and half: (before, after) the evaluation kernel of each iteration
+  FrameStats stats_, completed_stats_;
   std::vector<float> iter_ms_;
 };
 

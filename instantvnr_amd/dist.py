@@ -143,19 +143,21 @@ class ShardedRenderer:
             check(lib().vnrAmdRendererSetDistributed(renderer.h, 1))
 
     def render(self):
-        if not self.ctx.distributed:
-            api.vnrRender(self.r)
-            return api.vnrRendererMapFrame(self.r)   # syncs the render stream
         out = C.c_void_p()
         check(lib().vnrAmdRendererRenderPipelined(self.r.h, C.byref(out)))
         return out if out.value else None
 
     def flush(self):
-        if not self.ctx.distributed:
-            return None
         out = C.c_void_p()
         check(lib().vnrAmdRendererFlushPipeline(self.r.h, C.byref(out)))
         return out if out.value else None
+
+    def completed_stats(self):
+        """statistics of the frame completed last (does not complete the frame in flight)"""
+        from ._lib import FrameStats
+        st = FrameStats()
+        check(lib().vnrAmdRendererGetCompletedFrameStats(self.r.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in FrameStats._fields_}
 
     def download(self, ptr):
         """a frame returned by render() / flush() as a [height, width, 4] numpy array"""

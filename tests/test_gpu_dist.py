@@ -236,3 +236,55 @@ def test_asynchronous_frames_equal_synchronous_ones(monkeypatch):
     api.vnrRender(r_async)
     st = api.vnrRendererGetFrameStats(r_async)
     assert st["n_iterations"] == iterations[-1]
+
+
+def test_pipelined_frames_of_one_renderer_equal_synchronous_ones():
+    """vnrAmdRendererRenderPipelined without a process group: the head of frame k + 1 (ray generation, first batch of samples) is
+    enqueued before the host has seen frame k complete.  Frames accumulate over a still camera (the case that pipelines), then
+    the camera moves (a frame that restarts the accumulation is not pipelined), then accumulate again; every frame handed out
+    must equal the synchronous renderer's, statistics included."""
+    size = (96, 80)
+    n_pixels = size[0] * size[1]
+    vol = syn.analytic_volume(48)
+    sv = api.vnrCreateSimpleVolume(vol)
+    nv = api.vnrCreateNeuralVolume(syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2), sv,
+                                   online_macrocell_construction=False)
+    api.vnrNeuralVolumeTrain(nv, 30, True)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    for volume in (sv, nv):
+        def renderer():
+            r = api.vnrCreateRenderer(volume)
+            api.vnrRendererSetTransferFunction(r, tfn)
+            api.vnrRendererSetFramebufferSize(r, size)
+            api.vnrRendererSetMode(r, 5)
+            api.vnrRendererSetOutputAsDeviceFramebuffer(r, True)
+            return r
+        r_sync, r_pipe = renderer(), renderer()
+        want, got, want_samples, got_samples = [], [], [], []
+        out = C.c_void_p()
+        st = vdist.ShardedRenderer(vdist.Context(), r_pipe, size[0], size[1])
+        for distance, frames in ((1.2, 4), (2.5, 1), (0.9, 3)):
+            cam = syn.oblique_camera((48, 48, 48), distance_scale=distance)
+            for r in (r_sync, r_pipe):
+                camera = api.vnrCreateCamera()
+                api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+                api.vnrRendererSetCamera(r, camera)    # (completes a frame of the pipelined renderer that is still in flight)
+            for _ in range(frames):
+                api.vnrRender(r_sync)
+                want.append(_download(api.vnrRendererMapFrame(r_sync), n_pixels))
+                want_samples.append(api.vnrRendererGetFrameStats(r_sync)["n_samples"])
+                check(lib().vnrAmdRendererRenderPipelined(r_pipe.h, C.byref(out)))
+                if out.value:
+                    got.append(_download(out, n_pixels))
+                    got_samples.append(st.completed_stats()["n_samples"])
+        check(lib().vnrAmdRendererFlushPipeline(r_pipe.h, C.byref(out)))
+        got.append(_download(out, n_pixels))
+        got_samples.append(st.completed_stats()["n_samples"])
+        assert len(got) == len(want) == 8
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert np.array_equal(g, w), k
+        assert got_samples == want_samples

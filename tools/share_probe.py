@@ -15,6 +15,7 @@ cfg = syn.model_config(n_levels=16, n_features=2, log2_hashmap_size=22, n_hidden
 nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
 api.vnrNeuralVolumeTrain(nv, 300, True)
 cam = syn.oblique_camera(dims, distance_scale=1.1)
+import os
 base = 0.0
 colors, alphas = syn.tfn_ramp_with_bumps(opacity_scale=0.06)
 import os
@@ -33,8 +34,15 @@ for parts in [int(v) for v in os.environ.get("SHARE_PARTS", "1,2,4,8").split(","
     check(L.vnrAmdSynchronize())
     t0 = time.perf_counter()
     n = 40
-    for _ in range(n):
-        api.vnrRender(ren); api.vnrRendererMapFrame(ren)
+    import ctypes as C
+    if os.environ.get("SHARE_PIPELINED"):   # the pipelined calls (head of frame k + 1 before frame k has completed on the host)
+        out = C.c_void_p()
+        for _ in range(n):
+            check(L.vnrAmdRendererRenderPipelined(ren.h, C.byref(out)))
+        check(L.vnrAmdRendererFlushPipeline(ren.h, C.byref(out)))
+    else:
+        for _ in range(n):
+            api.vnrRender(ren); api.vnrRendererMapFrame(ren)
     check(L.vnrAmdSynchronize())
     dt = (time.perf_counter() - t0) / n
     st = api.vnrRendererGetFrameStats(ren)

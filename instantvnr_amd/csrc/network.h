@@ -11,7 +11,7 @@
 namespace vnr {
 
 constexpr int kMaxLevels = 32;
-constexpr int kWidth = 64;        // FullyFusedMLP n_neurons supported by the MFMA kernels
+constexpr int kWidth = 64;        // FullyFusedMLP n_neurons of the MFMA kernels (16 / 32 / 128: generic kernel, inference only)
 constexpr int kLossScale = 128;   // tcnn default loss scale for fp16 (EXTERNAL)
 
 struct LevelInfo {
@@ -43,14 +43,16 @@ struct GridDevice {
   LevelInfo levels[kMaxLevels];
   uint32_t n_levels;
   uint32_t n_features;     // per level
-  uint32_t interpolation;  // 0 linear, 1 smoothstep
+  uint32_t interpolation;  // 0 linear, 1 smoothstep, 2 nearest
 };
 
 struct ModelConfig {
   // encoding (tcnn HashGrid; example-model.json:19-25)
   uint32_t n_levels = 8, n_features = 8, log2_hashmap_size = 19, base_resolution = 16;
   float per_level_scale = 2.0f;
-  uint32_t interpolation = 0;
+  uint32_t interpolation = 0;          // 0 Linear, 1 Smoothstep, 2 Nearest (tcnn_impl_decoder.cu:73-94)
+  float quantize_threshold = 0.0f;     // corner values below it in magnitude count as 0 (tcnn_impl_decoder.cu:120); tcnn default 0
+  float max_level = 1000.0f;           // levels l >= max_level + 1e-3 encode to 0 (tcnn_impl_decoder.cu:17); tcnn default: no masking
   // network (FullyFusedMLP; example-model.json:26-32)
   uint32_t n_neurons = 64, n_hidden_layers = 4;
   uint32_t activation = 1;  // 0 None, 1 ReLU
@@ -93,6 +95,11 @@ public:
   const Json& model_json() const { return model_; }
   const GridDevice& grid() const { return grid_; }
   uint32_t padded_width() const { return in_width_; }
+  uint32_t width() const { return cfg_.n_neurons; }
+  // the MFMA kernels cover n_neurons 64, Linear / Smoothstep, no quantisation; every other model the reference accepts
+  // (n_neurons 16 / 32 / 128, tcnn_impl.cu:315-347; Nearest; quantize_threshold) is evaluated by a generic kernel: inference only
+  bool fast_path() const { return cfg_.n_neurons == (uint32_t)kWidth && cfg_.interpolation != 2u && cfg_.quantize_threshold == 0.0f; }
+  uint32_t n_active_levels() const;    // levels below max_level + 1e-3
   uint32_t n_hidden_matmuls() const { return cfg_.n_hidden_layers - 1; }
   size_t n_params() const { return n_params_; }
   size_t n_mlp_params() const { return n_mlp_; }

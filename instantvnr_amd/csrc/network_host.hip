@@ -20,7 +20,10 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
                   const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr,
                   uint32_t sharers = 1);
 void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
-                        uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s);
+                        uint32_t n_hidden_matmuls, uint32_t width, uint64_t seed, hipStream_t s);
+void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, uint32_t n_active_levels, uint32_t in_width, const LevelInfo* d_levels,
+                    const uint16_t* params, size_t n_mlp, const float* coords, float* out, uint16_t* features_out, size_t n, const uint32_t* d_n,
+                    size_t n_max, hipStream_t s, const uint32_t* d_dest, uint32_t queue_out_stride);
 // master weights <- fp16 parameters; reset_optimizer also zeroes the moments and step counts
 void launch_master_from_f16(const uint16_t* params, OptState* state, size_t n, bool reset_optimizer, hipStream_t s);
 
@@ -149,7 +152,12 @@ void Network::configure(const Json& config, uint64_t init_seed)
   const std::string it = json_str(enc, "interpolation", "Linear");
   if (it == "Linear") c.interpolation = 0;
   else if (it == "Smoothstep") c.interpolation = 1;
+  else if (it == "Nearest") c.interpolation = 2;
   else throw std::runtime_error("unsupported interpolation: " + it);
+  // the reference reads both from the tcnn encoding object (tcnn_device_api.h:53-54), where only tcnn's own API can set them, so
+  // a params.json never carries them; here they may be given with the encoding (absent = tcnn's defaults)
+  c.quantize_threshold = json_f32(enc, "quantize_threshold", 0.0f);
+  c.max_level = json_f32(enc, "max_level", 1000.0f);
   if (c.n_features != 1 && c.n_features != 2 && c.n_features != 4 && c.n_features != 8)
     throw std::runtime_error("n_features_per_level must be 1, 2, 4 or 8");  // method_raymarching.cu:1241-1244
   if (c.log2_hashmap_size > 28) throw std::runtime_error("log2_hashmap_size too large");
@@ -158,7 +166,8 @@ void Network::configure(const Json& config, uint64_t init_seed)
   if (nt != "FullyFusedMLP") throw std::runtime_error("unsupported network otype: " + nt + " (FullyFusedMLP only)");
   c.n_neurons = json_u32(net, "n_neurons", 128);
   c.n_hidden_layers = json_u32(net, "n_hidden_layers", 5);
-  if (c.n_neurons != (uint32_t)kWidth) throw std::runtime_error("FullyFusedMLP n_neurons must be 64 in this build");
+  if (c.n_neurons != 16 && c.n_neurons != 32 && c.n_neurons != 64 && c.n_neurons != 128)
+    throw std::runtime_error("FullyFusedMLP n_neurons must be 16, 32, 64 or 128");   // tcnn_impl.cu:315-347
   if (c.n_hidden_layers < 1) throw std::runtime_error("n_hidden_layers must be >= 1");
   const std::string act = json_str(net, "activation", "ReLU");
   if (act == "ReLU") c.activation = 1;
@@ -183,7 +192,8 @@ void Network::build_layout()
   const uint32_t total_entries = grid_make_layout(cfg_, &grid_);
   in_width_ = next_multiple(cfg_.n_levels * cfg_.n_features, 16u);
   if (in_width_ > 128) throw std::runtime_error("encoded width > 128 is not supported");
-  n_mlp_ = (size_t)kWidth * in_width_ + (size_t)n_hidden_matmuls() * kWidth * kWidth + (size_t)16 * kWidth;
+  const size_t W = cfg_.n_neurons;
+  n_mlp_ = W * in_width_ + (size_t)n_hidden_matmuls() * W * W + (size_t)16 * W;
   n_params_ = n_mlp_ + (size_t)total_entries * cfg_.n_features;
   if ((n_params_ - n_mlp_) * sizeof(uint16_t) >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
   lds_halves_ = (in_width_ / 16) * 1024 + n_hidden_matmuls() * 4096 + 64;
@@ -200,13 +210,20 @@ void Network::build_layout()
 void Network::initialize_params(uint64_t seed, hipStream_t s)
 {
   opt_state_.resize(n_params_);
-  launch_init_params(opt_state_.ptr, params_f16_.ptr, n_mlp_, n_params_, in_width_, n_hidden_matmuls(), seed, s);
+  launch_init_params(opt_state_.ptr, params_f16_.ptr, n_mlp_, n_params_, in_width_, n_hidden_matmuls(), cfg_.n_neurons, seed, s);
   refresh_inference_weights(s);
+}
+
+uint32_t Network::n_active_levels() const
+{
+  uint32_t n = 0;
+  while (n < cfg_.n_levels && !((float)n >= cfg_.max_level + 1e-3f)) ++n;
+  return n;
 }
 
 void Network::refresh_inference_weights(hipStream_t s)
 {
-  launch_pack_mlp(params_f16_.ptr, mlp_packed_.ptr, in_width_, n_hidden_matmuls(), s);
+  if (fast_path()) launch_pack_mlp(params_f16_.ptr, mlp_packed_.ptr, in_width_, n_hidden_matmuls(), s);
   // the parameters changed: the brick image is stale (it is rebuilt once they have been left alone again)
   brick_valid_ = false;
   brick_stable_calls_ = 0;
@@ -436,26 +453,44 @@ void Network::deserialize_params(const Json& j, hipStream_t s)
 void Network::inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                         const uint32_t* d_dest) const
 {
+  if (!fast_path()) {
+    launch_generic(0, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_coords, d_out, nullptr, n, d_n, n_max, s, d_dest, 0);
+    return;
+  }
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
-  launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
+  GridDevice grid = grid_;
+  grid.n_levels = n_active_levels();   // masked levels encode to zero, like the padding
+  launch_fused(0, grid, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
                mlp_packed_.ptr, lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest, 0, image);
 }
 
 void Network::inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
                               uint32_t sharers) const
 {
+  if (!fast_path()) {
+    launch_generic(0, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_records, d_out, nullptr, 0, d_n, n_max, s, nullptr, out_stride);
+    return;
+  }
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
-  launch_fused(0, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
+  GridDevice grid = grid_;
+  grid.n_levels = n_active_levels();
+  launch_fused(0, grid, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
                mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image, sharers);
 }
 
 void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const
 {
+  if (!fast_path()) {
+    launch_generic(1, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_coords, nullptr, d_features, n, nullptr, n, s, nullptr, 0);
+    return;
+  }
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
-  launch_fused(1, grid_, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
+  GridDevice grid = grid_;
+  grid.n_levels = n_active_levels();
+  launch_fused(1, grid, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
                mlp_packed_.ptr, lds_halves_, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s, nullptr, 0, image);
 }
 

@@ -57,20 +57,20 @@ struct Pcg32 {
 
 // EXTERNAL tcnn init: MLP Xavier-uniform per weight matrix, grid uniform(-1e-4, 1e-4)
 __global__ void init_params_kernel(OptState* __restrict__ state, half_t* __restrict__ params, size_t n_mlp, size_t n_total,
-                                   uint32_t in_width, uint32_t n_hidden_matmuls, uint64_t seed)
+                                   uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t width, uint64_t seed)
 {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t e0 = t * 4;
   if (e0 >= n_total) return;
   Pcg32 rng(seed);
   rng.advance(e0);
-  const size_t first = (size_t)kWidth * in_width, hidden_end = first + (size_t)n_hidden_matmuls * kWidth * kWidth;
+  const size_t first = (size_t)width * in_width, hidden_end = first + (size_t)n_hidden_matmuls * width * width;
   for (size_t e = e0; e < e0 + 4 && e < n_total; ++e) {
     const float u = rng.next_float();
     float scale;
-    if (e < first) scale = sqrtf(6.0f / (float)(in_width + kWidth));
-    else if (e < hidden_end) scale = sqrtf(6.0f / (float)(kWidth + kWidth));
-    else if (e < n_mlp) scale = sqrtf(6.0f / (float)(kWidth + 16));
+    if (e < first) scale = sqrtf(6.0f / (float)(in_width + width));
+    else if (e < hidden_end) scale = sqrtf(6.0f / (float)(width + width));
+    else if (e < n_mlp) scale = sqrtf(6.0f / (float)(width + 16));
     else scale = 1e-4f;
     const float v = u * (2.0f * scale) - scale;
     state[e] = OptState{v, 0.0f, 0.0f, 0u};
@@ -79,11 +79,11 @@ __global__ void init_params_kernel(OptState* __restrict__ state, half_t* __restr
 }
 
 void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
-                        uint32_t n_hidden_matmuls, uint64_t seed, hipStream_t s)
+                        uint32_t n_hidden_matmuls, uint32_t width, uint64_t seed, hipStream_t s)
 {
   const size_t threads = (n_total + 3) / 4;
   init_params_kernel<<<div_round_up(threads, 256), 256, 0, s>>>(state, (half_t*)params, n_mlp, n_total, in_width,
-                                                                n_hidden_matmuls, seed);
+                                                                n_hidden_matmuls, width, seed);
   VNR_HIP_CHECK(hipGetLastError());
 }
 
@@ -550,6 +550,9 @@ void Network::ensure_training_state(hipStream_t s)
 void Network::forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s, GradExchange* exchange)
 {
   if (!valid()) throw std::runtime_error("network is not configured");
+  if (!fast_path() || n_active_levels() != cfg_.n_levels)
+    throw std::runtime_error("training is implemented for FullyFusedMLP n_neurons 64 with Linear or Smoothstep interpolation, quantize_threshold 0 and no "
+                             "max_level (the reference's training configuration, example-model.json); this model can be loaded, evaluated and rendered");
   if (batch == 0) return;
   TrainScratch& ts = scratch_of(this);
   const uint32_t nh = n_hidden_matmuls();

@@ -26,7 +26,8 @@ def build(force=False):
 class GridConfig(C.Structure):
     _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32),
                 ("log2_hashmap_size", C.c_uint32), ("base_resolution", C.c_uint32),
-                ("per_level_scale", C.c_float), ("interpolation", C.c_uint32)]
+                ("per_level_scale", C.c_float), ("interpolation", C.c_uint32),
+                ("quantize_threshold", C.c_float), ("max_level", C.c_float)]
 
 
 class GridLayout(C.Structure):
@@ -106,9 +107,10 @@ def f32_to_f16_bits(x):
 
 # --------------------------------------------------------------------------- grid
 def grid_config(n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale=2.0,
-                interpolation=0):
+                interpolation=0, quantize_threshold=0.0, max_level=1000.0):
+    """interpolation: 0 Linear, 1 Smoothstep, 2 Nearest"""
     return GridConfig(n_levels, n_features, log2_hashmap_size, base_resolution,
-                      float(per_level_scale), interpolation)
+                      float(per_level_scale), interpolation, float(quantize_threshold), float(max_level))
 
 
 def grid_layout(cfg):

@@ -153,6 +153,10 @@ static void encode_one_level(const vnro_grid_config* cfg, const vnro_grid_layout
                              uint16_t* out /* [F] */)
 {
   const uint32_t F = cfg->n_features;
+  if ((float)level >= cfg->max_level + 1e-3f) {                           /* :17-35 */
+    for (uint32_t f = 0; f < F; ++f) out[f] = 0;
+    return;
+  }
   const uint16_t* grid = table + (size_t)lay->offsets[level] * F;         /* :38 */
   const uint32_t hashmap_size = lay->offsets[level + 1] - lay->offsets[level]; /* :39 */
   const float scale = lay->scale[level];
@@ -171,6 +175,12 @@ static void encode_one_level(const vnro_grid_config* cfg, const vnro_grid_layout
     pos[d] = p;
   }
 
+  if (cfg->interpolation == 2) {                 /* Nearest (:73-94): the entry of the lower corner, no quantisation, no blend */
+    const uint32_t index = vnro_grid_index(hashmap_size, res, pos_grid) * F;
+    for (uint32_t f = 0; f < F; ++f) out[f] = grid[index + f];
+    return;
+  }
+
   uint16_t result[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* PerLevelVec result = {} (:96) */
   for (uint32_t idx = 0; idx < 8; ++idx) {       /* :99-123 */
     float weight = 1.0f;
@@ -186,7 +196,8 @@ static void encode_one_level(const vnro_grid_config* cfg, const vnro_grid_layout
     }
     const uint32_t index = vnro_grid_index(hashmap_size, res, pl) * F;
     for (uint32_t f = 0; f < F; ++f) {
-      const float data = vnro_f16_to_f32(grid[index + f]);
+      float data = vnro_f16_to_f32(grid[index + f]);
+      if (fabsf(data) < cfg->quantize_threshold) data = 0.0f;             /* :120 */
       /* result[f] += (T)(weight * data): fp16 accumulate (:119-121) */
       result[f] = h_add(result[f], vnro_f32_to_f16(weight * data));
     }

@@ -40,7 +40,9 @@ typedef struct {
   uint32_t log2_hashmap_size;
   uint32_t base_resolution;
   float    per_level_scale;   /* tcnn default 2.0 */
-  uint32_t interpolation;     /* 0 = Linear (default), 1 = Smoothstep */
+  uint32_t interpolation;     /* 0 = Linear (default), 1 = Smoothstep, 2 = Nearest (tcnn_impl_decoder.cu:73-94) */
+  float    quantize_threshold;/* corner values below it in magnitude count as 0 (:120); EXTERNAL tcnn default 0 */
+  float    max_level;         /* levels l >= max_level + 1e-3 encode to 0 (:17); EXTERNAL tcnn default 1000 (no masking) */
 } vnro_grid_config;
 
 #define VNRO_MAX_LEVELS 32

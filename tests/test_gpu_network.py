@@ -198,3 +198,87 @@ def test_free_temporary_gpu_memory_drops_the_caches(oracle):
     for _ in range(30):
         api.neural_inference(vol, coords[:64])
     assert api.neural_brick_image(vol)["in_use"]          # and it comes back
+
+
+# ------------------------------------------------------------------------------------------------ every shape the reference accepts
+# (L, F, log2T, base, pls, H, n_neurons, interpolation, quantize_threshold, max_level)
+ACCEPTED = [
+    (8, 2, 12, 4, None, 2, 16, "Linear", 0.0, None),       # FullyFusedMLP WIDTH 16 / 32 / 128 (tcnn_impl.cu:315-347)
+    (8, 2, 12, 4, None, 3, 32, "Linear", 0.0, None),
+    (6, 4, 12, 4, None, 2, 128, "Smoothstep", 0.0, None),
+    (8, 8, 14, 8, None, 2, 128, "Linear", 0.0, None),
+    (8, 2, 12, 4, None, 2, 64, "Nearest", 0.0, None),      # tcnn_impl_decoder.cu:73-94
+    (5, 1, 10, 3, None, 2, 32, "Nearest", 0.0, None),
+    (8, 2, 12, 4, None, 2, 64, "Linear", 0.02, None),      # quantize_threshold (:120): with random fp16 parameters ~ a fifth of the entries are below it
+    (8, 4, 12, 4, None, 2, 64, "Smoothstep", 0.05, None),
+    (8, 2, 12, 4, None, 2, 64, "Linear", 0.0, 5.0),        # max_level (:17): levels l >= 5.001, i.e. 6 and 7, encode to zero; on the MFMA kernels
+    (8, 2, 12, 4, None, 2, 64, "Linear", 0.0, 2.5),        # a fractional bound: levels >= 2.501, i.e. 3 ..
+    (8, 2, 12, 4, None, 2, 16, "Nearest", 0.0, 4.0),
+]
+INTERP = {"Linear": 0, "Smoothstep": 1, "Nearest": 2}
+
+
+@pytest.mark.parametrize("case", ACCEPTED)
+def test_models_the_reference_accepts_load_and_evaluate(oracle, case):
+    """encode bit-exact, output within 2^-8 of the oracle for the model shapes outside the MFMA kernels' configuration; they are
+    evaluated by the generic kernel (max_level alone stays on the MFMA kernels).  Training such a model fails with an explanation."""
+    L, F, log2T, base, pls, H, W, interp, qt, max_level = case
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base, n_hidden_layers=H, per_level_scale=pls)
+    cfg["encoding"]["interpolation"] = interp
+    cfg["network"]["n_neurons"] = W
+    if qt:
+        cfg["encoding"]["quantize_threshold"] = qt
+    if max_level is not None:
+        cfg["encoding"]["max_level"] = max_level
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(16))
+    vol = api.vnrCreateNeuralVolume(cfg, sv)
+    info = api.neural_info(vol)
+    assert info["n_neurons"] == W
+    ocfg = oracle.grid_config(L, F, log2T, base, 2.0 if pls is None else pls, INTERP[interp], qt, 1000.0 if max_level is None else max_level)
+    assert info["n_params"] == oracle.n_params(ocfg, W, H)
+    n_mlp = oracle.mlp_n_params(info["padded_width"], W, H - 1)
+    params = syn.random_params(info["n_params"], n_mlp, seed=11)
+    api.neural_set_params_fp16(vol, params)
+    coords = coords_for(2049, 12)
+    enc = api.neural_encode(vol, coords)
+    want_enc = oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords)
+    assert np.array_equal(enc.view(np.uint16), want_enc)
+    if max_level is not None:   # the masked levels really are zero, the others are not
+        first_masked = int(np.ceil(max_level + 1e-3 - 1e-9))
+        assert not enc[:, first_masked * F:].any() and enc[:, :first_masked * F].any()
+    got = api.neural_inference(vol, coords)
+    want = oracle.network_inference(ocfg, W, H, params.view(np.uint16), coords)
+    assert np.isfinite(got).all() and np.abs(want).max() > 0.01
+    assert np.abs(got - want).max() <= TOL_ABS * max(1.0, np.abs(want).max())
+    if W != 64 or interp == "Nearest" or qt or max_level is not None:
+        with pytest.raises(api.VnrAmdError, match="training is implemented for"):
+            api.vnrNeuralVolumeTrain(vol, 1, True)
+
+
+def test_a_rendered_frame_of_a_generic_model_equals_the_oracle(oracle):
+    """the renderer's sample queue goes through the same dispatch: a 32-neuron Nearest model renders"""
+    cfg = syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
+    cfg["network"]["n_neurons"] = 32
+    vol = syn.analytic_volume(32)
+    sv = api.vnrCreateSimpleVolume(vol)
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+    info = api.neural_info(nv)
+    n_mlp = oracle.mlp_n_params(info["padded_width"], 32, 1)
+    params = syn.random_params(info["n_params"], n_mlp, seed=13)
+    api.neural_set_params_fp16(nv, params)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas); api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = syn.oblique_camera((32, 32, 32))
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    ren = api.vnrCreateRenderer(nv)
+    api.vnrRendererSetTransferFunction(ren, tfn); api.vnrRendererSetCamera(ren, camera); api.vnrRendererSetFramebufferSize(ren, (64, 48))
+    api.vnrRender(ren)
+    img = api.vnrRendererMapFrame(ren).copy()
+    ocfg = oracle.grid_config(4, 2, 12, 4)
+    mo = api.volume_macrocell(nv)["max_opacity"]
+    sc = oracle.SceneHolder(64, 48, (32, 32, 32), oracle.TfnHolder(colors, alphas), mo, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    ref, _, _ = oracle.render_streaming(sc, lambda c: oracle.network_inference(ocfg, 32, 2, params.view(np.uint16), c))
+    mse = float(((img - ref) ** 2).mean())
+    assert img[..., 3].max() > 0.005 and 10 * np.log10(1.0 / max(mse, 1e-20)) > 40.0

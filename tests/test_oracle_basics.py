@@ -231,3 +231,40 @@ def test_mssim_known_answers_and_explicit_loop(oracle):
                 acc.append((2 * ux * uy + c1) * (2 * vxy + c2) / ((ux * ux + uy * uy + c1) * (vx + vy + c2)))
     assert oracle.mssim(b, a) == pytest.approx(np.mean(acc), abs=1e-10)     # mssim(pred, ref); SSIM is symmetric
     assert oracle.mssim(b, a) < 0.99
+
+
+def test_nearest_quantize_and_max_level_hand_cases(oracle):
+    """the three encoding options of tcnn_impl_decoder.cu the oracle restates beyond Linear / Smoothstep, on the index-ramp table of the
+    hand case above (L = 2 here: level 0 has 8 entries, table[e] = e / -e; level 1: base 2 x scale 2 - 1 = 3 -> res 4, 64 entries).
+    Nearest (:73-94): the entry of the LOWER corner, no blend: x = (0.25, 0.5, 0.5) -> cell (0, 1, 1) -> index 6.
+    quantize_threshold (:120): a corner value below it in magnitude counts as 0 in the blend (and Nearest ignores it).
+    max_level (:17): levels l >= max_level + 1e-3 encode to zero."""
+    x = np.array([[0.25, 0.5, 0.5]], np.float32)
+
+    def table_for(cfg):
+        lay = oracle.grid_layout(cfg)
+        t = np.zeros(lay["total_entries"] * 2, np.float16)
+        t[0:16:2] = np.arange(8); t[1:16:2] = -np.arange(8)
+        t[16::2] = 0.5; t[17::2] = -0.25
+        return t
+
+    near = oracle.grid_config(2, 2, 8, 2, interpolation=2)
+    out = oracle.grid_encode(near, table_for(near).view(np.uint16), x).view(np.float16)
+    assert out[0, 0] == 6 and out[0, 1] == -6 and out[0, 2] == np.float16(0.5) and out[0, 3] == np.float16(-0.25)
+    # Linear at the same point blends entries 6 and 7 (0.25 / 0.75); a threshold of 6.5 removes entry 6 from the blend
+    lin = oracle.grid_config(2, 2, 8, 2)
+    q = oracle.grid_config(2, 2, 8, 2, quantize_threshold=6.5)
+    assert oracle.grid_encode(lin, table_for(lin).view(np.uint16), x).view(np.float16)[0, 0] == np.float16(6.75)
+    out = oracle.grid_encode(q, table_for(q).view(np.uint16), x).view(np.float16)
+    assert out[0, 0] == np.float16(0.75 * 7) and out[0, 1] == np.float16(-0.75 * 7)
+    assert out[0, 2] == 0 and out[0, 3] == 0          # level 1: every value (0.5, -0.25) is below the threshold
+    nq = oracle.grid_config(2, 2, 8, 2, interpolation=2, quantize_threshold=6.5)
+    assert oracle.grid_encode(nq, table_for(nq).view(np.uint16), x).view(np.float16)[0, 0] == 6   # Nearest does not quantise
+    # max_level: 1.0 masks level 1 only (1 >= 1.001 is false for level 0 ... and true for level 1? 1 >= 1.001 is FALSE: level 1 stays)
+    m1 = oracle.grid_config(2, 2, 8, 2, max_level=1.0)
+    assert oracle.grid_encode(m1, table_for(m1).view(np.uint16), x).view(np.float16)[0, 2] == np.float16(0.5)
+    m0 = oracle.grid_config(2, 2, 8, 2, max_level=0.5)    # 1 >= 0.501: level 1 is masked, level 0 (0 >= 0.501 false) is not
+    out = oracle.grid_encode(m0, table_for(m0).view(np.uint16), x).view(np.float16)
+    assert out[0, 0] == np.float16(6.75) and out[0, 2] == 0 and out[0, 3] == 0
+    mz = oracle.grid_config(2, 2, 8, 2, max_level=-1.0)   # everything masked
+    assert not oracle.grid_encode(mz, table_for(mz).view(np.uint16), x).any()

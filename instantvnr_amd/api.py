@@ -411,15 +411,32 @@ def vnrVolumeGetValueRange(v):
 
 
 # ------------------------------------------------------------------------------------------------ tfn (api.h:154-162)
-def vnrCreateTransferFunction(scene=None):
+def vnrCreateTransferFunction(scene=None, table=None):
     """api.h:154-155.  vnrCreateTransferFunction(scene) decodes the scene's transfer function with OVR's tfn module
-    (tfn::loadTransferFunction, serializer.cpp:192-193), which is not part of the reference tree: unsupported here; the value
-    range of the scene is available through scene_value_range()."""
-    if scene is not None:
+    (tfn::loadTransferFunction, serializer.cpp:192-193), which is not part of the reference tree.  `table` is what that module
+    yields (tfn::TransferFunctionCore::data(): resolution x RGBA): given it, this does the rest of create_scene_vidi__tfn
+    (serializer.cpp:195-256): colours = rgb, alphas at i / (resolution - 1), end alphas below 0.01 forced to zero, value range from
+    the scene.  A scene without a table is refused with an explanation rather than rendered with an invented table."""
+    if scene is not None and table is None:
         raise VnrAmdError("vnrCreateTransferFunction(scene): the transfer-function table of a scene is decoded by OVR's tfn module "
-                          "(tfn::loadTransferFunction), which is outside the reference tree; set colours / alphas explicitly "
-                          "(the scene's value range: scene_value_range)")
-    return vnrTransferFunction(lib().vnrAmdCreateTransferFunction())
+                          "(tfn::loadTransferFunction), which is outside the reference tree; pass the decoded RGBA table (table=) or "
+                          "set colours / alphas explicitly (the scene's value range: scene_value_range)")
+    t = vnrTransferFunction(lib().vnrAmdCreateTransferFunction())
+    if table is not None:
+        rgba = np.asarray(table, dtype=np.float32).reshape(-1, 4)
+        if rgba.shape[0] < 2:
+            raise VnrAmdError("vnrCreateTransferFunction: a transfer-function table needs at least two RGBA entries")
+        alpha = np.stack([np.arange(rgba.shape[0], dtype=np.float32) / np.float32(rgba.shape[0] - 1), rgba[:, 3]], axis=1)
+        for i in (0, -1):
+            if alpha[i, 1] < 0.01:
+                alpha[i, 1] = 0.0
+        vnrTransferFunctionSetColor(t, rgba[:, :3])
+        vnrTransferFunctionSetAlpha(t, alpha)
+        if scene is not None:
+            rng = scene_value_range(scene)
+            if rng is not None:
+                vnrTransferFunctionSetValueRange(t, rng)
+    return t
 
 
 def vnrTransferFunctionSetColor(t, colors):

@@ -176,3 +176,112 @@ def test_vnr_cmd_train_command_line(tmp_path):
                            "--quiet"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert out2.returncode == 0, out2.stderr[-2000:]
     assert float(dict(l.strip().split("=") for l in out2.stdout.splitlines() if "=" in l)["PSNR"]) > 30.0
+
+
+def test_transfer_function_from_a_decoded_table():
+    """the part of create_scene_vidi__tfn after OVR's tfn::loadTransferFunction (serializer.cpp:195-256): rgb -> colours, alpha at
+    i / (resolution - 1), the end alphas below 0.01 forced to zero, the scene's value range"""
+    sc = vidi_scene(["a.raw"], (8, 8, 8), "UNSIGNED_BYTE", volume_extra={"scalarMappingRange": {"minimum": 0.25, "maximum": 0.5}})
+    table = np.array([[1, 0, 0, 0.005], [0, 1, 0, 0.5], [0, 0, 1, 0.2], [1, 1, 1, 0.02]], np.float32)
+    t = api.vnrCreateTransferFunction(sc, table=table)
+    from instantvnr_amd._lib import lib
+    import ctypes as C
+    nc, na = C.c_int(), C.c_int()
+    assert lib().vnrAmdTransferFunctionGetSizes(t.h, C.byref(nc), C.byref(na)) == 0 and (nc.value, na.value) == (4, 4)
+    rgb, xy, rng = np.zeros((4, 3), np.float32), np.zeros((4, 2), np.float32), np.zeros(2, np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib().vnrAmdTransferFunctionGet(t.h, fp(rgb), fp(xy), fp(rng)) == 0
+    assert np.array_equal(rgb, table[:, :3])
+    assert np.array_equal(xy[:, 0], np.array([0, 1, 2, 3], np.float32) / np.float32(3))
+    assert np.array_equal(xy[:, 1], np.array([0.0, 0.5, 0.2, 0.02], np.float32))
+    assert tuple(rng) == (0.25 * 255, 0.5 * 255)
+    with pytest.raises(api.VnrAmdError, match="tfn::loadTransferFunction"):
+        api.vnrCreateTransferFunction(sc)
+    with pytest.raises(api.VnrAmdError, match="at least two"):
+        api.vnrCreateTransferFunction(sc, table=table[:1])
+
+
+def _read_png_rgba(path):
+    import struct
+    import zlib
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    o, w, h, data = 8, 0, 0, b""
+    while o < len(b):
+        n, tag = struct.unpack(">I", b[o:o + 4])[0], b[o + 4:o + 8]
+        body = b[o + 8:o + 8 + n]
+        assert zlib.crc32(tag + body) & 0xFFFFFFFF == struct.unpack(">I", b[o + 8 + n:o + 12 + n])[0]
+        if tag == b"IHDR":
+            w, h = struct.unpack(">II", body[:8])
+        if tag == b"IDAT":
+            data += body
+        o += 12 + n
+    raw = np.frombuffer(zlib.decompress(data), np.uint8).reshape(h, 1 + 4 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+@pytest.mark.gpu
+def test_vnr_cmd_render_command_line(tmp_path):
+    """tools/vnr_cmd_render.py takes the reference's flags (apps/batch_renderer.cpp:62-133): 768 x 768, 5 warm-up frames, the log, the
+    screenshot (the frame the API renders, flipped and quantised like saveJPG) and the Summary block; for a scene and for params.json"""
+    import os
+    import subprocess
+    import sys
+    from instantvnr_amd import synthetic as syn
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "vnr_cmd_render.py")
+    vol = syn.analytic_volume(48)
+    vol.astype(np.float32).tofile(tmp_path / "v.raw")
+    scene = vidi_scene([str(tmp_path / "v.raw")], (48, 48, 48), "FLOAT")
+    scene["view"]["camera"] = {"eye": {"x": 100.0, "y": 90.0, "z": -60.0}, "center": {"x": 24.0, "y": 24.0, "z": 24.0},
+                               "up": {"x": 0.0, "y": 1.0, "z": 0.0}, "fovy": 40.0}
+    (tmp_path / "scene.json").write_text(json.dumps(scene))
+    x = np.linspace(0, 1, 64, dtype=np.float32)
+    table = np.stack([x, 1 - x, 0.5 + 0.5 * np.sin(6 * x), np.clip(1.5 * x - 0.2, 0, 1)], axis=1).astype(np.float32)
+    np.save(tmp_path / "table.npy", table)
+    base = [sys.executable, tool, "--tfn", str(tmp_path / "scene.json"), "--num-frames", "7", "--sampling-rate", "1.5"]
+    # without the decoded table the tool stops and says why
+    out = subprocess.run(base + ["--simple-volume", str(tmp_path / "scene.json")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "tfn::loadTransferFunction" in out.stderr
+    # the two volume flags exclude each other; one is required
+    out = subprocess.run(base + ["--tfn-table", str(tmp_path / "table.npy")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "required" in out.stderr
+    out = subprocess.run(base + ["--tfn-table", str(tmp_path / "table.npy"), "--simple-volume", str(tmp_path / "scene.json"), "--rendering-mode", "5",
+                                 "--exp", "gt"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    i = lines.index("Summary: gt")
+    assert lines[i + 1] == f"\tvolume: {tmp_path / 'scene.json'}" and lines[i + 3].startswith("\t   fps: ") and float(lines[i + 3].split(":")[1]) > 1.0
+    assert lines[i + 5] == "\tsampling rate: 1.5" and lines[i + 6] == "\tcamera: (76,66,-84)" and lines[i + 7].strip() == "(0,0,0)"
+    log = (tmp_path / "gt.csv").read_text().splitlines()
+    assert log[0] == "#,frame time,fps" and len(log) == 8 and log[7].startswith("6.0,")
+    shot = _read_png_rgba(tmp_path / "gt-screenshot.png")
+    # the same frame through the API: 5 + 7 frames accumulate (mode 5 jitters per frame)
+    sv = api.vnrCreateSimpleVolume(str(tmp_path / "scene.json"), "GPU")
+    cam = api.vnrCreateCamera(str(tmp_path / "scene.json"))
+    tfn = api.vnrCreateTransferFunction(str(tmp_path / "scene.json"), table=table)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    r = api.vnrCreateRenderer(sv)
+    api.vnrRendererSetTransferFunction(r, tfn)
+    api.vnrRendererSetCamera(r, cam)
+    api.vnrRendererSetFramebufferSize(r, (768, 768))
+    api.vnrRendererSetMode(r, 5)
+    api.vnrRendererSetVolumeSamplingRate(r, 1.5)
+    for _ in range(12):
+        api.vnrRender(r)
+    frame = api.vnrRendererMapFrame(r).copy()
+    want = (np.float32(255.99) * np.clip(frame, 0, 1)).astype(np.uint32).astype(np.uint8)[::-1]
+    assert shot.shape == (768, 768, 4) and (shot[..., 3] > 0).mean() > 0.1
+    assert np.array_equal(shot, want)
+    # a neural volume from params.json
+    cfg = syn.model_config(n_levels=4, n_features=4, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
+    nv = api.vnrCreateNeuralVolume(cfg, sv, True)
+    api.vnrNeuralVolumeTrain(nv, 200, True)
+    api.vnrNeuralVolumeSerializeParams(nv, str(tmp_path / "params.json"))
+    out = subprocess.run(base + ["--tfn-table", str(tmp_path / "table.npy"), "--neural-volume", str(tmp_path / "params.json"), "--rendering-mode", "5",
+                                 "--exp", "nn"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    shot_nn = _read_png_rgba(tmp_path / "nn-screenshot.png")
+    err = shot_nn[..., :3].astype(np.float32) - shot[..., :3].astype(np.float32)
+    assert 10 * np.log10(255.0 ** 2 / float((err ** 2).mean())) > 20.0    # 200 steps of a 4-level model: the same picture, roughly

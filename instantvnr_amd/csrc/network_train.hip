@@ -314,7 +314,8 @@ struct WGradArgs {
   const half_t* d_all;     // [(nh+1)][n][64]
   const half_t* dy;        // [n]
   float* grads;            // tcnn-order fp32 gradient blob
-  uint32_t n, nh, in_width;
+  float* slab;             // MFMA kernel: [blocks][n_mlp] partial sums
+  uint32_t n, nh, in_width, n_mlp;
 };
 
 constexpr int kWgChunk = 128;
@@ -386,6 +387,177 @@ __global__ void __launch_bounds__(256) weight_grad_kernel(const WGradArgs args, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradients (MFMA)
+// The same sums on the matrix cores: dW^T is a [64 x in] product whose reduction dimension is the BATCH, so both operands are needed
+// transposed ([neuron][sample] with 8 consecutive samples per lane) while the forward / backward kernels leave them row-major
+// [sample][64].  A block stages 64 samples of d and x row-major in LDS (rows padded to a stride of 64 + 8 halves: lanes r = 0..31 of
+// a transposed read touch 16 consecutive dwords, the two lane halves rows 8 apart = 32 banks apart); every wave owns 32 x 32
+// tiles of the product (not a share of the samples: summing the waves' partial tiles with ds_add_f32 took 12 us per block, four
+// times the products) and runs the stage's four k-steps of v_mfma_f32_32x32x16_f16 on them; all loads of the block's 256 samples
+// are issued before the first product; the tiles leave as plain stores into the block's row of a slab [blocks][n_mlp], which
+// weight_grad_reduce_kernel sums.  fp16 products are exact in the fp32 accumulator as in the VALU kernel; only the order of the sums differs.
+constexpr int kWgStage = 64;           // samples per stage
+constexpr int kWgStages = 4;           // stages per block: a block owns 256 samples and issues ALL their loads before the first product
+constexpr int kWgStride = 64 + 8;      // halves per staged row of d (and of x when the input is 64 wide)
+
+template <int NT>  // 32-column tiles of the input: in_width padded to 32 * NT
+__global__ void __launch_bounds__(256) weight_grad_mfma_kernel(const WGradArgs args, uint32_t layer_lo)
+{
+  constexpr int XS = 32 * NT + 8;      // halves per staged row of x
+  constexpr int XC = 4 * NT;           // uint4 per row of x
+  constexpr int XQ = (kWgStage * XC + 255) / 256;
+  __shared__ __attribute__((aligned(16))) half_t sd[kWgStage * kWgStride];
+  __shared__ __attribute__((aligned(16))) half_t sx[kWgStage * XS];
+  __shared__ float red[32 * 64];   // last layer: [32 sample lanes][64]; two-tile form: [2 tiles][16 registers][64 lanes]
+  const uint32_t layer = layer_lo + blockIdx.y;
+  const uint32_t n = args.n, nh = args.nh;
+  const uint32_t blk0 = blockIdx.x * (uint32_t)(kWgStage * kWgStages);
+  if (blk0 >= n) return;
+  const uint32_t blk_end = min(n, blk0 + (uint32_t)(kWgStage * kWgStages));
+  float* slab = args.slab + (size_t)blockIdx.x * args.n_mlp;   // this block's partial sums, tcnn order
+
+  if (layer == nh + 1) {
+    // last layer: dWl[0][k] = sum_b dy[b] * a_nh[b][k].  Thread = (8 neurons, one of 32 sample lanes): every load of the block's
+    // 256 rows is in flight at once (one dependent load per sample was 64 latencies in a row: the longest block of the launch)
+    const uint32_t c = threadIdx.x & 7u, sr = threadIdx.x >> 3;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    half8_t av[kWgStages * 2];
+    float gv[kWgStages * 2];
+#pragma unroll
+    for (int q = 0; q < kWgStages * 2; ++q) {
+      const uint32_t b = blk0 + sr + 32u * q;
+      const bool ok = b < blk_end;
+      av[q] = ok ? *(const half8_t*)(args.acts + ((size_t)nh * n + b) * 64 + c * 8) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      gv[q] = ok ? (float)args.dy[b] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < kWgStages * 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(gv[q], (float)av[q][j], acc[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[sr * 64 + c * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.0f;
+      for (int q = 0; q < 32; ++q) t += red[q * 64 + threadIdx.x];
+      slab[(size_t)kWidth * args.in_width + (size_t)nh * 4096 + threadIdx.x] = t;
+    }
+    return;
+  }
+  const uint32_t in_w = layer == 0 ? args.in_width : 64u;   // a multiple of 8 (rows are read as uint4)
+  const uint32_t xc = in_w / 8;
+  const half_t* dsrc = args.d_all + (size_t)layer * n * 64;
+  const half_t* xsrc = layer == 0 ? args.features : args.acts + (size_t)(layer - 1) * n * 64;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31u;
+  constexpr int T = 2 * NT;                    // 32 x 32 tiles of the product [64 out][32 NT in]
+  constexpr int TW = T >= 4 ? T / 4 : 1;       // tiles per wave (same 32 output rows, TW column tiles)
+  constexpr int KS = T >= 4 ? 4 : 2;           // k-steps of a stage per wave: with two tiles the wave pairs split the stage
+  const uint32_t t0 = T >= 4 ? wave * TW : (wave & 1u);
+  const uint32_t m = t0 / NT, nt0 = t0 % NT;
+  const uint32_t kbase = T >= 4 ? 0u : 2u * (wave >> 1);
+
+  uint4_t rd[kWgStages][2], rx[kWgStages][XQ];
+#pragma unroll
+  for (int st = 0; st < kWgStages; ++st) {
+    const uint32_t b0 = blk0 + (uint32_t)(st * kWgStage);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t e = threadIdx.x + 256u * q, b = b0 + (e >> 3);
+      rd[st][q] = b < blk_end ? *(const uint4_t*)(dsrc + (size_t)b * 64 + (e & 7u) * 8) : uint4_t{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      const uint32_t e = threadIdx.x + 256u * q, row = e / XC, c = e % XC, b = b0 + row;
+      rx[st][q] = (row < (uint32_t)kWgStage && c < xc && b < blk_end) ? *(const uint4_t*)(xsrc + (size_t)b * in_w + c * 8) : uint4_t{0, 0, 0, 0};
+    }
+  }
+
+  f32x16 acc[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+
+#pragma unroll
+  for (int st = 0; st < kWgStages; ++st) {
+    if (st) __syncthreads();   // the previous stage has been consumed
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t e = threadIdx.x + 256u * q;
+      *(uint4_t*)(sd + (e >> 3) * kWgStride + (e & 7u) * 8) = rd[st][q];
+    }
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      const uint32_t e = threadIdx.x + 256u * q, row = e / XC, c = e % XC;
+      if (row < (uint32_t)kWgStage) *(uint4_t*)(sx + row * XS + c * 8) = rx[st][q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint32_t k0 = 16u * (kbase + (uint32_t)ks) + 8u * h;
+      half8_t a, bx[TW];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a[j] = sd[(k0 + j) * kWgStride + m * 32 + r];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) bx[t][j] = sx[(k0 + j) * XS + (nt0 + t) * 32 + r];
+      }
+#pragma unroll
+      for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[t], acc[t], 0, 0, 0);
+    }
+  }
+  if (T < 4) {   // two tiles: waves 2 and 3 hand their half of the samples to waves 0 and 1 (plain LDS traffic, 4 KB each)
+    __syncthreads();
+    if (wave >= 2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[((wave & 1u) * 16 + e) * 64 + lane] = acc[0][e];
+    }
+    __syncthreads();
+    if (wave >= 2) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][e] += red[((wave & 1u) * 16 + e) * 64 + lane];
+  }
+  // element (out, in) of tile (m, nt) sits in lane (in = 32 nt + r), register e with out = 32 m + 8 (e / 4) + 4 h + e % 4
+  float* g = slab + (layer == 0 ? 0 : (size_t)kWidth * args.in_width + (size_t)(layer - 1) * 4096);
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    const uint32_t col = 32u * (nt0 + t) + r;
+    if (col < in_w) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t out = 32u * m + 8u * (e >> 2) + 4u * h + (e & 3);
+        g[(size_t)out * in_w + col] = acc[t][e];
+      }
+    }
+  }
+}
+
+// grads[p] += sum over the blocks' partial sums, in block order: the MLP's gradient no longer depends on the order in which atomics
+// arrive.  (Float atomics of every block into the same 64 rows run at a fourteenth of the atomic rate, MI355X_MICROARCH.md "Global
+// float atomics", contention row: 128 blocks x 16 KB per matrix took longer than the products.)
+__global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const float* __restrict__ slab, uint32_t n_blocks, uint32_t n_mlp, float* __restrict__ grads)
+{
+  // 64 parameters x 4 interleaved groups of slab rows per block, 16 loads in flight per thread: the sum is short, its loads' latency is all it costs
+  __shared__ float part[4][64];
+  const uint32_t tx = threadIdx.x & 63u, g = threadIdx.x >> 6;
+  const uint32_t p = blockIdx.x * 64u + tx;
+  float acc = 0.0f;
+  if (p < n_mlp) {
+    uint32_t b = g;
+    for (; b + 60 < n_blocks; b += 64) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = slab[(size_t)(b + 4 * j) * n_mlp + p];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc += v[j];
+    }
+    for (; b < n_blocks; b += 4) acc += slab[(size_t)b * n_mlp + p];
+  }
+  part[g][tx] = acc;
+  __syncthreads();
+  if (g == 0 && p < n_mlp) grads[p] += (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+}
+
 // ------------------------------------------------------------------------------------------------ grid backward
 // EXTERNAL tcnn kernel_grid_backward: for every (sample, level): grad[idx*F+f] += w * dL/dfeature[f].
 template <int F>
@@ -419,16 +591,47 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
   }
 }
 
+// TIMING PROBE (VNR_AMD_GRID_BWD_PK=1, tools/dp_probe.py): the scatter with one packed fp16 atomic per pair of features into a
+// half-precision gradient array (what tcnn does for F > 1: grad_t = __half, atomicAdd(__half2)).  It writes fp16 pairs over the
+// fp32 gradient blob, so a step run with it trains on garbage: the switch exists to price the design, nothing else reads it.
+template <int F>
+__global__ void grid_backward_pk_probe_kernel(const GridDevice grid, const float* __restrict__ coords, const half_t* __restrict__ dfeat,
+                                              uint32_t n, uint32_t in_width, half_t* __restrict__ grid_grads, uint32_t level0)
+{
+  constexpr uint32_t P = (uint32_t)F / 2u;          // packed pairs per entry
+  constexpr uint32_t kLanesPerSample = 2u * P;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = t / kLanesPerSample, r = t % kLanesPerSample;
+  const uint32_t xb = r / P, f = 2u * (r % P);
+  if (i >= n) return;
+  const uint32_t level = level0 + blockIdx.y;
+  const LevelInfo lv = grid.levels[level];
+  const half2_t g2 = *(const half2_t*)(dfeat + (size_t)i * in_width + level * F + f);
+  const float g0 = (float)g2[0], g1 = (float)g2[1];
+  if (g0 == 0.0f && g1 == 0.0f) return;
+  const CornerSetup c = level_setup(lv, grid.interpolation, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
+  half_t* base = grid_grads + (size_t)lv.offset * F + f;
+#pragma unroll
+  for (int yz = 0; yz < 4; ++yz) {
+    const int corner = (int)xb | (yz << 1);
+    const uint32_t idx = level_index(lv, c.g[0] + xb, c.g[1] + (uint32_t)(yz & 1), c.g[2] + (uint32_t)(yz >> 1));
+    const float w = corner_weight(c, corner);
+    const half2_t v = {(half_t)(w * g0), (half_t)(w * g1)};
+    half_t* addr = base + (size_t)idx * F;
+    asm volatile("global_atomic_pk_add_f16 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ Adam
 // EXTERNAL tcnn adam_step (optimizers/adam.h): see header comment.  Also clears the gradient for the next step.
 // Measured split at C4 (70 M parameters, tools/adam_probe.py): the sweep over all gradients alone 0.15 ms, the ~10 M touched
 // parameters of a 65 536-sample batch 0.44 ms with master / m / v / step in four arrays.  Hence one 16-byte record per
 // parameter (OptState), and no zero written over a gradient that is already zero.
-__global__ void adam_kernel(size_t n_total, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float log2_beta1,
+__global__ void adam_kernel(size_t lo, size_t n_total, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float log2_beta1,
                             float log2_beta2, float epsilon, float l2_reg, OptState* __restrict__ state, half_t* __restrict__ params,
                             float* __restrict__ grads)
 {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // parameters [lo, n_total)
   if (i >= n_total) return;
   const float raw = grads[i];
   if (raw != 0.0f) grads[i] = 0.0f;
@@ -517,6 +720,7 @@ struct TrainScratch {  // per-Network extra buffers that do not need to live in 
   DeviceBuffer<uint16_t> dy{MemTag::Network};
   DeviceBuffer<uint16_t> d_all{MemTag::Network};
   DeviceBuffer<uint16_t> packedT{MemTag::Network};
+  DeviceBuffer<float> wgrad_slab{MemTag::Network};   // [blocks][n_mlp] partial weight gradients
   uint32_t loss_blocks = 0;
 };
 
@@ -613,15 +817,33 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
       const int v = e ? std::atoi(e) : 0;
       return v >= 1 && v <= 64 ? v : 0;
     }();
-    const uint32_t sub_chunks = forced ? (uint32_t)forced : std::min<uint32_t>(8u, std::max<uint32_t>(1u, (uint32_t)(batch / (128u * kWgChunk))));
-    const uint32_t nblk = div_round_up(batch, (uint64_t)kWgChunk * sub_chunks);
-    const dim3 g1(nblk, 1);
-    if (in_width_ <= 16) weight_grad_kernel<16><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
-    else if (in_width_ <= 32) weight_grad_kernel<32><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
-    else if (in_width_ <= 64) weight_grad_kernel<64><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
-    else weight_grad_kernel<128><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
-    const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
-    weight_grad_kernel<64><<<g2, 256, 0, s>>>(wa, 1, sub_chunks);
+    static const bool valu = [] { const char* e = std::getenv("VNR_AMD_WGRAD_VALU"); return e && e[0] == '1'; }();   // diagnostics: the VALU kernel
+    if (valu || in_width_ % 8 != 0 || in_width_ > 128) {
+      const uint32_t sub_chunks = forced ? (uint32_t)forced : std::min<uint32_t>(8u, std::max<uint32_t>(1u, (uint32_t)(batch / (128u * kWgChunk))));
+      const uint32_t nblk = div_round_up(batch, (uint64_t)kWgChunk * sub_chunks);
+      const dim3 g1(nblk, 1);
+      if (in_width_ <= 16) weight_grad_kernel<16><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
+      else if (in_width_ <= 32) weight_grad_kernel<32><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
+      else if (in_width_ <= 64) weight_grad_kernel<64><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
+      else weight_grad_kernel<128><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
+      const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
+      weight_grad_kernel<64><<<g2, 256, 0, s>>>(wa, 1, sub_chunks);
+    } else {
+      // MFMA kernel: a block per 256 samples and matrix
+      const uint32_t nblk = div_round_up(batch, (uint64_t)(kWgStage * kWgStages));
+      if (ts.wgrad_slab.count < (size_t)nblk * n_mlp_) {   // elements no block writes (padded rows of the last layer) stay zero
+        ts.wgrad_slab.resize((size_t)nblk * n_mlp_);
+        ts.wgrad_slab.zero(s);
+      }
+      wa.slab = ts.wgrad_slab.ptr; wa.n_mlp = (uint32_t)n_mlp_;
+      const dim3 g1(nblk, 1);
+      if (in_width_ <= 32) weight_grad_mfma_kernel<1><<<g1, 256, 0, s>>>(wa, 0);
+      else if (in_width_ <= 64) weight_grad_mfma_kernel<2><<<g1, 256, 0, s>>>(wa, 0);
+      else weight_grad_mfma_kernel<4><<<g1, 256, 0, s>>>(wa, 0);
+      const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
+      weight_grad_mfma_kernel<2><<<g2, 256, 0, s>>>(wa, 1);
+      weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, s>>>(ts.wgrad_slab.ptr, nblk, (uint32_t)n_mlp_, grads_.ptr);
+    }
   }
   profile_mark(3, s);
   if (exchange) exchange->range_ready(0, n_mlp_, s);   // the MLP's gradient travels while the grid backward runs
@@ -629,6 +851,12 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   auto grid_backward = [&](uint32_t l0, uint32_t l1) {
     const dim3 g(div_round_up((uint64_t)batch * cfg_.n_features * 2, 256), l1 - l0);  // one lane per (sample, x bit, feature)
     float* gg = grads_.ptr + n_mlp_;
+    static const bool pk_probe = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_PK"); return e && e[0] == '1'; }();
+    if (pk_probe && cfg_.n_features == 2) {
+      const dim3 gp(div_round_up((uint64_t)batch * 2, 256), l1 - l0);
+      grid_backward_pk_probe_kernel<2><<<gp, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, (half_t*)gg, l0);
+      return;
+    }
     switch (cfg_.n_features) {
     case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
     case 2: grid_backward_kernel<2><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
@@ -637,11 +865,19 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     }
   };
   if (!exchange) {
-    grid_backward(0, cfg_.n_levels);
+    // diagnostics (tools/train_probe.py): VNR_AMD_GRID_BWD_LEVELS="l0,l1" scatters levels [l0, l1) only, to price a level
+    static const std::pair<int, int> only = [] {
+      const char* e = std::getenv("VNR_AMD_GRID_BWD_LEVELS");
+      int a = -1, b = -1;
+      if (e && std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b > a) return std::make_pair(a, b);
+      return std::make_pair(-1, -1);
+    }();
+    if (only.first >= 0) grid_backward((uint32_t)only.first, std::min<uint32_t>((uint32_t)only.second, cfg_.n_levels));
+    else grid_backward(0, cfg_.n_levels);
   } else {
     // finest levels first (the large tables), in buckets of at least kBucket parameters: a bucket's exchange overlaps the
     // backward launches of the coarser levels and, afterwards, the optimizer update of the buckets before it
-    constexpr size_t kBucket = 16u << 20;   // 32 MB of fp16 per message: 4 grid buckets at C4 (10 at 4 M cost 0.03 ms more per step in launches on one rank)
+    const size_t kBucket = exchange->bucket_params();
     uint32_t l1 = cfg_.n_levels;
     while (l1 > 0) {
       uint32_t l0 = l1;
@@ -661,7 +897,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
 void Network::optimizer_step(float grad_scale, hipStream_t s)
 {
   if (grads_.count != n_params_) throw std::runtime_error("optimizer_step before forward_backward");
-  adam_kernel<<<div_round_up(n_params_, 256), 256, 0, s>>>(n_params_, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1,
+  adam_kernel<<<div_round_up(n_params_, 256), 256, 0, s>>>(0, n_params_, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1,
                                                            cfg_.beta2, (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2),
                                                            cfg_.epsilon, cfg_.l2_reg, opt_state_.ptr,
                                                            (half_t*)params_f16_.ptr, grads_.ptr);

@@ -48,7 +48,7 @@ def test_c3_ten_thousand_steps_reach_the_published_quality(c3_model):
           f"L1 loss {losses[0]:.5f} -> {losses[-1]:.5f}")
     assert psnr >= 30.0, psnr                       # README.md:24, the only quality number the reference publishes
     assert ssim > 0.9
-    assert np.mean(losses[-10:]) < 0.25 * losses[0]  # the loss of a batch fluctuates by a factor of two late in the run; its level fell
+    assert np.mean(losses[-10:]) < 0.5 * losses[0]   # losses[0] is the loss after the first 100 steps already; a batch's loss fluctuates by a factor of two late in the run
     assert c3_model["ms_per_step"] < 2.0            # a generous bound (0.45 ms measured): the step did not fall off a cliff
 
 

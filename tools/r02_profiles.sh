@@ -14,7 +14,7 @@ f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $
 find $O/stats -name "*.csv" -size +2M -delete
 for c in FETCH_SIZE WRITE_SIZE FETCH_SIZE_h1 WRITE_SIZE_h1; do
   d=$O/pmc_bench_$c
-  export VNR_AMD_RENDER_HALVES=2; case $c in *_h1) export VNR_AMD_RENDER_HALVES=1;; esac
+  export VNR_AMD_BRICK=1 VNR_AMD_RENDER_HALVES=2; case $c in *_h1) export VNR_AMD_RENDER_HALVES=1;; esac   # the brick image from the first launch: with one stream 24 launches are 3.4 frames
   c=${c%_h1}
   (cd /tmp && timeout -s ABRT -k 10 120 rocprofv3 --pmc $c --output-format csv -d "$d" -o bench -- python3 -X faulthandler $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-psnr --no-alone --no-brick-off --train-steps 300) > "$d.log" 2>&1
   rc=$?; echo "[pmc bench.py] $c exit $rc"
@@ -23,6 +23,6 @@ for c in FETCH_SIZE WRITE_SIZE FETCH_SIZE_h1 WRITE_SIZE_h1; do
   find $O -name "*.csv" -size +4M -delete
   [ $rc -ne 0 ] && tail -30 "$d.log" && break
 done
-unset VNR_AMD_RENDER_HALVES
+unset VNR_AMD_RENDER_HALVES VNR_AMD_BRICK
 python3 tools/pmc_traffic.py $O $O/bench.json > $O/pmc_traffic.json && python3 -c "import json; j=json.load(open('$O/pmc_traffic.json')); print({k: round(j[k]['bytes_per_sample'], 1) for k in ('one_stream', 'two_streams') if k in j})"
 exit 0

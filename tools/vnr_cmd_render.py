@@ -6,7 +6,7 @@
   --num-frames <int>         number of frames to render                                                            [required]
   --sampling-rate <float>    ray marching sampling rate                                                            [1]
   --density-scale <float>    path tracing density scale                                                            [1]
-  --rendering-mode <int>     0 ... 15, the reference's list (batch_renderer.cpp:44-60)                             [0]
+  --rendering-mode <int>     the vnrRenderMode enum (api.h:35-58): 4-12 ray marching, 13-15 path tracing                [0]
   --exp <name>               experiment name: <name>.csv (#, frame time, fps) and <name>-screenshot.*              [output]
   --camera-from / --camera-at / --camera-up   accepted and, like in the reference (batch_renderer.cpp:193), unused
 
@@ -32,12 +32,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from instantvnr_amd import api  # noqa: E402
 
-RENDER_MODES = ["0 Ray Marching (Decoding - Debug)", "1 Ray Marching (Sample Streaming - Debug)", "2 Ray Marching (In Shader - Debug)",
-                "3 Ray Marching (Decoding)", "4 Ray Marching (Sample Streaming)", "5 Ray Marching (In Shader)",
-                "6 Ray Marching + GGX Shading (Decoding)", "7 Ray Marching + GGX Shading (Sample Streaming)",
-                "8 Ray Marching + GGX Shading (In Shader)", "9 ...", "10 Ray Marching + SSH (Decoding - Debug)",
-                "11 Ray Marching + SSH (Sample Streaming)", "12 Ray Marching + SSH (In Shader)", "13 Path Tracing (Decoding - Debug)",
-                "14 Path Tracing (Sample Streaming)", "15 Path Tracing (In Shader)"]
+# the vnrRenderMode enum (api.h:35-58), in the order of the reference tool's help text (batch_renderer.cpp:45-60)
+RENDER_MODES = ["0-3 OptiX reference marcher (not implemented here)", "4 ray marching, decoding", "5 ray marching, sample streaming",
+                "6 ray marching, in shader", "7 / 8 / 9 the same three with local illumination (gradient shading)",
+                "10 / 11 / 12 the same three with the single-shade heuristic", "13 / 14 / 15 path tracing: decoding, sample streaming, in shader"]
 
 
 def save_png(fname, pixels):

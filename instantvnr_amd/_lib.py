@@ -170,6 +170,7 @@ def lib():
     sig("vnrAmdRendererGetFrameStats", I, P, C.POINTER(FrameStats))
     sig("vnrAmdRendererSetProfiling", I, P, I)
     sig("vnrAmdRendererSetAsync", I, P, I)
+    sig("vnrAmdRendererSetInShaderKernel", I, P, I)
     sig("vnrAmdRendererDebugQueues", I, P, C.POINTER(P), C.POINTER(P), FP, I)
     sig("vnrAmdReleaseRenderer", None, P)
     sig("vnrAmdDistGetUniqueId", I, P)

@@ -711,6 +711,7 @@ int vnrAmdRendererDebugQueues(vnrAmdRenderer r, const float** d_coords, const ui
 }
 int vnrAmdRendererSetProfiling(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_profiling(e != 0); }); }
 int vnrAmdRendererSetAsync(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_async(e != 0); }); }
+int vnrAmdRendererSetInShaderKernel(vnrAmdRenderer r, int m) { return guarded([&]() { VNR_REN(r); r->r->set_in_shader_kernel(m); }); }
 void vnrAmdReleaseRenderer(vnrAmdRenderer r) { delete r; }
 
 // ------------------------------------------------------------------------------------------------ multi-GPU (dist.h)

@@ -1,0 +1,212 @@
+// infer_tile.h — the evaluation of ONE wave-tile of 64 samples (hash-grid encode + MLP on the matrix cores) as device functions,
+// shared by the evaluation kernels (network_infer.hip) and the in-shader ray marcher (render.hip), which evaluates the network
+// inside its marching loop (method_raymarching.cu:981-1249 calls DeviceNeuralVolume::sample, tcnn_impl.cu:34-102, the same way).
+// Design notes: network_infer.hip's header.
+#pragma once
+#include "grid_device.h"
+
+namespace vnr {
+
+struct float3_packed { float x, y, z; };
+
+__device__ __forceinline__ half8_t pack_act(const f32x16& acc, int sh, bool relu)
+{
+  float8_t v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = acc[8 * sh + j];
+  half8_t r = __builtin_convertvector(v, half8_t);
+  if (relu) {
+    const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    r = __builtin_elementwise_max(r, zero);
+  }
+  return r;
+}
+
+// swaps the upper 32 lanes of a with the lower 32 lanes of b:  a' = [a.lo | b.lo],  b' = [a.hi | b.hi]
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b)
+{
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+
+__device__ __forceinline__ void swap_halves8(half8_t& p, half8_t& q)
+{
+  uint4_t a = __builtin_bit_cast(uint4_t, p), b = __builtin_bit_cast(uint4_t, q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t x = a[i], y = b[i];
+    swap_halves(x, y);
+    a[i] = x;
+    b[i] = y;
+  }
+  p = __builtin_bit_cast(half8_t, a);
+  q = __builtin_bit_cast(half8_t, b);
+}
+
+__device__ __forceinline__ void store_acts(half_t* row, const half8_t (&bf)[4], uint32_t h)
+{
+  // element j of bf[s] on lane (r, h) is neuron 16 s + 8 (j>>2) + 4 h + (j&3)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    *(half4_t*)(row + 16 * s + 4 * h) = half4_t{bf[s][0], bf[s][1], bf[s][2], bf[s][3]};
+    *(half4_t*)(row + 16 * s + 8 + 4 * h) = half4_t{bf[s][4], bf[s][5], bf[s][6], bf[s][7]};
+  }
+}
+
+// The MLP for ONE 32-sample column tile of the wave.  b1[s] = first-layer B fragments (k = 16 s + 8 h + j).
+// Returns this lane's partial sum of the output neuron (its 32 of the 64 last-layer terms).
+template <int S1, bool TRAIN>
+__device__ __forceinline__ float mlp_column_tile(const half_t* __restrict__ lds, const half8_t (&b1)[S1], uint32_t nh, bool relu,
+                                                 uint32_t h, uint32_t r, half_t* acts_out, size_t n, uint32_t smp, bool smp_ok)
+{
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < S1; ++s) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const half8_t a = *(const half8_t*)(lds + ((s * 2 + h) * 64 + m * 32 + r) * 8);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1[s], acc[m], 0, 0, 0);
+    }
+  }
+  half8_t bf[4];  // activations as next-layer B fragments, one per k-step
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) bf[2 * m + sh] = pack_act(acc[m], sh, relu);
+  if (TRAIN && acts_out && smp_ok) store_acts(acts_out + (size_t)smp * 64, bf, h);
+
+  for (uint32_t layer = 0; layer < nh; ++layer) {
+    const half_t* w = lds + S1 * 1024 + layer * 4096;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * 64 + m * 32 + r) * 8);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s], acc[m], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) bf[2 * m + sh] = pack_act(acc[m], sh, relu);
+    if (TRAIN && acts_out && smp_ok) store_acts(acts_out + ((size_t)(layer + 1) * n + smp) * 64, bf, h);
+  }
+
+  // last layer: output neuron 0 only (the other 15 padded rows are never read)
+  const half_t* wl = lds + S1 * 1024 + nh * 4096;
+  float part = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const half8_t wv = *(const half8_t*)(wl + (s * 2 + h) * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const half2_t a2 = {bf[s][2 * q], bf[s][2 * q + 1]};
+      const half2_t w2 = {wv[2 * q], wv[2 * q + 1]};
+      part = __builtin_amdgcn_fdot2(a2, w2, part, false);
+    }
+  }
+  return part;
+}
+
+
+// ---- encode: lane = sample, level wave-uniform -> feat[K_IN / 8] (the sample's K_IN features, fp16, zero padded) ---------------
+template <int F, int K_IN>
+__device__ __forceinline__ void encode_tile(const LevelInfo* levels, uint32_t n_levels, uint32_t interpolation, const table_rsrc_t& rsrc,
+                                            const uint8_t* brick_image, float x, float y, float z, half8_t (&feat)[K_IN / 8])
+{
+  constexpr int L_PAD = K_IN / F;   // levels incl. zero padding
+  // The level table is re-read (scalar loads) every tile: making the pointer opaque per call keeps the
+  // compiler from hoisting 16 x 6 loop-invariant scalars out of a persistent loop and spilling them.
+  // (constant address space => scalar s_load_dwordx8 per level)
+  typedef const __attribute__((address_space(4))) LevelInfo* const_levels_t;
+  const LevelInfo* lvtab_generic = levels;
+  asm volatile("" : "+s"(lvtab_generic));
+  const const_levels_t lvtab = (const_levels_t)lvtab_generic;
+  // wave-uniform by construction; say so, or hipcc wraps every buffer load in a waterfall loop
+  auto level_consts = [&](int l) {
+    LevelInfo lv;
+    lv.scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lvtab[l].scale)));
+    lv.resolution = __builtin_amdgcn_readfirstlane(lvtab[l].resolution);
+    lv.res2 = __builtin_amdgcn_readfirstlane(lvtab[l].res2);
+    lv.size = __builtin_amdgcn_readfirstlane(lvtab[l].size);
+    lv.offset = __builtin_amdgcn_readfirstlane(lvtab[l].offset);
+    lv.hashed = __builtin_amdgcn_readfirstlane(lvtab[l].hashed);
+    lv.brick = __builtin_amdgcn_readfirstlane(lvtab[l].brick);
+    return lv;
+  };
+#pragma unroll
+  for (int l = 0; l < L_PAD; ++l) {
+    half_t o[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
+    if (l < (int)n_levels) encode_level_fast<F>(level_consts(l), interpolation, rsrc, brick_image, x, y, z, o);
+#pragma unroll
+    for (int f = 0; f < F; ++f) feat[(l * F + f) / 8][(l * F + f) % 8] = o[f];
+    // keep the level constants (scalar registers) of at most four levels live at a time
+    if ((l & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- MLP on the wave's 64 samples: feat (consumed) -> this lane's sample's output, before the final rounding to fp16 ------------
+// tile_base = index of the wave's first sample (training: where the activations are stored)
+template <int F, int K_IN, bool TRAIN>
+__device__ __forceinline__ float mlp_tile(const half_t* __restrict__ lds, half8_t (&feat)[K_IN / 8], uint32_t nh, bool relu, uint32_t h,
+                                          uint32_t r, half_t* acts_out, size_t n, uint32_t tile_base)
+{
+  constexpr int S1 = K_IN / 16;     // k-steps of the first layer
+  // first layer operands: B = X^T via permlane32 swaps
+  // before: lane (sample) holds chunks 2s (P) and 2s+1 (Q) of its own sample.
+  // after : P = B fragment of column tile 0, Q = B fragment of column tile 1 (k = 16 s + 8 h + j).
+#pragma unroll
+  for (int s = 0; s < S1; ++s) swap_halves8(feat[2 * s], feat[2 * s + 1]);
+
+  float part[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    half8_t b1[S1];
+#pragma unroll
+    for (int s = 0; s < S1; ++s) b1[s] = feat[2 * s + nt];
+    const uint32_t smp = tile_base + 32u * nt + r;
+    part[nt] = mlp_column_tile<S1, TRAIN>(lds, b1, nh, relu, h, r, acts_out, n, smp, smp < n);
+  }
+
+  // combine the two lane halves: lanes < 32 get column tile 0, lanes >= 32 column tile 1
+  uint32_t p0 = __builtin_bit_cast(uint32_t, part[0]), p1 = __builtin_bit_cast(uint32_t, part[1]);
+  swap_halves(p0, p1);
+  return __builtin_bit_cast(float, p0) + __builtin_bit_cast(float, p1);
+}
+
+// What a kernel other than the evaluation kernels needs to evaluate the network itself (Network::tile_net)
+struct TileNet {
+  const LevelInfo* levels;     // per-level constants (the brick variant when the image is in use)
+  uint32_t n_levels, interpolation;
+  const half_t* table;         // grid part of the parameter blob
+  uint32_t table_bytes;
+  const uint8_t* brick_image;  // or null
+  const half_t* packed_mlp;    // LDS image of the weights (pack_mlp_kernel), lds_halves halves
+  uint32_t lds_halves, n_hidden_matmuls, activation;
+  uint32_t n_features, in_width;
+};
+
+// the network at this lane's point, all 64 lanes of the wave taking part (inactive lanes pass any in-domain point): the value
+// fused_infer_kernel writes for it, bit for bit (network output in half precision, then cast to float: tcnn_impl.cu:421-431)
+template <int F, int K_IN>
+__device__ __forceinline__ float eval_tile(const TileNet& net, const half_t* __restrict__ lds, const table_rsrc_t& rsrc, float x, float y, float z)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  half8_t feat[K_IN / 8];
+  encode_tile<F, K_IN>(net.levels, net.n_levels, net.interpolation, rsrc, net.brick_image, x, y, z, feat);
+  const float v = mlp_tile<F, K_IN, false>(lds, feat, net.n_hidden_matmuls, net.activation == 1, lane >> 5, lane & 31u, nullptr, 0, 0);
+  return (float)(half_t)v;
+}
+
+}  // namespace vnr

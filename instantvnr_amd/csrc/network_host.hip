@@ -9,7 +9,7 @@
 #include <cstdlib>
 #include <set>
 
-#include "grid_device.h"
+#include "infer_tile.h"
 
 namespace vnr {
 
@@ -478,6 +478,27 @@ void Network::inference_queue(const float* d_records, float* d_out, uint32_t out
   grid.n_levels = n_active_levels();
   launch_fused(0, grid, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
                mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image, sharers);
+}
+
+bool Network::tile_net(TileNet* out, hipStream_t s) const
+{
+  if (!fast_path()) return false;
+  if (n_grid_params() * 2 >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
+  const uint8_t* image;
+  const LevelInfo* levels = inference_levels(s, &image);
+  out->levels = levels;
+  out->n_levels = n_active_levels();
+  out->interpolation = grid_.interpolation;
+  out->table = (const half_t*)(params_f16_.ptr + n_mlp_);
+  out->table_bytes = (uint32_t)(n_grid_params() * 2);
+  out->brick_image = image;
+  out->packed_mlp = (const half_t*)mlp_packed_.ptr;
+  out->lds_halves = lds_halves_;
+  out->n_hidden_matmuls = n_hidden_matmuls();
+  out->activation = cfg_.activation;
+  out->n_features = grid_.n_features;
+  out->in_width = in_width_;
+  return true;
 }
 
 void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const

@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "dist.h"
+#include "infer_tile.h"
 #include "sampling_device.h"
 
 namespace vnr {
@@ -940,6 +941,10 @@ __global__ void monolithic_kernel(const RenderParams p)
   write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
 }
 
+}  // namespace vnr
+#include "in_shader.h"   // in_shader_kernel: uses everything above
+namespace vnr {
+
 // ================================================================================================ path tracing (mode 14)
 // Sample-streaming path tracer: core/renderer/method_pathtracing.cu:532-813 (DeltaTrackingIter with the macrocell majorants,
 // iterative_take_sample, iterative_shade, raygen / shade kernels, do_path_tracing_iterative); VARYING_MAJORANT = 1 there
@@ -1511,7 +1516,8 @@ void Renderer::render()
 {
   // an asynchronous single-pass frame that is still pending stays pending until the head of this frame is enqueued
   // (render_streaming); everything else completes first
-  const bool pipeline_head = async_ && (skip_download_ || distributed_) && (mode_ == 5 || mode_ == 6 || mode_ == 8 || mode_ == 9) &&
+  const bool in_shader = (mode_ == 6 || mode_ == 9 || mode_ == 12) && in_shader_applies();
+  const bool pipeline_head = async_ && (skip_download_ || distributed_) && (mode_ == 5 || mode_ == 6 || mode_ == 8 || mode_ == 9) && !in_shader &&
                              frame_[slot_] && frame_[slot_]->pending && !(frame_[slot_ ^ 1] && frame_[slot_ ^ 1]->pending) &&
                              !reset_;   // (a frame that restarts the accumulation overwrites it: its head must not run beside the tail of the frame before)
   if (!pipeline_head) finish_pending();
@@ -1598,8 +1604,14 @@ void Renderer::render()
 
   frame_of_buffer_[fb_cur_] = -1;
   if (p.pixel_hi > p.pixel_lo && p.n_local > 0) {
+    if (in_shader) {
+      // VNR_RAYMARCHING_{NO_SHADING, GRADIENT_SHADING, SINGLE_SHADE_HEURISTIC}_IN_SHADER on a neural volume: the network inside the
+      // marching loop, one launch per frame (in_shader.h; method_raymarching.cu:981-1249)
+      render_in_shader(p, mode_ == 9 ? M_GRADIENT : mode_ == 12 ? M_SSH : M_NONE);
+    } else
     switch (mode_) {
-    case 6:   // VNR_RAYMARCHING_NO_SHADING_IN_SHADER: the reference evaluates the network inside the marching loop
+    case 6:   // VNR_RAYMARCHING_NO_SHADING_IN_SHADER where in_shader_applies() says no (a dense volume, a model shape without an
+              // in-shader instance, VNR_AMD_IN_SHADER=0): the reference evaluates the network inside the marching loop
               // (network_raymarching_traceray / _iterator, method_raymarching.cu:310-356, 1037-1100): the per-ray arithmetic is
               // mode 5's without the interruptions, i.e. mode 5's up to the last bit of the samples at batch boundaries (a ray
               // resumes at t_min + (t - t_min)): measured 4e-5 at most on 0.2 % of the pixels, two orders below what the network's
@@ -1655,6 +1667,63 @@ void Renderer::render()
     const size_t off = p.pixel_lo, cnt = p.pixel_hi - p.pixel_lo;  // (interleaved shares copy the covering range)
     if (cnt) VNR_HIP_CHECK(hipMemcpyAsync(host_fb_[fb_cur_] + off, fb_[fb_cur_].ptr + off, cnt * sizeof(vec4f), hipMemcpyDeviceToHost, stream_));
   }
+}
+
+// model shapes with an in-shader instance (F, padded input width); the others take the streaming path
+#define VNR_IN_SHADER_SHAPES(X) X(2, 16) X(2, 32) X(2, 64) X(4, 32) X(4, 64) X(8, 64)
+
+bool Renderer::in_shader_applies() const
+{
+  // Off unless asked for (vnrAmdRendererSetInShaderKernel(1) or VNR_AMD_IN_SHADER=1): measured on the bench frame in mode 6, the
+  // in-shader kernel takes 8.2 ms for the whole frame and 1.98 ms for a 1/8 share where the streaming path takes 4.2 and 0.70 ms
+  // (mode 9: 36.8 / 6.6 against 12.2 / 1.8 ms; gpurun_out/r02_inshader/perf.log): a wave marches until its longest ray
+  // has ended, and the streaming path's compaction is exactly what removes that wait.  Same frames either way.
+  static const bool env_on = [] { const char* e = std::getenv("VNR_AMD_IN_SHADER"); return e && e[0] == '1'; }();
+  if (!(in_shader_mode_ < 0 ? env_on : in_shader_mode_ == 1) || !volume_->is_network()) return false;
+  const Network& net = static_cast<NeuralVolume*>(volume_.get())->network();
+  if (!net.valid() || !net.fast_path()) return false;
+  const uint32_t F = net.config().n_features, K = net.padded_width();
+#define X(f, k) if (F == f && K == k) return true;
+  VNR_IN_SHADER_SHAPES(X)
+#undef X
+  return false;
+}
+
+void Renderer::render_in_shader(const RenderParams& p, int shade)
+{
+  NeuralVolume* nv = static_cast<NeuralVolume*>(volume_.get());
+  TileNet net;
+  if (!nv->network().tile_net(&net, stream_)) throw std::runtime_error("internal: in-shader rendering of a model without an MFMA kernel");
+  if (is_samples_.count == 0) { is_samples_.resize(kInShaderStatSlots); is_hits_.resize(kInShaderStatSlots); }
+  is_samples_.zero(stream_);
+  is_hits_.zero(stream_);
+  const uint32_t blocks = div_round_up(p.n_local, 256);
+  const size_t shmem = (size_t)net.lds_halves * sizeof(uint16_t);
+  bool launched = false;
+  auto launch = [&](auto kernel) {
+    // (the kernel also has 48 bytes of static LDS: the dynamic part cannot be the whole 160 KB)
+    if (shmem > 48 * 1024) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    kernel<<<blocks, 256, shmem, stream_>>>(p, net, is_samples_.ptr, is_hits_.ptr);
+    launched = true;
+  };
+#define X(f, k)                                                                     \
+  if (!launched && net.n_features == f && net.in_width == k) {                      \
+    if (shade == M_GRADIENT) launch(in_shader_kernel<f, k, M_GRADIENT>);            \
+    else if (shade == M_SSH) launch(in_shader_kernel<f, k, M_SSH>);                 \
+    else launch(in_shader_kernel<f, k, M_NONE>);                                    \
+  }
+  VNR_IN_SHADER_SHAPES(X)
+#undef X
+  if (!launched) throw std::runtime_error("internal: no in-shader instance for this model shape");
+  VNR_HIP_CHECK(hipGetLastError());
+  unsigned long long hs[kInShaderStatSlots];
+  uint32_t hh[kInShaderStatSlots];
+  VNR_HIP_CHECK(hipMemcpyAsync(hs, is_samples_.ptr, sizeof(hs), hipMemcpyDeviceToHost, stream_));
+  VNR_HIP_CHECK(hipMemcpyAsync(hh, is_hits_.ptr, sizeof(hh), hipMemcpyDeviceToHost, stream_));
+  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+  for (int k = 0; k < kInShaderStatSlots; ++k) { stats_.n_samples += hs[k]; stats_.n_rays_hit += hh[k]; }
+  stats_.n_reference_slots = stats_.n_samples;
+  stats_.n_iterations = 1;
 }
 
 void Renderer::render_monolithic(const RenderParams& p)

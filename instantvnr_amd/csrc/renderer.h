@@ -43,6 +43,10 @@ public:
   // what the frame reads complete it first (further iterations if rays are still alive).  Off by default: the caller
   // must not change the volume (training, decoding, time step) between render() and map_frame().
   void set_async(bool e) { finish_pending(); async_ = e; }
+  // rendering modes 6 / 9 / 12 on a neural volume: 1 the in-shader kernel, 0 the streaming path, -1 the environment's choice
+  // (VNR_AMD_IN_SHADER, default 0: the streaming path is faster, render.hip in_shader_applies).  Same frames up to the streaming
+  // path's resume rounding.
+  void set_in_shader_kernel(int mode) { finish_pending(); in_shader_mode_ = mode; }
   // diagnostics: the compacted sample queue of the last iteration and per-iteration kernel times of the last frame
   const float* debug_coords() { finish_pending(); return (const float*)queue_.ptr; }  // 16-byte records {x, y, z, slot}
   const uint32_t* debug_counters() { finish_pending(); return counters_.ptr; }
@@ -80,6 +84,10 @@ private:
   void finish_streaming(StreamingFrame& f);
   void finish_pending();
   void render_monolithic(const RenderParams& p);
+  // rendering modes 6 / 9 / 12 on a neural volume: one launch, the network evaluated inside the marching loop (in_shader.h).
+  // false: this model / configuration is not covered and the caller takes the streaming path (same frames up to resume rounding)
+  bool in_shader_applies() const;
+  void render_in_shader(const RenderParams& p, int shade);
   void render_pathtracing(const RenderParams& p);   // do_path_tracing_iterative (method_pathtracing.cu:786-806)
   void ensure_queues(size_t n_pixels, int n_iters, bool gradient);
   void ensure_share_buffers();
@@ -106,6 +114,9 @@ private:
   // samples per ray and iteration, VNR_RM_N_ITERS (method_raymarching.cu:30-40; 16 there, tuned on the authors' GPU).  Frames
   // depend on it only through the last bit of samples at batch boundaries (0.2 % of the pixels, max 4e-5); on MI355X 24 is the fastest (bench workload: 16: 122, 24: 129, 32: 126 frames/s)
   int n_iters_ = 24;
+  DeviceBuffer<unsigned long long> is_samples_{MemTag::Renderer};   // in-shader kernel statistics, kInShaderStatSlots each
+  DeviceBuffer<uint32_t> is_hits_{MemTag::Renderer};
+  int in_shader_mode_ = -1;
   bool n_iters_fixed_ = false;   // VNR_RM_N_ITERS given: no adaptation to the size of the share
   // LaunchParams::light_directional_dir (instantvnr_types.h:148): a member the reference negates IN PLACE whenever it points
   // along the view direction (renderer.cpp:98-101), so it persists across frames

@@ -599,3 +599,92 @@ def test_in_shader_mode_15_path_tracing(oracle, scene):
         assert np.array_equal(want, mono)                                  # one estimator, two programs
         assert (np.abs(img - want).max(axis=2) < 1e-5).mean() > 0.995
     assert (np.abs(other - want).max(axis=2) > 1e-6).sum() > 10            # and it is not mode 14's
+
+
+# ---- the in-shader kernel on neural volumes (in_shader.h): one launch per frame, the network evaluated inside the marching loop ----
+def _neural_c4_shape(oracle, scene, seed):
+    L, F, log2T, base, pls, H = 16, 2, 19, 16, 1.3195, 3
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base, n_hidden_layers=H, per_level_scale=pls)
+    nv = api.vnrCreateNeuralVolume(cfg, scene["sv"], online_macrocell_construction=False)
+    info = api.neural_info(nv)
+    params = syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], 64, H - 1), seed=seed)
+    api.neural_set_params_fp16(nv, params)
+    return nv, oracle.grid_config(L, F, log2T, base, pls), params, H
+
+
+def _set_in_shader(r, mode):
+    from instantvnr_amd._lib import check, lib
+    check(lib().vnrAmdRendererSetInShaderKernel(r.h, mode))
+
+
+@pytest.mark.parametrize("mode,shading_mode", [(6, 0), (9, 4), (12, 3)])
+def test_in_shader_kernel_on_a_neural_volume(oracle, scene, mode, shading_mode):
+    """modes 6 / 9 / 12 on a neural volume run in_shader_kernel (the network inside the marching loop, method_raymarching.cu:981-1249).
+    Against the oracle's uninterrupted march driven by the oracle network: the bars of the streaming modes 5 / 8 / 11.  Against the
+    library's own streaming path on the same parameters (vnrAmdRendererSetInShaderKernel(0)): the network values are the same bits, so
+    the two frames differ only by the streaming path's resume rounding; hit rays equal, and no more evaluations than the streaming path."""
+    nv, ocfg, params, H = _neural_c4_shape(oracle, scene, seed=20 + mode)
+    size = (64, 56)
+    frames, stats = {}, {}
+    for kernel in (1, 0):
+        r = make_renderer(scene, nv, size=size, mode=mode)
+        _set_in_shader(r, kernel)
+        api.vnrRender(r)
+        first = api.vnrRendererMapFrame(r).copy()
+        stats[kernel] = api.vnrRendererGetFrameStats(r)
+        api.vnrRender(r)                                  # a second, accumulated frame (other jitter)
+        frames[kernel] = (first, api.vnrRendererMapFrame(r).copy())
+    assert stats[1]["n_iterations"] == 1 and stats[0]["n_iterations"] >= 1
+    assert stats[1]["n_rays_hit"] == stats[0]["n_rays_hit"] > 1000
+    # the streaming path evaluates a whole batch before it composes it, i.e. also the samples behind the one that saturates a ray;
+    # the in-shader loop stops there
+    assert 0.5 * stats[0]["n_samples"] < stats[1]["n_samples"] <= stats[0]["n_samples"]
+    for k in (0, 1):
+        d = np.abs(frames[1][k] - frames[0][k])
+        assert d.max() < 2e-3 and psnr(frames[1][k], frames[0][k]) > 70, (k, d.max(), psnr(frames[1][k], frames[0][k]))
+    assert not np.array_equal(frames[1][0], frames[1][1])     # the second frame did add something
+    mo = api.volume_macrocell(scene["sv"])["max_opacity"]
+    cam = scene["cam"]
+    sc = oracle.SceneHolder(size[0], size[1], (48, 48, 48), scene["otfn"], mo, cam["from"], cam["at"], cam["up"], cam["fovy"], shading_mode=shading_mode)
+    want, _, ost = oracle.render_streaming(sc, lambda c: oracle.network_inference(ocfg, 64, H, params.view(np.uint16), c), n_iters=512)
+    assert ost["n_rays_hit"] == stats[1]["n_rays_hit"]
+    assert frames[1][0][..., 3].max() > 0.05
+    assert psnr(frames[1][0], want) > (40 if mode == 6 else 70), psnr(frames[1][0], want)
+
+
+def test_in_shader_kernel_shares_and_pixel_ranges(oracle, scene):
+    """the in-shader kernel under the multi-GPU interleave and under a pixel range: every pixel is the unsharded frame's, bit for bit
+    (a pixel's ray does not depend on which rays share its wave)"""
+    nv, _, _, _ = _neural_c4_shape(oracle, scene, seed=31)
+    size = (96, 80)
+    r = make_renderer(scene, nv, size=size, mode=6)
+    api.vnrRender(r)
+    full = api.vnrRendererMapFrame(r).copy().reshape(-1, 4)
+    got = np.zeros_like(full)
+    for part in range(3):
+        rp = make_renderer(scene, nv, size=size, mode=6)
+        api.vnrRendererSetPixelInterleave(rp, 8 * size[0], 3, part)
+        api.vnrRender(rp)
+        share = api.vnrRendererMapFrame(rp).reshape(-1, 4)
+        rows = np.arange(size[1]) // 8 % 3 == part
+        mask = np.repeat(rows, size[0])
+        got[mask] = share[mask]
+    assert np.array_equal(got, full)
+    lo, hi = 17 * size[0] + 5, 41 * size[0] + 90
+    rr = make_renderer(scene, nv, size=size, mode=6)
+    api.vnrRendererSetPixelRange(rr, lo, hi)
+    api.vnrRender(rr)
+    assert np.array_equal(api.vnrRendererMapFrame(rr).reshape(-1, 4)[lo:hi], full[lo:hi])
+
+
+def test_in_shader_kernel_falls_back_where_it_has_no_instance(oracle, scene):
+    """a model shape without an in-shader instance (F = 1) and a dense volume take the streaming path: mode 6 still renders"""
+    cfg = syn.model_config(n_levels=16, n_features=1, log2_hashmap_size=14, base_resolution=4, n_hidden_layers=2)
+    nv = api.vnrCreateNeuralVolume(cfg, scene["sv"], online_macrocell_construction=False)
+    info = api.neural_info(nv)
+    api.neural_set_params_fp16(nv, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], 64, 1), seed=5))
+    for volume in (nv, scene["sv"]):
+        r6, r5 = make_renderer(scene, volume, size=(64, 56), mode=6), make_renderer(scene, volume, size=(64, 56), mode=5)
+        api.vnrRender(r6); api.vnrRender(r5)
+        assert api.vnrRendererGetFrameStats(r6)["n_iterations"] >= 1
+        assert np.array_equal(api.vnrRendererMapFrame(r6), api.vnrRendererMapFrame(r5))

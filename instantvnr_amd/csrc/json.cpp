@@ -335,9 +335,12 @@ void put_i32(std::vector<uint8_t>& o, int32_t v) { for (int i = 0; i < 4; ++i) o
 void put_i64(std::vector<uint8_t>& o, int64_t v) { for (int i = 0; i < 8; ++i) o.push_back((uint8_t)((uint64_t)v >> (8 * i))); }
 void patch_i32(std::vector<uint8_t>& o, size_t at, int32_t v) { for (int i = 0; i < 4; ++i) o[at + i] = (uint8_t)((uint32_t)v >> (8 * i)); }
 
+constexpr int kBsonMaxDepth = 64;   // params.json nests 3 deep; a corrupt or crafted file must not recurse the stack away
+
 struct BsonReader {
   const uint8_t* p;
-  const uint8_t* end;
+  const uint8_t* end;   // end of the enclosing document while its elements are read (of the buffer at the top)
+  int depth = 0;
   [[noreturn]] void fail(const char* m) const { throw std::runtime_error(std::string("bson parse error: ") + m); }
   void need(size_t n) const { if ((size_t)(end - p) < n) fail("unexpected end of input"); }
   int32_t i32() { need(4); uint32_t v = 0; for (int i = 0; i < 4; ++i) v |= (uint32_t)p[i] << (8 * i); p += 4; return (int32_t)v; }
@@ -353,10 +356,13 @@ struct BsonReader {
   }
   Json document(bool as_array)
   {
+    if (++depth > kBsonMaxDepth) fail("documents nested too deeply");
     const uint8_t* start = p;
     const int32_t len = i32();
-    if (len < 5 || (size_t)len > (size_t)(end - start)) fail("bad document length");
+    if (len < 5 || (size_t)len > (size_t)(end - start)) fail("bad document length");   // `end` is the parent's end: a child cannot overrun it
     const uint8_t* doc_end = start + len;
+    const uint8_t* parent_end = end;
+    end = doc_end;   // strings, binaries and nested documents of this document are bounded by it
     Json out = as_array ? Json::array() : Json::object();
     while (p < doc_end - 1) {
       need(1);
@@ -396,6 +402,8 @@ struct BsonReader {
     }
     if (p != doc_end - 1 || *p != 0) fail("bad document terminator");
     ++p;
+    end = parent_end;
+    --depth;
     return out;
   }
 };
@@ -417,12 +425,15 @@ void Json::bson_element(std::vector<uint8_t>& o, const std::string& key) const
     break;
   case Double: { header(0x01); int64_t raw; std::memcpy(&raw, &d_, 8); put_i64(o, raw); break; }
   case String:
+    if (s_.size() >= (size_t)INT32_MAX) throw std::runtime_error("bson: string of 2 GiB or more cannot be encoded");
     header(0x02);
     put_i32(o, (int32_t)s_.size() + 1);
     o.insert(o.end(), s_.begin(), s_.end());
     o.push_back(0);
     break;
   case Binary:
+    // a BSON length is an int32 (nlohmann throws out_of_range here): a parameter blob of 2 GiB or more has no params.json form
+    if (s_.size() > (size_t)INT32_MAX) throw std::runtime_error("bson: binary of more than 2 GiB - 1 bytes cannot be encoded (" + std::to_string(s_.size()) + " bytes)");
     header(0x05);
     put_i32(o, (int32_t)s_.size());
     o.push_back(0x00);
@@ -443,6 +454,7 @@ void Json::bson_document(std::vector<uint8_t>& o) const
     for (const auto& kv : obj_) kv.second.bson_element(o, kv.first);
   }
   o.push_back(0);
+  if (o.size() - at > (size_t)INT32_MAX) throw std::runtime_error("bson: document of more than 2 GiB - 1 bytes cannot be encoded");
   patch_i32(o, at, (int32_t)(o.size() - at));
 }
 
@@ -456,7 +468,7 @@ std::vector<uint8_t> Json::to_bson() const
 
 Json Json::from_bson(const uint8_t* data, size_t size)
 {
-  BsonReader r{data, data + size};
+  BsonReader r{data, data + size, 0};
   return r.document(false);
 }
 

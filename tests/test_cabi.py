@@ -62,6 +62,42 @@ def test_bson_binary_roundtrip_matches_pymongo(L):
     assert again == enc
 
 
+def test_bson_reader_bounds_children_by_their_parent_and_limits_depth(L):
+    """a corrupt or crafted params file: a child document that claims to reach beyond its parent, a string or binary that does, and
+    nesting deeper than 64 levels are parse errors, not overruns or a blown stack"""
+    import struct
+    out, n = C.c_void_p(), C.c_size_t()
+
+    def convert(b):
+        return L.vnrAmdJsonConvert(b, len(b), api.JSON_BSON, api.JSON_TEXT, C.byref(out), C.byref(n))
+
+    def doc(elements):   # elements: raw bytes of the element list
+        return struct.pack("<i", 4 + len(elements) + 1) + elements + b"\0"
+
+    inner = doc(b"\x10a\0" + struct.pack("<i", 7))
+    good = doc(b"\x03d\0" + inner) + b"PADDINGPADDING"        # trailing bytes behind the top-level document are not its business
+    assert convert(good[:len(good) - 14]) == 0
+    L.vnrAmdFreeHost(out)
+    # the child claims 8 more bytes than it has: they exist in the buffer (the padding) but lie outside the parent
+    lying = bytearray(good)
+    off = 4 + 3                                                  # parent length, element header "\x03d\0"
+    struct.pack_into("<i", lying, off, len(inner) + 8)
+    assert convert(bytes(lying)) != 0 and b"bson parse error" in L.vnrAmdGetLastError()
+    # a string whose length runs past its document
+    s = doc(b"\x02s\0" + struct.pack("<i", 50) + b"abc\0") + b"x" * 64
+    assert convert(s) != 0 and b"bson parse error" in L.vnrAmdGetLastError()
+    # 65 nested documents
+    deep = doc(b"")
+    for _ in range(65):
+        deep = doc(b"\x03d\0" + deep)
+    assert convert(deep) != 0 and b"nested too deeply" in L.vnrAmdGetLastError()
+    ok = doc(b"")
+    for _ in range(40):
+        ok = doc(b"\x03d\0" + ok)
+    assert convert(ok) == 0
+    L.vnrAmdFreeHost(out)
+
+
 def test_json_save_and_load_files(L, tmp_path):
     p = str(tmp_path / "m.json")
     api.vnrSaveJsonText({"a": 1, "b": [1, 2]}, p)

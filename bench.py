@@ -56,7 +56,7 @@ def parse():
     p.add_argument("--no-alone", action="store_true", help="skip the un-timed one-stream leg (roofline.alone)")
     p.add_argument("--no-brick-off", action="store_true", help="skip the un-timed leg without the brick image (train-while-render configuration)")
     p.add_argument("--no-kernel-events", action="store_true", help="diagnostics: no HIP events around the evaluation kernel (roofline.achieved reads 0)")
-    p.add_argument("--mode", type=int, default=5, choices=(5, 8, 11, 14),
+    p.add_argument("--mode", type=int, default=5, choices=(5, 6, 8, 9, 11, 12, 14),
                    help="rendering mode: 5 = sample streaming (BASELINE metric, default), 8 = the same with gradient shading (4 evaluations per sample)")
     return p.parse_args()
 
@@ -294,7 +294,7 @@ def main():
     fps = a.steps / elapsed
     # the renderer counts SHADED samples; with gradient shading (mode 8) the network evaluates 4 coordinates for each of them,
     # and every rate below is per network evaluation
-    evals_per_sample = 4 if a.mode == 8 else 1
+    evals_per_sample = 4 if a.mode in (8, 9) else 1
     shaded_samples_per_frame = int(samples_all / a.steps)
     samples *= evals_per_sample
     samples_all *= evals_per_sample
@@ -402,7 +402,7 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{workload_name(a)}: {volume_desc}, HashGrid L={a.levels} F={a.features} "
                                f"T=2^{a.log2_hashmap_size} base 16 per_level_scale {pls:.4f} + {a.hidden_layers}x64 FullyFusedMLP, "
-                               f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading' if a.mode == 8 else 'sample streaming, single-shade heuristic: camera pass + shadow pass' if a.mode == 11 else 'path tracing, sample streaming'}), sampling rate 1, N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24 (32 when a rank renders at most 196608 pixels)')}",
+                               f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading' if a.mode == 8 else 'sample streaming, single-shade heuristic: camera pass + shadow pass' if a.mode == 11 else 'path tracing, sample streaming' if a.mode == 14 else 'in-shader mode: the in-shader kernel with VNR_AMD_IN_SHADER=1, else the streaming path'}), sampling rate 1, N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24 (32 when a rank renders at most 196608 pixels)')}",
                    "volume": f"{a.size}^3", "framebuffer": f"{a.fb}x{a.fb}", "n_params": info["n_params"],
                    "tfn": f"256-entry ramp-with-bumps, seed 7, opacity scale {a.opacity_scale}",
                    "camera": cam, "train_steps": a.train_steps, "batch": 65536,

@@ -381,8 +381,8 @@ def main():
     bwd_bytes = Lv * 8 * F * 2 * 2 * B
     opt_bytes = n_params * (2 + 4 + 4 + 4) * 2
     step_bytes = fwd_bytes + bwd_bytes + opt_bytes
-    names = ["forward (fused encode + MLP, keeps activations)", "loss + MLP backward (MFMA)", "weight gradients", "grid backward (float atomics)",
-             "optimizer (Adam, fp32 master)" + (" incl. waiting for the gradient exchange" if ctx.distributed else "")]
+    names = ["forward (fused encode + MLP, keeps activations)", "loss + MLP backward (MFMA)", "weight gradients (MFMA, block partials summed in order)", "grid backward (packed fp16 atomics)",
+             "optimizer (Adam, fp32 master, fp16 gradient)" + (" incl. waiting for the gradient exchange" if ctx.distributed else "")]
     kernel_ms = [float(phase_ms[i]) for i in range(5)]
     step_kernel_ms = sum(kernel_ms)
     train_roofline = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,

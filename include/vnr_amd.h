@@ -208,9 +208,11 @@ int    vnrAmdNeuralVolumeGetInfo(vnrAmdVolume, int* n_levels, int* n_features_pe
 int    vnrAmdNeuralVolumeGetParamsFP16(vnrAmdVolume, uint16_t* host_out, size_t count);
 int    vnrAmdNeuralVolumeSetParamsFP16(vnrAmdVolume, const uint16_t* host_in, size_t count);
 
-/* Data-parallel training hooks (new work): TrainBegin = sample + forward + backward, leaves the
- * gradient of the whole parameter blob in one fp32 device buffer (all-reduce it across ranks), TrainEnd =
- * optimizer step (+ macrocell update).  vnrAmdNeuralVolumeTrain(steps) == steps x (Begin; End). */
+/* Data-parallel training hooks (new work): TrainBegin = sample + forward + backward, leaves the loss-scaled (x 128)
+ * gradient of the whole parameter blob in ONE half-precision device buffer (tcnn keeps its gradients in half precision too; sum it over
+ * the ranks with vnrAmdNeuralVolumeAllReduceGradients), TrainEnd = optimizer step (+ macrocell update).
+ * vnrAmdNeuralVolumeTrain(steps) == steps x (Begin; End).  vnrAmdNeuralVolumeGradients returns a FLOAT COPY of that buffer for
+ * inspection (device pointer, valid until the next call); changing it changes nothing. */
 int    vnrAmdNeuralVolumeTrainBegin(vnrAmdVolume);
 float* vnrAmdNeuralVolumeGradients(vnrAmdVolume, size_t* count);
 int    vnrAmdNeuralVolumeTrainEnd(vnrAmdVolume, float grad_scale, int fast_mode);
@@ -323,8 +325,8 @@ int  vnrAmdRendererFlushPipeline(vnrAmdRenderer, const float** last_frame);
  * optimizer state, step count and learning rate (SyncReplicas) and gives every rank its own sample stream. */
 int  vnrAmdNeuralVolumeTrainDataParallel(vnrAmdVolume, int steps, int fast_mode);
 int  vnrAmdNeuralVolumeSyncReplicas(vnrAmdVolume);
-/* for the TrainBegin / TrainEnd form: sums vnrAmdNeuralVolumeGradients() over the ranks (fp16 payload, result back in the fp32
- * buffer); follow with vnrAmdNeuralVolumeTrainEnd(v, 1.0f / world, fast_mode) */
+/* for the TrainBegin / TrainEnd form: sums the gradient buffer over the ranks, in place (fp16 payload); follow with
+ * vnrAmdNeuralVolumeTrainEnd(v, 1.0f / world, fast_mode) */
 int  vnrAmdNeuralVolumeAllReduceGradients(vnrAmdVolume);
 
 /* ---- misc (api.h:185-188) -------------------------------------------------- */

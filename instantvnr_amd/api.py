@@ -636,7 +636,7 @@ def simple_volume_take_samples(v, n, lower=(0, 0, 0), upper=(1, 1, 1)):
 
 
 def neural_forward_backward(v, coords, targets):
-    """forward + backward on a host batch; returns the fp32 (loss-scaled x128) gradient blob as numpy"""
+    """forward + backward on a host batch; returns the (loss-scaled x128) gradient blob, which the library keeps in half precision, as float32 numpy"""
     c = DeviceArray.from_numpy(np.ascontiguousarray(coords, dtype=np.float32))
     t = DeviceArray.from_numpy(np.ascontiguousarray(targets, dtype=np.float32))
     check(lib().vnrAmdNeuralVolumeForwardBackward(v.h, c.shape[0], c.ptr, t.ptr))

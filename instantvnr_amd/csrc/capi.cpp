@@ -575,8 +575,9 @@ float* vnrAmdNeuralVolumeGradients(vnrAmdVolume v, size_t* count)
 {
   float* p = nullptr;
   guarded([&]() {
-    Network& n = as_neural(v)->network();
-    p = n.grads();
+    NeuralVolume* nv = as_neural(v);
+    Network& n = nv->network();
+    p = n.grads_as_f32(nv->stream);
     if (count) *count = n.grads_count();
   });
   return p;

@@ -134,12 +134,15 @@ public:
 
   // training step pieces (tcnn Trainer::training_step, EXTERNAL): forward+loss+backward into grads()
   void forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s, GradExchange* exchange = nullptr);
-  float* grads() { return grads_.ptr; }
+  // The gradient of the whole blob, loss-scaled (x 128), in HALF precision like tcnn's (its gradient matrices and, for F > 1, its
+  // grid gradients are network_precision_t): the unit of the data-parallel exchange, read and cleared by the optimizer.
+  uint16_t* grads_f16() { return grads_.ptr; }
   size_t grads_count() const { return grads_.count; }
+  float* grads_as_f32(hipStream_t s);   // a float copy for inspection (vnrAmdNeuralVolumeGradients); not an input of anything
   void optimizer_step(float grad_scale, hipStream_t s);
-  // the same step in pieces, for gradients that arrive range by range as fp16 (data-parallel exchange, volume.hip):
-  // Adam on parameters [lo, hi) with gradient d_grads_f16[i] * grad_scale / loss_scale, then the bookkeeping of ONE step
-  void optimizer_step_range(size_t lo, size_t hi, const uint16_t* d_grads_f16, float grad_scale, hipStream_t s);
+  // the same step in pieces, for gradients that become final range by range (data-parallel exchange, volume.hip):
+  // Adam on parameters [lo, hi) with gradient grads[i] * grad_scale / loss_scale (clearing it), then the bookkeeping of ONE step
+  void optimizer_step_range(size_t lo, size_t hi, float grad_scale, hipStream_t s);
   void optimizer_finish_step(hipStream_t s);
   float learning_rate() const { return lr_; }
   // replica state for data-parallel training: everything an optimizer step reads
@@ -187,7 +190,8 @@ private:
   DeviceBuffer<uint16_t> mlp_packed_{MemTag::Network};   // MFMA/LDS image of the MLP weights
   DeviceBuffer<LevelInfo> levels_dev_{MemTag::Network};  // per-level constants, read with scalar loads
   DeviceBuffer<OptState> opt_state_{MemTag::Network};    // per parameter: fp32 master copy + Adam moments + step count (training)
-  DeviceBuffer<float> grads_{MemTag::Network};           // fp32 gradient of the whole blob (ONE buffer: the all-reduce unit)
+  DeviceBuffer<uint16_t> grads_{MemTag::Network};        // fp16 gradient of the whole blob (ONE buffer: the all-reduce unit)
+  DeviceBuffer<float> grads_f32_{MemTag::Network};       // grads_as_f32()
   // training workspace
   DeviceBuffer<uint16_t> ws_features_{MemTag::Network};  // [B][in_width]
   DeviceBuffer<uint16_t> ws_acts_{MemTag::Network};      // [(nh+1)][B][64]

@@ -203,7 +203,7 @@ void Network::build_layout()
   levels_dev_.upload(grid_.levels, kMaxLevels, Runtime::get().stream);
   VNR_HIP_CHECK(hipStreamSynchronize(Runtime::get().stream));
   // training state is allocated lazily on the first training step
-  opt_state_.release(); grads_.release();
+  opt_state_.release(); grads_.release(); grads_f32_.release();
   ws_batch_ = 0;
 }
 
@@ -517,7 +517,7 @@ void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipS
 
 size_t Network::bytes_allocated() const
 {
-  return brick_image_.bytes() + params_f16_.bytes() + mlp_packed_.bytes() + opt_state_.bytes() + grads_.bytes() + ws_features_.bytes() + ws_acts_.bytes() + ws_dfeat_.bytes() + ws_loss_.bytes();
+  return brick_image_.bytes() + params_f16_.bytes() + mlp_packed_.bytes() + opt_state_.bytes() + grads_.bytes() + grads_f32_.bytes() + ws_features_.bytes() + ws_acts_.bytes() + ws_dfeat_.bytes() + ws_loss_.bytes();
 }
 
 }  // namespace vnr

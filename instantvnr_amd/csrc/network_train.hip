@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
   }
 }
 
-// ------------------------------------------------------------------------------------------------ weight gradients (VALU, fp32 accumulate)
+// ------------------------------------------------------------------------------------------------ weight gradients
 // dW[out][in] = sum_b d[b][out] * x[b][in].  blockIdx.y selects the matrix: 0 = first layer (x = features),
 // 1..nh = hidden (x = acts[l-1]), nh+1 = last layer row 0 (d = dy, x = acts[nh]).
 struct WGradArgs {
@@ -313,82 +313,11 @@ struct WGradArgs {
   const half_t* acts;      // [(nh+1)][n][64]
   const half_t* d_all;     // [(nh+1)][n][64]
   const half_t* dy;        // [n]
-  float* grads;            // tcnn-order fp32 gradient blob
-  float* slab;             // MFMA kernel: [blocks][n_mlp] partial sums
+  float* slab;             // [blocks][n_mlp] partial sums (fp32), summed by weight_grad_reduce_kernel into the fp16 gradient blob
   uint32_t n, nh, in_width, n_mlp;
 };
 
-constexpr int kWgChunk = 128;
-
-template <int IN_T>  // compile-time padded input width of the matrices handled by this launch (16, 32, 64, 128)
-__global__ void __launch_bounds__(256) weight_grad_kernel(const WGradArgs args, uint32_t layer_lo, uint32_t sub_chunks)
-{
-  constexpr int IG = IN_T / 4;       // threads along the input dimension (4 inputs each)
-  constexpr int OG = 256 / IG;       // thread groups along the output dimension
-  constexpr int R = 64 / OG;         // output rows per thread
-  __shared__ __attribute__((aligned(16))) half_t sd[kWgChunk * 64];
-  __shared__ __attribute__((aligned(16))) half_t sx[kWgChunk * IN_T];
-  const uint32_t layer = layer_lo + blockIdx.y;
-  const uint32_t n = args.n, nh = args.nh;
-  // A block owns `sub_chunks` consecutive chunks of kWgChunk samples and adds its partial sums to the gradient blob
-  // ONCE: the arithmetic here is negligible, what the kernel pays for is float atomics from every block into the same
-  // 64 rows of 256 B (heavy contention, MI355X_MICROARCH.md "Global float atomics"), so fewer, larger partial sums win.
-  const uint32_t blk0 = blockIdx.x * kWgChunk * sub_chunks;
-  if (blk0 >= n) return;
-  const uint32_t blk_end = min(n, blk0 + kWgChunk * sub_chunks);
-
-  if (layer == nh + 1) {
-    // last layer: dWl[0][k] = sum_b dy[b] * a_nh[b][k]
-    const uint32_t k = threadIdx.x & 63u, sub = threadIdx.x >> 6;
-    float acc = 0.0f;
-    for (uint32_t b = blk0 + sub; b < blk_end; b += 4) acc += (float)args.dy[b] * (float)args.acts[((size_t)nh * n + b) * 64 + k];
-    atomicAdd(&args.grads[(size_t)kWidth * args.in_width + (size_t)nh * 4096 + k], acc);
-    return;
-  }
-  const uint32_t in_w = layer == 0 ? args.in_width : 64u;
-  const uint32_t ig = threadIdx.x % IG, og = threadIdx.x / IG;
-  float acc[R][4];
-#pragma unroll
-  for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[rr][c] = 0.0f;
-  for (uint32_t b0 = blk0; b0 < blk_end; b0 += kWgChunk) {
-    const uint32_t nb = min((uint32_t)kWgChunk, blk_end - b0);
-    const half_t* dsrc = args.d_all + ((size_t)layer * n + b0) * 64;
-    const half_t* xsrc = layer == 0 ? args.features + (size_t)b0 * args.in_width : args.acts + ((size_t)(layer - 1) * n + b0) * 64;
-    if (b0 != blk0) __syncthreads();  // the previous chunk has been consumed
-    // stage the chunk (row-major, zero padded to IN_T columns)
-    for (uint32_t e = threadIdx.x; e < nb * 8; e += 256) ((uint4_t*)sd)[e] = ((const uint4_t*)dsrc)[e];
-    for (uint32_t e = threadIdx.x; e < nb * (IN_T / 8); e += 256) {
-      const uint32_t b = e / (IN_T / 8), c = e % (IN_T / 8);
-      uint4_t v = {0, 0, 0, 0};
-      if (c * 8 < in_w) v = *(const uint4_t*)(xsrc + (size_t)b * in_w + c * 8);
-      ((uint4_t*)sx)[e] = v;
-    }
-    __syncthreads();
-    for (uint32_t b = 0; b < nb; ++b) {
-      const half4_t xv = *(const half4_t*)(sx + b * IN_T + ig * 4);
-      half_t dv[R];
-#pragma unroll
-      for (int rr = 0; rr < R; ++rr) dv[rr] = sd[b * 64 + og * R + rr];
-#pragma unroll
-      for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[rr][c] = __builtin_fmaf((float)dv[rr], (float)xv[c], acc[rr][c]);
-    }
-  }
-  float* g = args.grads + (layer == 0 ? 0 : (size_t)kWidth * args.in_width + (size_t)(layer - 1) * 4096);
-#pragma unroll
-  for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const uint32_t col = ig * 4 + c;
-      if (col < in_w) atomicAdd(&g[(size_t)(og * R + rr) * in_w + col], acc[rr][c]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ weight gradients (MFMA)
-// The same sums on the matrix cores: dW^T is a [64 x in] product whose reduction dimension is the BATCH, so both operands are needed
+// On the matrix cores: dW^T is a [64 x in] product whose reduction dimension is the BATCH, so both operands are needed
 // transposed ([neuron][sample] with 8 consecutive samples per lane) while the forward / backward kernels leave them row-major
 // [sample][64].  A block stages 64 samples of d and x row-major in LDS (rows padded to a stride of 64 + 8 halves: lanes r = 0..31 of
 // a transposed read touch 16 consecutive dwords, the two lane halves rows 8 apart = 32 banks apart); every wave owns 32 x 32
@@ -532,10 +461,10 @@ __global__ void __launch_bounds__(256) weight_grad_mfma_kernel(const WGradArgs a
   }
 }
 
-// grads[p] += sum over the blocks' partial sums, in block order: the MLP's gradient no longer depends on the order in which atomics
+// grads[p] += sum over the blocks' partial sums, in block order: the MLP's gradient does not depend on the order in which atomics
 // arrive.  (Float atomics of every block into the same 64 rows run at a fourteenth of the atomic rate, MI355X_MICROARCH.md "Global
 // float atomics", contention row: 128 blocks x 16 KB per matrix took longer than the products.)
-__global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const float* __restrict__ slab, uint32_t n_blocks, uint32_t n_mlp, float* __restrict__ grads)
+__global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const float* __restrict__ slab, uint32_t n_blocks, uint32_t n_mlp, half_t* __restrict__ grads)
 {
   // 64 parameters x 4 interleaved groups of slab rows per block, 16 loads in flight per thread: the sum is short, its loads' latency is all it costs
   __shared__ float part[4][64];
@@ -555,50 +484,24 @@ __global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const float* __
   }
   part[g][tx] = acc;
   __syncthreads();
-  if (g == 0 && p < n_mlp) grads[p] += (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+  // the sum over the batch in fp32, rounded to the gradient's half precision once (tcnn's gradient matrices are __half)
+  if (g == 0 && p < n_mlp) grads[p] = (half_t)((float)grads[p] + ((part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx])));
 }
 
 // ------------------------------------------------------------------------------------------------ grid backward
-// EXTERNAL tcnn kernel_grid_backward: for every (sample, level): grad[idx*F+f] += w * dL/dfeature[f].
+// EXTERNAL tcnn kernel_grid_backward: for every (sample, level): grad[idx*F+f] += w * dL/dfeature[f], accumulated in HALF precision
+// with packed atomics as tcnn does for F > 1 (grad_t = __half, atomicAdd(__half2)); F = 1 (tcnn: float atomics) uses the same packed
+// atomic with a zero in the other half of the aligned pair.
+// lane = (sample, x bit, feature pair).  Memory-side float atomics are priced per 64-byte REQUEST, whatever the request carries
+// (MI355X_MICROARCH.md "Global float atomics"; measured here: one lane per sample and dword 0.846 ms, (sample, feature) lanes 0.425,
+// with the x bit 0.242, packed fp16 pairs 0.242: DESIGN.md 4.3), so what matters is that the lanes of one entry pair are adjacent:
+// the x-neighbour of a corner is the adjacent table entry on dense levels and, for even x, on hashed levels ((x+1)^h = (x^h)^1).
+// Every lane repeats the (cheap) index arithmetic of its sample.
 template <int F>
 __global__ void grid_backward_kernel(const GridDevice grid, const float* __restrict__ coords, const half_t* __restrict__ dfeat,
-                                     uint32_t n, uint32_t in_width, float* __restrict__ grid_grads, uint32_t level0)
+                                     uint32_t n, uint32_t in_width, half_t* __restrict__ grid_grads, uint32_t level0)
 {
-  // lane = (sample, feature): the F features of a table entry are adjacent in memory, so F adjacent lanes add to one
-  // contiguous 4F-byte segment in ONE wave-instruction.  Global float atomics are priced per memory-side request, and
-  // 64 lanes on 64 unrelated addresses is their slowest shape (MI355X_MICROARCH.md "Global float atomics": 0.08 TB/s of
-  // added bytes, which is what the one-lane-per-sample form of this kernel ran at: 16.8 M adds in 0.846 ms at C4).
-  // Every lane repeats the (cheap) index arithmetic of its sample; the adds and their values are unchanged.
-  // Measured at C4 (F = 2): (sample, feature) lanes, i.e. 8-byte segments: 0.846 -> 0.425 ms.  The x-neighbour of a corner
-  // is the adjacent table entry on dense levels and, for even x, on hashed levels ((x+1)^h = (x^h)^1), so the lane also
-  // carries the corner's x bit: 2F adjacent lanes then add to one 8F-byte segment where the entries are adjacent.
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  constexpr uint32_t kLanesPerSample = 2u * (uint32_t)F;
-  const uint32_t i = t / kLanesPerSample, r = t % kLanesPerSample;
-  const uint32_t xb = r / (uint32_t)F, f = r % (uint32_t)F;
-  if (i >= n) return;
-  const uint32_t level = level0 + blockIdx.y;
-  const LevelInfo lv = grid.levels[level];
-  const float g = (float)dfeat[(size_t)i * in_width + level * F + f];
-  if (g == 0.0f) return;
-  const CornerSetup c = level_setup(lv, grid.interpolation, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
-  float* base = grid_grads + (size_t)lv.offset * F + f;
-#pragma unroll
-  for (int yz = 0; yz < 4; ++yz) {
-    const int corner = (int)xb | (yz << 1);
-    const uint32_t idx = level_index(lv, c.g[0] + xb, c.g[1] + (uint32_t)(yz & 1), c.g[2] + (uint32_t)(yz >> 1));
-    atomicAdd(&base[(size_t)idx * F], corner_weight(c, corner) * g);
-  }
-}
-
-// TIMING PROBE (VNR_AMD_GRID_BWD_PK=1, tools/dp_probe.py): the scatter with one packed fp16 atomic per pair of features into a
-// half-precision gradient array (what tcnn does for F > 1: grad_t = __half, atomicAdd(__half2)).  It writes fp16 pairs over the
-// fp32 gradient blob, so a step run with it trains on garbage: the switch exists to price the design, nothing else reads it.
-template <int F>
-__global__ void grid_backward_pk_probe_kernel(const GridDevice grid, const float* __restrict__ coords, const half_t* __restrict__ dfeat,
-                                              uint32_t n, uint32_t in_width, half_t* __restrict__ grid_grads, uint32_t level0)
-{
-  constexpr uint32_t P = (uint32_t)F / 2u;          // packed pairs per entry
+  constexpr uint32_t P = F >= 2 ? (uint32_t)F / 2u : 1u;   // packed pairs per entry
   constexpr uint32_t kLanesPerSample = 2u * P;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t i = t / kLanesPerSample, r = t % kLanesPerSample;
@@ -606,35 +509,49 @@ __global__ void grid_backward_pk_probe_kernel(const GridDevice grid, const float
   if (i >= n) return;
   const uint32_t level = level0 + blockIdx.y;
   const LevelInfo lv = grid.levels[level];
-  const half2_t g2 = *(const half2_t*)(dfeat + (size_t)i * in_width + level * F + f);
-  const float g0 = (float)g2[0], g1 = (float)g2[1];
+  float g0, g1 = 0.0f;
+  if constexpr (F >= 2) {
+    const half2_t g2 = *(const half2_t*)(dfeat + (size_t)i * in_width + level * F + f);
+    g0 = (float)g2[0]; g1 = (float)g2[1];
+  } else {
+    g0 = (float)dfeat[(size_t)i * in_width + level];
+  }
   if (g0 == 0.0f && g1 == 0.0f) return;
   const CornerSetup c = level_setup(lv, grid.interpolation, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
-  half_t* base = grid_grads + (size_t)lv.offset * F + f;
+  half_t* base = grid_grads + (size_t)lv.offset * F + (F >= 2 ? f : 0u);
 #pragma unroll
   for (int yz = 0; yz < 4; ++yz) {
     const int corner = (int)xb | (yz << 1);
     const uint32_t idx = level_index(lv, c.g[0] + xb, c.g[1] + (uint32_t)(yz & 1), c.g[2] + (uint32_t)(yz >> 1));
     const float w = corner_weight(c, corner);
-    const half2_t v = {(half_t)(w * g0), (half_t)(w * g1)};
-    half_t* addr = base + (size_t)idx * F;
+    half2_t v;
+    half_t* addr;
+    if constexpr (F >= 2) {
+      v = half2_t{(half_t)(w * g0), (half_t)(w * g1)};
+      addr = base + (size_t)idx * F;
+    } else {   // the entry's half of its aligned pair (level offsets are even: level sizes are multiples of 8 entries)
+      const half_t h = (half_t)(w * g0), z = (half_t)0.0f;
+      v = (idx & 1u) ? half2_t{z, h} : half2_t{h, z};
+      addr = base + (size_t)(idx & ~1u);
+    }
     asm volatile("global_atomic_pk_add_f16 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
   }
 }
 
 // ------------------------------------------------------------------------------------------------ Adam
-// EXTERNAL tcnn adam_step (optimizers/adam.h): see header comment.  Also clears the gradient for the next step.
-// Measured split at C4 (70 M parameters, tools/adam_probe.py): the sweep over all gradients alone 0.15 ms, the ~10 M touched
-// parameters of a 65 536-sample batch 0.44 ms with master / m / v / step in four arrays.  Hence one 16-byte record per
-// parameter (OptState), and no zero written over a gradient that is already zero.
-__global__ void adam_kernel(size_t lo, size_t n_total, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float log2_beta1,
+// EXTERNAL tcnn adam_step (optimizers/adam.h): see header comment.  Parameters [lo, hi); also clears the gradient for the next step.
+// Measured split at C4 (70 M parameters, tools/adam_probe.py, with the fp32 gradient blob of round 1): the sweep over all gradients
+// alone 0.15 ms, the ~10 M touched parameters of a 65 536-sample batch 0.44 ms with master / m / v / step in four arrays.  Hence one
+// 16-byte record per parameter (OptState), and no zero written over a gradient that is already zero.
+__global__ void adam_kernel(size_t lo, size_t hi, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float log2_beta1,
                             float log2_beta2, float epsilon, float l2_reg, OptState* __restrict__ state, half_t* __restrict__ params,
-                            float* __restrict__ grads)
+                            half_t* __restrict__ grads)
 {
-  const size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // parameters [lo, n_total)
-  if (i >= n_total) return;
-  const float raw = grads[i];
-  if (raw != 0.0f) grads[i] = 0.0f;
+  const size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  const half_t raw_h = grads[i];
+  const float raw = (float)raw_h;
+  if (raw != 0.0f) grads[i] = (half_t)0.0f;
   float gradient = raw * grad_mul;
   if (i >= n_matrix && gradient == 0.0f) return;  // untouched hash-grid entries are skipped entirely
   OptState st = state[i];
@@ -654,62 +571,10 @@ __global__ void adam_kernel(size_t lo, size_t n_total, size_t n_matrix, float gr
   params[i] = (half_t)nw;
 }
 
-// Data-parallel variant (volume.hip train_data_parallel): parameters [lo, hi) only, gradient = the all-reduced fp16 copy
-// (sum over ranks; grad_mul carries 1 / (world * loss_scale)).  The fp32 blob was cleared when the copy was made.
-__global__ void adam_range_f16_kernel(size_t lo, size_t hi, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float log2_beta1,
-                                      float log2_beta2, float epsilon, float l2_reg, OptState* __restrict__ state, half_t* __restrict__ params,
-                                      const half_t* __restrict__ grads)
+// fp16 gradient blob -> a float copy (vnrAmdNeuralVolumeGradients: inspection and tests)
+__global__ void unpack_grads_f16_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n)
 {
-  const size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= hi) return;
-  float gradient = (float)grads[i] * grad_mul;
-  if (i >= n_matrix && gradient == 0.0f) return;
-  OptState st = state[i];
-  const float w = st.master;
-  if (i < n_matrix) gradient += l2_reg * w;
-  const float m = st.m = beta1 * st.m + (1.0f - beta1) * gradient;
-  const float v = st.v = beta2 * st.v + (1.0f - beta2) * (gradient * gradient);
-  const uint32_t step = ++st.step;
-  const float fs = (float)step;
-  const float lr_t = lr * sqrtf(1.0f - __builtin_amdgcn_exp2f(fs * log2_beta2)) / (1.0f - __builtin_amdgcn_exp2f(fs * log2_beta1));
-  const float eff = lr_t / (sqrtf(v) + epsilon);
-  const float nw = w - eff * m;
-  st.master = nw;
-  state[i] = st;
-  params[i] = (half_t)nw;
-}
-
-// fp32 gradient range -> fp16 exchange payload, clearing the fp32 range for the next step (4 elements per thread; lo and
-// hi - lo are multiples of 4 for every range forward_backward reports: level sizes are multiples of 8 entries)
-__global__ void pack_grads_f16_kernel(float* __restrict__ grads, half_t* __restrict__ out, size_t n4)
-{
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const float4_t g = ((const float4_t*)grads)[i];
-    ((half4_t*)out)[i] = half4_t{(half_t)g.x, (half_t)g.y, (half_t)g.z, (half_t)g.w};
-    if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) ((float4_t*)grads)[i] = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
-  }
-}
-void launch_pack_grads_f16(float* grads, uint16_t* out, size_t n, hipStream_t s)
-{
-  if (n % 4) throw std::runtime_error("internal: gradient range is not a multiple of 4 elements");
-  const size_t n4 = n / 4;
-  pack_grads_f16_kernel<<<(uint32_t)std::min<size_t>((n4 + 255) / 256, 8192), 256, 0, s>>>(grads, (half_t*)out, n4);
-  VNR_HIP_CHECK(hipGetLastError());
-}
-
-__global__ void unpack_grads_f16_kernel(const half_t* __restrict__ in, float* __restrict__ grads, size_t n4)
-{
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const half4_t h = ((const half4_t*)in)[i];
-    if (h.x != (half_t)0.0f || h.y != (half_t)0.0f || h.z != (half_t)0.0f || h.w != (half_t)0.0f)   // the fp32 blob was cleared by the pack
-      ((float4_t*)grads)[i] = float4_t{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
-  }
-}
-void launch_unpack_grads_f16(const uint16_t* in, float* grads, size_t n, hipStream_t s)
-{
-  const size_t n4 = n / 4;
-  unpack_grads_f16_kernel<<<(uint32_t)std::min<size_t>((n4 + 255) / 256, 8192), 256, 0, s>>>((const half_t*)in, grads, n4);
-  VNR_HIP_CHECK(hipGetLastError());
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -806,57 +671,31 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   profile_mark(2, s);
   WGradArgs wa;
   wa.features = (const half_t*)ws_features_.ptr; wa.acts = (const half_t*)ws_acts_.ptr; wa.d_all = (const half_t*)ts.d_all.ptr;
-  wa.dy = (const half_t*)ts.dy.ptr; wa.grads = grads_.ptr; wa.n = n; wa.nh = nh; wa.in_width = in_width_;
+  wa.dy = (const half_t*)ts.dy.ptr; wa.n = n; wa.nh = nh; wa.in_width = in_width_;
   {
-    // Chunks of kWgChunk samples a block sums before its atomics.  Measured at batch 65 536 (both launches together):
-    // 1 chunk (512 blocks per matrix) 0.209 ms, 2: 0.128, 4 (128 blocks): 0.102, 8: 0.119, 16: 0.207, 32: 0.407 --
-    // contention on the 64 gradient rows falls with the block count until too few blocks are left to fill the GPU.
-    // Default: about 128 blocks per matrix.  VNR_AMD_WGRAD_SUBCHUNKS (1..64) overrides, for diagnostics.
-    static const int forced = [] {
-      const char* e = std::getenv("VNR_AMD_WGRAD_SUBCHUNKS");
-      const int v = e ? std::atoi(e) : 0;
-      return v >= 1 && v <= 64 ? v : 0;
-    }();
-    static const bool valu = [] { const char* e = std::getenv("VNR_AMD_WGRAD_VALU"); return e && e[0] == '1'; }();   // diagnostics: the VALU kernel
-    if (valu || in_width_ % 8 != 0 || in_width_ > 128) {
-      const uint32_t sub_chunks = forced ? (uint32_t)forced : std::min<uint32_t>(8u, std::max<uint32_t>(1u, (uint32_t)(batch / (128u * kWgChunk))));
-      const uint32_t nblk = div_round_up(batch, (uint64_t)kWgChunk * sub_chunks);
-      const dim3 g1(nblk, 1);
-      if (in_width_ <= 16) weight_grad_kernel<16><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
-      else if (in_width_ <= 32) weight_grad_kernel<32><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
-      else if (in_width_ <= 64) weight_grad_kernel<64><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
-      else weight_grad_kernel<128><<<g1, 256, 0, s>>>(wa, 0, sub_chunks);
-      const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
-      weight_grad_kernel<64><<<g2, 256, 0, s>>>(wa, 1, sub_chunks);
-    } else {
-      // MFMA kernel: a block per 256 samples and matrix
-      const uint32_t nblk = div_round_up(batch, (uint64_t)(kWgStage * kWgStages));
-      if (ts.wgrad_slab.count < (size_t)nblk * n_mlp_) {   // elements no block writes (padded rows of the last layer) stay zero
-        ts.wgrad_slab.resize((size_t)nblk * n_mlp_);
-        ts.wgrad_slab.zero(s);
-      }
-      wa.slab = ts.wgrad_slab.ptr; wa.n_mlp = (uint32_t)n_mlp_;
-      const dim3 g1(nblk, 1);
-      if (in_width_ <= 32) weight_grad_mfma_kernel<1><<<g1, 256, 0, s>>>(wa, 0);
-      else if (in_width_ <= 64) weight_grad_mfma_kernel<2><<<g1, 256, 0, s>>>(wa, 0);
-      else weight_grad_mfma_kernel<4><<<g1, 256, 0, s>>>(wa, 0);
-      const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
-      weight_grad_mfma_kernel<2><<<g2, 256, 0, s>>>(wa, 1);
-      weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, s>>>(ts.wgrad_slab.ptr, nblk, (uint32_t)n_mlp_, grads_.ptr);
+    // a block per 256 samples and matrix (padded_width is a multiple of 16 and at most 128: every model of the MFMA kernels)
+    if (in_width_ % 8 != 0 || in_width_ > 128) throw std::runtime_error("internal: weight gradients of an input width the MFMA kernel does not cover");
+    const uint32_t nblk = div_round_up(batch, (uint64_t)(kWgStage * kWgStages));
+    if (ts.wgrad_slab.count < (size_t)nblk * n_mlp_) {   // elements no block writes (padded rows of the last layer) stay zero
+      ts.wgrad_slab.resize((size_t)nblk * n_mlp_);
+      ts.wgrad_slab.zero(s);
     }
+    wa.slab = ts.wgrad_slab.ptr; wa.n_mlp = (uint32_t)n_mlp_;
+    const dim3 g1(nblk, 1);
+    if (in_width_ <= 32) weight_grad_mfma_kernel<1><<<g1, 256, 0, s>>>(wa, 0);
+    else if (in_width_ <= 64) weight_grad_mfma_kernel<2><<<g1, 256, 0, s>>>(wa, 0);
+    else weight_grad_mfma_kernel<4><<<g1, 256, 0, s>>>(wa, 0);
+    const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
+    weight_grad_mfma_kernel<2><<<g2, 256, 0, s>>>(wa, 1);
+    weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, s>>>(ts.wgrad_slab.ptr, nblk, (uint32_t)n_mlp_, (half_t*)grads_.ptr);
   }
   profile_mark(3, s);
   if (exchange) exchange->range_ready(0, n_mlp_, s);   // the MLP's gradient travels while the grid backward runs
   // 5. hash-grid backward: levels [l0, l1) per launch (blockIdx.y + l0 = level)
   auto grid_backward = [&](uint32_t l0, uint32_t l1) {
-    const dim3 g(div_round_up((uint64_t)batch * cfg_.n_features * 2, 256), l1 - l0);  // one lane per (sample, x bit, feature)
-    float* gg = grads_.ptr + n_mlp_;
-    static const bool pk_probe = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_PK"); return e && e[0] == '1'; }();
-    if (pk_probe && cfg_.n_features == 2) {
-      const dim3 gp(div_round_up((uint64_t)batch * 2, 256), l1 - l0);
-      grid_backward_pk_probe_kernel<2><<<gp, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, (half_t*)gg, l0);
-      return;
-    }
+    const uint32_t pairs = cfg_.n_features >= 2 ? cfg_.n_features / 2 : 1u;
+    const dim3 g(div_round_up((uint64_t)batch * pairs * 2, 256), l1 - l0);  // one lane per (sample, x bit, feature pair)
+    half_t* gg = (half_t*)grads_.ptr + n_mlp_;
     switch (cfg_.n_features) {
     case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
     case 2: grid_backward_kernel<2><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
@@ -900,19 +739,28 @@ void Network::optimizer_step(float grad_scale, hipStream_t s)
   adam_kernel<<<div_round_up(n_params_, 256), 256, 0, s>>>(0, n_params_, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1,
                                                            cfg_.beta2, (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2),
                                                            cfg_.epsilon, cfg_.l2_reg, opt_state_.ptr,
-                                                           (half_t*)params_f16_.ptr, grads_.ptr);
+                                                           (half_t*)params_f16_.ptr, (half_t*)grads_.ptr);
   VNR_HIP_CHECK(hipGetLastError());
   optimizer_finish_step(s);
 }
 
-void Network::optimizer_step_range(size_t lo, size_t hi, const uint16_t* d_grads_f16, float grad_scale, hipStream_t s)
+void Network::optimizer_step_range(size_t lo, size_t hi, float grad_scale, hipStream_t s)
 {
-  if (opt_state_.count != n_params_) throw std::runtime_error("optimizer_step_range before forward_backward");
+  if (opt_state_.count != n_params_ || grads_.count != n_params_) throw std::runtime_error("optimizer_step_range before forward_backward");
   if (hi > n_params_ || lo >= hi) throw std::runtime_error("optimizer_step_range: invalid parameter range");
-  adam_range_f16_kernel<<<div_round_up(hi - lo, 256), 256, 0, s>>>(lo, hi, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1, cfg_.beta2,
-                                                                  (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2), cfg_.epsilon,
-                                                                  cfg_.l2_reg, opt_state_.ptr, (half_t*)params_f16_.ptr, (const half_t*)d_grads_f16);
+  adam_kernel<<<div_round_up(hi - lo, 256), 256, 0, s>>>(lo, hi, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1, cfg_.beta2,
+                                                        (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2), cfg_.epsilon,
+                                                        cfg_.l2_reg, opt_state_.ptr, (half_t*)params_f16_.ptr, (half_t*)grads_.ptr);
   VNR_HIP_CHECK(hipGetLastError());
+}
+
+float* Network::grads_as_f32(hipStream_t s)
+{
+  if (grads_.count != n_params_) throw std::runtime_error("no gradient yet: call forward_backward / TrainBegin first");
+  grads_f32_.ensure(n_params_);
+  unpack_grads_f16_kernel<<<(uint32_t)std::min<size_t>((n_params_ + 255) / 256, 8192), 256, 0, s>>>((const half_t*)grads_.ptr, grads_f32_.ptr, n_params_);
+  VNR_HIP_CHECK(hipGetLastError());
+  return grads_f32_.ptr;
 }
 
 void Network::optimizer_finish_step(hipStream_t s)

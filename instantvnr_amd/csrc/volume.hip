@@ -646,7 +646,6 @@ static void reduce_errors(const float* pred, const float* ref, size_t n, bool l2
 // ================================================================================================ NeuralVolume
 void network_release_scratch(const Network* n);
 
-void launch_pack_grads_f16(float* grads, uint16_t* out, size_t n, hipStream_t s);
 
 // value ranges are stored as (min - 1, max + 1) with 0 = "nothing seen yet" (macrocell.cu:35-39, 213-219): min - 1 <= 0 and
 // max + 1 >= 1, so the element-wise MIN over ranks of .x and MAX of .y merge the ranks' macrocells, untouched cells included
@@ -658,8 +657,7 @@ __global__ void macrocell_merge_kernel(vec2f* __restrict__ range_max_reduced, co
 
 struct NeuralVolume::DpState : GradExchange {
   NeuralVolume* nv = nullptr;
-  DeviceBuffer<uint16_t> grads_f16{MemTag::Network};   // the exchange payload, indexed like the parameter blob
-  struct Range { size_t lo, hi; hipEvent_t packed, reduced; };
+  struct Range { size_t lo, hi; hipEvent_t packed, reduced; };   // packed: the range's gradient is final on the compute stream
   std::vector<Range> ranges;     // this step's ranges in the order they became ready
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // events, reused step after step
   hipEvent_t ev_updated = nullptr;   // the optimizer has consumed the payload of the previous step
@@ -682,10 +680,10 @@ struct NeuralVolume::DpState : GradExchange {
     }
     Range r{lo, hi, pool[used].first, pool[used].second};
     ++used;
-    launch_pack_grads_f16(nv->net_.grads() + lo, grads_f16.ptr + lo, hi - lo, s);   // compute stream: overlaps the exchange of the range before
+    // the gradient blob IS the payload (fp16, in place): nothing to pack
     VNR_HIP_CHECK(hipEventRecord(r.packed, s));
     VNR_HIP_CHECK(hipStreamWaitEvent(comm, r.packed, 0));
-    d.transport().all_reduce(grads_f16.ptr + lo, hi - lo, DistDType::F16, DistOp::Sum, comm);
+    d.transport().all_reduce(nv->net_.grads_f16() + lo, hi - lo, DistDType::F16, DistOp::Sum, comm);
     VNR_HIP_CHECK(hipEventRecord(r.reduced, comm));
     ranges.push_back(r);
   }
@@ -784,18 +782,13 @@ void NeuralVolume::train(size_t steps, bool fast_mode)
 }
 
 // ------------------------------------------------------------------------------------------------ data-parallel training
-void launch_unpack_grads_f16(const uint16_t* in, float* grads, size_t n, hipStream_t s);
 
 void NeuralVolume::all_reduce_gradients()
 {
   Dist& d = Dist::get();
   if (!d.active() || !pending_step_) return;   // a one-rank group still runs the exchange (the identity): tests
   if (!dp_) { dp_.reset(new DpState()); dp_->nv = this; VNR_HIP_CHECK(hipEventCreateWithFlags(&dp_->ev_updated, hipEventDisableTiming)); }
-  const size_t n = net_.n_params();
-  dp_->grads_f16.ensure(n);
-  launch_pack_grads_f16(net_.grads(), dp_->grads_f16.ptr, n, stream);
-  d.transport().all_reduce(dp_->grads_f16.ptr, n, DistDType::F16, DistOp::Sum, stream);
-  launch_unpack_grads_f16(dp_->grads_f16.ptr, net_.grads(), n, stream);
+  d.transport().all_reduce(net_.grads_f16(), net_.n_params(), DistDType::F16, DistOp::Sum, stream);
 }
 
 void NeuralVolume::sync_replicas()
@@ -823,7 +816,6 @@ void NeuralVolume::train_data_parallel(size_t steps, bool fast_mode)
   if (!replicas_synced_) sync_replicas();
   if (!dp_) { dp_.reset(new DpState()); dp_->nv = this; VNR_HIP_CHECK(hipEventCreateWithFlags(&dp_->ev_updated, hipEventDisableTiming)); }
   DpState& dp = *dp_;
-  dp.grads_f16.ensure(net_.n_params());
   hipStream_t comm = d.comm_stream();
   const vec3f lower = {0, 0, 0}, upper = {1, 1, 1};
   const float scale = 1.0f / (float)d.world();
@@ -835,7 +827,7 @@ void NeuralVolume::train_data_parallel(size_t steps, bool fast_mode)
     // the update of a range waits for that range's exchange only: Adam of the first ranges runs while the last ones travel
     for (const DpState::Range& r : dp.ranges) {
       VNR_HIP_CHECK(hipStreamWaitEvent(stream, r.reduced, 0));
-      net_.optimizer_step_range(r.lo, r.hi, dp.grads_f16.ptr, scale, stream);
+      net_.optimizer_step_range(r.lo, r.hi, scale, stream);
     }
     net_.optimizer_finish_step(stream);
     const bool update_mc = !(fast_mode && mc_.is_external());

@@ -111,10 +111,12 @@ def test_data_parallel_training_on_several_ranks(world, tmp_path):
     hand = res[0]["params_by_hand"].view(np.float16).astype(np.float32)
     want, psnr_ref = _reference_concatenated(world, steps, syn.analytic_volume(32))
     moved = np.abs(want - _initial_params()).mean()
-    # float atomics (summation order) and the fp16 payload: same bar as the split-step test of the single-GPU path, relative to
-    # how far 20 steps move the parameters
-    assert np.abs(p - want).mean() < 0.02 * moved + 1e-5, (np.abs(p - want).mean(), moved)
-    assert np.abs(hand - want).mean() < 0.02 * moved + 1e-5
+    # Gradients are accumulated in half precision with packed atomics, as tcnn does (grid.h: grad_t = __half for F > 1): the one
+    # process adds world x 65 536 samples into these small tables in fp16, the ranks add 65 536 each and the exchange sums them in
+    # fp32, so the two differ by the rounding of a few thousand fp16 adds per entry (and by the order of the atomics).  Relative to
+    # how far 20 steps move the parameters: measured 1.6 % at world 2, 3.4 % at world 4 (< 2 % with the fp32 blob of round 1).
+    assert np.abs(p - want).mean() < 0.06 * moved + 1e-5, (np.abs(p - want).mean(), moved)
+    assert np.abs(hand - want).mean() < 0.06 * moved + 1e-5
     assert abs(float(res[0]["psnr"]) - psnr_ref) < 1.0
 
 

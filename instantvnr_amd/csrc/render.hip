@@ -1317,18 +1317,7 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   counters_.resize(2 * kMaxParts * C_COUNT);  // one block of counters per frame slot and half
   counters_.zero(stream_);
   VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 2 * kMaxParts * (256 + C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
-  {
-    // VNR_AMD_PART_PRIORITY=1 (experiment): the second ray part's stream gets the highest priority, so the two parts stop marching and
-    // evaluating in lock-step
-    static const int prio_mode = [] { const char* e = std::getenv("VNR_AMD_PART_PRIORITY"); return e ? std::atoi(e) : 0; }();
-    int lo = 0, hi = 0;
-    VNR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least, hi = greatest priority (numerically lower)
-    for (int i = 1; i < kMaxParts; ++i) {
-      const int prio = prio_mode == 1 ? hi : prio_mode == 2 ? lo : 0;
-      VNR_HIP_CHECK(hipStreamCreateWithPriority(&part_streams_[i], hipStreamNonBlocking, prio_mode ? prio : 0));
-    }
-    if (prio_mode) fprintf(stderr, "[vnr_amd] part stream priority %d (range least %d .. greatest %d)\n", prio_mode == 1 ? hi : lo, lo, hi);
-  }
+  for (int i = 1; i < kMaxParts; ++i) VNR_HIP_CHECK(hipStreamCreateWithFlags(&part_streams_[i], hipStreamNonBlocking));
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 }
 

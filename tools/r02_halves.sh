@@ -2,6 +2,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r02_halves; mkdir -p $O
 cd $R
-for pr in 0 1 2 0 1 2; do
-  VNR_AMD_PART_PRIORITY=$pr timeout -k 10 200 python bench.py --no-cpu-baseline --no-psnr --no-alone --no-brick-off --train-steps 300 > $O/p$pr.json 2> $O/p$pr.err && python tools/bench_line.py prio$pr < $O/p$pr.json; grep "part stream" $O/p$pr.err | head -1
+for st in 0 1 0 1; do
+  VNR_AMD_STAGGER=$st timeout -k 10 200 python bench.py --no-cpu-baseline --no-psnr --no-alone --no-brick-off --train-steps 300 > $O/s$st.json 2> $O/s$st.err && python tools/bench_line.py stagger$st < $O/s$st.json
 done
+for st in 0 1; do echo "stagger $st: $(VNR_AMD_STAGGER=$st SHARE_PARTS=8 SHARE_PIPELINED=1 timeout -k 10 200 python tools/share_probe.py 2>&1 | grep 'share 1/')"; done

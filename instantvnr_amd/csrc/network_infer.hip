@@ -87,6 +87,7 @@ struct InferArgs {
   uint32_t activation;       // 0 none, 1 relu
   uint32_t lds_halves;
   uint32_t sharers;          // kernels of this kind expected to share the GPU (host-side launch sizing only)
+  uint32_t lds_table_halves; // VNR_LDS_LEVELS experiment: halves of the table's head staged behind the weights (0: none)
 };
 
 // MODE 0: inference (out only), 1: encode only (features_out), 2: training forward (features + acts + out)
@@ -113,6 +114,13 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
     const uint4_t* src = (const uint4_t*)args.packed_mlp;
     uint4_t* dst = (uint4_t*)lds;
     for (uint32_t i = threadIdx.x; i < args.lds_halves / 8; i += blockDim.x) dst[i] = src[i];
+#if defined(VNR_LDS_LEVELS)
+    {
+      const uint4_t* ts = (const uint4_t*)args.table;
+      uint4_t* td = (uint4_t*)(lds + args.lds_halves);
+      for (uint32_t i = threadIdx.x; i < args.lds_table_halves / 8; i += blockDim.x) td[i] = ts[i];
+    }
+#endif
     __syncthreads();
   }
   const uint32_t nh = args.n_hidden_matmuls;
@@ -137,7 +145,12 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
 
     // ---- encode: lane = sample, level wave-uniform (infer_tile.h) -----------------------------------
     half8_t feat[NCHUNK];
+#if defined(VNR_LDS_LEVELS)
+    encode_tile<F, K_IN>(args.levels, args.n_levels, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, feat,
+                         args.lds_table_halves ? (const half_t*)lds + args.lds_halves : nullptr);
+#else
     encode_tile<F, K_IN>(args.levels, args.n_levels, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, feat);
+#endif
 
     if (MODE != 0 && args.features_out && i < n) {
       half8_t* dst = (half8_t*)(args.features_out + (size_t)i * K_IN);
@@ -181,7 +194,7 @@ static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
   if (!forced && a.n_ptr && a.queue_mode) max_blocks = std::min((uint32_t)rt.n_cus * 32u, std::max((uint32_t)rt.n_cus * 4u, n_tiles / 33u));
   if (blocks > max_blocks) blocks = max_blocks;
   blocks = next_multiple(blocks, 8);
-  const size_t shmem = MODE == 1 ? 16 : (size_t)a.lds_halves * sizeof(uint16_t);
+  const size_t shmem = MODE == 1 ? 16 : ((size_t)a.lds_halves + a.lds_table_halves) * sizeof(uint16_t);
   auto kernel = fused_infer_kernel<F, K_IN, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -348,6 +361,11 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
   a.n_hidden_matmuls = n_hidden_matmuls;
   a.activation = activation;
   a.lds_halves = lds_halves;
+  a.lds_table_halves = 0;
+#if defined(VNR_LDS_LEVELS)
+  if (mode == 0 && grid.n_features == 2 && grid.n_levels > VNR_LDS_LEVELS && !grid.levels[VNR_LDS_LEVELS - 1].hashed)
+    a.lds_table_halves = (grid.levels[VNR_LDS_LEVELS].offset * 2u + 7u) & ~7u;   // the first levels are the head of the table
+#endif
   if (mode == 0) dispatch<0>(grid.n_features, in_width, a, n_max, s);
   else if (mode == 1) dispatch<1>(grid.n_features, in_width, a, n_max, s);
   else dispatch<2>(grid.n_features, in_width, a, n_max, s);

@@ -56,7 +56,7 @@ def parse():
     p.add_argument("--no-alone", action="store_true", help="skip the un-timed one-stream leg (roofline.alone)")
     p.add_argument("--no-brick-off", action="store_true", help="skip the un-timed leg without the brick image (train-while-render configuration)")
     p.add_argument("--no-kernel-events", action="store_true", help="diagnostics: no HIP events around the evaluation kernel (roofline.achieved reads 0)")
-    p.add_argument("--mode", type=int, default=5, choices=(5, 6, 8, 9, 11, 12, 14),
+    p.add_argument("--mode", type=int, default=5, choices=(5, 6, 8, 9, 11, 12, 14, 15),
                    help="rendering mode: 5 = sample streaming (BASELINE metric, default), 8 = the same with gradient shading (4 evaluations per sample)")
     return p.parse_args()
 

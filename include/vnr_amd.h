@@ -270,10 +270,11 @@ int  vnrAmdRendererSetProfiling(vnrAmdRenderer, int enable);
  * predicted iterations are enqueued and vnrAmdRendererMapFrame / GetFrameStats / the next vnrAmdRender complete it.  The caller
  * must not change the volume between Render and MapFrame.  Off by default. */
 int  vnrAmdRendererSetAsync(vnrAmdRenderer, int enable);
-/* rendering modes 6 / 9 / 12 (VNR_RAYMARCHING_*_IN_SHADER, api.h:45,49,53) on a neural volume: 1 = the reference's execution strategy, one
- * launch per frame with the network evaluated inside the marching loop (method_raymarching.cu:981-1249), 0 = the sample-streaming path,
- * -1 = env VNR_AMD_IN_SHADER (default 0: measured 2 x slower than streaming on a whole frame and 2.8 x on a 1/8 share).
- * The frames agree up to the streaming path's resume rounding. */
+/* Execution strategy of rendering modes 6 / 9 / 12 (ray marching) and 14 / 15 (path tracing) on a neural volume: 1 = in shader, one
+ * launch per frame with the network evaluated inside the marching / tracking loop (method_raymarching.cu:981-1249,
+ * method_pathtracing.cu:968-1025), 0 = sample streaming, -1 (default) = env VNR_AMD_IN_SHADER or, without it, the faster one for the
+ * mode as measured: ray marching streams (in shader is 2 x slower on a whole frame), path tracing runs in shader
+ * (1.25 x faster).  Same frames either way: bit for bit for path tracing, up to the streaming path's resume rounding for ray marching. */
 int  vnrAmdRendererSetInShaderKernel(vnrAmdRenderer, int mode);
 /* diagnostics: device pointers to the compacted sample queue ([n][3] fp32) and the counter block, plus the
  * per-iteration duration (ms) of the sample-evaluation kernel in the last profiled frame */

@@ -1,4 +1,4 @@
-// in_shader.h — the in-shader ray marcher (rendering modes 6, 9, 12 on a neural volume).  Part of render.hip's translation unit
+// in_shader.h — the in-shader ray marcher (rendering modes 6, 9, 12) and path tracer (mode 15) on a neural volume.  Part of render.hip's translation unit
 // (included there: it uses RenderParams and the marcher's device helpers), kept in a file of its own for reading.
 //
 // Reference: network_raymarching_traceray / _transmittance / _iterator (core/renderer/method_raymarching.cu:310-356, 981-1128) with
@@ -207,6 +207,85 @@ __global__ void __launch_bounds__(256) in_shader_kernel(const RenderParams p, co
   if (valid) write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
 
   // statistics: per block, then one add per block on one of kInShaderStatSlots addresses
+  const uint32_t hits = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+  if (lane == 0) { s_stat[2 * wave] = (uint32_t)n_samples; s_stat[2 * wave + 1] = (uint32_t)(n_samples >> 32); s_stat[8 + wave] = hits; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long s = 0; uint32_t h = 0;
+    for (int k = 0; k < 4; ++k) { s += (unsigned long long)s_stat[2 * k] | ((unsigned long long)s_stat[2 * k + 1] << 32); h += s_stat[8 + k]; }
+    const uint32_t slot = blockIdx.x % (uint32_t)kInShaderStatSlots;
+    if (s) atomicAdd(&stat_samples[slot], s);
+    if (h) atomicAdd(&stat_hits[slot], h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ path tracing in shader (mode 15)
+// network_path_tracing_traceray (core/renderer/method_pathtracing.cu:968-1025): the delta-tracking estimator with the network sampled
+// inside the loop.  Per lane it is the streaming path tracer's own chain of decisions (pt_take_sample -> evaluate -> pt_shade,
+// with p.pt_reset_interval = 1: DESIGN.md 7), so a path consumes the same random numbers and the frame is the streaming path's
+// frame bit for bit; what changes is that the 60-odd iterations of a frame are trips of ONE launch instead of 3 launches each.
+constexpr int kInShaderPathTracing = 4;   // render_in_shader's `shade` argument beside M_NONE / M_GRADIENT / M_SSH
+
+template <int F, int K_IN>
+__global__ void __launch_bounds__(256) in_shader_pt_kernel(const RenderParams p, const TileNet net, unsigned long long* __restrict__ stat_samples,
+                                                           uint32_t* __restrict__ stat_hits)
+{
+  extern __shared__ __attribute__((aligned(16))) half_t lds[];
+  __shared__ uint32_t s_stat[2 * 4 + 4];
+  {
+    const uint4_t* src = (const uint4_t*)net.packed_mlp;
+    uint4_t* dst = (uint4_t*)lds;
+    for (uint32_t i = threadIdx.x; i < net.lds_halves / 8; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const table_rsrc_t rsrc = make_table_rsrc(net.table, net.table_bytes);
+
+  uint32_t pixel = 0;
+  const bool valid = i < p.n_local && map_pixel(p, i, pixel);
+  PtRay r;
+  r.pidx = pixel; r.shadow = false;
+  r.org = {0, 0, 0}; r.dir = {0, 0, 1};
+  r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;
+  r.scatter_index = 0; r.sample_coord = {0.5f, 0.5f, 0.5f}; r.majorant = 0.0f;
+  r.L = {0, 0, 0}; r.throughput = {1, 1, 1};
+  r.rng = 0;
+  r.it.t_next = {0, 0, 0}; r.it.cell = {0, 0, 0}; r.it.next_cell_begin = 0.0f;
+  bool alive = false, hit = false;
+  if (valid) {  // iterative_raygen_kernel (:679-748)
+    compute_ray(p, pixel, r.org, r.dir);
+    {  // RandomTEA(frame_index, pidx): 16 TEA rounds seed the LCG
+      uint32_t v0 = (uint32_t)p.frame_index, v1 = pixel, s0 = 0;
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+      }
+      r.rng = v0;
+    }
+    hit = intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi);
+    if (hit) {
+      dda_init(r.it, r.org * p.mc_rcp, r.dir * p.mc_rcp, r.tnear, p.mc_dims);
+      alive = pt_take_sample(p, r);
+    }
+  }
+  unsigned long long n_samples = 0;
+  for (;;) {
+    const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
+    if (live == 0ull) break;
+    n_samples += (unsigned long long)__builtin_popcountll(live);
+    const vec3f c = alive ? r.sample_coord : vec3f{0.5f, 0.5f, 0.5f};
+    const float v = eval_tile<F, K_IN>(net, lds, rsrc, c.x, c.y, c.z);
+    if (alive) {  // iterative_shade_kernel (:750-768); the ray's interval is recomputed on every trip, as its load does (:126-129)
+      r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;
+      intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi);
+      alive = pt_shade(p, p.tfn, r, v) && pt_take_sample(p, r);
+    }
+  }
+  if (valid) write_pixel(p, {r.L.x, r.L.y, r.L.z, 1.0f}, pixel);
+
   const uint32_t hits = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
   if (lane == 0) { s_stat[2 * wave] = (uint32_t)n_samples; s_stat[2 * wave + 1] = (uint32_t)(n_samples >> 32); s_stat[8 + wave] = hits; }
   __syncthreads();

@@ -941,10 +941,6 @@ __global__ void monolithic_kernel(const RenderParams p)
   write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
 }
 
-}  // namespace vnr
-#include "in_shader.h"   // in_shader_kernel: uses everything above
-namespace vnr {
-
 // ================================================================================================ path tracing (mode 14)
 // Sample-streaming path tracer: core/renderer/method_pathtracing.cu:532-813 (DeltaTrackingIter with the macrocell majorants,
 // iterative_take_sample, iterative_shade, raygen / shade kernels, do_path_tracing_iterative); VARYING_MAJORANT = 1 there
@@ -1265,6 +1261,10 @@ __global__ void __launch_bounds__(1024) pt_compact_kernel(const PtRays src, cons
   }
 }
 
+}  // namespace vnr
+#include "in_shader.h"   // in_shader_kernel, in_shader_pt_kernel: use the device code above
+namespace vnr {
+
 // ================================================================================================ Renderer (host)
 struct PartState {
   RenderParams p;
@@ -1516,7 +1516,7 @@ void Renderer::render()
 {
   // an asynchronous single-pass frame that is still pending stays pending until the head of this frame is enqueued
   // (render_streaming); everything else completes first
-  const bool in_shader = (mode_ == 6 || mode_ == 9 || mode_ == 12) && in_shader_applies();
+  const bool in_shader = in_shader_applies();
   const bool pipeline_head = async_ && (skip_download_ || distributed_) && (mode_ == 5 || mode_ == 6 || mode_ == 8 || mode_ == 9) && !in_shader &&
                              frame_[slot_] && frame_[slot_]->pending && !(frame_[slot_ ^ 1] && frame_[slot_ ^ 1]->pending) &&
                              !reset_;   // (a frame that restarts the accumulation overwrites it: its head must not run beside the tail of the frame before)
@@ -1607,7 +1607,8 @@ void Renderer::render()
     if (in_shader) {
       // VNR_RAYMARCHING_{NO_SHADING, GRADIENT_SHADING, SINGLE_SHADE_HEURISTIC}_IN_SHADER on a neural volume: the network inside the
       // marching loop, one launch per frame (in_shader.h; method_raymarching.cu:981-1249)
-      render_in_shader(p, mode_ == 9 ? M_GRADIENT : mode_ == 12 ? M_SSH : M_NONE);
+      // (modes 14 / 15, path tracing: in_shader_pt_kernel, method_pathtracing.cu:968-1025; the two differ by p.pt_reset_interval)
+      render_in_shader(p, mode_ == 9 ? M_GRADIENT : mode_ == 12 ? M_SSH : (mode_ == 14 || mode_ == 15) ? kInShaderPathTracing : M_NONE);
     } else
     switch (mode_) {
     case 6:   // VNR_RAYMARCHING_NO_SHADING_IN_SHADER where in_shader_applies() says no (a dense volume, a model shape without an
@@ -1663,6 +1664,7 @@ void Renderer::render()
     }
   }
   reset_ = false;
+  if (!(frame_[slot_] && frame_[slot_]->pending)) completed_stats_ = stats_;   // every mode but a deferred streaming frame is complete here
   if (!skip_download_ && !distributed_) {  // renderer.cpp:133 framebuffer.download_async (distributed: the assembled frame, issue_gather)
     const size_t off = p.pixel_lo, cnt = p.pixel_hi - p.pixel_lo;  // (interleaved shares copy the covering range)
     if (cnt) VNR_HIP_CHECK(hipMemcpyAsync(host_fb_[fb_cur_] + off, fb_[fb_cur_].ptr + off, cnt * sizeof(vec4f), hipMemcpyDeviceToHost, stream_));
@@ -1674,12 +1676,18 @@ void Renderer::render()
 
 bool Renderer::in_shader_applies() const
 {
-  // Off unless asked for (vnrAmdRendererSetInShaderKernel(1) or VNR_AMD_IN_SHADER=1): measured on the bench frame in mode 6, the
-  // in-shader kernel takes 8.2 ms for the whole frame and 1.98 ms for a 1/8 share where the streaming path takes 4.2 and 0.70 ms
-  // (mode 9: 36.8 / 6.6 against 12.2 / 1.8 ms; gpurun_out/r02_inshader/perf.log): a wave marches until its longest ray
-  // has ended, and the streaming path's compaction is exactly what removes that wait.  Same frames either way.
-  static const bool env_on = [] { const char* e = std::getenv("VNR_AMD_IN_SHADER"); return e && e[0] == '1'; }();
-  if (!(in_shader_mode_ < 0 ? env_on : in_shader_mode_ == 1) || !volume_->is_network()) return false;
+  if (mode_ != 6 && mode_ != 9 && mode_ != 12 && mode_ != 14 && mode_ != 15) return false;
+  // Which execution strategy, where both exist and give the same frames (gpurun_out/r02_inshader/perf.log, bench frame):
+  //  * ray marching (6 / 9 / 12): the in-shader kernel takes 8.2 ms for the whole frame and 1.98 ms for a 1/8 share where the
+  //    streaming path takes 4.2 and 0.70 ms (mode 9: 36.8 / 6.6 against 12.2 / 1.8): a wave marches until its longest ray has ended,
+  //    which the streaming path's compaction removes.  Default: streaming.
+  //  * path tracing (14 / 15): one evaluation per ray and trip, 60-odd dependent trips per frame: 5.5 ms in one launch against 6.7-7.0 ms
+  //    as a chain of 3 launches per trip, and the frames are equal bit for bit.  Default: in shader.
+  // vnrAmdRendererSetInShaderKernel(0 | 1) or VNR_AMD_IN_SHADER=0 | 1 force one or the other.
+  static const int env = [] { const char* e = std::getenv("VNR_AMD_IN_SHADER"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
+  const int choice = in_shader_mode_ >= 0 ? in_shader_mode_ : env;
+  const bool want = choice >= 0 ? choice == 1 : (mode_ == 14 || mode_ == 15);
+  if (!want || !volume_->is_network()) return false;
   const Network& net = static_cast<NeuralVolume*>(volume_.get())->network();
   if (!net.valid() || !net.fast_path()) return false;
   const uint32_t F = net.config().n_features, K = net.padded_width();
@@ -1708,7 +1716,8 @@ void Renderer::render_in_shader(const RenderParams& p, int shade)
   };
 #define X(f, k)                                                                     \
   if (!launched && net.n_features == f && net.in_width == k) {                      \
-    if (shade == M_GRADIENT) launch(in_shader_kernel<f, k, M_GRADIENT>);            \
+    if (shade == kInShaderPathTracing) launch(in_shader_pt_kernel<f, k>);          \
+    else if (shade == M_GRADIENT) launch(in_shader_kernel<f, k, M_GRADIENT>);       \
     else if (shade == M_SSH) launch(in_shader_kernel<f, k, M_SSH>);                 \
     else launch(in_shader_kernel<f, k, M_NONE>);                                    \
   }
@@ -1724,7 +1733,6 @@ void Renderer::render_in_shader(const RenderParams& p, int shade)
   for (int k = 0; k < kInShaderStatSlots; ++k) { stats_.n_samples += hs[k]; stats_.n_rays_hit += hh[k]; }
   stats_.n_reference_slots = stats_.n_samples;
   stats_.n_iterations = 1;
-  completed_stats_ = stats_;   // the frame is complete when this returns
 }
 
 void Renderer::render_monolithic(const RenderParams& p)

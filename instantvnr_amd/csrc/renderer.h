@@ -43,9 +43,9 @@ public:
   // what the frame reads complete it first (further iterations if rays are still alive).  Off by default: the caller
   // must not change the volume (training, decoding, time step) between render() and map_frame().
   void set_async(bool e) { finish_pending(); async_ = e; }
-  // rendering modes 6 / 9 / 12 on a neural volume: 1 the in-shader kernel, 0 the streaming path, -1 the environment's choice
-  // (VNR_AMD_IN_SHADER, default 0: the streaming path is faster, render.hip in_shader_applies).  Same frames up to the streaming
-  // path's resume rounding.
+  // rendering modes 6 / 9 / 12 / 14 / 15 on a neural volume: 1 the in-shader kernels, 0 the streaming path, -1 the environment's
+  // choice (VNR_AMD_IN_SHADER) or, without one, whichever is faster for the mode (render.hip in_shader_applies: ray marching
+  // streams, path tracing runs in shader).  Same frames (ray marching: up to the streaming path's resume rounding).
   void set_in_shader_kernel(int mode) { finish_pending(); in_shader_mode_ = mode; }
   // diagnostics: the compacted sample queue of the last iteration and per-iteration kernel times of the last frame
   const float* debug_coords() { finish_pending(); return (const float*)queue_.ptr; }  // 16-byte records {x, y, z, slot}

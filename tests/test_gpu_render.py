@@ -688,3 +688,28 @@ def test_in_shader_kernel_falls_back_where_it_has_no_instance(oracle, scene):
         api.vnrRender(r6); api.vnrRender(r5)
         assert api.vnrRendererGetFrameStats(r6)["n_iterations"] >= 1
         assert np.array_equal(api.vnrRendererMapFrame(r6), api.vnrRendererMapFrame(r5))
+
+
+@pytest.mark.parametrize("mode", [14, 15])
+def test_in_shader_path_tracing_kernel_equals_the_streaming_path_tracer(oracle, scene, mode):
+    """modes 14 / 15 on a neural volume through in_shader_pt_kernel (the default for path tracing: it is the faster of the two) (one launch, the network inside the delta-tracking loop): per pixel the
+    same chain of decisions on the same random numbers with the same network bits as the streaming path tracer, so the frames are
+    equal BIT FOR BIT over accumulated frames, hit rays and evaluations equal"""
+    nv, _, _, _ = _neural_c4_shape(oracle, scene, seed=41)
+    size = (96, 80)
+    frames, stats = {}, {}
+    for kernel in (1, 0):
+        r = make_renderer(scene, nv, size=size, mode=mode)
+        api.vnrRendererSetVolumeDensityScale(r, 0.5)
+        _set_in_shader(r, kernel)
+        acc, n = [], 0
+        for _ in range(3):
+            api.vnrRender(r)
+            acc.append(api.vnrRendererMapFrame(r).copy())
+            n += api.vnrRendererGetFrameStats(r)["n_samples"]
+        frames[kernel], stats[kernel] = acc, (n, api.vnrRendererGetFrameStats(r)["n_rays_hit"], api.vnrRendererGetFrameStats(r)["n_iterations"])
+    assert stats[1][2] == 1 and stats[0][2] > 3                     # one launch against a chain of iterations
+    assert stats[1][0] == stats[0][0] > 10000 and stats[1][1] == stats[0][1]
+    for k in range(3):
+        assert np.array_equal(frames[1][k], frames[0][k])
+    assert frames[1][2][..., 3].min() == 1.0 and frames[1][2][..., :3].max() > 0.1

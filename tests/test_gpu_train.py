@@ -160,3 +160,33 @@ def test_split_training_step_equals_train(oracle):
         res.append((api.vnrNeuralVolumeGetTrainingLoss(nv), api.neural_get_params_fp16(nv).astype(np.float32)))
     assert abs(res[0][0] - res[1][0]) < 0.1 * res[0][0]          # float atomics: not bitwise reproducible
     assert np.mean(np.abs(res[0][1] - res[1][1])) < 1e-3
+
+
+def test_set_model_resets_the_learning_rate_and_the_decay_schedule():
+    """Network::configure rebuilds the optimizer like the reference's deserialize_model (tcnn_network.h:195-209): after training past
+    decay_start, vnrNeuralVolumeSetModel with another learning rate must train with THAT rate from step 0, not with the decayed one.
+    The first Adam step moves every touched parameter by lr (m / sqrt(v) = sign(g) at step 1), which makes the rate observable."""
+    import os
+    os.environ["VNR_AMD_INIT_SEED"] = "77"
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))
+    cfg = syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
+    cfg["optimizer"].update({"decay_start": 5, "decay_interval": 5, "decay_base": 0.1})
+    cfg["optimizer"]["nested"]["learning_rate"] = 1e-2
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+    n_mlp = 64 * api.neural_info(nv)["padded_width"] + 64 * 64 + 16 * 64
+
+    def first_step_move():
+        before = api.neural_get_params_fp16(nv).astype(np.float32)
+        api.vnrNeuralVolumeTrain(nv, 1, True)
+        d = np.abs(api.neural_get_params_fp16(nv).astype(np.float32) - before)[:n_mlp - 15 * 64]   # MLP weights: every one has a gradient
+        return float(np.median(d[d > 0]))
+
+    assert 0.5e-2 < first_step_move() < 1.5e-2
+    api.vnrNeuralVolumeTrain(nv, 40, True)                 # lr is now 1e-2 x 0.1^8: steps move nothing a half can show
+    before = api.neural_get_params_fp16(nv).astype(np.float32)
+    api.vnrNeuralVolumeTrain(nv, 1, True)
+    assert np.abs(api.neural_get_params_fp16(nv).astype(np.float32) - before)[:n_mlp].max() < 1e-4
+    cfg["optimizer"]["nested"]["learning_rate"] = 2e-3
+    api.vnrNeuralVolumeSetModel(nv, cfg)
+    assert api.vnrNeuralVolumeGetTrainingStep(nv) == 0
+    assert 1e-3 < first_step_move() < 3e-3                 # the new rate, undecayed

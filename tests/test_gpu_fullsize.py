@@ -102,3 +102,35 @@ def test_a_1024x1024_frame_does_not_depend_on_the_schedule(big_scene, monkeypatc
             rows = (np.arange(1024) // 8) % 8 == part
             full[rows] = share[rows]
         assert np.array_equal(full, one)
+
+
+def test_gradients_of_the_c4_model_match_the_restatement(oracle):
+    """the training step's backward pass on the FULL model (70 M parameters: hashed levels of 2^22 entries, packed fp16 atomics at byte
+    offsets up to 140 MB into the gradient blob) against the numpy restatement on a batch the restatement can afford: same bars as the
+    small shapes of tests/test_gpu_train.py, plus: no gradient lands outside the entries the batch touches"""
+    from oracle import train_oracle as T
+    nv = api.vnrCreateNeuralVolume(c4_config(), (1024, 1024, 1024))
+    info = api.neural_info(nv)
+    n_mlp = oracle.mlp_n_params(info["padded_width"], 64, 2)
+    params = syn.random_params(info["n_params"], n_mlp, seed=9)
+    api.neural_set_params_fp16(nv, params)
+    rng = np.random.default_rng(10)
+    B = 2000
+    coords = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    targets = rng.uniform(0, 1, B).astype(np.float32)
+    got = api.neural_forward_backward(nv, coords, targets).astype(np.float64)
+    ocfg = oracle.grid_config(16, 2, 22, 16, float(np.exp(np.log(1024 / 16.0) / 15)))
+    ref = T.training_gradients(ocfg, 64, 3, params.view(np.uint16), coords, targets, loss="L1")
+    want = ref["grads"]
+    assert got.shape == want.shape == (70212496,)
+    assert np.isclose(api.vnrNeuralVolumeGetTrainingLoss(nv), ref["loss"], rtol=2e-3)
+    for name, sl in [("mlp", slice(0, n_mlp)), ("grid", slice(n_mlp, None))]:
+        g, w = got[sl], want[sl]
+        rel = np.linalg.norm(g - w) / np.linalg.norm(w)
+        assert rel < 3e-2, (name, rel)
+        assert np.abs(g - w).max() < 6e-2 * np.abs(w).max(), name
+    touched = want[n_mlp:] != 0
+    assert 0 < touched.sum() <= B * 16 * 8 * 2
+    # an entry the batch does not touch has no gradient (a stray atomic would show here), an entry it touches nearly always has one
+    assert np.count_nonzero(got[n_mlp:][~touched]) == 0
+    assert np.count_nonzero(got[n_mlp:][touched]) > 0.98 * touched.sum()

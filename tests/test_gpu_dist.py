@@ -290,3 +290,15 @@ def test_pipelined_frames_of_one_renderer_equal_synchronous_ones():
         for k, (g, w) in enumerate(zip(got, want)):
             assert np.array_equal(g, w), k
         assert got_samples == want_samples
+
+
+def test_pipelined_renderer_survives_what_an_application_does_between_frames():
+    """tools/pipeline_soak.py: 1500 vnrAmdRendererRenderPipelined calls with camera moves, mode switches (5 / 6 / 8), resizes, transfer
+    function updates, accumulation resets and training steps in between; after every event the pipelined frame equals the frame of a
+    fresh sequential renderer in the same state, bit for bit"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pipeline_soak.py"), "1500"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "[soak] ok: 1500 pipelined frames" in out.stdout

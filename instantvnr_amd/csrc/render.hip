@@ -1864,7 +1864,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
   const uint32_t row_items = p_all.tiles_per_row * 64u;
   const uint32_t R = p_all.n_local / row_items;  // local tile rows
   // a small share is bound by the length of the kernel chain of one part, not by throughput: more, shorter chains side by side
-  const int want = (!n_halves_fixed_ && p_all.n_local <= 196608u) ? small_share_parts_ : n_halves_;
+  const int want = (!n_halves_fixed_ && p_all.n_local <= 262144u) ? small_share_parts_ : n_halves_;
   const int H = (int)std::min<uint32_t>((uint32_t)want, std::max(R, 1u));
   const uint32_t P_total = p_all.n_local;
   const bool grad = pass_mode == M_GRADIENT;

@@ -302,3 +302,56 @@ def test_pipelined_renderer_survives_what_an_application_does_between_frames():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "pipeline_soak.py"), "1500"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert "[soak] ok: 1500 pipelined frames" in out.stdout
+
+
+def _run_tool_ranks(argv, world, cwd, timeout=420):
+    """one process per rank of a command-line tool, torchrun-style environment, host-staged transport (all ranks on this box's GPU)"""
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "VNR_AMD_DIST_TRANSPORT": "shm", "VNR_AMD_DIST_TIMEOUT": "120", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "VNR_AMD_INIT_SEED": str(500 + rank)})
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=str(cwd), stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=timeout)
+            outs.append((o.decode("utf-8", "replace"), e.decode("utf-8", "replace")))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rank, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} of {world} failed:\n{o[-1500:]}\n{e[-2500:]}"
+    return outs
+
+
+def test_command_line_tools_on_two_ranks(tmp_path):
+    """tools/vnr_cmd_train.py and tools/vnr_cmd_render.py with one process per GPU (here: two ranks on one GPU): the trainer's steps are
+    data-parallel steps and rank 0 writes params.json; the renderer's screenshot is the one-process screenshot, bit for bit"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vol = syn.analytic_volume(48)
+    vol.astype(np.float32).tofile(tmp_path / "v.raw")
+    scene = {"dataSource": [{"format": "REGULAR_GRID_RAW_BINARY", "fileName": str(tmp_path / "v.raw"), "dimensions": {"x": 48, "y": 48, "z": 48}, "type": "FLOAT"}],
+             "view": {"camera": {"eye": {"x": 100.0, "y": 90.0, "z": -60.0}, "center": {"x": 24.0, "y": 24.0, "z": 24.0}, "up": {"x": 0.0, "y": 1.0, "z": 0.0}, "fovy": 40.0},
+                      "volume": {"transferFunction": {}}}}
+    (tmp_path / "scene.json").write_text(json.dumps(scene))
+    (tmp_path / "model.json").write_text(json.dumps(syn.model_config(n_levels=6, n_features=4, log2_hashmap_size=14, base_resolution=4, n_hidden_layers=2)))
+    outs = _run_tool_ranks([os.path.join(root, "tools", "vnr_cmd_train.py"), "--volume", str(tmp_path / "scene.json"), "--network", str(tmp_path / "model.json"),
+                            "--max-num-steps", "200", "--quiet"], 2, tmp_path)
+    summary = dict(line.strip().split("=") for line in outs[0][0].splitlines() if "=" in line)
+    assert summary["STEP"] == "200" and float(summary["PSNR"]) > 28.0
+    assert "Summary" not in outs[1][0]                                  # rank 0 reports
+    nv = api.vnrCreateNeuralVolume(str(tmp_path / "params.json"))
+    assert api.vnrVolumeGetDims(nv) == (48, 48, 48)
+    x = np.linspace(0, 1, 64, dtype=np.float32)
+    np.save(tmp_path / "table.npy", np.stack([x, 1 - x, 0.5 + 0.5 * np.sin(6 * x), np.clip(1.5 * x - 0.2, 0, 1)], axis=1).astype(np.float32))
+    args = [os.path.join(root, "tools", "vnr_cmd_render.py"), "--tfn", str(tmp_path / "scene.json"), "--tfn-table", str(tmp_path / "table.npy"), "--num-frames", "4",
+            "--neural-volume", str(tmp_path / "params.json"), "--rendering-mode", "5"]
+    outs = _run_tool_ranks(args + ["--exp", "two"], 2, tmp_path)
+    assert "Summary: two" in outs[0][0] and "gpus: 2" in outs[0][0] and "Summary" not in outs[1][0]
+    one = subprocess.run([sys.executable] + args + ["--exp", "one"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    assert (tmp_path / "two-screenshot.png").read_bytes() == (tmp_path / "one-screenshot.png").read_bytes()

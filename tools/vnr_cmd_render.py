@@ -13,6 +13,10 @@
 Like the reference: 768 x 768 frame buffer, transfer function value range (0, 1), no denoiser, 5 warm-up frames, then --num-frames
 timed calls of vnrRender, per-frame times in the log, "fps = num_frames / total time", the Summary block.
 
+More than one GPU (new: the reference is single-GPU): one process per GPU with the torchrun environment (RANK, LOCAL_RANK, WORLD_SIZE,
+MASTER_ADDR, MASTER_PORT); the frame is then rendered as interleaved tile rows, one share per rank, all-gathered over RCCL and
+pipelined (vnrAmdRendererRenderPipelined); rank 0 writes the log, the screenshot and the Summary.
+
 Two differences, both stated at run time:
   * the table of the --tfn preset is decoded in the reference by OVR's tfn module (tfn::loadTransferFunction), which is not part of
     the reference tree: --tfn-table <file> supplies what that module yields (resolution x RGBA; .npy, or JSON [[r,g,b,a], ...]);
@@ -30,7 +34,7 @@ import zlib
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from instantvnr_amd import api  # noqa: E402
+from instantvnr_amd import api, dist  # noqa: E402
 
 # the vnrRenderMode enum (api.h:35-58), in the order of the reference tool's help text (batch_renderer.cpp:45-60)
 RENDER_MODES = ["0-3 OptiX reference marcher (not implemented here)", "4 ray marching, decoding", "5 ray marching, sample streaming",
@@ -78,7 +82,7 @@ def main(argv=None):
     if any(given) and not all(given):      # args::Group::Validators::AllOrNone
         p.error("--camera-from, --camera-at and --camera-up: all or none")
 
-    api.check(api.lib().vnrAmdInit(-1))
+    ctx = dist.init_from_env()        # one rank: binds the GPU; more: meets the other ranks (RCCL)
     if a.simple_volume:
         volume = api.vnrCreateSimpleVolume(a.simple_volume, "GPU", False)
     else:
@@ -101,23 +105,41 @@ def main(argv=None):
     api.vnrRendererSetVolumeDensityScale(ren, a.density_scale)
     api.vnrRendererSetVolumeSamplingRate(ren, a.sampling_rate)
 
-    for _ in range(5):   # warm up
-        api.vnrRender(ren)
-
     timings = np.zeros(max(a.num_frames, 0))
-    t_all = time.perf_counter()
-    for i in range(a.num_frames):
-        t0 = time.perf_counter()
-        api.vnrRender(ren)
-        timings[i] = (time.perf_counter() - t0) * 1e3
-    total_s = time.perf_counter() - t_all
+    if not ctx.distributed:
+        for _ in range(5):   # warm up
+            api.vnrRender(ren)
+        t_all = time.perf_counter()
+        for i in range(a.num_frames):
+            t0 = time.perf_counter()
+            api.vnrRender(ren)
+            timings[i] = (time.perf_counter() - t0) * 1e3
+        total_s = time.perf_counter() - t_all
+        pixels = api.vnrRendererMapFrame(ren)
+    else:
+        sr = dist.ShardedRenderer(ctx, ren, size[0], size[1])
+        for _ in range(5):
+            sr.render()
+        sr.flush()
+        dist.barrier(ctx)
+        t_all = time.perf_counter()
+        for i in range(a.num_frames):   # call i hands out frame i - 1, gathered; the flush hands out the last one
+            t0 = time.perf_counter()
+            sr.render()
+            timings[i] = (time.perf_counter() - t0) * 1e3
+        last = sr.flush()
+        dist.barrier(ctx)
+        total_s = time.perf_counter() - t_all
+        pixels = sr.download(last)
+        if ctx.rank != 0:
+            dist.finalize()
+            return 0
 
     with open(a.exp + ".csv", "w") as log:   # Logger: {"#", "frame time", "fps"}
         log.write("#,frame time,fps\n")
         for i, ms in enumerate(timings):
             log.write(f"{float(i)},{ms / 1000.0},{1000.0 / ms}\n")
 
-    pixels = api.vnrRendererMapFrame(ren)
     save_png(a.exp + "-screenshot.png", np.asarray(pixels).reshape(size[1], size[0], 4))
 
     vec = lambda v: "(" + ",".join(f"{x:g}" for x in v) + ")"
@@ -130,6 +152,9 @@ def main(argv=None):
     print(f"\tcamera: {vec(cam_from)}")
     print(f"\t        {vec(cam_at)}")
     print(f"\t        {vec(cam_up)}")
+    if ctx.distributed:
+        print(f"\t  gpus: {ctx.world}")
+        dist.finalize()
     return 0
 
 

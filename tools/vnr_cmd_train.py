@@ -11,14 +11,19 @@
   --train-macrocell          train the macrocell grid at the same time
 
 Like the reference it trains in bursts of 10 steps in fast mode, restarts when the loss is still > 0.9 after 5000 steps, prints
-the Summary block (STEP / LOSS / TIME / PSNR / SSIM) and writes ./params.json (BSON)."""
+the Summary block (STEP / LOSS / TIME / PSNR / SSIM) and writes ./params.json (BSON).
+
+More than one GPU (new: the reference is single-GPU): start one process per GPU with the torchrun environment (RANK, LOCAL_RANK,
+WORLD_SIZE, MASTER_ADDR, MASTER_PORT; `python -m torch.distributed.run --nproc-per-node N tools/vnr_cmd_train.py ...` or any
+launcher that sets them) and the steps become data-parallel steps on N x 65 536 samples (vnrAmdNeuralVolumeTrainDataParallel);
+rank 0 reports and writes the files."""
 import argparse
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from instantvnr_amd import api  # noqa: E402
+from instantvnr_amd import api, dist  # noqa: E402
 
 
 def main(argv=None):
@@ -33,7 +38,8 @@ def main(argv=None):
     p.add_argument("--train-macrocell", action="store_true", help="train the macrocell grid at the same time")
     a = p.parse_args(argv)
 
-    api.check(api.lib().vnrAmdInit(-1))
+    ctx = dist.init_from_env()        # one rank: binds the GPU; more: meets the other ranks (RCCL)
+    root = ctx.rank == 0
     simple_volume = api.vnrCreateSimpleVolume(a.volume, a.training_mode)
     while True:
         # vnrCreateNeuralVolume(model, simple_volume, online_macrocell_construction = args.train_macrocell); a path is a model file
@@ -41,30 +47,37 @@ def main(argv=None):
         if a.resume:
             api.vnrNeuralVolumeSetParams(neural_volume, a.resume)
         report = None
-        if a.report not in ("", "none"):
+        if root and a.report not in ("", "none"):
             report = open(a.report if a.report.endswith(".csv") else a.report + ".csv", "w")
             report.write("step,loss\n")
         train_s, restart = 0.0, False
         for i in range(0, a.max_num_steps, 10):
             t0 = time.perf_counter()
-            api.vnrNeuralVolumeTrain(neural_volume, 10, True)
+            dist.train_data_parallel(ctx, neural_volume, 10, True)
             api.check(api.lib().vnrAmdSynchronize())
             train_s += time.perf_counter() - t0
             loss = api.vnrNeuralVolumeGetTrainingLoss(neural_volume)
             if report:
                 report.write(f"{api.vnrNeuralVolumeGetTrainingStep(neural_volume)},{loss}\n")
-            if not a.quiet:
+            if root and not a.quiet:
                 print(f"\r[train] {100.0 * i / max(a.max_num_steps, 1):5.1f} %  LOSS {loss:f}", end="", flush=True)
+            if ctx.distributed:   # every rank takes the same decision: the largest loss any of them sees
+                loss = dist.all_reduce_host([loss], dist.MAX)[0]
             if i >= 5000 and loss > 0.9:   # bad loss (batch_trainer.cpp:108-112)
-                print("\nbad setup, ... restart")
+                if root:
+                    print("\nbad setup, ... restart")
                 restart = True
                 break
         if report:
             report.close()
         if not restart:
             break
-    if not a.quiet:
+    if root and not a.quiet:
         print()
+    if not root:   # the replicas are identical: rank 0 evaluates and writes
+        dist.barrier(ctx)
+        dist.finalize()
+        return 0
     psnr = api.vnrNeuralVolumeGetPSNR(neural_volume, a.report == "")
     ssim = api.vnrNeuralVolumeGetSSIM(neural_volume, a.report == "")
     print("Summary")
@@ -74,6 +87,9 @@ def main(argv=None):
     print(f"  PSNR={psnr}")
     print(f"  SSIM={ssim}")
     api.vnrNeuralVolumeSerializeParams(neural_volume, "params.json")
+    if ctx.distributed:
+        dist.barrier(ctx)
+        dist.finalize()
     return 0
 
 

@@ -1,4 +1,7 @@
 #!/bin/bash
+# RECORD of an experiment: VNR_AMD_STAGGER / VNR_AMD_PART_PRIORITY were switches of experimental builds that ordered the ray
+# parts' marches across streams / raised one part's stream priority; both measured slower and the code is gone, so today this script
+# only compares identical runs.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r02_halves; mkdir -p $O
 cd $R

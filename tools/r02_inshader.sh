@@ -1,4 +1,6 @@
 #!/bin/bash
+# in-shader kernels: tests, then path-tracing timings (VNR_AMD_PT_TILES_PER_WAVE belonged to the lane-refill experiment, DESIGN.md 7:
+# measured slower, code removed; the sweep below is kept as the record of how it was measured)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r02_inshader; mkdir -p $O
 cd $R

@@ -1,5 +1,5 @@
 """GPU box: the training step of the C4 model by phase (HIP events between the phases of 64 profiled steps), under whatever
-diagnostic switches the environment carries (VNR_AMD_WGRAD_VALU, VNR_AMD_WGRAD_SUBCHUNKS, VNR_AMD_GRID_BWD_PK ...).
+diagnostic switches the environment carries (VNR_AMD_GRID_BWD_LEVELS=l0,l1: scatter only those levels).
 usage: python tools/train_probe.py [steps]"""
 import ctypes as C
 import os

@@ -1677,7 +1677,7 @@ void Renderer::render()
 bool Renderer::in_shader_applies() const
 {
   if (mode_ != 6 && mode_ != 9 && mode_ != 12 && mode_ != 14 && mode_ != 15) return false;
-  // Which execution strategy, where both exist and give the same frames (gpurun_out/r02_inshader/perf.log, bench frame):
+  // Which execution strategy, where both exist and give the same frames (profiles/r02_in_shader_vs_streaming.txt, bench frame):
   //  * ray marching (6 / 9 / 12): the in-shader kernel takes 8.2 ms for the whole frame and 1.98 ms for a 1/8 share where the
   //    streaming path takes 4.2 and 0.70 ms (mode 9: 36.8 / 6.6 against 12.2 / 1.8): a wave marches until its longest ray has ended,
   //    which the streaming path's compaction removes.  Default: streaming.

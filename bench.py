@@ -200,7 +200,11 @@ def main():
         api.vnrRendererSetProfiling(rr, profiling)
         return rr
 
-    ren = make_renderer(nv, device_output=False, profiling=not a.no_kernel_events)  # HIP events around the fused encode+MLP kernel, on its own stream
+    # HIP events around every launch of the evaluation kernel, on the stream it is launched on.  With more than one rank they stay
+    # out of the timed region (two timed events per launch are 6 % of the frame time of a 1/8 share, tools/r02_share_prof.sh) and an
+    # un-timed leg behind it measures the launches instead.
+    events_in_timed_region = not a.no_kernel_events and ctx.world == 1
+    ren = make_renderer(nv, device_output=False, profiling=events_in_timed_region)
     sr = dist.ShardedRenderer(ctx, ren, a.fb, a.fb)
     setup_s = time.perf_counter() - t_setup
 
@@ -232,6 +236,24 @@ def main():
     dist.barrier(ctx)
     elapsed = time.perf_counter() - t0
     rays_hit = st["n_rays_hit"]
+    samples_evt, evt_frames = samples, a.steps     # the frames the kernel events cover
+    if ctx.world > 1 and not a.no_kernel_events:   # un-timed: the same frames with the events on
+        api.vnrRendererSetProfiling(ren, True)
+        keep = (samples, slots, iters)
+        samples = slots = 0
+        infer_ms = union_ms = 0.0
+        launches = 0
+        evt_frames = max(5, min(a.steps // 2, 30))
+        for k in range(evt_frames):
+            sr.render()
+            if k > 0:
+                add(sr.completed_stats())
+        sr.flush()
+        add(sr.completed_stats())
+        samples_evt = samples
+        samples, slots, iters = keep
+        api.vnrRendererSetProfiling(ren, False)
+        dist.barrier(ctx)
     brick_state = api.neural_brick_image(nv)
 
     # ---- un-timed: the neural frame against the frame of the ground-truth volume (same camera / TFN / mode / macrocell) --------
@@ -303,23 +325,27 @@ def main():
     flops_per_sample = 2 * (in_pad * 64 + (info["n_hidden_layers"] - 1) * 64 * 64 + 64)
     # dominant kernel: fused hash-grid gather + MLP.  achieved = algorithmic bytes of the samples this rank's
     # launches processed / summed launch durations (HIP events on the render stream), i.e. per-launch average.
-    achieved = (samples * bytes_per_sample) / (infer_ms * 1e-3) / 1e9 if infer_ms > 0 else 0.0
+    samples_evt *= evals_per_sample
+    achieved = (samples_evt * bytes_per_sample) / (infer_ms * 1e-3) / 1e9 if infer_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": "fused_infer_kernel (hash-grid gather + 3x64 MLP on MFMA)",
                 "algorithmic_bytes_per_sample": bytes_per_sample, "flops_per_sample": flops_per_sample,
                 "avg_launch_ms": round(infer_ms / max(launches, 1), 4), "launches": launches,
-                "mfma_tflops": round(samples * flops_per_sample / (infer_ms * 1e-3) / 1e12, 2) if infer_ms > 0 else 0.0}
+                "mfma_tflops": round(samples_evt * flops_per_sample / (infer_ms * 1e-3) / 1e12, 2) if infer_ms > 0 else 0.0}
+    if ctx.world > 1:
+        roofline["events"] = (f"rank 0's launches in an un-timed leg of {evt_frames} frames behind the timed region: with more than one rank the HIP events "
+                              "around every launch stay out of the timed frames (they cost 6 % of a 1/8 share's frame time)")
     # The renderer runs the rays as 2 halves on 2 streams by default (march of one half overlaps inference of the other,
     # and the two halves' inference kernels overlap each other), so a launch's HIP-event duration includes time it shares
     # the GPU: `achieved`/`frac` (defined per launch) drop although the frame gets faster.  The frame-level figure below
     # does not depend on scheduling: algorithmic bytes of all live samples of a frame / frame time.
     halves = 1 if os.environ.get("VNR_AMD_RENDER_HALVES", "2") == "1" else 2
     if union_ms > 0:
-        u = (samples * bytes_per_sample) / (union_ms * 1e-3) / 1e9
-        roofline["union"] = {"what": "timed region: algorithmic bytes of all launches / the time during which at least one launch of the kernel was "
+        u = (samples_evt * bytes_per_sample) / (union_ms * 1e-3) / 1e9
+        roofline["union"] = {"what": "algorithmic bytes of all launches / the time during which at least one launch of the kernel was "
                                      "running (union of the HIP-event intervals of both streams): overlapping launches count once",
-                             "achieved": round(u, 1), "frac": round(u / HBM_PEAK_GBS, 4), "ms_per_frame": round(union_ms / a.steps, 4)}
+                             "achieved": round(u, 1), "frac": round(u / HBM_PEAK_GBS, 4), "ms_per_frame": round(union_ms / evt_frames, 4)}
     if alone and alone["ms"] > 0:
         ev = alone["samples"] * evals_per_sample
         a_gbs = ev * bytes_per_sample / (alone["ms"] * 1e-3) / 1e9
@@ -349,7 +375,7 @@ def main():
         roofline["algorithmic_bytes_per_launch"] = round(samples * bytes_per_sample / max(launches, 1))
         # the bound the counters point at: what actually crosses the fabric per second while the kernel runs
         if union_ms > 0:
-            t_gbs = per_sample * samples / (union_ms * 1e-3) / 1e9
+            t_gbs = per_sample * samples_evt / (union_ms * 1e-3) / 1e9
             roofline["traffic_frac"] = {"what": "measured fabric bytes per sample x this run's samples / the union of the launch intervals / 8 TB/s: the kernel "
                                                 "is no longer bound by bytes (L1 / texture-addresser latency, DESIGN 4.1); the algorithmic fraction flatters it",
                                         "achieved": round(t_gbs, 1), "frac": round(t_gbs / HBM_PEAK_GBS, 4), "bytes_per_sample": round(per_sample, 1)}
@@ -413,7 +439,7 @@ def main():
                             "in_use": bool(brick_state["in_use"]), "brick_image_bytes": int(brick_state["bytes"]), "model_bytes": int(info["n_params"]) * 2,
                             "ratio": round(brick_state["bytes"] / (info["n_params"] * 2.0), 1), "build_ms": round(brick_state["build_ms"], 2)},
         "mlp_msamples_per_s": round(samples_all / elapsed / 1e6, 1),
-        "mlp_msamples_per_s_kernel_only": round(samples / (infer_ms * 1e-3) / 1e6, 1) if infer_ms > 0 else None,
+        "mlp_msamples_per_s_kernel_only": round(samples_evt / (infer_ms * 1e-3) / 1e6, 1) if infer_ms > 0 else None,
         "samples_per_frame": int(samples_all / a.steps), "samples_per_hit_ray": round(samples_all / a.steps / max(rays_hit, 1), 1),
         "network_evaluations_per_shaded_sample": evals_per_sample, "shaded_samples_per_frame": shaded_samples_per_frame,
         "reference_slots_per_frame": int(slots_all / a.steps), "iterations_per_frame": iters, "rays_hit": rays_hit,

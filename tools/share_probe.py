@@ -24,6 +24,8 @@ for parts in [int(v) for v in os.environ.get("SHARE_PARTS", "1,2,4,8").split(","
     api.vnrRendererSetFramebufferSize(ren, (fb, fb))
     api.vnrRendererSetMode(ren, int(os.environ.get("SHARE_MODE", 5)))   # 6 / 9 / 12: the in-shader kernel (VNR_AMD_IN_SHADER=0: streaming)
     api.vnrRendererSetOutputAsDeviceFramebuffer(ren, True)
+    if os.environ.get("SHARE_PROFILING"):   # the HIP events bench.py records around every evaluation launch
+        api.vnrRendererSetProfiling(ren, True)
     camera = api.vnrCreateCamera(); api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
     api.vnrRendererSetCamera(ren, camera)
     tfn = api.vnrCreateTransferFunction(); api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas)

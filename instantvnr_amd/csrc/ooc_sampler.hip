@@ -261,15 +261,27 @@ void OutOfCoreSampler::refresh_worker(uint64_t first)
   try {
     VNR_HIP_CHECK(hipSetDevice(Runtime::get().device));
     VNR_HIP_CHECK(hipEventSynchronize(ev_copied_));   // the staging buffers are free once the previous refresh has been copied
-    // 1. preads: slab j of this refresh goes to staging slot j, z-slice by z-slice (x-full rows are contiguous in the file)
+    // 1. preads: slab j of this refresh goes to staging slot j, z-slice by z-slice (x-full rows are contiguous in the file).
+    // 2. the slabs travel to the device in chunks while the later ones are still being read: at the reference's 1024 slabs per step a
+    //    refresh is 102 MiB, i.e. ~1.5 ms of preads from the page cache on 16 threads and ~2 ms of PCIe; one after the other they
+    //    were the 3.8 ms of a step, overlapped 2.8-2.9.  The copies start after the last sampling kernel that may still
+    //    read the slots being replaced.  A small refresh (VNR_NUM_CONCURRENT_BLOCKS=128: 13 MiB) goes as one copy: chunking it cost 0.1 ms.
+    //    (The read threads are started per refresh.  A persistent pool saves ~0.4 ms of thread starts and was measured at 2.3 ms per
+    //    step in half of the runs and at 2.8-3.6 in the other half, depending on where its threads had first been placed: not kept.)
+    constexpr uint64_t kChunks = 8;
+    const uint64_t n_chunks = std::max<uint64_t>(1, std::min<uint64_t>(kChunks, n_concurrent_ / 128));
+    const uint64_t chunk = (n_concurrent_ + n_chunks - 1) / n_chunks;
     std::atomic<uint64_t> next{0}, bytes{0};
+    std::atomic<uint64_t> done[kChunks];
+    for (auto& d : done) d.store(0);
+    std::atomic<bool> failed{false};
     std::string err;
     std::mutex err_mutex;
     auto io = [&]() {
       try {
         for (;;) {
           const uint64_t j = next.fetch_add(1);
-          if (j >= n_concurrent_) break;
+          if (j >= n_concurrent_ || failed.load()) break;
           const OocBlock& b = blocks_[(first + j) % n_blocks_];
           staging_blocks_[j] = b;
           uint8_t* data = staging_ + j * block_bytes_;
@@ -279,30 +291,41 @@ void OutOfCoreSampler::refresh_worker(uint64_t first)
             pread_all(fd_, data + (uint64_t)z * slice_bytes, slice_bytes, file_offset_ + file_index * elem_);
           }
           bytes.fetch_add(slice_bytes * b.ghost_nz);
+          done[j / chunk].fetch_add(1, std::memory_order_release);
         }
       } catch (const std::exception& e) {
         std::lock_guard<std::mutex> g(err_mutex);
         err = e.what();
+        failed.store(true);
       }
     };
     std::vector<std::thread> pool;
+    struct Joiner {   // the readers use this frame's variables: whatever ends it, they have come back first
+      std::vector<std::thread>* pool; std::atomic<bool>* failed;
+      ~Joiner() { failed->store(true); for (auto& t : *pool) if (t.joinable()) t.join(); }
+    } joiner{&pool, &failed};
     const unsigned nt = (unsigned)std::min<uint64_t>(io_threads_, n_concurrent_);
-    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(io);
-    io();
+    for (unsigned t = n_chunks > 1 ? 0 : 1; t < nt; ++t) pool.emplace_back(io);
+    if (n_chunks == 1) io();   // nothing to orchestrate: this thread reads too
+    VNR_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_sampled_, 0));
+    // staging slot j belongs to cache slot (first + j) % n_blocks: a contiguous range of j is one copy, two where it wraps
+    auto copy_range = [&](uint64_t j0, uint64_t j1) {
+      while (j0 < j1) {
+        const uint64_t slot = (first + j0) % n_blocks_;
+        const uint64_t run = std::min(j1 - j0, n_blocks_ - slot);
+        VNR_HIP_CHECK(hipMemcpyAsync(cache_.ptr + slot * block_bytes_, staging_ + j0 * block_bytes_, run * block_bytes_, hipMemcpyHostToDevice, copy_stream_));
+        VNR_HIP_CHECK(hipMemcpyAsync(d_blocks_.ptr + slot, staging_blocks_ + j0, run * sizeof(OocBlock), hipMemcpyHostToDevice, copy_stream_));
+        j0 += run;
+      }
+    };
+    for (uint64_t c = 0; c * chunk < n_concurrent_ && !failed.load(); ++c) {
+      const uint64_t j0 = c * chunk, j1 = std::min(n_concurrent_, j0 + chunk);
+      while (done[c].load(std::memory_order_acquire) < j1 - j0 && !failed.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      if (!failed.load()) copy_range(j0, j1);
+    }
     for (auto& t : pool) t.join();
     if (!err.empty()) throw std::runtime_error(err);
     bytes_read_ += bytes.load();
-    // 2. one (two when the slot range wraps) copy of slabs and of table entries, after the last sampling kernel that may
-    //    still read the slots being replaced
-    VNR_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_sampled_, 0));
-    const uint64_t first_run = std::min(n_concurrent_, n_blocks_ - first);
-    VNR_HIP_CHECK(hipMemcpyAsync(cache_.ptr + first * block_bytes_, staging_, first_run * block_bytes_, hipMemcpyHostToDevice, copy_stream_));
-    VNR_HIP_CHECK(hipMemcpyAsync(d_blocks_.ptr + first, staging_blocks_, first_run * sizeof(OocBlock), hipMemcpyHostToDevice, copy_stream_));
-    if (first_run < n_concurrent_) {
-      const uint64_t rest = n_concurrent_ - first_run;
-      VNR_HIP_CHECK(hipMemcpyAsync(cache_.ptr, staging_ + first_run * block_bytes_, rest * block_bytes_, hipMemcpyHostToDevice, copy_stream_));
-      VNR_HIP_CHECK(hipMemcpyAsync(d_blocks_.ptr, staging_blocks_ + first_run, rest * sizeof(OocBlock), hipMemcpyHostToDevice, copy_stream_));
-    }
     VNR_HIP_CHECK(hipEventRecord(ev_copied_, copy_stream_));
   } catch (const std::exception& e) {
     worker_error_ = e.what();

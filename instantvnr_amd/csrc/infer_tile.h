@@ -165,6 +165,7 @@ __device__ __forceinline__ void encode_tile(const LevelInfo* levels, uint32_t n_
     lv.offset = __builtin_amdgcn_readfirstlane(lvtab[l].offset);
     lv.hashed = __builtin_amdgcn_readfirstlane(lvtab[l].hashed);
     lv.brick = __builtin_amdgcn_readfirstlane(lvtab[l].brick);
+    lv.pad1 = __builtin_amdgcn_readfirstlane(lvtab[l].pad1);
     return lv;
   };
 #pragma unroll

@@ -22,20 +22,21 @@ struct LevelInfo {
   uint32_t offset;  // first entry of this level (entries, x F for elements)
   uint32_t hashed;  // 1: prime-XOR hash (size is a power of two), 0: dense index
   uint32_t brick;   // 0: read the parameter blob; else 1 + first 128-byte line of this level in the brick image (below)
-  uint32_t pad1;    // 32 bytes: one s_load_dwordx8 per level
+  uint32_t pad1;    // bricked levels with F = 2: bricks per row of the image (resolution / 7 + 1); else 0.  32 bytes: one s_load_dwordx8 per level
 };
 
 // Brick image (inference only): a level whose table is hashed is ALSO kept de-hashed, as a dense array over the level's
-// (res + 1)^3 grid points stored in bricks of one 128-byte line: 4x4x4 entries for F = 1, 4x4x2 for F = 2, 4x2x2 for F = 4,
-// 2x2x2 for F = 8.  The values are copies (image[x, y, z] = table[hash(x, y, z)]), so results are bit-identical; what changes
+// (res + 1)^3 grid points stored in bricks of one 128-byte line: 4x4x4 entries for F = 1, 4x2x2 for F = 4, 2x2x2 for F = 8, and
+// for F = 2 8x2x2 entries of which the 8th column repeats the +x neighbour's first (grid_device.h: a cell's x-pairs never straddle).  The values are copies (image[x, y, z] = table[hash(x, y, z)]), so results are bit-identical; what changes
 // is which lines a wave touches: the 8 corners of a cell fall into ~2.3 lines instead of 4-8 and neighbouring samples share
 // them, where the hash scatters every (y, z) row to an unrelated line (measured on the bench frame's sample queue: 917 -> 385
-// fetched bytes per sample inside a 64-sample wave).  The price is memory, 7.6 GB instead of 140 MB for the bench model,
+// fetched bytes per sample inside a 64-sample wave).  The price is memory, 8.8 GB instead of 140 MB for the bench model,
 // which is what 288 GB of HBM are for, and a rebuild (a few ms) after the parameters change, so the image is only built once
 // the parameters have been left alone for a while (Network::brick_policy).
 template <int F> struct BrickShape;
 template <> struct BrickShape<1> { static constexpr uint32_t lx = 2, ly = 2, lz = 2; };
-template <> struct BrickShape<2> { static constexpr uint32_t lx = 2, ly = 2, lz = 1; };
+template <> struct BrickShape<2> { static constexpr uint32_t lx = 2, ly = 2, lz = 1; };   // (superseded for the image itself: F = 2 uses 8 x 2 x 2 bricks
+                                                                                          // with a repeated column, grid_device.h gather_corners_brick; kept for the sizing code's defaults)
 template <> struct BrickShape<4> { static constexpr uint32_t lx = 2, ly = 1, lz = 1; };
 template <> struct BrickShape<8> { static constexpr uint32_t lx = 1, ly = 1, lz = 1; };
 

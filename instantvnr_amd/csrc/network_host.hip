@@ -309,6 +309,20 @@ __global__ void brick_build_kernel(const LevelInfo lv, const half_t* __restrict_
   const uint32_t nbx = (lv.resolution >> LX) + 1u, nby = (lv.resolution >> LY) + 1u;
   vec_t* out = (vec_t*)(image + (size_t)(lv.brick - 1u) * 128u);
   const vec_t* src = (const vec_t*)(table + (size_t)lv.offset * F);
+  if constexpr (F == 2) {   // 8 x 2 x 2 entries, column 7 = column 0 of the +x neighbour (grid_device.h gather_corners_brick)
+    const uint32_t gnbx = lv.pad1, gnby = (lv.resolution >> 1) + 1u;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += (uint64_t)gridDim.x * blockDim.x) {
+      const uint32_t w = (uint32_t)(e & 31u);
+      const uint64_t b = e >> 5;
+      const uint32_t bx = (uint32_t)(b % gnbx), by = (uint32_t)((b / gnbx) % gnby), bz = (uint32_t)(b / ((uint64_t)gnbx * gnby));
+      const uint32_t x = bx * 7u + (w & 7u), y = (by << 1) | ((w >> 3) & 1u), z = (bz << 1) | (w >> 4);
+      vec_t v;
+      if (x <= lv.resolution && y <= lv.resolution && z <= lv.resolution) v = src[level_index(lv, x, y, z)];
+      else v = vec_t{};
+      out[e] = v;
+    }
+    return;
+  }
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t w = (uint32_t)(e & (E - 1u));
     const uint64_t b = e >> (LX + LY + LZ);
@@ -349,7 +363,12 @@ void Network::build_brick_image(hipStream_t s) const
     if (!lv[l].hashed && !dense_too) continue;
     if (brick_res_cap_ && lv[l].resolution > brick_res_cap_ + 1u) continue;
     const uint64_t res = lv[l].resolution;
-    const uint64_t n = ((res >> lx) + 1) * ((res >> ly) + 1) * ((res >> lz) + 1);
+    uint64_t n = ((res >> lx) + 1) * ((res >> ly) + 1) * ((res >> lz) + 1);
+    if (F == 2) {   // the brick with a repeated column: 7 useful columns (grid_device.h gather_corners_brick)
+      if (res >= 13000) continue;   // (x * 9363) >> 16 is x / 7 below 13 107
+      n = (res / 7 + 1) * ((res >> 1) + 1) * ((res >> 1) + 1);
+      lv[l].pad1 = (uint32_t)(res / 7 + 1);
+    }
     if (n * entries_per_line >= (1ull << 32) || used + n + 1 > budget_lines || used + n + 1 >= 0xffffffffull) continue;
     lv[l].brick = (uint32_t)used + 1u;
     lines[l] = n;

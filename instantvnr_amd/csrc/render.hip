@@ -1544,7 +1544,8 @@ void Renderer::render()
   p.n_local = rows_local * p.tiles_per_row * 64u;
   p.debug_flags = 0;
   if (const char* e = std::getenv("VNR_AMD_DEBUG_FLAGS")) p.debug_flags = (uint32_t)std::atoi(e);
-  p.bin_depth_rcp = 1.0f / 8.0f;  // 8 world units (voxels) per depth bin ~ the footprint of an 8x8 pixel tile
+  static const float bin_depth = std::getenv("VNR_AMD_BIN_DEPTH") ? std::max(0.5f, (float)std::atof(std::getenv("VNR_AMD_BIN_DEPTH"))) : 8.0f;   // diagnostics (3 .. 8 measure the same)
+  p.bin_depth_rcp = 1.0f / bin_depth;  // 8 world units (voxels) per depth bin ~ the footprint of an 8x8 pixel tile
   // camera, renderer.cpp:87-96
   const float t = 2.0f * tanf(camera_.fovy * 0.5f * (float)M_PI / 180.0f);
   const float aspect = (float)width_ / (float)height_;

@@ -11,6 +11,7 @@ timeout -k 10 500 python -m pytest tests/test_scene.py -m gpu -x -q > $O/pytest_
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python tools/bench_line.py $T < $O/bench.json
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $R/bench.py --no-cpu-baseline --no-psnr) > $O/stats.log 2>&1; echo "stats rc=$?"
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats.csv && head -12 $O/bench_kernel_stats.csv | cut -c1-170
+t=$(find $O/stats -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python3 tools/union_digest.py "$t" "fused_infer_kernel<2, 32, 0>" $O/bench_infer_intervals.csv > $O/bench_infer_union_digest.txt && cat $O/bench_infer_union_digest.txt
 find $O/stats -name "*.csv" -size +2M -delete
 for c in FETCH_SIZE WRITE_SIZE FETCH_SIZE_h1 WRITE_SIZE_h1; do
   d=$O/pmc_bench_$c

@@ -81,6 +81,49 @@ def scenario_frames(ctx, out):
         vdist.barrier()
 
 
+def scenario_frames_c4(ctx, out):
+    """BASELINE C4 at its full size on every rank: 1024^2 frame of a 1024^3 volume, L = 16 / F = 2 / T = 2^22 hash grid + 3 x 64 MLP with its
+    de-hashed image (finest level beyond 4 GiB): the frame assembled from the ranks' pipelined shares equals the unsharded frame, bit for bit
+    (N_ITERS pinned by the caller: a share of at most 196 608 pixels would otherwise march 32 samples per iteration)"""
+    L = lib()
+    dims = (1024, 1024, 1024)
+    sv = api.vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=6.0)
+    os.environ["VNR_AMD_INIT_SEED"] = "4242"
+    pls = float(np.exp(np.log(1024 / 16.0) / 15))
+    cfg = syn.model_config(n_levels=16, n_features=2, log2_hashmap_size=22, n_hidden_layers=3, per_level_scale=pls)
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+    api.vnrNeuralVolumeTrain(nv, 100, True)
+    check(L.vnrAmdNeuralVolumeSyncReplicas(nv.h))
+    colors, alphas = syn.tfn_ramp_with_bumps(opacity_scale=0.06)
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = syn.oblique_camera(dims, distance_scale=1.1)
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    size = (1024, 1024)
+    plain = make_renderer(nv, tfn, camera, size, 5)
+    n_frames = 4   # the image is built after 24 launches: the later frames read it
+    want = []
+    for _ in range(n_frames):
+        api.vnrRender(plain)
+        want.append(api.vnrRendererMapFrame(plain).copy())
+    out["brick_in_use"] = bool(api.neural_brick_image(nv)["in_use"])
+    sr = vdist.ShardedRenderer(ctx, make_renderer(nv, tfn, camera, size, 5), size[0], size[1])
+    got = []
+    for k in range(n_frames):
+        f = sr.render()
+        if k:
+            got.append(sr.download(f))
+    got.append(sr.download(sr.flush()))
+    out["equal"] = np.array([bool(np.array_equal(g, w)) for g, w in zip(got, want)])
+    out["max_diff"] = float(max(np.abs(g - w).max() for g, w in zip(got, want)))
+    out["differing_pixels"] = float(np.mean(np.any(got[-1] != want[-1], axis=-1)))
+    out["coverage"] = float((want[-1][..., 3] > 0).mean())
+    out["samples"] = int(api.vnrRendererGetFrameStats(sr.r)["n_samples"])
+
+
 def scenario_train(ctx, out):
     """data-parallel training: replicas start from DIFFERENT seeds and must be identical after the first call; parameters stay
     identical over the steps; the by-hand form (TrainBegin / AllReduceGradients / TrainEnd) follows the same trajectory"""
@@ -135,7 +178,7 @@ def main():
     scenario, out_path = sys.argv[1], sys.argv[2]
     ctx = vdist.init_from_env()
     out = {"rank": ctx.rank, "world": ctx.world, "transport": ctx.transport or "none"}
-    {"frames": scenario_frames, "train": scenario_train, "macrocell": scenario_macrocell, "ooc": scenario_ooc}[scenario](ctx, out)
+    {"frames": scenario_frames, "frames_c4": scenario_frames_c4, "train": scenario_train, "macrocell": scenario_macrocell, "ooc": scenario_ooc}[scenario](ctx, out)
     vdist.barrier()
     np.savez(out_path, **out)
     vdist.finalize()

@@ -166,3 +166,15 @@ def test_adam_step_of_the_c4_model_matches_the_restatement(oracle):
         assert np.all(api.neural_gradients(nv) == 0)
     assert api.vnrNeuralVolumeGetTrainingStep(nv) == 2
     assert set(np.unique(steps[n_mlp:])) == {0.0, 1.0, 2.0}     # entries untouched, touched once, touched in both steps
+
+
+@pytest.mark.parametrize("n_iters", ["16", "24"])
+def test_two_ranks_render_the_c4_frame_like_one(n_iters, tmp_path):
+    """BASELINE C4 as it is sharded (tests/dist_gpu_worker.py::scenario_frames_c4; both ranks on this box's one GPU, host-staged
+    collectives), at the reference's N_ITERS and at the library's: every frame assembled from the ranks' pipelined shares is the
+    unsharded frame bit for bit, with the de-hashed image (finest level beyond 4 GiB) in use on every rank"""
+    from test_gpu_dist import run_ranks
+    res = run_ranks("frames_c4", 2, tmp_path, extra_env={"VNR_RM_N_ITERS": n_iters}, timeout=600)
+    for r in res:
+        assert bool(r["brick_in_use"]) and float(r["coverage"]) > 0.5 and int(r["samples"]) > 5_000_000
+        assert bool(np.all(r["equal"])), (int(r["rank"]), r["equal"], float(r["max_diff"]), float(r["differing_pixels"]))

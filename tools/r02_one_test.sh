@@ -1,4 +1,5 @@
 #!/bin/bash
+# one test file / expression on the GPU box: r02_one_test.sh <pytest args>
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-timeout -k 10 500 python -m pytest tests/test_gpu_dist.py tests/test_scene.py -m gpu -x -q -k "command_line" 2>&1 | tail -25
+timeout -k 10 900 python -m pytest "$@" -m gpu -x -q 2>&1 | tail -15

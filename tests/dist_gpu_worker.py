@@ -148,6 +148,25 @@ def scenario_train(ctx, out):
     out["psnr"] = api.vnrNeuralVolumeGetPSNR(nv)
 
 
+def scenario_train_c4(ctx, out):
+    """the C4 model (70 M parameters, 140 MB fp16 gradient blob exchanged range by range under the backward pass) trained data-parallel:
+    replicas that start from different seeds are identical after every call, and the loss falls"""
+    os.environ["VNR_AMD_INIT_SEED"] = str(300 + ctx.rank)
+    sv = api.vnrCreateSimpleVolumePerlin((256, 256, 256), seed=7, octaves=4, base_frequency=6.0)
+    pls = float(np.exp(np.log(1024 / 16.0) / 15))
+    cfg = syn.model_config(n_levels=16, n_features=2, log2_hashmap_size=22, n_hidden_layers=3, per_level_scale=pls)
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+    out["n_params"] = api.neural_info(nv)["n_params"]
+    out["checksum_before"] = vdist.params_checksum(nv)
+    vdist.train_data_parallel(ctx, nv, 2)
+    out["loss_first"] = api.vnrNeuralVolumeGetTrainingLoss(nv)
+    out["checksum_2"] = vdist.params_checksum(nv)
+    vdist.train_data_parallel(ctx, nv, 38)
+    out["loss_last"] = api.vnrNeuralVolumeGetTrainingLoss(nv)
+    out["checksum_40"] = vdist.params_checksum(nv)
+    out["step"] = api.vnrNeuralVolumeGetTrainingStep(nv)
+
+
 def scenario_macrocell(ctx, out):
     """online macrocell construction under data-parallel training: every rank ends with the min / max over ALL ranks' samples"""
     vol = syn.analytic_volume(32)
@@ -178,7 +197,7 @@ def main():
     scenario, out_path = sys.argv[1], sys.argv[2]
     ctx = vdist.init_from_env()
     out = {"rank": ctx.rank, "world": ctx.world, "transport": ctx.transport or "none"}
-    {"frames": scenario_frames, "frames_c4": scenario_frames_c4, "train": scenario_train, "macrocell": scenario_macrocell, "ooc": scenario_ooc}[scenario](ctx, out)
+    {"frames": scenario_frames, "frames_c4": scenario_frames_c4, "train": scenario_train, "train_c4": scenario_train_c4, "macrocell": scenario_macrocell, "ooc": scenario_ooc}[scenario](ctx, out)
     vdist.barrier()
     np.savez(out_path, **out)
     vdist.finalize()

@@ -178,3 +178,16 @@ def test_two_ranks_render_the_c4_frame_like_one(n_iters, tmp_path):
     for r in res:
         assert bool(r["brick_in_use"]) and float(r["coverage"]) > 0.5 and int(r["samples"]) > 5_000_000
         assert bool(np.all(r["equal"])), (int(r["rank"]), r["equal"], float(r["max_diff"]), float(r["differing_pixels"]))
+
+
+def test_two_ranks_train_the_c4_model_data_parallel(tmp_path):
+    """the gradient exchange at the full model size (tests/dist_gpu_worker.py::scenario_train_c4): 70 212 496 parameters, ranks that start
+    from different seeds hold identical parameters after the first call and after 40 steps, and the loss falls"""
+    from test_gpu_dist import run_ranks
+    res = run_ranks("train_c4", 2, tmp_path, timeout=600)
+    a, b = res
+    assert int(a["n_params"]) == 70212496 and int(a["step"]) == 40 and int(b["step"]) == 40
+    assert int(a["checksum_before"]) != int(b["checksum_before"])
+    assert int(a["checksum_2"]) == int(b["checksum_2"]) and int(a["checksum_40"]) == int(b["checksum_40"])
+    assert int(a["checksum_40"]) != int(a["checksum_2"])
+    assert float(a["loss_last"]) < 0.5 * float(a["loss_first"]), (float(a["loss_first"]), float(a["loss_last"]))

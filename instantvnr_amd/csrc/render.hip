@@ -97,7 +97,7 @@ struct RenderParams {
 // streaming kernel modes (ShadingMode, method_raymarching.cu:51-56)
 enum { M_NONE = 0, M_GRADIENT = 1, M_SSH = 2, M_SHADOW = 3 };
 
-// Result arena of one half and one parity, in floats: [slot_cap][2] = {value, t1 - t0} per ray-major sample slot, then (gradient
+// Result arena of one half and one parity, in floats: [slot_cap][2] = {value, t1 - t0} per sample slot, then (gradient
 // shading only) [slot_cap][4] = {f(c + gx), f(c + gy), f(c + gz), unused}.  A queue record's 4th word is the absolute float
 // index its result goes to, so the inference kernel and the ground-truth sampler need not know about shading modes.
 __device__ __forceinline__ uint32_t arena_value_index(uint32_t slot) { return 2u * slot; }
@@ -399,9 +399,10 @@ __device__ __forceinline__ uint32_t depth_bin(const RenderParams& p, float t, fl
 // FIRST: thread = pixel of an 8x8 pixel tile (raygen, method_raymarching.cu:840-875) and emits the first batch.
 // !FIRST: thread = alive ray: compose the batch inferred last iteration (:732-838), then emit the next (:687-730).
 //
-// Two views of one iteration's samples, both over the same compacted range [0, n_samples):
-//  * ray-major (values, dts): a ray's samples are contiguous, so compose needs only (base, count);
-//  * gather order (16-byte queue records {x, y, z, ray-major slot}): inside the 64-ray group of a wave the samples are counting-sorted by DEPTH BIN
+// Two views of one iteration's samples:
+//  * result slots (values, dts): sample j of the ray in lane l of group g is slot (g n_iters + j) 64 + l, so compose needs only (base,
+//    count) and a wave's loads of "sample j of my ray" are neighbours (round 2; ray-major slots before);
+//  * gather order (16-byte queue records {x, y, z, result slot}, compacted over [0, n_samples)): inside the 64-ray group of a wave the samples are counting-sorted by DEPTH BIN
 //    (bin = (t - t_group_front) / bin_depth, LDS-atomic histogram + wave scan).  One bin is a thin slab of an 8x8-pixel
 //    frustum, i.e. a compact brick of the volume, whatever the per-ray sample index is.  The fused inference kernel
 //    reads coords in this order (coherent hash-grid gathers: measured ~2x faster than ray-major order once rays have
@@ -536,7 +537,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         for (uint32_t k0 = 0; k0 < sc_eff && !saturated; k0 += kChunk) {
           vec2f chunk[kChunk];
 #pragma unroll
-          for (uint32_t j = 0; j < kChunk; ++j) chunk[j] = vd_in[sb + min(k0 + j, sc - 1u)];
+          for (uint32_t j = 0; j < kChunk; ++j) chunk[j] = vd_in[sb + 64u * min(k0 + j, sc - 1u)];
           // classification and opacity correction of the whole chunk first: eight independent instruction streams for the
           // scheduler to interleave (a march block runs one or two waves per SIMD, where a dependent instruction issues every
           // ~10 cycles and an independent one every 4); only the blend below is sequential
@@ -554,7 +555,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
             vec3f rgb = crgb[j]; float a = ca[j];
             const vec2f vd = chunk[j];  // {network value, t1 - t0}
             if (GRAD) {  // f(c + gx), f(c + gy), f(c + gz) of this sample, written by the evaluation kernel; .w: the sample's t
-              const vec4f fg = *(const vec4f*)((const float*)vd_in + arena_grad_index(p.slot_cap, sb + k));
+              const vec4f fg = *(const vec4f*)((const float*)vd_in + arena_grad_index(p.slot_cap, sb + 64u * k));
               vec3f stp = p.grad_step;
               if (p.grad_flip) {  // in shader (mode 9): repeat sampleGradient's flip of a step that would leave [0,1] (raytracing.h:128-143)
                 const vec3f c = org + fg.w * dir;
@@ -565,7 +566,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
               rgb = gradient_shade(p, dir, vd.x, fg.x, fg.y, fg.z, stp, rgb);
             }
             if (MODE == M_SSH && h_alpha < (1.0f - alpha) * a) {  // :789-795; the sample's t is kept where GRAD keeps f(c + gx)
-              const float t = ((const float*)vd_in)[arena_grad_index(p.slot_cap, sb + k)];
+              const float t = ((const float*)vd_in)[arena_grad_index(p.slot_cap, sb + 64u * k)];
               h_org = org + t * dir;
               h_color = rgb;
               h_alpha = (1.0f - alpha) * a;
@@ -672,7 +673,10 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
 
     if (survive) {
       const uint32_t slot = (group << 6) + (uint32_t)__popcll(mask & lt_mask);
-      const uint32_t sb = smp_base + (incl - k);  // ray-major base of this ray
+      // Result slots: sample j of the ray in lane l of group g lives in slot (g n_iters + j) 64 + l, so that the 64 rays of a wave read
+      // (compose, next launch) and write (dt below; the evaluation kernel's scatter of a depth bin) NEIGHBOURING slots: a ray-major arena
+      // made every one of those instructions touch 64 lines.  The arena has n_iters slots for every ray anyway; unused ones are holes.
+      const uint32_t sb = group * (uint32_t)p.n_iters * 64u + lane;
       nxt.pixel_index[slot] = pixel;
       nxt.jitter[slot] = jitter;
       nxt.alpha[slot] = alpha;
@@ -690,7 +694,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         const uint32_t g = hist[depth_bin(p, t, front)] + s_rk[j * 256u + tid];  // gather-order slot
         // one 16-byte record per evaluation: position + the float index of the result arena its value goes to
         if (GRAD) {
-          const uint32_t gi = arena_grad_index(p.slot_cap, sb + j);
+          const uint32_t gi = arena_grad_index(p.slot_cap, sb + 64u * j);
           vec4f* q = queue + 4u * (size_t)g;  // the four records of a sample stay adjacent: they fall into the same grid cells
           vec3f stp = p.grad_step;
           if (p.grad_flip) {
@@ -699,15 +703,15 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
             if (c.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
             ((float*)vd_out)[gi + 3u] = t;
           }
-          q[0] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + j))};
+          q[0] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + 64u * j))};
           q[1] = {c.x + stp.x, c.y, c.z, __uint_as_float(gi + 0u)};
           q[2] = {c.x, c.y + stp.y, c.z, __uint_as_float(gi + 1u)};
           q[3] = {c.x, c.y, c.z + stp.z, __uint_as_float(gi + 2u)};
         } else {
-          queue[g] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + j))};
+          queue[g] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + 64u * j))};
         }
-        vd_out[sb + j].y = t1 - t0;
-        if (MODE == M_SSH) ((float*)vd_out)[arena_grad_index(p.slot_cap, sb + j)] = t;   // compose needs the position of the sample
+        vd_out[sb + 64u * j].y = t1 - t0;
+        if (MODE == M_SSH) ((float*)vd_out)[arena_grad_index(p.slot_cap, sb + 64u * j)] = t;   // compose needs the position of the sample
       }
     }
     __builtin_amdgcn_wave_barrier();  // the LDS arrays are reused by the next loop trip

@@ -176,7 +176,7 @@ def test_two_ranks_render_the_c4_frame_like_one(n_iters, tmp_path):
     from test_gpu_dist import run_ranks
     res = run_ranks("frames_c4", 2, tmp_path, extra_env={"VNR_RM_N_ITERS": n_iters}, timeout=600)
     for r in res:
-        assert bool(r["brick_in_use"]) and float(r["coverage"]) > 0.5 and int(r["samples"]) > 5_000_000
+        assert bool(r["brick_in_use"]) and float(r["coverage"]) > 0.3 and int(r["samples"]) > 5_000_000
         assert bool(np.all(r["equal"])), (int(r["rank"]), r["equal"], float(r["max_diff"]), float(r["differing_pixels"]))
 
 

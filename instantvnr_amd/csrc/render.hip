@@ -429,14 +429,16 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
   // the TFN tables are read 4x per composed sample: keep them in LDS (no TA traffic) when they fit
   DeviceTfn tfn = p.tfn;
   constexpr bool GRAD = MODE == M_GRADIENT;
+  tfn_lds_colors_t lds_colors = nullptr;
+  tfn_lds_alphas_t lds_alphas = nullptr;
   if (!FIRST && p.tfn_in_lds) {
     vec4f* s_colors = (vec4f*)(s_rk + (size_t)p.n_iters * 256);
     float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
     for (int e = threadIdx.x; e < p.tfn.n_colors; e += blockDim.x) s_colors[e] = p.tfn.colors[e];
     for (int e = threadIdx.x; e < p.tfn.n_alphas; e += blockDim.x) s_alphas[e] = p.tfn.alphas[e];
     __syncthreads();
-    tfn.colors = s_colors;
-    tfn.alphas = s_alphas;
+    lds_colors = (tfn_lds_colors_t)s_colors;
+    lds_alphas = (tfn_lds_alphas_t)s_alphas;
   }
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t n_in = FIRST ? p.n_local : counters[C_RAYS0 + parity];
@@ -534,20 +536,35 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         constexpr uint32_t kChunk = 8;
         const uint32_t sc_eff = (p.debug_flags & 1u) ? 0u : sc;
         bool saturated = false;
+#if defined(VNR_MARCH_STAMPS)
+        unsigned long long acc_load = 0, acc_cls = 0, acc_blend = 0;
+#endif
         for (uint32_t k0 = 0; k0 < sc_eff && !saturated; k0 += kChunk) {
           vec2f chunk[kChunk];
+          VNR_STAMP(sc0);
 #pragma unroll
           for (uint32_t j = 0; j < kChunk; ++j) chunk[j] = vd_in[sb + 64u * min(k0 + j, sc - 1u)];
+#if defined(VNR_MARCH_STAMPS)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          VNR_STAMP(sc1);
+          acc_load += sc1 - sc0;
+#endif
           // classification and opacity correction of the whole chunk first: eight independent instruction streams for the
           // scheduler to interleave (a march block runs one or two waves per SIMD, where a dependent instruction issues every
           // ~10 cycles and an independent one every 4); only the blend below is sequential
           vec3f crgb[kChunk]; float ca[kChunk];
 #pragma unroll
           for (uint32_t j = 0; j < kChunk; ++j) {
-            if (p.debug_flags & 2u) { crgb[j] = {0.5f, 0.5f, 0.5f}; ca[j] = chunk[j].x * 0.01f; } else
-            tfn_sample(tfn, chunk[j].x, crgb[j], ca[j]);
+            if (p.debug_flags & 2u) { crgb[j] = {0.5f, 0.5f, 0.5f}; ca[j] = chunk[j].x * 0.01f; }
+            else if (p.tfn_in_lds) tfn_sample_lds(tfn, lds_colors, lds_alphas, chunk[j].x, crgb[j], ca[j]);   // uniform branch
+            else tfn_sample(tfn, chunk[j].x, crgb[j], ca[j]);
             ca[j] = opacity_correction(p.step_rcp, chunk[j].y, ca[j]);
           }
+#if defined(VNR_MARCH_STAMPS)
+          asm volatile("" :: "v"(ca[0]), "v"(ca[7]), "v"(crgb[7].x));
+          VNR_STAMP(sc2);
+          acc_cls += sc2 - sc1;
+#endif
 #pragma unroll
           for (uint32_t j = 0; j < kChunk; ++j) {
             const uint32_t k = k0 + j;
@@ -576,7 +593,15 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
             if (MODE != M_SHADOW) { color.x += tr * rgb.x * a; color.y += tr * rgb.y * a; color.z += tr * rgb.z * a; }
             if (!(alpha < VNR_NEARLY_ONE)) { saturated = true; break; }
           }
+#if defined(VNR_MARCH_STAMPS)
+          asm volatile("" :: "v"(alpha), "v"(color.x));
+          VNR_STAMP(sc3);
+          acc_blend += sc3 - sc2;
+#endif
         }
+#if defined(VNR_MARCH_STAMPS)
+        VNR_STAMP_ADD(8, 0ull, acc_load); VNR_STAMP_ADD(9, 0ull, acc_cls); VNR_STAMP_ADD(10, 0ull, acc_blend);
+#endif
         alive = (alpha < VNR_NEARLY_ONE) && dda_resumable(it, m_dir, tmin, tmax, p.mc_dims);
         if (!alive) finish();
       }

@@ -78,4 +78,31 @@ __device__ __forceinline__ void tfn_sample(const DeviceTfn& tfn, float value, ve
   }
 }
 
+// the same lookup with both tables in LDS, read through LDS-typed pointers: a generic pointer that may or may not point to LDS
+// compiles to flat_load, which travels through the texture path and is counted on both wait counters (render.hip, march_kernel)
+typedef float tfn_float4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) tfn_float4_t* tfn_lds_colors_t;
+typedef const __attribute__((address_space(3))) float* tfn_lds_alphas_t;
+__device__ __forceinline__ void tfn_sample_lds(const DeviceTfn& tfn, tfn_lds_colors_t colors, tfn_lds_alphas_t alphas, float value, vec3f& rgb, float& alpha)
+{
+  const float v = (clampf(value, tfn.range_lo, tfn.range_hi) - tfn.range_lo) * tfn.range_rcp_norm;
+  if (tfn.n_colors > 0) {
+    int i0, i1; float a;
+    tfn_coords(tfn.n_colors, v, i0, i1, a);
+    const tfn_float4_t c0 = colors[i0], c1 = colors[i1];
+    rgb.x = c0.x * (1.0f - a) + c1.x * a;
+    rgb.y = c0.y * (1.0f - a) + c1.y * a;
+    rgb.z = c0.z * (1.0f - a) + c1.z * a;
+  } else {
+    rgb = {0, 0, 0};
+  }
+  if (tfn.n_alphas > 0) {
+    int i0, i1; float a;
+    tfn_coords(tfn.n_alphas, v, i0, i1, a);
+    alpha = alphas[i0] * (1.0f - a) + alphas[i1] * a;
+  } else {
+    alpha = 0.0f;
+  }
+}
+
 }  // namespace vnr

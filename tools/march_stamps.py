@@ -38,4 +38,6 @@ for parts in (1, 8):
     print(f"share 1/{parts}: {trips / n:.0f} wave-trips per frame; cycles per trip (s_memtime, 100 MHz ticks x ... as reported):")
     for i in range(7):
         print(f"   {names[i]:28s} {out[i] / trips:10.0f}")
+    for i, nm in ((8, "compose: result loads"), (9, "compose: classify"), (10, "compose: blend")):
+        print(f"   {nm:28s} {out[i] / trips:10.0f}")
     del ren

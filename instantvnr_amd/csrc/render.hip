@@ -611,6 +611,10 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     VNR_STAMP_ADD(1, st0, st2);   // ... + compose
     // emit the next batch of this ray into LDS
     uint32_t k = 0;
+#if defined(VNR_MARCH_STAMPS)
+    uint32_t dbg_cells = 0;
+    const vec3i dbg_cell0 = it.cell;
+#endif
     if (alive && !(p.debug_flags & 8u)) {
       const int n_iters = p.n_iters;
       iter_exec(p, it, m_dir, tmin, tmax, p.step, [&](float t0, float t1) -> bool {
@@ -619,7 +623,18 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         return (int)(++k) < n_iters;
       });
       if (k == 0) finish();  // nothing left to sample: the ray is finished
+#if defined(VNR_MARCH_STAMPS)
+      dbg_cells = (uint32_t)(abs(it.cell.x - dbg_cell0.x) + abs(it.cell.y - dbg_cell0.y) + abs(it.cell.z - dbg_cell0.z));
+#endif
     }
+#if defined(VNR_MARCH_STAMPS)
+    {  // macrocell steps of this trip: the wave's longest ray, the sum over its rays, its alive rays
+      uint32_t mx = dbg_cells, sm = dbg_cells;
+      for (int d = 32; d > 0; d >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, d)); sm += (uint32_t)__shfl_xor((int)sm, d); }
+      const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+      VNR_STAMP_ADD(11, 0ull, (unsigned long long)mx); VNR_STAMP_ADD(12, 0ull, (unsigned long long)sm); VNR_STAMP_ADD(13, 0ull, (unsigned long long)n_alive);
+    }
+#endif
     const bool survive = alive && k > 0;
     VNR_STAMP(st3);
     VNR_STAMP_ADD(2, st2, st3);   // DDA walk + samples to LDS

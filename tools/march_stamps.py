@@ -40,4 +40,5 @@ for parts in (1, 8):
         print(f"   {names[i]:28s} {out[i] / trips:10.0f}")
     for i, nm in ((8, "compose: result loads"), (9, "compose: classify"), (10, "compose: blend")):
         print(f"   {nm:28s} {out[i] / trips:10.0f}")
+    print(f"   macrocell steps per trip: longest ray of the wave {out[11] / trips:.1f}, mean over its alive rays {out[12] / max(out[13], 1):.2f}; alive rays per trip {out[13] / trips:.1f}")
     del ren

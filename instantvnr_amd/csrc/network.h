@@ -205,7 +205,6 @@ private:
   mutable DeviceBuffer<LevelInfo> levels_brick_dev_{MemTag::Network};
   mutable bool brick_valid_ = false, brick_refused_ = false;
   mutable uint32_t brick_stable_calls_ = 0;
-  mutable hipEvent_t brick_event_ = nullptr;
   mutable float brick_build_ms_ = 0.0f;
   uint32_t brick_res_cap_ = 0;   // 0: no cap
   int brick_mode_ = -1;

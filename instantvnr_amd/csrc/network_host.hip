@@ -232,7 +232,6 @@ void Network::refresh_inference_weights(hipStream_t s)
 Network::~Network()
 {
   live_networks().erase(this);
-  if (brick_event_) (void)hipEventDestroy(brick_event_);
   for (hipEvent_t e : prof_events_) (void)hipEventDestroy(e);
 }
 
@@ -393,8 +392,6 @@ void Network::build_brick_image(hipStream_t s) const
   // pageable host source: the copy has completed for the host when the call returns, the device side is ordered on `s`
   VNR_HIP_CHECK(hipMemcpyAsync(levels_brick_dev_.ptr, lv.data(), kMaxLevels * sizeof(LevelInfo), hipMemcpyHostToDevice, s));
   VNR_HIP_CHECK(hipEventRecord(t1, s));
-  if (!brick_event_) VNR_HIP_CHECK(hipEventCreateWithFlags(&brick_event_, hipEventDisableTiming));
-  VNR_HIP_CHECK(hipEventRecord(brick_event_, s));
   VNR_HIP_CHECK(hipEventSynchronize(t1));
   VNR_HIP_CHECK(hipEventElapsedTime(&brick_build_ms_, t0, t1));
   (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
@@ -413,8 +410,9 @@ const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image)
     build_brick_image(s);
     if (!brick_valid_) return levels_dev_.ptr;
   }
-  // the image was built on one stream; launches on any other stream wait for it (a no-op once it has completed)
-  VNR_HIP_CHECK(hipStreamWaitEvent(s, brick_event_, 0));
+  // the image was built on one stream and build_brick_image returned only after the host had seen the build complete, so launches
+  // on any stream may read it (a per-launch hipStreamWaitEvent on the build's event stood here: one more API call and one more barrier
+  // packet in front of every evaluation kernel, always on a completed event)
   *image = brick_image_.ptr;
   return levels_brick_dev_.ptr;
 }

@@ -120,7 +120,7 @@ public:
   void deserialize_params(const Json& j, hipStream_t s);
 
   // inference: coords [n][3] fp32 -> out [n] fp32.  n either by value or read on the device from d_n.
-  // d_dest (optional): result of sample i is written to d_out[d_dest[i]] (the ray marcher's gather order -> ray-major map).
+  // d_dest (optional): result of sample i is written to d_out[d_dest[i]] (the ray marcher's gather order -> result slot map).
   void inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                  const uint32_t* d_dest = nullptr) const;
   // ray marcher's sample queue: records {x, y, z, dest} (16 B); result of a record goes to d_out[dest * out_stride]

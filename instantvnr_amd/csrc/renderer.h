@@ -154,7 +154,7 @@ private:
   uint32_t predicted_pt_ = 0;
   DeviceBuffer<float> ssh_px_;     // ... and per pixel: org[3], colour[3], alpha, second jitter, unshaded rgba[4]
   DeviceBuffer<uint32_t> ray_counts_;  // surviving rays per 64-ray group of the last march (order-preserving compaction)
-  DeviceBuffer<vec4f> queue_;      // gather-order sample records {x, y, z, ray-major slot}
+  DeviceBuffer<vec4f> queue_;      // gather-order sample records {x, y, z, result slot}
   DeviceBuffer<float> arena_;      // evaluation results, x2 (ping-pong): per slot {value, t1 - t0}, then (gradient shading) 4 more floats
   bool queue_grad_ = false;        // queues currently sized for 4 records / 6 result floats per sample
   DeviceBuffer<uint32_t> counters_;  // 2 x C_COUNT: one block per half

@@ -418,7 +418,8 @@ template <bool FIRST, int MODE>
 __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const RayList cur, const RayList nxt,
                                                     const vec2f* __restrict__ vd_in, vec4f* __restrict__ queue,
                                                     vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters,
-                                                    uint32_t* __restrict__ ray_counts, int parity, const SshLists ssh_lists)
+                                                    uint32_t* __restrict__ ray_counts, int parity, const SshLists ssh_lists,
+                                                    uint32_t* __restrict__ tail_flag)
 {
   extern __shared__ float s_t[];  // [n_iters][256] x {t0, t1}, histogram[256], claims[16], [n_iters][256] ranks (u16), then the transfer function tables
   float* s_t0 = s_t;
@@ -657,6 +658,9 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     }
     const uint32_t wave_samples = __shfl(incl, 63);
     const uint32_t wave_rays = (uint32_t)__popcll(mask);
+    // the march the host expects to be the frame's last is launched without evaluation and packing behind it and reports here (pinned
+    // host memory) whether that expectation held (launch_iteration)
+    if (tail_flag && lane == 0 && wave_rays) *tail_flag = 1u;
     // Surviving rays go to the wave's OWN 64 slots of the scratch list (`nxt`) and compact_rays_kernel packs the groups in
     // wave order afterwards: an order-preserving compaction, so a 64-ray group stays a compact patch of the image over the
     // iterations.  (Claiming slots with an atomic, as the reference does, hands them out in wave-arrival order; by the third
@@ -1331,6 +1335,7 @@ struct PartState {
   size_t s_max;
   uint32_t it = 0, used = 0;
   bool done = false;
+  bool tail_skipped = false;   // the last march launched has no evaluation / packing behind it yet (launch_iteration)
   hipEvent_t ev_done = nullptr;   // recorded behind the last iteration launched so far: the host (and the communication stream)
                                   // wait for THIS, not for the stream, which may already hold the head of the next frame
 };
@@ -1863,6 +1868,14 @@ void Renderer::launch_iteration(StreamingFrame& f, int h)
     const int parity = (int)(it & 1u);
     const uint32_t P = hf.p.n_local;
     uint32_t* c = hf.c;
+    // The march the previous frame ended with (it composes the last batch and finds no ray left to sample) is launched WITHOUT an
+    // evaluation and a packing kernel behind it: both would be empty, and on a small share of the frame they are two more launches
+    // on a chain of fifteen.  The march says in pinned memory whether a ray did survive; finish_streaming then launches the two
+    // kernels after all (launch_tail) and goes on as if they had been there.  VNR_AMD_TAIL_SKIP=0 switches this off (diagnostics).
+    static const bool tail_skip = [] { const char* e = std::getenv("VNR_AMD_TAIL_SKIP"); return !e || std::atoi(e) != 0; }();
+    const bool skip_tail = tail_skip && it >= 1 && it + 1 == f.predicted[h] && it + 1 < max_iterations;
+    uint32_t* tail_flag = nullptr;
+    if (skip_tail) { hf.hs[0] = 0; tail_flag = hf.hs; }   // hs[0 .. C_HIT) is not used by the packing kernel's statistics
     // march(it): reads the dense ray list rl[0] (count: counter `parity`), leaves the survivors of every 64-ray group in the
     // group's slots of the scratch list rl[1] and appends their samples to queue `parity`
     {
@@ -1871,7 +1884,7 @@ void Renderer::launch_iteration(StreamingFrame& f, int h)
       const size_t lds = first ? shmem : shmem_compose;
       const vec2f* vd_in = hf.vd[parity ^ 1];
       vec2f* vd_out = hf.vd[parity];
-#define VNR_MARCH(FIRST_, MODE_) march_kernel<FIRST_, MODE_><<<blocks, 256, lds, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], vd_in, hf.queue, vd_out, c, hf.rc, parity, hf.ssh)
+#define VNR_MARCH(FIRST_, MODE_) march_kernel<FIRST_, MODE_><<<blocks, 256, lds, hf.s>>>(hf.p, hf.rl[0], hf.rl[1], vd_in, hf.queue, vd_out, c, hf.rc, parity, hf.ssh, tail_flag)
       switch (pass_mode) {
       case M_GRADIENT: if (first) VNR_MARCH(true, M_GRADIENT); else VNR_MARCH(false, M_GRADIENT); break;
       case M_SSH: if (first) VNR_MARCH(true, M_SSH); else VNR_MARCH(false, M_SSH); break;
@@ -1881,6 +1894,34 @@ void Renderer::launch_iteration(StreamingFrame& f, int h)
 #undef VNR_MARCH
     }
     VNR_HIP_CHECK(hipGetLastError());
+    if (skip_tail) {
+      if (profiling_) { VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], hf.s)); VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it + 1], hf.s)); }
+      hf.tail_skipped = true;
+      ++hf.it;
+      if (hf.it >= max_iterations) hf.done = true;
+      return;
+    }
+  }
+  launch_tail(f, h, half[h].it);
+  {
+    PartState& hf = half[h];
+    ++hf.it;
+    if (hf.it >= max_iterations) hf.done = true;
+  }
+}
+
+// evaluation of the samples march(it) emitted, then the packing of its survivors
+void Renderer::launch_tail(StreamingFrame& f, int h, uint32_t it)
+{
+  PartState* half = f.part;
+  const int H = f.H;
+  const bool grad = f.grad, ssh = f.ssh;
+  NeuralVolume* nv = f.nv;
+  {
+    PartState& hf = half[h];
+    const int parity = (int)(it & 1u);
+    const uint32_t P = hf.p.n_local;
+    uint32_t* c = hf.c;
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], hf.s));
     if (nv) {
       // a record's 4th word is the float index of its result in this arena (stride 1)
@@ -1901,8 +1942,6 @@ void Renderer::launch_iteration(StreamingFrame& f, int h)
       compact_rays_kernel<16><<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
                                                                         hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
     VNR_HIP_CHECK(hipGetLastError());
-    ++hf.it;
-    if (hf.it >= max_iterations) hf.done = true;
   }
 }
 
@@ -1941,7 +1980,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
   f.slot = slot;
   slot_ = slot;
   PartState* half = f.part;
-  for (int h = 0; h < kMaxParts; ++h) { half[h].it = 0; half[h].used = 0; half[h].done = false; }
+  for (int h = 0; h < kMaxParts; ++h) { half[h].it = 0; half[h].used = 0; half[h].done = false; half[h].tail_skipped = false; }
   const size_t n_groups_slot = QP / 64 + 64 + 8 * kMaxParts;
   uint32_t* const u32_base = q_u32_.ptr + (size_t)slot * 6 * QP;
   float* const f32_base = q_f32_.ptr + (size_t)slot * 18 * QP;
@@ -2058,6 +2097,14 @@ void Renderer::finish_streaming(StreamingFrame& f)
       if (hf.done) continue;
       if (hf.it > 0) {
         VNR_HIP_CHECK(hipEventSynchronize(hf.ev_done));
+        if (hf.tail_skipped) {   // the last march went out alone (launch_iteration)
+          hf.tail_skipped = false;
+          if (hf.hs[0] == 0) { hf.hc[(hf.it - 1) & 255u] = 0; hf.done = true; continue; }   // as expected: no ray left, what the packing kernel would have published
+          launch_tail(f, h, hf.it - 1);   // a ray did survive: evaluate and pack after all, then look at the count like after any iteration
+          f.mark(h);
+          pending = true;
+          continue;
+        }
         if (hf.hc[(hf.it - 1) & 255u] == 0) { hf.done = true; continue; }
       }
       launch_iteration(f, h);

@@ -81,6 +81,7 @@ private:
   struct StreamingFrame;   // render.hip
   void render_streaming(const RenderParams& p, int pass_mode, bool defer = false);   // one iterative_raymarching_loop<MODE> (method_raymarching.cu:931-958)
   void launch_iteration(StreamingFrame& f, int part);
+  void launch_tail(StreamingFrame& f, int part, uint32_t it);
   void finish_streaming(StreamingFrame& f);
   void finish_pending();
   void render_monolithic(const RenderParams& p);

@@ -79,7 +79,8 @@ static_assert(sizeof(OptState) == 16, "OptState must be one 16-byte record");
 // Data-parallel hook (dist.h): forward_backward calls it in stream order whenever this rank's fp32 gradient of a
 // contiguous parameter range is complete (the MLP first, then the hash-grid levels from the finest to the coarsest in buckets),
 // so the exchange of one range runs while the backward pass of the next still does.
-struct TileNet;   // infer_tile.h: what a kernel needs to evaluate the network itself
+struct TileNet;
+struct PackArgs;   // infer_tile.h: what a kernel needs to evaluate the network itself
 
 struct GradExchange {
   virtual ~GradExchange() = default;
@@ -128,8 +129,10 @@ public:
   // for a kernel that evaluates the network inside its own loop (the in-shader ray marcher, in_shader.h): levels (brick image
   // policy applied, as for an inference launch on `s`), table, weight image.  false: this model is not one of the MFMA kernels' shapes
   bool tile_net(TileNet* out, hipStream_t s) const;
-  void inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
-                       uint32_t sharers = 1) const;
+  // `pack` (pack_rays.h): the ray marcher's packing of the iteration, run as a prologue of the evaluation kernel; -> false when this
+  // model's kernel cannot take it (the caller then launches the packing kernel itself)
+  bool inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
+                       uint32_t sharers = 1, const PackArgs* pack = nullptr) const;
   // encode only: fp16 [n][padded_width]
   void encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const;
 

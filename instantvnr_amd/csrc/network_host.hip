@@ -10,6 +10,7 @@
 #include <set>
 
 #include "infer_tile.h"
+#include "pack_rays.h"
 
 namespace vnr {
 
@@ -18,7 +19,7 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                   const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr,
-                  uint32_t sharers = 1);
+                  uint32_t sharers = 1, const struct PackArgs* pack = nullptr);
 void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
                         uint32_t n_hidden_matmuls, uint32_t width, uint64_t seed, hipStream_t s);
 void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, uint32_t n_active_levels, uint32_t in_width, const LevelInfo* d_levels,
@@ -482,19 +483,20 @@ void Network::inference(const float* d_coords, float* d_out, size_t n, const uin
                mlp_packed_.ptr, lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest, 0, image);
 }
 
-void Network::inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
-                              uint32_t sharers) const
+bool Network::inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
+                              uint32_t sharers, const PackArgs* pack) const
 {
   if (!fast_path()) {
     launch_generic(0, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_records, d_out, nullptr, 0, d_n, n_max, s, nullptr, out_stride);
-    return;
+    return false;
   }
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
   GridDevice grid = grid_;
   grid.n_levels = n_active_levels();
   launch_fused(0, grid, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image, sharers);
+               mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image, sharers, pack);
+  return pack != nullptr;
 }
 
 bool Network::tile_net(TileNet* out, hipStream_t s) const

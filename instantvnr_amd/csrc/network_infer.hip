@@ -20,6 +20,7 @@
 //  * persistent blocks, XCD-contiguous tile ranges, sample count optionally read from device memory so the
 //    ray marcher never syncs with the host.
 #include "infer_tile.h"
+#include "pack_rays.h"
 
 namespace vnr {
 
@@ -88,6 +89,7 @@ struct InferArgs {
   uint32_t lds_halves;
   uint32_t sharers;          // kernels of this kind expected to share the GPU (host-side launch sizing only)
   uint32_t lds_table_halves; // VNR_LDS_LEVELS experiment: halves of the table's head staged behind the weights (0: none)
+  PackArgs pack;             // MODE 0, queue launches of the ray marcher: the iteration's ray packing as a prologue (pack.n_blocks > 0)
 };
 
 // MODE 0: inference (out only), 1: encode only (features_out), 2: training forward (features + acts + out)
@@ -100,6 +102,16 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
 
+  // The ray marcher's packing of this iteration's survivors (pack_rays.h) needs what the march kernel wrote and nothing this kernel
+  // writes: as a prologue it costs no launch of its own on the chain march -> evaluate -> pack -> march.  Work items are dealt over the
+  // blocks; the words of LDS it uses are overwritten by the weights afterwards.
+  if (MODE == 0 && args.pack.n_blocks) {
+    uint32_t* s_part = (uint32_t*)lds;
+    for (uint32_t item = blockIdx.x; item < args.pack.n_blocks; item += gridDim.x) {
+      pack_rays_block<4>(args.pack, item, s_part);
+      __syncthreads();
+    }
+  }
   const uint32_t n = args.n_ptr ? *args.n_ptr : args.n;
   const uint32_t n_tiles = (n + 63u) >> 6;
   // XCD-contiguous tile ranges: blocks with equal (blockIdx % 8) share an XCD / L2 (speed only)
@@ -335,9 +347,9 @@ void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, ui
 void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
-                  const uint32_t* d_dest, uint32_t queue_out_stride, const uint8_t* brick_image, uint32_t sharers)
+                  const uint32_t* d_dest, uint32_t queue_out_stride, const uint8_t* brick_image, uint32_t sharers, const PackArgs* pack)
 {
-  if (n_max == 0) return;
+  if (n_max == 0) { if (pack && pack->n_blocks) throw std::runtime_error("internal: ray packing fused into an empty evaluation launch"); return; }
   if (n_max > 0xffffffc0ull) throw std::runtime_error("inference batch too large (max 2^32-64 samples per call)");
   if (table_bytes >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
   InferArgs a;
@@ -362,6 +374,7 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
   a.activation = activation;
   a.lds_halves = lds_halves;
   a.lds_table_halves = 0;
+  if (pack && mode == 0) a.pack = *pack; else a.pack.n_blocks = 0;
 #if defined(VNR_LDS_LEVELS)
   if (mode == 0 && grid.n_features == 2 && grid.n_levels > VNR_LDS_LEVELS && !grid.levels[VNR_LDS_LEVELS - 1].hashed)
     a.lds_table_halves = (grid.levels[VNR_LDS_LEVELS].offset * 2u + 7u) & ~7u;   // the first levels are the head of the table

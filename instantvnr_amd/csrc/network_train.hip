@@ -16,7 +16,7 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
                   const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
                   float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                   const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr,
-                  uint32_t sharers = 1);
+                  uint32_t sharers = 1, const struct PackArgs* pack = nullptr);
 
 // ------------------------------------------------------------------------------------------------ pcg32
 struct Pcg32 {

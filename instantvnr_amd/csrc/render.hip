@@ -21,35 +21,13 @@
 
 #include "dist.h"
 #include "infer_tile.h"
+#include "pack_rays.h"
 #include "sampling_device.h"
 
 namespace vnr {
 
 #define VNR_FLOAT_LARGE 1e20f
 #define VNR_NEARLY_ONE 0.9999f
-
-struct RayList {  // per ray payload, SoA (RayMarchingData, method_raymarching.cu:59-93)
-  uint32_t* pixel_index;
-  float* jitter;
-  float* alpha;
-  vec3f* color;
-  vec3i* cell;
-  vec3f* t_next;
-  float* next_cell_begin;
-  uint32_t* sample_base;
-  uint32_t* sample_count;
-};
-
-// SINGLE_SHADE_HEURISTIC only (inter_highest_*, method_raymarching.cu:84-87): per ray, the sample that has contributed most so
-// far; [0] belongs to the dense ray list, [1] to the scratch list.  A kernel argument of its own, behind the others, so that
-// the instances that never touch it do not drag it through their scalar registers: as members of RayList these six pointers
-// cost the unshaded march kernel 6 more spilled SGPRs (90 -> 96) and the bench 3 % of its frame rate (A/B on one box,
-// tools/ab/ab.sh, n = 3 each: 195-198 against 201-204 frames/s; 199-200 against 199-201 with this layout).
-struct SshLists {
-  vec3f* org[2];
-  vec3f* color[2];
-  float* alpha[2];
-};
 
 struct RenderParams {
   vec4f* frame;
@@ -116,7 +94,7 @@ __device__ unsigned long long g_march_stamps[16];
 #define VNR_STAMP_ADD(slot, a, b)
 #endif
 
-enum { C_RAYS0 = 0, C_RAYS1 = 1, C_SAMPLES0 = 2, C_SAMPLES1 = 3, C_HIT = 4, C_STAT_SAMPLES = 6, C_STAT_REFRAYS = 8, C_COUNT = 16 };
+// C_*: the device counters of a ray part (pack_rays.h)
 
 // ------------------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
@@ -793,90 +771,12 @@ __global__ void gt_sample_kernel(const uint32_t* __restrict__ n_ptr, const float
   }
 }
 
-// Packs the 64-ray groups march_kernel left in the scratch list (group g holds ray_counts[g] rays in slots 64 g ..) into the
-// dense list, in group order.  One thread per scratch slot; a block (16 groups) first sums the counts of all groups before
-// it (at most 64 KiB of L2-resident counts per block), so no second launch and no inter-block dependency is needed.  The block
-// that holds the last group publishes the number of alive rays; block 0 also clears the sample counter the next march adds to.
+// pack_rays_block (pack_rays.h) as a kernel of its own: ground-truth volumes, models outside the MFMA kernels' shapes, VNR_AMD_FUSED_PACK=0
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) compact_rays_kernel(const RayList src, const RayList dst, const uint32_t* __restrict__ ray_counts,
-                                                            uint32_t n_first, uint32_t* __restrict__ counters, int parity, int first, int ssh, const SshLists ssh_lists,
-                                                            uint32_t* __restrict__ host_alive, uint32_t* __restrict__ host_stats, int grad)
+__global__ void __launch_bounds__(64 * WAVES) compact_rays_kernel(const PackArgs a)
 {
-  constexpr uint32_t T = 64u * WAVES;  // threads = scratch slots per block; WAVES groups
   __shared__ uint32_t s_part[WAVES];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t n_in = first ? n_first : counters[C_RAYS0 + parity];   // rays the march that just ran consumed
-  const uint32_t n_groups = ((n_in + 255u) & ~255u) >> 6;               // groups it wrote a count for
-  if (blockIdx.x == 0 && tid == 0) counters[C_SAMPLES0 + (parity ^ 1)] = 0;
-  // the host reads the alive-ray count and the frame statistics from pinned memory the kernel writes itself: a copy
-  // engine operation between two kernels of a stream costs more than either of the small kernels
-  if (n_groups == 0) {  // nothing marched: the statistics are those of the previous launch
-    if (blockIdx.x == 0 && tid == 0) { counters[C_RAYS0 + (parity ^ 1)] = 0; *host_alive = 0; }
-    if (blockIdx.x == 0 && tid >= C_HIT && tid < C_COUNT) host_stats[tid] = counters[tid];
-    return;
-  }
-  const uint32_t g0 = blockIdx.x * (uint32_t)WAVES;
-  if (g0 >= n_groups) return;
-  // a group's count: survivors in the low byte, rays that were alive when the march began to emit above it
-  uint32_t sum = 0;
-  for (uint32_t g = tid; g < g0; g += T) sum += ray_counts[g] & 0xffu;
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
-  if (lane == 0) s_part[wave] = sum;
-  __syncthreads();
-  uint32_t before = 0;
-#pragma unroll
-  for (int w = 0; w < WAVES; ++w) before += s_part[w];
-  // counts of this block's groups: lane l < WAVES of every wave holds count[g0 + l]
-  const uint32_t mine = (lane < (uint32_t)WAVES && g0 + lane < n_groups) ? ray_counts[g0 + lane] & 0xffu : 0u;
-  uint32_t incl = mine;
-#pragma unroll
-  for (int d = 1; d < WAVES; d <<= 1) {
-    const uint32_t y = __shfl_up(incl, d);
-    if ((int)lane >= d) incl += y;
-  }
-  const uint32_t count = __shfl(mine, (int)wave), base = before + __shfl(incl, (int)wave) - count;
-  const uint32_t block_total = __shfl(incl, WAVES - 1);
-  const bool last_block = g0 + (uint32_t)WAVES >= n_groups;  // (block-uniform) the block that holds the last group
-  if (last_block && tid == 0) { counters[C_RAYS0 + (parity ^ 1)] = before + block_total; *host_alive = before + block_total; }
-  if (lane < count) {
-    const uint32_t from = ((g0 + wave) << 6) + lane, to = base + lane;
-    dst.pixel_index[to] = src.pixel_index[from];
-    dst.jitter[to] = src.jitter[from];
-    dst.alpha[to] = src.alpha[from];
-    dst.color[to] = src.color[from];
-    dst.cell[to] = src.cell[from];
-    dst.t_next[to] = src.t_next[from];
-    dst.next_cell_begin[to] = src.next_cell_begin[from];
-    dst.sample_base[to] = src.sample_base[from];
-    dst.sample_count[to] = src.sample_count[from];
-    if (ssh) {  // scratch [1] -> dense [0]
-      ssh_lists.org[0][to] = ssh_lists.org[1][from]; ssh_lists.color[0][to] = ssh_lists.color[1][from]; ssh_lists.alpha[0][to] = ssh_lists.alpha[1][from];
-    }
-  }
-  // Frame statistics of the march that just ran (it used to count them with three device-scope atomics per wave), summed by
-  // the last block after its copies so that the kernel needs no more registers than the copies do: a 1024-thread block has
-  // to find room next to the persistent blocks of the other half's evaluation kernel.
-  if (last_block) {
-    uint32_t asum = 0;
-    for (uint32_t g = tid; g < n_groups; g += T) asum += ray_counts[g] >> 8;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) asum += __shfl_xor(asum, d);
-    __syncthreads();  // s_part is read above
-    if (lane == 0) s_part[wave] = asum;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t alive_total = 0;
-      for (int w = 0; w < WAVES; ++w) alive_total += s_part[w];
-      const uint32_t records = counters[C_SAMPLES0 + parity];
-      unsigned long long* c64 = (unsigned long long*)counters;
-      c64[C_STAT_SAMPLES / 2] += (unsigned long long)(grad ? records >> 2 : records);
-      c64[C_STAT_REFRAYS / 2] += (unsigned long long)alive_total;
-      if (first) counters[C_HIT] += alive_total;
-    }
-    __syncthreads();
-    if (tid >= C_HIT && tid < C_COUNT) host_stats[tid] = ((volatile uint32_t*)counters)[tid];
-  }
+  pack_rays_block<WAVES>(a, blockIdx.x, s_part);
 }
 
 // ------------------------------------------------------------------------------------------------ monolithic marcher (mode 4)
@@ -1922,25 +1822,35 @@ void Renderer::launch_tail(StreamingFrame& f, int h, uint32_t it)
     const int parity = (int)(it & 1u);
     const uint32_t P = hf.p.n_local;
     uint32_t* c = hf.c;
+    // the packing of march(it)'s survivors into rl[0] in group order (count -> counter `parity^1`; clears the sample counter of march(it+1)):
+    // as a prologue of the evaluation kernel when that is one of the MFMA kernels, else a kernel of its own behind it
+    PackArgs pk;
+    pk.src = hf.rl[1]; pk.dst = hf.rl[0]; pk.ray_counts = hf.rc; pk.n_first = P; pk.counters = c; pk.parity = parity; pk.first = it == 0 ? 1 : 0;
+    pk.ssh = ssh ? 1 : 0; pk.grad = grad ? 1 : 0; pk.ssh_lists = hf.ssh; pk.host_alive = hf.hc + (it & 255u); pk.host_stats = hf.hs;
+    pk.n_blocks = div_round_up(P, 256);
+    static const bool fused_pack = [] { const char* e = std::getenv("VNR_AMD_FUSED_PACK"); return !e || std::atoi(e) != 0; }();   // 0: diagnostics
+    bool packed = false;
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], hf.s));
     if (nv) {
       // a record's 4th word is the float index of its result in this arena (stride 1)
-      nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 1, c + C_SAMPLES0 + parity, hf.s_max, hf.s, (uint32_t)H);
+      packed = nv->network().inference_queue((const float*)hf.queue, (float*)hf.vd[parity], 1, c + C_SAMPLES0 + parity, hf.s_max, hf.s, (uint32_t)H,
+                                             fused_pack ? &pk : nullptr);
     } else {
       const uint32_t blocks = std::min<uint32_t>(div_round_up(hf.s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
       gt_sample_kernel<<<blocks, 256, 0, hf.s>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, (float*)hf.vd[parity]);
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it + 1], hf.s));
-    // pack the survivors into rl[0] in group order (count -> counter `parity^1`) and clear the sample counter of march(it+1)
-    // 1024-thread blocks need 4 free wave slots on every SIMD of one CU at once, which the other half's evaluation kernel
-    // rarely leaves: a small share (where the wait shows) packs with 256-thread blocks
-    static const uint32_t small_limit = [] { const char* e = std::getenv("VNR_AMD_COMPACT_SMALL_LIMIT"); return e ? (uint32_t)std::atoll(e) : 262144u; }();  // diagnostics
-    if (P <= small_limit)
-      compact_rays_kernel<4><<<div_round_up(P, 256), 256, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
-                                                                     hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
-    else
-      compact_rays_kernel<16><<<div_round_up(P, 1024), 1024, 0, hf.s>>>(hf.rl[1], hf.rl[0], hf.rc, P, c, parity, it == 0 ? 1 : 0, ssh ? 1 : 0, hf.ssh,
-                                                                        hf.hc + (it & 255u), hf.hs, grad ? 1 : 0);
+    if (!packed) {
+      // 1024-thread blocks need 4 free wave slots on every SIMD of one CU at once, which the other half's evaluation kernel
+      // rarely leaves: a small share (where the wait shows) packs with 256-thread blocks
+      static const uint32_t small_limit = [] { const char* e = std::getenv("VNR_AMD_COMPACT_SMALL_LIMIT"); return e ? (uint32_t)std::atoll(e) : 262144u; }();  // diagnostics
+      if (P <= small_limit) {
+        compact_rays_kernel<4><<<pk.n_blocks, 256, 0, hf.s>>>(pk);
+      } else {
+        pk.n_blocks = div_round_up(P, 1024);
+        compact_rays_kernel<16><<<pk.n_blocks, 1024, 0, hf.s>>>(pk);
+      }
+    }
     VNR_HIP_CHECK(hipGetLastError());
   }
 }

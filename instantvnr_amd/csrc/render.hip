@@ -1828,7 +1828,12 @@ void Renderer::launch_tail(StreamingFrame& f, int h, uint32_t it)
     pk.src = hf.rl[1]; pk.dst = hf.rl[0]; pk.ray_counts = hf.rc; pk.n_first = P; pk.counters = c; pk.parity = parity; pk.first = it == 0 ? 1 : 0;
     pk.ssh = ssh ? 1 : 0; pk.grad = grad ? 1 : 0; pk.ssh_lists = hf.ssh; pk.host_alive = hf.hc + (it & 255u); pk.host_stats = hf.hs;
     pk.n_blocks = div_round_up(P, 256);
-    static const bool fused_pack = [] { const char* e = std::getenv("VNR_AMD_FUSED_PACK"); return !e || std::atoi(e) != 0; }();   // 0: diagnostics
+    // Only where the launch it saves is on the critical path, i.e. a part of at most 262 144 rays (a 1/2 .. 1/8 share of the bench frame):
+    // a whole frame's packing kernel runs under the other part's evaluation kernel, the frame takes the same time either way, and the
+    // evaluation kernel's own time (what bench.py's roofline is computed from) would carry the packing's 15-20 us per launch.
+    // VNR_AMD_FUSED_PACK=0 / 2: never / always (diagnostics).
+    static const int fused_pack_mode = [] { const char* e = std::getenv("VNR_AMD_FUSED_PACK"); return e ? std::atoi(e) : 1; }();
+    const bool fused_pack = fused_pack_mode == 2 || (fused_pack_mode == 1 && P <= 262144u);
     bool packed = false;
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], hf.s));
     if (nv) {

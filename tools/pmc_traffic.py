@@ -16,12 +16,13 @@ KERNEL = "fused_infer_kernel<2, 32, 0>"
 
 def frames_of(path, n_frames):
     """-> list of frames, each a list of counter values (KiB) of the evaluation kernel's dispatches.  Dispatch ids are in enqueue
-    order and every frame enqueues the same number of launches (ITERS x halves), so the dispatches split evenly"""
+    order and every steady-state frame enqueues the same number of launches (ITERS x halves)"""
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"]))
     vals = [float(r["Counter_Value"]) for r in rows if KERNEL in r["Kernel_Name"]]
-    if len(vals) % n_frames:
-        raise SystemExit(f"{path}: {len(vals)} dispatches do not split into {n_frames} frames")
+    # the first frame of a pass launches more (no iteration count to predict from, and it keeps the evaluation launch behind its last
+    # march): the surplus dispatches are the pass's first ones, the frames that are used are the last
     per = len(vals) // n_frames
+    vals = vals[len(vals) - per * n_frames:]
     return [vals[i * per:(i + 1) * per] for i in range(n_frames)]
 
 

@@ -1757,9 +1757,7 @@ void Renderer::render_pathtracing(const RenderParams& p)
 void Renderer::launch_iteration(StreamingFrame& f, int h)
 {
   PartState* half = f.part;
-  const int pass_mode = f.pass_mode, H = f.H;
-  const bool grad = f.grad, ssh = f.ssh;
-  NeuralVolume* nv = f.nv;
+  const int pass_mode = f.pass_mode;
   const size_t shmem = f.shmem, shmem_compose = f.shmem_compose;
   const uint32_t max_iterations = f.max_iterations;
   {

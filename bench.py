@@ -468,4 +468,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        # every rank releases the communicator explicitly (ncclCommDestroy, the communication stream) while librccl and the HIP runtime
+        # are still alive; nothing is left for exit-time destructors (csrc/dist.cpp ~Dist leaks an RCCL communicator rather than touch it)
+        try:
+            dist.finalize()
+        except Exception as e:   # never turn a printed bench line into a failed run
+            print(f"warning: vnrAmdDistFinalize: {e}", file=sys.stderr)

@@ -299,7 +299,7 @@ int  vnrAmdDistRank(void);
 int  vnrAmdDistWorldSize(void);
 const char* vnrAmdDistTransport(void);
 int  vnrAmdDistBarrier(void);                                      /* device synchronize + host barrier */
-/* host values over the control plane (the bench's MAX / SUM over ranks); op: 0 sum, 1 max, 2 min */
+/* host values over the control plane (the bench's MAX / SUM over ranks); op: 0 sum, 1 max, 2 min, 3 mean */
 int  vnrAmdDistAllReduceHost(double* values, int n, int op);
 /* the transport's collectives on caller buffers (device pointers; host pointers on the shm transport), blocking.
  * dtype: 0 f32, 1 f16, 2 u8.  AllGather: rank r's bytes land at recv + r * bytes_per_rank (send may be that address). */
@@ -309,7 +309,9 @@ int  vnrAmdDistReduceScatter(void* buf, size_t count_per_rank, int dtype);
 int  vnrAmdDistBroadcast(void* buf, size_t bytes, int root);
 /* Image tiles: the rank renders the 8-scanline tile rows r with r % world == rank into its slot of a [world][share] buffer;
  * vnrAmdRendererMapFrame (= vnrAmdRendererGatherFrame) all-gathers in place, de-interleaves and returns the WHOLE frame on
- * every rank, bit-identical to the unsharded frame.  RenderPipelined: enqueue frame k, gather frame k - 1 meanwhile on the
+ * every rank, bit-identical to the unsharded frame rendered with the same batch size (VNR_RM_N_ITERS): a share of at most 196 608
+ * pixels marches 32 samples per ray and iteration instead of 24 unless VNR_RM_N_ITERS pins it, and the batch size moves the last bit
+ * of a few samples (0.2 % of the pixels, <= 4e-5; the same holds in the reference for its N_ITERS).  RenderPipelined: enqueue frame k, gather frame k - 1 meanwhile on the
  * communication stream, complete frame k, return the assembled frame k - 1 (NULL the first time); FlushPipeline returns the
  * frame still in flight.  The head of frame k (ray generation, first batch of samples) is enqueued before the host has seen
  * frame k - 1 complete, so the GPU does not idle during the host's turn-around; a renderer that is not distributed pipelines the
@@ -320,15 +322,28 @@ int  vnrAmdRendererRenderPipelined(vnrAmdRenderer, const float** previous_frame)
 /* statistics of the frame COMPLETED last (vnrAmdRendererGetFrameStats completes a pending frame first, which ends the overlap) */
 int  vnrAmdRendererGetCompletedFrameStats(vnrAmdRenderer, vnrAmdFrameStats*);
 int  vnrAmdRendererFlushPipeline(vnrAmdRenderer, const float** last_frame);
-/* Data-parallel training: `steps` steps, each equal to ONE step on the concatenated batch of all ranks.  Gradients travel as
- * fp16 (2 B x n_params per step), range by range while the backward pass of the coarser levels and the update of earlier
- * ranges run; no host synchronisation inside a step on the rccl transport.  The first call broadcasts rank 0's parameters,
- * optimizer state, step count and learning rate (SyncReplicas) and gives every rank its own sample stream. */
+/* Data-parallel training: `steps` steps, each equal to ONE step on the concatenated batch of all ranks (Adam on the MEAN of the
+ * ranks' gradients).  Gradients travel as fp16 (2 B x n_params per step), range by range (the MLP, then the hash-grid levels from
+ * the finest to the coarsest in buckets) while the backward pass of the coarser levels and the update of earlier ranges run; no host
+ * synchronisation inside a step on the rccl transport.  The optimizer is SHARDED by default: a range is reduce-scattered (ncclAvg),
+ * the rank updates its 1/world of the range and the fp16 parameters are all-gathered in place: the bytes of an all-reduce on the
+ * wire, 1/world of the optimizer sweep per rank (VNR_AMD_DP_SHARDED=0: all-reduce + the whole update on every rank; the same bits
+ * wherever the reduction gives the same bits).  A call first asks over the control plane whether any rank's parameters changed
+ * outside an optimizer step since the last synchronisation (first call, SetParams, SetModel, a loaded params.json) and if so makes
+ * the replicas identical (SyncReplicas: rank 0's parameters, optimizer state, step count and learning rate; with a sharded
+ * optimizer state the ranks' slices of it are all-gathered instead).  Every rank draws its own sample stream.
+ * After sharded steps a rank's optimizer state of the OTHER ranks' slices is stale: vnrAmdNeuralVolumeTrain / TrainEnd on such a
+ * volume fail until vnrAmdNeuralVolumeSyncReplicas has been called on every rank. */
 int  vnrAmdNeuralVolumeTrainDataParallel(vnrAmdVolume, int steps, int fast_mode);
 int  vnrAmdNeuralVolumeSyncReplicas(vnrAmdVolume);
 /* for the TrainBegin / TrainEnd form: sums the gradient buffer over the ranks, in place (fp16 payload); follow with
  * vnrAmdNeuralVolumeTrainEnd(v, 1.0f / world, fast_mode) */
 int  vnrAmdNeuralVolumeAllReduceGradients(vnrAmdVolume);
+/* ... or exchange + update of the pending step in one call, nothing overlapped: sharded = 1 reduce-scatter / 1/world Adam /
+ * all-gather, 0 all-reduce + full Adam, -1 the process default */
+int  vnrAmdNeuralVolumeTrainEndDataParallel(vnrAmdVolume, int fast_mode, int sharded);
+/* tests: replaces the gradient buffer by `count` host floats (rounded to its half precision) and marks a step as pending */
+int  vnrAmdNeuralVolumeSetGradients(vnrAmdVolume, const float* host, size_t count);
 
 /* ---- misc (api.h:185-188) -------------------------------------------------- */
 void vnrAmdMemoryQuery(size_t* used_by_renderer, size_t* used_by_network); /* vnrMemoryQuery */

@@ -43,6 +43,25 @@ struct vec3i { int x, y, z; };
 struct vec3f { float x, y, z; };
 struct vec4f { float x, y, z, w; };
 struct range1f { float lower, upper; };
+// core/mathdef.h:51-83 (what api.h:11 brings in with the reference's own math): the voxel types, in the order and with the values
+// of the VNR_AMD_TYPE_* enum of vnr_amd.h, and their sizes
+enum ValueType {
+  VALUE_TYPE_UINT8 = VNR_AMD_TYPE_UINT8, VALUE_TYPE_INT8 = VNR_AMD_TYPE_INT8, VALUE_TYPE_UINT16 = VNR_AMD_TYPE_UINT16,
+  VALUE_TYPE_INT16 = VNR_AMD_TYPE_INT16, VALUE_TYPE_UINT32 = VNR_AMD_TYPE_UINT32, VALUE_TYPE_INT32 = VNR_AMD_TYPE_INT32,
+  VALUE_TYPE_UINT64 = VNR_AMD_TYPE_UINT64, VALUE_TYPE_INT64 = VNR_AMD_TYPE_INT64, VALUE_TYPE_FLOAT = VNR_AMD_TYPE_FLOAT,
+  VALUE_TYPE_FLOAT2 = VNR_AMD_TYPE_FLOAT2, VALUE_TYPE_FLOAT3 = VNR_AMD_TYPE_FLOAT3, VALUE_TYPE_FLOAT4 = VNR_AMD_TYPE_FLOAT4,
+  VALUE_TYPE_DOUBLE = VNR_AMD_TYPE_DOUBLE,
+};
+inline int value_type_size(ValueType type)
+{
+  switch (type) {
+  case VALUE_TYPE_UINT8: case VALUE_TYPE_INT8: return 1;
+  case VALUE_TYPE_UINT16: case VALUE_TYPE_INT16: return 2;
+  case VALUE_TYPE_UINT32: case VALUE_TYPE_INT32: case VALUE_TYPE_FLOAT: return 4;
+  case VALUE_TYPE_UINT64: case VALUE_TYPE_INT64: case VALUE_TYPE_DOUBLE: return 8;
+  default: return 0;
+  }
+}
 #endif
 
 namespace shim {
@@ -76,6 +95,7 @@ typedef std::shared_ptr<vnrAmdRenderer_t> vnrRenderer;
 typedef std::shared_ptr<vnrAmdTransferFunction_t> vnrTransferFunction;
 typedef std::shared_ptr<vnrAmdCamera_t> vnrCamera;
 typedef vnr::json vnrJson;
+typedef vnr::ValueType vnrType;   // api.h:34 (device/device_impl.cpp:179 passes one to the volume it creates from memory)
 
 // api.h:36-60 (same numeric values as the VNR_AMD_* enum)
 enum vnrRenderMode {

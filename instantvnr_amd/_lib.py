@@ -197,6 +197,8 @@ def lib():
     sig("vnrAmdNeuralVolumeSetTrainProfiling", I, P, I)
     sig("vnrAmdNeuralVolumeGetTrainProfile", I, P, C.POINTER(D), IP)
     sig("vnrAmdNeuralVolumeAllReduceGradients", I, P)
+    sig("vnrAmdNeuralVolumeTrainEndDataParallel", I, P, I, I)
+    sig("vnrAmdNeuralVolumeSetGradients", I, P, C.POINTER(C.c_float), SZ)
     sig("vnrAmdMemoryQuery", None, C.POINTER(SZ), C.POINTER(SZ))
     sig("vnrAmdFreeTemporaryGPUMemory", None)
     sig("vnrAmdSimpleVolumeTakeSamples", I, P, SZ, FP, FP, P, P, P)

@@ -752,7 +752,7 @@ int vnrAmdDistBarrier(void)
 int vnrAmdDistAllReduceHost(double* values, int n, int op)
 {
   return guarded([&]() {
-    if (op < 0 || op > 2) throw std::runtime_error("unknown reduction");
+    if (op < 0 || op > 3) throw std::runtime_error("unknown reduction");
     Dist::get().all_reduce_host(values, n, (DistOp)op);
   });
 }
@@ -761,7 +761,7 @@ static void dist_call_done() { if (Runtime::get().ready()) VNR_HIP_CHECK(hipStre
 int vnrAmdDistAllReduce(void* buf, size_t count, int dtype, int op)
 {
   return guarded([&]() {
-    if (dtype < 0 || dtype > 2 || op < 0 || op > 2) throw std::runtime_error("unknown dtype / reduction");
+    if (dtype < 0 || dtype > 2 || op < 0 || op > 3) throw std::runtime_error("unknown dtype / reduction");
     Dist::get().transport().all_reduce(buf, count, (DistDType)dtype, (DistOp)op, dist_call_stream());
     dist_call_done();
   });
@@ -774,7 +774,7 @@ int vnrAmdDistReduceScatter(void* buf, size_t count_per_rank, int dtype)
 {
   return guarded([&]() {
     if (dtype < 0 || dtype > 2) throw std::runtime_error("unknown dtype");
-    Dist::get().transport().reduce_scatter(buf, count_per_rank, (DistDType)dtype, dist_call_stream());
+    Dist::get().transport().reduce_scatter(buf, count_per_rank, (DistDType)dtype, DistOp::Sum, dist_call_stream());
     dist_call_done();
   });
 }
@@ -826,6 +826,18 @@ int vnrAmdNeuralVolumeGetTrainProfile(vnrAmdVolume v, double ms_per_step[5], int
 }
 int vnrAmdNeuralVolumeSyncReplicas(vnrAmdVolume v) { return guarded([&]() { as_neural(v)->sync_replicas(); }); }
 int vnrAmdNeuralVolumeAllReduceGradients(vnrAmdVolume v) { return guarded([&]() { as_neural(v)->all_reduce_gradients(); }); }
+int vnrAmdNeuralVolumeTrainEndDataParallel(vnrAmdVolume v, int fast_mode, int sharded)
+{
+  return guarded([&]() { as_neural(v)->train_end_data_parallel(fast_mode != 0, sharded); });
+}
+int vnrAmdNeuralVolumeSetGradients(vnrAmdVolume v, const float* host, size_t count)
+{
+  return guarded([&]() {
+    NeuralVolume* n = as_neural(v);
+    n->network().set_grads_from_f32(host, count, n->stream);
+    n->mark_external_gradient();
+  });
+}
 
 // ------------------------------------------------------------------------------------------------ misc
 void vnrAmdMemoryQuery(size_t* used_by_renderer, size_t* used_by_network)

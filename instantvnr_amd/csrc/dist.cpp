@@ -43,13 +43,24 @@ int dist_timeout_s()
   return v > 0 ? v : 300;
 }
 
-void set_socket_timeouts(int fd)
+// The rendezvous (accept / connect / hello) is bounded by VNR_AMD_DIST_TIMEOUT.  Afterwards the sockets block: a rank may sit in a
+// barrier for as long as another one computes (PSNR / SSIM over an out-of-core volume on rank 0 takes minutes), and a rank that
+// dies closes its socket, which ends the wait with "a peer closed the control plane".  VNR_AMD_DIST_STEADY_TIMEOUT (seconds)
+// bounds the steady state as well for jobs that want it.
+void set_socket_timeouts(int fd, int seconds)
 {
   timeval tv;
-  tv.tv_sec = dist_timeout_s();
+  tv.tv_sec = seconds;   // 0: block
   tv.tv_usec = 0;
   (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
   (void)setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
+
+int dist_steady_timeout_s()
+{
+  const char* e = std::getenv("VNR_AMD_DIST_STEADY_TIMEOUT");
+  const int v = e ? std::atoi(e) : 0;
+  return v > 0 ? v : 0;
 }
 
 void send_all(int fd, const void* p, size_t n)
@@ -92,6 +103,30 @@ public:
   ControlPlane(int rank, int world, const std::string& address) : rank_(rank), world_(world)
   {
     if (world <= 1) return;
+    try {
+      connect_all(rank, world, address);
+    } catch (...) {   // the destructor of a half-built object does not run: close what was opened
+      close_all();
+      throw;
+    }
+    // rendezvous done: from here on a wait is as long as the slowest rank's work
+    const int steady = dist_steady_timeout_s();
+    if (up_ >= 0) set_socket_timeouts(up_, steady);
+    for (int fd : peers_) if (fd >= 0) set_socket_timeouts(fd, steady);
+  }
+
+  ~ControlPlane() { close_all(); }
+
+private:
+  void close_all()
+  {
+    if (up_ >= 0) ::close(up_);
+    up_ = -1;
+    for (int& fd : peers_) { if (fd >= 0) ::close(fd); fd = -1; }
+  }
+
+  void connect_all(int rank, int world, const std::string& address)
+  {
     const bool is_unix = address.rfind("unix:", 0) == 0;
     std::string host;
     int port = 0;
@@ -140,10 +175,10 @@ public:
       for (int k = 1; k < world; ++k) {
         const int fd = ::accept(ls, nullptr, nullptr);
         if (fd < 0) { ::close(ls); throw std::runtime_error("[vnr dist] rank 0 timed out waiting for " + std::to_string(world - k) + " more rank(s) on " + address); }
-        set_socket_timeouts(fd);
+        set_socket_timeouts(fd, dist_timeout_s());
         if (!is_unix) { int one = 1; (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one)); }
         int32_t hello[2];
-        recv_all(fd, hello, sizeof(hello));
+        try { recv_all(fd, hello, sizeof(hello)); } catch (...) { ::close(fd); ::close(ls); throw; }
         if (hello[1] != world || hello[0] <= 0 || hello[0] >= world || peers_[hello[0]] != -1) {
           ::close(fd); ::close(ls);
           throw std::runtime_error("[vnr dist] unexpected rank " + std::to_string(hello[0]) + " / world " + std::to_string(hello[1]) + " on the control plane");
@@ -169,7 +204,7 @@ public:
           }
         }
         if (rc == 0) {
-          set_socket_timeouts(fd);
+          set_socket_timeouts(fd, dist_timeout_s());
           if (!is_unix) { int one = 1; (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one)); }
           up_ = fd;
           break;
@@ -183,12 +218,7 @@ public:
     }
   }
 
-  ~ControlPlane()
-  {
-    if (up_ >= 0) ::close(up_);
-    for (int fd : peers_) if (fd >= 0) ::close(fd);
-  }
-
+public:
   // gather `bytes` from every rank to rank 0 (in rank order), let rank 0 transform the world * bytes, send `out_bytes` back
   template <typename F>
   void exchange(const void* mine, size_t bytes, void* out, size_t out_bytes, F&& combine_on_root)
@@ -239,7 +269,7 @@ struct NcclUniqueId { char internal[128]; };
 typedef void* NcclComm;
 enum { kNcclSuccess = 0 };
 enum { kNcclUint8 = 1, kNcclFloat16 = 6, kNcclFloat32 = 7 };
-enum { kNcclSum = 0, kNcclMax = 2, kNcclMin = 3 };
+enum { kNcclSum = 0, kNcclMax = 2, kNcclMin = 3, kNcclAvg = 4 };
 
 struct RcclApi {
   void* handle = nullptr;
@@ -298,7 +328,7 @@ void rccl_check(int rc, const char* what)
 }
 
 int nccl_type(DistDType t) { return t == DistDType::F32 ? kNcclFloat32 : t == DistDType::F16 ? kNcclFloat16 : kNcclUint8; }
-int nccl_op(DistOp op) { return op == DistOp::Sum ? kNcclSum : op == DistOp::Max ? kNcclMax : kNcclMin; }
+int nccl_op(DistOp op) { return op == DistOp::Sum ? kNcclSum : op == DistOp::Max ? kNcclMax : op == DistOp::Min ? kNcclMin : kNcclAvg; }
 size_t dtype_bytes(DistDType t) { return t == DistDType::F32 ? 4 : t == DistDType::F16 ? 2 : 1; }
 
 class RcclTransport : public Transport {
@@ -320,10 +350,10 @@ public:
   {
     rccl_check(RcclApi::get().AllReduce(d_buf, d_buf, count, nccl_type(t), nccl_op(op), comm_, s), "ncclAllReduce");
   }
-  void reduce_scatter(void* d_buf, size_t count_per_rank, DistDType t, hipStream_t s) override
+  void reduce_scatter(void* d_buf, size_t count_per_rank, DistDType t, DistOp op, hipStream_t s) override
   {
     char* mine = (char*)d_buf + (size_t)rank_ * count_per_rank * dtype_bytes(t);   // in place: recvbuff = sendbuff + rank * count
-    rccl_check(RcclApi::get().ReduceScatter(d_buf, mine, count_per_rank, nccl_type(t), kNcclSum, comm_, s), "ncclReduceScatter");
+    rccl_check(RcclApi::get().ReduceScatter(d_buf, mine, count_per_rank, nccl_type(t), nccl_op(op), comm_, s), "ncclReduceScatter");
   }
   void broadcast(void* d_buf, size_t bytes, int root, hipStream_t s) override
   {
@@ -417,7 +447,7 @@ public:
     }
   }
 
-  void reduce_scatter(void* d_buf, size_t count_per_rank, DistDType t, hipStream_t s) override
+  void reduce_scatter(void* d_buf, size_t count_per_rank, DistDType t, DistOp op, hipStream_t s) override
   {
     // rank r needs the sum of everyone's slice r: move slice by slice (world rounds of at most one slot each)
     const size_t eb = dtype_bytes(t), per = slot_bytes_ / eb;
@@ -430,7 +460,7 @@ public:
         barrier();
         if (r == rank_) {
           res.resize(n * eb);
-          reduce_slots(res.data(), 0, n, t, DistOp::Sum);
+          reduce_slots(res.data(), 0, n, t, op);
           from_host(p, res.data(), n * eb, s);
         }
         finish(s);
@@ -483,20 +513,22 @@ private:
   }
   void reduce_slots(char* out, size_t first, size_t n, DistDType t, DistOp op)
   {
-    auto combine = [op](float a, float b) { return op == DistOp::Sum ? a + b : op == DistOp::Max ? (a > b ? a : b) : (a < b ? a : b); };
+    const bool sum = op == DistOp::Sum || op == DistOp::Avg;
+    auto combine = [op, sum](float a, float b) { return sum ? a + b : op == DistOp::Max ? (a > b ? a : b) : (a < b ? a : b); };
+    const float post = op == DistOp::Avg ? 1.0f / (float)world_ : 1.0f;   // exact for power-of-two worlds
     if (t == DistDType::F32) {
       float* o = (float*)out;
       for (size_t i = 0; i < n; ++i) {
         float acc = ((const float*)slot(0))[first + i];
         for (int r = 1; r < world_; ++r) acc = combine(acc, ((const float*)slot(r))[first + i]);
-        o[i] = acc;
+        o[i] = acc * post;
       }
     } else if (t == DistDType::F16) {
       uint16_t* o = (uint16_t*)out;
       for (size_t i = 0; i < n; ++i) {
         float acc = f16_to_f32(((const uint16_t*)slot(0))[first + i]);
         for (int r = 1; r < world_; ++r) acc = combine(acc, f16_to_f32(((const uint16_t*)slot(r))[first + i]));
-        o[i] = f32_to_f16(acc);
+        o[i] = f32_to_f16(acc * post);
       }
     } else {
       uint8_t* o = (uint8_t*)out;
@@ -504,9 +536,9 @@ private:
         uint32_t acc = ((const uint8_t*)slot(0))[first + i];
         for (int r = 1; r < world_; ++r) {
           const uint32_t v = ((const uint8_t*)slot(r))[first + i];
-          acc = op == DistOp::Sum ? acc + v : op == DistOp::Max ? std::max(acc, v) : std::min(acc, v);
+          acc = sum ? acc + v : op == DistOp::Max ? std::max(acc, v) : std::min(acc, v);
         }
-        o[i] = (uint8_t)acc;
+        o[i] = (uint8_t)(op == DistOp::Avg ? acc / (uint32_t)world_ : acc);
       }
     }
   }
@@ -538,7 +570,16 @@ private:
 
 // ================================================================================================ Dist
 Dist::Dist() = default;
-Dist::~Dist() { transport_.reset(); ctl_.reset(); }
+// Exit-time destruction of the process-wide object: librccl was opened with dlopen AFTER this object was constructed, so its own
+// statics (and possibly the HIP runtime's) are gone by the time this runs, and ncclCommDestroy from here is a known hang or crash at
+// exit.  A communicator (and the communication stream) that the application did not release with vnrAmdDistFinalize is therefore
+// LEAKED here, deliberately: the process is ending and the driver reclaims it.  The host-staged transport owns only a mapping.
+Dist::~Dist()
+{
+  if (transport_ && std::strcmp(transport_->name(), "rccl") == 0) (void)transport_.release();
+  else transport_.reset();
+  ctl_.reset();
+}
 
 Dist& Dist::get()
 {
@@ -630,9 +671,9 @@ void Dist::all_reduce_host(double* values, int n, DistOp op)
       double acc = a[i];
       for (int r = 1; r < world; ++r) {
         const double v = a[(size_t)r * n + i];
-        acc = op == DistOp::Sum ? acc + v : op == DistOp::Max ? std::max(acc, v) : std::min(acc, v);
+        acc = (op == DistOp::Sum || op == DistOp::Avg) ? acc + v : op == DistOp::Max ? std::max(acc, v) : std::min(acc, v);
       }
-      o[i] = acc;
+      o[i] = op == DistOp::Avg ? acc / (double)world : acc;
     }
   });
 }

@@ -27,7 +27,7 @@
 namespace vnr {
 
 enum class DistDType { F32 = 0, F16 = 1, U8 = 2 };
-enum class DistOp { Sum = 0, Max = 1, Min = 2 };
+enum class DistOp { Sum = 0, Max = 1, Min = 2, Avg = 3 };   // Avg = Sum / world (ncclAvg; the shm transport divides the fp32 sum before rounding)
 
 class ControlPlane;
 
@@ -42,7 +42,7 @@ public:
   virtual void all_reduce(void* d_buf, size_t count, DistDType t, DistOp op, hipStream_t s) = 0;
   // rank r ends up with the reduced elements [r * count_per_rank, (r + 1) * count_per_rank) of d_buf, in place at that
   // offset (the rest of d_buf is unspecified afterwards); all_gather of the same slices completes a sharded update
-  virtual void reduce_scatter(void* d_buf, size_t count_per_rank, DistDType t, hipStream_t s) = 0;
+  virtual void reduce_scatter(void* d_buf, size_t count_per_rank, DistDType t, DistOp op, hipStream_t s) = 0;
   virtual void broadcast(void* d_buf, size_t bytes, int root, hipStream_t s) = 0;
 };
 

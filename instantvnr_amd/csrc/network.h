@@ -5,6 +5,10 @@
 // tiny-cuda-nn Trainer behind them (forward/backward/L1 loss/Adam+ExponentialDecay).
 #pragma once
 
+#include <functional>
+#include <utility>
+#include <vector>
+
 #include "common.h"
 #include "json.h"
 
@@ -154,7 +158,24 @@ public:
   OptState* opt_state_device() { return opt_state_.ptr; }
   void set_replica_state(uint64_t steps, float lr, hipStream_t s) { steps_ = steps; lr_ = lr; refresh_inference_weights(s); }
   void ensure_training_state(hipStream_t s);
+  void reset_master_from_params(hipStream_t s);   // master weights <- fp16 parameters (moments and step counts kept)
   double training_loss(hipStream_t s);  // mean loss of the last forward_backward
+  // counts the parameter changes that do NOT come from an optimizer step (configure, set_params_f16, deserialize_params): replicas of a
+  // data-parallel run whose counters differ from what they were at the last synchronisation are synchronised again (volume.hip)
+  uint64_t params_generation() const { return params_generation_; }
+  // Sharded optimizer (volume.hip train_data_parallel): a rank updates master weights and moments of ITS slices only and receives the
+  // other ranks' fp16 parameters, so its optimizer state of the other slices is stale until NeuralVolume::sync_replicas gathers it;
+  // a full optimizer step on such a state would be wrong and throws
+  void set_opt_sharded(bool e) { opt_sharded_ = e; }
+  bool opt_sharded() const { return opt_sharded_; }
+  // the parameter ranges a data-parallel step exchanges, in the order forward_backward hands them over: the MLP, then the hash-grid
+  // levels from the finest to the coarsest in buckets of at least `bucket` parameters (levels [first, second) each)
+  std::vector<std::pair<uint32_t, uint32_t>> exchange_level_buckets(size_t bucket) const;
+  void for_each_exchange_range(size_t bucket, const std::function<void(size_t, size_t)>& fn) const;
+  size_t level_range_lo(uint32_t level) const { return n_mlp_ + (size_t)grid_.levels[level].offset * cfg_.n_features; }
+  size_t level_range_hi(uint32_t level_end) const { return n_mlp_ + ((size_t)grid_.levels[level_end - 1].offset + grid_.levels[level_end - 1].size) * cfg_.n_features; }
+  // tests: the gradient blob from a float array (rounded to the blob's half precision)
+  void set_grads_from_f32(const float* host, size_t count, hipStream_t s);
 
   size_t bytes_allocated() const;
   // vnrFreeTemporaryGPUMemory (api.cpp:554-557 -> tcnn's free_all_gpu_memory_arenas): drops what can be rebuilt on demand,
@@ -188,6 +209,8 @@ private:
   uint32_t in_width_ = 0;
   size_t n_params_ = 0, n_mlp_ = 0;
   uint64_t steps_ = 0;
+  uint64_t params_generation_ = 0;
+  bool opt_sharded_ = false;
   float lr_ = 0.0f;   // current learning rate (ExponentialDecay state); reset by configure() like the reference's rebuilt optimizer (tcnn_network.h:195-209)
 
   DeviceBuffer<uint16_t> params_f16_{MemTag::Network};   // tcnn-order blob (inference + serialisation)

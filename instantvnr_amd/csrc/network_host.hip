@@ -212,6 +212,8 @@ void Network::initialize_params(uint64_t seed, hipStream_t s)
 {
   opt_state_.resize(n_params_);
   launch_init_params(opt_state_.ptr, params_f16_.ptr, n_mlp_, n_params_, in_width_, n_hidden_matmuls(), cfg_.n_neurons, seed, s);
+  ++params_generation_;
+  opt_sharded_ = false;
   refresh_inference_weights(s);
 }
 
@@ -423,6 +425,7 @@ void Network::set_params_f16(const uint16_t* host, size_t count, hipStream_t s)
   if (count != n_params_) throw std::runtime_error("parameter count mismatch: got " + std::to_string(count) + ", model has " + std::to_string(n_params_));
   VNR_HIP_CHECK(hipMemcpyAsync(params_f16_.ptr, host, count * sizeof(uint16_t), hipMemcpyHostToDevice, s));
   if (opt_state_.count == n_params_) launch_master_from_f16(params_f16_.ptr, opt_state_.ptr, n_params_, false, s);  // moments kept, as before
+  ++params_generation_;
   refresh_inference_weights(s);
   VNR_HIP_CHECK(hipStreamSynchronize(s));
 }

@@ -616,6 +616,11 @@ void Network::ensure_training_state(hipStream_t s)
   if (grads_.count != n_params_) { grads_.resize(n_params_); grads_.zero(s); }
 }
 
+void Network::reset_master_from_params(hipStream_t s)
+{
+  if (opt_state_.count == n_params_) launch_master_from_f16(params_f16_.ptr, opt_state_.ptr, n_params_, false, s);
+}
+
 void Network::forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s, GradExchange* exchange)
 {
   if (!valid()) throw std::runtime_error("network is not configured");
@@ -714,28 +719,43 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     if (only.first >= 0) grid_backward((uint32_t)only.first, std::min<uint32_t>((uint32_t)only.second, cfg_.n_levels));
     else grid_backward(0, cfg_.n_levels);
   } else {
-    // finest levels first (the large tables), in buckets of at least kBucket parameters: a bucket's exchange overlaps the
+    // finest levels first (the large tables), in buckets of at least bucket_params() parameters: a bucket's exchange overlaps the
     // backward launches of the coarser levels and, afterwards, the optimizer update of the buckets before it
-    const size_t kBucket = exchange->bucket_params();
-    uint32_t l1 = cfg_.n_levels;
-    while (l1 > 0) {
-      uint32_t l0 = l1;
-      size_t count = 0;
-      while (l0 > 0 && (count < kBucket || (size_t)grid_.levels[l0 - 1].offset * cfg_.n_features < kBucket)) { --l0; count += (size_t)grid_.levels[l0].size * cfg_.n_features; }
-      grid_backward(l0, l1);
-      const size_t lo = n_mlp_ + (size_t)grid_.levels[l0].offset * cfg_.n_features;
-      const size_t hi = n_mlp_ + ((size_t)grid_.levels[l1 - 1].offset + grid_.levels[l1 - 1].size) * cfg_.n_features;
-      exchange->range_ready(lo, hi, s);
-      l1 = l0;
+    for (const auto& b : exchange_level_buckets(exchange->bucket_params())) {
+      grid_backward(b.first, b.second);
+      exchange->range_ready(level_range_lo(b.first), level_range_hi(b.second), s);
     }
   }
   VNR_HIP_CHECK(hipGetLastError());
   profile_mark(4, s);
 }
 
+std::vector<std::pair<uint32_t, uint32_t>> Network::exchange_level_buckets(size_t bucket) const
+{
+  std::vector<std::pair<uint32_t, uint32_t>> out;
+  uint32_t l1 = cfg_.n_levels;
+  while (l1 > 0) {
+    uint32_t l0 = l1;
+    size_t count = 0;
+    while (l0 > 0 && (count < bucket || (size_t)grid_.levels[l0 - 1].offset * cfg_.n_features < bucket)) { --l0; count += (size_t)grid_.levels[l0].size * cfg_.n_features; }
+    out.emplace_back(l0, l1);
+    l1 = l0;
+  }
+  return out;
+}
+
+void Network::for_each_exchange_range(size_t bucket, const std::function<void(size_t, size_t)>& fn) const
+{
+  fn(0, n_mlp_);
+  for (const auto& b : exchange_level_buckets(bucket)) fn(level_range_lo(b.first), level_range_hi(b.second));
+}
+
 void Network::optimizer_step(float grad_scale, hipStream_t s)
 {
   if (grads_.count != n_params_) throw std::runtime_error("optimizer_step before forward_backward");
+  if (opt_sharded_)
+    throw std::runtime_error("the optimizer state of this volume is sharded over the ranks (vnrAmdNeuralVolumeTrainDataParallel): call "
+                             "vnrAmdNeuralVolumeSyncReplicas on every rank before a step that updates all parameters on one rank");
   adam_kernel<<<div_round_up(n_params_, 256), 256, 0, s>>>(0, n_params_, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1,
                                                            cfg_.beta2, (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2),
                                                            cfg_.epsilon, cfg_.l2_reg, opt_state_.ptr,
@@ -761,6 +781,22 @@ float* Network::grads_as_f32(hipStream_t s)
   unpack_grads_f16_kernel<<<(uint32_t)std::min<size_t>((n_params_ + 255) / 256, 8192), 256, 0, s>>>((const half_t*)grads_.ptr, grads_f32_.ptr, n_params_);
   VNR_HIP_CHECK(hipGetLastError());
   return grads_f32_.ptr;
+}
+
+__global__ void pack_grads_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (half_t)in[i];
+}
+
+void Network::set_grads_from_f32(const float* host, size_t count, hipStream_t s)
+{
+  if (count != n_params_) throw std::runtime_error("gradient count mismatch");
+  ensure_training_state(s);
+  grads_f32_.ensure(n_params_);
+  VNR_HIP_CHECK(hipMemcpyAsync(grads_f32_.ptr, host, count * sizeof(float), hipMemcpyHostToDevice, s));
+  pack_grads_f16_kernel<<<(uint32_t)std::min<size_t>((n_params_ + 255) / 256, 8192), 256, 0, s>>>(grads_f32_.ptr, (half_t*)grads_.ptr, n_params_);
+  VNR_HIP_CHECK(hipGetLastError());
+  VNR_HIP_CHECK(hipStreamSynchronize(s));
 }
 
 void Network::optimizer_finish_step(hipStream_t s)

@@ -1522,9 +1522,13 @@ void Renderer::render()
   p.mc_max_opacity = mc.d_max_opacity();
   p.tfn = tfn_.view();
   p.tfn_in_lds = ((size_t)p.tfn.n_colors * sizeof(vec4f) + (size_t)p.tfn.n_alphas * sizeof(float)) <= 24 * 1024 ? 1u : 0u;
-  // A small share of a frame (one rank of 8) is bound by the latency of the per-iteration kernel chain, not by throughput:
-  // fewer, longer iterations (tools/share_probe.py, 1/8 of the bench frame: 24 -> 0.995 ms, 32 -> 0.910 ms, 48 -> 0.905 ms)
-  p.n_iters = (!n_iters_fixed_ && p.n_local <= 196608u) ? 32 : n_iters_;
+  // A small SHARE of a frame (one rank of 8) is bound by the latency of the per-iteration kernel chain, not by throughput:
+  // fewer, longer iterations (tools/share_probe.py, 1/8 of the bench frame: 24 -> 0.995 ms, 32 -> 0.910 ms, 48 -> 0.905 ms).
+  // Only for shares (distributed mode or a pixel interleave), so that an unsharded small framebuffer keeps the default; and the
+  // batch size moves a few samples by an ulp (a ray interrupted inside a macrocell resumes at t_min + (t - t_min), as in the
+  // reference), so a frame assembled from such shares equals the unsharded frame rendered with VNR_RM_N_ITERS=32 bit for bit and
+  // the unsharded frame at the default 24 to ~4e-5 on 0.2 % of the pixels (tests/test_gpu_fullsize.py); VNR_RM_N_ITERS pins both.
+  p.n_iters = (!n_iters_fixed_ && (distributed_ || il_parts_ > 1) && p.n_local <= 196608u) ? 32 : n_iters_;
   // gradient shading (modes 7 / 8)
   p.otw = volume_->transform;
   p.grad_step = {1.0f / (float)p.vol_dims.x, 1.0f / (float)p.vol_dims.y, 1.0f / (float)p.vol_dims.z};  // object.cpp:305

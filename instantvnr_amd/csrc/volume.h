@@ -165,10 +165,13 @@ public:
   // sample stream; an online macrocell is merged over the ranks at the end of the call (min / max per cell).
   void train_data_parallel(size_t steps, bool fast_mode);
   void all_reduce_gradients();                              // the TrainBegin / TrainEnd form: grads() summed over the ranks
-  void sync_replicas();                                     // broadcast rank 0's training state (also after SetParams on one rank)
+  // ... or in one call: exchange (mean over the ranks) + update in the sharded (1) or replicated (0) shape; -1: the default shape
+  void train_end_data_parallel(bool fast_mode, int sharded);
+  void sync_replicas();                                     // collective: rank 0's training state to everyone, or (sharded optimizer) the ranks' slices of it to everyone
   void train_begin();                                       // sample + forward + backward
   void train_end(float grad_scale, bool fast_mode);         // optimizer + macrocell update
   void forward_backward(const float* d_coords, const float* d_targets, size_t n);  // caller-provided batch
+  void mark_external_gradient() { pending_step_ = true; pending_internal_ = false; }   // the gradient blob was set by the caller (tests)
   float test_loss();                                        // network.cu:261-288
   float get_psnr(bool quiet);                               // network.cu:410-472
   float get_ssim(bool quiet);                               // network.cu:474-549 (get_mssim: mean SSIM, 7^3 uniform windows)
@@ -200,8 +203,10 @@ private:
   int decode_blob_ = 0;
   bool pending_step_ = false, pending_internal_ = false;
   bool replicas_synced_ = false;
+  uint64_t synced_generation_ = 0;   // Network::params_generation() at the last sync_replicas
   struct DpState;
   std::unique_ptr<DpState> dp_;
+  DpState& dp_state();
   friend struct VolumeKeepAlive;
 
 public:

@@ -655,37 +655,81 @@ __global__ void macrocell_merge_kernel(vec2f* __restrict__ range_max_reduced, co
     range_max_reduced[i].x = range_min_reduced[i].x;
 }
 
+// Data-parallel step, two shapes of the same arithmetic (one step = one Adam step on the MEAN of the ranks' gradients):
+//  * sharded (default; ZeRO-1 shape, SURVEY.md 8e "reduce-scatter + all-gather (each peer owns 1/8)"): a range's gradient is
+//    reduce-scattered, the rank runs Adam on ITS 1/world of the range and the fp16 parameters are all-gathered in place.  The same
+//    bytes on the wire as an all-reduce; the optimizer sweep, its touched-state traffic and (per rank) the live optimizer state are
+//    1/world of the replicated form (C4 at 8 ranks: Adam 0.30 -> ~0.04 ms of a 0.65 ms step);
+//  * replicated (VNR_AMD_DP_SHARDED=0): all-reduce, every rank updates everything.
+// Both exchange with the Avg reduction (ncclAvg; fp32 sum / world before the one rounding on the shm transport), so the 1 / world
+// factor is applied inside the exchange and the fp16 payload cannot overflow where a single GPU would not (it shrinks instead of
+// growing with the world size); Adam is per parameter, hence the two shapes give the same bits wherever the reduction does
+// (tests/test_gpu_dist.py: bit-equal on the shm transport).
 struct NeuralVolume::DpState : GradExchange {
   NeuralVolume* nv = nullptr;
-  struct Range { size_t lo, hi; hipEvent_t packed, reduced; };   // packed: the range's gradient is final on the compute stream
+  bool sharded = true;
+  // lo .. hi: the range; [lo, lo + world * per) is exchanged slice-wise (per: a multiple of 8 parameters), the rest (only when the
+  // range does not divide: world sizes that are not a power of two) is all-reduced and updated by every rank
+  struct Range { size_t lo, hi, per; hipEvent_t ready, reduced, updated, gathered; };
   std::vector<Range> ranges;     // this step's ranges in the order they became ready
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // events, reused step after step
-  hipEvent_t ev_updated = nullptr;   // the optimizer has consumed the payload of the previous step
+  struct Events { hipEvent_t e[4]; };
+  std::vector<Events> pool;      // reused step after step
   size_t used = 0;
 
   ~DpState() override
   {
-    for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    if (ev_updated) (void)hipEventDestroy(ev_updated);
+    for (auto& p : pool) for (hipEvent_t e : p.e) (void)hipEventDestroy(e);
   }
   void range_ready(size_t lo, size_t hi, hipStream_t s) override
   {
     Dist& d = Dist::get();
     hipStream_t comm = d.comm_stream();
     if (used == pool.size()) {
-      hipEvent_t a, b;
-      VNR_HIP_CHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-      VNR_HIP_CHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-      pool.emplace_back(a, b);
+      Events ev;
+      for (hipEvent_t& e : ev.e) VNR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      pool.push_back(ev);
     }
-    Range r{lo, hi, pool[used].first, pool[used].second};
+    const size_t world = (size_t)d.world();
+    Range r{lo, hi, sharded ? ((hi - lo) / world) & ~(size_t)7 : 0, pool[used].e[0], pool[used].e[1], pool[used].e[2], pool[used].e[3]};
     ++used;
     // the gradient blob IS the payload (fp16, in place): nothing to pack
-    VNR_HIP_CHECK(hipEventRecord(r.packed, s));
-    VNR_HIP_CHECK(hipStreamWaitEvent(comm, r.packed, 0));
-    d.transport().all_reduce(nv->net_.grads_f16() + lo, hi - lo, DistDType::F16, DistOp::Sum, comm);
+    VNR_HIP_CHECK(hipEventRecord(r.ready, s));
+    VNR_HIP_CHECK(hipStreamWaitEvent(comm, r.ready, 0));
+    uint16_t* g = nv->net_.grads_f16();
+    if (r.per) d.transport().reduce_scatter(g + lo, r.per, DistDType::F16, DistOp::Avg, comm);
+    const size_t rest = lo + world * r.per;
+    if (rest < hi) d.transport().all_reduce(g + rest, hi - rest, DistDType::F16, DistOp::Avg, comm);
     VNR_HIP_CHECK(hipEventRecord(r.reduced, comm));
     ranges.push_back(r);
+  }
+  // the optimizer update of the ranges handed over so far, each behind its own exchange, and (sharded) the parameters' way back
+  void update(hipStream_t s)
+  {
+    Dist& d = Dist::get();
+    hipStream_t comm = d.comm_stream();
+    Network& net = nv->net_;
+    const size_t world = (size_t)d.world(), rank = (size_t)d.rank();
+    for (const Range& r : ranges) {
+      VNR_HIP_CHECK(hipStreamWaitEvent(s, r.reduced, 0));
+      if (!r.per) { net.optimizer_step_range(r.lo, r.hi, 1.0f, s); continue; }
+      const size_t mine = r.lo + rank * r.per, rest = r.lo + world * r.per;
+      // what the reduce-scatter left in the other ranks' slices is unspecified: the next step accumulates into zeros
+      uint16_t* g = net.grads_f16();
+      if (mine > r.lo) VNR_HIP_CHECK(hipMemsetAsync(g + r.lo, 0, (mine - r.lo) * sizeof(uint16_t), s));
+      if (rest > mine + r.per) VNR_HIP_CHECK(hipMemsetAsync(g + mine + r.per, 0, (rest - mine - r.per) * sizeof(uint16_t), s));
+      net.optimizer_step_range(mine, mine + r.per, 1.0f, s);
+      if (rest < r.hi) net.optimizer_step_range(rest, r.hi, 1.0f, s);
+      VNR_HIP_CHECK(hipEventRecord(r.updated, s));
+      VNR_HIP_CHECK(hipStreamWaitEvent(comm, r.updated, 0));
+      uint16_t* p = net.params_device();
+      d.transport().all_gather(p + mine, p + r.lo, r.per * sizeof(uint16_t), comm);   // in place
+      VNR_HIP_CHECK(hipEventRecord(r.gathered, comm));
+    }
+    bool any = false;
+    for (const Range& r : ranges) if (r.per) { VNR_HIP_CHECK(hipStreamWaitEvent(s, r.gathered, 0)); any = true; }
+    if (any && world > 1) net.set_opt_sharded(true);
+    ranges.clear();
+    used = 0;
   }
 };
 
@@ -721,6 +765,8 @@ void NeuralVolume::set_network(vec3i dims, const Json& config, SimpleVolume* ref
   if (config.contains("fvsrn")) throw std::runtime_error("fvsrn is not enabled");  // network.cu:572-578
   const uint64_t seed = init_seed ? init_seed : (uint64_t)time(nullptr);             // tcnn_network.h:209
   net_.configure(config, seed);
+  replicas_synced_ = false;   // (a data-parallel run re-synchronises: the clock seed may differ between ranks)
+  dp_.reset();
   net_.set_brick_resolution_cap(2u * (uint32_t)std::max(desc.dims.x, std::max(desc.dims.y, desc.dims.z)));
   train_x_.resize(batch_size_ * 3);
   train_y_.resize(batch_size_);
@@ -739,6 +785,8 @@ void NeuralVolume::set_model(const Json& config)
 {
   const uint64_t seed = init_seed ? init_seed : (uint64_t)time(nullptr);
   net_.configure(config, seed);
+  replicas_synced_ = false;
+  dp_.reset();
   net_.set_brick_resolution_cap(2u * (uint32_t)std::max(desc.dims.x, std::max(desc.dims.y, desc.dims.z)));
 }
 
@@ -783,28 +831,84 @@ void NeuralVolume::train(size_t steps, bool fast_mode)
 
 // ------------------------------------------------------------------------------------------------ data-parallel training
 
+NeuralVolume::DpState& NeuralVolume::dp_state()
+{
+  if (!dp_) {
+    dp_.reset(new DpState());
+    dp_->nv = this;
+    const char* e = std::getenv("VNR_AMD_DP_SHARDED");
+    dp_->sharded = !e || std::atoi(e) != 0;
+  }
+  return *dp_;
+}
+
 void NeuralVolume::all_reduce_gradients()
 {
   Dist& d = Dist::get();
   if (!d.active() || !pending_step_) return;   // a one-rank group still runs the exchange (the identity): tests
-  if (!dp_) { dp_.reset(new DpState()); dp_->nv = this; VNR_HIP_CHECK(hipEventCreateWithFlags(&dp_->ev_updated, hipEventDisableTiming)); }
   d.transport().all_reduce(net_.grads_f16(), net_.n_params(), DistDType::F16, DistOp::Sum, stream);
 }
 
+// TrainBegin / TrainEndDataParallel form of one data-parallel step on whatever the gradient blob holds: the exchange (mean over the
+// ranks) and the update in one of the two shapes of DpState, nothing overlapped.  sharded < 0: the process default.
+void NeuralVolume::train_end_data_parallel(bool fast_mode, int sharded)
+{
+  Dist& d = Dist::get();
+  if (!d.active()) { train_end(1.0f, fast_mode); return; }
+  if (!pending_step_) return;
+  DpState& dp = dp_state();
+  const bool was = dp.sharded;
+  if (sharded >= 0) dp.sharded = sharded != 0;
+  if (!dp.sharded && net_.opt_sharded()) { dp.sharded = was; throw std::runtime_error("the optimizer state is sharded: vnrAmdNeuralVolumeSyncReplicas first"); }
+  dp.ranges.clear();
+  dp.used = 0;
+  // the same ranges as the overlapped step: the MLP, then the hash-grid levels in buckets (finest first)
+  net_.for_each_exchange_range(dp.bucket_params(), [&](size_t lo, size_t hi) { dp.range_ready(lo, hi, stream); });
+  dp.update(stream);
+  dp.sharded = was;
+  net_.optimizer_finish_step(stream);
+  const bool update_mc = !(fast_mode && mc_.is_external());
+  if (update_mc && pending_internal_ && !mc_.is_external()) mc_.update_explicit(train_x_.ptr, train_y_.ptr, batch_size_, stream);
+  pending_step_ = false;
+}
+
+// Makes the replicas identical, collectively: every rank ends with rank 0's parameters, optimizer state, step count and learning
+// rate.  After sharded steps rank 0's own copy of the optimizer state is current for ITS slices only, so the ranks' slices are
+// all-gathered first; if nothing else changed (the parameters are identical already: every call of train_data_parallel leaves them so)
+// that is all there is to do.
 void NeuralVolume::sync_replicas()
 {
   Dist& d = Dist::get();
   if (!d.active()) { replicas_synced_ = true; return; }
   net_.ensure_training_state(stream);
   Transport& t = d.transport();
-  t.broadcast(net_.params_device(), net_.n_params() * sizeof(uint16_t), 0, stream);
-  t.broadcast(net_.opt_state_device(), net_.n_params() * sizeof(OptState), 0, stream);
+  double dirty = (!replicas_synced_ || synced_generation_ != net_.params_generation()) ? 1.0 : 0.0;
+  d.all_reduce_host(&dirty, 1, DistOp::Max);
+  double r0_sharded = net_.opt_sharded() ? 1.0 : 0.0;
+  d.broadcast_host(&r0_sharded, sizeof(r0_sharded), 0);
+  if (r0_sharded > 0.0 && d.world() > 1) {
+    const size_t world = (size_t)d.world(), rank = (size_t)d.rank();
+    OptState* st = net_.opt_state_device();
+    net_.for_each_exchange_range(dp_state().bucket_params(), [&](size_t lo, size_t hi) {
+      const size_t per = ((hi - lo) / world) & ~(size_t)7;
+      if (per) t.all_gather(st + lo + rank * per, st + lo, per * sizeof(OptState), stream);
+    });
+  }
+  if (dirty > 0.0 || r0_sharded == 0.0) {
+    t.broadcast(net_.params_device(), net_.n_params() * sizeof(uint16_t), 0, stream);
+    t.broadcast(net_.opt_state_device(), net_.n_params() * sizeof(OptState), 0, stream);
+    // gathered state next to parameters that some rank replaced: the master copies of that rank's slices would bring its parameters
+    // back with the next step.  Rank 0's parameters win, as documented: master weights restart from them (what SetParams does too)
+    if (r0_sharded > 0.0) net_.reset_master_from_params(stream);
+  }
+  net_.set_opt_sharded(false);
   double host[2] = {(double)net_.steps(), (double)net_.learning_rate()};
   d.broadcast_host(host, sizeof(host), 0);
   net_.set_replica_state((uint64_t)host[0], (float)host[1], stream);
   if (source_) source_->set_sampler_rank(d.rank());
   VNR_HIP_CHECK(hipStreamSynchronize(stream));
   replicas_synced_ = true;
+  synced_generation_ = net_.params_generation();
 }
 
 void NeuralVolume::train_data_parallel(size_t steps, bool fast_mode)
@@ -813,27 +917,27 @@ void NeuralVolume::train_data_parallel(size_t steps, bool fast_mode)
   if (!d.active()) { train(steps, fast_mode); return; }
   if (!net_.valid()) return;
   if (!source_) throw std::runtime_error("missing a reference volume");
-  if (!replicas_synced_) sync_replicas();
-  if (!dp_) { dp_.reset(new DpState()); dp_->nv = this; VNR_HIP_CHECK(hipEventCreateWithFlags(&dp_->ev_updated, hipEventDisableTiming)); }
-  DpState& dp = *dp_;
-  hipStream_t comm = d.comm_stream();
+  // A replica whose parameters changed outside an optimizer step since the last synchronisation (SetParams, SetModel, a loaded
+  // params.json; a model re-initialised from the clock) would train and render something else than the others, silently.  One
+  // control-plane round trip per call finds out whether ANY rank is in that state, and then all of them synchronise.
+  double dirty = (!replicas_synced_ || synced_generation_ != net_.params_generation()) ? 1.0 : 0.0;
+  d.all_reduce_host(&dirty, 1, DistOp::Max);
+  if (dirty > 0.0) sync_replicas();
+  DpState& dp = dp_state();
+  if (!dp.sharded && net_.opt_sharded()) sync_replicas();   // the shape was switched between calls
   const vec3f lower = {0, 0, 0}, upper = {1, 1, 1};
-  const float scale = 1.0f / (float)d.world();
   for (size_t i = 0; i < steps; ++i) {
     source_->take_samples(train_x_.ptr, train_y_.ptr, batch_size_, lower, upper, stream);
     dp.ranges.clear();
     dp.used = 0;
     net_.forward_backward(train_x_.ptr, train_y_.ptr, batch_size_, stream, &dp);
-    // the update of a range waits for that range's exchange only: Adam of the first ranges runs while the last ones travel
-    for (const DpState::Range& r : dp.ranges) {
-      VNR_HIP_CHECK(hipStreamWaitEvent(stream, r.reduced, 0));
-      net_.optimizer_step_range(r.lo, r.hi, scale, stream);
-    }
+    // the update of a range waits for that range's exchange only: Adam of the first ranges runs while the last ones travel, and
+    // (sharded) a range's parameters travel back while the next range is updated
+    dp.update(stream);
     net_.optimizer_finish_step(stream);
     const bool update_mc = !(fast_mode && mc_.is_external());
     if (update_mc && !mc_.is_external()) mc_.update_explicit(train_x_.ptr, train_y_.ptr, batch_size_, stream);
   }
-  (void)comm;
   if (!mc_.is_external()) {  // every rank has seen other samples: merge the value ranges so that all ranks skip the same cells
     const size_t n = mc_.n_cells();
     DeviceBuffer<float> tmp;
@@ -1086,7 +1190,7 @@ void NeuralVolume::load_params_from_json(const Json& root)
     mc_.upload_value_range(bin.data(), bin.size(), stream);
     mc_.update_max_opacity(tfn_.view(), stream);
   }
-  if (root.contains("model")) net_.configure(root.at("model"), init_seed ? init_seed : 1);
+  if (root.contains("model")) { net_.configure(root.at("model"), init_seed ? init_seed : 1); replicas_synced_ = false; dp_.reset(); }
   if (root.contains("parameters")) net_.deserialize_params(root.at("parameters"), stream);
   else net_.deserialize_params(root, stream);  // legacy format, network.cu:934-936
 }

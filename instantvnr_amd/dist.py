@@ -20,7 +20,7 @@ import numpy as np
 from . import api
 from ._lib import check, lib
 
-SUM, MAX, MIN = 0, 1, 2
+SUM, MAX, MIN, AVG = 0, 1, 2, 3
 F32, F16, U8 = 0, 1, 2
 
 

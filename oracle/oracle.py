@@ -172,6 +172,39 @@ def network_inference(cfg, width, n_hidden_layers, params_bits, coords, activati
     return out
 
 
+def network_inference_mt(cfg, width, n_hidden_layers, params_bits, coords, activation=1, acc_mode=0, n_threads=None):
+    """network_inference over all host threads: the C function is scalar and re-entrant, ctypes releases the GIL during the call, so
+    the coordinates are cut into chunks that a pool of threads pulls from (same values as one call: samples are independent)"""
+    params = np.ascontiguousarray(params_bits, dtype=np.uint16)
+    coords = _f32(coords)
+    n = coords.shape[0]
+    n_threads = n_threads or (os.cpu_count() or 1)
+    if n_threads <= 1 or n < 4096:
+        return network_inference(cfg, width, n_hidden_layers, params, coords, activation, acc_mode)
+    out = np.zeros(n, dtype=np.float32)
+    chunk = max(1024, min(65536, n // (4 * n_threads) + 1))
+    starts = iter(range(0, n, chunk))
+    lk = threading.Lock()
+    L = lib()
+
+    def runner():
+        while True:
+            with lk:
+                a = next(starts, None)
+            if a is None:
+                return
+            b = min(n, a + chunk)
+            c = coords[a:b]
+            o = out[a:b]
+            L.vnro_network_inference(C.byref(cfg), C.c_uint32(width), C.c_uint32(n_hidden_layers), C.c_int(activation), C.c_int(acc_mode),
+                                     _p(params, C.c_uint16), _p(c, C.c_float), C.c_size_t(b - a), _p(o, C.c_float))
+
+    ts = [threading.Thread(target=runner) for _ in range(n_threads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    return out
+
+
 def n_params(cfg, width, n_hidden_layers):
     lay = grid_layout(cfg)
     return mlp_n_params(padded_width(cfg), width, n_hidden_layers - 1) + lay["total_entries"] * cfg.n_features

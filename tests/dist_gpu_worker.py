@@ -148,6 +148,138 @@ def scenario_train(ctx, out):
     out["psnr"] = api.vnrNeuralVolumeGetPSNR(nv)
 
 
+def scenario_frames_unpinned(ctx, out):
+    """what a rank of the driver's 8-GPU run executes: VNR_RM_N_ITERS NOT set, a share of at most 196 608 pixels, hence 32 samples per ray
+    and iteration, 4 ray parts and the packing fused into the evaluation kernel (render.hip Renderer::render / render_streaming /
+    launch_tail).  The frame assembled from such shares must equal, bit for bit, the unsharded frame rendered with the batch size
+    pinned to 32; and differ from the unsharded default (24) by no more than the resume rounding."""
+    L = lib()
+    assert "VNR_RM_N_ITERS" not in os.environ
+    dims = (160, 160, 160)
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(160))
+    os.environ["VNR_AMD_INIT_SEED"] = "4243"
+    cfg = syn.model_config(n_levels=12, n_features=2, log2_hashmap_size=19, n_hidden_layers=3, per_level_scale=1.4)
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+    api.vnrNeuralVolumeTrain(nv, 150, True)
+    check(L.vnrAmdNeuralVolumeSyncReplicas(nv.h))
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = syn.oblique_camera(dims, distance_scale=0.8)
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    size = (1024, 192 * ctx.world)             # 24 tile rows = 196 608 pixels per rank at any world size
+    n_frames = 4
+    frames = {}
+    for pin in ("32", "24"):
+        os.environ["VNR_RM_N_ITERS"] = pin      # read when a renderer is created
+        plain = make_renderer(nv, tfn, camera, size, 5)
+        frames[pin] = []
+        for _ in range(n_frames):
+            api.vnrRender(plain)
+            frames[pin].append(api.vnrRendererMapFrame(plain).copy())
+        out["iterations_" + pin] = int(api.vnrRendererGetFrameStats(plain)["n_iterations"])
+    del os.environ["VNR_RM_N_ITERS"]
+    out["brick_in_use"] = bool(api.neural_brick_image(nv)["in_use"])
+    sr = vdist.ShardedRenderer(ctx, make_renderer(nv, tfn, camera, size, 5), size[0], size[1])
+    got = []
+    for k in range(n_frames):
+        f = sr.render()
+        if k:
+            got.append(sr.download(f))
+    got.append(sr.download(sr.flush()))
+    r_sync = make_renderer(nv, tfn, camera, size, 5)
+    check(L.vnrAmdRendererSetDistributed(r_sync.h, 1))
+    ok_sync = True
+    for k in range(n_frames):
+        api.vnrRender(r_sync)
+        ok_sync = ok_sync and bool(np.array_equal(api.vnrRendererMapFrame(r_sync), frames["32"][k]))
+    out["equal_32"] = np.array([bool(np.array_equal(g, w)) for g, w in zip(got, frames["32"])])
+    out["equal_32_sync"] = ok_sync
+    out["equal_24"] = np.array([bool(np.array_equal(g, w)) for g, w in zip(got, frames["24"])])
+    out["max_diff_24"] = float(max(np.abs(g - w).max() for g, w in zip(got, frames["24"])))
+    out["coverage"] = float((frames["32"][-1][..., 3] > 0).mean())
+    out["samples"] = int(api.vnrRendererGetFrameStats(sr.r)["n_samples"])
+    out["iterations"] = int(api.vnrRendererGetFrameStats(sr.r)["n_iterations"])
+
+
+def scenario_sharded_optimizer(ctx, out):
+    """the sharded step (reduce-scatter, Adam on the rank's 1/world of every range, all-gather of the fp16 parameters) against the
+    replicated one (all-reduce, Adam on everything) on the SAME gradients: Adam is per parameter and both exchange with the same
+    reduction, so the parameters must agree bit for bit, step after step; then the optimizer state is gathered (SyncReplicas) and a
+    replicated step on both volumes must still agree (the gathered moments and step counts are the replicated ones)."""
+    L = lib()
+    import ctypes as C
+    os.environ["VNR_AMD_INIT_SEED"] = "77"
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))
+    model = dict(SMALL_MODEL, n_levels=6, log2_hashmap_size=14)
+    a = api.vnrCreateNeuralVolume(syn.model_config(**model), sv, online_macrocell_construction=False)
+    b = api.vnrCreateNeuralVolume(syn.model_config(**model), sv, online_macrocell_construction=False)
+    check(L.vnrAmdNeuralVolumeSyncReplicas(a.h))
+    check(L.vnrAmdNeuralVolumeSyncReplicas(b.h))
+    n = api.neural_info(a)["n_params"]
+    out["n_params"] = n
+    assert np.array_equal(api.neural_get_params_fp16(a).view(np.uint16), api.neural_get_params_fp16(b).view(np.uint16))
+
+    def gradient(step):
+        rng = np.random.default_rng(1000 * step + ctx.rank)
+        g = (rng.normal(size=n) * 0.5).astype(np.float32)
+        g[rng.random(n) < 0.6] = 0.0     # most hash-grid entries are untouched in a step: their parameters must not move
+        return g
+
+    def set_grad(v, g):
+        check(L.vnrAmdNeuralVolumeSetGradients(v.h, g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
+
+    equal, moved = [], []
+    before = api.neural_get_params_fp16(a).view(np.uint16).copy()
+    for step in range(5):
+        g = gradient(step)
+        set_grad(a, g); set_grad(b, g)
+        check(L.vnrAmdNeuralVolumeTrainEndDataParallel(a.h, 1, 0))
+        check(L.vnrAmdNeuralVolumeTrainEndDataParallel(b.h, 1, 1))
+        pa, pb = api.neural_get_params_fp16(a).view(np.uint16), api.neural_get_params_fp16(b).view(np.uint16)
+        equal.append(bool(np.array_equal(pa, pb)))
+        moved.append(float((pa != before).mean()))
+        assert np.all(api.neural_gradients(a) == 0) and np.all(api.neural_gradients(b) == 0)   # both shapes leave a clear blob
+    out["equal"] = np.array(equal)
+    out["moved"] = np.array(moved)
+    out["checksum"] = vdist.params_checksum(b)
+    # a full step on one rank would read stale state of the other ranks' slices: refused until the state has been gathered
+    set_grad(b, gradient(99))
+    out["refused"] = L.vnrAmdNeuralVolumeTrainEnd(b.h, 1.0, 1) != 0 if ctx.world > 1 else True
+    check(L.vnrAmdNeuralVolumeSyncReplicas(b.h))
+    g = gradient(5)
+    set_grad(a, g); set_grad(b, g)
+    check(L.vnrAmdNeuralVolumeTrainEndDataParallel(a.h, 1, 0))
+    check(L.vnrAmdNeuralVolumeTrainEndDataParallel(b.h, 1, 0))
+    out["equal_after_gather"] = bool(np.array_equal(api.neural_get_params_fp16(a).view(np.uint16), api.neural_get_params_fp16(b).view(np.uint16)))
+    out["step"] = api.vnrNeuralVolumeGetTrainingStep(b)
+
+
+def scenario_resync(ctx, out):
+    """a replica whose parameters change outside an optimizer step (SetParams on ONE rank, a re-initialised model) is found by the
+    next data-parallel call (one control-plane round trip) and the replicas are synchronised again"""
+    os.environ["VNR_AMD_INIT_SEED"] = str(500 + ctx.rank)
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))
+    nv = api.vnrCreateNeuralVolume(syn.model_config(**SMALL_MODEL), sv, online_macrocell_construction=False)
+    vdist.train_data_parallel(ctx, nv, 3)
+    out["checksum_a"] = vdist.params_checksum(nv)
+    if ctx.rank == ctx.world - 1:       # one rank loads other parameters
+        p = api.neural_get_params_fp16(nv)
+        api.neural_set_params_fp16(nv, (p.astype(np.float32) * 0.5).astype(np.float16))
+    out["checksum_changed"] = vdist.params_checksum(nv)
+    vdist.train_data_parallel(ctx, nv, 2)
+    out["checksum_b"] = vdist.params_checksum(nv)
+    if ctx.rank == 0:                   # one rank re-creates its model (a fresh seed)
+        os.environ["VNR_AMD_INIT_SEED"] = "999"
+        api.vnrNeuralVolumeSetModel(nv, syn.model_config(**SMALL_MODEL))
+    vdist.train_data_parallel(ctx, nv, 2)
+    out["checksum_c"] = vdist.params_checksum(nv)
+    out["step"] = api.vnrNeuralVolumeGetTrainingStep(nv)
+
+
 def scenario_train_c4(ctx, out):
     """the C4 model (70 M parameters, 140 MB fp16 gradient blob exchanged range by range under the backward pass) trained data-parallel:
     replicas that start from different seeds are identical after every call, and the loss falls"""
@@ -197,7 +329,9 @@ def main():
     scenario, out_path = sys.argv[1], sys.argv[2]
     ctx = vdist.init_from_env()
     out = {"rank": ctx.rank, "world": ctx.world, "transport": ctx.transport or "none"}
-    {"frames": scenario_frames, "frames_c4": scenario_frames_c4, "train": scenario_train, "train_c4": scenario_train_c4, "macrocell": scenario_macrocell, "ooc": scenario_ooc}[scenario](ctx, out)
+    {"frames": scenario_frames, "frames_c4": scenario_frames_c4, "frames_unpinned": scenario_frames_unpinned, "train": scenario_train,
+     "train_c4": scenario_train_c4, "sharded_optimizer": scenario_sharded_optimizer, "resync": scenario_resync, "macrocell": scenario_macrocell,
+     "ooc": scenario_ooc}[scenario](ctx, out)
     vdist.barrier()
     np.savez(out_path, **out)
     vdist.finalize()

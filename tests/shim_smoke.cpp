@@ -61,6 +61,9 @@ int main() {
     for (int b = 0; b < vnrNeuralVolumeGetNumberOfBlobs(v); ++b) vnrNeuralVolumeDecodeProgressive(v);
     vnrRender(r);
     try { (void)vnrSimpleVolumeGetNumberOfTimeSteps(v); return 14; } catch (const std::runtime_error&) {}   // not a simple volume
+    // api.h:34 vnrType = vnr::ValueType, the voxel type of a volume made from memory (device/device_impl.cpp:175-184)
+    const vnrType ty = vnr::VALUE_TYPE_UINT16;
+    if (vnr::value_type_size(ty) != 2 || (int)vnr::VALUE_TYPE_FLOAT != 8 || (int)vnr::VALUE_TYPE_DOUBLE != 12) return 18;
   } catch (const std::runtime_error& e) { return 42; }
   return 0;
 }

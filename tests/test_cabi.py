@@ -143,9 +143,7 @@ def test_no_cpu_fallback_without_device(L):
                                   (8, 8, 8))
 
 
-def test_cpp_api_shim_compiles_and_throws_like_the_reference(L, tmp_path):
-    """include/vnr_api_shim.hpp restores the api.h C++ signatures over the C-ABI.  Compiled here against the only
-    nlohmann::json in the image (3.1.1, no BSON => VNR_SHIM_JSON_TEXT_TRANSPORT); errors surface as std::runtime_error."""
+def _build_and_run_shim_smoke(tmp_path):
     import shutil
     import subprocess
     inc = "/opt/conda/include"
@@ -157,8 +155,21 @@ def test_cpp_api_shim_compiles_and_throws_like_the_reference(L, tmp_path):
                            os.path.join(root, "tests", "shim_smoke.cpp"), "-o", exe,
                            "-L", os.path.join(root, "instantvnr_amd"), "-lvnr_amd",
                            "-Wl,-rpath," + os.path.join(root, "instantvnr_amd")])
-    rc = subprocess.call([exe])
+    return subprocess.call([exe])
+
+
+def test_cpp_api_shim_compiles_and_throws_like_the_reference(L, tmp_path):
+    """include/vnr_api_shim.hpp restores the api.h C++ signatures over the C-ABI.  Compiled here against the only
+    nlohmann::json in the image (3.1.1, no BSON => VNR_SHIM_JSON_TEXT_TRANSPORT); errors surface as std::runtime_error."""
+    rc = _build_and_run_shim_smoke(tmp_path)
     assert rc == (0 if L.vnrAmdHasDevice() else 42)   # 42 = std::runtime_error ("no HIP capable devices")
+
+
+@pytest.mark.gpu
+def test_cpp_api_shim_runs_its_gpu_half(tmp_path):
+    """the same program where a GPU exists (the driver's `-m gpu` run): a C++ application written against api.h creates a neural volume
+    and a volume from memory (vnrType), renders, decodes and renders the decoded volume through the shim; exit code 0"""
+    assert _build_and_run_shim_smoke(tmp_path) == 0
 
 
 @pytest.mark.parametrize("order,ok", [("lib-first", False), ("torch-first", True)])

@@ -72,6 +72,10 @@ def _collectives_worker(rank, world, port, q):
     h = (_rank_data(rank, n, 1) * 1e-2).astype(np.float16)
     check(L.vnrAmdDistAllReduce(_ptr(h), h.size, vdist.F16, vdist.SUM))
     out["f16_sum"] = h
+    # fp16 mean: the data-parallel gradient exchange (DistOp::Avg = ncclAvg)
+    h2 = (_rank_data(rank, n, 1) * 1e-2).astype(np.float16)
+    check(L.vnrAmdDistAllReduce(_ptr(h2), h2.size, vdist.F16, vdist.AVG))
+    out["f16_avg"] = h2
     # u8 max
     u = np.random.default_rng(50 + rank).integers(0, 255, 4096, dtype=np.uint8)
     check(L.vnrAmdDistAllReduce(_ptr(u), u.size, vdist.U8, vdist.MAX))
@@ -114,6 +118,7 @@ def test_shm_transport_collectives(world):
     for r in range(1, world):
         acc = acc + h[r].astype(np.float32)
     want["f16_sum"] = acc.astype(np.float16)           # summed in fp32, rounded once
+    want["f16_avg"] = (acc * np.float32(1.0 / world)).astype(np.float16)   # ... divided in fp32 before the one rounding
     want["u8_max"] = np.max([np.random.default_rng(50 + r).integers(0, 255, 4096, dtype=np.uint8) for r in range(world)], 0)
     share, per = 300_017, 123_457
     want["gather"] = np.concatenate([_rank_data(r, share, 2) for r in range(world)])
@@ -123,7 +128,7 @@ def test_shm_transport_collectives(world):
         rs_sum = rs_sum + rs[r]
     want["bcast"] = _rank_data(world - 1, 5000, 4)
     for rank, out in res:
-        for k in ("f32_sum", "f32_max", "f32_min", "f16_sum", "u8_max", "gather", "bcast"):
+        for k in ("f32_sum", "f32_max", "f32_min", "f16_sum", "f16_avg", "u8_max", "gather", "bcast"):
             assert np.array_equal(out[k], want[k]), (rank, k)
         assert np.array_equal(out["rs_mine"], rs_sum[rank * per:(rank + 1) * per]), rank
         assert out["host_max"] == [float(world - 1), 10.0]

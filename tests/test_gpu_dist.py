@@ -120,6 +120,46 @@ def test_data_parallel_training_on_several_ranks(world, tmp_path):
     assert abs(float(res[0]["psnr"]) - psnr_ref) < 1.0
 
 
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_optimizer_step_equals_the_replicated_step(world, tmp_path):
+    """reduce-scatter + Adam on 1/world + all-gather against all-reduce + Adam on everything, on identical gradients (world 3: ranges
+    that do not divide, so their last parameters are all-reduced and updated by everyone)"""
+    res = run_ranks("sharded_optimizer", world, tmp_path)
+    assert len({int(r["checksum"]) for r in res}) == 1          # one model on all ranks
+    for r in res:
+        assert bool(np.all(r["equal"])), (int(r["rank"]), r["equal"])
+        assert r["moved"][0] > 0.2 and r["moved"][-1] >= r["moved"][0]   # the steps did update (40 % of the entries carry a gradient per rank)
+        assert bool(r["refused"]) and bool(r["equal_after_gather"]) and int(r["step"]) == 6
+
+
+def test_replicas_are_synchronised_again_after_one_rank_changes_its_parameters(tmp_path):
+    res = run_ranks("resync", 2, tmp_path)
+    a, b = res
+    assert int(a["checksum_a"]) == int(b["checksum_a"])
+    assert int(a["checksum_changed"]) != int(b["checksum_changed"])     # rank 1 did load something else ...
+    assert int(a["checksum_b"]) == int(b["checksum_b"])                 # ... and the next call made the replicas one again
+    assert int(a["checksum_c"]) == int(b["checksum_c"]) and int(a["checksum_c"]) != int(a["checksum_b"])
+    assert int(a["step"]) == int(b["step"]) == 2                        # rank 0's re-created model restarts the schedule for everyone
+
+
+def test_shares_of_an_eighth_frame_size_take_the_unpinned_branch_and_equal_the_frame_at_32(tmp_path):
+    """VNR_RM_N_ITERS unset (tests/conftest.py pins 16 for the rest of the suite): 2 ranks x 196 608 pixels, i.e. what a rank of the
+    8-GPU bench renders: N_ITERS 32, 4 ray parts, packing fused into the evaluation kernel"""
+    saved = os.environ.pop("VNR_RM_N_ITERS", None)
+    try:
+        res = run_ranks("frames_unpinned", 2, tmp_path, timeout=600)
+    finally:
+        if saved is not None:
+            os.environ["VNR_RM_N_ITERS"] = saved
+    for r in res:
+        assert float(r["coverage"]) > 0.2 and int(r["samples"]) > 1_000_000
+        assert bool(np.all(r["equal_32"])) and bool(r["equal_32_sync"]), (int(r["rank"]), r["equal_32"])
+        # the branch was taken: as many iterations as the frame pinned to 32 needs, fewer than at 24; against the frame at 24 only last bits move
+        assert int(r["iterations"]) <= int(r["iterations_32"]) < int(r["iterations_24"])
+        assert not bool(np.all(r["equal_24"])) and float(r["max_diff_24"]) < 1e-3
+        print(f"rank {int(r['rank'])}: shares vs the unsharded frame at 24: equal {r['equal_24']}, max |diff| {float(r['max_diff_24']):.2e}")
+
+
 def _initial_params():
     os.environ["VNR_AMD_INIT_SEED"] = "100"
     sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))

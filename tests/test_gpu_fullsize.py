@@ -41,6 +41,12 @@ def test_brick_image_of_the_c4_model_is_bit_identical(oracle):
     ocfg = oracle.grid_config(16, 2, 22, 16, float(np.exp(np.log(1024 / 16.0) / 15)))
     k = 4096
     assert np.array_equal(enc0[:k], oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords[:k]))
+    # ... and the network OUTPUT of the T = 2^22 model on the same coordinates (the bar of tests/test_gpu_network.py: 2^-8, median 2^-11)
+    want = oracle.network_inference_mt(ocfg, 64, 3, params.view(np.uint16), coords[:k])
+    got = y0.view(np.float32)[:k]
+    err = np.abs(got - want)
+    assert err.max() <= 2.0 ** -8 * max(1.0, float(np.abs(want).max())), err.max()
+    assert np.median(err) <= 2.0 ** -11
 
 
 @pytest.fixture(scope="module")
@@ -102,6 +108,102 @@ def test_a_1024x1024_frame_does_not_depend_on_the_schedule(big_scene, monkeypatc
             rows = (np.arange(1024) // 8) % 8 == part
             full[rows] = share[rows]
         assert np.array_equal(full, one)
+
+
+def test_eight_unpinned_shares_of_the_1024x1024_frame_equal_the_frame_at_32(big_scene, monkeypatch):
+    """what the ranks of the 8-GPU bench execute, here on one renderer per share: VNR_RM_N_ITERS unset, so a share of 131 072 pixels
+    marches 32 samples per ray and iteration on 4 ray parts with the packing fused into the evaluation kernel (render.hip Renderer::render,
+    render_streaming, launch_tail); the 8 shares must assemble to the unsharded frame rendered with the batch size pinned to 32"""
+    monkeypatch.setenv("VNR_RM_N_ITERS", "32")
+    one = frame(big_scene, 5, frames=2)
+    monkeypatch.delenv("VNR_RM_N_ITERS")
+    full = np.zeros_like(one)
+    for part in range(8):
+        share = frame(big_scene, 5, parts=(8, part), frames=2)
+        rows = (np.arange(1024) // 8) % 8 == part
+        full[rows] = share[rows]
+    assert (one[..., 3] > 0).mean() > 0.2
+    assert np.array_equal(full, one)
+    # an UNSHARDED frame of a small framebuffer keeps the default batch size (24), whatever its size
+    monkeypatch.setenv("VNR_RM_N_ITERS", "24")
+    r = small_frame(big_scene)
+    monkeypatch.delenv("VNR_RM_N_ITERS")
+    assert np.array_equal(small_frame(big_scene), r)
+
+
+def small_frame(scene):
+    r = api.vnrCreateRenderer(scene["nv"])
+    api.vnrRendererSetTransferFunction(r, scene["tfn"])
+    api.vnrRendererSetCamera(r, scene["camera"])
+    api.vnrRendererSetFramebufferSize(r, (256, 192))
+    api.vnrRender(r)
+    return api.vnrRendererMapFrame(r).copy()
+
+
+@pytest.fixture(scope="module")
+def c4_scene():
+    """BASELINE C4 as bench.py sets it up: 1024^3 Perlin volume, the 70 M-parameter model trained on it, the bench's transfer function
+    and camera"""
+    import os
+    os.environ["VNR_AMD_INIT_SEED"] = "20240611"
+    dims = (1024, 1024, 1024)
+    sv = api.vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=6.0)
+    nv = api.vnrCreateNeuralVolume(c4_config(), sv, online_macrocell_construction=False)
+    api.vnrNeuralVolumeTrain(nv, 400, True)
+    colors, alphas = syn.tfn_ramp_with_bumps(opacity_scale=0.06)
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = syn.oblique_camera(dims, distance_scale=1.1)
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+    return {"nv": nv, "sv": sv, "tfn": tfn, "camera": camera, "cam": cam, "colors": colors, "alphas": alphas}
+
+
+def test_a_band_of_the_c4_frame_equals_the_oracle(oracle, c4_scene):
+    """the frame bench.py times (1024^2 of the 1024^3 volume, trained L16 F2 T2^22 + 3x64 model, de-hashed image in use), 16 scanlines
+    through its middle against the oracle's streaming marcher (method_raymarching.cu:931-958 restated) driven by the oracle's network
+    on all host threads: the same rays hit, the same number of iterations, the same samples up to saturation ties, and the pixels at
+    the neural-frame bar of tests/test_gpu_configs.py (PSNR >= 45 dB, max < 0.05)"""
+    nv = c4_scene["nv"]
+    warm = frame(c4_scene, 5, frames=3)           # 3 frames x 2 ray parts x ~9 launches: the image is built along the way
+    st_img = api.neural_brick_image(nv)
+    assert st_img["in_use"] and st_img["bytes"] > 7 * 2**30
+    assert (warm[..., 3] > 0).mean() > 0.5
+    lo, hi = 504 * 1024, 520 * 1024
+    r = api.vnrCreateRenderer(nv)
+    api.vnrRendererSetTransferFunction(r, c4_scene["tfn"])
+    api.vnrRendererSetCamera(r, c4_scene["camera"])
+    api.vnrRendererSetFramebufferSize(r, (1024, 1024))
+    api.vnrRendererSetMode(r, 5)
+    api.vnrRendererSetPixelRange(r, lo, hi)
+    api.vnrRender(r)
+    band = api.vnrRendererMapFrame(r).reshape(-1, 4)[lo:hi].copy()
+    st = api.vnrRendererGetFrameStats(r)
+    one = frame(c4_scene, 5)
+    assert np.array_equal(band, one.reshape(-1, 4)[lo:hi])          # the band is the whole frame's pixels
+    params = api.neural_get_params_fp16(nv).view(np.uint16)
+    pls = float(np.exp(np.log(1024 / 16.0) / 15))
+    ocfg = oracle.grid_config(16, 2, 22, 16, pls)
+    mo = api.volume_macrocell(nv)["max_opacity"]
+    cam = c4_scene["cam"]
+    sc = oracle.SceneHolder(1024, 1024, (1024, 1024, 1024), oracle.TfnHolder(c4_scene["colors"], c4_scene["alphas"]), mo, cam["from"], cam["at"],
+                            cam["up"], cam["fovy"], pixel_range=(lo, hi))
+    import time
+    t0 = time.perf_counter()
+    ref, _, ost = oracle.render_streaming(sc, lambda c: oracle.network_inference_mt(ocfg, 64, 3, params, c))
+    dt = time.perf_counter() - t0
+    ref = ref.reshape(-1, 4)[lo:hi]
+    err = np.abs(band - ref)
+    psnr = 10 * np.log10(1.0 / float((err ** 2).mean()))
+    print(f"\nC4 band of 16 scanlines: oracle {dt:.1f} s for {ost['n_slots']} slots; rays hit {st['n_rays_hit']}, iterations {st['n_iterations']}, "
+          f"samples {st['n_samples']} (oracle {ost['n_samples']}), PSNR {psnr:.1f} dB, max |err| {err.max():.4f}")
+    assert ost["n_rays_hit"] == st["n_rays_hit"] and ost["n_iterations"] == st["n_iterations"]
+    assert abs(ost["n_samples"] - st["n_samples"]) <= 0.002 * ost["n_samples"]
+    assert (ref[:, 3] > 0).mean() > 0.5
+    assert psnr > 45.0, psnr
+    assert err.max() < 0.05
 
 
 def test_gradients_of_the_c4_model_match_the_restatement(oracle):

@@ -268,3 +268,15 @@ def test_nearest_quantize_and_max_level_hand_cases(oracle):
     assert out[0, 0] == np.float16(6.75) and out[0, 2] == 0 and out[0, 3] == 0
     mz = oracle.grid_config(2, 2, 8, 2, max_level=-1.0)   # everything masked
     assert not oracle.grid_encode(mz, table_for(mz).view(np.uint16), x).any()
+
+
+def test_threaded_network_inference_equals_the_scalar_call(oracle):
+    """oracle.network_inference_mt (the C4 band test's value function) cuts the batch over a thread pool: same values, bit for bit"""
+    cfg = oracle.grid_config(6, 2, 12, 4, 1.5)
+    n_p = oracle.n_params(cfg, 64, 2)
+    rng = np.random.default_rng(3)
+    params = (rng.normal(size=n_p) * 0.3).astype(np.float16).view(np.uint16)
+    coords = rng.random((20000, 3), dtype=np.float32)
+    a = oracle.network_inference(cfg, 64, 2, params, coords)
+    b = oracle.network_inference_mt(cfg, 64, 2, params, coords, n_threads=4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.abs(a).max() > 0

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) fused_infer_kernel(const InferArgs args)
       __syncthreads();
     }
   }
-  const uint32_t n = args.n_ptr ? *args.n_ptr : args.n;
+  const uint32_t n = args.n_ptr ? min(*args.n_ptr, args.n) : args.n;   // (args.n: the caller's upper bound when the count lives on the device)
   const uint32_t n_tiles = (n + 63u) >> 6;
   // XCD-contiguous tile ranges: blocks with equal (blockIdx % 8) share an XCD / L2 (speed only)
   const uint32_t xcd = blockIdx.x & 7u;
@@ -253,7 +253,7 @@ struct GenericArgs {
 
 __global__ void __launch_bounds__(128) generic_infer_kernel(const GenericArgs a)
 {
-  const uint32_t n = a.n_ptr ? *a.n_ptr : a.n;
+  const uint32_t n = a.n_ptr ? min(*a.n_ptr, a.n) : a.n;
   const half_t* table = a.params + a.n_mlp;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float x, y, z;
@@ -338,7 +338,7 @@ void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, ui
   a.params = (const half_t*)params; a.n_mlp = n_mlp; a.in_width = in_width; a.width = cfg.n_neurons;
   a.n_hidden_matmuls = cfg.n_hidden_layers - 1; a.activation = cfg.activation;
   a.coords = coords; a.out = out; a.features_out = (half_t*)features_out; a.n_ptr = d_n; a.dest = d_dest;
-  a.queue_mode = queue_out_stride ? 1u : 0u; a.out_stride = queue_out_stride; a.n = (uint32_t)n; a.encode_only = mode == 1 ? 1u : 0u;
+  a.queue_mode = queue_out_stride ? 1u : 0u; a.out_stride = queue_out_stride; a.n = d_n ? (uint32_t)n_max : (uint32_t)n; a.encode_only = mode == 1 ? 1u : 0u;
   const uint32_t blocks = std::min<uint32_t>(div_round_up(n_max, 128), (uint32_t)Runtime::get().n_cus * 16u);
   generic_infer_kernel<<<blocks, 128, 0, s>>>(a);
   VNR_HIP_CHECK(hipGetLastError());
@@ -369,7 +369,7 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
   a.dest = d_dest;
   a.queue_mode = queue_out_stride ? 1u : 0u;
   a.out_stride = queue_out_stride;
-  a.n = (uint32_t)n;
+  a.n = d_n ? (uint32_t)n_max : (uint32_t)n;
   a.n_hidden_matmuls = n_hidden_matmuls;
   a.activation = activation;
   a.lds_halves = lds_halves;

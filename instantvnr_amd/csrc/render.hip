@@ -737,7 +737,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
           q[2] = {c.x, c.y + stp.y, c.z, __uint_as_float(gi + 1u)};
           q[3] = {c.x, c.y, c.z + stp.z, __uint_as_float(gi + 2u)};
         } else {
-          queue[g] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + 64u * j))};
+          if (g < p.slot_cap) queue[g] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + 64u * j))};   // (always: the claims of a launch sum to at most n_local x n_iters)
         }
         vd_out[sb + 64u * j].y = t1 - t0;
         if (MODE == M_SSH) ((float*)vd_out)[arena_grad_index(p.slot_cap, sb + 64u * j)] = t;   // compose needs the position of the sample
@@ -1218,6 +1218,7 @@ __global__ void __launch_bounds__(1024) pt_compact_kernel(const PtRays src, cons
 
 }  // namespace vnr
 #include "in_shader.h"   // in_shader_kernel, in_shader_pt_kernel: use the device code above
+#include "decoupled.h"   // walk_kernel, compose_kernel: the streaming loop with the walk off the evaluate -> compose chain
 namespace vnr {
 
 // ================================================================================================ Renderer (host)
@@ -1242,8 +1243,31 @@ struct PartState {
 
 // One pass of the streaming loop between its two halves: everything launch_iteration / finish_streaming need.  With
 // set_async(true) a frame stays in this state ("pending") from render() until the next call that needs its result.
+// one ray part of the decoupled loop (decoupled.h)
+struct DPart {
+  RenderParams p;
+  DRays rays;
+  DRing ring[8];
+  DHost* host = nullptr;
+  hipStream_t sw = nullptr, se = nullptr, sc = nullptr;
+  std::vector<hipEvent_t> ev_w, ev_e, ev_c;   // per iteration
+  uint32_t it_w = 0, it_c = 0, target = 0;     // walks (+ evaluations) and composes enqueued so far; iterations to enqueue
+  size_t s_max = 0;
+  bool done = false;
+  hipEvent_t& ev(std::vector<hipEvent_t>& v, uint32_t it)
+  {
+    if (it >= 1024u) throw std::runtime_error("internal: decoupled loop asked for the event of iteration " + std::to_string(it));   // (an index that wrapped must not become four billion events)
+    while (v.size() <= it) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); v.push_back(e); }
+    return v[it];
+  }
+  ~DPart() { for (auto* v : {&ev_w, &ev_e, &ev_c}) for (hipEvent_t e : *v) (void)hipEventDestroy(e); }
+};
+
 struct Renderer::StreamingFrame {
   bool pending = false;
+  bool decoupled = false;
+  int ahead = 2, ring = 3;
+  DPart dpart[Renderer::kMaxParts];
   int slot = 0;
   int H = 0, pass_mode = 0;
   bool grad = false, ssh = false;
@@ -1270,6 +1294,9 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
     const int w = std::atoi(e);
     tile_w_log2_ = w == 16 ? 4u : w == 32 ? 5u : w == 64 ? 6u : 3u;
   }
+  if (const char* e = std::getenv("VNR_AMD_DECOUPLED")) decoupled_mode_ = std::max(0, std::min(2, std::atoi(e)));
+  if (const char* e = std::getenv("VNR_AMD_DECOUPLED_AHEAD")) decoupled_ahead_ = std::max(1, std::min(7, std::atoi(e)));
+  if (const char* e = std::getenv("VNR_AMD_DECOUPLED_PARTS")) decoupled_parts_ = std::max(1, std::min(kMaxParts, std::atoi(e)));
   counters_.resize(2 * kMaxParts * C_COUNT);  // one block of counters per frame slot and half
   counters_.zero(stream_);
   VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 2 * kMaxParts * (256 + C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
@@ -1282,6 +1309,9 @@ Renderer::~Renderer()
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (int i = 1; i < kMaxParts; ++i) if (part_streams_[i]) { (void)hipStreamSynchronize(part_streams_[i]); (void)hipStreamDestroy(part_streams_[i]); }
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  for (auto& ps : d_streams_) for (hipStream_t st : ps) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  frame_[0].reset(); frame_[1].reset();
+  if (d_host_) (void)hipHostFree(d_host_);
   if (distributed_) (void)hipStreamSynchronize(Dist::get().comm_stream());
   if (ev_rendered_) (void)hipEventDestroy(ev_rendered_);
   for (int i = 0; i < 2; ++i) if (ev_gathered_[i]) (void)hipEventDestroy(ev_gathered_[i]);
@@ -1294,7 +1324,7 @@ void Renderer::resize(int w, int h)
 {
   finish_pending();
   if (w <= 0 || h <= 0) throw std::runtime_error("invalid framebuffer size");
-  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+  VNR_HIP_CHECK(hipDeviceSynchronize());   // buffers are replaced below: nothing may still run on any of the renderer's streams
   width_ = w; height_ = h;
   const size_t n = (size_t)w * h;
   for (int i = 0; i < 2; ++i) { fb_[i].resize(n); fb_[i].zero(stream_); }
@@ -1444,7 +1474,7 @@ void Renderer::ensure_queues(size_t n_pixels, int n_iters, bool gradient)
 {
   if (queue_pixels_ >= n_pixels && queue_iters_ >= n_iters && (queue_grad_ || !gradient)) return;
   finish_pending();   // a pending frame lives in the buffers that are about to be replaced
-  VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+  VNR_HIP_CHECK(hipDeviceSynchronize());
   const size_t P = std::max(n_pixels, queue_pixels_);
   const int iters = std::max(n_iters, queue_iters_);
   const bool grad = gradient || queue_grad_;
@@ -1864,6 +1894,7 @@ void Renderer::launch_tail(StreamingFrame& f, int h, uint32_t it)
 
 void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool defer)
 {
+  if (decoupled_applies(p_all, pass_mode)) { render_decoupled(p_all, defer); return; }
   // The rank's rays are dealt to `n_halves_` independent halves (alternate local tile rows; same mechanism as the
   // multi-GPU interleave), each with its own ray lists, sample queue, counters and HIP stream.  The arithmetic per ray
   // is untouched; what changes is that march(i) of one half runs while the other half's inference kernel does: the
@@ -1896,6 +1927,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
   if (f.pending) throw std::runtime_error("internal: both frame slots are pending");
   f.slot = slot;
   slot_ = slot;
+  f.decoupled = false;   // (the slot's previous frame may have run the decoupled loop: finish_streaming dispatches on this)
   PartState* half = f.part;
   for (int h = 0; h < kMaxParts; ++h) { half[h].it = 0; half[h].used = 0; half[h].done = false; half[h].tail_skipped = false; }
   const size_t n_groups_slot = QP / 64 + 64 + 8 * kMaxParts;
@@ -2002,6 +2034,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
 void Renderer::finish_streaming(StreamingFrame& f)
 {
   if (!f.pending) return;
+  if (f.decoupled) { finish_decoupled(f); return; }
   f.pending = false;
   PartState* half = f.part;
   const int H = f.H, pass_mode = f.pass_mode;
@@ -2048,35 +2081,12 @@ void Renderer::finish_streaming(StreamingFrame& f)
     // march(j) emits what the reference's iteration j intersects and march(j+1) composes it, so `used` marches
     // correspond to used-1 reference iterations (= inference launches with samples); halves run side by side
     pass_iterations = std::max<uint32_t>(pass_iterations, used > 0 ? used - 1 : 0);
-    if (profiling_) {
-      for (uint32_t k = 0; k < hf.it; ++k) {
-        float ms = 0.0f;
-        VNR_HIP_CHECK(hipEventElapsedTime(&ms, events_[f.slot][h][2 * k], events_[f.slot][h][2 * k + 1]));
-        stats_.infer_kernel_ms += ms;
-        iter_ms_[k] += ms;
-      }
-      stats_.infer_kernel_launches += used > 0 ? used - 1 : 0;
-    }
+    if (profiling_) stats_.infer_kernel_launches += used > 0 ? used - 1 : 0;
   }
-  if (profiling_ && half[0].it > 0) {
-    // the halves' launches overlap: the union of their intervals (all timed against part 0's first event) is the time the
-    // evaluation kernel had the GPU or a share of it
-    std::vector<std::pair<float, float>> iv;
-    for (int h = 0; h < H; ++h)
-      for (uint32_t k = 0; k < half[h].it; ++k) {
-        float t0 = 0.0f, t1 = 0.0f;
-        VNR_HIP_CHECK(hipEventElapsedTime(&t0, events_[f.slot][0][0], events_[f.slot][h][2 * k]));
-        VNR_HIP_CHECK(hipEventElapsedTime(&t1, events_[f.slot][0][0], events_[f.slot][h][2 * k + 1]));
-        iv.emplace_back(t0, t1);
-      }
-    std::sort(iv.begin(), iv.end());
-    float lo = iv[0].first, hi = iv[0].second;
-    double total = 0.0;
-    for (size_t e = 1; e < iv.size(); ++e) {
-      if (iv[e].first > hi) { total += hi - lo; lo = iv[e].first; hi = iv[e].second; }
-      else hi = std::max(hi, iv[e].second);
-    }
-    stats_.infer_union_ms += total + (hi - lo);
+  {
+    uint32_t launched[kMaxParts] = {};
+    for (int h = 0; h < H; ++h) launched[h] = half[h].it;
+    collect_eval_profile(f, launched, nullptr);
   }
   // summed over the passes of a frame (mode 11: camera pass + shadow pass)
   stats_.n_iterations += pass_iterations;
@@ -2085,6 +2095,275 @@ void Renderer::finish_streaming(StreamingFrame& f)
   completed_stats_ = stats_;
 }
 
+
+// per-launch and union times of the evaluation kernel from the HIP events around its launches (profiling_): `launched[h]` launches of
+// part h were enqueued with an event pair each
+void Renderer::collect_eval_profile(StreamingFrame& f, const uint32_t* launched, const uint32_t* /*used*/)
+{
+  if (!profiling_) return;
+  const int H = f.H;
+  bool any = false;
+  for (int h = 0; h < H; ++h) {
+    for (uint32_t k = 0; k < launched[h]; ++k) {
+      float ms = 0.0f;
+      VNR_HIP_CHECK(hipEventElapsedTime(&ms, events_[f.slot][h][2 * k], events_[f.slot][h][2 * k + 1]));
+      stats_.infer_kernel_ms += ms;
+      if (k < iter_ms_.size()) iter_ms_[k] += ms;
+      any = true;
+    }
+  }
+  if (!any || launched[0] == 0) return;
+  // the parts' launches overlap: the union of their intervals (all timed against part 0's first event) is the time the
+  // evaluation kernel had the GPU or a share of it
+  std::vector<std::pair<float, float>> iv;
+  for (int h = 0; h < H; ++h)
+    for (uint32_t k = 0; k < launched[h]; ++k) {
+      float t0 = 0.0f, t1 = 0.0f;
+      VNR_HIP_CHECK(hipEventElapsedTime(&t0, events_[f.slot][0][0], events_[f.slot][h][2 * k]));
+      VNR_HIP_CHECK(hipEventElapsedTime(&t1, events_[f.slot][0][0], events_[f.slot][h][2 * k + 1]));
+      iv.emplace_back(t0, t1);
+    }
+  std::sort(iv.begin(), iv.end());
+  float lo = iv[0].first, hi = iv[0].second;
+  double total = 0.0;
+  for (size_t e = 1; e < iv.size(); ++e) {
+    if (iv[e].first > hi) { total += hi - lo; lo = iv[e].first; hi = iv[e].second; }
+    else hi = std::max(hi, iv[e].second);
+  }
+  stats_.infer_union_ms += total + (hi - lo);
+}
+
+// ------------------------------------------------------------------------------------------------ decoupled loop (decoupled.h)
+bool Renderer::decoupled_applies(const RenderParams& p, int pass_mode) const
+{
+  if (pass_mode != M_NONE || decoupled_mode_ == 0) return false;
+  if ((size_t)p.n_local * (size_t)p.n_iters >= (1ull << 28)) return false;   // 32-bit float indices into a ring slot's arena
+  return decoupled_mode_ == 2 || p.n_local <= 262144u;
+}
+
+void Renderer::render_decoupled(const RenderParams& p_all, bool defer)
+{
+  const uint32_t row_items = p_all.tiles_per_row * 64u;
+  const uint32_t R = p_all.n_local / row_items;  // local tile rows
+  const int H = (int)std::min<uint32_t>((uint32_t)decoupled_parts_, std::max(R, 1u));
+  const uint32_t P_total = p_all.n_local;
+  const int A = decoupled_ahead_, RING = A + 1;
+  NeuralVolume* nv = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get()) : nullptr;
+  if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
+  if (!nv && !p_all.volume) throw std::runtime_error("this volume has no resident data to sample");
+
+  // buffers: everything x 2 frame slots (a frame's head runs beside the tail of the frame before it)
+  const size_t Pt = (size_t)P_total + 256u * kMaxParts;   // every part rounded up to whole blocks
+  if (d_rays_ < Pt || d_iters_ < p_all.n_iters || d_ring_ < RING) {
+    finish_pending();
+    VNR_HIP_CHECK(hipDeviceSynchronize());
+    d_rays_ = std::max(d_rays_, Pt); d_iters_ = std::max(d_iters_, p_all.n_iters); d_ring_ = std::max(d_ring_, RING);
+    const size_t words = 15 * d_rays_ + (size_t)d_ring_ * d_rays_ + (size_t)d_ring_ * kMaxParts * D_COUNT;
+    for (int sl = 0; sl < 2; ++sl) {
+      d_words_[sl].resize(words);
+      d_words_[sl].zero(stream_);   // the counters start at zero; compose_kernel leaves them so
+      d_queue_[sl].resize((size_t)d_ring_ * d_rays_ * d_iters_);
+      d_arena_[sl].resize((size_t)d_ring_ * d_rays_ * d_iters_);
+    }
+    VNR_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+  if (!d_host_) {
+    VNR_HIP_CHECK(hipHostMalloc(&d_host_, 2 * kMaxParts * sizeof(DHost), hipHostMallocDefault));
+    std::memset(d_host_, 0, 2 * kMaxParts * sizeof(DHost));
+  }
+  for (int h = 0; h < H; ++h)
+    for (int k = 0; k < 3; ++k)
+      if (!d_streams_[h][k]) VNR_HIP_CHECK(hipStreamCreateWithFlags(&d_streams_[h][k], hipStreamNonBlocking));
+
+  // the slot the previous frame does not occupy if that one is still pending (asynchronous frames), else the same slot again
+  StreamingFrame* older = frame_[slot_] && frame_[slot_]->pending ? frame_[slot_].get() : nullptr;
+  const int slot = older ? slot_ ^ 1 : slot_;
+  if (!frame_[slot]) frame_[slot].reset(new StreamingFrame());
+  StreamingFrame& f = *frame_[slot];
+  if (f.pending) throw std::runtime_error("internal: both frame slots are pending");
+  f.slot = slot;
+  slot_ = slot;
+  f.decoupled = true; f.ahead = A; f.ring = RING;
+  f.H = H; f.pass_mode = M_NONE; f.grad = false; f.ssh = false; f.nv = nv; f.p_all = p_all;
+  f.shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + 16 * sizeof(uint32_t) + (size_t)p_all.n_iters * 256 * sizeof(uint16_t);
+  f.shmem_compose = p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0;
+  if (f.shmem > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
+  f.max_iterations = 240;
+  if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) f.max_iterations = std::max(1, std::min(240, std::atoi(e)));  // diagnostics only
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    lds_attr_set = true;
+  }
+  if (profiling_) {
+    iter_ms_.assign(f.max_iterations, 0.0f);
+    for (int h = 0; h < H; ++h)
+      while (events_[slot][h].size() < 2 * f.max_iterations) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreate(&e)); events_[slot][h].push_back(e); }
+  }
+
+  uint32_t* w = d_words_[slot].ptr;
+  uint32_t* const rec_base = w + 15 * d_rays_;
+  uint32_t* const ctr_base = rec_base + (size_t)d_ring_ * d_rays_;
+  size_t off = 0;
+  for (int h = 0; h < H; ++h) {
+    DPart& d = f.dpart[h];
+    d.p = p_all;
+    if (H > 1) {
+      d.p.il_parts = p_all.il_parts * (uint32_t)H;
+      d.p.il_part = p_all.il_part + p_all.il_parts * (uint32_t)h;
+      d.p.n_local = ((R + (uint32_t)(H - 1 - h)) / (uint32_t)H) * row_items;
+    }
+    d.p.slot_cap = (uint32_t)((size_t)d.p.n_local * d.p.n_iters);   // walk_kernel: capacity of a ring slot's sample queue
+    const size_t Pr = ((size_t)d.p.n_local + 255u) & ~(size_t)255u;
+    uint32_t* b = w + off;
+    const size_t N = d_rays_;
+    d.rays.pixel = b; d.rays.jitter = (float*)(b + N); d.rays.ncb = (float*)(b + 2 * N); d.rays.walking = b + 3 * N;
+    d.rays.alpha = (float*)(b + 4 * N); d.rays.done = b + 5 * N;
+    // the 3-word members: plane bases are carved per part (off is a ray index; 3 words per ray from the plane's start)
+    d.rays.cell = (vec3i*)(w + 6 * N) + off; d.rays.t_next = (vec3f*)(w + 9 * N) + off; d.rays.color = (vec3f*)(w + 12 * N) + off;
+    for (int q = 0; q < RING; ++q) {
+      d.ring[q].queue = d_queue_[slot].ptr + ((size_t)q * d_rays_ + off) * d_iters_;
+      d.ring[q].arena = d_arena_[slot].ptr + ((size_t)q * d_rays_ + off) * d_iters_;
+      d.ring[q].rec = rec_base + (size_t)q * d_rays_ + off;
+      d.ring[q].ctr = ctr_base + ((size_t)q * kMaxParts + h) * D_COUNT;
+    }
+    d.host = (DHost*)d_host_ + (size_t)slot * kMaxParts + h;
+    d.sw = d_streams_[h][0]; d.se = d_streams_[h][1]; d.sc = d_streams_[h][2];
+    d.it_w = d.it_c = 0;
+    d.target = std::max<uint32_t>(decoupled_predicted_[h], 1u);
+    d.s_max = (size_t)d.p.n_local * d.p.n_iters;
+    d.done = false;
+    f.part[h].s = d.sc;   // the stream the part's completion event is recorded on (StreamingFrame::mark)
+    off += Pr;
+  }
+  // fork: the part streams start after everything queued on the render stream so far
+  VNR_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
+  for (int h = 0; h < H; ++h)
+    for (int k = 0; k < 3; ++k) VNR_HIP_CHECK(hipStreamWaitEvent(d_streams_[h][k], ev_fork_, 0));
+
+  // The HEAD of a frame is everything that needs no compose: the walks and evaluations of its first `ahead` batches.  A compose
+  // writes pixels the frame before it may still be accumulating into, so with a frame pending only the head is enqueued before
+  // that frame has been completed (the accumulation stays ordered: composes of one part run on one stream, frame after frame).
+  if (older) {
+    for (bool any = true; any;) {
+      any = false;
+      for (int h = 0; h < H; ++h) { const uint32_t before = f.dpart[h].it_w; decoupled_step(f, h, true); any = any || f.dpart[h].it_w != before; }
+    }
+    finish_streaming(*older);
+    stats_ = FrameStats();
+  }
+  frame_of_buffer_[fb_cur_] = slot;
+  for (bool any = true; any;) {
+    any = false;
+    for (int h = 0; h < H; ++h) {
+      DPart& d = f.dpart[h];
+      const uint32_t bw = d.it_w, bc = d.it_c;
+      decoupled_step(f, h, false);
+      any = any || d.it_w != bw || d.it_c != bc;
+    }
+  }
+  for (int h = 0; h < H; ++h) f.mark(h);
+  f.pending = true;
+  if (!defer) finish_streaming(f);
+}
+
+// the next launch of part h in its canonical order W0 E0 .. W(A-1) E(A-1) | C0 W(A) E(A) C1 W(A+1) E(A+1) ... up to `target` iterations
+void Renderer::decoupled_step(StreamingFrame& f, int h, bool head_only)
+{
+  DPart& d = f.dpart[h];
+  const uint32_t A = (uint32_t)f.ahead, RING = (uint32_t)f.ring;
+  if (d.it_w < d.target && d.it_w < d.it_c + A) {
+    const uint32_t it = d.it_w;
+    const DRing& ring = d.ring[it % RING];
+    // W(it) after C(it - A): the look-ahead bound, and the ring slot W(it) writes was read by E / C(it - A - 1)
+    if (it >= A) VNR_HIP_CHECK(hipStreamWaitEvent(d.sw, d.ev(d.ev_c, it - A), 0));
+    const uint32_t P = d.p.n_local;
+    const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
+    if (it == 0) walk_kernel<true><<<blocks, 256, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
+    else walk_kernel<false><<<blocks, 256, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
+    VNR_HIP_CHECK(hipGetLastError());
+    VNR_HIP_CHECK(hipEventRecord(d.ev(d.ev_w, it), d.sw));
+    VNR_HIP_CHECK(hipStreamWaitEvent(d.se, d.ev(d.ev_w, it), 0));
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], d.se));
+    if (f.nv) {
+      f.nv->network().inference_queue((const float*)ring.queue, (float*)ring.arena, 1, ring.ctr + D_SAMPLES, d.s_max, d.se, (uint32_t)f.H, nullptr);
+    } else {
+      const uint32_t eb = std::min<uint32_t>(div_round_up(d.s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);
+      gt_sample_kernel<<<eb, 256, 0, d.se>>>(ring.ctr + D_SAMPLES, d.p.volume, d.p.vol_dims, ring.queue, (float*)ring.arena);
+      VNR_HIP_CHECK(hipGetLastError());
+    }
+    if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it + 1], d.se));
+    VNR_HIP_CHECK(hipEventRecord(d.ev(d.ev_e, it), d.se));
+    ++d.it_w;
+    return;
+  }
+  if (!head_only && d.it_c < d.it_w) {
+    const uint32_t it = d.it_c;
+    const DRing& ring = d.ring[it % RING];
+    VNR_HIP_CHECK(hipStreamWaitEvent(d.sc, d.ev(d.ev_e, it), 0));
+    const uint32_t blocks = std::min<uint32_t>(div_round_up(d.p.n_local, 256), 2048u);
+    compose_kernel<<<blocks, 256, f.shmem_compose, d.sc>>>(d.p, d.rays, ring, d.host, it);
+    VNR_HIP_CHECK(hipGetLastError());
+    VNR_HIP_CHECK(hipEventRecord(d.ev(d.ev_c, it), d.sc));
+    ++d.it_c;
+  }
+}
+
+void Renderer::finish_decoupled(StreamingFrame& f)
+{
+  if (!f.pending) return;
+  f.pending = false;
+  const int H = f.H;
+  // everything enqueued so far runs to its end; a part whose last walk left rays walking gets one more iteration at a time
+  for (;;) {
+    bool more = false;
+    for (int h = 0; h < H; ++h) {
+      DPart& d = f.dpart[h];
+      if (d.done) continue;
+      for (;;) {   // (a frame whose head only was enqueued: the rest of its predicted iterations)
+        const uint32_t bw = d.it_w, bc = d.it_c;
+        decoupled_step(f, h, false);
+        if (d.it_w == bw && d.it_c == bc) break;
+      }
+    }
+    for (int h = 0; h < H; ++h) {
+      DPart& d = f.dpart[h];
+      if (d.done) continue;
+      if (d.it_c == 0 || d.it_w == 0) throw std::runtime_error("internal: a decoupled frame with nothing enqueued");
+      VNR_HIP_CHECK(hipEventSynchronize(d.ev(d.ev_c, d.it_c - 1)));
+      if (d.host->walking[(d.it_w - 1) & 255u] == 0 || d.it_w >= f.max_iterations) { d.done = true; continue; }
+      ++d.target;
+      more = true;
+    }
+    if (!more) break;
+  }
+  uint32_t pass_iterations = 0, launched[kMaxParts] = {};
+  uint64_t n_samples = 0, n_ref = 0;
+  for (int h = 0; h < H; ++h) {
+    DPart& d = f.dpart[h];
+    f.mark(h);
+    // iterations that had walking rays to begin with = index of the first walk that left none, + 1
+    uint32_t used = 0;
+    while (used < d.it_w && used < 256u) { ++used; if (d.host->walking[(used - 1) & 255u] == 0) break; }
+    decoupled_predicted_[h] = used;
+    uint32_t with_samples = 0;
+    for (uint32_t it = 0; it < used; ++it) {
+      n_samples += d.host->n_smp[it & 255u];
+      n_ref += d.host->n_ref[it & 255u];
+      if (d.host->n_ref[it & 255u]) with_samples = it + 1;
+    }
+    pass_iterations = std::max(pass_iterations, with_samples);
+    stats_.n_rays_hit += d.host->hit;
+    launched[h] = d.it_w;
+    if (profiling_) stats_.infer_kernel_launches += with_samples;
+  }
+  collect_eval_profile(f, launched, nullptr);
+  stats_.n_iterations += pass_iterations;
+  stats_.n_samples += n_samples;
+  stats_.n_reference_slots += n_ref * (uint64_t)f.p_all.n_iters;
+  completed_stats_ = stats_;
+}
 
 const float* Renderer::map_frame()
 {

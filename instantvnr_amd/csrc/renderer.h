@@ -83,6 +83,13 @@ private:
   void launch_iteration(StreamingFrame& f, int part);
   void launch_tail(StreamingFrame& f, int part, uint32_t it);
   void finish_streaming(StreamingFrame& f);
+  // the same loop with the walk decoupled from evaluation and compose (decoupled.h): three kernels per iteration on three streams per
+  // ray part, the walks up to `decoupled_ahead_` batches ahead of the composes.  Frames are bit-identical to render_streaming's.
+  bool decoupled_applies(const RenderParams& p, int pass_mode) const;
+  void render_decoupled(const RenderParams& p, bool defer);
+  void decoupled_step(StreamingFrame& f, int part, bool head_only);
+  void finish_decoupled(StreamingFrame& f);
+  void collect_eval_profile(StreamingFrame& f, const uint32_t* launched, const uint32_t* used);
   void finish_pending();
   void render_monolithic(const RenderParams& p);
   // rendering modes 6 / 9 / 12 on a neural volume: one launch, the network evaluated inside the marching loop (in_shader.h).
@@ -129,6 +136,16 @@ private:
   int small_share_parts_ = 4;  // parts of a share of at most 262 144 pixels (a quarter of a 1024 x 1024 frame): with pipelined frames
                                // 4 short chains side by side beat 2 (1/4 share 1.17 -> 1.13 ms, 1/8 share 0.66 -> 0.65 ms; whole frames: no difference)
   uint32_t predicted_iterations_[2][kMaxParts] = {};   // [camera pass | shadow pass][half]
+  // decoupled path: 0 never, 1 for ray sets of at most 262 144 rays (shares of a frame, small framebuffers), 2 always (VNR_AMD_DECOUPLED);
+  // look-ahead of the walks in batches (VNR_AMD_DECOUPLED_AHEAD: 1 = walk, evaluate, compose in turn; default 2); ray parts (VNR_AMD_DECOUPLED_PARTS)
+  int decoupled_mode_ = 1, decoupled_ahead_ = 2, decoupled_parts_ = 2;
+  uint32_t decoupled_predicted_[kMaxParts] = {};
+  hipStream_t d_streams_[kMaxParts][3] = {};           // walk, evaluate, compose
+  DeviceBuffer<uint32_t> d_words_[2];                  // per frame slot: ray state, batch records, counters
+  DeviceBuffer<vec4f> d_queue_[2];
+  DeviceBuffer<vec2f> d_arena_[2];
+  void* d_host_ = nullptr;                             // pinned DHost[2][kMaxParts]
+  size_t d_rays_ = 0; int d_iters_ = 0, d_ring_ = 0;   // what the buffers are sized for
   hipStream_t stream_ = nullptr, part_streams_[kMaxParts] = {};
   hipEvent_t ev_fork_ = nullptr;
 

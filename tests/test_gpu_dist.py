@@ -152,7 +152,7 @@ def test_shares_of_an_eighth_frame_size_take_the_unpinned_branch_and_equal_the_f
         if saved is not None:
             os.environ["VNR_RM_N_ITERS"] = saved
     for r in res:
-        assert float(r["coverage"]) > 0.2 and int(r["samples"]) > 1_000_000
+        assert float(r["coverage"]) > 0.1 and int(r["samples"]) > 500_000   # (a 1024 x 384 frame of a cube: 16 % of the pixels hit it)
         assert bool(np.all(r["equal_32"])) and bool(r["equal_32_sync"]), (int(r["rank"]), r["equal_32"])
         # the branch was taken: as many iterations as the frame pinned to 32 needs, fewer than at 24; against the frame at 24 only last bits move
         assert int(r["iterations"]) <= int(r["iterations_32"]) < int(r["iterations_24"])

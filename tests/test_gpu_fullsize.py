@@ -170,7 +170,7 @@ def test_a_band_of_the_c4_frame_equals_the_oracle(oracle, c4_scene):
     warm = frame(c4_scene, 5, frames=3)           # 3 frames x 2 ray parts x ~9 launches: the image is built along the way
     st_img = api.neural_brick_image(nv)
     assert st_img["in_use"] and st_img["bytes"] > 7 * 2**30
-    assert (warm[..., 3] > 0).mean() > 0.5
+    assert (warm[..., 3] > 0).mean() > 0.4
     lo, hi = 504 * 1024, 520 * 1024
     r = api.vnrCreateRenderer(nv)
     api.vnrRendererSetTransferFunction(r, c4_scene["tfn"])
@@ -201,7 +201,7 @@ def test_a_band_of_the_c4_frame_equals_the_oracle(oracle, c4_scene):
           f"samples {st['n_samples']} (oracle {ost['n_samples']}), PSNR {psnr:.1f} dB, max |err| {err.max():.4f}")
     assert ost["n_rays_hit"] == st["n_rays_hit"] and ost["n_iterations"] == st["n_iterations"]
     assert abs(ost["n_samples"] - st["n_samples"]) <= 0.002 * ost["n_samples"]
-    assert (ref[:, 3] > 0).mean() > 0.5
+    assert (ref[:, 3] > 0).mean() > 0.4
     assert psnr > 45.0, psnr
     assert err.max() < 0.05
 

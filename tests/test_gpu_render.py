@@ -106,6 +106,81 @@ def test_frames_do_not_depend_on_n_iters_or_tile_shape(scene, monkeypatch):
         assert np.array_equal(f, frames[0])
 
 
+@pytest.fixture(scope="module")
+def small_network(scene):
+    import os
+    os.environ["VNR_AMD_INIT_SEED"] = "515"
+    nv = api.vnrCreateNeuralVolume(syn.model_config(n_levels=6, n_features=2, log2_hashmap_size=14, base_resolution=4, n_hidden_layers=2),
+                                   scene["sv"], online_macrocell_construction=False)
+    api.vnrNeuralVolumeTrain(nv, 60, True)
+    return nv
+
+
+@pytest.mark.parametrize("volume_kind", ["dense", "neural"])
+def test_decoupled_walks_give_the_coupled_loop_s_frames_and_statistics(scene, small_network, monkeypatch, volume_kind):
+    """csrc/decoupled.h: walk / evaluate / compose as three kernels on three streams with the walks up to A batches ahead of the
+    composes, against march_kernel's loop (walk, evaluate, compose in turn): the same frames bit for bit over accumulated frames (the
+    per-ray arithmetic and its order are the same; a saturated ray's batches emitted ahead are evaluated and dropped), the same
+    statistics (samples are counted where a ray was alive when it emitted them), for every look-ahead and number of ray parts, through
+    the synchronous and the pipelined calls, with a transfer function opaque enough that most rays saturate early"""
+    from instantvnr_amd._lib import check, lib
+    import ctypes as C
+    volume = scene["sv"] if volume_kind == "dense" else small_network
+    colors, alphas = syn.tfn_ramp_with_bumps(opacity_scale=3.0)
+    opaque = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(opaque, colors)
+    api.vnrTransferFunctionSetAlpha(opaque, alphas)
+    api.vnrTransferFunctionSetValueRange(opaque, (0, 1))
+    size = (200, 144)
+    n_frames = 3
+
+    def run(tfn, pipelined):
+        r = api.vnrCreateRenderer(volume)
+        api.vnrRendererSetTransferFunction(r, tfn)
+        api.vnrRendererSetCamera(r, scene["camera"])
+        api.vnrRendererSetFramebufferSize(r, size)
+        frames, stats = [], []
+        if not pipelined:
+            for _ in range(n_frames):
+                api.vnrRender(r)
+                frames.append(api.vnrRendererMapFrame(r).copy())
+                stats.append(api.vnrRendererGetFrameStats(r))
+            return frames, stats
+        api.vnrRendererSetOutputAsDeviceFramebuffer(r, True)
+        out = C.c_void_p()
+        n = size[0] * size[1]
+
+        def grab(ptr):
+            a = np.empty((size[1], size[0], 4), np.float32)
+            check(lib().vnrAmdMemcpyD2H(a.ctypes.data_as(C.c_void_p), ptr, a.nbytes))
+            return a
+        for k in range(n_frames):
+            check(lib().vnrAmdRendererRenderPipelined(r.h, C.byref(out)))
+            if k:
+                frames.append(grab(out))
+        check(lib().vnrAmdRendererFlushPipeline(r.h, C.byref(out)))
+        frames.append(grab(out))
+        return frames, [api.vnrRendererGetFrameStats(r)]
+
+    keys = ("n_samples", "n_reference_slots", "n_iterations", "n_rays_hit")
+    for tfn in (scene["tfn"], opaque):
+        monkeypatch.setenv("VNR_AMD_DECOUPLED", "0")
+        want, want_stats = run(tfn, False)
+        assert want_stats[0]["n_iterations"] >= 2 and want_stats[0]["n_samples"] > 10000
+        for ahead, parts in (("1", "1"), ("2", "2"), ("2", "1"), ("3", "4"), ("5", "2")):
+            monkeypatch.setenv("VNR_AMD_DECOUPLED", "2")
+            monkeypatch.setenv("VNR_AMD_DECOUPLED_AHEAD", ahead)
+            monkeypatch.setenv("VNR_AMD_DECOUPLED_PARTS", parts)
+            got, got_stats = run(tfn, False)
+            for k in range(n_frames):
+                assert np.array_equal(got[k], want[k]), (volume_kind, ahead, parts, k, float(np.abs(got[k] - want[k]).max()))
+                assert {q: got_stats[k][q] for q in keys} == {q: want_stats[k][q] for q in keys}, (ahead, parts, k)
+            piped, piped_stats = run(tfn, True)
+            for k in range(n_frames):
+                assert np.array_equal(piped[k], want[k]), (volume_kind, ahead, parts, k, "pipelined")
+            assert {q: piped_stats[0][q] for q in keys} == {q: want_stats[-1][q] for q in keys}
+
+
 def test_accumulation_over_frames(oracle, scene):
     r = make_renderer(scene, scene["sv"])
     mo = api.volume_macrocell(scene["sv"])["max_opacity"]

@@ -19,38 +19,56 @@ import os
 base = 0.0
 colors, alphas = syn.tfn_ramp_with_bumps(opacity_scale=0.06)
 import os
-for parts in [int(v) for v in os.environ.get("SHARE_PARTS", "1,2,4,8").split(",")]:
-    ren = api.vnrCreateRenderer(nv)
-    api.vnrRendererSetFramebufferSize(ren, (fb, fb))
-    api.vnrRendererSetMode(ren, int(os.environ.get("SHARE_MODE", 5)))   # 6 / 9 / 12: the in-shader kernel (VNR_AMD_IN_SHADER=0: streaming)
-    api.vnrRendererSetOutputAsDeviceFramebuffer(ren, True)
-    if os.environ.get("SHARE_PROFILING"):   # the HIP events bench.py records around every evaluation launch
-        api.vnrRendererSetProfiling(ren, True)
-    camera = api.vnrCreateCamera(); api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
-    api.vnrRendererSetCamera(ren, camera)
-    tfn = api.vnrCreateTransferFunction(); api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas)
-    api.vnrTransferFunctionSetValueRange(tfn, (0, 1)); api.vnrRendererSetTransferFunction(ren, tfn)
-    if parts > 1:
-        api.vnrRendererSetPixelInterleave(ren, 8 * fb, parts, 0)
-    for _ in range(6):
-        api.vnrRender(ren); api.vnrRendererMapFrame(ren)
-    check(L.vnrAmdSynchronize())
-    t0 = time.perf_counter()
-    n = 40
-    import ctypes as C
-    if os.environ.get("SHARE_PIPELINED"):   # the pipelined calls (head of frame k + 1 before frame k has completed on the host)
-        out = C.c_void_p()
-        for _ in range(n):
-            check(L.vnrAmdRendererRenderPipelined(ren.h, C.byref(out)))
-        check(L.vnrAmdRendererFlushPipeline(ren.h, C.byref(out)))
-    else:
-        for _ in range(n):
+# SHARE_CONFIGS="name:VAR=v,VAR=v;name2:..." renders every share once per configuration (the variables are read when a renderer is
+# created), in one process on one trained model: an A/B of renderer settings without the set-up in between
+configs = [("", {})]
+if os.environ.get("SHARE_CONFIGS"):
+    configs = []
+    for item in os.environ["SHARE_CONFIGS"].split(";"):
+        name, _, kv = item.partition(":")
+        configs.append((name, dict(x.split("=") for x in kv.split(",") if x)))
+reps = int(os.environ.get("SHARE_REPS", "1"))
+for rep in range(reps):
+  for cname, cenv in configs:
+    saved = {k: os.environ.get(k) for k in cenv}
+    os.environ.update(cenv)
+    for parts in [int(v) for v in os.environ.get("SHARE_PARTS", "1,2,4,8").split(",")]:
+        ren = api.vnrCreateRenderer(nv)
+        api.vnrRendererSetFramebufferSize(ren, (fb, fb))
+        api.vnrRendererSetMode(ren, int(os.environ.get("SHARE_MODE", 5)))   # 6 / 9 / 12: the in-shader kernel (VNR_AMD_IN_SHADER=0: streaming)
+        api.vnrRendererSetOutputAsDeviceFramebuffer(ren, True)
+        if os.environ.get("SHARE_PROFILING"):   # the HIP events bench.py records around every evaluation launch
+            api.vnrRendererSetProfiling(ren, True)
+        camera = api.vnrCreateCamera(); api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+        api.vnrRendererSetCamera(ren, camera)
+        tfn = api.vnrCreateTransferFunction(); api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas)
+        api.vnrTransferFunctionSetValueRange(tfn, (0, 1)); api.vnrRendererSetTransferFunction(ren, tfn)
+        if parts > 1:
+            api.vnrRendererSetPixelInterleave(ren, 8 * fb, parts, 0)
+        for _ in range(6):
             api.vnrRender(ren); api.vnrRendererMapFrame(ren)
-    check(L.vnrAmdSynchronize())
-    dt = (time.perf_counter() - t0) / n
-    st = api.vnrRendererGetFrameStats(ren)
-    print(f"share 1/{parts}: {dt * 1e3:.3f} ms per frame, {st['n_samples'] / 1e6:.2f} M samples, {st['n_iterations']} iterations "
-          f"-> speed-up {base / dt if parts > 1 and base else 0:.2f}x of {parts}", flush=True)
-    if parts == 1:
-        base = dt
-    del ren
+        check(L.vnrAmdSynchronize())
+        t0 = time.perf_counter()
+        n = int(os.environ.get("SHARE_FRAMES", "40"))
+        import ctypes as C
+        if os.environ.get("SHARE_PIPELINED"):   # the pipelined calls (head of frame k + 1 before frame k has completed on the host)
+            out = C.c_void_p()
+            for _ in range(n):
+                check(L.vnrAmdRendererRenderPipelined(ren.h, C.byref(out)))
+            check(L.vnrAmdRendererFlushPipeline(ren.h, C.byref(out)))
+        else:
+            for _ in range(n):
+                api.vnrRender(ren); api.vnrRendererMapFrame(ren)
+        check(L.vnrAmdSynchronize())
+        dt = (time.perf_counter() - t0) / n
+        st = api.vnrRendererGetFrameStats(ren)
+        print(f"{cname + ' ' if cname else ''}share 1/{parts}: {dt * 1e3:.3f} ms per frame, {st['n_samples'] / 1e6:.2f} M samples, {st['n_iterations']} iterations "
+              f"-> speed-up {base / dt if parts > 1 and base else 0:.2f}x of {parts}", flush=True)
+        if parts == 1 and not base:
+            base = dt
+        del ren
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v

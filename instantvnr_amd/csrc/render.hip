@@ -2171,9 +2171,15 @@ void Renderer::render_decoupled(const RenderParams& p_all, bool defer)
     VNR_HIP_CHECK(hipHostMalloc(&d_host_, 2 * kMaxParts * sizeof(DHost), hipHostMallocDefault));
     std::memset(d_host_, 0, 2 * kMaxParts * sizeof(DHost));
   }
+  // The walks are the frame's critical path (a chain of launches whose duration is the latency of one wave) and the evaluation kernel
+  // fills every wave slot it is given: the walk and compose streams are created with the highest priority, the evaluation streams with
+  // the lowest, so that a slot an evaluation block leaves goes to a waiting walk block first (VNR_AMD_DECOUPLED_PRIO=0: all equal)
+  static const bool prio = [] { const char* e = std::getenv("VNR_AMD_DECOUPLED_PRIO"); return !e || std::atoi(e) != 0; }();
+  int prio_least = 0, prio_greatest = 0;
+  if (prio) VNR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   for (int h = 0; h < H; ++h)
     for (int k = 0; k < 3; ++k)
-      if (!d_streams_[h][k]) VNR_HIP_CHECK(hipStreamCreateWithFlags(&d_streams_[h][k], hipStreamNonBlocking));
+      if (!d_streams_[h][k]) VNR_HIP_CHECK(hipStreamCreateWithPriority(&d_streams_[h][k], hipStreamNonBlocking, k == 1 ? prio_least : prio_greatest));
 
   // the slot the previous frame does not occupy if that one is still pending (asynchronous frames), else the same slot again
   StreamingFrame* older = frame_[slot_] && frame_[slot_]->pending ? frame_[slot_].get() : nullptr;
@@ -2286,7 +2292,9 @@ void Renderer::decoupled_step(StreamingFrame& f, int h, bool head_only)
     VNR_HIP_CHECK(hipEventRecord(d.ev(d.ev_w, it), d.sw));
     VNR_HIP_CHECK(hipStreamWaitEvent(d.se, d.ev(d.ev_w, it), 0));
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], d.se));
-    if (f.nv) {
+    static const bool skip_eval = [] { const char* e = std::getenv("VNR_AMD_DEBUG_SKIP_EVAL"); return e && std::atoi(e) != 0; }();   // timing of the walk / compose kernels alone (frames are garbage)
+    if (skip_eval) {
+    } else if (f.nv) {
       f.nv->network().inference_queue((const float*)ring.queue, (float*)ring.arena, 1, ring.ctr + D_SAMPLES, d.s_max, d.se, (uint32_t)f.H, nullptr);
     } else {
       const uint32_t eb = std::min<uint32_t>(div_round_up(d.s_max, 256), (uint32_t)Runtime::get().n_cus * 8u);

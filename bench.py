@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--no-psnr", action="store_true")
     p.add_argument("--no-alone", action="store_true", help="skip the un-timed one-stream leg (roofline.alone)")
     p.add_argument("--no-brick-off", action="store_true", help="skip the un-timed leg without the brick image (train-while-render configuration)")
+    p.add_argument("--no-brick-table", action="store_true", help="skip the un-timed legs at smaller budgets of the brick image (inference_cache.budget_table)")
     p.add_argument("--no-kernel-events", action="store_true", help="diagnostics: no HIP events around the evaluation kernel (roofline.achieved reads 0)")
     p.add_argument("--mode", type=int, default=5, choices=(5, 6, 8, 9, 11, 12, 14, 15),
                    help="rendering mode: 5 = sample streaming (BASELINE metric, default), 8 = the same with gradient shading (4 evaluations per sample)")
@@ -315,6 +316,26 @@ def main():
                      "alone_samples": c_samples, "alone_ms": c_ms, "alone_launches": c_launches}
         check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
 
+    # (3) what a budget for the image buys: the hashed levels are taken finest first while they fit, so a budget is a number of levels.
+    # One un-timed leg per budget, each a fresh renderer on the same model: frames/s (two streams) and the evaluation kernel's union fraction.
+    budget_table = None
+    if ctx.world == 1 and not a.no_brick_table and not a.no_brick_off and brick_state["in_use"] and a.mode == 5:
+        budget_table = []
+        full = int(brick_state["bytes"])
+        for gb in (0.25, 0.75, 1.7, 3.8):
+            if gb * 2**30 >= full:
+                continue
+            api.neural_set_brick_budget(nv, int(gb * 2**30))
+            check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, 1))     # build at the next launch
+            rr = make_renderer(nv)
+            fps_b, s_b, ms_b, l_b, u_b = untimed_frames(rr, max(5, n_leg // 2))
+            del rr
+            stb = api.neural_brick_image(nv)
+            budget_table.append({"budget_gib": gb, "image_bytes": int(stb["bytes"]), "levels_in_image": [l for l in range(32) if stb["levels"] >> l & 1],
+                                 "fps": round(fps_b, 2), "samples": s_b, "union_ms": u_b})
+        api.neural_set_brick_budget(nv, 0)
+        check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
+
     if ctx.distributed:
         elapsed = dist.all_reduce_host([elapsed], dist.MAX)[0]          # MAX over ranks of the timed region
         samples_all, slots_all, rays_f = dist.all_reduce_host([float(samples), float(slots), float(rays_hit)], dist.SUM)
@@ -433,6 +454,16 @@ def main():
                       "note": "the optimizer sweep dominates the algorithmic bytes; the implementation skips untouched grid entries (about 10 % are touched "
                               "per step), so `frac` measures the step against a dense sweep it does not perform"}
 
+    budget_rows = None
+    if budget_table is not None:
+        budget_rows = [{"budget_gib": 0, "image_bytes": 0, "levels_in_image": [], "fps": roofline.get("brick_off", {}).get("fps"),
+                        "kernel_union_frac": roofline.get("brick_off", {}).get("kernel_union_frac")}]
+        for row in budget_table:
+            ev = row["samples"] * evals_per_sample
+            budget_rows.append({"budget_gib": row["budget_gib"], "image_bytes": row["image_bytes"], "levels_in_image": row["levels_in_image"], "fps": row["fps"],
+                                "kernel_union_frac": round(ev * bytes_per_sample / (row["union_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if row["union_ms"] > 0 else None})
+        budget_rows.append({"budget_gib": "default", "image_bytes": int(brick_state["bytes"]), "levels_in_image": [l for l in range(32) if brick_state.get("levels", 0) >> l & 1],
+                            "fps": round(fps, 2), "kernel_union_frac": roofline.get("union", {}).get("frac")})
     out = {
         "metric": "fps at 1024^2 on 1024^3 volume" if (a.size, a.fb, a.mode) == (1024, 1024, 5) else f"fps at {a.fb}^2 on {a.size}^3 volume, rendering mode {a.mode}" if a.mode != 5 else f"fps at {a.fb}^2 on {a.size}^3 volume",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,
@@ -449,7 +480,11 @@ def main():
         "inference_cache": {"what": "brick image: de-hashed copy of the hashed levels, built once the parameters have been left unchanged for 24 launches, "
                                     "dropped by every optimizer step; results are bit-identical with and without it",
                             "in_use": bool(brick_state["in_use"]), "brick_image_bytes": int(brick_state["bytes"]), "model_bytes": int(info["n_params"]) * 2,
-                            "ratio": round(brick_state["bytes"] / (info["n_params"] * 2.0), 1), "build_ms": round(brick_state["build_ms"], 2)},
+                            "ratio": round(brick_state["bytes"] / (info["n_params"] * 2.0), 1), "build_ms": round(brick_state["build_ms"], 2),
+                            "levels_in_image": [l for l in range(32) if brick_state.get("levels", 0) >> l & 1],
+                            "policy": "budget = 1/16 of the device's memory (18 GB on MI355X), at most a quarter of the free memory; VNR_AMD_BRICK_MAX_GB / "
+                                      "vnrAmdNeuralVolumeSetBrickImageBudget set it; levels are taken finest first",
+                            "budget_table": budget_rows},
         "mlp_msamples_per_s": round(samples_all / elapsed / 1e6, 1),
         "mlp_msamples_per_s_kernel_only": round(samples_evt / (infer_ms * 1e-3) / 1e6, 1) if infer_ms > 0 else None,
         "samples_per_frame": int(samples_all / a.steps), "samples_per_hit_ray": round(samples_all / a.steps / max(rays_hit, 1), 1),

@@ -193,11 +193,18 @@ int    vnrAmdNeuralVolumeInference(vnrAmdVolume, size_t n, const float* d_coords
 int    vnrAmdNeuralVolumeEncode(vnrAmdVolume, size_t n, const float* d_coords, uint16_t* d_features, void* stream);
 /* AMD extension: state of the brick image, the de-hashed inference copy of the hashed levels (csrc/network.h).  It is built
  * once the parameters have been left unchanged for VNR_AMD_BRICK_AFTER (24) inference launches and dropped when they change;
- * VNR_AMD_BRICK=0 disables it, =1 builds it at the first launch; VNR_AMD_BRICK_MAX_GB (32) bounds it.  Results do not depend on it. */
+ * VNR_AMD_BRICK=0 disables it, =1 builds it at the first launch; its size is bounded (SetBrickImageBudget below).  Results do not depend on it. */
 int    vnrAmdNeuralVolumeBrickImageInfo(vnrAmdVolume, int* in_use, size_t* bytes, float* build_ms);
 /* AMD extension: -1 = the environment's policy, 0 = never use the image (frees it: the train-while-render configuration),
  * 1 = build it at the next launch */
 int    vnrAmdNeuralVolumeSetBrickImageMode(vnrAmdVolume, int mode);
+/* AMD extension: the image's budget in bytes.  0 = the default policy: 1/16 of the device's memory (18 GB on an MI355X; the image of the
+ * BASELINE C4 model is 8.8 GB for a 140 MB model, 2 x the fp32 volume it represents) and never more than a quarter of the memory
+ * that is free when the image is built; VNR_AMD_BRICK_MAX_GB overrides the policy for the process.  Hashed levels are taken finest
+ * first while they fit (what each step buys on the bench frame: profiles/r03_brick_budget_table.json); a new budget drops the
+ * image, the next launches rebuild it.  BrickImageLevels: bit l set = level l is read from the image. */
+int      vnrAmdNeuralVolumeSetBrickImageBudget(vnrAmdVolume, size_t bytes);
+unsigned vnrAmdNeuralVolumeBrickImageLevels(vnrAmdVolume);
 /* AMD extension (measurement): HIP events around the kernels of the training step; GetTrainProfile averages the last <= 64 steps:
  * ms_per_step = {forward, loss + MLP backward, weight gradients, grid backward (+ the exchange's pack kernels), optimizer} */
 int    vnrAmdNeuralVolumeSetTrainProfiling(vnrAmdVolume, int enable);

@@ -194,6 +194,8 @@ def lib():
     sig("vnrAmdNeuralVolumeTrainDataParallel", I, P, I, I)
     sig("vnrAmdNeuralVolumeSyncReplicas", I, P)
     sig("vnrAmdNeuralVolumeSetBrickImageMode", I, P, I)
+    sig("vnrAmdNeuralVolumeSetBrickImageBudget", I, P, SZ)
+    sig("vnrAmdNeuralVolumeBrickImageLevels", C.c_uint, P)
     sig("vnrAmdNeuralVolumeSetTrainProfiling", I, P, I)
     sig("vnrAmdNeuralVolumeGetTrainProfile", I, P, C.POINTER(D), IP)
     sig("vnrAmdNeuralVolumeAllReduceGradients", I, P)

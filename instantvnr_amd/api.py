@@ -552,7 +552,12 @@ def neural_brick_image(v):
     """state of the de-hashed inference copy of the hashed levels (csrc/network.h)"""
     u, b, ms = C.c_int(), C.c_size_t(), C.c_float()
     check(lib().vnrAmdNeuralVolumeBrickImageInfo(v.h, C.byref(u), C.byref(b), C.byref(ms)))
-    return {"in_use": bool(u.value), "bytes": b.value, "build_ms": ms.value}
+    return {"in_use": bool(u.value), "bytes": b.value, "build_ms": ms.value, "levels": int(lib().vnrAmdNeuralVolumeBrickImageLevels(v.h))}
+
+
+def neural_set_brick_budget(v, n_bytes):
+    """budget of the de-hashed inference copy in bytes (0: the default policy); the next launches rebuild it"""
+    check(lib().vnrAmdNeuralVolumeSetBrickImageBudget(v.h, int(n_bytes)))
 
 
 def neural_info(v):

@@ -816,6 +816,13 @@ int vnrAmdNeuralVolumeTrainDataParallel(vnrAmdVolume v, int steps, int fast_mode
   return guarded([&]() { as_neural(v)->train_data_parallel((size_t)std::max(steps, 0), fast_mode != 0); });
 }
 int vnrAmdNeuralVolumeSetBrickImageMode(vnrAmdVolume v, int mode) { return guarded([&]() { as_neural(v)->network().set_brick_mode(mode); }); }
+int vnrAmdNeuralVolumeSetBrickImageBudget(vnrAmdVolume v, size_t bytes) { return guarded([&]() { as_neural(v)->network().set_brick_budget(bytes); }); }
+unsigned vnrAmdNeuralVolumeBrickImageLevels(vnrAmdVolume v)
+{
+  unsigned m = 0;
+  guarded([&]() { m = as_neural(v)->network().brick_levels_mask(); });
+  return m;
+}
 int vnrAmdNeuralVolumeSetTrainProfiling(vnrAmdVolume v, int e) { return guarded([&]() { as_neural(v)->network().set_train_profiling(e != 0); }); }
 int vnrAmdNeuralVolumeGetTrainProfile(vnrAmdVolume v, double ms_per_step[5], int* n_steps)
 {

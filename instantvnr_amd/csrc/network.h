@@ -192,6 +192,10 @@ public:
   void set_brick_resolution_cap(uint32_t cap) { brick_res_cap_ = cap; }
   // -1: the environment's policy (VNR_AMD_BRICK, default automatic), 0: never (drops an existing image), 1: build at the next launch
   void set_brick_mode(int mode);
+  // budget of the image in bytes (0: the default policy, network_host.hip build_brick_image); drops an existing image, which is rebuilt
+  // within the new budget by the next launches.  Levels are taken finest first while they fit.
+  void set_brick_budget(size_t bytes);
+  uint32_t brick_levels_mask() const { return brick_levels_mask_; }   // bit l: level l is read from the image
   bool brick_image_in_use() const { return brick_valid_; }
   size_t brick_image_bytes() const { return brick_image_.bytes(); }
   float brick_build_ms() const { return brick_build_ms_; }
@@ -233,6 +237,8 @@ private:
   mutable uint32_t brick_stable_calls_ = 0;
   mutable float brick_build_ms_ = 0.0f;
   uint32_t brick_res_cap_ = 0;   // 0: no cap
+  size_t brick_budget_ = 0;      // 0: default policy
+  mutable uint32_t brick_levels_mask_ = 0;
   int brick_mode_ = -1;
 
 public:

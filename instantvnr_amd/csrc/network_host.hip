@@ -24,7 +24,7 @@ void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t 
                         uint32_t n_hidden_matmuls, uint32_t width, uint64_t seed, hipStream_t s);
 void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, uint32_t n_active_levels, uint32_t in_width, const LevelInfo* d_levels,
                     const uint16_t* params, size_t n_mlp, const float* coords, float* out, uint16_t* features_out, size_t n, const uint32_t* d_n,
-                    size_t n_max, hipStream_t s, const uint32_t* d_dest, uint32_t queue_out_stride);
+                    size_t n_max, hipStream_t s, const uint32_t* d_dest, uint32_t queue_out_stride, uint16_t* acts_out = nullptr);
 // master weights <- fp16 parameters; reset_optimizer also zeroes the moments and step counts
 void launch_master_from_f16(const uint16_t* params, OptState* state, size_t n, bool reset_optimizer, hipStream_t s);
 
@@ -251,6 +251,20 @@ void Network::set_brick_mode(int mode)
   brick_stable_calls_ = 0;
 }
 
+void Network::set_brick_budget(size_t bytes)
+{
+  brick_budget_ = bytes;
+  brick_refused_ = false;
+  if (brick_valid_) {
+    if (Runtime::get().ready()) (void)hipDeviceSynchronize();
+    brick_image_.release();
+    levels_brick_dev_.release();
+    brick_valid_ = false;
+  }
+  brick_levels_mask_ = 0;
+  brick_stable_calls_ = 0;
+}
+
 void Network::set_train_profiling(bool e)
 {
   train_profiling_ = e;
@@ -349,10 +363,17 @@ void Network::build_brick_image(hipStream_t s) const
 {
   // which levels: the hashed ones (VNR_AMD_BRICK_DENSE=1: every level), finest first, while the image stays within the budget
   static const bool dense_too = [] { const char* e = std::getenv("VNR_AMD_BRICK_DENSE"); return e && std::atoi(e) != 0; }();
-  static const double max_gb = [] { const char* e = std::getenv("VNR_AMD_BRICK_MAX_GB"); return e ? std::atof(e) : 32.0; }();
+  // Budget.  The image is a cache in memory nothing else of the process uses: a renderer that holds a 1024^3 fp32 volume (4.3 GB), its
+  // 140 MB model and its frame buffers occupies 2 % of the 288 GB of an MI355X.  Default: 1/16 of the device's memory (18 GB), and never
+  // more than a quarter of what is free when the image is built; VNR_AMD_BRICK_MAX_GB or vnrAmdNeuralVolumeSetBrickImageBudget set it.
+  // What a budget buys on the bench model (profiles/r03_brick_budget_table.json): the levels are taken finest first, because the
+  // finest hashed levels are the ones whose 8 corners land in 8 unrelated lines of the table.
+  static const double max_gb = [] { const char* e = std::getenv("VNR_AMD_BRICK_MAX_GB"); return e ? std::atof(e) : -1.0; }();
   size_t free_b = 0, total_b = 0;
   VNR_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-  const uint64_t budget_lines = (uint64_t)std::min(max_gb * 1073741824.0, (double)(free_b + brick_image_.bytes()) / 4.0) / 128u;
+  const double policy = brick_budget_ ? (double)brick_budget_ : max_gb >= 0.0 ? max_gb * 1073741824.0 : (double)total_b / 16.0;
+  const uint64_t budget_lines = (uint64_t)std::min(policy, (double)(free_b + brick_image_.bytes()) / 4.0) / 128u;
+  brick_levels_mask_ = 0;
   hipEvent_t t0, t1;
   VNR_HIP_CHECK(hipEventCreate(&t0)); VNR_HIP_CHECK(hipEventCreate(&t1));
   const uint32_t F = cfg_.n_features;
@@ -375,6 +396,7 @@ void Network::build_brick_image(hipStream_t s) const
     lv[l].brick = (uint32_t)used + 1u;
     lines[l] = n;
     used += n;
+    brick_levels_mask_ |= 1u << l;
   }
   if (used == 0) { brick_refused_ = true; (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); return; }
   brick_image_.resize((used + 1) * 128u);   // + one spare line: a pair load at the last entry reads 2 entries

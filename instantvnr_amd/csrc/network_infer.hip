@@ -246,6 +246,7 @@ struct GenericArgs {
   const float* coords;
   float* out;
   half_t* features_out;
+  half_t* acts_out;         // training: [(nh + 1)][n][width] post-activation outputs of the hidden layers (may be null)
   const uint32_t* n_ptr;
   const uint32_t* dest;
   uint32_t queue_mode, out_stride, n, encode_only;
@@ -305,6 +306,7 @@ __global__ void __launch_bounds__(128) generic_infer_kernel(const GenericArgs a)
       half_t v = (half_t)s;
       if (a.activation == 1u && (__builtin_bit_cast(unsigned short, v) & 0x8000u)) v = (half_t)0.0f;   // ReLU on the fp16 value
       h0[o] = v;
+      if (a.acts_out) a.acts_out[(size_t)i * W + o] = v;
     }
     w += (size_t)W * a.in_width;
     half_t* cur = h0; half_t* nxt = h1;
@@ -315,6 +317,7 @@ __global__ void __launch_bounds__(128) generic_infer_kernel(const GenericArgs a)
         half_t v = (half_t)s;
         if (a.activation == 1u && (__builtin_bit_cast(unsigned short, v) & 0x8000u)) v = (half_t)0.0f;
         nxt[o] = v;
+        if (a.acts_out) a.acts_out[((size_t)(layer + 1) * n + i) * W + o] = v;
       }
       w += (size_t)W * W;
       half_t* t = cur; cur = nxt; nxt = t;
@@ -327,7 +330,7 @@ __global__ void __launch_bounds__(128) generic_infer_kernel(const GenericArgs a)
 
 void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, uint32_t n_active_levels, uint32_t in_width, const LevelInfo* d_levels,
                     const uint16_t* params, size_t n_mlp, const float* coords, float* out, uint16_t* features_out, size_t n, const uint32_t* d_n,
-                    size_t n_max, hipStream_t s, const uint32_t* d_dest, uint32_t queue_out_stride)
+                    size_t n_max, hipStream_t s, const uint32_t* d_dest, uint32_t queue_out_stride, uint16_t* acts_out)
 {
   if (n_max == 0) return;
   if (n_max > 0xffffffc0ull) throw std::runtime_error("inference batch too large (max 2^32-64 samples per call)");
@@ -337,7 +340,7 @@ void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, ui
   a.interpolation = cfg.interpolation; a.quantize_threshold = cfg.quantize_threshold;
   a.params = (const half_t*)params; a.n_mlp = n_mlp; a.in_width = in_width; a.width = cfg.n_neurons;
   a.n_hidden_matmuls = cfg.n_hidden_layers - 1; a.activation = cfg.activation;
-  a.coords = coords; a.out = out; a.features_out = (half_t*)features_out; a.n_ptr = d_n; a.dest = d_dest;
+  a.coords = coords; a.out = out; a.features_out = (half_t*)features_out; a.acts_out = (half_t*)acts_out; a.n_ptr = d_n; a.dest = d_dest;
   a.queue_mode = queue_out_stride ? 1u : 0u; a.out_stride = queue_out_stride; a.n = d_n ? (uint32_t)n_max : (uint32_t)n; a.encode_only = mode == 1 ? 1u : 0u;
   const uint32_t blocks = std::min<uint32_t>(div_round_up(n_max, 128), (uint32_t)Runtime::get().n_cus * 16u);
   generic_infer_kernel<<<blocks, 128, 0, s>>>(a);

@@ -18,6 +18,10 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t 
                   const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr,
                   uint32_t sharers = 1, const struct PackArgs* pack = nullptr);
 
+void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, uint32_t n_active_levels, uint32_t in_width, const LevelInfo* d_levels,
+                    const uint16_t* params, size_t n_mlp, const float* coords, float* out, uint16_t* features_out, size_t n, const uint32_t* d_n,
+                    size_t n_max, hipStream_t s, const uint32_t* d_dest, uint32_t queue_out_stride, uint16_t* acts_out);
+
 // ------------------------------------------------------------------------------------------------ pcg32
 struct Pcg32 {
   uint64_t state, inc;
@@ -488,6 +492,92 @@ __global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const float* __
   if (g == 0 && p < n_mlp) grads[p] = (half_t)((float)grads[p] + ((part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx])));
 }
 
+// ------------------------------------------------------------------------------------------------ generic MLP backward / weight gradients
+// Every model shape the reference trains that the MFMA kernels do not cover (FullyFusedMLP n_neurons 16 / 32 / 128, tcnn_impl.cu:315-347;
+// the 64-neuron models with Nearest interpolation, quantize_threshold or max_level take this path too, so that one code path holds the
+// encoding's special cases): the same arithmetic as mlp_backward_kernel / weight_grad_mfma_kernel (fp16 activation gradients, ReLU mask
+// from the stored activations, fp32 sums over the batch rounded once to the fp16 gradient), one lane per sample and plain loops, weights
+// from L1 / L2.  Correct, not fast (DESIGN.md 4.3 has the rates); nothing in the BASELINE configurations uses these shapes.
+struct GenericBackwardArgs {
+  const half_t* params;   // tcnn-order blob (MLP weights first)
+  const half_t* dy;       // [n]
+  const half_t* acts;     // [(nh + 1)][n][W]
+  half_t* d_out;          // [(nh + 1)][n][W]
+  half_t* dfeat;          // [n][in_width]
+  uint32_t n, nh, activation, in_width, width;
+};
+
+__global__ void __launch_bounds__(128) generic_backward_kernel(const GenericBackwardArgs a)
+{
+  const uint32_t W = a.width, n = a.n, nh = a.nh;
+  const bool relu = a.activation == 1u;
+  const half_t* w1 = a.params;
+  const half_t* wh = a.params + (size_t)W * a.in_width;
+  const half_t* wl = wh + (size_t)nh * W * W;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    half_t d0[128], d1[128];
+    half_t* cur = d0; half_t* nxt = d1;
+    const float g = (float)a.dy[i];
+    {  // through the last layer: d_nh[k] = Wl[0][k] * dy, masked by relu'(a_nh)
+      const half_t* arow = a.acts + ((size_t)nh * n + i) * W;
+      for (uint32_t k = 0; k < W; ++k) {
+        half_t d = (half_t)((float)wl[k] * g);
+        if (relu && !((float)arow[k] > 0.0f)) d = (half_t)0.0f;
+        cur[k] = d;
+        a.d_out[((size_t)nh * n + i) * W + k] = d;
+      }
+    }
+    for (int layer = (int)nh - 1; layer >= 0; --layer) {   // d_l = Wh_l^T d_{l+1}, masked
+      const half_t* w = wh + (size_t)layer * W * W;
+      const half_t* arow = a.acts + ((size_t)layer * n + i) * W;
+      for (uint32_t k = 0; k < W; ++k) {
+        float sum = 0.0f;
+        for (uint32_t o = 0; o < W; ++o) sum = __builtin_fmaf((float)w[(size_t)o * W + k], (float)cur[o], sum);
+        half_t d = (half_t)sum;
+        if (relu && !((float)arow[k] > 0.0f)) d = (half_t)0.0f;
+        nxt[k] = d;
+        a.d_out[((size_t)layer * n + i) * W + k] = d;
+      }
+      half_t* t = cur; cur = nxt; nxt = t;
+    }
+    for (uint32_t k = 0; k < a.in_width; ++k) {   // dL/dfeatures = W1^T d_0
+      float sum = 0.0f;
+      for (uint32_t o = 0; o < W; ++o) sum = __builtin_fmaf((float)w1[(size_t)o * a.in_width + k], (float)cur[o], sum);
+      a.dfeat[(size_t)i * a.in_width + k] = (half_t)sum;
+    }
+  }
+}
+
+// dW[out][in] = sum_b d[b][out] * x[b][in] over one chunk of the batch (blockIdx.y), one thread per element (threads of a wave: the same
+// `out`, neighbouring `in`: d is a broadcast, x a coalesced row); partial sums go to the chunk's row of the slab weight_grad_reduce_kernel sums
+struct GenericWGradArgs {
+  const half_t* features; const half_t* acts; const half_t* d_all; const half_t* dy;
+  float* slab;
+  uint32_t n, nh, in_width, width, n_mlp, chunk;
+};
+
+__global__ void __launch_bounds__(256) generic_wgrad_kernel(const GenericWGradArgs a)
+{
+  const uint32_t W = a.width, n = a.n, nh = a.nh;
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;   // element of the MLP's part of the blob, tcnn order
+  const uint32_t first = W * a.in_width, hidden = nh * W * W;
+  if (e >= first + hidden + W) return;   // rows 1 .. 15 of the padded last layer never receive a gradient
+  const uint32_t b0 = blockIdx.y * a.chunk, b1 = min(n, b0 + a.chunk);
+  const half_t* dsrc; const half_t* xsrc;
+  uint32_t o, k, xw;
+  if (e < first) { o = e / a.in_width; k = e % a.in_width; dsrc = a.d_all; xsrc = a.features; xw = a.in_width; }
+  else if (e < first + hidden) {
+    const uint32_t q = e - first, layer = q / (W * W), r = q % (W * W);
+    o = r / W; k = r % W; dsrc = a.d_all + (size_t)(layer + 1) * n * W; xsrc = a.acts + (size_t)layer * n * W; xw = W;
+  } else { o = 0; k = e - first - hidden; dsrc = nullptr; xsrc = a.acts + (size_t)nh * n * W; xw = W; }
+  float acc = 0.0f;
+  for (uint32_t b = b0; b < b1; ++b) {
+    const float d = dsrc ? (float)dsrc[(size_t)b * W + o] : (float)a.dy[b];
+    acc = __builtin_fmaf(d, (float)xsrc[(size_t)b * xw + k], acc);
+  }
+  a.slab[(size_t)blockIdx.y * a.n_mlp + e] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------ grid backward
 // EXTERNAL tcnn kernel_grid_backward: for every (sample, level): grad[idx*F+f] += w * dL/dfeature[f], accumulated in HALF precision
 // with packed atomics as tcnn does for F > 1 (grad_t = __half, atomicAdd(__half2)); F = 1 (tcnn: float atomics) uses the same packed
@@ -517,13 +607,16 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
     g0 = (float)dfeat[(size_t)i * in_width + level];
   }
   if (g0 == 0.0f && g1 == 0.0f) return;
-  const CornerSetup c = level_setup(lv, grid.interpolation, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
+  const bool nearest = grid.interpolation == 2u;   // EXTERNAL tcnn kernel_grid_backward, Nearest: the whole gradient to the lower corner's entry
+  if (nearest && xb) return;
+  const CornerSetup c = level_setup(lv, grid.interpolation == 1u ? 1u : 0u, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
   half_t* base = grid_grads + (size_t)lv.offset * F + (F >= 2 ? f : 0u);
 #pragma unroll
   for (int yz = 0; yz < 4; ++yz) {
+    if (nearest && yz) break;
     const int corner = (int)xb | (yz << 1);
     const uint32_t idx = level_index(lv, c.g[0] + xb, c.g[1] + (uint32_t)(yz & 1), c.g[2] + (uint32_t)(yz >> 1));
-    const float w = corner_weight(c, corner);
+    const float w = nearest ? 1.0f : corner_weight(c, corner);
     half2_t v;
     half_t* addr;
     if constexpr (F >= 2) {
@@ -624,19 +717,20 @@ void Network::reset_master_from_params(hipStream_t s)
 void Network::forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s, GradExchange* exchange)
 {
   if (!valid()) throw std::runtime_error("network is not configured");
-  if (!fast_path() || n_active_levels() != cfg_.n_levels)
-    throw std::runtime_error("training is implemented for FullyFusedMLP n_neurons 64 with Linear or Smoothstep interpolation, quantize_threshold 0 and no "
-                             "max_level (the reference's training configuration, example-model.json); this model can be loaded, evaluated and rendered");
   if (batch == 0) return;
+  // the MFMA kernels: 64 neurons, Linear / Smoothstep, every level active, no quantisation; everything else the reference trains
+  // (tcnn_network.h:163-252 builds whatever the model JSON asks for) takes the generic kernels
+  const bool generic = !fast_path() || n_active_levels() != cfg_.n_levels;
   TrainScratch& ts = scratch_of(this);
   const uint32_t nh = n_hidden_matmuls();
   const uint32_t n = (uint32_t)batch;
+  const uint32_t Wn = cfg_.n_neurons;
   ensure_training_state(s);  // lazily allocated
   if (ws_batch_ != batch) {
     ws_features_.resize(batch * in_width_);
-    ws_acts_.resize((size_t)(nh + 1) * batch * 64);
+    ws_acts_.resize((size_t)(nh + 1) * batch * Wn);
     ws_dfeat_.resize(batch * in_width_);
-    ts.d_all.resize((size_t)(nh + 1) * batch * 64);
+    ts.d_all.resize((size_t)(nh + 1) * batch * Wn);
     ts.y.resize(batch);
     ts.dy.resize(batch);
     ts.loss_blocks = std::min<uint32_t>(div_round_up(batch, 256), 1024u);
@@ -648,11 +742,35 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
 
   // 1. forward, keeping features and hidden activations
   profile_mark(0, s);
-  launch_fused(2, grid_, in_width_, nh, cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2, mlp_packed_.ptr,
-               lds_halves_, d_coords, ts.y.ptr, ws_features_.ptr, ws_acts_.ptr, batch, nullptr, batch, s);
+  if (generic)
+    launch_generic(2, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_coords, ts.y.ptr, ws_features_.ptr, batch, nullptr,
+                   batch, s, nullptr, 0, ws_acts_.ptr);
+  else
+    launch_fused(2, grid_, in_width_, nh, cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2, mlp_packed_.ptr,
+                 lds_halves_, d_coords, ts.y.ptr, ws_features_.ptr, ws_acts_.ptr, batch, nullptr, batch, s);
   // 2. loss + output gradient
   profile_mark(1, s);
   loss_grad_kernel<<<ts.loss_blocks, 256, 0, s>>>(ts.y.ptr, d_targets, n, cfg_.loss, (half_t*)ts.dy.ptr, ws_loss_.ptr);
+  if (generic) {
+    // 3g. MLP backward, 4g. weight gradients (generic kernels)
+    GenericBackwardArgs ga;
+    ga.params = (const half_t*)params_f16_.ptr; ga.dy = (const half_t*)ts.dy.ptr; ga.acts = (const half_t*)ws_acts_.ptr;
+    ga.d_out = (half_t*)ts.d_all.ptr; ga.dfeat = (half_t*)ws_dfeat_.ptr; ga.n = n; ga.nh = nh; ga.activation = cfg_.activation;
+    ga.in_width = in_width_; ga.width = Wn;
+    generic_backward_kernel<<<std::min<uint32_t>(div_round_up(batch, 128), (uint32_t)Runtime::get().n_cus * 16u), 128, 0, s>>>(ga);
+    profile_mark(2, s);
+    GenericWGradArgs gw;
+    gw.features = (const half_t*)ws_features_.ptr; gw.acts = (const half_t*)ws_acts_.ptr; gw.d_all = (const half_t*)ts.d_all.ptr;
+    gw.dy = (const half_t*)ts.dy.ptr; gw.n = n; gw.nh = nh; gw.in_width = in_width_; gw.width = Wn; gw.n_mlp = (uint32_t)n_mlp_;
+    gw.chunk = 1024;
+    const uint32_t nchunks = div_round_up(batch, gw.chunk);
+    if (ts.wgrad_slab.count < (size_t)nchunks * n_mlp_) { ts.wgrad_slab.resize((size_t)nchunks * n_mlp_); ts.wgrad_slab.zero(s); }   // the padded last-layer rows stay zero
+    gw.slab = ts.wgrad_slab.ptr;
+    const uint32_t n_elems = Wn * in_width_ + nh * Wn * Wn + Wn;
+    generic_wgrad_kernel<<<dim3(div_round_up(n_elems, 256), nchunks), 256, 0, s>>>(gw);
+    weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, s>>>(ts.wgrad_slab.ptr, nchunks, (uint32_t)n_mlp_, (half_t*)grads_.ptr);
+    VNR_HIP_CHECK(hipGetLastError());
+  } else {
   // 3. MLP backward
   pack_mlp_T_kernel<<<div_round_up(pt, 256), 256, 0, s>>>((const half_t*)params_f16_.ptr, (half_t*)ts.packedT.ptr, in_width_, nh);
   BackwardArgs ba;
@@ -694,6 +812,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     weight_grad_mfma_kernel<2><<<g2, 256, 0, s>>>(wa, 1);
     weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, s>>>(ts.wgrad_slab.ptr, nblk, (uint32_t)n_mlp_, (half_t*)grads_.ptr);
   }
+  }   // MFMA kernels
   profile_mark(3, s);
   if (exchange) exchange->range_ready(0, n_mlp_, s);   // the MLP's gradient travels while the grid backward runs
   // 5. hash-grid backward: levels [l0, l1) per launch (blockIdx.y + l0 = level)
@@ -716,13 +835,14 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
       if (e && std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b > a) return std::make_pair(a, b);
       return std::make_pair(-1, -1);
     }();
-    if (only.first >= 0) grid_backward((uint32_t)only.first, std::min<uint32_t>((uint32_t)only.second, cfg_.n_levels));
-    else grid_backward(0, cfg_.n_levels);
+    // levels at or beyond max_level + 1e-3 encode to zero and receive no gradient (EXTERNAL tcnn kernel_grid_backward has the same test)
+    if (only.first >= 0) grid_backward((uint32_t)only.first, std::min<uint32_t>((uint32_t)only.second, n_active_levels()));
+    else if (n_active_levels() > 0) grid_backward(0, n_active_levels());
   } else {
     // finest levels first (the large tables), in buckets of at least bucket_params() parameters: a bucket's exchange overlaps the
     // backward launches of the coarser levels and, afterwards, the optimizer update of the buckets before it
     for (const auto& b : exchange_level_buckets(exchange->bucket_params())) {
-      grid_backward(b.first, b.second);
+      if (b.first < n_active_levels()) grid_backward(b.first, std::min(b.second, n_active_levels()));
       exchange->range_ready(level_range_lo(b.first), level_range_hi(b.second), s);
     }
   }

@@ -5,6 +5,10 @@ submodule (Trainer::training_step, call site /root/reference/core/networks/tcnn_
 restates the published upstream algorithm (L1/L2 loss with loss scale 128, fp16 activation gradients, ReLU
 masking, hash-grid scatter-add, Adam with per-parameter step count) — every assumption is listed in
 SURVEY.md Appendix A.  Used only for gradient checks on small cases.
+Model shapes beyond the reference's example (n_neurons 16 / 32 / 128, Nearest, max_level, quantize_threshold): the MLP part is generic in the
+width; Nearest sends the gradient to the one entry the forward pass read; a masked level gets none; quantize_threshold (a forward-pass zeroing of
+small table values that exists only in the reference's fork, tcnn_impl_decoder.cu:120) is ASSUMED to pass the gradient through unchanged
+(straight-through), the only reading under which a zeroed entry can ever move again.
 """
 import numpy as np
 
@@ -47,6 +51,11 @@ def corner_indices_and_weights(cfg, lay, coords):
         hashed = size < stride
         idxs = np.zeros((coords.shape[0], 8), np.int64)
         ws = np.zeros((coords.shape[0], 8), np.float32)
+        if float(l) >= cfg.max_level + 1e-3:
+            # a masked level encodes to zero and receives no gradient (EXTERNAL tcnn kernel_grid_backward tests max_level like the forward pass,
+            # /root/reference/core/networks/tcnn_impl_decoder.cu:17): all weights zero
+            out.append((idxs, ws))
+            continue
         for c in range(8):
             pl = [(g[:, k] + ((c >> k) & 1)) & 0xFFFFFFFF for k in range(3)]
             wk = [np.where((c >> k) & 1, w[:, k], np.float32(1) - w[:, k]).astype(np.float32) for k in range(3)]
@@ -56,6 +65,11 @@ def corner_indices_and_weights(cfg, lay, coords):
             else:
                 idx = (pl[0] + pl[1] * res + pl[2] * res * res) & 0xFFFFFFFF
             idxs[:, c] = idx % size
+        if cfg.interpolation == 2:
+            # Nearest (tcnn_impl_decoder.cu:73-94 reads the lower corner's entry as it is): EXTERNAL tcnn kernel_grid_backward gives that one
+            # entry the whole gradient
+            ws[:, 0] = 1.0
+            ws[:, 1:] = 0.0
         out.append((idxs, ws))
     return out
 

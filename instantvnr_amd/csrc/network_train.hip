@@ -631,6 +631,56 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
   }
 }
 
+// The dense coarse levels through LDS.  A level of a few thousand entries takes 65 536 x 8 corner updates per step; as global atomics
+// those are 262 144 memory-side requests per level whatever the level's size (one 64-byte request per x-pair segment, the floor the
+// scatter above sits on).  Here a block owns a TILE of a level's table (a contiguous entry range that fits its LDS as fp32 accumulators)
+// and a slice of the batch: it repeats the index arithmetic of every sample of its slice, adds the corners that fall into its tile
+// with LDS atomics (fp32: one rounding to the gradient's half precision at the end instead of one per update) and flushes the tile
+// with packed fp16 atomics on CONTIGUOUS entries, 16 entries per 64-byte request, skipping pairs nobody touched.  Requests per level:
+// slices x entries / 16 instead of 4 x batch.  Levels whose table needs more than VNR_AMD_GRID_BWD_LDS_TILES tiles, and hashed levels,
+// keep the global-atomic kernel.
+struct LdsBwdItem { uint32_t level, e0, e1, s0, s1; };   // entries [e0, e1) of `level`, samples [s0, s1)
+
+template <int F>
+__global__ void __launch_bounds__(256) grid_backward_lds_kernel(const GridDevice grid, const LdsBwdItem* __restrict__ items, const float* __restrict__ coords,
+                                                                const half_t* __restrict__ dfeat, uint32_t in_width, half_t* __restrict__ grid_grads)
+{
+  extern __shared__ float s_acc[];   // [e1 - e0][F]
+  const LdsBwdItem it = items[blockIdx.x];
+  const LevelInfo lv = grid.levels[it.level];
+  const uint32_t n_acc = (it.e1 - it.e0) * (uint32_t)F;
+  for (uint32_t e = threadIdx.x; e < n_acc; e += blockDim.x) s_acc[e] = 0.0f;
+  __syncthreads();
+  const bool nearest = grid.interpolation == 2u;
+  for (uint32_t i = it.s0 + threadIdx.x; i < it.s1; i += blockDim.x) {
+    float g[F];
+    bool any = false;
+#pragma unroll
+    for (int f = 0; f < F; ++f) { g[f] = (float)dfeat[(size_t)i * in_width + it.level * F + f]; any = any || g[f] != 0.0f; }
+    if (!any) continue;
+    const CornerSetup c = level_setup(lv, grid.interpolation == 1u ? 1u : 0u, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      if (nearest && corner) break;
+      const uint32_t idx = level_index(lv, c.g[0] + (corner & 1), c.g[1] + ((corner >> 1) & 1), c.g[2] + ((corner >> 2) & 1));
+      if (idx < it.e0 || idx >= it.e1) continue;
+      const float w = nearest ? 1.0f : corner_weight(c, corner);
+#pragma unroll
+      for (int f = 0; f < F; ++f) atomicAdd(&s_acc[(idx - it.e0) * F + f], w * g[f]);
+    }
+  }
+  __syncthreads();
+  // flush: one packed atomic per pair of halves that received something (e0 is even and level offsets are multiples of 8 entries)
+  half_t* base = grid_grads + ((size_t)lv.offset + it.e0) * F;
+  for (uint32_t q = threadIdx.x; 2u * q < n_acc; q += blockDim.x) {
+    const float a = s_acc[2u * q], b = 2u * q + 1u < n_acc ? s_acc[2u * q + 1u] : 0.0f;
+    if (a == 0.0f && b == 0.0f) continue;
+    const half2_t v = half2_t{(half_t)a, (half_t)b};
+    half_t* addr = base + 2u * (size_t)q;
+    asm volatile("global_atomic_pk_add_f16 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ Adam
 // EXTERNAL tcnn adam_step (optimizers/adam.h): see header comment.  Parameters [lo, hi); also clears the gradient for the next step.
 // Measured split at C4 (70 M parameters, tools/adam_probe.py, with the fp32 gradient blob of round 1): the sweep over all gradients
@@ -679,6 +729,8 @@ struct TrainScratch {  // per-Network extra buffers that do not need to live in 
   DeviceBuffer<uint16_t> d_all{MemTag::Network};
   DeviceBuffer<uint16_t> packedT{MemTag::Network};
   DeviceBuffer<float> wgrad_slab{MemTag::Network};   // [blocks][n_mlp] partial weight gradients
+  DeviceBuffer<uint8_t> lds_items{MemTag::Network};  // work items of grid_backward_lds_kernel (as bytes: the item type is local to this file)
+  size_t lds_items_key = 0;
   uint32_t loss_blocks = 0;
 };
 
@@ -816,7 +868,58 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   profile_mark(3, s);
   if (exchange) exchange->range_ready(0, n_mlp_, s);   // the MLP's gradient travels while the grid backward runs
   // 5. hash-grid backward: levels [l0, l1) per launch (blockIdx.y + l0 = level)
+  // levels [0, lds_levels) go through grid_backward_lds_kernel: dense, and at most kLdsBwdMaxTiles LDS tiles (VNR_AMD_GRID_BWD_LDS=0: none)
+  static const bool lds_bwd = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS"); return !e || std::atoi(e) != 0; }();
+  static const uint32_t lds_kb = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_KB"); return e ? (uint32_t)std::max(8, std::min(144, std::atoi(e))) : 24u; }();
+  static const uint32_t lds_blocks = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_BLOCKS"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 768u; }();
+  static const uint32_t lds_max_tiles = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_TILES"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 64u; }();
+  // (sweep of the three on the C4 model, profiles/r03_grid_backward_lds_sweep.txt: 24 KB tiles, ~768 blocks per level, levels of at most 64 tiles =
+  // levels 0 - 4 of C4: grid backward 0.239 -> 0.18 - 0.22 ms, bimodal from run to run; larger tiles or more levels cost more in scanning
+  // than their atomics saved)
+  const uint32_t tile_entries = (lds_kb * 1024u / (4u * cfg_.n_features)) & ~15u;
+  uint32_t lds_levels = 0;
+  if (lds_bwd)
+    while (lds_levels < n_active_levels() && !grid_.levels[lds_levels].hashed && div_round_up(grid_.levels[lds_levels].size, tile_entries) <= lds_max_tiles) ++lds_levels;
+  auto grid_backward_lds = [&](uint32_t l0, uint32_t l1) {
+    // work items: every tile of every level x slices of the batch; more slices where a level has few tiles, so that ~2 blocks per CU exist
+    std::vector<LdsBwdItem> items;
+    for (uint32_t l = l0; l < l1; ++l) {
+      const uint32_t size = grid_.levels[l].size, tiles = div_round_up(size, tile_entries);
+      const uint32_t slices = std::max(4u, std::min(128u, lds_blocks / tiles));
+      const uint32_t per = (uint32_t)div_round_up(batch, slices);
+      for (uint32_t t = 0; t < tiles; ++t)
+        for (uint32_t sl = 0; sl < slices; ++sl) {
+          const uint32_t s0 = sl * per, s1 = std::min<uint32_t>(n, s0 + per);
+          if (s0 < s1) items.push_back({l, t * tile_entries, std::min(size, (t + 1) * tile_entries), s0, s1});
+        }
+    }
+    if (items.empty()) return;
+    if (ts.lds_items_key != batch * 64 + l0 * 8 + l1 || ts.lds_items.count < items.size() * sizeof(LdsBwdItem)) {   // (the list depends on the batch size and the level range only)
+      ts.lds_items.resize(items.size() * sizeof(LdsBwdItem));
+      VNR_HIP_CHECK(hipMemcpyAsync(ts.lds_items.ptr, items.data(), items.size() * sizeof(LdsBwdItem), hipMemcpyHostToDevice, s));
+      VNR_HIP_CHECK(hipStreamSynchronize(s));   // pageable source
+      ts.lds_items_key = batch * 64 + l0 * 8 + l1;
+    }
+    const size_t shmem = (size_t)tile_entries * cfg_.n_features * sizeof(float);
+    half_t* gg = (half_t*)grads_.ptr + n_mlp_;
+    auto launch = [&](auto kernel) {
+      static bool attr = false;
+      if (!attr) { VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+      kernel<<<(uint32_t)items.size(), 256, shmem, s>>>(grid_, (const LdsBwdItem*)ts.lds_items.ptr, d_coords, (const half_t*)ws_dfeat_.ptr, in_width_, gg);
+    };
+    switch (cfg_.n_features) {
+    case 1: launch(grid_backward_lds_kernel<1>); break;
+    case 2: launch(grid_backward_lds_kernel<2>); break;
+    case 4: launch(grid_backward_lds_kernel<4>); break;
+    default: launch(grid_backward_lds_kernel<8>); break;
+    }
+  };
   auto grid_backward = [&](uint32_t l0, uint32_t l1) {
+    if (l0 < lds_levels) {
+      grid_backward_lds(l0, std::min(l1, lds_levels));
+      l0 = std::min(l1, lds_levels);
+      if (l0 >= l1) return;
+    }
     const uint32_t pairs = cfg_.n_features >= 2 ? cfg_.n_features / 2 : 1u;
     const dim3 g(div_round_up((uint64_t)batch * pairs * 2, 256), l1 - l0);  // one lane per (sample, x bit, feature pair)
     half_t* gg = (half_t*)grads_.ptr + n_mlp_;

@@ -231,6 +231,13 @@ int    vnrAmdNeuralVolumeSetInitSeed(vnrAmdVolume, uint64_t seed); /* reference 
 /* ---- general volume (api.h:146-148) --------------------------------------- */
 int  vnrAmdVolumeSetClippingBox(vnrAmdVolume, const float lower[3], const float upper[3]); /* vnrVolumeSetClippingBox */
 int  vnrAmdVolumeSetScaling(vnrAmdVolume, const float scale[3]);                           /* vnrVolumeSetScaling */
+/* AMD extension: the volume's object -> world map as gdt::affine3f stores it (columns vx, vy, vz, then the translation p: 12 floats).
+ * The reference's vnr* API only ever scales the default map; its OVR plugin hands the renderer an arbitrary one
+ * (device/device_impl.cpp:151-153, 175-184: translate(grid_origin) * scale(grid_spacing * dims)). */
+int  vnrAmdVolumeSetTransform(vnrAmdVolume, const float vx_vy_vz_p[12]);
+/* AMD extension: the value range of a simple volume's voxels BEFORE the normalisation to [0, 1] on load (m_value_range_unnormalized,
+ * neural_sampler.cu:117-118): what maps a transfer function's range given in data units onto the normalised voxels */
+int  vnrAmdSimpleVolumeGetDataRange(vnrAmdVolume, float range[2]);
 int  vnrAmdVolumeGetValueRange(vnrAmdVolume, float range[2]);                              /* vnrVolumeGetValueRange */
 int  vnrAmdVolumeGetDims(vnrAmdVolume, int dims[3]);
 int  vnrAmdVolumeIsNetwork(vnrAmdVolume);
@@ -351,6 +358,16 @@ int  vnrAmdNeuralVolumeAllReduceGradients(vnrAmdVolume);
 int  vnrAmdNeuralVolumeTrainEndDataParallel(vnrAmdVolume, int fast_mode, int sharded);
 /* tests: replaces the gradient buffer by `count` host floats (rounded to its half precision) and marks a step as pending */
 int  vnrAmdNeuralVolumeSetGradients(vnrAmdVolume, const float* host, size_t count);
+
+/* ---- isosurface (core/marching_cube.cuh:6-8; apps/batch_isosurface.cpp:70-76) --------------------------------- */
+/* vnrMarchingCube(volume, isovalue, &ptr, &size, cuda): marching cubes over the dual grid of the volume's dims voxels (a neural volume is
+ * evaluated at the grid nodes index / dims, core/marching_cube.cu:117-122); *xyz = 3 floats per vertex, 3 vertices per triangle, in voxel
+ * units (+ 0.5, :245).  on_device = 0: a malloc'ed host array (vnrAmdFreeHost; the reference hands out new[]), 1: a device array
+ * (vnrAmdFree).  Same surface rules as the reference (classification <=, the vertex rule with its 0.001 guard); the case table is this
+ * library's own derivation (tools/gen_mc_table.py), so triangle order and the cut of ambiguous faces may differ from the reference's.
+ * vnrSaveTriangles(filename, ptr, size): Wavefront OBJ with one "v" line per vertex and one "f" triple per triangle. */
+int  vnrAmdMarchingCube(vnrAmdVolume, float isovalue, float** xyz, size_t* n_vertices, int on_device);
+int  vnrAmdSaveTriangles(const char* filename, const float* xyz, size_t n_vertices);
 
 /* ---- misc (api.h:185-188) -------------------------------------------------- */
 void vnrAmdMemoryQuery(size_t* used_by_renderer, size_t* used_by_network); /* vnrMemoryQuery */

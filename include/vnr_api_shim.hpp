@@ -312,3 +312,22 @@ inline bool vnrRequireDecoding(int m)
 // api.h:118-119: time-varying raw volumes (one file per time step in the scene's dataSource / filename array)
 inline int vnrSimpleVolumeGetNumberOfTimeSteps(vnrVolume v) { const int n = vnrAmdSimpleVolumeGetNumberOfTimeSteps(v.get()); if (n < 0) vnr::shim::fail(); return n; }
 inline void vnrSimpleVolumeSetCurrentTimeStep(vnrVolume v, int time) { vnr::shim::check(vnrAmdSimpleVolumeSetCurrentTimeStep(v.get(), time)); }
+
+// ---- isosurface (core/marching_cube.cuh:6-8; apps/batch_isosurface.cpp:70-76) ------------------------------------------------
+// vnrMarchingCube(volume, isovalue, &ptr, &size, cuda): cuda = false hands out a new[]-ed host array (the application delete[]s it, as
+// apps/batch_isosurface.cpp:76 does), cuda = true a device array
+inline void vnrMarchingCube(vnrVolume volume, float isovalue, vnr::vec3f** ptr, size_t* size, bool cuda)
+{
+  float* xyz = nullptr;
+  size_t n = 0;
+  vnr::shim::check(vnrAmdMarchingCube(volume.get(), isovalue, &xyz, &n, cuda ? 1 : 0));
+  *size = n;
+  if (cuda) { *ptr = (vnr::vec3f*)xyz; return; }
+  *ptr = new vnr::vec3f[n];
+  for (size_t i = 0; i < n; ++i) (*ptr)[i] = vnr::vec3f{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  vnrAmdFreeHost(xyz);
+}
+inline void vnrSaveTriangles(std::string filename, const vnr::vec3f* ptr, size_t size)
+{
+  vnr::shim::check(vnrAmdSaveTriangles(filename.c_str(), (const float*)ptr, size));
+}

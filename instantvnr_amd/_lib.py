@@ -148,6 +148,10 @@ def lib():
     sig("vnrAmdNeuralVolumeSetInitSeed", I, P, U64)
     sig("vnrAmdVolumeSetClippingBox", I, P, FP, FP)
     sig("vnrAmdVolumeSetScaling", I, P, FP)
+    sig("vnrAmdVolumeSetTransform", I, P, FP)
+    sig("vnrAmdSimpleVolumeGetDataRange", I, P, FP)
+    sig("vnrAmdMarchingCube", I, P, F, C.POINTER(C.POINTER(C.c_float)), C.POINTER(SZ), I)
+    sig("vnrAmdSaveTriangles", I, C.c_char_p, C.POINTER(C.c_float), SZ)
     sig("vnrAmdVolumeGetValueRange", I, P, FP)
     sig("vnrAmdVolumeGetDims", I, P, IP)
     sig("vnrAmdVolumeIsNetwork", I, P)

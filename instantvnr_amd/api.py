@@ -410,6 +410,25 @@ def vnrVolumeGetValueRange(v):
     return tuple(r)
 
 
+# ------------------------------------------------------------------------------------------------ isosurface (core/marching_cube.cuh:6-8)
+def vnrMarchingCube(v, isovalue):
+    """vnrMarchingCube(volume, isovalue, &ptr, &size, false): -> float32 [n_vertices, 3], three vertices per triangle, voxel units"""
+    p = C.POINTER(C.c_float)()
+    n = C.c_size_t()
+    check(lib().vnrAmdMarchingCube(v.h, float(isovalue), C.byref(p), C.byref(n), 0))
+    if n.value == 0:
+        return np.zeros((0, 3), np.float32)
+    out = np.ctypeslib.as_array(p, shape=(n.value, 3)).copy()
+    lib().vnrAmdFreeHost(p)
+    return out
+
+
+def vnrSaveTriangles(filename, vertices):
+    """vnrSaveTriangles(filename, ptr, size): Wavefront OBJ"""
+    a = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+    check(lib().vnrAmdSaveTriangles(str(filename).encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0]))
+
+
 # ------------------------------------------------------------------------------------------------ tfn (api.h:154-162)
 def vnrCreateTransferFunction(scene=None, table=None):
     """api.h:154-155.  vnrCreateTransferFunction(scene) decodes the scene's transfer function with OVR's tfn module

@@ -622,6 +622,51 @@ int vnrAmdVolumeSetScaling(vnrAmdVolume v, const float scale[3])
     v->v->transform = affine_scale_then({scale[0], scale[1], scale[2]}, v->v->transform);
   });
 }
+namespace vnr {
+size_t marching_cubes(VolumeBase& volume, float isovalue, DeviceBuffer<vec3f>& vertices);
+void save_triangles_obj(const std::string& filename, const float* xyz, size_t n_vertices);
+}
+int vnrAmdMarchingCube(vnrAmdVolume v, float isovalue, float** xyz, size_t* n_vertices, int on_device)
+{
+  return guarded([&]() {
+    if (!v || !v->v) throw std::runtime_error("null volume");
+    if (!xyz || !n_vertices) throw std::runtime_error("null output pointer");
+    DeviceBuffer<vec3f> verts;
+    const size_t n = marching_cubes(*v->v, isovalue, verts);
+    *n_vertices = n;
+    *xyz = nullptr;
+    if (on_device) {   // the caller owns the device array: vnrAmdFree
+      *xyz = (float*)verts.ptr;
+      verts.counter() -= verts.count * sizeof(vec3f);
+      verts.ptr = nullptr; verts.count = 0;
+    } else if (n) {
+      float* h = (float*)std::malloc(n * sizeof(vec3f));
+      if (!h) throw std::runtime_error("out of host memory");
+      const hipError_t e = hipMemcpy(h, verts.ptr, n * sizeof(vec3f), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { std::free(h); throw std::runtime_error("device to host copy of the vertices failed"); }
+      *xyz = h;
+    }
+  });
+}
+int vnrAmdSaveTriangles(const char* filename, const float* xyz, size_t n_vertices)
+{
+  return guarded([&]() { if (!filename) throw std::runtime_error("null file name"); save_triangles_obj(filename, xyz, n_vertices); });
+}
+int vnrAmdSimpleVolumeGetDataRange(vnrAmdVolume v, float range[2])
+{
+  return guarded([&]() {
+    if (!v || !v->v || v->v->is_network()) throw std::runtime_error("not a simple volume");
+    const SimpleVolume* sv = static_cast<const SimpleVolume*>(v->v.get());
+    range[0] = sv->unnormalized_lo; range[1] = sv->unnormalized_hi;
+  });
+}
+int vnrAmdVolumeSetTransform(vnrAmdVolume v, const float m[12])
+{
+  return guarded([&]() {  // MainRenderer::set_scene(..., matrix, ...) of the OVR plugin (device/device_impl.cpp:175-184): object -> world
+    if (!v || !v->v) throw std::runtime_error("null volume");
+    v->v->transform = affine3f{{m[0], m[1], m[2]}, {m[3], m[4], m[5]}, {m[6], m[7], m[8]}, {m[9], m[10], m[11]}};
+  });
+}
 int vnrAmdVolumeGetValueRange(vnrAmdVolume v, float range[2])
 {
   return guarded([&]() {

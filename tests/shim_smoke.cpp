@@ -61,6 +61,13 @@ int main() {
     for (int b = 0; b < vnrNeuralVolumeGetNumberOfBlobs(v); ++b) vnrNeuralVolumeDecodeProgressive(v);
     vnrRender(r);
     try { (void)vnrSimpleVolumeGetNumberOfTimeSteps(v); return 14; } catch (const std::runtime_error&) {}   // not a simple volume
+    // core/marching_cube.cuh:6-8: the isosurface of the untrained network at a value it cannot reach is empty; the calls go through
+    {
+      vnr::vec3f* tri = nullptr; size_t n_tri = 123;
+      vnrMarchingCube(v, 1.0e9f, &tri, &n_tri, false);
+      if (n_tri != 0) return 19;
+      delete[] tri;
+    }
     // api.h:34 vnrType = vnr::ValueType, the voxel type of a volume made from memory (device/device_impl.cpp:175-184)
     const vnrType ty = vnr::VALUE_TYPE_UINT16;
     if (vnr::value_type_size(ty) != 2 || (int)vnr::VALUE_TYPE_FLOAT != 8 || (int)vnr::VALUE_TYPE_DOUBLE != 12) return 18;

@@ -622,10 +622,6 @@ int vnrAmdVolumeSetScaling(vnrAmdVolume v, const float scale[3])
     v->v->transform = affine_scale_then({scale[0], scale[1], scale[2]}, v->v->transform);
   });
 }
-namespace vnr {
-size_t marching_cubes(VolumeBase& volume, float isovalue, DeviceBuffer<vec3f>& vertices);
-void save_triangles_obj(const std::string& filename, const float* xyz, size_t n_vertices);
-}
 int vnrAmdMarchingCube(vnrAmdVolume v, float isovalue, float** xyz, size_t* n_vertices, int on_device)
 {
   return guarded([&]() {

@@ -213,4 +213,8 @@ public:
   void keep_source_alive(std::shared_ptr<void> p) { source_keepalive_ = std::move(p); }
 };
 
+// marching_cubes.hip: vnrMarchingCube / vnrSaveTriangles (core/marching_cube.cuh:6-8)
+size_t marching_cubes(VolumeBase& volume, float isovalue, DeviceBuffer<vec3f>& vertices);
+void save_triangles_obj(const std::string& filename, const float* xyz, size_t n_vertices);
+
 }  // namespace vnr

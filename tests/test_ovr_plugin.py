@@ -77,7 +77,8 @@ def test_plugin_frames_equal_the_api_s_frames(tmp_path):
     assert np.array_equal(got[0], want0)
     api.vnrTransferFunctionSetColor(tfn, [[1, 1, 1], [1, 0.5, 0]])
     api.vnrTransferFunctionSetAlpha(tfn, [[0.0, 0.0], [0.5, 0.05], [1.0, 0.8]])
-    api.vnrTransferFunctionSetValueRange(tfn, ((8000.0 - lo) / (hi - lo), (60000.0 - lo) / (hi - lo)))
+    w = np.float32(1.0) / (np.float32(hi) - np.float32(lo))      # the adapter maps the range in single precision, in this order
+    api.vnrTransferFunctionSetValueRange(tfn, (float((np.float32(8000.0) - np.float32(lo)) * w), float((np.float32(60000.0) - np.float32(lo)) * w)))
     api.vnrRendererSetTransferFunction(r, tfn)
     api.vnrRendererSetVolumeSamplingRate(r, 2.0)
     api.vnrRender(r)

@@ -116,6 +116,8 @@ def lib():
     sig("vnrAmdCameraSetFromScene", I, P, P, SZ, I)
     sig("vnrAmdSimpleVolumeOutOfCoreInfo", I, P, C.POINTER(OutOfCoreInfo))
     sig("vnrAmdSimpleVolumeOutOfCoreBlocks", I, P, IP, SZ)
+    sig("vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh", I, P, I)
+    sig("vnrAmdSimpleVolumeOutOfCoreRefreshStats", I, P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
     sig("vnrAmdCreateNeuralVolume", P, P, SZ, I, P, I)
     sig("vnrAmdCreateNeuralVolumeFromDims", P, P, SZ, I, IP)
     sig("vnrAmdCreateNeuralVolumeFromParams", P, P, SZ, I)

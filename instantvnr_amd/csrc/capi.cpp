@@ -375,6 +375,23 @@ int vnrAmdSimpleVolumeOutOfCoreInfo(vnrAmdVolume v, vnrAmdOutOfCoreInfo* info)
     info->block_size_aligned = o->block_size_aligned(); info->bytes_read = o->bytes_read();
   });
 }
+int vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh(vnrAmdVolume v, int enable)
+{
+  return guarded([&]() {
+    OutOfCoreSampler* o = as_simple(v)->out_of_core();
+    if (!o) throw std::runtime_error("not an out-of-core volume");
+    o->set_async_refresh(enable != 0);
+  });
+}
+int vnrAmdSimpleVolumeOutOfCoreRefreshStats(vnrAmdVolume v, uint64_t* refreshes, uint64_t* steps_without_refresh)
+{
+  return guarded([&]() {
+    OutOfCoreSampler* o = as_simple(v)->out_of_core();
+    if (!o) throw std::runtime_error("not an out-of-core volume");
+    if (refreshes) *refreshes = o->refreshes();
+    if (steps_without_refresh) *steps_without_refresh = o->steps_without_refresh();
+  });
+}
 int vnrAmdSimpleVolumeOutOfCoreBlocks(vnrAmdVolume v, int* block_index_yz, size_t n_slots)
 {
   return guarded([&]() {

@@ -70,6 +70,7 @@ struct OocSampleArgs {
   const uint8_t* cache;
   const OocBlock* blocks;
   uint64_t n_blocks, block_bytes;
+  uint64_t excl_first, excl_count;   // asynchronous refresh: slots [excl_first, excl_first + excl_count) (wrapping) are being replaced and are not sampled
   vec3i dims;
   int type;
   float lo, vscale;
@@ -110,7 +111,10 @@ __global__ void ooc_sample_kernel(const OocSampleArgs a)
   const float r_v = rb.next_float();
 
   // the reference throws when float rounding carries a pick to the end of its range; here it is clamped to the last element
-  const uint64_t bidx = min((uint64_t)(r_b * (float)a.n_blocks), a.n_blocks - 1ull);
+  // (asynchronous refresh: the pick runs over the slots that are NOT being replaced, counted from the end of the range that is)
+  const uint64_t n_pick = a.n_blocks - a.excl_count;
+  uint64_t bidx = min((uint64_t)(r_b * (float)n_pick), n_pick - 1ull);
+  if (a.excl_count) { bidx += a.excl_first + a.excl_count; if (bidx >= a.n_blocks) bidx -= a.n_blocks; }
   const OocBlock b = a.blocks[bidx];
   const uint64_t vidx = min((uint64_t)(r_v * (float)b.length), (uint64_t)b.length - 1ull);
   const uint64_t index = b.offset + vidx;  // locate_voxel, then to_grid_index (:339-345)
@@ -197,6 +201,7 @@ OutOfCoreSampler::OutOfCoreSampler(const std::string& filename, vec3i dims, int 
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_sampled_, hipEventDisableTiming));
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_copied_, hipEventDisableTiming));
 
+  if (const char* e = std::getenv("VNR_AMD_OOC_ASYNC")) async_refresh_ = std::atoi(e) != 0;
   // preloading (:555-559), then the first refresh in flight
   for (uint64_t i = 0; i < n_blocks_; i += n_concurrent_) {
     submit((int64_t)i);
@@ -252,8 +257,11 @@ void OutOfCoreSampler::submit(int64_t first)
     plan_block((i + j) % n_blocks_, vec3i{(int)(index % sy), (int)((index % sz) / sy), (int)(index / sz)});
   }
   in_flight_ = true;
+  inflight_first_ = i;
+  ++refreshes_;
+  worker_done_.store(false, std::memory_order_relaxed);
   worker_error_.clear();
-  worker_ = std::thread([this, i]() { refresh_worker(i); });
+  worker_ = std::thread([this, i]() { refresh_worker(i); worker_done_.store(true, std::memory_order_release); });
 }
 
 void OutOfCoreSampler::refresh_worker(uint64_t first)
@@ -352,11 +360,25 @@ void OutOfCoreSampler::sample(float* d_coords, float* d_values, size_t n, vec3f 
   if (!(lo_ < hi_)) throw std::runtime_error("a valid value range must be provided");  // :1069-1071
   if (n == 0) return;
   if (n > 0xffffffffull) throw std::runtime_error("out-of-core sampler: batch too large");
-  wait();                                                  // randbuf.wait_all_jobs()
-  VNR_HIP_CHECK(hipStreamWaitEvent(s, ev_copied_, 0));     // ... and its copy to the device
+  // The reference's schedule: wait for the refresh submitted by the previous call, sample, submit the next (a step is then as long as a
+  // refresh whenever a refresh takes longer than a step: 102 MiB of preads and PCIe per step at the default 1024 slabs, 3 ms against a
+  // 0.65 ms step).  Asynchronous refresh (VNR_AMD_OOC_ASYNC=1 / set_async_refresh): a step never waits.  While a refresh is in flight the
+  // batch is drawn from the slots that are NOT being replaced (the kernel skips the range, so no sample reads a half-written slab), and the
+  // next refresh is submitted by the first call that finds the previous one complete: slabs turn over at the rate the storage delivers
+  // them instead of at a fixed 1024 per step, everything else (slab geometry, random slab choice, per-sample arithmetic) is unchanged.
+  bool busy = false;
+  if (async_refresh_ && in_flight_) {
+    if (worker_done_.load(std::memory_order_acquire)) wait();
+    else busy = true;
+  } else {
+    wait();                                                // randbuf.wait_all_jobs()
+  }
+  if (!busy) VNR_HIP_CHECK(hipStreamWaitEvent(s, ev_copied_, 0));     // ... and its copy to the device
   OocSampleArgs a;
   a.cache = cache_.ptr; a.blocks = d_blocks_.ptr;
   a.n_blocks = n_blocks_; a.block_bytes = block_bytes_;
+  a.excl_first = busy ? inflight_first_ : 0; a.excl_count = busy ? n_concurrent_ : 0;
+  if (busy && n_concurrent_ >= n_blocks_) throw std::runtime_error("out-of-core sampler: asynchronous refresh needs more resident slabs than one refresh replaces");
   a.dims = dims_; a.type = type_;
   a.lo = lo_; a.vscale = 1.0f / (hi_ - lo_);
   a.lower = lower; a.upper = upper;
@@ -364,8 +386,9 @@ void OutOfCoreSampler::sample(float* d_coords, float* d_values, size_t n, vec3f 
   a.n = (uint32_t)n; a.coords = d_coords; a.values = d_values;
   ooc_sample_kernel<<<div_round_up(n, 256), 256, 0, s>>>(a);
   VNR_HIP_CHECK(hipGetLastError());
-  VNR_HIP_CHECK(hipEventRecord(ev_sampled_, s));
   rng_offset += 5ull * n;
+  if (busy) { ++steps_without_refresh_; return; }          // (the refresh in flight copies behind the LAST kernel that could read its slots: recorded when it was submitted)
+  VNR_HIP_CHECK(hipEventRecord(ev_sampled_, s));
   submit(-1);                                              // randbuf.submit_all_jobs()
 }
 

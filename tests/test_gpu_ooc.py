@@ -121,3 +121,44 @@ def test_training_from_an_out_of_core_volume(oracle, tmp_path):
     lo, hi = vr[touched, 0] + 1.0, vr[touched, 1] - 1.0
     assert lo.min() >= 0.0 and hi.max() <= 1.0 and (hi >= lo).all()
     assert api.out_of_core_info(sv)["bytes_read"] >= 400 * 16 * 64 * 64
+
+
+def test_asynchronous_refresh_never_samples_a_slab_that_is_being_replaced(oracle, tmp_path):
+    """vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh: steps do not wait for the storage; while a refresh is in flight the batch comes from the
+    slabs that are not being replaced.  Whatever the timing, every sample must be the file's own trilinear value at its coordinate (a
+    slab read while it is half overwritten would not be), and the refreshes must go on (the slab set keeps changing)"""
+    import ctypes as C
+    from instantvnr_amd._lib import check, lib
+    shape = (24, 200, 256)
+    rng = np.random.default_rng(5)
+    vol = rng.integers(0, 255, shape, dtype=np.uint8)
+    path = tmp_path / "async.raw"
+    vol.tofile(path)
+    dims = shape[::-1]
+    sv = api.vnrCreateSimpleVolumeOutOfCore(str(path), dims, np.uint8, (0.0, 255.0), n_concurrent_blocks=16, n_blocks=96)
+    check(lib().vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh(sv.h, 1))
+    norm = np.clip(vol.astype(np.float32) / np.float32(255.0), 0, 1)
+    first = np.asarray(api.out_of_core_blocks(sv)).copy()
+    worst = 0.0
+    for step in range(300):
+        c, v = api.simple_volume_take_samples(sv, 4096)
+        # trilinear_vkl at clamp(p, 0.5, dims - 0.5) over the normalised voxels (neural_sampler.cpp:302-329), in double precision here
+        p = c.astype(np.float64) * np.array(dims, np.float64)
+        q = np.clip(p, 0.5, np.array(dims, np.float64) - 0.5) - 0.5
+        i0 = np.floor(q).astype(np.int64)
+        w = q - i0
+        i0 = np.minimum(i0, np.array(dims) - 1)
+        i1 = np.minimum(i0 + 1, np.array(dims) - 1)
+        acc = np.zeros(len(c))
+        for dz, wz in ((0, 1 - w[:, 2]), (1, w[:, 2])):
+            for dy, wy in ((0, 1 - w[:, 1]), (1, w[:, 1])):
+                for dx, wx in ((0, 1 - w[:, 0]), (1, w[:, 0])):
+                    zi = (i1 if dz else i0)[:, 2]; yi = (i1 if dy else i0)[:, 1]; xi = (i1 if dx else i0)[:, 0]
+                    acc += wz * wy * wx * norm[zi, yi, xi]
+        worst = max(worst, float(np.abs(acc - v).max()))
+    assert worst < 2e-5, worst
+    n_ref, n_busy = C.c_uint64(), C.c_uint64()
+    check(lib().vnrAmdSimpleVolumeOutOfCoreRefreshStats(sv.h, C.byref(n_ref), C.byref(n_busy)))
+    assert n_ref.value > 96 // 16 + 5                              # beyond the pre-load: refreshes keep coming
+    assert not np.array_equal(np.asarray(api.out_of_core_blocks(sv)), first)
+    print(f"asynchronous refresh: {n_ref.value} refreshes, {n_busy.value} of 300 steps ran beside one, max |value - file| {worst:.2e}")

@@ -1,6 +1,7 @@
 """GPU box: training throughput from an out-of-core volume (SURVEY 8 a15 / BASELINE C5 in miniature).
 Writes a synthetic uint8 volume file under /tmp, opens it with vnrCreateSimpleVolumeOutOfCore and trains the C4-shaped model.
-usage: python tools/ooc_bench.py [nx ny nz] [n_concurrent_blocks] [n_blocks] [steps] [keep the file: 0 | 1]"""
+usage: python tools/ooc_bench.py [nx ny nz] [n_concurrent_blocks] [n_blocks] [steps] [keep the file: 0 | 1]
+VNR_AMD_OOC_ASYNC=1: asynchronous refresh (a step never waits for the storage; include/vnr_amd.h)"""
 import os
 import sys
 import time
@@ -46,5 +47,9 @@ dt = time.perf_counter() - t0
 b1 = api.out_of_core_info(sv)["bytes_read"]
 print(f"training from the file: {steps} steps, {dt / steps * 1e3:.3f} ms per step (65536 samples each) = {65536 * steps / dt / 1e6:.1f} M samples/s; "
       f"refresh traffic {(b1 - b0) / steps / 2**20:.1f} MiB per step = {(b1 - b0) / dt / 2**30:.2f} GiB/s from the page cache; loss {api.vnrNeuralVolumeGetTrainingLoss(nv):.4f}", flush=True)
+import ctypes as C
+n_ref, n_busy = C.c_uint64(), C.c_uint64()
+check(L.vnrAmdSimpleVolumeOutOfCoreRefreshStats(sv.h, C.byref(n_ref), C.byref(n_busy)))
+print(f"refreshes submitted {n_ref.value} (pre-load {nb // ncb}), steps that ran beside a refresh in flight {n_busy.value}; asynchronous refresh: {os.environ.get('VNR_AMD_OOC_ASYNC', '0')}", flush=True)
 if not (len(a) > 6 and a[6]):
     os.remove(path)

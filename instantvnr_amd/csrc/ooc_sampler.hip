@@ -215,6 +215,7 @@ OutOfCoreSampler::~OutOfCoreSampler()
   if (worker_.joinable()) worker_.join();
   if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
   if (ev_sampled_) (void)hipEventDestroy(ev_sampled_);
+  for (hipEvent_t e : throttle_) (void)hipEventDestroy(e);
   if (ev_copied_) (void)hipEventDestroy(ev_copied_);
   if (staging_) (void)hipHostFree(staging_);
   if (staging_blocks_) (void)hipHostFree(staging_blocks_);
@@ -387,6 +388,18 @@ void OutOfCoreSampler::sample(float* d_coords, float* d_values, size_t n, vec3f 
   ooc_sample_kernel<<<div_round_up(n, 256), 256, 0, s>>>(a);
   VNR_HIP_CHECK(hipGetLastError());
   rng_offset += 5ull * n;
+  if (async_refresh_) {
+    // A refresh is tied to positions in the training stream (its copies run behind the last kernel that may read the slots, the first
+    // kernel that reads them again waits for the copies), so a host that enqueues hundreds of steps ahead of the GPU would stretch every
+    // refresh over that distance.  The host therefore stays at most kAhead sampling kernels ahead of the GPU here (it needs a fraction
+    // of a step's time to enqueue a step, so this costs nothing).
+    constexpr uint64_t kAhead = 6;
+    if (throttle_.empty()) { throttle_.resize(kAhead); for (auto& e : throttle_) VNR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+    hipEvent_t e = throttle_[calls_ % kAhead];
+    if (calls_ >= kAhead) VNR_HIP_CHECK(hipEventSynchronize(e));
+    VNR_HIP_CHECK(hipEventRecord(e, s));
+    ++calls_;
+  }
   if (busy) { ++steps_without_refresh_; return; }          // (the refresh in flight copies behind the LAST kernel that could read its slots: recorded when it was submitted)
   VNR_HIP_CHECK(hipEventRecord(ev_sampled_, s));
   submit(-1);                                              // randbuf.submit_all_jobs()

@@ -2138,7 +2138,7 @@ bool Renderer::decoupled_applies(const RenderParams& p, int pass_mode) const
 {
   if (pass_mode != M_NONE || decoupled_mode_ == 0) return false;
   if ((size_t)p.n_local * (size_t)p.n_iters >= (1ull << 28)) return false;   // 32-bit float indices into a ring slot's arena
-  return decoupled_mode_ == 2 || p.n_local <= 262144u;
+  return decoupled_mode_ == 2 || p.n_local <= 20480u;
 }
 
 void Renderer::render_decoupled(const RenderParams& p_all, bool defer)

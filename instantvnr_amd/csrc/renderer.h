@@ -136,11 +136,12 @@ private:
   int small_share_parts_ = 4;  // parts of a share of at most 262 144 pixels (a quarter of a 1024 x 1024 frame): with pipelined frames
                                // 4 short chains side by side beat 2 (1/4 share 1.17 -> 1.13 ms, 1/8 share 0.66 -> 0.65 ms; whole frames: no difference)
   uint32_t predicted_iterations_[2][kMaxParts] = {};   // [camera pass | shadow pass][half]
-  // decoupled path (VNR_AMD_DECOUPLED): 0 never (default: measured SLOWER than the coupled loop on a 1/8 share of the bench frame, 0.85
-  // against 0.58 ms, DESIGN.md 4.2: the walk kernel is as expensive as the evaluation and the two do not share a CU gracefully),
-  // 1 for ray sets of at most 262 144 rays, 2 always; look-ahead of the walks in batches (VNR_AMD_DECOUPLED_AHEAD: 1 = walk, evaluate,
-  // compose in turn; default 2); ray parts (VNR_AMD_DECOUPLED_PARTS)
-  int decoupled_mode_ = 0, decoupled_ahead_ = 2, decoupled_parts_ = 1;
+  // decoupled path (VNR_AMD_DECOUPLED): 0 never, 1 (default) for ray sets of at most 20 480 rays, 2 always.  Measured on shares of the bench
+  // frame (profiles/r03_decoupled_share_sweeps.txt): 1/64 (16 384 rays) 0.203 against 0.248 ms coupled, 1/32 equal, 1/16 0.45 against 0.38,
+  // 1/8 0.85 against 0.58: the walk kernel is as expensive as the evaluation (0.43 ms alone on the 1/8 share) and the two do not share a
+  // CU gracefully, so taking the walks off the chain pays only where the GPU is mostly idle.  Look-ahead of the walks in batches
+  // (VNR_AMD_DECOUPLED_AHEAD: 1 = walk, evaluate, compose in turn; default 3); ray parts (VNR_AMD_DECOUPLED_PARTS, default 1)
+  int decoupled_mode_ = 1, decoupled_ahead_ = 3, decoupled_parts_ = 1;
   uint32_t decoupled_predicted_[kMaxParts] = {};
   hipStream_t d_streams_[kMaxParts][3] = {};           // walk, evaluate, compose
   DeviceBuffer<uint32_t> d_words_[2];                  // per frame slot: ray state, batch records, counters

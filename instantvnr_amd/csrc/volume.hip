@@ -680,6 +680,14 @@ struct NeuralVolume::DpState : GradExchange {
   {
     for (auto& p : pool) for (hipEvent_t e : p.e) (void)hipEventDestroy(e);
   }
+  // diagnostics (tools/dp_probe.py on one GPU): VNR_AMD_DP_EMULATE_WORLD=8 slices the ranges as rank 0 of 8 would, so that the probe times the
+  // compute side of one rank of an 8-rank step (the memsets, Adam on 1/8, the launches); the collectives then only see this rank's slice and
+  // the other slices' parameters are never updated: timing only
+  static size_t emulated_world()
+  {
+    static const int e = [] { const char* v = std::getenv("VNR_AMD_DP_EMULATE_WORLD"); return v ? std::atoi(v) : 0; }();
+    return e > 1 ? (size_t)e : (size_t)Dist::get().world();
+  }
   void range_ready(size_t lo, size_t hi, hipStream_t s) override
   {
     Dist& d = Dist::get();
@@ -689,7 +697,7 @@ struct NeuralVolume::DpState : GradExchange {
       for (hipEvent_t& e : ev.e) VNR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       pool.push_back(ev);
     }
-    const size_t world = (size_t)d.world();
+    const size_t world = emulated_world();
     Range r{lo, hi, sharded ? ((hi - lo) / world) & ~(size_t)7 : 0, pool[used].e[0], pool[used].e[1], pool[used].e[2], pool[used].e[3]};
     ++used;
     // the gradient blob IS the payload (fp16, in place): nothing to pack
@@ -708,7 +716,7 @@ struct NeuralVolume::DpState : GradExchange {
     Dist& d = Dist::get();
     hipStream_t comm = d.comm_stream();
     Network& net = nv->net_;
-    const size_t world = (size_t)d.world(), rank = (size_t)d.rank();
+    const size_t world = emulated_world(), rank = (size_t)d.rank();
     for (const Range& r : ranges) {
       VNR_HIP_CHECK(hipStreamWaitEvent(s, r.reduced, 0));
       if (!r.per) { net.optimizer_step_range(r.lo, r.hi, 1.0f, s); continue; }

@@ -35,8 +35,11 @@ n_params = api.neural_info(nv)["n_params"]
 plain = timed(lambda k: api.vnrNeuralVolumeTrain(nv, k, True), 300)
 nv2 = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
 dp = timed(lambda k: check(L.vnrAmdNeuralVolumeTrainDataParallel(nv2.h, k, 1)), 300)
-hand = timed(lambda k: dist.train_data_parallel_by_hand(ctx, nv2, k), 100)
-print(f"C4 model, {n_params} parameters: plain step {plain:.3f} ms; data-parallel step on a one-rank communicator {dp:.3f} ms "
+check(L.vnrAmdNeuralVolumeSyncReplicas(nv2.h))
+nv3 = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+hand = timed(lambda k: dist.train_data_parallel_by_hand(ctx, nv3, k), 100)
+print(f"[VNR_AMD_DP_SHARDED={os.environ.get('VNR_AMD_DP_SHARDED', '1')} VNR_AMD_DP_EMULATE_WORLD={os.environ.get('VNR_AMD_DP_EMULATE_WORLD', '-')}] "
+      f"C4 model, {n_params} parameters: plain step {plain:.3f} ms; data-parallel step on a one-rank communicator {dp:.3f} ms "
       f"(fp16 payload {n_params * 2 / 1e6:.1f} MB per step in ranges, exchange overlapped); by hand (one message, nothing overlapped) {hand:.3f} ms", flush=True)
 # the exchange alone
 buf = api.DeviceArray((n_params,), np.float16)

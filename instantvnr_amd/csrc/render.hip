@@ -179,7 +179,11 @@ __device__ __forceinline__ float adaptive_sampling_rate(float base_step, float m
 }
 __device__ __forceinline__ float opacity_correction(float step_rcp, float distance, float opacity)
 {
+#if defined(VNR_FAST_POW)   // experiment (tools/ab_build.sh fastpow -DVNR_FAST_POW): v_log_f32 / v_exp_f32 instead of the ~80 instructions of powf
+  return 1.0f - __builtin_amdgcn_exp2f(step_rcp * distance * __builtin_amdgcn_logf(1.0f - opacity));
+#else
   return 1.0f - __builtin_powf(1.0f - opacity, step_rcp * distance);
+#endif
 }
 __device__ __forceinline__ void write_pixel(const RenderParams& p, vec4f rgba, uint32_t pixel)
 {

@@ -5,7 +5,7 @@ T=${1:-a}; shift
 O=$R/gpurun_out/r03_share_tl_$T; mkdir -p $O
 cd $R
 for kv in "$@"; do export "$kv"; done
-export TMPDIR=/tmp SHARE_PARTS=8 SHARE_PIPELINED=1
+export TMPDIR=/tmp SHARE_PARTS=${SHARE_PARTS:-8} SHARE_PIPELINED=1
 (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/t -o t -- python3 $R/tools/share_probe.py) > $O/log.txt 2>&1
 grep "share 1" $O/log.txt
 f=$(find $O/t -name "*kernel_trace.csv" | head -1)

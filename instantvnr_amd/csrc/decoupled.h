@@ -111,6 +111,10 @@ __global__ void __launch_bounds__(256) walk_kernel(const RenderParams p, const D
     // RayMarchingIter::exec: the next batch of this ray into LDS
     uint32_t k = 0;
     bool last = false;
+#if defined(VNR_MARCH_STAMPS)
+    unsigned long long w0, w1, w2, w3, w4;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0) :: "memory");
+#endif
     if (walk) {
       const int n_iters = p.n_iters;
       iter_exec(p, it_, m_dir, tmin, tmax, p.step, [&](float t0, float t1) -> bool {
@@ -127,6 +131,9 @@ __global__ void __launch_bounds__(256) walk_kernel(const RenderParams p, const D
       r.walking[i] = 0u;
     }
     if (active) ring.rec[i] = walk ? (k | kRecValid | (last ? kRecLast : 0u)) : 0u;
+#if defined(VNR_MARCH_STAMPS)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w1) :: "memory");
+#endif
 
     // samples by wave prefix sum, one claim per block (march_kernel)
     uint32_t incl = k;
@@ -147,6 +154,10 @@ __global__ void __launch_bounds__(256) walk_kernel(const RenderParams p, const D
     uint32_t smp_base = claim[4];
     for (uint32_t w = 0; w < (tid >> 6); ++w) smp_base += claim[w];
     ++trip;
+#if defined(VNR_MARCH_STAMPS)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w2) :: "memory");
+    if (!FIRST && lane == 0) { atomicAdd(&g_march_stamps[0], w1 - w0); atomicAdd(&g_march_stamps[1], w2 - w1); atomicAdd(&g_march_stamps[7], 1ull); }
+#endif
     if (wave_samples == 0) continue;  // wave-uniform
 
     const bool emit = k > 0;
@@ -173,6 +184,9 @@ __global__ void __launch_bounds__(256) walk_kernel(const RenderParams p, const D
     }
     hist[lane] = smp_base + hs - h;
     __builtin_amdgcn_wave_barrier();
+#if defined(VNR_MARCH_STAMPS)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w3) :: "memory");
+#endif
     if (emit) {
       const uint32_t sb = (i >> 6) * (uint32_t)p.n_iters * 64u + lane;   // sample j of this ray: slot sb + 64 j
       for (uint32_t j = 0; j < k; ++j) {
@@ -187,6 +201,10 @@ __global__ void __launch_bounds__(256) walk_kernel(const RenderParams p, const D
       }
     }
     __builtin_amdgcn_wave_barrier();
+#if defined(VNR_MARCH_STAMPS)
+    asm volatile("s_memtime %0\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=s"(w4) :: "memory");
+    if (!FIRST && lane == 0) { atomicAdd(&g_march_stamps[2], w3 - w2); atomicAdd(&g_march_stamps[3], w4 - w3); atomicAdd(&g_march_stamps[4], w4 - w0); }
+#endif
   }
 
   // rays still walking (and, at i = 0, rays that hit the volume): one atomic per block, the last block to arrive publishes

@@ -310,6 +310,9 @@ __device__ __forceinline__ bool dda_resumable(const DDAState& it, vec3f dir, flo
 
 __device__ __forceinline__ float opacity_upper_bound(const RenderParams& p, vec3i cell)
 {
+#if defined(VNR_WALK_NOLOAD)   // experiment: what the walk costs without its one load per macrocell (frames are garbage)
+  return 0.05f + 1e-9f * (float)cell.x;
+#endif
   const uint32_t idx = cell.x + cell.y * (uint32_t)p.mc_dims.x + cell.z * (uint32_t)p.mc_dims.x * (uint32_t)p.mc_dims.y;
   return p.mc_max_opacity[idx];
 }

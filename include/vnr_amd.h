@@ -260,7 +260,7 @@ int  vnrAmdRendererSetFramebufferSize(vnrAmdRenderer, int width, int height);   
 int  vnrAmdRendererSetTransferFunction(vnrAmdRenderer, vnrAmdTransferFunction);      /* vnrRendererSetTransferFunction */
 int  vnrAmdRendererSetCamera(vnrAmdRenderer, vnrAmdCamera);                          /* vnrRendererSetCamera */
 int  vnrAmdRendererSetMode(vnrAmdRenderer, int mode);                                /* vnrRendererSetMode */
-int  vnrAmdRendererSetDenoiser(vnrAmdRenderer, int enable);                          /* vnrRendererSetDenoiser (no-op: OptiX denoiser) */
+int  vnrAmdRendererSetDenoiser(vnrAmdRenderer, int enable);                          /* vnrRendererSetDenoiser: 0 accepted; 1 refused (OptiX's trained denoiser has no counterpart here) unless VNR_AMD_DENOISER_IGNORE=1 */
 int  vnrAmdRendererSetVolumeSamplingRate(vnrAmdRenderer, float rate);                /* vnrRendererSetVolumeSamplingRate */
 int  vnrAmdRendererSetVolumeDensityScale(vnrAmdRenderer, float scale);               /* vnrRendererSetVolumeDensityScale */
 int  vnrAmdRendererResetAccumulation(vnrAmdRenderer);                                /* vnrRendererResetAccumulation */

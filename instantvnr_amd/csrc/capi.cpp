@@ -3,6 +3,7 @@
 #include "../../include/vnr_amd.h"
 
 #include <cstdlib>
+#include <cstdio>
 #include <fstream>
 #include <memory>
 
@@ -732,7 +733,20 @@ int vnrAmdRendererSetCamera(vnrAmdRenderer r, vnrAmdCamera c)
   return guarded([&]() { VNR_REN(r); if (!c) throw std::runtime_error("null camera"); r->r->set_camera(c->d); });
 }
 int vnrAmdRendererSetMode(vnrAmdRenderer r, int mode) { return guarded([&]() { VNR_REN(r); r->r->set_mode(mode); }); }
-int vnrAmdRendererSetDenoiser(vnrAmdRenderer r, int) { return guarded([&]() { VNR_REN(r); }); }
+// vnrRendererSetDenoiser (api.cpp:466): the reference runs OptiX's trained denoiser (optix_program.h:151-230, NVIDIA's weights: not something to
+// restate).  Switching it off is accepted; switching it on is refused, so that nobody takes an undenoised frame for a denoised one.
+// VNR_AMD_DENOISER_IGNORE=1 turns the refusal into a warning for hosts that set the flag unconditionally at start-up.
+int vnrAmdRendererSetDenoiser(vnrAmdRenderer r, int enable)
+{
+  return guarded([&]() {
+    VNR_REN(r);
+    if (!enable) return;
+    const char* e = std::getenv("VNR_AMD_DENOISER_IGNORE");
+    if (!e || std::atoi(e) == 0) throw std::runtime_error("the denoiser is not available (the reference's is OptiX's trained denoiser); VNR_AMD_DENOISER_IGNORE=1 accepts the call and renders undenoised frames");
+    static bool warned = false;
+    if (!warned) { std::fprintf(stderr, "[vnr_amd] denoiser requested and ignored (VNR_AMD_DENOISER_IGNORE=1): frames are not denoised\n"); warned = true; }
+  });
+}
 int vnrAmdRendererSetVolumeSamplingRate(vnrAmdRenderer r, float rate) { return guarded([&]() { VNR_REN(r); r->r->set_sampling_rate(rate); }); }
 int vnrAmdRendererSetVolumeDensityScale(vnrAmdRenderer r, float s) { return guarded([&]() { VNR_REN(r); r->r->set_density_scale(s); }); }
 int vnrAmdRendererResetAccumulation(vnrAmdRenderer r) { return guarded([&]() { VNR_REN(r); r->r->reset_accumulation(); }); }

@@ -87,6 +87,12 @@ constexpr int kDepthBins = 64;
 // "In-kernel stamps"): cycles per phase summed over the waves of every march_kernel<false> launch, read by tools/march_stamps.py
 #if defined(VNR_MARCH_STAMPS)
 __device__ unsigned long long g_march_stamps[16];
+// one record per wave-trip of the walk kernels' launch `it == 1` (plain stores: atomics on a few addresses from every wave of a launch
+// would themselves be what is measured): {s_memrealtime at the trip's start, at its end (100 MHz, one clock for the device), then
+// s_memtime differences of the trip's phases}
+constexpr uint32_t kWaveRecs = 65536;
+__device__ unsigned long long g_wave_rec[kWaveRecs][8];
+#define VNR_REALTIME(var) unsigned long long var; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
 #define VNR_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
 #define VNR_STAMP_ADD(slot, a, b) do { if (!FIRST && (threadIdx.x & 63u) == 0) atomicAdd(&g_march_stamps[slot], (b) - (a)); } while (0)
 #else
@@ -759,6 +765,13 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
 }
 
 #if defined(VNR_MARCH_STAMPS)
+extern "C" int vnrAmdDebugWaveRecords(unsigned long long* out, unsigned n_records, int reset)
+{
+  if (n_records > kWaveRecs) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_rec), (size_t)n_records * 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) { void* d = nullptr; if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_wave_rec)) != hipSuccess || hipMemset(d, 0, sizeof(g_wave_rec)) != hipSuccess) return 1; }
+  return 0;
+}
 extern "C" int vnrAmdDebugMarchStamps(unsigned long long* out16, int reset)
 {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_march_stamps), sizeof(g_march_stamps)) != hipSuccess) return 1;
@@ -1273,7 +1286,7 @@ struct DPart {
 struct Renderer::StreamingFrame {
   bool pending = false;
   bool decoupled = false;
-  int ahead = 2, ring = 3;
+  int ahead = 2, ring = 3, lanes = 1;
   DPart dpart[Renderer::kMaxParts];
   int slot = 0;
   int H = 0, pass_mode = 0;
@@ -1304,6 +1317,7 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   if (const char* e = std::getenv("VNR_AMD_DECOUPLED")) decoupled_mode_ = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("VNR_AMD_DECOUPLED_AHEAD")) decoupled_ahead_ = std::max(1, std::min(7, std::atoi(e)));
   if (const char* e = std::getenv("VNR_AMD_DECOUPLED_PARTS")) decoupled_parts_ = std::max(1, std::min(kMaxParts, std::atoi(e)));
+  if (const char* e = std::getenv("VNR_AMD_DECOUPLED_LANES")) decoupled_lanes_ = std::atoi(e) == 8 ? 8 : 1;
   counters_.resize(2 * kMaxParts * C_COUNT);  // one block of counters per frame slot and half
   counters_.zero(stream_);
   VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 2 * kMaxParts * (256 + C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
@@ -2198,8 +2212,15 @@ void Renderer::render_decoupled(const RenderParams& p_all, bool defer)
   slot_ = slot;
   f.decoupled = true; f.ahead = A; f.ring = RING;
   f.H = H; f.pass_mode = M_NONE; f.grad = false; f.ssh = false; f.nv = nv; f.p_all = p_all;
+  f.lanes = decoupled_lanes_;
   f.shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + 16 * sizeof(uint32_t) + (size_t)p_all.n_iters * 256 * sizeof(uint16_t);
   f.shmem_compose = p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0;
+  if (f.lanes == 8) {   // walk8_kernel / compose8_kernel: one 64-ray group per block (decoupled.h)
+    uint32_t st = ((uint32_t)p_all.n_iters + 7u) & ~7u;
+    if ((st & 15u) == 0u) st += 8u;
+    f.shmem = (size_t)128 * st * sizeof(float) + 136 * sizeof(uint32_t) + (size_t)64 * st * sizeof(uint16_t);
+    f.shmem_compose += (size_t)p_all.n_iters * 64 * sizeof(vec4f);
+  }
   if (f.shmem > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
   f.max_iterations = 240;
   if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) f.max_iterations = std::max(1, std::min(240, std::atoi(e)));  // diagnostics only
@@ -2207,6 +2228,9 @@ void Renderer::render_decoupled(const RenderParams& p_all, bool defer)
   if (!lds_attr_set) {
     VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)compose8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     lds_attr_set = true;
   }
   if (profiling_) {
@@ -2293,7 +2317,12 @@ void Renderer::decoupled_step(StreamingFrame& f, int h, bool head_only)
     if (it >= A) VNR_HIP_CHECK(hipStreamWaitEvent(d.sw, d.ev(d.ev_c, it - A), 0));
     const uint32_t P = d.p.n_local;
     const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
-    if (it == 0) walk_kernel<true><<<blocks, 256, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
+    if (f.lanes == 8) {
+      static const uint32_t cap8 = [] { const char* e = std::getenv("VNR_AMD_DECOUPLED_BLOCKS"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 8192u; }();
+      const uint32_t groups = std::min<uint32_t>(div_round_up(P, 64), cap8);
+      if (it == 0) walk8_kernel<true><<<groups, 512, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
+      else walk8_kernel<false><<<groups, 512, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
+    } else if (it == 0) walk_kernel<true><<<blocks, 256, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
     else walk_kernel<false><<<blocks, 256, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
     VNR_HIP_CHECK(hipGetLastError());
     VNR_HIP_CHECK(hipEventRecord(d.ev(d.ev_w, it), d.sw));
@@ -2318,7 +2347,9 @@ void Renderer::decoupled_step(StreamingFrame& f, int h, bool head_only)
     const DRing& ring = d.ring[it % RING];
     VNR_HIP_CHECK(hipStreamWaitEvent(d.sc, d.ev(d.ev_e, it), 0));
     const uint32_t blocks = std::min<uint32_t>(div_round_up(d.p.n_local, 256), 2048u);
-    compose_kernel<<<blocks, 256, f.shmem_compose, d.sc>>>(d.p, d.rays, ring, d.host, it);
+    static const uint32_t cap8 = [] { const char* e = std::getenv("VNR_AMD_DECOUPLED_BLOCKS"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 8192u; }();
+    if (f.lanes == 8) compose8_kernel<<<std::min<uint32_t>(div_round_up(d.p.n_local, 64), cap8), 512, f.shmem_compose, d.sc>>>(d.p, d.rays, ring, d.host, it);
+    else compose_kernel<<<blocks, 256, f.shmem_compose, d.sc>>>(d.p, d.rays, ring, d.host, it);
     VNR_HIP_CHECK(hipGetLastError());
     VNR_HIP_CHECK(hipEventRecord(d.ev(d.ev_c, it), d.sc));
     ++d.it_c;

@@ -142,6 +142,7 @@ private:
   // CU gracefully, so taking the walks off the chain pays only where the GPU is mostly idle.  Look-ahead of the walks in batches
   // (VNR_AMD_DECOUPLED_AHEAD: 1 = walk, evaluate, compose in turn; default 3); ray parts (VNR_AMD_DECOUPLED_PARTS, default 1)
   int decoupled_mode_ = 1, decoupled_ahead_ = 3, decoupled_parts_ = 1;
+  int decoupled_lanes_ = 1;   // lanes per ray of the walk / compose kernels (1: walk_kernel / compose_kernel; 8: walk8_kernel / compose8_kernel, measured slower: DESIGN 4.2b)
   uint32_t decoupled_predicted_[kMaxParts] = {};
   hipStream_t d_streams_[kMaxParts][3] = {};           // walk, evaluate, compose
   DeviceBuffer<uint32_t> d_words_[2];                  // per frame slot: ray state, batch records, counters

@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 k = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows]
 k.sort()
 # frames start with a march_kernel<true, ...> on the main queue; take frame boundaries from the first-half's first march
-firsts = [i for i, r in enumerate(k) if "march_kernel<true" in r[2] or "march_kernel<(bool)1" in r[2] or "walk_kernel<true" in r[2] or "walk_kernel<(bool)1" in r[2]]
+firsts = [i for i, r in enumerate(k) if "march_kernel<true" in r[2] or "march_kernel<(bool)1" in r[2] or "walk_kernel<true" in r[2] or "walk_kernel<(bool)1" in r[2] or "walk8_kernel<true" in r[2] or "walk8_kernel<(bool)1" in r[2]]
 queues = sorted({r[3] for r in k})
 # a frame = from one first-march of the lowest queue to the next
 q0 = k[firsts[0]][3] if firsts else None

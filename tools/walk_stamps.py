@@ -36,7 +36,17 @@ for parts in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "8,16").spl
     check(L.vnrAmdSynchronize())
     L.vnrAmdDebugMarchStamps(out, 1)
     trips = max(out[7], 1)
-    print(f"share 1/{parts}: {trips / n:.0f} wave-trips of walk_kernel<false> per frame; cycles per trip (s_memtime):")
-    for i in range(5):
-        print(f"   {names[i]:44s} {out[i] / trips:10.0f}")
+    if os.environ.get("VNR_AMD_DECOUPLED_LANES", "1") == "8":   # walk8_kernel: a trip is one wave's part (8 rays) of a 64-ray group
+        print(f"share 1/{parts}: {trips / n:.0f} wave-trips of walk8_kernel<false> per frame; cycles per trip (s_memtime):")
+        rows = [("walk (state load + rounds of 8 cells)", out[0]), ("claim (two block barriers, one atomic)", out[1]), ("depth-bin sort (block)", out[2]),
+                ("queue records + dt stores (drained, barrier)", out[3] - out[2]), ("whole trip", out[4]),
+                ("  of the first ray's rounds: DDA copies", out[8]), ("  opacity bound fetched", out[9]), ("  rate + count", out[10]),
+                ("  scan + ballot", out[11]), ("  emit + advance", out[12]), ("  hand-over (7 shuffles)", out[13])]
+        for name, v in rows:
+            print(f"   {name:48s} {v / trips:10.0f}")
+        print(f"   rounds of the wave's first ray per trip          {out[14] / trips:10.2f}")
+    else:
+        print(f"share 1/{parts}: {trips / n:.0f} wave-trips of walk_kernel<false> per frame; cycles per trip (s_memtime):")
+        for i in range(5):
+            print(f"   {names[i]:44s} {out[i] / trips:10.0f}")
     del ren

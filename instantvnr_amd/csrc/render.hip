@@ -473,6 +473,9 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
       }
     };
 
+#if defined(VNR_MARCH_STAMPS)
+    VNR_REALTIME(rt0);
+#endif
     VNR_STAMP(st0);
     if (active) {
       if (FIRST) {
@@ -761,6 +764,15 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     VNR_STAMP_ADD(5, st5, st6);   // ray state + queue records + dt written
     VNR_STAMP_ADD(6, st0, st6);   // the whole trip
     VNR_STAMP_ADD(7, st0, st0 + 1ull);   // trips
+#if defined(VNR_MARCH_STAMPS)
+    if (!FIRST && lane == 0) {   // the longest trip of this group over the launches since the records were cleared (tools/wave_records.py)
+      VNR_REALTIME(rt1);
+      unsigned long long* rec = g_wave_rec[((p.il_part & 7u) << 13) | (group & 8191u)];
+      if (st6 - st0 > rec[7]) {
+        rec[0] = rt0; rec[1] = rt1; rec[2] = st2 - st0; rec[3] = st3 - st2; rec[4] = st4 - st3; rec[5] = st5 - st4; rec[6] = st6 - st5; rec[7] = st6 - st0;
+      }
+    }
+#endif
   }
 }
 

@@ -105,7 +105,7 @@ def _collectives_worker(rank, world, port, q):
     q.put((rank, out))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])   # 8: the world size of the driver's scaling run (one process per GPU of a node)
 def test_shm_transport_collectives(world):
     res = _spawn(_collectives_worker, world)
     n = 700_001
@@ -212,7 +212,7 @@ def _tiles_worker(rank, world, port, q, width, height):
     q.put((rank, bool(np.array_equal(full, want))))
 
 
-@pytest.mark.parametrize("world,width,height", [(2, 64, 48), (2, 40, 36), (3, 24, 100)])  # even division, ragged height, ragged blocks
+@pytest.mark.parametrize("world,width,height", [(2, 64, 48), (2, 40, 36), (3, 24, 100), (8, 1024, 1024), (8, 200, 72)])  # even division, ragged height, ragged blocks, the bench frame on a node, fewer bands than twice the ranks
 def test_frame_shares_gather_and_assemble(world, width, height):
     for rank, ok in _spawn(_tiles_worker, world, width, height):
         assert ok, rank

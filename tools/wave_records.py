@@ -30,6 +30,24 @@ for parts in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "8").split(
     for _ in range(6):
         api.vnrRender(ren); api.vnrRendererMapFrame(ren)
     check(L.vnrAmdSynchronize())
+    if os.environ.get("VNR_AMD_DECOUPLED", "1") == "0":   # the coupled loop: the LONGEST trip of every 64-ray group of march_kernel<false> over a frame
+        out = np.zeros((65536, 8), np.uint64)
+        L.vnrAmdDebugWaveRecords(out.ctypes.data_as(C.c_void_p), 65536, 1)
+        api.vnrRender(ren); api.vnrRendererMapFrame(ren)
+        check(L.vnrAmdSynchronize())
+        L.vnrAmdDebugWaveRecords(out.ctypes.data_as(C.c_void_p), 65536, 0)
+        r = out[out[:, 7] > 0].astype(np.int64)
+        dur = (r[:, 1] - r[:, 0]) / 100.0
+        order = np.argsort(-r[:, 7])
+        print(f"share 1/{parts}, coupled loop: {len(r)} groups; the longest trip of a group lasts (us, percentiles 0 10 50 90 99 100): "
+              + " ".join(f"{np.percentile(dur, q):.1f}" for q in (0, 10, 50, 90, 99, 100)))
+        names = ["state load + compose", "walk + emit to LDS", "compaction + claim", "depth-bin sort", "stores", "whole trip"]
+        for label, sel in (("all groups", order), ("the longest tenth", order[:max(len(order) // 10, 1)]), ("the longest hundredth", order[:max(len(order) // 100, 1)])):
+            print(f"   {label}: cycles, mean per phase")
+            for k, name in enumerate(names):
+                print(f"      {name:24s} {r[sel, 2 + k].mean():9.0f}")
+        del ren
+        continue
     n_rays = fb * fb // parts
     n_rec = n_rays // 64 * (8 if lanes == 8 else 1)
     out = np.zeros((n_rec, 8), np.uint64)

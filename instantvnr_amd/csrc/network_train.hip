@@ -714,6 +714,107 @@ __global__ void adam_kernel(size_t lo, size_t hi, size_t n_matrix, float grad_mu
   params[i] = (half_t)nw;
 }
 
+// The same step with the sweep and the update taken apart.  adam_kernel gives every parameter a thread: 1.1 M waves, each of which loads
+// 128 bytes of gradients and then walks the ~50 instructions of the update for the few lanes whose gradient is not zero (a 65 536-sample
+// batch touches ~12 % of the 70 M parameters): the kernel is bound by instruction issue, 0.32 ms (profiles/r02_train_step_timeline.txt).
+// Here a lane sweeps EIGHT gradients (one 16-byte load, one 16-byte store of zeros where any was set), the wave compacts what it found
+// (offset in the wave's 512 parameters and the gradient's bits, through 2 KB of LDS) and then runs the update on dense lanes: the update
+// path is executed once per 64 TOUCHED parameters instead of once per 64 parameters.  Per parameter the arithmetic is adam_kernel's,
+// statement for statement (bit-identical state and parameters: tests/test_gpu_train.py).
+__global__ void __launch_bounds__(256) adam_compact_kernel(size_t lo, size_t hi, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2,
+                                                           float log2_beta1, float log2_beta2, float epsilon, float l2_reg,
+                                                           OptState* __restrict__ state, half_t* __restrict__ params, half_t* __restrict__ grads)
+{
+  __shared__ uint32_t s_list[4][512];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const size_t a0 = lo & ~(size_t)7;                                   // groups of 8 parameters, aligned to 16 bytes of the gradient blob
+  const size_t wave_base = a0 + ((size_t)blockIdx.x * 256u + wave * 64u) * 8u;
+  const size_t base = wave_base + (size_t)lane * 8u;
+  uint32_t h[4] = {0u, 0u, 0u, 0u};   // the group's 8 gradients (bits)
+  uint32_t mask = 0;                   // parameters of the group to look at: in [lo, hi) and (gradient set, or a matrix weight)
+  if (base < hi) {
+    const bool whole = base >= lo && base + 8u <= hi;
+    if (whole) {
+      const uint4 v = *reinterpret_cast<const uint4*>(grads + base);
+      h[0] = v.x; h[1] = v.y; h[2] = v.z; h[3] = v.w;
+    } else {
+      const uint16_t* g16 = reinterpret_cast<const uint16_t*>(grads);
+      for (uint32_t j = 0; j < 8u; ++j)
+        if (base + j >= lo && base + j < hi) h[j >> 1] |= (uint32_t)g16[base + j] << (16u * (j & 1u));
+    }
+    uint32_t set = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; ++j) {
+      const uint32_t bits = (h[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+      const bool in = whole || (base + j >= lo && base + j < hi);
+      const bool nz = (bits & 0x7fffu) != 0u;                          // raw != 0.0f (a negative zero is a zero)
+      if (in && nz) set |= 1u << j;
+      if (in && (nz || base + j < n_matrix)) mask |= 1u << j;
+    }
+    if (set) {   // clear what was set, for the next step
+      if (whole) *reinterpret_cast<uint4*>(grads + base) = uint4{0u, 0u, 0u, 0u};
+      else {
+        uint16_t* g16 = reinterpret_cast<uint16_t*>(grads);
+        for (uint32_t j = 0; j < 8u; ++j) if (set & (1u << j)) g16[base + j] = 0;
+      }
+    }
+  }
+  // wave compaction
+  const uint32_t cnt = (uint32_t)__popc(mask);
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(incl, d);
+    if ((int)lane >= d) incl += y;
+  }
+  const uint32_t total = __shfl(incl, 63);
+  if (total == 0) return;   // wave-uniform
+  uint32_t pos = incl - cnt;
+  uint32_t* list = s_list[wave];
+#pragma unroll
+  for (uint32_t j = 0; j < 8u; ++j)
+    if (mask & (1u << j)) list[pos++] = ((lane * 8u + j) << 16) | ((h[j >> 1] >> (16u * (j & 1u))) & 0xffffu);
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t t = lane; t < total; t += 64u) {
+    const uint32_t e = list[t];
+    const size_t i = wave_base + (e >> 16);
+    const uint16_t hb = (uint16_t)(e & 0xffffu);
+    half_t raw_h;
+    __builtin_memcpy(&raw_h, &hb, 2);
+    const float raw = (float)raw_h;
+    float gradient = raw * grad_mul;
+    if (i >= n_matrix && gradient == 0.0f) continue;  // untouched hash-grid entries are skipped entirely
+    OptState st = state[i];
+    const float w = st.master;
+    if (i < n_matrix) gradient += l2_reg * w;       // no L2 regularisation for grid parameters
+    const float m = st.m = beta1 * st.m + (1.0f - beta1) * gradient;
+    const float v = st.v = beta2 * st.v + (1.0f - beta2) * (gradient * gradient);
+    const uint32_t step = ++st.step;
+    const float fs = (float)step;
+    const float lr_t = lr * sqrtf(1.0f - __builtin_amdgcn_exp2f(fs * log2_beta2)) / (1.0f - __builtin_amdgcn_exp2f(fs * log2_beta1));
+    const float eff = lr_t / (sqrtf(v) + epsilon);
+    const float nw = w - eff * m;
+    st.master = nw;
+    state[i] = st;
+    params[i] = (half_t)nw;
+  }
+}
+
+static void launch_adam(size_t lo, size_t hi, size_t n_matrix, float grad_mul, float lr, float beta1, float beta2, float epsilon, float l2_reg,
+                        OptState* state, half_t* params, half_t* grads, hipStream_t s)
+{
+  const char* e = std::getenv("VNR_AMD_ADAM_COMPACT");   // (read per step: the two kernels are compared inside one process, tests/test_gpu_train.py)
+  const bool compact = !e || std::atoi(e) != 0;
+  const float l2b1 = (float)std::log2((double)beta1), l2b2 = (float)std::log2((double)beta2);
+  if (compact) {
+    const size_t groups = (hi - (lo & ~(size_t)7) + 7) / 8;
+    adam_compact_kernel<<<div_round_up(groups, 256), 256, 0, s>>>(lo, hi, n_matrix, grad_mul, lr, beta1, beta2, l2b1, l2b2, epsilon, l2_reg, state, params, grads);
+  } else {
+    adam_kernel<<<div_round_up(hi - lo, 256), 256, 0, s>>>(lo, hi, n_matrix, grad_mul, lr, beta1, beta2, l2b1, l2b2, epsilon, l2_reg, state, params, grads);
+  }
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
 // fp16 gradient blob -> a float copy (vnrAmdNeuralVolumeGradients: inspection and tests)
 __global__ void unpack_grads_f16_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n)
 {
@@ -979,11 +1080,8 @@ void Network::optimizer_step(float grad_scale, hipStream_t s)
   if (opt_sharded_)
     throw std::runtime_error("the optimizer state of this volume is sharded over the ranks (vnrAmdNeuralVolumeTrainDataParallel): call "
                              "vnrAmdNeuralVolumeSyncReplicas on every rank before a step that updates all parameters on one rank");
-  adam_kernel<<<div_round_up(n_params_, 256), 256, 0, s>>>(0, n_params_, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1,
-                                                           cfg_.beta2, (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2),
-                                                           cfg_.epsilon, cfg_.l2_reg, opt_state_.ptr,
-                                                           (half_t*)params_f16_.ptr, (half_t*)grads_.ptr);
-  VNR_HIP_CHECK(hipGetLastError());
+  launch_adam(0, n_params_, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1, cfg_.beta2, cfg_.epsilon, cfg_.l2_reg, opt_state_.ptr,
+              (half_t*)params_f16_.ptr, (half_t*)grads_.ptr, s);
   optimizer_finish_step(s);
 }
 
@@ -991,10 +1089,8 @@ void Network::optimizer_step_range(size_t lo, size_t hi, float grad_scale, hipSt
 {
   if (opt_state_.count != n_params_ || grads_.count != n_params_) throw std::runtime_error("optimizer_step_range before forward_backward");
   if (hi > n_params_ || lo >= hi) throw std::runtime_error("optimizer_step_range: invalid parameter range");
-  adam_kernel<<<div_round_up(hi - lo, 256), 256, 0, s>>>(lo, hi, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1, cfg_.beta2,
-                                                        (float)std::log2((double)cfg_.beta1), (float)std::log2((double)cfg_.beta2), cfg_.epsilon,
-                                                        cfg_.l2_reg, opt_state_.ptr, (half_t*)params_f16_.ptr, (half_t*)grads_.ptr);
-  VNR_HIP_CHECK(hipGetLastError());
+  launch_adam(lo, hi, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1, cfg_.beta2, cfg_.epsilon, cfg_.l2_reg, opt_state_.ptr,
+              (half_t*)params_f16_.ptr, (half_t*)grads_.ptr, s);
 }
 
 float* Network::grads_as_f32(hipStream_t s)

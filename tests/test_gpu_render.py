@@ -296,15 +296,15 @@ def test_neural_streaming_matches_oracle(oracle, scene, model):
     assert st["n_rays_hit"] == ost["n_rays_hit"]
     assert img[..., 3].max() > 0.05
     # stated tolerance: network outputs differ by <= 2^-8, which the TFN + compositing can amplify slightly
-    assert psnr(img, want) > 40, psnr(img, want)
+    assert psnr(img, want) > 75, psnr(img, want)       # measured 87.6 - 102.5 dB on the three shapes (round 2's bar was 40 dB)
     l2 = np.sqrt(((img - want) ** 2).sum(-1))
-    assert l2.mean() < 5e-3 and np.quantile(l2, 0.99) < 5e-2
+    assert l2.mean() < 2e-4 and np.quantile(l2, 0.99) < 2e-3
     # the renderer alone: the oracle's marcher fed by the library's network values at the oracle's own sample positions (the network's
     # 2^-8 per sample is tests/test_gpu_network.py's subject): the bar of the ground-truth frames
     want2, _, ost2 = oracle.render_streaming(sc, lambda c: api.neural_inference(nv, c))
     assert st["n_iterations"] == ost2["n_iterations"]
     print(f"\nneural frame {model}: vs oracle network PSNR {psnr(img, want):.1f} dB; compositor alone PSNR {psnr(img, want2):.1f} dB, max |err| {np.abs(img - want2).max():.2e}")
-    assert np.abs(img - want2).max() < 1e-3 and psnr(img, want2) > 70, (float(np.abs(img - want2).max()), psnr(img, want2))
+    assert np.abs(img - want2).max() < 5e-6 and psnr(img, want2) > 130, (float(np.abs(img - want2).max()), psnr(img, want2))   # measured 2.4e-7, 157 dB
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

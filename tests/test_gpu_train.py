@@ -71,6 +71,37 @@ def test_adam_step_matches_restatement(oracle):
     assert np.all(api.neural_gradients(vol) == 0)  # cleared for the next step
 
 
+def test_the_compacting_adam_kernel_gives_the_per_parameter_kernel_s_bits(oracle, monkeypatch):
+    """adam_compact_kernel (a lane sweeps eight gradients, the wave compacts the touched ones, the update runs on dense lanes) against
+    adam_kernel (a thread per parameter): the same parameters bit for bit over five steps on gradients with zeros, negative zeros, the
+    smallest halves and dense runs, and a cleared gradient blob afterwards.  (Ranges [lo, hi) that start and end inside a group of
+    eight are the sharded optimizer's: tests/test_gpu_dist.py compares them with the whole-blob step at world 2 / 3 / 4.)"""
+    import ctypes as C
+    from instantvnr_amd._lib import check, lib
+    L = lib()
+    vols = []
+    for _ in range(2):
+        vol, ocfg, params, n_mlp, info = small_model(oracle, seed=3)
+        vols.append(vol)
+    n = info["n_params"]
+    rng = np.random.default_rng(11)
+    for step in range(5):
+        g = np.zeros(n, np.float32)
+        pick = rng.random(n) < (0.12 if step != 3 else 0.9)
+        g[pick] = rng.normal(0, 1e-2, int(pick.sum())).astype(np.float32)
+        g[rng.integers(0, n, 500)] = -0.0
+        g[rng.integers(0, n, 500)] = 6e-8          # the smallest subnormal half
+        g[n_mlp + 1000:n_mlp + 1600] = 0.25         # a dense run
+        for vol, compact in zip(vols, ("0", "1")):
+            monkeypatch.setenv("VNR_AMD_ADAM_COMPACT", compact)
+            check(L.vnrAmdNeuralVolumeSetGradients(vol.h, g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
+            api.neural_train_end(vol)
+            assert np.all(api.neural_gradients(vol) == 0)
+        pa, pb = (api.neural_get_params_fp16(v).view(np.uint16) for v in vols)
+        assert np.array_equal(pa, pb), (step, int((pa != pb).sum()))
+    assert (pa != params.view(np.uint16)).mean() > 0.3
+
+
 @pytest.fixture(scope="module")
 def trained(oracle):
     import os

@@ -1,6 +1,7 @@
 // renderer.h — MainRenderer equivalent (renderer.{h,cpp}, object.{h,cpp}, framebuffer.h) with the
 // sample-streaming ray marcher (core/renderer/method_raymarching.{h,cu}, dda.h, raytracing.h).
 #pragma once
+#include <vector>
 
 #include <memory>
 
@@ -81,7 +82,7 @@ private:
   struct StreamingFrame;   // render.hip
   void render_streaming(const RenderParams& p, int pass_mode, bool defer = false);   // one iterative_raymarching_loop<MODE> (method_raymarching.cu:931-958)
   void launch_iteration(StreamingFrame& f, int part);
-  void launch_tail(StreamingFrame& f, int part, uint32_t it);
+  void launch_tail(StreamingFrame& f, int part, uint32_t it, hipStream_t s);
   void finish_streaming(StreamingFrame& f);
   // the same loop with the walk decoupled from evaluation and compose (decoupled.h): three kernels per iteration on three streams per
   // ray part, the walks up to `decoupled_ahead_` batches ahead of the composes.  Frames are bit-identical to render_streaming's.
@@ -152,6 +153,16 @@ private:
   size_t d_rays_ = 0; int d_iters_ = 0, d_ring_ = 0;   // what the buffers are sized for
   hipStream_t stream_ = nullptr, part_streams_[kMaxParts] = {};
   hipEvent_t ev_fork_ = nullptr;
+  // Pipelined frames, experiment (VNR_AMD_HEAD_GATE=1 / 2; default 0: the head behind the frame before it, on the part streams): the HEAD of
+  // frame k + 1 (1: ray generation, first batch, its evaluation and packing; 2: the first march only) on streams of its own, released when
+  // frame k has launched the last of its LARGE evaluations (an event in frame k's part streams), so that it runs beside frame k's tail of
+  // small launches instead of behind it.  Bit-identical frames; measured SLOWER (3.74-3.85 against 3.69-3.74 ms per frame,
+  // 0.76-0.92 against 0.57 ms on the 1/8 share).
+  hipStream_t head_streams_[kMaxParts] = {};
+  hipEvent_t ev_fork_head_ = nullptr;
+  int head_gate_mode_ = 0;
+  float head_gate_frac_ = 0.3f;                       // an evaluation is "large" while more than this fraction of the first batch's rays is alive
+  std::vector<uint32_t> alive_hist_[2][kMaxParts];    // alive rays after every march of the last completed frame [pass][part]
 
   // framebuffer: double-buffered device + pinned host (framebuffer.h:7-98)
   DeviceBuffer<vec4f> fb_[2], accumulation_;

@@ -40,6 +40,7 @@ struct RenderParams {
   uint32_t tile_w_log2;                  // tile shape: 2^tile_w_log2 x 2^(6 - tile_w_log2) pixels (8x8, 16x4, 32x2 or 64x1)
   float bin_depth_rcp;                   // 1 / depth of one sample-sorting bin (world units)
   uint32_t tfn_in_lds;                   // the TFN tables fit in the march kernel's LDS
+  uint32_t no_ranks;                     // march_kernel: a sample's rank inside its depth bin is not kept in LDS (2 bytes per sample) but claimed again from the bin's counter
   uint32_t debug_flags;                  // timing ablations only (VNR_AMD_DEBUG_FLAGS): 1 no compose, 2 no TFN, 4 no sort, 8 no DDA walk, 16 no sample records
   vec3f cam_pos, cam_dir, cam_hor, cam_ver;
   affine3f wto;
@@ -424,7 +425,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
   tfn_lds_colors_t lds_colors = nullptr;
   tfn_lds_alphas_t lds_alphas = nullptr;
   if (!FIRST && p.tfn_in_lds) {
-    vec4f* s_colors = (vec4f*)(s_rk + (size_t)p.n_iters * 256);
+    vec4f* s_colors = (vec4f*)(s_rk + (p.no_ranks ? 0 : (size_t)p.n_iters * 256));
     float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
     for (int e = threadIdx.x; e < p.tfn.n_colors; e += blockDim.x) s_colors[e] = p.tfn.colors[e];
     for (int e = threadIdx.x; e < p.tfn.n_alphas; e += blockDim.x) s_alphas[e] = p.tfn.alphas[e];
@@ -699,7 +700,8 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
         const float t = (1.0f - jitter) * t0 + jitter * t1;
         const uint32_t bin = depth_bin(p, t, front);
-        s_rk[j * 256u + tid] = (uint16_t)atomicAdd(&hist[bin], 1u);
+        if (p.no_ranks) atomicAdd(&hist[bin], 1u);   // count only: the slot is claimed from the bin's counter when the record is written
+        else s_rk[j * 256u + tid] = (uint16_t)atomicAdd(&hist[bin], 1u);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -736,7 +738,9 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         const float t0 = s_t0[j * 256u + tid], t1 = s_t1[j * 256u + tid];
         const float t = (1.0f - jitter) * t0 + jitter * t1;  // lerp(jitter, t0, t1), instantvnr_types.h:162-166
         const vec3f c = org + t * dir;
-        const uint32_t g = hist[depth_bin(p, t, front)] + s_rk[j * 256u + tid];  // gather-order slot
+        // gather-order slot: the bin's first slot + the sample's rank in the bin; without stored ranks the bin's counter is the next free slot
+        // (any order of a bin's samples will do: the evaluation of a sample does not depend on its neighbours in the queue)
+        const uint32_t g = p.no_ranks ? atomicAdd(&hist[depth_bin(p, t, front)], 1u) : hist[depth_bin(p, t, front)] + s_rk[j * 256u + tid];
         // one 16-byte record per evaluation: position + the float index of the result arena its value goes to
         if (GRAD) {
           const uint32_t gi = arena_grad_index(p.slot_cap, sb + 64u * j);
@@ -1333,6 +1337,8 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
 {
   if (!Runtime::get().ready()) Runtime::get().init(-1);
   stream_ = Runtime::get().stream;
+  // experiment (tools/two_renderers.py): a renderer whose part-0 chain does not share the runtime's stream with other renderers
+  if (const char* e = std::getenv("VNR_AMD_RENDERER_OWN_STREAM")) if (std::atoi(e) != 0) { VNR_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); own_stream_ = true; }
   if (const char* e = std::getenv("VNR_RM_N_ITERS")) { n_iters_ = std::max(1, std::min(48, std::atoi(e))); n_iters_fixed_ = true; }  // 2.5 KiB of LDS per iteration slot and block
   // streaming mode runs the rays as two halves on two streams (render_streaming); VNR_AMD_RENDER_HALVES=1: one stream
   if (const char* e = std::getenv("VNR_AMD_RENDER_HALVES")) { n_halves_ = std::max(1, std::min(kMaxParts, std::atoi(e))); n_halves_fixed_ = true; }
@@ -1358,6 +1364,7 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
 Renderer::~Renderer()
 {
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (own_stream_) (void)hipStreamDestroy(stream_);
   for (int i = 1; i < kMaxParts; ++i) if (part_streams_[i]) { (void)hipStreamSynchronize(part_streams_[i]); (void)hipStreamDestroy(part_streams_[i]); }
   for (int i = 0; i < kMaxParts; ++i) if (head_streams_[i]) { (void)hipStreamSynchronize(head_streams_[i]); (void)hipStreamDestroy(head_streams_[i]); }
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
@@ -1612,6 +1619,13 @@ void Renderer::render()
   // reference), so a frame assembled from such shares equals the unsharded frame rendered with VNR_RM_N_ITERS=32 bit for bit and
   // the unsharded frame at the default 24 to ~4e-5 on 0.2 % of the pixels (tests/test_gpu_fullsize.py); VNR_RM_N_ITERS pins both.
   p.n_iters = (!n_iters_fixed_ && (distributed_ || il_parts_ > 1) && p.n_local <= 196608u) ? 32 : n_iters_;
+  // A march block stages its batch in LDS: 10 bytes per sample with the depth sort's ranks (83 KB at 32 samples: ONE block per CU), 8 without
+  // them (67 KB: two).  VNR_AMD_MARCH_RANKS=0 drops the ranks (the slot inside a bin is then claimed from the bin's counter when the record
+  // is written; same frames).  Measured on 1/8 .. 1/1 of the bench frame: no difference (profiles/r03_march_ranks.txt), so they stay.
+  {
+    static const int ranks_mode = [] { const char* e = std::getenv("VNR_AMD_MARCH_RANKS"); return e ? std::atoi(e) : 1; }();
+    p.no_ranks = ranks_mode == 0 ? 1u : 0u;
+  }
   // gradient shading (modes 7 / 8)
   p.otw = volume_->transform;
   p.grad_step = {1.0f / (float)p.vol_dims.x, 1.0f / (float)p.vol_dims.y, 1.0f / (float)p.vol_dims.z};  // object.cpp:305
@@ -2093,7 +2107,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
       for (int h = 1; h < H; ++h) VNR_HIP_CHECK(hipStreamWaitEvent(part_streams_[h], ev_fork_, 0));
     }
   }
-  const size_t shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + 16 * sizeof(uint32_t) + (size_t)p_all.n_iters * 256 * sizeof(uint16_t);
+  const size_t shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + 16 * sizeof(uint32_t) + (p_all.no_ranks ? 0 : (size_t)p_all.n_iters * 256 * sizeof(uint16_t));
   const size_t shmem_compose = shmem + (p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0);
   if (shmem_compose > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
   static bool lds_attr_set = false;

@@ -153,6 +153,7 @@ private:
   size_t d_rays_ = 0; int d_iters_ = 0, d_ring_ = 0;   // what the buffers are sized for
   hipStream_t stream_ = nullptr, part_streams_[kMaxParts] = {};
   hipEvent_t ev_fork_ = nullptr;
+  bool own_stream_ = false;
   // Pipelined frames, experiment (VNR_AMD_HEAD_GATE=1 / 2; default 0: the head behind the frame before it, on the part streams): the HEAD of
   // frame k + 1 (1: ray generation, first batch, its evaluation and packing; 2: the first march only) on streams of its own, released when
   // frame k has launched the last of its LARGE evaluations (an event in frame k's part streams), so that it runs beside frame k's tail of

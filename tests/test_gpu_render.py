@@ -96,9 +96,11 @@ def test_frames_do_not_depend_on_n_iters_or_tile_shape(scene, monkeypatch):
     by an ulp where a ray is interrupted inside a macrocell (it resumes at t_min + (t - t_min), as in the reference), which
     tests/test_gpu_fullsize.py measures at 1024 x 1024: max 4e-5, 0.2 % of the pixels"""
     frames = []
-    for n_iters, tile_w in (("16", "8"), ("24", "8"), ("5", "8"), ("16", "32"), ("24", "16"), ("16", "64")):
+    # (ranks: whether the depth sort keeps a sample's rank inside its bin in LDS or claims a slot of the bin again when it writes the record)
+    for n_iters, tile_w, ranks in (("16", "8", "1"), ("24", "8", "0"), ("5", "8", "1"), ("16", "32", "0"), ("24", "16", "1"), ("16", "64", "0"), ("16", "8", "0")):
         monkeypatch.setenv("VNR_RM_N_ITERS", n_iters)
         monkeypatch.setenv("VNR_AMD_TILE_W", tile_w)
+        monkeypatch.setenv("VNR_AMD_MARCH_RANKS", ranks)
         r = make_renderer(scene, scene["sv"])
         api.vnrRender(r)
         frames.append(api.vnrRendererMapFrame(r).copy())

@@ -246,11 +246,11 @@ __global__ void __launch_bounds__(256) compose_kernel(const RenderParams p, cons
   DeviceTfn tfn = p.tfn;
   tfn_lds_colors_t lds_colors = nullptr;
   tfn_lds_alphas_t lds_alphas = nullptr;
+  bool tfn_merged = false;
   if (p.tfn_in_lds) {
     vec4f* s_colors = (vec4f*)s_tfn;
     float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
-    for (int e = threadIdx.x; e < p.tfn.n_colors; e += blockDim.x) s_colors[e] = p.tfn.colors[e];
-    for (int e = threadIdx.x; e < p.tfn.n_alphas; e += blockDim.x) s_alphas[e] = p.tfn.alphas[e];
+    tfn_merged = tfn_tables_to_lds(p.tfn, s_colors, s_alphas, !(p.debug_flags & 32u));
     __syncthreads();
     lds_colors = (tfn_lds_colors_t)s_colors;
     lds_alphas = (tfn_lds_alphas_t)s_alphas;
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) compose_kernel(const RenderParams p, cons
         vec3f crgb[kChunk]; float ca[kChunk];
 #pragma unroll
         for (uint32_t j = 0; j < kChunk; ++j) {
-          if (p.tfn_in_lds) tfn_sample_lds(tfn, lds_colors, lds_alphas, chunk[j].x, crgb[j], ca[j]);   // uniform branch
+          if (p.tfn_in_lds) tfn_sample_lds(tfn, lds_colors, lds_alphas, chunk[j].x, crgb[j], ca[j], tfn_merged);   // uniform branch
           else tfn_sample(tfn, chunk[j].x, crgb[j], ca[j]);
           ca[j] = opacity_correction(p.step_rcp, chunk[j].y, ca[j]);
         }
@@ -630,11 +630,11 @@ __global__ void __launch_bounds__(512) compose8_kernel(const RenderParams p, con
   DeviceTfn tfn = p.tfn;
   tfn_lds_colors_t lds_colors = nullptr;
   tfn_lds_alphas_t lds_alphas = nullptr;
+  bool tfn_merged = false;
   if (p.tfn_in_lds) {
     vec4f* s_colors = s_cls + (size_t)p.n_iters * 64u;
     float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
-    for (int e = threadIdx.x; e < p.tfn.n_colors; e += blockDim.x) s_colors[e] = p.tfn.colors[e];
-    for (int e = threadIdx.x; e < p.tfn.n_alphas; e += blockDim.x) s_alphas[e] = p.tfn.alphas[e];
+    tfn_merged = tfn_tables_to_lds(p.tfn, s_colors, s_alphas, !(p.debug_flags & 32u));
     lds_colors = (tfn_lds_colors_t)s_colors;
     lds_alphas = (tfn_lds_alphas_t)s_alphas;
   }
@@ -657,7 +657,7 @@ __global__ void __launch_bounds__(512) compose8_kernel(const RenderParams p, con
       for (uint32_t j = s; j < sc; j += 8u) {
         const vec2f vd = vd_in[sb + 64u * j];   // {value, t1 - t0}
         vec3f rgb; float a;
-        if (p.tfn_in_lds) tfn_sample_lds(tfn, lds_colors, lds_alphas, vd.x, rgb, a);   // uniform branch
+        if (p.tfn_in_lds) tfn_sample_lds(tfn, lds_colors, lds_alphas, vd.x, rgb, a, tfn_merged);   // uniform branch
         else tfn_sample(tfn, vd.x, rgb, a);
         a = opacity_correction(p.step_rcp, vd.y, a);
         s_cls[j * 64u + rl] = {rgb.x, rgb.y, rgb.z, a};

@@ -41,7 +41,7 @@ struct RenderParams {
   float bin_depth_rcp;                   // 1 / depth of one sample-sorting bin (world units)
   uint32_t tfn_in_lds;                   // the TFN tables fit in the march kernel's LDS
   uint32_t no_ranks;                     // march_kernel: a sample's rank inside its depth bin is not kept in LDS (2 bytes per sample) but claimed again from the bin's counter
-  uint32_t debug_flags;                  // timing ablations only (VNR_AMD_DEBUG_FLAGS): 1 no compose, 2 no TFN, 4 no sort, 8 no DDA walk, 16 no sample records
+  uint32_t debug_flags;                  // timing ablations only (VNR_AMD_DEBUG_FLAGS): 1 no compose, 2 no TFN, 4 no sort, 8 no DDA walk, 16 no sample records, 32 separate colour / opacity lookups
   vec3f cam_pos, cam_dir, cam_hor, cam_ver;
   affine3f wto;
   vec3i vol_dims;
@@ -424,11 +424,11 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
   constexpr bool GRAD = MODE == M_GRADIENT;
   tfn_lds_colors_t lds_colors = nullptr;
   tfn_lds_alphas_t lds_alphas = nullptr;
+  bool tfn_merged = false;
   if (!FIRST && p.tfn_in_lds) {
     vec4f* s_colors = (vec4f*)(s_rk + (p.no_ranks ? 0 : (size_t)p.n_iters * 256));
     float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
-    for (int e = threadIdx.x; e < p.tfn.n_colors; e += blockDim.x) s_colors[e] = p.tfn.colors[e];
-    for (int e = threadIdx.x; e < p.tfn.n_alphas; e += blockDim.x) s_alphas[e] = p.tfn.alphas[e];
+    tfn_merged = tfn_tables_to_lds(p.tfn, s_colors, s_alphas, !(p.debug_flags & 32u));
     __syncthreads();
     lds_colors = (tfn_lds_colors_t)s_colors;
     lds_alphas = (tfn_lds_alphas_t)s_alphas;
@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
 #pragma unroll
           for (uint32_t j = 0; j < kChunk; ++j) {
             if (p.debug_flags & 2u) { crgb[j] = {0.5f, 0.5f, 0.5f}; ca[j] = chunk[j].x * 0.01f; }
-            else if (p.tfn_in_lds) tfn_sample_lds(tfn, lds_colors, lds_alphas, chunk[j].x, crgb[j], ca[j]);   // uniform branch
+            else if (p.tfn_in_lds) tfn_sample_lds(tfn, lds_colors, lds_alphas, chunk[j].x, crgb[j], ca[j], tfn_merged);   // uniform branch
             else tfn_sample(tfn, chunk[j].x, crgb[j], ca[j]);
             ca[j] = opacity_correction(p.step_rcp, chunk[j].y, ca[j]);
           }

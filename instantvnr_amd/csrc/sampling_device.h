@@ -83,9 +83,23 @@ __device__ __forceinline__ void tfn_sample(const DeviceTfn& tfn, float value, ve
 typedef float tfn_float4_t __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) tfn_float4_t* tfn_lds_colors_t;
 typedef const __attribute__((address_space(3))) float* tfn_lds_alphas_t;
-__device__ __forceinline__ void tfn_sample_lds(const DeviceTfn& tfn, tfn_lds_colors_t colors, tfn_lds_alphas_t alphas, float value, vec3f& rgb, float& alpha)
+// `merged` (uniform; the caller's LDS copy of the colour table carries the opacity table in its 4th component, which it can when the two
+// tables have the same length: tfn_tables_to_lds): one index / weight computation and one pair of 16-byte reads per sample instead of two of
+// each; the same operations on the same operands as the separate lookups.
+__device__ __forceinline__ void tfn_sample_lds(const DeviceTfn& tfn, tfn_lds_colors_t colors, tfn_lds_alphas_t alphas, float value, vec3f& rgb, float& alpha,
+                                               bool merged = false)
 {
   const float v = (clampf(value, tfn.range_lo, tfn.range_hi) - tfn.range_lo) * tfn.range_rcp_norm;
+  if (merged) {
+    int i0, i1; float a;
+    tfn_coords(tfn.n_colors, v, i0, i1, a);
+    const tfn_float4_t c0 = colors[i0], c1 = colors[i1];
+    rgb.x = c0.x * (1.0f - a) + c1.x * a;
+    rgb.y = c0.y * (1.0f - a) + c1.y * a;
+    rgb.z = c0.z * (1.0f - a) + c1.z * a;
+    alpha = c0.w * (1.0f - a) + c1.w * a;
+    return;
+  }
   if (tfn.n_colors > 0) {
     int i0, i1; float a;
     tfn_coords(tfn.n_colors, v, i0, i1, a);
@@ -103,6 +117,19 @@ __device__ __forceinline__ void tfn_sample_lds(const DeviceTfn& tfn, tfn_lds_col
   } else {
     alpha = 0.0f;
   }
+}
+
+// the block's copy of the transfer function tables (the caller synchronises); returns whether the colour table carries the opacities
+__device__ __forceinline__ bool tfn_tables_to_lds(const DeviceTfn& tfn, vec4f* s_colors, float* s_alphas, bool allow_merged = true)
+{
+  const bool merged = allow_merged && tfn.n_colors == tfn.n_alphas && tfn.n_colors > 0;
+  for (int e = threadIdx.x; e < tfn.n_colors; e += blockDim.x) {
+    vec4f c = tfn.colors[e];
+    if (merged) c.w = tfn.alphas[e];
+    s_colors[e] = c;
+  }
+  for (int e = threadIdx.x; e < tfn.n_alphas; e += blockDim.x) s_alphas[e] = tfn.alphas[e];
+  return merged;
 }
 
 }  // namespace vnr

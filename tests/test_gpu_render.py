@@ -90,6 +90,34 @@ def test_streaming_groundtruth_matches_oracle(oracle, scene):
     assert st["n_samples"] > 0.5 * ost["n_samples"]
 
 
+@pytest.mark.parametrize("n_colors,n_alphas", [(256, 256), (64, 100), (300, 17)])
+def test_transfer_function_tables_of_equal_and_of_different_lengths(oracle, scene, n_colors, n_alphas):
+    """the compose kernels keep the tables in LDS; when the colour and the opacity table have the same length the opacities ride in the colour
+    table's 4th component and a sample takes one index computation and one pair of reads (sampling_device.h tfn_sample_lds `merged`), else
+    two of each: the same frame as the oracle's either way, for the coupled and the decoupled loop"""
+    colors, _ = syn.tfn_ramp_with_bumps(n=n_colors)
+    _, alphas = syn.tfn_ramp_with_bumps(n=n_alphas)
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    mo = None
+    for size in ((96, 80), (200, 144)):   # (the small frame takes the decoupled loop)
+        r = api.vnrCreateRenderer(scene["sv"])
+        api.vnrRendererSetTransferFunction(r, tfn)
+        api.vnrRendererSetCamera(r, scene["camera"])
+        api.vnrRendererSetFramebufferSize(r, size)
+        api.vnrRender(r)
+        img = api.vnrRendererMapFrame(r).copy()
+        if mo is None:
+            mo = api.volume_macrocell(scene["sv"])["max_opacity"]
+        cam = scene["cam"]
+        sc = oracle.SceneHolder(size[0], size[1], (48, 48, 48), oracle.TfnHolder(colors, alphas), mo, cam["from"], cam["at"], cam["up"], cam["fovy"])
+        want, _, _ = oracle.render_streaming(sc, lambda c: oracle.sample_volume(scene["vol"], c, nodal=True))
+        assert (img[..., 3] > 0).mean() > 0.02
+        assert np.abs(img - want).max() < 2e-4, (size, float(np.abs(img - want).max()))
+
+
 def test_frames_do_not_depend_on_n_iters_or_tile_shape(scene, monkeypatch):
     """the batch size of the streaming loop (VNR_RM_N_ITERS; library default 24, reference default 16) and the shape of the ray
     tiles are scheduling choices.  On this scene the frames are the same bit for bit; in general the batch size moves a sample

@@ -361,11 +361,16 @@ __device__ __forceinline__ void iter_exec(const RenderParams& p, DDAState& it, v
     if (!(fabsf(r) <= FLT_EPSILON)) {
       const float ss = adaptive_sampling_rate(step, r);
       float tx = cell_t0, ty = fminf(cell_t1, cell_t0 + ss);
-      while (ty > tx) {
+      // (one exit: `while (ty > tx) { ...; if (!body(tx, ty)) { go = false; break; } ... }` written so that the loop's divergent lanes
+      // rejoin in one place: 20 instructions and one branch per sample instead of 30 and three; what is computed once more after a full
+      // batch, tx and ty, is not read again.  The frame did not notice: 3.65-3.72 against 3.67-3.68 ms, n = 3)
+      bool run = ty > tx;
+      while (run) {
         it.next_cell_begin = ty - t_min;
-        if (!body(tx, ty)) { go = false; break; }
+        go = body(tx, ty);
         tx = ty;
         ty = fminf(tx + ss, cell_t1);
+        run = go && ty > tx;
       }
     }
     const bool adv = go || fmaxf(t_min + it.next_cell_begin, t_min) >= cell_t1;

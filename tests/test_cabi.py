@@ -143,6 +143,20 @@ def test_no_cpu_fallback_without_device(L):
                                   (8, 8, 8))
 
 
+def test_bench_and_smoke_fail_loudly_without_a_device(L):
+    """bench.py and __graft_entry__.smoke() are the product path: without a GPU they end with the library's error, not with numbers from a
+    CPU stand-in (the oracle is reachable from bench.py only as the `cpu_baseline` leg, after the timed region)"""
+    if L.vnrAmdHasDevice():
+        pytest.skip("a GPU is present")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "no HIP capable devices" in out.stderr and not any(line.startswith("{") for line in out.stdout.splitlines())
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "smoke ok" not in out.stdout
+
+
 def _build_and_run_shim_smoke(tmp_path):
     import shutil
     import subprocess

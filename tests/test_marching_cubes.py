@@ -59,11 +59,27 @@ def test_sphere_vertices_lie_on_the_sphere():
     verts = mc_oracle.marching_cubes(r, 10.3)          # inside = r <= 10.3 (no node lies exactly on the surface)
     d = np.sqrt(((verts - 0.5 - 16) ** 2).sum(1))      # the reference offsets vertices by + 0.5 (core/marching_cube.cu:245)
     assert verts.shape[0] > 3000 and np.abs(d - 10.3).max() < 0.08
-    # outward orientation: normals point from inside (<= iso) to outside
+    # the reference's winding (its case table, core/marching_cube_constants.cuh, compared case by case in tools/mc_table_vs_reference.py): the
+    # right-hand normal of (v0, v1, v2) points from the outside to the inside (<= iso), here towards the sphere's centre
     tri = verts.reshape(-1, 3, 3)
     nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
     ctr = tri.mean(1) - 0.5 - 16
-    assert ((nrm * ctr).sum(1) > 0).mean() > 0.999 and not ((nrm * ctr).sum(1) < 0).any()
+    assert ((nrm * ctr).sum(1) < 0).mean() > 0.999 and not ((nrm * ctr).sum(1) > 0).any()
+
+
+def test_the_derived_case_table_is_the_reference_s_surface_case_by_case():
+    """tools/mc_table_vs_reference.py: where the reference's sources are present (this container, not the GPU box) its hand-made case table
+    is read as text and compared with the table this library derives: in all 256 cases the triangles meet the cell's faces in the same
+    directed segments (same topology, same resolution of the 120 ambiguous cases, same winding) and are equally many"""
+    import os
+    import subprocess
+    import sys
+    if not os.path.exists("/root/reference/core/marching_cube_constants.cuh"):
+        pytest.skip("the reference's sources are not on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "mc_table_vs_reference.py")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "256 of 256 cases: the same directed face segments and the same number of triangles" in out.stdout, out.stdout[-800:]
+    assert "reference [False, False, False, False, False, False, False, False], here [False, False, False, False, False, False, False, False]" in out.stdout
 
 
 @pytest.mark.gpu

@@ -8,7 +8,13 @@ is constructed from first principles and gives the same kind of surface: for eac
      with two diagonally opposite corners inside (<= isovalue) is AMBIGUOUS and is resolved by one fixed rule, "inside corners are cut off
      separately", which depends on the face's four signs only, so the two cells that share a face agree and the surface is watertight;
   2. the segments of the six faces chain into closed loops over the cut edges (every cut edge lies on exactly two faces);
-  3. every loop is oriented so that its normal points from the inside (<= isovalue) to the outside and is cut into a triangle fan.
+  3. every loop is oriented like the reference's triangles (right-hand normal pointing from the outside to the inside, <= isovalue) and is
+     cut into a triangle fan.
+
+tools/mc_table_vs_reference.py (development time, this container: it reads the reference's table as text) compares the result with the
+reference's hand-made table case by case: in all 256 cases, the 120 with an ambiguous face included, the triangles meet the faces of the
+cell in the same DIRECTED segments and there are equally many of them: the same surface, the same winding, crack-free against a neighbour
+triangulated by either table; only the way a loop's interior is cut into triangles may differ.
 
 Numbering: corner i has offset (i & 1, (i >> 1) & 1, (i >> 2) & 1); edge e of EDGES joins two corners.  A case has at most 4 loops and
 12 cut edges; no case needs more than 5 triangles (16 table elements per case with the terminator, like the classic table).
@@ -81,14 +87,14 @@ def case_triangles(case):
             loop.append(nxt); seen.add(nxt)
             prev, cur = cur, nxt
         loops.append(loop)
-    # 3. orientation + fan.  Edge midpoints stand in for the vertices; the normal must point away from the inside corners of the loop's edges
+    # 3. orientation + fan.  Edge midpoints stand in for the vertices; the normal points towards the inside corners of the loop's edges
     tris = []
     for loop in loops:
         pts = np.array([(np.array(CORNERS[EDGES[e][0]]) + np.array(CORNERS[EDGES[e][1]])) / 2.0 for e in loop])
         centre = pts.mean(0)
         normal = sum(np.cross(pts[k] - centre, pts[(k + 1) % len(loop)] - centre) for k in range(len(loop)))
         ins = np.array([CORNERS[a] if inside[a] else CORNERS[b] for a, b in (EDGES[e] for e in loop)], float).mean(0)
-        if np.dot(normal, centre - ins) < 0:
+        if np.dot(normal, centre - ins) > 0:   # the reference's winding: the normal of (v0, v1, v2) points TOWARDS the inside (<= isovalue) corners
             loop = loop[::-1]
         for k in range(1, len(loop) - 1):
             tris.append((loop[0], loop[k], loop[k + 1]))

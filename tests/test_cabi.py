@@ -143,6 +143,24 @@ def test_no_cpu_fallback_without_device(L):
                                   (8, 8, 8))
 
 
+def test_constants_taken_from_the_reference_are_still_what_the_reference_says(L):
+    """tools/reference_constants_audit.py, where the reference's sources are present (this container, not the GPU box): 22 constants and
+    defaults (ray termination, empty-cell test, adaptive step, macrocell size, batch size, sampler seed, default mode, out-of-core slab
+    counts, the example model's optimizer) are found by pattern on both sides; and the reference's own example-model.json, // comments and
+    all, goes through this library's JSON reader"""
+    import subprocess
+    import sys
+    if not os.path.exists("/root/reference/example-model.json"):
+        pytest.skip("the reference's sources are not on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "reference_constants_audit.py")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "22 of 22 constants agree" in out.stdout, out.stdout[-1500:]
+    model = api.vnrCreateJsonText("/root/reference/example-model.json")
+    assert model["encoding"]["otype"] == "HashGrid" and model["encoding"]["n_levels"] == 8 and model["encoding"]["log2_hashmap_size"] == 19
+    assert model["network"] == {"otype": "FullyFusedMLP", "activation": "ReLU", "n_neurons": 64, "n_hidden_layers": 4, "output_activation": "None"}
+    assert model["loss"]["otype"] == "L1" and model["optimizer"]["nested"]["otype"] == "Adam"
+
+
 def test_bench_and_smoke_fail_loudly_without_a_device(L):
     """bench.py and __graft_entry__.smoke() are the product path: without a GPU they end with the library's error, not with numbers from a
     CPU stand-in (the oracle is reachable from bench.py only as the `cpu_baseline` leg, after the timed region)"""

@@ -161,6 +161,19 @@ def test_constants_taken_from_the_reference_are_still_what_the_reference_says(L)
     assert model["loss"]["otype"] == "L1" and model["optimizer"]["nested"]["otype"] == "Adam"
 
 
+def test_the_shim_defines_every_declaration_of_the_reference_s_api_h():
+    """tools/api_surface_vs_reference.py, where the reference's api.h is present: each of its declarations (name, parameter types, return type;
+    namespace prefixes, parameter names and defaults dropped) has a definition in include/vnr_api_shim.hpp"""
+    import subprocess
+    import sys
+    if not os.path.exists("/root/reference/api.h"):
+        pytest.skip("the reference's sources are not on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "api_surface_vs_reference.py")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "59 of 59 declarations have a definition with the same parameter types" in out.stdout, out.stdout[-1500:]
+    assert "59 of 59 declarations have the same return type too" in out.stdout
+
+
 def test_bench_and_smoke_fail_loudly_without_a_device(L):
     """bench.py and __graft_entry__.smoke() are the product path: without a GPU they end with the library's error, not with numbers from a
     CPU stand-in (the oracle is reachable from bench.py only as the `cpu_baseline` leg, after the timed region)"""

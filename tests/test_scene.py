@@ -2,6 +2,7 @@
 and the value range of a scene's transfer function.  The expected values are worked out by hand from the reference's loader;
 the host-only parts run without a GPU."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -285,3 +286,15 @@ def test_vnr_cmd_render_command_line(tmp_path):
     shot_nn = _read_png_rgba(tmp_path / "nn-screenshot.png")
     err = shot_nn[..., :3].astype(np.float32) - shot[..., :3].astype(np.float32)
     assert 10 * np.log10(255.0 ** 2 / float((err ** 2).mean())) > 20.0    # 200 steps of a 4-level model: the same picture, roughly
+
+
+def test_every_key_of_the_reference_s_scene_reader_is_read_here_or_explained():
+    """tools/scene_keys_vs_reference.py, where the reference's serializer.cpp is present: its JSON keys and enumeration strings against
+    csrc/scene.cpp's"""
+    import subprocess
+    import sys
+    if not os.path.exists("/root/reference/serializer.cpp"):
+        pytest.skip("the reference's sources are not on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "scene_keys_vs_reference.py")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "UNEXPLAINED" not in out.stdout, out.stdout

@@ -46,5 +46,22 @@ for k, v in want.items():
     ok = m is not None and abs(float(m.group(1)) - float(v)) <= 1e-12 * max(1.0, abs(float(v)))
     bad += not ok
     print(f"{'ok ' if ok else 'BAD'} optimizer default {k}: example-model.json {v}, network.h {m.group(1) if m else 'not found'}")
-print(f"{len(ROWS) + len(want) - bad} of {len(ROWS) + len(want)} constants agree")
+# params.json: the keys network.cu:827-939 writes and reads, against every string of this library's sources
+import glob  # noqa: E402
+
+
+def literals(text):
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return set(re.findall(r'"([A-Za-z_][\w .\-]*)"', re.sub(r"//[^\n]*", " ", text)))
+
+
+ref_keys = literals("\n".join(open(os.path.join(REF, "core/network.cu")).read().split("\n")[820:945]))
+ref_keys -= {"saving parameters to ", "total time", "mismatch macrocell dimension or spacing"}   # two log lines and a printf (the library compares the macrocell too: tests/test_cabi.py)
+mine = set()
+for f in glob.glob(os.path.join(ROOT, CS, "*.hip")) + glob.glob(os.path.join(ROOT, CS, "*.cpp")) + glob.glob(os.path.join(ROOT, CS, "*.h")):
+    mine |= literals(open(f).read())
+lack = sorted(ref_keys - mine)
+bad += len(lack)
+print(f"{'ok ' if not lack else 'BAD'} params.json: {len(ref_keys)} keys and messages of network.cu:827-939, {len(ref_keys) - len(lack)} of them in this library's sources" + (f"; missing {lack}" if lack else ""))
+print(f"{len(ROWS) + len(want) - min(bad, len(ROWS) + len(want))} of {len(ROWS) + len(want)} constants agree")
 sys.exit(1 if bad else 0)

@@ -68,4 +68,19 @@ for s_, a, b in ret_diff:
 print(f"{len(ref) - len(missing) - len(ret_diff)} of {len(ref)} declarations have the same return type too")
 hard += ret_diff
 print(f"{len(ref) - len(missing)} of {len(ref)} declarations have a definition with the same parameter types; {len(hard)} have none with that name and arity")
+
+
+# the enumerations of api.h (rendering modes, value types): the same enumerators in the same order
+def enums(text):
+    out = {}
+    for m in re.finditer(r"\benum\s+(?:class\s+)?(\w+)\s*(?::\s*\w+\s*)?\{([^}]*)\}", strip(text)):
+        out[m.group(1)] = [e.split("=")[0].strip() for e in m.group(2).split(",") if e.strip()]
+    return out
+
+
+ref_e, shim_e = enums(open(REF).read()), enums(open(os.path.join(ROOT, "include", "vnr_api_shim.hpp")).read())
+for name, items in ref_e.items():
+    ok = shim_e.get(name) == items
+    hard += [] if ok else [name]
+    print(f"{'ok ' if ok else 'BAD'} enum {name}: {len(items)} enumerators" + ("" if ok else f"; here {shim_e.get(name)}"))
 sys.exit(1 if hard else 0)

@@ -88,3 +88,17 @@ def test_plugin_frames_equal_the_api_s_frames(tmp_path):
 
 import ctypes as _C   # noqa: E402
 C_float12 = _C.c_float * 12
+
+
+def test_the_uncompiled_half_uses_only_names_the_reference_s_plugin_uses():
+    """tools/ovr_adapter_vs_reference.py, where the reference's device/ sources are present: the OVR-facing half of the adapter cannot be
+    compiled in this image, so every OVR-side identifier in it is at least looked up in the reference's own plugin"""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference/device"):
+        pytest.skip("the reference's sources are not on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "ovr_adapter_vs_reference.py")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "unknown" not in out.stdout, out.stdout

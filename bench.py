@@ -379,6 +379,9 @@ def main():
         roofline["union"] = {"what": "algorithmic bytes of all launches / the time during which at least one launch of the kernel was "
                                      "running (union of the HIP-event intervals of both streams): overlapping launches count once",
                              "achieved": round(u, 1), "frac": round(u / HBM_PEAK_GBS, 4), "ms_per_frame": round(union_ms / evt_frames, 4)}
+        # beside `frac` (per launch, HIP events of ONE stream: two streams' launches overlap and are counted twice there): the same bytes
+        # over the time during which the kernel was running at all.  This is the figure to read the kernel by.
+        roofline["union_frac"] = roofline["union"]["frac"]
     if alone and alone["ms"] > 0:
         ev = alone["samples"] * evals_per_sample
         a_gbs = ev * bytes_per_sample / (alone["ms"] * 1e-3) / 1e9

@@ -140,6 +140,7 @@ def lib():
     sig("vnrAmdNeuralVolumeEncode", I, P, SZ, P, P, P)
     sig("vnrAmdNeuralVolumeBrickImageInfo", I, P, IP, C.POINTER(SZ), FP)
     sig("vnrAmdNeuralVolumeGetInfo", I, P, IP, IP, IP, IP, IP, C.POINTER(U64))
+    sig("vnrAmdNeuralVolumeGetModelKind", I, P, IP, IP, IP, IP, IP, IP)
     sig("vnrAmdNeuralVolumeGetParamsFP16", I, P, P, SZ)
     sig("vnrAmdNeuralVolumeSetParamsFP16", I, P, P, SZ)
     sig("vnrAmdNeuralVolumeTrainBegin", I, P)

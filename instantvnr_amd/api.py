@@ -586,6 +586,9 @@ def neural_info(v):
     keys = ["n_levels", "n_features_per_level", "padded_width", "n_neurons", "n_hidden_layers"]
     d = {k: x.value for k, x in zip(keys, vals)}
     d["n_params"] = n.value
+    kind = [C.c_int() for _ in range(6)]
+    check(lib().vnrAmdNeuralVolumeGetModelKind(v.h, *[C.byref(x) for x in kind]))
+    d.update({k: x.value for k, x in zip(["activation", "output_activation", "grid_type", "interpolation", "mfma_kernels", "mfma_training_kernels"], kind)})
     return d
 
 

@@ -567,6 +567,20 @@ int vnrAmdNeuralVolumeBrickImageInfo(vnrAmdVolume v, int* in_use, size_t* bytes,
     if (build_ms) *build_ms = n.brick_build_ms();
   });
 }
+int vnrAmdNeuralVolumeGetModelKind(vnrAmdVolume v, int* activation, int* output_activation, int* grid_type, int* interpolation, int* mfma_inference,
+                                   int* mfma_training)
+{
+  return guarded([&]() {
+    Network& n = as_neural(v)->network();
+    if (activation) *activation = (int)n.config().activation;
+    if (output_activation) *output_activation = (int)n.config().output_activation;
+    if (grid_type) *grid_type = (int)n.config().grid_type;
+    if (interpolation) *interpolation = (int)n.config().interpolation;
+    if (mfma_inference) *mfma_inference = n.fast_path() ? 1 : 0;
+    if (mfma_training) *mfma_training = n.fast_train_path() ? 1 : 0;
+  });
+}
+
 int vnrAmdNeuralVolumeGetInfo(vnrAmdVolume v, int* n_levels, int* n_features, int* padded_width, int* n_neurons,
                               int* n_hidden_layers, uint64_t* n_params)
 {

@@ -46,11 +46,20 @@ __device__ __forceinline__ CornerSetup level_setup(const LevelInfo& lv, uint32_t
 }
 
 // entry index (not yet multiplied by F) of corner (px,py,pz) in level lv; exact `% size` semantics
+// lv.hashed: 0 = dense over all three dimensions (Hash levels that fit their table, Dense grids), 1 = prime-XOR hash,
+// 2 / 3 / 4 = Tiled grid whose stride walk stopped after 1 / 2 / 3 dimensions (EXTERNAL tcnn grid_index: the walk ends as soon as the
+// stride exceeds the level's size, and only a Hash grid replaces the partial sum by the hash; the sum is then taken modulo the size)
 __device__ __forceinline__ uint32_t level_index(const LevelInfo& lv, uint32_t px, uint32_t py, uint32_t pz)
 {
-  if (lv.hashed) {
+  if (lv.hashed == 1u) {
     // size is a power of two whenever a level is hashed
     return (px ^ (py * 2654435761u) ^ (pz * 805459861u)) & (lv.size - 1u);
+  }
+  if (lv.hashed >= 2u) {
+    uint32_t idx = px;
+    if (lv.hashed >= 3u) idx += py * lv.resolution;
+    if (lv.hashed >= 4u) idx += pz * (lv.resolution * lv.resolution);
+    return idx % lv.size;
   }
   uint32_t idx = px + py * lv.resolution + pz * (lv.resolution * lv.resolution);
   if (idx >= lv.size) {
@@ -174,13 +183,21 @@ __device__ __noinline__ uint8x32_t level_indices_exact(const LevelInfo lv, uint3
   return idx;
 }
 
-template <int F>
+// GENERAL (here and below): the instance also covers what only the rarer models need: Tiled grid levels, Nearest interpolation (and, in
+// infer_tile.h, the transcendental activations).  The instances without it are the instruction stream of the common models (Hash / Dense
+// grid, Linear / Smoothstep, ReLU / None) and nothing else: with everything in one kernel the evaluation kernel of the bench model grew from
+// 5 213 to 23 993 instructions and lost 8 % of its rate (instruction cache), although none of the added code ever ran.
+template <int F, bool GENERAL = false>
 __device__ __forceinline__ void gather_corners(const LevelInfo& lv, const CornerSetup& c, table_rsrc_t rsrc,
                                                typename RawFeat<F>::raw_t (&v)[8])
 {
   constexpr uint32_t kBytes = (uint32_t)(F * 2);
   const uint32_t soff = lv.offset * kBytes;
-  if (lv.hashed) {
+  if (GENERAL && lv.hashed >= 2u) {   // Tiled grid level (wave-uniform): the exact index of every corner, out of line
+    const uint8x32_t idx = level_indices_exact(lv, c.g[0], c.g[1], c.g[2]);
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) v[corner] = RawFeat<F>::load(rsrc, idx[corner] * kBytes, soff);
+  } else if (lv.hashed) {
     const uint32_t mask = lv.size - 1u;
     const uint32_t hy0 = c.g[1] * 2654435761u, hy1 = hy0 + 2654435761u;
     const uint32_t hz0 = c.g[2] * 805459861u, hz1 = hz0 + 805459861u;
@@ -364,14 +381,24 @@ __device__ __forceinline__ void blend_level(const float (&wd)[3], const typename
   }
 }
 
-template <int F>
+template <int F, bool GENERAL = false>
 __device__ __forceinline__ void encode_level_fast(const LevelInfo& lv, uint32_t interpolation, table_rsrc_t rsrc, const uint8_t* image,
                                                   float x, float y, float z, half_t* out)
 {
   typedef typename RawFeat<F>::raw_t raw_t;
   const CornerSetup c = level_setup(lv, interpolation, x, y, z);
+  if (GENERAL && interpolation == 2u) {   // Nearest (tcnn_impl_decoder.cu:73-94): the entry of the lower corner as it is, one gather
+    const raw_t one = RawFeat<F>::load(rsrc, level_index(lv, c.g[0], c.g[1], c.g[2]) * (uint32_t)(F * 2), lv.offset * (uint32_t)(F * 2));
+    const typename FeatVec<F>::type vv = __builtin_bit_cast(typename FeatVec<F>::type, one);
+    if constexpr (F == 1) out[0] = vv;
+    else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) out[f] = vv[f];
+    }
+    return;
+  }
   raw_t v[8];
-  if (lv.brick == 0u || !gather_corners_brick<F>(lv, c, image, v)) gather_corners<F>(lv, c, rsrc, v);
+  if (lv.brick == 0u || !gather_corners_brick<F>(lv, c, image, v)) gather_corners<F, GENERAL>(lv, c, rsrc, v);
   if constexpr (F >= 2) {   // the blend of the grouped form: same values, 4 instead of 5-6 instructions per corner and feature pair
     typename FeatVec<F>::type vv[8];
 #pragma unroll

@@ -15,7 +15,8 @@
 namespace vnr {
 
 constexpr int kMaxLevels = 32;
-constexpr int kWidth = 64;        // FullyFusedMLP n_neurons of the MFMA kernels (16 / 32 / 128: generic kernel, inference only)
+constexpr int kWidth = 64;        // FullyFusedMLP n_neurons of the in-shader kernels (in_shader.h); the evaluation kernels cover 16 / 32 / 64 / 128
+constexpr size_t kLdsBytes = 160 * 1024;   // LDS of a CU: what a weight image may take
 constexpr int kLossScale = 128;   // tcnn default loss scale for fp16 (EXTERNAL)
 
 struct LevelInfo {
@@ -24,7 +25,7 @@ struct LevelInfo {
   uint32_t res2;    // resolution^2 (dense index stride of z)
   uint32_t size;    // entries in this level
   uint32_t offset;  // first entry of this level (entries, x F for elements)
-  uint32_t hashed;  // 1: prime-XOR hash (size is a power of two), 0: dense index
+  uint32_t hashed;  // 0: dense index, 1: prime-XOR hash (size is a power of two), 2 / 3 / 4: Tiled grid, index over 1 / 2 / 3 dimensions modulo size
   uint32_t brick;   // 0: read the parameter blob; else 1 + first 128-byte line of this level in the brick image (below)
   uint32_t pad1;    // bricked levels with F = 2: bricks per row of the image (resolution / 7 + 1); else 0.  32 bytes: one s_load_dwordx8 per level
 };
@@ -59,8 +60,10 @@ struct ModelConfig {
   float quantize_threshold = 0.0f;     // corner values below it in magnitude count as 0 (tcnn_impl_decoder.cu:120); tcnn default 0
   float max_level = 1000.0f;           // levels l >= max_level + 1e-3 encode to 0 (tcnn_impl_decoder.cu:17); tcnn default: no masking
   // network (FullyFusedMLP; example-model.json:26-32)
+  uint32_t grid_type = 0;              // 0 Hash, 1 Dense, 2 Tiled (tcnn GridType; tcnn_impl_decoder.cu:68-69 passes it to grid_index)
   uint32_t n_neurons = 64, n_hidden_layers = 4;
-  uint32_t activation = 1;  // 0 None, 1 ReLU
+  uint32_t activation = 1;         // 0 None, 1 ReLU, 2 Exponential, 3 Sigmoid, 4 Squareplus, 5 Softplus (infer_tile.h kAct*; tcnn_impl.cu:405-415)
+  uint32_t output_activation = 0;  // the same set, applied to the fp16 output (tcnn_threadblock.h:497)
   // optimizer (ExponentialDecay{Adam}; example-model.json:2-15)
   float learning_rate = 5e-3f, beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-15f, l2_reg = 1e-6f;
   uint32_t decay_start = 2000, decay_interval = 1000;
@@ -85,6 +88,7 @@ static_assert(sizeof(OptState) == 16, "OptState must be one 16-byte record");
 // so the exchange of one range runs while the backward pass of the next still does.
 struct TileNet;
 struct PackArgs;   // infer_tile.h: what a kernel needs to evaluate the network itself
+struct FusedMlp;   // infer_kernel.h: weight image + shape of a launch
 
 struct GradExchange {
   virtual ~GradExchange() = default;
@@ -106,9 +110,14 @@ public:
   const GridDevice& grid() const { return grid_; }
   uint32_t padded_width() const { return in_width_; }
   uint32_t width() const { return cfg_.n_neurons; }
-  // the MFMA kernels cover n_neurons 64, Linear / Smoothstep, no quantisation; every other model the reference accepts
-  // (n_neurons 16 / 32 / 128, tcnn_impl.cu:315-347; Nearest; quantize_threshold) is evaluated by a generic kernel: inference only
-  bool fast_path() const { return cfg_.n_neurons == (uint32_t)kWidth && cfg_.interpolation != 2u && cfg_.quantize_threshold == 0.0f; }
+  // the MFMA kernels cover every width the reference instantiates (16 / 32 / 64 / 128, tcnn_impl.cu:315-347), every interpolation,
+  // activation and grid type; a model with a quantize_threshold, or whose weight image exceeds the LDS, takes the generic kernels
+  bool fast_path() const { return cfg_.quantize_threshold == 0.0f && (size_t)lds_halves_ * 2 <= kLdsBytes; }
+  // the common kind of model: Hash / Dense grid, Linear / Smoothstep, ReLU / None, no output activation.  Its kernels are instances of their
+  // own that contain nothing else (grid_device.h gather_corners); everything else runs on the GENERAL instances
+  bool common_kind() const { return cfg_.activation <= 1u && cfg_.output_activation == 0u && cfg_.interpolation != 2u && cfg_.grid_type != 2u; }
+  // the training kernels also need the backward image in the LDS of its kernel
+  bool fast_train_path() const { return fast_path() && (size_t)lds_halves_T_ * 2 <= kLdsBytes; }
   uint32_t n_active_levels() const;    // levels below max_level + 1e-3
   uint32_t n_hidden_matmuls() const { return cfg_.n_hidden_layers - 1; }
   size_t n_params() const { return n_params_; }
@@ -145,7 +154,8 @@ public:
   // The gradient of the whole blob, loss-scaled (x 128), in HALF precision like tcnn's (its gradient matrices and, for F > 1, its
   // grid gradients are network_precision_t): the unit of the data-parallel exchange, read and cleared by the optimizer.
   uint16_t* grads_f16() { return grads_.ptr; }
-  size_t grads_count() const { return grads_.count; }
+  size_t grads_count() const { return grads_.count ? n_params_ : 0; }
+  size_t grads_alloc() const { return n_params_ + (n_params_ & 1); }   // halves allocated: the packed atomics add aligned pairs
   float* grads_as_f32(hipStream_t s);   // a float copy for inspection (vnrAmdNeuralVolumeGradients); not an input of anything
   void optimizer_step(float grad_scale, hipStream_t s);
   // the same step in pieces, for gradients that become final range by range (data-parallel exchange, volume.hip):
@@ -204,6 +214,7 @@ private:
   void build_layout();
   void initialize_params(uint64_t seed, hipStream_t s);
   void refresh_inference_weights(hipStream_t s);
+  FusedMlp fused_mlp() const;
   const LevelInfo* inference_levels(hipStream_t s, const uint8_t** image) const;  // decides / builds / orders streams
   void build_brick_image(hipStream_t s) const;
 
@@ -218,18 +229,19 @@ private:
   float lr_ = 0.0f;   // current learning rate (ExponentialDecay state); reset by configure() like the reference's rebuilt optimizer (tcnn_network.h:195-209)
 
   DeviceBuffer<uint16_t> params_f16_{MemTag::Network};   // tcnn-order blob (inference + serialisation)
-  DeviceBuffer<uint16_t> mlp_packed_{MemTag::Network};   // MFMA/LDS image of the MLP weights
+  DeviceBuffer<uint16_t> mlp_packed_{MemTag::Network};   // MFMA/LDS image of the MLP weights (forward)
+  DeviceBuffer<uint16_t> mlp_packed_T_{MemTag::Network}; // ... transposed, for the MLP backward
   DeviceBuffer<LevelInfo> levels_dev_{MemTag::Network};  // per-level constants, read with scalar loads
   DeviceBuffer<OptState> opt_state_{MemTag::Network};    // per parameter: fp32 master copy + Adam moments + step count (training)
   DeviceBuffer<uint16_t> grads_{MemTag::Network};        // fp16 gradient of the whole blob (ONE buffer: the all-reduce unit)
   DeviceBuffer<float> grads_f32_{MemTag::Network};       // grads_as_f32()
   // training workspace
   DeviceBuffer<uint16_t> ws_features_{MemTag::Network};  // [B][in_width]
-  DeviceBuffer<uint16_t> ws_acts_{MemTag::Network};      // [(nh+1)][B][64]
+  DeviceBuffer<uint16_t> ws_acts_{MemTag::Network};      // [(nh+1)][B][n_neurons]
   DeviceBuffer<uint16_t> ws_dfeat_{MemTag::Network};     // [B][in_width] dL/dfeatures (fp16, loss-scaled)
   DeviceBuffer<float> ws_loss_{MemTag::Network};         // [blocks] partial loss sums
   size_t ws_batch_ = 0;
-  uint32_t lds_halves_ = 0;
+  uint32_t lds_halves_ = 0, lds_halves_T_ = 0;
   // brick image (inference cache; mutable: built lazily from const inference calls)
   mutable DeviceBuffer<uint8_t> brick_image_{MemTag::Network};
   mutable DeviceBuffer<LevelInfo> levels_brick_dev_{MemTag::Network};

@@ -9,15 +9,13 @@
 #include <cstdlib>
 #include <set>
 
-#include "infer_tile.h"
-#include "pack_rays.h"
+#include "infer_kernel.h"
 
 namespace vnr {
 
-void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width, uint32_t n_hidden_matmuls, hipStream_t s);
-void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
-                  const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
-                  float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
+void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint16_t* packedT, uint32_t in_width, uint32_t W, uint32_t n_hidden_matmuls, hipStream_t s);
+void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, const FusedMlp& mlp, const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes,
+                  const float* coords, float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                   const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr,
                   uint32_t sharers = 1, const struct PackArgs* pack = nullptr);
 void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
@@ -76,20 +74,30 @@ uint32_t grid_make_layout(const ModelConfig& cfg, GridDevice* out)
     const double cube = (double)res * (double)res * (double)res;
     uint32_t n = cube > (double)max_params ? max_params : (uint32_t)cube;
     n = next_multiple(n, 8u);
-    const uint32_t cap = 1u << cfg.log2_hashmap_size;
-    if (n > cap) n = cap;
-    // hash iff the dense stride walk exceeds the level size (tcnn grid_index)
-    uint32_t stride = 1;
-    for (uint32_t dim = 0; dim < 3 && stride <= n; ++dim) stride *= res;
+    // EXTERNAL tcnn GridEncodingTemplated ctor: Dense keeps the full level, Tiled caps it at base_resolution^3 (the level then repeats
+    // with that period), Hash at 2^log2_hashmap_size
+    if (cfg.grid_type == 2u) {
+      const double tile = (double)cfg.base_resolution * cfg.base_resolution * cfg.base_resolution;
+      if ((double)n > tile) n = (uint32_t)tile;
+    } else if (cfg.grid_type == 0u) {
+      const uint32_t cap = 1u << cfg.log2_hashmap_size;
+      if (n > cap) n = cap;
+    }
+    if (n == 0) throw std::runtime_error("grid level without entries");
+    // tcnn grid_index: the stride walk stops as soon as the stride exceeds the level's size; a Hash grid then hashes instead
+    uint32_t stride = 1, dims = 0;
+    for (; dims < 3 && stride <= n; ++dims) stride *= res;
     LevelInfo& lv = out->levels[l];
     lv.scale = scale;
     lv.resolution = res;
     lv.res2 = res * res;
     lv.size = n;
     lv.offset = offset;
-    lv.hashed = n < stride ? 1u : 0u;
+    if (cfg.grid_type == 0u) lv.hashed = n < stride ? 1u : 0u;
+    else lv.hashed = (dims == 3 && (uint64_t)res * res * res <= (uint64_t)n) ? 0u : 1u + dims;   // 2 / 3 / 4: index over 1 / 2 / 3 dimensions, modulo
     lv.brick = lv.pad1 = 0;
-    if (lv.hashed && (n & (n - 1)) != 0) throw std::runtime_error("internal: hashed level with non power-of-two size");
+    if (lv.hashed == 1u && (n & (n - 1)) != 0) throw std::runtime_error("internal: hashed level with non power-of-two size");
+    if ((uint64_t)offset + n > 0xffffffffull) throw std::runtime_error("grid encoding too large (more than 2^32 entries)");
     offset += n;
   }
   out->n_levels = cfg.n_levels;
@@ -143,8 +151,14 @@ void Network::configure(const Json& config, uint64_t init_seed)
   else throw std::runtime_error("unsupported loss otype: " + lt);
 
   const std::string et = json_str(enc, "otype", "");
-  if (et != "HashGrid" && et != "Grid") throw std::runtime_error("unsupported encoding otype: '" + et + "' (HashGrid only)");
-  if (json_str(enc, "type", "Hash") != "Hash") throw std::runtime_error("unsupported grid type (Hash only)");
+  // EXTERNAL tcnn create_grid_encoding: otype Grid / HashGrid / TiledGrid / DenseGrid, "type" (default by otype) Hash / Dense / Tiled
+  if (et != "HashGrid" && et != "Grid" && et != "DenseGrid" && et != "TiledGrid")
+    throw std::runtime_error("unsupported encoding otype: '" + et + "' (HashGrid / Grid / DenseGrid / TiledGrid)");
+  const std::string gt = json_str(enc, "type", et == "DenseGrid" ? "Dense" : et == "TiledGrid" ? "Tiled" : "Hash");
+  if (gt == "Hash") c.grid_type = 0;
+  else if (gt == "Dense") c.grid_type = 1;
+  else if (gt == "Tiled") c.grid_type = 2;
+  else throw std::runtime_error("unsupported grid type: " + gt + " (Hash / Dense / Tiled)");
   c.n_levels = json_u32(enc, "n_levels", 16);
   c.n_features = json_u32(enc, "n_features_per_level", 2);
   c.log2_hashmap_size = json_u32(enc, "log2_hashmap_size", 19);
@@ -170,11 +184,18 @@ void Network::configure(const Json& config, uint64_t init_seed)
   if (c.n_neurons != 16 && c.n_neurons != 32 && c.n_neurons != 64 && c.n_neurons != 128)
     throw std::runtime_error("FullyFusedMLP n_neurons must be 16, 32, 64 or 128");   // tcnn_impl.cu:315-347
   if (c.n_hidden_layers < 1) throw std::runtime_error("n_hidden_layers must be >= 1");
-  const std::string act = json_str(net, "activation", "ReLU");
-  if (act == "ReLU") c.activation = 1;
-  else if (act == "None") c.activation = 0;
-  else throw std::runtime_error("unsupported activation: " + act);
-  if (json_str(net, "output_activation", "None") != "None") throw std::runtime_error("unsupported output_activation (None only)");
+  // the activations the reference's kernels dispatch (tcnn_impl.cu:405-415, tcnn_device_api.h:274-285; no Sine there)
+  auto activation_of = [](const std::string& a, const char* what) -> uint32_t {
+    if (a == "None") return kActNone;
+    if (a == "ReLU") return kActReLU;
+    if (a == "Exponential") return kActExponential;
+    if (a == "Sigmoid") return kActSigmoid;
+    if (a == "Squareplus") return kActSquareplus;
+    if (a == "Softplus") return kActSoftplus;
+    throw std::runtime_error(std::string("unsupported ") + what + ": " + a + " (None / ReLU / Exponential / Sigmoid / Squareplus / Softplus)");
+  };
+  c.activation = activation_of(json_str(net, "activation", "ReLU"), "activation");
+  c.output_activation = activation_of(json_str(net, "output_activation", "None"), "output_activation");
 
   cfg_ = c;
   model_ = Json::object();
@@ -197,9 +218,11 @@ void Network::build_layout()
   n_mlp_ = W * in_width_ + (size_t)n_hidden_matmuls() * W * W + (size_t)16 * W;
   n_params_ = n_mlp_ + (size_t)total_entries * cfg_.n_features;
   if ((n_params_ - n_mlp_) * sizeof(uint16_t) >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
-  lds_halves_ = (in_width_ / 16) * 1024 + n_hidden_matmuls() * 4096 + 64;
+  lds_halves_ = packed_mlp_halves(in_width_, cfg_.n_neurons, n_hidden_matmuls());
+  lds_halves_T_ = packedT_halves(in_width_, cfg_.n_neurons, n_hidden_matmuls());
   params_f16_.resize(n_params_);
   mlp_packed_.resize(lds_halves_);
+  mlp_packed_T_.resize(lds_halves_T_);
   levels_dev_.resize(kMaxLevels);
   levels_dev_.upload(grid_.levels, kMaxLevels, Runtime::get().stream);
   VNR_HIP_CHECK(hipStreamSynchronize(Runtime::get().stream));
@@ -226,7 +249,8 @@ uint32_t Network::n_active_levels() const
 
 void Network::refresh_inference_weights(hipStream_t s)
 {
-  if (fast_path()) launch_pack_mlp(params_f16_.ptr, mlp_packed_.ptr, in_width_, n_hidden_matmuls(), s);
+  // both weight images (forward; transposed for the MLP backward) in one launch
+  launch_pack_mlp(params_f16_.ptr, mlp_packed_.ptr, mlp_packed_T_.ptr, in_width_, cfg_.n_neurons, n_hidden_matmuls(), s);
   // the parameters changed: the brick image is stale (it is rebuilt once they have been left alone again)
   brick_valid_ = false;
   brick_stable_calls_ = 0;
@@ -383,7 +407,7 @@ void Network::build_brick_image(hipStream_t s) const
   std::vector<uint64_t> lines(kMaxLevels, 0);
   uint64_t used = 0;
   for (int l = (int)grid_.n_levels - 1; l >= 0; --l) {
-    if (!lv[l].hashed && !dense_too) continue;
+    if (lv[l].hashed >= 2u || (!lv[l].hashed && !dense_too)) continue;   // (a Tiled level repeats: nothing to de-hash)
     if (brick_res_cap_ && lv[l].resolution > brick_res_cap_ + 1u) continue;
     const uint64_t res = lv[l].resolution;
     uint64_t n = ((res >> lx) + 1) * ((res >> ly) + 1) * ((res >> lz) + 1);
@@ -504,8 +528,7 @@ void Network::inference(const float* d_coords, float* d_out, size_t n, const uin
   const LevelInfo* levels = inference_levels(s, &image);
   GridDevice grid = grid_;
   grid.n_levels = n_active_levels();   // masked levels encode to zero, like the padding
-  launch_fused(0, grid, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest, 0, image);
+  launch_fused(0, grid, in_width_, fused_mlp(), levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest, 0, image);
 }
 
 bool Network::inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
@@ -519,14 +542,20 @@ bool Network::inference_queue(const float* d_records, float* d_out, uint32_t out
   const LevelInfo* levels = inference_levels(s, &image);
   GridDevice grid = grid_;
   grid.n_levels = n_active_levels();
-  launch_fused(0, grid, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr, out_stride, image, sharers, pack);
+  if (cfg_.n_neurons == 128u) pack = nullptr;   // blocks of 8 waves: the caller launches the packing kernel itself
+  launch_fused(0, grid, in_width_, fused_mlp(), levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2, d_records, d_out, nullptr, nullptr, 0, d_n, n_max, s, nullptr,
+               out_stride, image, sharers, pack);
   return pack != nullptr;
+}
+
+FusedMlp Network::fused_mlp() const
+{
+  return FusedMlp{mlp_packed_.ptr, lds_halves_, cfg_.n_neurons, n_hidden_matmuls(), cfg_.activation, cfg_.output_activation, !common_kind()};
 }
 
 bool Network::tile_net(TileNet* out, hipStream_t s) const
 {
-  if (!fast_path()) return false;
+  if (!fast_path() || !common_kind() || cfg_.n_neurons != (uint32_t)kWidth) return false;
   if (n_grid_params() * 2 >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
@@ -555,13 +584,12 @@ void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipS
   const LevelInfo* levels = inference_levels(s, &image);
   GridDevice grid = grid_;
   grid.n_levels = n_active_levels();
-  launch_fused(1, grid, in_width_, n_hidden_matmuls(), cfg_.activation, levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2,
-               mlp_packed_.ptr, lds_halves_, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s, nullptr, 0, image);
+  launch_fused(1, grid, in_width_, fused_mlp(), levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s, nullptr, 0, image);
 }
 
 size_t Network::bytes_allocated() const
 {
-  return brick_image_.bytes() + params_f16_.bytes() + mlp_packed_.bytes() + opt_state_.bytes() + grads_.bytes() + grads_f32_.bytes() + ws_features_.bytes() + ws_acts_.bytes() + ws_dfeat_.bytes() + ws_loss_.bytes();
+  return brick_image_.bytes() + params_f16_.bytes() + mlp_packed_.bytes() + mlp_packed_T_.bytes() + opt_state_.bytes() + grads_.bytes() + grads_f32_.bytes() + ws_features_.bytes() + ws_acts_.bytes() + ws_dfeat_.bytes() + ws_loss_.bytes();
 }
 
 }  // namespace vnr

@@ -8,13 +8,12 @@
 // Differences chosen for MI355X (documented in DESIGN.md): gradients are accumulated in ONE fp32 buffer
 // (tcnn: fp16 with half2 atomics) so a data-parallel run all-reduces a single tensor; the MLP backward
 // runs on MFMA with the same transposed register-resident scheme as the forward.
-#include "grid_device.h"
+#include "infer_kernel.h"
 
 namespace vnr {
 
-void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, uint32_t n_hidden_matmuls, uint32_t activation,
-                  const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes, const uint16_t* packed, uint32_t lds_halves, const float* coords,
-                  float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
+void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, const FusedMlp& mlp, const LevelInfo* d_levels, const uint16_t* table, size_t table_bytes,
+                  const float* coords, float* out, uint16_t* features_out, uint16_t* acts_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                   const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr,
                   uint32_t sharers = 1, const struct PackArgs* pack = nullptr);
 
@@ -106,8 +105,10 @@ void launch_master_from_f16(const uint16_t* params, OptState* state, size_t n, b
 }
 
 // ------------------------------------------------------------------------------------------------ loss
-// EXTERNAL tcnn L1Loss / L2Loss: values = |d|/N (d^2/N), gradient = loss_scale * sign(d)/N (2 d/N), stored fp16.
-__global__ void loss_grad_kernel(const float* __restrict__ y, const float* __restrict__ target, uint32_t n, uint32_t loss_type,
+// EXTERNAL tcnn L1Loss / L2Loss: values = |d|/N (d^2/N), gradient = loss_scale * sign(d)/N (2 d/N), stored fp16.  With an output
+// activation the network's backward pass first takes that gradient through it, from the OUTPUT values (EXTERNAL tcnn
+// FullyFusedMLP::backward -> activation_backward_output_gpu): folded in here.
+__global__ void loss_grad_kernel(const float* __restrict__ y, const float* __restrict__ target, uint32_t n, uint32_t loss_type, uint32_t out_act,
                                  half_t* __restrict__ dy, float* __restrict__ loss_partials)
 {
   __shared__ float red[256];
@@ -118,7 +119,7 @@ __global__ void loss_grad_kernel(const float* __restrict__ y, const float* __res
     float g;
     if (loss_type == 0) { acc += fabsf(d) * inv_n; g = copysignf(1.0f, d); }
     else { acc += d * d * inv_n; g = 2.0f * d; }
-    dy[i] = (half_t)((float)kLossScale * g * inv_n);
+    dy[i] = act_backward_f16((half_t)((float)kLossScale * g * inv_n), (half_t)y[i], out_act);
   }
   red[threadIdx.x] = acc;
   __syncthreads();
@@ -129,45 +130,14 @@ __global__ void loss_grad_kernel(const float* __restrict__ y, const float* __res
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = red[0];
 }
 
-// ------------------------------------------------------------------------------------------------ backward weights image
-// LDS image for the MLP backward (halves):
-//   last row  : [s<4][h][j]                      = Wl[0][kk]                       (64)
-//   hidden l  : [s<4][h][row<64][j]              = Wh_l[kk][row]   (transposed)     (4096 each)
-//   first     : [s<4][h][row<RP][j], RP = roundup(in_width,32) = W1[kk][row] or 0   (64*RP)
-// with kk = 16 s + 8 (j>>2) + 4 h + (j&3)  (the k-order of an accumulator tile reused as B operand).
-__host__ __device__ inline uint32_t packedT_halves(uint32_t in_width, uint32_t nh) { return 64 + nh * 4096 + 64 * (((in_width + 31) / 32) * 32); }
-
-__global__ void pack_mlp_T_kernel(const half_t* __restrict__ params, half_t* __restrict__ packed, uint32_t in_width, uint32_t nh)
-{
-  const uint32_t rp = ((in_width + 31) / 32) * 32;
-  const uint32_t total = packedT_halves(in_width, nh);
-  const uint32_t first_sz = kWidth * in_width;
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    half_t v;
-    if (e < 64) {
-      const uint32_t j = e & 7, h = (e >> 3) & 1, s = e >> 4;
-      v = params[first_sz + nh * 4096 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
-    } else if (e < 64 + nh * 4096) {
-      const uint32_t q = (e - 64) & 4095, layer = (e - 64) >> 12;
-      const uint32_t j = q & 7, row = (q >> 3) & 63, h = (q >> 9) & 1, s = q >> 10;
-      const uint32_t kk = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-      v = params[first_sz + layer * 4096 + kk * 64 + row];
-    } else {
-      const uint32_t q = e - 64 - nh * 4096;
-      const uint32_t j = q & 7, row = (q >> 3) % rp, hs = (q >> 3) / rp, h = hs & 1, s = hs >> 1;
-      const uint32_t kk = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-      v = row < in_width ? params[kk * in_width + row] : (half_t)0.0f;
-    }
-    packed[e] = v;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ MLP backward (MFMA)
+// The backward image of the weights (layout: network_infer.hip pack_mlp_kernel) is packed together with the forward image
+// whenever the parameters change; kk = 16 s + 8 (j>>2) + 4 h + (j&3) is the k-order of an accumulator tile reused as B operand.
 struct BackwardArgs {
   const half_t* packedT;
   const half_t* dy;      // [n] loss-scaled dL/dy
-  const half_t* acts;    // [(nh+1)][n][64]
-  half_t* d_out;         // [(nh+1)][n][64]  dL/d(pre-activation) of every hidden layer output
+  const half_t* acts;    // [(nh+1)][n][W]
+  half_t* d_out;         // [(nh+1)][n][W]  dL/d(pre-activation) of every hidden layer output
   half_t* dfeat;         // [n][in_width]
   uint32_t n, nh, activation, in_width, lds_halves;
 };
@@ -190,17 +160,30 @@ __device__ __forceinline__ half8_t pack_plain(const f32x16& acc, int sh)
   for (int j = 0; j < 8; ++j) v[j] = acc[8 * sh + j];
   return __builtin_convertvector(v, half8_t);
 }
-__device__ __forceinline__ half8_t mask_relu(const half8_t& d, const half8_t& a)
+// the gradient through the activation, from the stored OUTPUT of the layer (infer_tile.h act_backward_f16)
+__device__ __noinline__ half8_t act_backward_general8(half8_t d, half8_t a, uint32_t act)
 {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = act_backward_f16(d[j], a[j], act);
+  return d;
+}
+template <bool GENERAL>   // GENERAL: the transcendental activations too (instances of their own: grid_device.h gather_corners)
+__device__ __forceinline__ half8_t act_backward8(const half8_t& d, const half8_t& a, uint32_t act)
+{
+  if (act == kActNone) return d;
+  if (GENERAL && act > kActReLU) return act_backward_general8(d, a, act);
   half8_t r;
 #pragma unroll
   for (int j = 0; j < 8; ++j) r[j] = a[j] > (half_t)0.0f ? d[j] : (half_t)0.0f;
   return r;
 }
 
-template <int MT>  // MT = number of 32-row tiles of the feature gradient (roundup(in_width, 32) / 32)
+template <int W, int MTF, bool GENERAL>  // MTF = number of 32-row tiles of the feature gradient (roundup(in_width, 32) / 32)
 __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs args)
 {
+  typedef MlpShape<W> Sh;
+  constexpr int MT = Sh::MT, RW = Sh::RW, KS = Sh::KS;
+  constexpr int NTB = W == 128 ? 1 : 2;   // 32-sample column tiles in flight (128 neurons: one, its accumulators are 4 tiles of registers already)
   extern __shared__ __attribute__((aligned(16))) half_t lds[];
   {
     const uint4_t* src = (const uint4_t*)args.packedT;
@@ -211,99 +194,100 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t h = lane >> 5, r = lane & 31u;
   const uint32_t n = args.n, nh = args.nh;
-  const bool relu = args.activation == 1;
+  const uint32_t act = args.activation;
   const uint32_t n_tiles = (n + 63u) >> 6;
-  constexpr int RP = MT * 32;
+  constexpr int RP = MTF * 32;
 
   for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
-    half8_t bf[4][2];
-    uint32_t smp[2];
-    bool ok[2];
-    // ---- through the last layer: d_nh[k] = Wl[0][k] * dy, masked by relu'(a_nh) -------------------
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      smp[nt] = tile * 64u + 32u * nt + r;
-      ok[nt] = smp[nt] < n;
-      const uint32_t sc = ok[nt] ? smp[nt] : n - 1u;
-      const float g = (float)args.dy[sc];
-      const half_t* arow = args.acts + ((size_t)nh * n + sc) * 64;
+    for (int nt0 = 0; nt0 < 2; nt0 += NTB) {
+      half8_t bf[KS][NTB];
+      uint32_t smp[NTB];
+      bool ok[NTB];
+      // ---- through the last layer: d_nh[k] = Wl[0][k] * dy, through the activation of a_nh ----------------
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const half8_t wv = *(const half8_t*)(lds + (s * 2 + h) * 8);
-        half8_t d;
+      for (int q = 0; q < NTB; ++q) {
+        smp[q] = tile * 64u + 32u * (uint32_t)(nt0 + q) + r;
+        ok[q] = smp[q] < n;
+        const uint32_t sc = ok[q] ? smp[q] : n - 1u;
+        const float g = (float)args.dy[sc];
+        const half_t* arow = args.acts + ((size_t)nh * n + sc) * W;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = (half_t)((float)wv[j] * g);
-        if (relu) d = mask_relu(d, load_frag_rowmajor(arow, s, h));
-        bf[s][nt] = d;
-        if (ok[nt]) store_frag_rowmajor(args.d_out + ((size_t)nh * n + smp[nt]) * 64, s, h, d);
-      }
-    }
-    // ---- hidden layers, last to first: d_l^T = Wh_l^T . d_{l+1}^T, masked ----------------------------
-    for (int layer = (int)nh - 1; layer >= 0; --layer) {
-      const half_t* w = lds + 64 + layer * 4096;
-      f32x16 acc[2][2];
+        for (int s = 0; s < KS; ++s) {
+          const half8_t wv = *(const half8_t*)(lds + (s * 2 + h) * 8);
+          half8_t d;
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * 64 + m * 32 + r) * 8);
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s][nt], acc[m][nt], 0, 0, 0);
+          for (int j = 0; j < 8; ++j) d[j] = (half_t)((float)wv[j] * g);
+          d = act_backward8<GENERAL>(d, load_frag_rowmajor(arow, s, h), act);
+          bf[s][q] = d;
+          if (ok[q]) store_frag_rowmajor(args.d_out + ((size_t)nh * n + smp[q]) * W, s, h, d);
         }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const uint32_t sc = ok[nt] ? smp[nt] : n - 1u;
-        const half_t* arow = args.acts + ((size_t)layer * n + sc) * 64;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int sh = 0; sh < 2; ++sh) {
-            half8_t d = pack_plain(acc[m][nt], sh);
-            if (relu) d = mask_relu(d, load_frag_rowmajor(arow, 2 * m + sh, h));
-            bf[2 * m + sh][nt] = d;
-            if (ok[nt]) store_frag_rowmajor(args.d_out + ((size_t)layer * n + smp[nt]) * 64, 2 * m + sh, h, d);
-          }
       }
-    }
-    // ---- feature gradient: dfeat^T = W1^T . d_0^T -------------------------------------------------
-    {
-      const half_t* w = lds + 64 + nh * 4096;
-      f32x16 acc[MT][2];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.0f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * RP + m * 32 + r) * 8);
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s][nt], acc[m][nt], 0, 0, 0);
-        }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        if (!ok[nt]) continue;
-        half_t* row = args.dfeat + (size_t)smp[nt] * args.in_width;
+      // ---- hidden layers, last to first: d_l^T = Wh_l^T . d_{l+1}^T, through the activation --------------
+      for (int layer = (int)nh - 1; layer >= 0; --layer) {
+        const half_t* w = lds + Sh::LAST + layer * Sh::HIDDEN;
+        f32x16 acc[MT][NTB];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int sh = 0; sh < 2; ++sh) {
-            const half8_t d = pack_plain(acc[m][nt], sh);
-            const uint32_t f0 = 32 * m + 16 * sh;  // features f0 + 4h + {0..3} and f0 + 8 + 4h + {0..3}
-            if (f0 < args.in_width) {
-              *(half4_t*)(row + f0 + 4 * h) = half4_t{d[0], d[1], d[2], d[3]};
-              *(half4_t*)(row + f0 + 8 + 4 * h) = half4_t{d[4], d[5], d[6], d[7]};
-            }
+          for (int q = 0; q < NTB; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][q][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * RW + m * 32 + r) * 8);
+#pragma unroll
+            for (int q = 0; q < NTB; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s][q], acc[m][q], 0, 0, 0);
           }
+#pragma unroll
+        for (int q = 0; q < NTB; ++q) {
+          const uint32_t sc = ok[q] ? smp[q] : n - 1u;
+          const half_t* arow = args.acts + ((size_t)layer * n + sc) * W;
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            half8_t d = pack_plain(acc[s >> 1][q], s & 1);
+            d = act_backward8<GENERAL>(d, load_frag_rowmajor(arow, s, h), act);
+            bf[s][q] = d;
+            if (ok[q]) store_frag_rowmajor(args.d_out + ((size_t)layer * n + smp[q]) * W, s, h, d);
+          }
+        }
+      }
+      // ---- feature gradient: dfeat^T = W1^T . d_0^T -------------------------------------------------
+      {
+        const half_t* w = lds + Sh::LAST + nh * Sh::HIDDEN;
+        f32x16 acc[MTF][NTB];
+#pragma unroll
+        for (int m = 0; m < MTF; ++m)
+#pragma unroll
+          for (int q = 0; q < NTB; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][q][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int m = 0; m < MTF; ++m) {
+            const half8_t a = *(const half8_t*)(w + ((s * 2 + h) * RP + m * 32 + r) * 8);
+#pragma unroll
+            for (int q = 0; q < NTB; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[s][q], acc[m][q], 0, 0, 0);
+          }
+#pragma unroll
+        for (int q = 0; q < NTB; ++q) {
+          if (!ok[q]) continue;
+          half_t* row = args.dfeat + (size_t)smp[q] * args.in_width;
+#pragma unroll
+          for (int m = 0; m < MTF; ++m)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+              const half8_t d = pack_plain(acc[m][q], sh);
+              const uint32_t f0 = 32 * m + 16 * sh;  // features f0 + 4h + {0..3} and f0 + 8 + 4h + {0..3}
+              if (f0 < args.in_width) {
+                *(half4_t*)(row + f0 + 4 * h) = half4_t{d[0], d[1], d[2], d[3]};
+                *(half4_t*)(row + f0 + 8 + 4 * h) = half4_t{d[4], d[5], d[6], d[7]};
+              }
+            }
+        }
       }
     }
   }
@@ -314,89 +298,98 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
 // 1..nh = hidden (x = acts[l-1]), nh+1 = last layer row 0 (d = dy, x = acts[nh]).
 struct WGradArgs {
   const half_t* features;  // [n][in_width]
-  const half_t* acts;      // [(nh+1)][n][64]
-  const half_t* d_all;     // [(nh+1)][n][64]
+  const half_t* acts;      // [(nh+1)][n][W]
+  const half_t* d_all;     // [(nh+1)][n][W]
   const half_t* dy;        // [n]
   float* slab;             // [blocks][n_mlp] partial sums (fp32), summed by weight_grad_reduce_kernel into the fp16 gradient blob
   uint32_t n, nh, in_width, n_mlp;
 };
 
-// On the matrix cores: dW^T is a [64 x in] product whose reduction dimension is the BATCH, so both operands are needed
+// On the matrix cores: dW^T is a [W x in] product whose reduction dimension is the BATCH, so both operands are needed
 // transposed ([neuron][sample] with 8 consecutive samples per lane) while the forward / backward kernels leave them row-major
-// [sample][64].  A block stages 64 samples of d and x row-major in LDS (rows padded to a stride of 64 + 8 halves: lanes r = 0..31 of
-// a transposed read touch 16 consecutive dwords, the two lane halves rows 8 apart = 32 banks apart); every wave owns 32 x 32
-// tiles of the product (not a share of the samples: summing the waves' partial tiles with ds_add_f32 took 12 us per block, four
-// times the products) and runs the stage's four k-steps of v_mfma_f32_32x32x16_f16 on them; all loads of the block's 256 samples
-// are issued before the first product; the tiles leave as plain stores into the block's row of a slab [blocks][n_mlp], which
-// weight_grad_reduce_kernel sums.  fp16 products are exact in the fp32 accumulator as in the VALU kernel; only the order of the sums differs.
+// [sample][W].  A block stages 64 samples of d and x row-major in LDS (rows padded by 8 halves: lanes r = 0..31 of a transposed read
+// touch 16 consecutive dwords, the two lane halves rows 8 apart = 32 banks apart); every wave owns 32 x 32 tiles of the product (not
+// a share of the samples: summing the waves' partial tiles with ds_add_f32 took 12 us per block, four times the products) and runs
+// the stage's four k-steps of v_mfma_f32_32x32x16_f16 on them; products of fewer than four tiles (16 / 32 neurons, narrow inputs)
+// split the stage's k-steps over the waves of a tile instead and add up through LDS once at the end.  All loads of the block's 256
+// samples are issued before the first product; the tiles leave as plain stores into the block's row of a slab [blocks][n_mlp], which
+// weight_grad_reduce_kernel sums.  fp16 products are exact in the fp32 accumulator; only the order of the sums differs from a loop.
 constexpr int kWgStage = 64;           // samples per stage
 constexpr int kWgStages = 4;           // stages per block: a block owns 256 samples and issues ALL their loads before the first product
-constexpr int kWgStride = 64 + 8;      // halves per staged row of d (and of x when the input is 64 wide)
 
-template <int NT>  // 32-column tiles of the input: in_width padded to 32 * NT
+template <int W, int NT>  // NT: 32-column tiles of the input (in_width, or W for the hidden layers, padded to 32 NT)
 __global__ void __launch_bounds__(256) weight_grad_mfma_kernel(const WGradArgs args, uint32_t layer_lo)
 {
+  typedef MlpShape<W> Sh;
+  constexpr int MT = Sh::MT;
+  constexpr int DS = W + 8;            // halves per staged row of d
+  constexpr int DC = W / 8;            // uint4 per row of d
+  constexpr int DQ = (kWgStage * DC + 255) / 256;
   constexpr int XS = 32 * NT + 8;      // halves per staged row of x
   constexpr int XC = 4 * NT;           // uint4 per row of x
   constexpr int XQ = (kWgStage * XC + 255) / 256;
-  __shared__ __attribute__((aligned(16))) half_t sd[kWgStage * kWgStride];
+  __shared__ __attribute__((aligned(16))) half_t sd[kWgStage * DS];
   __shared__ __attribute__((aligned(16))) half_t sx[kWgStage * XS];
-  __shared__ float red[32 * 64];   // last layer: [32 sample lanes][64]; two-tile form: [2 tiles][16 registers][64 lanes]
+  __shared__ float red[3 * 16 * 64];   // last layer: [sample lanes][W] (2048 floats); tile sums: [contributors - 1][tiles][16 registers][64 lanes]
   const uint32_t layer = layer_lo + blockIdx.y;
   const uint32_t n = args.n, nh = args.nh;
   const uint32_t blk0 = blockIdx.x * (uint32_t)(kWgStage * kWgStages);
   if (blk0 >= n) return;
   const uint32_t blk_end = min(n, blk0 + (uint32_t)(kWgStage * kWgStages));
   float* slab = args.slab + (size_t)blockIdx.x * args.n_mlp;   // this block's partial sums, tcnn order
+  const size_t first_sz = (size_t)W * args.in_width;
 
   if (layer == nh + 1) {
-    // last layer: dWl[0][k] = sum_b dy[b] * a_nh[b][k].  Thread = (8 neurons, one of 32 sample lanes): every load of the block's
+    // last layer: dWl[0][k] = sum_b dy[b] * a_nh[b][k].  Thread = (8 neurons, one of SL sample lanes): every load of the block's
     // 256 rows is in flight at once (one dependent load per sample was 64 latencies in a row: the longest block of the launch)
-    const uint32_t c = threadIdx.x & 7u, sr = threadIdx.x >> 3;
+    constexpr uint32_t CH = W / 8, SL = 256 / CH, ROWS = (kWgStage * kWgStages) / SL;
+    const uint32_t c = threadIdx.x % CH, sr = threadIdx.x / CH;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    half8_t av[kWgStages * 2];
-    float gv[kWgStages * 2];
+    half8_t av[ROWS];
+    float gv[ROWS];
 #pragma unroll
-    for (int q = 0; q < kWgStages * 2; ++q) {
-      const uint32_t b = blk0 + sr + 32u * q;
+    for (uint32_t q = 0; q < ROWS; ++q) {
+      const uint32_t b = blk0 + sr + SL * q;
       const bool ok = b < blk_end;
-      av[q] = ok ? *(const half8_t*)(args.acts + ((size_t)nh * n + b) * 64 + c * 8) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      av[q] = ok ? *(const half8_t*)(args.acts + ((size_t)nh * n + b) * W + c * 8) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
       gv[q] = ok ? (float)args.dy[b] : 0.0f;
     }
 #pragma unroll
-    for (int q = 0; q < kWgStages * 2; ++q)
+    for (uint32_t q = 0; q < ROWS; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(gv[q], (float)av[q][j], acc[j]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[sr * 64 + c * 8 + j] = acc[j];
+    for (int j = 0; j < 8; ++j) red[sr * W + c * 8 + j] = acc[j];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < (uint32_t)W) {
       float t = 0.0f;
-      for (int q = 0; q < 32; ++q) t += red[q * 64 + threadIdx.x];
-      slab[(size_t)kWidth * args.in_width + (size_t)nh * 4096 + threadIdx.x] = t;
+      for (uint32_t q = 0; q < SL; ++q) t += red[q * W + threadIdx.x];
+      slab[first_sz + (size_t)nh * W * W + threadIdx.x] = t;
     }
     return;
   }
-  const uint32_t in_w = layer == 0 ? args.in_width : 64u;   // a multiple of 8 (rows are read as uint4)
+  const uint32_t in_w = layer == 0 ? args.in_width : (uint32_t)W;   // a multiple of 8 (rows are read as uint4)
   const uint32_t xc = in_w / 8;
-  const half_t* dsrc = args.d_all + (size_t)layer * n * 64;
-  const half_t* xsrc = layer == 0 ? args.features : args.acts + (size_t)(layer - 1) * n * 64;
+  const half_t* dsrc = args.d_all + (size_t)layer * n * W;
+  const half_t* xsrc = layer == 0 ? args.features : args.acts + (size_t)(layer - 1) * n * W;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31u;
-  constexpr int T = 2 * NT;                    // 32 x 32 tiles of the product [64 out][32 NT in]
+  constexpr int T = MT * NT;                   // 32 x 32 tiles of the product [32 MT out][32 NT in]
   constexpr int TW = T >= 4 ? T / 4 : 1;       // tiles per wave (same 32 output rows, TW column tiles)
-  constexpr int KS = T >= 4 ? 4 : 2;           // k-steps of a stage per wave: with two tiles the wave pairs split the stage
-  const uint32_t t0 = T >= 4 ? wave * TW : (wave & 1u);
+  constexpr int WPT = T >= 4 ? 1 : 4 / T;      // waves per tile: with fewer than four tiles the waves of a tile split the stage's k-steps
+  constexpr int KSW = 4 / WPT;                 // k-steps of a stage per wave
+  const uint32_t t0 = T >= 4 ? wave * TW : wave % (uint32_t)T;
   const uint32_t m = t0 / NT, nt0 = t0 % NT;
-  const uint32_t kbase = T >= 4 ? 0u : 2u * (wave >> 1);
+  const uint32_t part = T >= 4 ? 0u : wave / (uint32_t)T;   // which share of the k-steps
+  const uint32_t kbase = part * KSW;
 
-  uint4_t rd[kWgStages][2], rx[kWgStages][XQ];
+  uint4_t rd[kWgStages][DQ], rx[kWgStages][XQ];
 #pragma unroll
   for (int st = 0; st < kWgStages; ++st) {
     const uint32_t b0 = blk0 + (uint32_t)(st * kWgStage);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const uint32_t e = threadIdx.x + 256u * q, b = b0 + (e >> 3);
-      rd[st][q] = b < blk_end ? *(const uint4_t*)(dsrc + (size_t)b * 64 + (e & 7u) * 8) : uint4_t{0, 0, 0, 0};
+    for (int q = 0; q < DQ; ++q) {
+      const uint32_t e = threadIdx.x + 256u * q, row = e / DC, c = e % DC, b = b0 + row;
+      rd[st][q] = (row < (uint32_t)kWgStage && b < blk_end) ? *(const uint4_t*)(dsrc + (size_t)b * W + c * 8) : uint4_t{0, 0, 0, 0};
     }
 #pragma unroll
     for (int q = 0; q < XQ; ++q) {
@@ -410,14 +403,15 @@ __global__ void __launch_bounds__(256) weight_grad_mfma_kernel(const WGradArgs a
   for (int t = 0; t < TW; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+  const bool row_ok = W >= 32 || r < (uint32_t)W;   // 16 neurons: rows 16 .. 31 of the one tile do not exist
 
 #pragma unroll
   for (int st = 0; st < kWgStages; ++st) {
     if (st) __syncthreads();   // the previous stage has been consumed
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const uint32_t e = threadIdx.x + 256u * q;
-      *(uint4_t*)(sd + (e >> 3) * kWgStride + (e & 7u) * 8) = rd[st][q];
+    for (int q = 0; q < DQ; ++q) {
+      const uint32_t e = threadIdx.x + 256u * q, row = e / DC, c = e % DC;
+      if (row < (uint32_t)kWgStage) *(uint4_t*)(sd + row * DS + c * 8) = rd[st][q];
     }
 #pragma unroll
     for (int q = 0; q < XQ; ++q) {
@@ -426,12 +420,12 @@ __global__ void __launch_bounds__(256) weight_grad_mfma_kernel(const WGradArgs a
     }
     __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KSW; ++ks) {
       const uint32_t k0 = 16u * (kbase + (uint32_t)ks) + 8u * h;
       half8_t a, bx[TW];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        a[j] = sd[(k0 + j) * kWgStride + m * 32 + r];
+        a[j] = row_ok ? sd[(k0 + j) * DS + m * 32 + r] : (half_t)0.0f;
 #pragma unroll
         for (int t = 0; t < TW; ++t) bx[t][j] = sx[(k0 + j) * XS + (nt0 + t) * 32 + r];
       }
@@ -439,19 +433,21 @@ __global__ void __launch_bounds__(256) weight_grad_mfma_kernel(const WGradArgs a
       for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[t], acc[t], 0, 0, 0);
     }
   }
-  if (T < 4) {   // two tiles: waves 2 and 3 hand their half of the samples to waves 0 and 1 (plain LDS traffic, 4 KB each)
+  if (T < 4) {   // the other shares of the k-steps hand their sums to the tile's first wave (plain LDS traffic, 4 KB each)
     __syncthreads();
-    if (wave >= 2) {
+    if (part > 0) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) red[((wave & 1u) * 16 + e) * 64 + lane] = acc[0][e];
+      for (int e = 0; e < 16; ++e) red[(((part - 1u) * T + t0) * 16 + e) * 64 + lane] = acc[0][e];
     }
     __syncthreads();
-    if (wave >= 2) return;
+    if (part > 0) return;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[0][e] += red[((wave & 1u) * 16 + e) * 64 + lane];
+    for (int c = 1; c < WPT; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][e] += red[(((uint32_t)(c - 1) * T + t0) * 16 + e) * 64 + lane];
   }
   // element (out, in) of tile (m, nt) sits in lane (in = 32 nt + r), register e with out = 32 m + 8 (e / 4) + 4 h + e % 4
-  float* g = slab + (layer == 0 ? 0 : (size_t)kWidth * args.in_width + (size_t)(layer - 1) * 4096);
+  float* g = slab + (layer == 0 ? 0 : first_sz + (size_t)(layer - 1) * W * W);
 #pragma unroll
   for (int t = 0; t < TW; ++t) {
     const uint32_t col = 32u * (nt0 + t) + r;
@@ -459,7 +455,7 @@ __global__ void __launch_bounds__(256) weight_grad_mfma_kernel(const WGradArgs a
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const uint32_t out = 32u * m + 8u * (e >> 2) + 4u * h + (e & 3);
-        g[(size_t)out * in_w + col] = acc[t][e];
+        if (W >= 32 || out < (uint32_t)W) g[(size_t)out * in_w + col] = acc[t][e];
       }
     }
   }
@@ -493,11 +489,10 @@ __global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------ generic MLP backward / weight gradients
-// Every model shape the reference trains that the MFMA kernels do not cover (FullyFusedMLP n_neurons 16 / 32 / 128, tcnn_impl.cu:315-347;
-// the 64-neuron models with Nearest interpolation, quantize_threshold or max_level take this path too, so that one code path holds the
-// encoding's special cases): the same arithmetic as mlp_backward_kernel / weight_grad_mfma_kernel (fp16 activation gradients, ReLU mask
-// from the stored activations, fp32 sums over the batch rounded once to the fp16 gradient), one lane per sample and plain loops, weights
-// from L1 / L2.  Correct, not fast (DESIGN.md 4.3 has the rates); nothing in the BASELINE configurations uses these shapes.
+// The models the MFMA kernels do not cover (Network::fast_train_path: a quantize_threshold, or 128-neuron models whose weight images
+// exceed the LDS): the same arithmetic as mlp_backward_kernel / weight_grad_mfma_kernel (fp16 activation gradients, the activation's
+// derivative from the stored activations, fp32 sums over the batch rounded once to the fp16 gradient), one lane per sample and plain
+// loops, weights from L1 / L2.  Correct, not fast; nothing in the BASELINE configurations uses these shapes.
 struct GenericBackwardArgs {
   const half_t* params;   // tcnn-order blob (MLP weights first)
   const half_t* dy;       // [n]
@@ -510,7 +505,7 @@ struct GenericBackwardArgs {
 __global__ void __launch_bounds__(128) generic_backward_kernel(const GenericBackwardArgs a)
 {
   const uint32_t W = a.width, n = a.n, nh = a.nh;
-  const bool relu = a.activation == 1u;
+  const uint32_t act = a.activation;
   const half_t* w1 = a.params;
   const half_t* wh = a.params + (size_t)W * a.in_width;
   const half_t* wl = wh + (size_t)nh * W * W;
@@ -521,8 +516,7 @@ __global__ void __launch_bounds__(128) generic_backward_kernel(const GenericBack
     {  // through the last layer: d_nh[k] = Wl[0][k] * dy, masked by relu'(a_nh)
       const half_t* arow = a.acts + ((size_t)nh * n + i) * W;
       for (uint32_t k = 0; k < W; ++k) {
-        half_t d = (half_t)((float)wl[k] * g);
-        if (relu && !((float)arow[k] > 0.0f)) d = (half_t)0.0f;
+        const half_t d = act_backward_f16((half_t)((float)wl[k] * g), arow[k], act);
         cur[k] = d;
         a.d_out[((size_t)nh * n + i) * W + k] = d;
       }
@@ -533,8 +527,7 @@ __global__ void __launch_bounds__(128) generic_backward_kernel(const GenericBack
       for (uint32_t k = 0; k < W; ++k) {
         float sum = 0.0f;
         for (uint32_t o = 0; o < W; ++o) sum = __builtin_fmaf((float)w[(size_t)o * W + k], (float)cur[o], sum);
-        half_t d = (half_t)sum;
-        if (relu && !((float)arow[k] > 0.0f)) d = (half_t)0.0f;
+        const half_t d = act_backward_f16((half_t)sum, arow[k], act);
         nxt[k] = d;
         a.d_out[((size_t)layer * n + i) * W + k] = d;
       }
@@ -610,7 +603,7 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
   const bool nearest = grid.interpolation == 2u;   // EXTERNAL tcnn kernel_grid_backward, Nearest: the whole gradient to the lower corner's entry
   if (nearest && xb) return;
   const CornerSetup c = level_setup(lv, grid.interpolation == 1u ? 1u : 0u, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
-  half_t* base = grid_grads + (size_t)lv.offset * F + (F >= 2 ? f : 0u);
+  half_t* base = grid_grads + (F >= 2 ? (size_t)lv.offset * F + f : (size_t)0);
 #pragma unroll
   for (int yz = 0; yz < 4; ++yz) {
     if (nearest && yz) break;
@@ -622,10 +615,11 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
     if constexpr (F >= 2) {
       v = half2_t{(half_t)(w * g0), (half_t)(w * g1)};
       addr = base + (size_t)idx * F;
-    } else {   // the entry's half of its aligned pair (level offsets are even: level sizes are multiples of 8 entries)
+    } else {   // the entry's half of its aligned pair of the gradient blob (by absolute element: a Tiled level may have an odd size)
       const half_t h = (half_t)(w * g0), z = (half_t)0.0f;
-      v = (idx & 1u) ? half2_t{z, h} : half2_t{h, z};
-      addr = base + (size_t)(idx & ~1u);
+      const size_t e = (size_t)lv.offset + idx;
+      v = (e & 1u) ? half2_t{z, h} : half2_t{h, z};
+      addr = base + (e & ~(size_t)1);
     }
     asm volatile("global_atomic_pk_add_f16 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
   }
@@ -822,16 +816,14 @@ __global__ void unpack_grads_f16_kernel(const half_t* __restrict__ in, float* __
 }
 
 // ------------------------------------------------------------------------------------------------ host
-void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint32_t in_width, uint32_t n_hidden_matmuls, hipStream_t s);
-
 struct TrainScratch {  // per-Network extra buffers that do not need to live in the class interface
   DeviceBuffer<float> y{MemTag::Network};
   DeviceBuffer<uint16_t> dy{MemTag::Network};
   DeviceBuffer<uint16_t> d_all{MemTag::Network};
-  DeviceBuffer<uint16_t> packedT{MemTag::Network};
   DeviceBuffer<float> wgrad_slab{MemTag::Network};   // [blocks][n_mlp] partial weight gradients
+  uint64_t slab_key = 0;                             // (n_mlp, kernel family) the slab's never-written elements were zeroed for
   DeviceBuffer<uint8_t> lds_items{MemTag::Network};  // work items of grid_backward_lds_kernel (as bytes: the item type is local to this file)
-  size_t lds_items_key = 0;
+  std::vector<uint8_t> lds_items_host;               // what lds_items holds: the list depends on the level sizes, n_features, tile size, batch and level range
   uint32_t loss_blocks = 0;
 };
 
@@ -859,7 +851,8 @@ void network_release_scratch(const Network* n) { scratch_map().erase(n); }
 void Network::ensure_training_state(hipStream_t s)
 {
   if (opt_state_.count != n_params_) { opt_state_.resize(n_params_); launch_master_from_f16(params_f16_.ptr, opt_state_.ptr, n_params_, true, s); }
-  if (grads_.count != n_params_) { grads_.resize(n_params_); grads_.zero(s); }
+  // (an even number of halves: the packed fp16 atomics of the grid backward add PAIRS, and a Tiled grid of F = 1 can end on an odd element)
+  if (grads_.count != grads_alloc()) { grads_.resize(grads_alloc()); grads_.zero(s); }
 }
 
 void Network::reset_master_from_params(hipStream_t s)
@@ -871,9 +864,9 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
 {
   if (!valid()) throw std::runtime_error("network is not configured");
   if (batch == 0) return;
-  // the MFMA kernels: 64 neurons, Linear / Smoothstep, every level active, no quantisation; everything else the reference trains
-  // (tcnn_network.h:163-252 builds whatever the model JSON asks for) takes the generic kernels
-  const bool generic = !fast_path() || n_active_levels() != cfg_.n_levels;
+  // the MFMA kernels: every width, interpolation, activation and grid type the reference instantiates; models with a quantize_threshold or
+  // weight images beyond the LDS take the generic kernels (tcnn_network.h:163-252 builds whatever the model JSON asks for)
+  const bool generic = !fast_train_path();
   TrainScratch& ts = scratch_of(this);
   const uint32_t nh = n_hidden_matmuls();
   const uint32_t n = (uint32_t)batch;
@@ -890,20 +883,31 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     ws_loss_.resize(ts.loss_blocks);
     ws_batch_ = batch;
   }
-  const uint32_t pt = packedT_halves(in_width_, nh);
-  ts.packedT.ensure(pt);
 
   // 1. forward, keeping features and hidden activations
   profile_mark(0, s);
   if (generic)
     launch_generic(2, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_coords, ts.y.ptr, ws_features_.ptr, batch, nullptr,
                    batch, s, nullptr, 0, ws_acts_.ptr);
-  else
-    launch_fused(2, grid_, in_width_, nh, cfg_.activation, levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2, mlp_packed_.ptr,
-                 lds_halves_, d_coords, ts.y.ptr, ws_features_.ptr, ws_acts_.ptr, batch, nullptr, batch, s);
+  else {
+    GridDevice grid = grid_;
+    grid.n_levels = n_active_levels();   // masked levels encode to zero, like the padding (and receive no gradient below)
+    launch_fused(2, grid, in_width_, fused_mlp(), levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2, d_coords, ts.y.ptr, ws_features_.ptr,
+                 ws_acts_.ptr, batch, nullptr, batch, s);
+  }
   // 2. loss + output gradient
   profile_mark(1, s);
-  loss_grad_kernel<<<ts.loss_blocks, 256, 0, s>>>(ts.y.ptr, d_targets, n, cfg_.loss, (half_t*)ts.dy.ptr, ws_loss_.ptr);
+  loss_grad_kernel<<<ts.loss_blocks, 256, 0, s>>>(ts.y.ptr, d_targets, n, cfg_.loss, cfg_.output_activation, (half_t*)ts.dy.ptr, ws_loss_.ptr);
+  // the slab's elements no block ever writes (rows 1 .. 15 of the padded last layer) must be zero: they are summed into the gradient.  Zeroed
+  // when the slab grows or when the layout it was zeroed for changes (another n_mlp, the other kernel family: ADVICE r03)
+  auto ensure_slab = [&](size_t rows) {
+    const uint64_t key = ((uint64_t)n_mlp_ << 1) | (generic ? 1u : 0u);
+    if (ts.wgrad_slab.count < rows * n_mlp_ || ts.slab_key != key) {
+      if (ts.wgrad_slab.count < rows * n_mlp_) ts.wgrad_slab.resize(rows * n_mlp_);
+      ts.wgrad_slab.zero(s);
+      ts.slab_key = key;
+    }
+  };
   if (generic) {
     // 3g. MLP backward, 4g. weight gradients (generic kernels)
     GenericBackwardArgs ga;
@@ -917,31 +921,39 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     gw.dy = (const half_t*)ts.dy.ptr; gw.n = n; gw.nh = nh; gw.in_width = in_width_; gw.width = Wn; gw.n_mlp = (uint32_t)n_mlp_;
     gw.chunk = 1024;
     const uint32_t nchunks = div_round_up(batch, gw.chunk);
-    if (ts.wgrad_slab.count < (size_t)nchunks * n_mlp_) { ts.wgrad_slab.resize((size_t)nchunks * n_mlp_); ts.wgrad_slab.zero(s); }   // the padded last-layer rows stay zero
+    ensure_slab(nchunks);
     gw.slab = ts.wgrad_slab.ptr;
     const uint32_t n_elems = Wn * in_width_ + nh * Wn * Wn + Wn;
     generic_wgrad_kernel<<<dim3(div_round_up(n_elems, 256), nchunks), 256, 0, s>>>(gw);
     weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, s>>>(ts.wgrad_slab.ptr, nchunks, (uint32_t)n_mlp_, (half_t*)grads_.ptr);
     VNR_HIP_CHECK(hipGetLastError());
   } else {
-  // 3. MLP backward
-  pack_mlp_T_kernel<<<div_round_up(pt, 256), 256, 0, s>>>((const half_t*)params_f16_.ptr, (half_t*)ts.packedT.ptr, in_width_, nh);
+  // 3. MLP backward (the transposed weight image was packed with the forward one when the parameters last changed)
   BackwardArgs ba;
-  ba.packedT = (const half_t*)ts.packedT.ptr; ba.dy = (const half_t*)ts.dy.ptr; ba.acts = (const half_t*)ws_acts_.ptr;
+  ba.packedT = (const half_t*)mlp_packed_T_.ptr; ba.dy = (const half_t*)ts.dy.ptr; ba.acts = (const half_t*)ws_acts_.ptr;
   ba.d_out = (half_t*)ts.d_all.ptr; ba.dfeat = (half_t*)ws_dfeat_.ptr;
-  ba.n = n; ba.nh = nh; ba.activation = cfg_.activation; ba.in_width = in_width_; ba.lds_halves = pt;
+  ba.n = n; ba.nh = nh; ba.activation = cfg_.activation; ba.in_width = in_width_; ba.lds_halves = lds_halves_T_;
   {
-    const uint32_t blocks = std::min<uint32_t>(div_round_up(div_round_up(batch, 64), 4), (uint32_t)Runtime::get().n_cus * 4u);
-    const size_t shmem = (size_t)pt * 2;
+    const size_t shmem = (size_t)lds_halves_T_ * 2;
+    const uint32_t fit = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, kLdsBytes / shmem));
+    const uint32_t blocks = std::min<uint32_t>(div_round_up(div_round_up(batch, 64), 4), (uint32_t)Runtime::get().n_cus * fit);
     const int mt = (int)((in_width_ + 31) / 32);
     auto launch = [&](auto kernel) {
-      VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
       kernel<<<blocks, 256, shmem, s>>>(ba);
     };
-    if (mt == 1) launch(mlp_backward_kernel<1>);
-    else if (mt == 2) launch(mlp_backward_kernel<2>);
-    else if (mt == 3) launch(mlp_backward_kernel<3>);
-    else launch(mlp_backward_kernel<4>);
+    const bool gen = cfg_.activation > 1u;
+#define VNR_BWD_G(w, g) do { if (mt == 1) launch(mlp_backward_kernel<w, 1, g>); else if (mt == 2) launch(mlp_backward_kernel<w, 2, g>); \
+                             else if (mt == 3) launch(mlp_backward_kernel<w, 3, g>); else launch(mlp_backward_kernel<w, 4, g>); } while (0)
+#define VNR_BWD(w) do { if (gen) VNR_BWD_G(w, true); else VNR_BWD_G(w, false); } while (0)
+    switch (Wn) {
+    case 16: VNR_BWD(16); break;
+    case 32: VNR_BWD(32); break;
+    case 64: VNR_BWD(64); break;
+    default: VNR_BWD(128); break;
+    }
+#undef VNR_BWD
+#undef VNR_BWD_G
   }
   // 4. weight gradients
   profile_mark(2, s);
@@ -949,20 +961,26 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   wa.features = (const half_t*)ws_features_.ptr; wa.acts = (const half_t*)ws_acts_.ptr; wa.d_all = (const half_t*)ts.d_all.ptr;
   wa.dy = (const half_t*)ts.dy.ptr; wa.n = n; wa.nh = nh; wa.in_width = in_width_;
   {
-    // a block per 256 samples and matrix (padded_width is a multiple of 16 and at most 128: every model of the MFMA kernels)
+    // a block per 256 samples and matrix (padded_width is a multiple of 16 and at most 128)
     if (in_width_ % 8 != 0 || in_width_ > 128) throw std::runtime_error("internal: weight gradients of an input width the MFMA kernel does not cover");
     const uint32_t nblk = div_round_up(batch, (uint64_t)(kWgStage * kWgStages));
-    if (ts.wgrad_slab.count < (size_t)nblk * n_mlp_) {   // elements no block writes (padded rows of the last layer) stay zero
-      ts.wgrad_slab.resize((size_t)nblk * n_mlp_);
-      ts.wgrad_slab.zero(s);
-    }
+    ensure_slab(nblk);
     wa.slab = ts.wgrad_slab.ptr; wa.n_mlp = (uint32_t)n_mlp_;
     const dim3 g1(nblk, 1);
-    if (in_width_ <= 32) weight_grad_mfma_kernel<1><<<g1, 256, 0, s>>>(wa, 0);
-    else if (in_width_ <= 64) weight_grad_mfma_kernel<2><<<g1, 256, 0, s>>>(wa, 0);
-    else weight_grad_mfma_kernel<4><<<g1, 256, 0, s>>>(wa, 0);
     const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
-    weight_grad_mfma_kernel<2><<<g2, 256, 0, s>>>(wa, 1);
+    const int nt1 = in_width_ <= 32 ? 1 : in_width_ <= 64 ? 2 : 4;
+#define VNR_WG(w, mt_hidden) do {                                                                          \
+      if (nt1 == 1) weight_grad_mfma_kernel<w, 1><<<g1, 256, 0, s>>>(wa, 0);                               \
+      else if (nt1 == 2) weight_grad_mfma_kernel<w, 2><<<g1, 256, 0, s>>>(wa, 0);                          \
+      else weight_grad_mfma_kernel<w, 4><<<g1, 256, 0, s>>>(wa, 0);                                        \
+      weight_grad_mfma_kernel<w, mt_hidden><<<g2, 256, 0, s>>>(wa, 1); } while (0)
+    switch (Wn) {
+    case 16: VNR_WG(16, 1); break;
+    case 32: VNR_WG(32, 1); break;
+    case 64: VNR_WG(64, 2); break;
+    default: VNR_WG(128, 4); break;
+    }
+#undef VNR_WG
     weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, s>>>(ts.wgrad_slab.ptr, nblk, (uint32_t)n_mlp_, (half_t*)grads_.ptr);
   }
   }   // MFMA kernels
@@ -980,7 +998,8 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   const uint32_t tile_entries = (lds_kb * 1024u / (4u * cfg_.n_features)) & ~15u;
   uint32_t lds_levels = 0;
   if (lds_bwd)
-    while (lds_levels < n_active_levels() && !grid_.levels[lds_levels].hashed && div_round_up(grid_.levels[lds_levels].size, tile_entries) <= lds_max_tiles) ++lds_levels;
+    while (lds_levels < n_active_levels() && !grid_.levels[lds_levels].hashed && ((size_t)grid_.levels[lds_levels].offset * cfg_.n_features) % 2 == 0 &&
+           div_round_up(grid_.levels[lds_levels].size, tile_entries) <= lds_max_tiles) ++lds_levels;   // (the flush adds aligned pairs of halves)
   auto grid_backward_lds = [&](uint32_t l0, uint32_t l1) {
     // work items: every tile of every level x slices of the batch; more slices where a level has few tiles, so that ~2 blocks per CU exist
     std::vector<LdsBwdItem> items;
@@ -995,11 +1014,14 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
         }
     }
     if (items.empty()) return;
-    if (ts.lds_items_key != batch * 64 + l0 * 8 + l1 || ts.lds_items.count < items.size() * sizeof(LdsBwdItem)) {   // (the list depends on the batch size and the level range only)
-      ts.lds_items.resize(items.size() * sizeof(LdsBwdItem));
-      VNR_HIP_CHECK(hipMemcpyAsync(ts.lds_items.ptr, items.data(), items.size() * sizeof(LdsBwdItem), hipMemcpyHostToDevice, s));
+    // (cached on the device while the list is the same: it depends on the level sizes, n_features, the tile size, the batch and the level range,
+    // so the bytes themselves are the key: a re-configured model must not reuse the old model's tile and slice ranges)
+    const size_t item_bytes = items.size() * sizeof(LdsBwdItem);
+    if (ts.lds_items_host.size() != item_bytes || std::memcmp(ts.lds_items_host.data(), items.data(), item_bytes) != 0) {
+      ts.lds_items.ensure(item_bytes);
+      VNR_HIP_CHECK(hipMemcpyAsync(ts.lds_items.ptr, items.data(), item_bytes, hipMemcpyHostToDevice, s));
       VNR_HIP_CHECK(hipStreamSynchronize(s));   // pageable source
-      ts.lds_items_key = batch * 64 + l0 * 8 + l1;
+      ts.lds_items_host.assign((const uint8_t*)items.data(), (const uint8_t*)items.data() + item_bytes);
     }
     const size_t shmem = (size_t)tile_entries * cfg_.n_features * sizeof(float);
     half_t* gg = (half_t*)grads_.ptr + n_mlp_;
@@ -1076,7 +1098,7 @@ void Network::for_each_exchange_range(size_t bucket, const std::function<void(si
 
 void Network::optimizer_step(float grad_scale, hipStream_t s)
 {
-  if (grads_.count != n_params_) throw std::runtime_error("optimizer_step before forward_backward");
+  if (grads_.count != grads_alloc()) throw std::runtime_error("optimizer_step before forward_backward");
   if (opt_sharded_)
     throw std::runtime_error("the optimizer state of this volume is sharded over the ranks (vnrAmdNeuralVolumeTrainDataParallel): call "
                              "vnrAmdNeuralVolumeSyncReplicas on every rank before a step that updates all parameters on one rank");
@@ -1087,7 +1109,7 @@ void Network::optimizer_step(float grad_scale, hipStream_t s)
 
 void Network::optimizer_step_range(size_t lo, size_t hi, float grad_scale, hipStream_t s)
 {
-  if (opt_state_.count != n_params_ || grads_.count != n_params_) throw std::runtime_error("optimizer_step_range before forward_backward");
+  if (opt_state_.count != n_params_ || grads_.count != grads_alloc()) throw std::runtime_error("optimizer_step_range before forward_backward");
   if (hi > n_params_ || lo >= hi) throw std::runtime_error("optimizer_step_range: invalid parameter range");
   launch_adam(lo, hi, n_mlp_, grad_scale / (float)kLossScale, lr_, cfg_.beta1, cfg_.beta2, cfg_.epsilon, cfg_.l2_reg, opt_state_.ptr,
               (half_t*)params_f16_.ptr, (half_t*)grads_.ptr, s);
@@ -1095,7 +1117,7 @@ void Network::optimizer_step_range(size_t lo, size_t hi, float grad_scale, hipSt
 
 float* Network::grads_as_f32(hipStream_t s)
 {
-  if (grads_.count != n_params_) throw std::runtime_error("no gradient yet: call forward_backward / TrainBegin first");
+  if (grads_.count != grads_alloc()) throw std::runtime_error("no gradient yet: call forward_backward / TrainBegin first");
   grads_f32_.ensure(n_params_);
   unpack_grads_f16_kernel<<<(uint32_t)std::min<size_t>((n_params_ + 255) / 256, 8192), 256, 0, s>>>((const half_t*)grads_.ptr, grads_f32_.ptr, n_params_);
   VNR_HIP_CHECK(hipGetLastError());

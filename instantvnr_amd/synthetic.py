@@ -99,12 +99,12 @@ def model_config_text(**kw):
     return json.dumps(model_config(**kw))
 
 
-def random_params(n_params, mlp_params, seed=0):
-    """Seeded fp16 parameter blob: MLP weights ~ U(-0.35, 0.35), grid ~ U(-1, 1).
+def random_params(n_params, mlp_params, seed=0, mlp_scale=1.0):
+    """Seeded fp16 parameter blob: MLP weights ~ U(-0.35, 0.35) x mlp_scale, grid ~ U(-1, 1).
     (Larger than tcnn's init on purpose: parity tests want non-trivial activations.)"""
     rng = np.random.default_rng(seed)
     p = np.empty(n_params, dtype=np.float16)
-    p[:mlp_params] = rng.uniform(-0.35, 0.35, mlp_params).astype(np.float16)
+    p[:mlp_params] = (rng.uniform(-0.35, 0.35, mlp_params) * mlp_scale).astype(np.float16)
     p[mlp_params:] = rng.uniform(-1.0, 1.0, n_params - mlp_params).astype(np.float16)
     return p
 

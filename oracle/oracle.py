@@ -27,7 +27,7 @@ class GridConfig(C.Structure):
     _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32),
                 ("log2_hashmap_size", C.c_uint32), ("base_resolution", C.c_uint32),
                 ("per_level_scale", C.c_float), ("interpolation", C.c_uint32),
-                ("quantize_threshold", C.c_float), ("max_level", C.c_float)]
+                ("quantize_threshold", C.c_float), ("max_level", C.c_float), ("grid_type", C.c_uint32)]
 
 
 class GridLayout(C.Structure):
@@ -106,11 +106,23 @@ def f32_to_f16_bits(x):
 
 
 # --------------------------------------------------------------------------- grid
+ACTIVATIONS = {"None": 0, "ReLU": 1, "Exponential": 2, "Sigmoid": 3, "Squareplus": 4, "Softplus": 5}
+GRID_TYPES = {"Hash": 0, "Dense": 1, "Tiled": 2}
+
+
+def act_code(activation=1, output_activation=0):
+    """the `activation` argument of the C functions: hidden activation | output activation << 8 (names or codes)"""
+    a = ACTIVATIONS.get(activation, activation)
+    o = ACTIVATIONS.get(output_activation, output_activation)
+    return int(a) | (int(o) << 8)
+
+
 def grid_config(n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale=2.0,
-                interpolation=0, quantize_threshold=0.0, max_level=1000.0):
-    """interpolation: 0 Linear, 1 Smoothstep, 2 Nearest"""
+                interpolation=0, quantize_threshold=0.0, max_level=1000.0, grid_type=0):
+    """interpolation: 0 Linear, 1 Smoothstep, 2 Nearest; grid_type: 0 Hash, 1 Dense, 2 Tiled (or the names)"""
     return GridConfig(n_levels, n_features, log2_hashmap_size, base_resolution,
-                      float(per_level_scale), interpolation, float(quantize_threshold), float(max_level))
+                      float(per_level_scale), interpolation, float(quantize_threshold), float(max_level),
+                      int(GRID_TYPES.get(grid_type, grid_type)))
 
 
 def grid_layout(cfg):

@@ -48,7 +48,8 @@ def corner_indices_and_weights(cfg, lay, coords):
         while d < 3 and stride <= size:
             stride *= res
             d += 1
-        hashed = size < stride
+        hashed = size < stride and getattr(cfg, "grid_type", 0) == 0   # EXTERNAL tcnn grid_index: only a Hash grid hashes
+        n_dims = d                                                        # a Dense / Tiled level indexes over the dimensions the walk covered
         idxs = np.zeros((coords.shape[0], 8), np.int64)
         ws = np.zeros((coords.shape[0], 8), np.float32)
         if float(l) >= cfg.max_level + 1e-3:
@@ -63,7 +64,12 @@ def corner_indices_and_weights(cfg, lay, coords):
             if hashed:
                 idx = pl[0] ^ ((pl[1] * 2654435761) & 0xFFFFFFFF) ^ ((pl[2] * 805459861) & 0xFFFFFFFF)
             else:
-                idx = (pl[0] + pl[1] * res + pl[2] * res * res) & 0xFFFFFFFF
+                idx = pl[0]
+                if n_dims >= 2:
+                    idx = idx + pl[1] * res
+                if n_dims >= 3:
+                    idx = idx + pl[2] * res * res
+                idx = idx & 0xFFFFFFFF
             idxs[:, c] = idx % size
         if cfg.interpolation == 2:
             # Nearest (tcnn_impl_decoder.cu:73-94 reads the lower corner's entry as it is): EXTERNAL tcnn kernel_grid_backward gives that one
@@ -74,7 +80,28 @@ def corner_indices_and_weights(cfg, lay, coords):
     return out
 
 
-def training_gradients(cfg, width, n_hidden_layers, params_bits, coords, targets, loss="L1", activation=1):
+def act_backward(d, y, activation):
+    """EXTERNAL tcnn warp_activation_backward: the gradient through the activation from its OUTPUT y (fp16 values as float32), every factor
+    rounded to fp16 as tcnn's half arithmetic rounds it.  d, y: float32 arrays of fp16 values; returns float32 of fp16 values."""
+    a = o.ACTIVATIONS.get(activation, activation)
+    if a == 0:
+        return d
+    if a == 1:
+        return np.where(y > 0, d, np.float32(0))
+    if a == 2:
+        return f16(d * y).astype(np.float32)
+    if a == 3:
+        inner = f16(np.float32(1) - y).astype(np.float32)
+        return f16(d * f16(y * inner).astype(np.float32)).astype(np.float32)
+    if a == 4:
+        t = y * np.float32(10)
+        return f16(d * f16(t * t / (t * t + np.float32(1))).astype(np.float32)).astype(np.float32)
+    if a == 5:
+        return f16(d * f16(np.float32(1) - np.exp(-y * np.float32(10))).astype(np.float32)).astype(np.float32)
+    raise ValueError(activation)
+
+
+def training_gradients(cfg, width, n_hidden_layers, params_bits, coords, targets, loss="L1", activation=1, output_activation=0):
     """returns dict(loss, grads [n_params] float64 (loss-scaled), y)"""
     lay = o.grid_layout(cfg)
     in_w = o.padded_width(cfg)
@@ -84,7 +111,7 @@ def training_gradients(cfg, width, n_hidden_layers, params_bits, coords, targets
     w1, wh, wl, n_mlp = split_mlp(params, in_w, width, nh)
     B = coords.shape[0]
     feat = o.grid_encode(cfg, params[n_mlp:].view(np.uint16), coords)
-    y, acts = o.mlp_forward(params[:n_mlp].view(np.uint16), in_w, width, nh, feat, activation=activation, want_activations=True)
+    y, acts = o.mlp_forward(params[:n_mlp].view(np.uint16), in_w, width, nh, feat, activation=o.act_code(activation, output_activation), want_activations=True)
     feat = feat.view(np.float16).astype(np.float32)
     acts = acts.view(np.float16).astype(np.float32)  # [nh+1, B, W]
     diff = y - np.asarray(targets, np.float32)
@@ -95,19 +122,19 @@ def training_gradients(cfg, width, n_hidden_layers, params_bits, coords, targets
         loss_val = float((diff * diff).sum() / B)
         g = 2 * diff
     dy = f16(np.float32(LOSS_SCALE) * g / np.float32(B)).astype(np.float32)
+    # EXTERNAL tcnn FullyFusedMLP::backward: with an output activation the loss gradient first goes through it, from the output values
+    dy = act_backward(dy, y.astype(np.float32), output_activation)
     grads = np.zeros(params.size, np.float64)
     # last layer (row 0 only; padded outputs have zero gradient)
     off_last = width * in_w + nh * width * width
     grads[off_last:off_last + width] = (dy[:, None].astype(np.float64) * acts[nh]).sum(0)
     d = f16(wl[0].astype(np.float32)[None, :] * dy[:, None]).astype(np.float32)
-    if activation == 1:
-        d = np.where(acts[nh] > 0, d, 0)
+    d = act_backward(d, acts[nh], activation)
     for l in range(nh - 1, -1, -1):
         off = width * in_w + l * width * width
         grads[off:off + width * width] = (d.astype(np.float64).T @ acts[l].astype(np.float64)).ravel()
         d = f16(d.astype(np.float64) @ wh[l].astype(np.float64)).astype(np.float32)
-        if activation == 1:
-            d = np.where(acts[l] > 0, d, 0)
+        d = act_backward(d, acts[l], activation)
     grads[0:width * in_w] = (d.astype(np.float64).T @ feat.astype(np.float64)).ravel()
     dfeat = f16(d.astype(np.float64) @ w1.astype(np.float64)).astype(np.float32)  # [B, in_w]
     cw = corner_indices_and_weights(cfg, lay, coords)

@@ -119,8 +119,14 @@ uint32_t vnro_grid_make_layout(const vnro_grid_config* cfg, vnro_grid_layout* ou
     const double cube = (double)res * (double)res * (double)res;
     uint32_t n = cube > (double)max_params ? max_params : (uint32_t)cube;
     n = next_multiple_u32(n, 8u);
-    const uint32_t cap = 1u << cfg->log2_hashmap_size;
-    if (n > cap) n = cap;
+    /* EXTERNAL tcnn GridEncodingTemplated ctor: Dense keeps the full level; Tiled caps it at base_resolution^3; Hash at 2^log2_hashmap_size */
+    if (cfg->grid_type == 2u) {
+      const double tile = (double)cfg->base_resolution * cfg->base_resolution * cfg->base_resolution;
+      if ((double)n > tile) n = (uint32_t)tile;
+    } else if (cfg->grid_type == 0u) {
+      const uint32_t cap = 1u << cfg->log2_hashmap_size;
+      if (n > cap) n = cap;
+    }
     out->offsets[l] = offset;
     out->scale[l] = scale;
     out->resolution[l] = res;
@@ -132,18 +138,24 @@ uint32_t vnro_grid_make_layout(const vnro_grid_config* cfg, vnro_grid_layout* ou
 
 /* EXTERNAL (tcnn `grid_index` + `fast_hash`, common_device.h / grid.h); call
  * site ref: core/networks/tcnn_impl_decoder.cu:68-69. */
-uint32_t vnro_grid_index(uint32_t hashmap_size, uint32_t resolution, const uint32_t p[3])
+uint32_t vnro_grid_index_typed(uint32_t grid_type, uint32_t hashmap_size, uint32_t resolution, const uint32_t p[3])
 {
   uint32_t stride = 1;
   uint32_t index = 0;
+  /* the second part of the loop condition avoids integer overflows in finer levels (upstream comment) */
   for (uint32_t dim = 0; dim < 3 && stride <= hashmap_size; ++dim) {
     index += p[dim] * stride;
     stride *= resolution;
   }
-  if (hashmap_size < stride) {
+  if (grid_type == 0u /* Hash */ && hashmap_size < stride) {
     index = (p[0] * 1u) ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u);
   }
   return index % hashmap_size;
+}
+
+uint32_t vnro_grid_index(uint32_t hashmap_size, uint32_t resolution, const uint32_t p[3])
+{
+  return vnro_grid_index_typed(0u, hashmap_size, resolution, p);
 }
 
 /* ref: core/networks/tcnn_impl_decoder.cu:7-175 (encode_one_level), Linear /
@@ -176,7 +188,7 @@ static void encode_one_level(const vnro_grid_config* cfg, const vnro_grid_layout
   }
 
   if (cfg->interpolation == 2) {                 /* Nearest (:73-94): the entry of the lower corner, no quantisation, no blend */
-    const uint32_t index = vnro_grid_index(hashmap_size, res, pos_grid) * F;
+    const uint32_t index = vnro_grid_index_typed(cfg->grid_type, hashmap_size, res, pos_grid) * F;
     for (uint32_t f = 0; f < F; ++f) out[f] = grid[index + f];
     return;
   }
@@ -194,7 +206,7 @@ static void encode_one_level(const vnro_grid_config* cfg, const vnro_grid_layout
         pl[d] = pos_grid[d] + 1u;
       }
     }
-    const uint32_t index = vnro_grid_index(hashmap_size, res, pl) * F;
+    const uint32_t index = vnro_grid_index_typed(cfg->grid_type, hashmap_size, res, pl) * F;
     for (uint32_t f = 0; f < F; ++f) {
       float data = vnro_f16_to_f32(grid[index + f]);
       if (fabsf(data) < cfg->quantize_threshold) data = 0.0f;             /* :120 */
@@ -253,12 +265,27 @@ static float dense_dot(const uint16_t* w_row, const uint16_t* x, uint32_t in, in
   return vnro_f16_to_f32(acc);
 }
 
+/* EXTERNAL tcnn warp_activation (common_device.h, v1.4-1.5 era; call sites tcnn_threadblock.h:125,308,437,497): the function is
+ * evaluated in fp32 on the half value and the result rounded back to half; K_ACT = 10 for Squareplus / Softplus.  tcnn uses the
+ * fast intrinsics __expf for Exponential / Sigmoid (a few fp32 ulp from expf: invisible after the rounding to half except at
+ * halfway cases, covered by the tests' 2^-8 tolerance). */
+static inline uint16_t act_on_f16(uint16_t h, int activation)
+{
+  const float x = vnro_f16_to_f32(h);
+  switch (activation) {
+  case VNRO_ACT_RELU: return (h & 0x8000u) ? 0 : h; /* relu(-0) = 0 too */
+  case VNRO_ACT_EXPONENTIAL: return vnro_f32_to_f16(expf(x));
+  case VNRO_ACT_SIGMOID: return vnro_f32_to_f16(1.0f / (1.0f + expf(-x)));
+  case VNRO_ACT_SQUAREPLUS: { const float t = x * 10.0f; return vnro_f32_to_f16(0.5f * (t + sqrtf(t * t + 4.0f)) / 10.0f); }
+  case VNRO_ACT_SOFTPLUS: return vnro_f32_to_f16(logf(expf(x * 10.0f) + 1.0f) / 10.0f);
+  default: return h;
+  }
+}
+
 static inline uint16_t apply_act_f16(float v, int activation)
 {
   /* activation is applied on the half result fragment (tcnn_threadblock.h:125) */
-  uint16_t h = vnro_f32_to_f16(v);
-  if (activation == VNRO_ACT_RELU && (h & 0x8000u)) h = 0; /* relu(-0) = 0 too */
-  return h;
+  return act_on_f16(vnro_f32_to_f16(v), activation);
 }
 
 /* ref: tcnn_impl.cu:191-246 (layer order + weight offsets), tcnn_threadblock.h:59-144,
@@ -269,6 +296,8 @@ void vnro_mlp_forward(const uint16_t* weights, uint32_t in_width, uint32_t width
 {
   uint16_t* a = (uint16_t*)malloc(sizeof(uint16_t) * width);
   uint16_t* b = (uint16_t*)malloc(sizeof(uint16_t) * width);
+  const int output_activation = (activation >> 8) & 0xff;   /* see vnr_oracle.h */
+  activation &= 0xff;
   const uint16_t* w_first = weights;
   const uint16_t* w_hidden = weights + (size_t)width * in_width;            /* first_layer_size, tcnn_impl.cu:209 */
   const uint16_t* w_last = w_hidden + (size_t)n_hidden_matmuls * width * width; /* :241 */
@@ -284,9 +313,9 @@ void vnro_mlp_forward(const uint16_t* weights, uint32_t in_width, uint32_t width
       uint16_t* t = a; a = b; b = t;
       if (act_out) memcpy(act_out + ((size_t)(l + 1) * n + i) * width, a, sizeof(uint16_t) * width);
     }
-    /* last layer: 16 padded outputs, output activation None, only neuron 0 is used */
+    /* last layer: 16 padded outputs, only neuron 0 is used; the output activation on the half result (tcnn_threadblock.h:497) */
     const float y = dense_dot(w_last, a, width, acc_mode);
-    out[i] = vnro_f16_to_f32(vnro_f32_to_f16(y));
+    out[i] = vnro_f16_to_f32(act_on_f16(vnro_f32_to_f16(y), output_activation));
   }
   free(a);
   free(b);

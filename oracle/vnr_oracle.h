@@ -43,6 +43,7 @@ typedef struct {
   uint32_t interpolation;     /* 0 = Linear (default), 1 = Smoothstep, 2 = Nearest (tcnn_impl_decoder.cu:73-94) */
   float    quantize_threshold;/* corner values below it in magnitude count as 0 (:120); EXTERNAL tcnn default 0 */
   float    max_level;         /* levels l >= max_level + 1e-3 encode to 0 (:17); EXTERNAL tcnn default 1000 (no masking) */
+  uint32_t grid_type;         /* 0 = Hash (default), 1 = Dense, 2 = Tiled: tcnn GridType, passed to grid_index at tcnn_impl_decoder.cu:68-69 */
 } vnro_grid_config;
 
 #define VNRO_MAX_LEVELS 32
@@ -56,8 +57,10 @@ typedef struct {
 /* returns total number of table entries (sum over levels) */
 uint32_t vnro_grid_make_layout(const vnro_grid_config* cfg, vnro_grid_layout* out);
 
-/* index of corner p in a level (entries, not elements) */
+/* index of corner p in a level (entries, not elements); Hash grid */
 uint32_t vnro_grid_index(uint32_t hashmap_size, uint32_t resolution, const uint32_t p[3]);
+/* the same for any grid type (0 Hash, 1 Dense, 2 Tiled) */
+uint32_t vnro_grid_index_typed(uint32_t grid_type, uint32_t hashmap_size, uint32_t resolution, const uint32_t p[3]);
 
 /* coords: [n][3] fp32 AoS in [0,1]; table: fp16 [total_entries * F];
  * out: fp16 [n][padded_width] row-major (padded_width = roundup(L*F,16), pad = 0) */
@@ -65,7 +68,9 @@ void vnro_grid_encode(const vnro_grid_config* cfg, const uint16_t* table,
                       const float* coords, size_t n, uint16_t* out, uint32_t padded_width);
 
 /* ---- fully fused MLP -------------------------------------------------- */
-enum { VNRO_ACT_NONE = 0, VNRO_ACT_RELU = 1 };
+/* the activations the reference dispatches (tcnn_impl.cu:405-415, tcnn_device_api.h:274-285).  `activation` arguments below carry the
+ * hidden activation in bits 0-7 and the OUTPUT activation in bits 8-15 (0 = None, the reference's example-model.json). */
+enum { VNRO_ACT_NONE = 0, VNRO_ACT_RELU = 1, VNRO_ACT_EXPONENTIAL = 2, VNRO_ACT_SIGMOID = 3, VNRO_ACT_SQUAREPLUS = 4, VNRO_ACT_SOFTPLUS = 5 };
 enum { VNRO_ACC_F32 = 0, VNRO_ACC_F16 = 1 };
 
 /* weights: fp16, row-major [out][in] per layer: first (W x in_width),

@@ -201,7 +201,8 @@ def test_free_temporary_gpu_memory_drops_the_caches(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ every shape the reference accepts
-# (L, F, log2T, base, pls, H, n_neurons, interpolation, quantize_threshold, max_level)
+# (L, F, log2T, base, pls, H, n_neurons, interpolation, quantize_threshold, max_level[, extras])
+# extras: activation / output_activation (tcnn_impl.cu:405-415, tcnn_device_api.h:274-285), grid type (tcnn_impl_decoder.cu:68-69)
 ACCEPTED = [
     (8, 2, 12, 4, None, 2, 16, "Linear", 0.0, None),       # FullyFusedMLP WIDTH 16 / 32 / 128 (tcnn_impl.cu:315-347)
     (8, 2, 12, 4, None, 3, 32, "Linear", 0.0, None),
@@ -214,18 +215,41 @@ ACCEPTED = [
     (8, 2, 12, 4, None, 2, 64, "Linear", 0.0, 5.0),        # max_level (:17): levels l >= 5.001, i.e. 6 and 7, encode to zero; on the MFMA kernels
     (8, 2, 12, 4, None, 2, 64, "Linear", 0.0, 2.5),        # a fractional bound: levels >= 2.501, i.e. 3 ..
     (8, 2, 12, 4, None, 2, 16, "Nearest", 0.0, 4.0),
+    # round 4: the rest of the reference's dispatch
+    (8, 2, 12, 4, None, 4, 128, "Linear", 0.0, None),      # 128 neurons, 3 hidden matmuls: a 104 KB weight image, one block of 8 waves per CU
+    (12, 8, 14, 4, 1.5, 2, 32, "Linear", 0.0, None),       # encoded width 96 into 32 neurons
+    (8, 2, 12, 4, None, 3, 64, "Linear", 0.0, None, {"activation": "Sigmoid"}),
+    (8, 2, 12, 4, None, 2, 64, "Linear", 0.0, None, {"activation": "Exponential"}),
+    (8, 4, 12, 4, None, 2, 32, "Linear", 0.0, None, {"activation": "Squareplus"}),
+    (6, 2, 12, 4, None, 2, 128, "Linear", 0.0, None, {"activation": "Softplus"}),
+    (8, 2, 12, 4, None, 2, 16, "Smoothstep", 0.0, None, {"activation": "None"}),
+    (8, 2, 12, 4, None, 2, 64, "Linear", 0.0, None, {"output_activation": "Sigmoid"}),
+    (8, 2, 12, 4, None, 2, 32, "Linear", 0.0, None, {"activation": "Squareplus", "output_activation": "Exponential"}),
+    (6, 2, 12, 4, None, 2, 64, "Linear", 0.0, None, {"output_activation": "ReLU"}),
+    (4, 2, 12, 4, None, 2, 64, "Linear", 0.0, None, {"grid_type": "Dense"}),       # levels of 4^3 .. 32^3 grid points, none hashed, no cap
+    (5, 4, 12, 4, None, 2, 32, "Smoothstep", 0.0, None, {"grid_type": "Dense"}),
+    (8, 2, 12, 4, None, 2, 64, "Linear", 0.0, None, {"grid_type": "Tiled"}),       # every level 4^3 entries, finer levels wrap (2 or 3 index dimensions)
+    (6, 8, 12, 8, 1.5, 2, 128, "Nearest", 0.0, None, {"grid_type": "Tiled"}),
+    (8, 1, 12, 5, None, 2, 16, "Linear", 0.0, None, {"grid_type": "Tiled"}),       # 5^3 = 125 entries: a modulus that is not a power of two
 ]
 INTERP = {"Linear": 0, "Smoothstep": 1, "Nearest": 2}
 
 
 @pytest.mark.parametrize("case", ACCEPTED)
 def test_models_the_reference_accepts_load_and_evaluate(oracle, case):
-    """encode bit-exact, output within 2^-8 of the oracle for the model shapes outside the MFMA kernels' configuration; they are
-    evaluated by the generic kernel (max_level alone stays on the MFMA kernels)."""
-    L, F, log2T, base, pls, H, W, interp, qt, max_level = case
+    """encode bit-exact, output within 2^-8 of the oracle, gradients within 3 % of the numpy restatement and 60 steps that converge, for
+    every FullyFusedMLP width, interpolation, activation, output activation and grid type the reference's dispatch accepts: all on the
+    MFMA kernels since round 4 (a quantize_threshold alone takes the generic kernels)."""
+    L, F, log2T, base, pls, H, W, interp, qt, max_level = case[:10]
+    extra = case[10] if len(case) > 10 else {}
+    act, out_act, gtype = extra.get("activation", "ReLU"), extra.get("output_activation", "None"), extra.get("grid_type", "Hash")
     cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base, n_hidden_layers=H, per_level_scale=pls)
     cfg["encoding"]["interpolation"] = interp
     cfg["network"]["n_neurons"] = W
+    cfg["network"]["activation"] = act
+    cfg["network"]["output_activation"] = out_act
+    if gtype != "Hash":
+        cfg["encoding"]["type"] = gtype
     if qt:
         cfg["encoding"]["quantize_threshold"] = qt
     if max_level is not None:
@@ -234,10 +258,12 @@ def test_models_the_reference_accepts_load_and_evaluate(oracle, case):
     vol = api.vnrCreateNeuralVolume(cfg, sv)
     info = api.neural_info(vol)
     assert info["n_neurons"] == W
-    ocfg = oracle.grid_config(L, F, log2T, base, 2.0 if pls is None else pls, INTERP[interp], qt, 1000.0 if max_level is None else max_level)
+    assert bool(info["mfma_kernels"]) == (qt == 0.0)
+    ocfg = oracle.grid_config(L, F, log2T, base, 2.0 if pls is None else pls, INTERP[interp], qt, 1000.0 if max_level is None else max_level, gtype)
     assert info["n_params"] == oracle.n_params(ocfg, W, H)
     n_mlp = oracle.mlp_n_params(info["padded_width"], W, H - 1)
-    params = syn.random_params(info["n_params"], n_mlp, seed=11)
+    # Exponential / Softplus (x 10 inside) grow fast: smaller weights keep the activations in fp16's range, as a trained model's are
+    params = syn.random_params(info["n_params"], n_mlp, seed=11, mlp_scale=0.35 if act in ("Exponential", "Softplus") or out_act == "Exponential" else 1.0)
     api.neural_set_params_fp16(vol, params)
     coords = coords_for(2049, 12)
     enc = api.neural_encode(vol, coords)
@@ -247,18 +273,18 @@ def test_models_the_reference_accepts_load_and_evaluate(oracle, case):
         first_masked = int(np.ceil(max_level + 1e-3 - 1e-9))
         assert not enc[:, first_masked * F:].any() and enc[:, :first_masked * F].any()
     got = api.neural_inference(vol, coords)
-    want = oracle.network_inference(ocfg, W, H, params.view(np.uint16), coords)
-    assert np.isfinite(got).all() and np.abs(want).max() > 0.01
-    assert np.abs(got - want).max() <= TOL_ABS * max(1.0, np.abs(want).max())
-    # ... and trains (round 3): gradients of one batch against the numpy restatement at the bar of tests/test_gpu_train.py; these shapes take
-    # the generic forward / backward / weight-gradient kernels (csrc/network_train.hip), Nearest and max_level their branches of the scatter
+    code = oracle.act_code(act, out_act)
+    want = oracle.network_inference(ocfg, W, H, params.view(np.uint16), coords, activation=code)
+    assert np.isfinite(got).all() and np.isfinite(want).all() and np.abs(want).max() > 0.01
+    assert np.abs(got - want).max() <= TOL_ABS * max(1.0, np.abs(want).max()), (np.abs(got - want).max(), np.abs(want).max())
+    # ... and trains: gradients of one batch against the numpy restatement at the bar of tests/test_gpu_train.py
     from oracle import train_oracle as T
     rng = np.random.default_rng(21)
     B = 700
     tc = rng.uniform(0, 1, (B, 3)).astype(np.float32)
     tt = rng.uniform(0, 1, B).astype(np.float32)
     grads = api.neural_forward_backward(vol, tc, tt).astype(np.float64)
-    ref = T.training_gradients(ocfg, W, H, params.view(np.uint16), tc, tt, loss="L1")
+    ref = T.training_gradients(ocfg, W, H, params.view(np.uint16), tc, tt, loss="L1", activation=act, output_activation=out_act)
     assert np.isclose(api.vnrNeuralVolumeGetTrainingLoss(vol), ref["loss"], rtol=2e-3)
     for name, sl in [("mlp", slice(0, n_mlp)), ("grid", slice(n_mlp, None))]:
         g, w = grads[sl], ref["grads"][sl]
@@ -272,13 +298,45 @@ def test_models_the_reference_accepts_load_and_evaluate(oracle, case):
         lay = oracle.grid_layout(ocfg)
         first_masked = int(np.ceil(max_level + 1e-3 - 1e-9))
         assert not grads[n_mlp + int(lay["offsets"][first_masked]) * F:].any()
-    # and an optimizer step moves the parameters; 30 steps on the analytic volume bring the loss down
+    # and an optimizer step moves the parameters; 60 steps on the analytic volume bring the loss down
     api.neural_train_end(vol)
     assert not np.array_equal(api.neural_get_params_fp16(vol).view(np.uint16), params.view(np.uint16))
     api.vnrNeuralVolumeTrain(vol, 1, True)
     first = api.vnrNeuralVolumeGetTrainingLoss(vol)
     api.vnrNeuralVolumeTrain(vol, 60, True)
     assert np.isfinite(api.vnrNeuralVolumeGetTrainingLoss(vol)) and api.vnrNeuralVolumeGetTrainingLoss(vol) < first
+
+
+def test_reconfiguring_a_model_does_not_reuse_the_old_models_training_scratch(oracle):
+    """the tile lists of the dense levels' LDS scatter and the zeroed part of the weight-gradient slab are cached per
+    network; SetModel to a shape with the same batch and level count (n_features 4 -> 2, n_neurons 64 -> 32) must give the gradients of a
+    freshly created model of that shape"""
+    from oracle import train_oracle as T
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(16))
+    cfg_a = syn.model_config(n_levels=6, n_features=4, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
+    cfg_b = syn.model_config(n_levels=6, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
+    cfg_b["network"]["n_neurons"] = 32
+    vol = api.vnrCreateNeuralVolume(cfg_a, sv)
+    rng = np.random.default_rng(5)
+    tc = rng.uniform(0, 1, (4096, 3)).astype(np.float32)
+    tt = rng.uniform(0, 1, 4096).astype(np.float32)
+    api.neural_forward_backward(vol, tc, tt)
+    api.neural_train_end(vol)
+    api.vnrNeuralVolumeSetModel(vol, cfg_b)
+    info = api.neural_info(vol)
+    n_mlp = oracle.mlp_n_params(info["padded_width"], 32, 1)
+    params = syn.random_params(info["n_params"], n_mlp, seed=3)
+    api.neural_set_params_fp16(vol, params)
+    got = api.neural_forward_backward(vol, tc, tt).astype(np.float64)
+    fresh = api.vnrCreateNeuralVolume(cfg_b, sv)
+    api.neural_set_params_fp16(fresh, params)
+    want = api.neural_forward_backward(fresh, tc, tt).astype(np.float64)
+    # packed fp16 atomics arrive in any order on the hashed levels: equal up to that, and equal to the restatement at the usual bar
+    assert np.linalg.norm(got - want) <= 2e-3 * np.linalg.norm(want)
+    assert np.array_equal(got[n_mlp - 16 * 32 + 32:n_mlp], np.zeros(15 * 32))      # the padded rows of the last layer
+    ocfg = oracle.grid_config(6, 2, 12, 4)
+    ref = T.training_gradients(ocfg, 32, 2, params.view(np.uint16), tc, tt, loss="L1")["grads"]
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 3e-2
 
 
 def test_a_rendered_frame_of_a_generic_model_equals_the_oracle(oracle):

@@ -280,3 +280,80 @@ def test_threaded_network_inference_equals_the_scalar_call(oracle):
     a = oracle.network_inference(cfg, 64, 2, params, coords)
     b = oracle.network_inference_mt(cfg, 64, 2, params, coords, n_threads=4)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.abs(a).max() > 0
+
+
+def test_dense_and_tiled_grids_hand_cases(oracle):
+    """round 4: grid types beside Hash (tcnn_impl_decoder.cu:68-69 passes grid_type to grid_index; EXTERNAL tcnn ctor sizes the levels).
+    base 4, 4 levels: resolutions 4, 8, 16, 32.  Dense keeps every level whole (64, 512, 4096, 32768 entries); Tiled caps every level at
+    base^3 = 64 entries and indexes with the partial stride walk modulo 64; Hash with T = 2^10 hashes levels 2 and 3."""
+    dense = oracle.grid_layout(oracle.grid_config(4, 2, 10, 4, grid_type="Dense"))
+    assert list(dense["offsets"]) == [0, 64, 64 + 512, 64 + 512 + 4096, 64 + 512 + 4096 + 32768]
+    tiled = oracle.grid_layout(oracle.grid_config(4, 2, 10, 4, grid_type="Tiled"))
+    assert list(tiled["offsets"]) == [0, 64, 128, 192, 256]
+    hashed = oracle.grid_layout(oracle.grid_config(4, 2, 10, 4))
+    assert list(hashed["offsets"]) == [0, 64, 64 + 512, 64 + 512 + 1024, 64 + 512 + 2048]
+    import ctypes as C
+    L = oracle.lib()
+    L.vnro_grid_index_typed.restype = C.c_uint32
+
+    def idx(t, size, res, p):
+        return int(L.vnro_grid_index_typed(C.c_uint32(t), C.c_uint32(size), C.c_uint32(res), (C.c_uint32 * 3)(*p)))
+
+    # Dense, res 8 (512 entries): x + 8 y + 64 z
+    assert idx(1, 512, 8, (3, 2, 1)) == 3 + 16 + 64
+    # Tiled, res 8, 64 entries: the walk takes x (stride 8 <= 64), y (stride 64 <= 64), z (stride 512 > 64 afterwards): x + 8 y + 64 z mod 64
+    assert idx(2, 64, 8, (3, 2, 1)) == (3 + 16 + 64) % 64 == 19
+    # Tiled, res 16: x (stride 16), y (stride 256 > 64: the walk stops): z does not enter the index
+    assert idx(2, 64, 16, (3, 2, 9)) == (3 + 32) % 64 == 35
+    assert idx(2, 64, 16, (3, 2, 9)) == idx(2, 64, 16, (3, 2, 0))
+    # Tiled, res 128: x only (stride 128 > 64 after the first dimension)
+    assert idx(2, 64, 128, (70, 5, 9)) == 70 % 64
+    # the same level under Hash hashes instead
+    assert idx(0, 64, 128, (70, 5, 9)) == ((70 ^ (5 * 2654435761) ^ (9 * 805459861)) & 0xFFFFFFFF) % 64
+    # a modulus that is not a power of two (base 5: 125 entries after next_multiple(125, 8) = 128 is capped at 125)
+    t5 = oracle.grid_layout(oracle.grid_config(3, 1, 10, 5, grid_type="Tiled"))
+    assert list(np.diff(t5["offsets"].astype(np.int64))) == [125, 125, 125]
+    assert idx(2, 125, 10, (9, 9, 9)) == (9 + 90 + 900) % 125
+    # encode of a Tiled level with a ramp table: value = index, Nearest picks table[index of the lower corner]
+    cfg = oracle.grid_config(2, 1, 10, 4, interpolation=2, grid_type="Tiled")
+    table = np.arange(128, dtype=np.float32).astype(np.float16)
+    c = np.array([[0.5, 0.25, 0.75]], np.float32)
+    enc = oracle.grid_encode(cfg, table.view(np.uint16), c).view(np.float16)[0]
+    # level 0: scale 3, pos = 0.5*3+0.5 = 2 -> g = (2, 1, 2): 2 + 4 + 32 = 38;  level 1: scale 7: g = (4, 2, 5): 4 + 16 + 320 = 340 % 64 = 20, + offset 64
+    assert enc[0] == 38 and enc[1] == 84
+
+
+def test_activations_hand_cases_and_derivatives(oracle):
+    """round 4: the activations the reference dispatches (tcnn_impl.cu:405-415): known values at 0 and 1 through the C MLP (one
+    1 x 16 layer chain with identity-like weights), and the backward formulas of oracle/train_oracle.py (EXTERNAL tcnn
+    warp_activation_backward, from the OUTPUT value) against central differences of the forward functions in float64"""
+    from oracle import train_oracle as T
+    fw = {"None": lambda x: x, "ReLU": lambda x: np.maximum(x, 0), "Exponential": np.exp, "Sigmoid": lambda x: 1 / (1 + np.exp(-x)),
+          "Squareplus": lambda x: 0.5 * (10 * x + np.sqrt(100 * x * x + 4)) / 10, "Softplus": lambda x: np.log(np.exp(10 * x) + 1) / 10}
+    # forward through the C oracle: W = 16, in = 16, one hidden layer: first layer = identity on feature 0, last layer row 0 picks neuron 0
+    W, in_w = 16, 16
+    w1 = np.zeros((W, in_w), np.float16); w1[0, 0] = 1
+    wl = np.zeros((16, W), np.float16); wl[0, 0] = 1
+    weights = np.concatenate([w1.ravel(), wl.ravel()]).view(np.uint16)
+    xs = np.array([0.0, 1.0, -1.0, 0.25], np.float32)
+    x = np.zeros((xs.size, in_w), np.float16); x[:, 0] = xs
+    for name, f in fw.items():
+        y = oracle.mlp_forward(weights, in_w, W, 0, x.view(np.uint16), activation=oracle.act_code(name))
+        want = f(xs.astype(np.float64)).astype(np.float16).astype(np.float32)
+        assert np.allclose(y, want, rtol=2e-3, atol=1e-6), (name, y, want)
+        # ... and as the OUTPUT activation on a linear hidden layer
+        y2 = oracle.mlp_forward(weights, in_w, W, 0, x.view(np.uint16), activation=oracle.act_code("None", name))
+        assert np.allclose(y2, want, rtol=2e-3, atol=1e-6), (name, y2, want)
+    assert oracle.mlp_forward(weights, in_w, W, 0, x.view(np.uint16), activation=oracle.act_code("Sigmoid"))[0] == 0.5
+    assert oracle.mlp_forward(weights, in_w, W, 0, x.view(np.uint16), activation=oracle.act_code("Exponential"))[0] == 1.0
+    assert abs(oracle.mlp_forward(weights, in_w, W, 0, x.view(np.uint16), activation=oracle.act_code("Squareplus"))[0] - 0.1) < 1e-4
+    assert abs(oracle.mlp_forward(weights, in_w, W, 0, x.view(np.uint16), activation=oracle.act_code("Softplus"))[0] - np.log(2) / 10) < 1e-4
+    # backward: d * f'(x) expressed through y = f(x)
+    pts = np.linspace(-0.4, 0.4, 33)
+    pts = pts[np.abs(pts) > 1e-3]      # (ReLU's kink)
+    for name, f in fw.items():
+        y = f(pts).astype(np.float16).astype(np.float32)
+        got = T.act_backward(np.ones_like(y), y, name).astype(np.float64)
+        h = 1e-5
+        want = (f(pts + h) - f(pts - h)) / (2 * h)
+        assert np.allclose(got, want, rtol=1e-2, atol=3e-3), (name, np.abs(got - want).max())

@@ -57,6 +57,10 @@ def parse():
     p.add_argument("--no-brick-off", action="store_true", help="skip the un-timed leg without the brick image (train-while-render configuration)")
     p.add_argument("--no-brick-table", action="store_true", help="skip the un-timed legs at smaller budgets of the brick image (inference_cache.budget_table)")
     p.add_argument("--no-kernel-events", action="store_true", help="diagnostics: no HIP events around the evaluation kernel (roofline.achieved reads 0)")
+    p.add_argument("--c5", action="store_true",
+                   help="extra un-timed leg: BASELINE C5's training step from an out-of-core file (2 GiB uint8 written to --c5-dir, 16 384 resident "
+                        "slabs, 1 024 replaced per refresh), synchronous and asynchronous refresh -> the `c5` object of the line")
+    p.add_argument("--c5-dir", default="/tmp")
     p.add_argument("--mode", type=int, default=5, choices=(5, 6, 8, 9, 11, 12, 14, 15),
                    help="rendering mode: 5 = sample streaming (BASELINE metric, default), 8 = the same with gradient shading (4 evaluations per sample)")
     return p.parse_args()
@@ -134,6 +138,65 @@ def untimed_frames(ren, n, warm=3):
         samples += s["n_samples"]; ms += s["infer_kernel_ms"]; launches += s["infer_kernel_launches"]; union += s["infer_union_ms"]
     check(lib().vnrAmdSynchronize())
     return n / (time.perf_counter() - t), samples, ms, launches, union
+
+
+def c5_leg(a, ctx):
+    """BASELINE C5 in the form one box can hold: a 2 GiB uint8 file (1024 x 1024 x 2048, written here once), the C4-shaped model trained
+    from it with 16 384 resident slabs (1.6 GiB of HBM) of which 1 024 are replaced per refresh (neural_sampler.cpp:1043-1127), every rank
+    with its own slab set and the gradients exchanged every step.  Two legs: the default (synchronous: each step waits for its refresh, the
+    reference's semantics) and asynchronous refresh (a step never waits for the storage).  -> dict for the bench line"""
+    import ctypes as C
+    L = lib()
+    nx, ny, nz = 1024, 1024, 2048
+    path = os.path.join(a.c5_dir, f"vnr_c5_{nx}x{ny}x{nz}.raw")
+    t0 = time.perf_counter()
+    if ctx.rank == 0 and (not os.path.exists(path) or os.path.getsize(path) != nx * ny * nz):
+        x = np.linspace(0, 1, nx, dtype=np.float32)[None, None, :]
+        y = np.linspace(0, 1, ny, dtype=np.float32)[None, :, None]
+        with open(path + ".tmp", "wb") as f:
+            for z0 in range(0, nz, 16):
+                z = (np.arange(z0, min(z0 + 16, nz), dtype=np.float32) / nz)[:, None, None]
+                v = 0.5 + 0.5 * np.sin(40 * x + 9 * z) * np.cos(31 * y) * np.sin(23 * z + 5 * x * y)
+                f.write((v * 255.0 + 0.5).astype(np.uint8).tobytes())
+        os.replace(path + ".tmp", path)
+    write_s = time.perf_counter() - t0
+    dist.barrier(ctx)
+    sv = api.vnrCreateSimpleVolumeOutOfCore(path, (nx, ny, nz), np.uint8, (0.0, 255.0), n_concurrent_blocks=1024, n_blocks=16384)
+    info = api.out_of_core_info(sv)
+    pls = float(np.exp(np.log(max(nx, ny, nz) / 16.0) / 15))
+    cfg = syn.model_config(n_levels=16, n_features=2, log2_hashmap_size=22, base_resolution=16, n_hidden_layers=3, per_level_scale=pls)
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=True)
+    dist.train_data_parallel(ctx, nv, 20, fast_mode=False)
+    first = api.vnrNeuralVolumeGetTrainingLoss(nv)
+
+    def leg(steps):
+        dist.barrier(ctx)
+        b0 = api.out_of_core_info(sv)["bytes_read"]
+        r0, y0 = C.c_uint64(), C.c_uint64()
+        check(L.vnrAmdSimpleVolumeOutOfCoreRefreshStats(sv.h, C.byref(r0), C.byref(y0)))
+        t = time.perf_counter()
+        dist.train_data_parallel(ctx, nv, steps, fast_mode=False)
+        dist.barrier(ctx)
+        dt = time.perf_counter() - t
+        if ctx.distributed:
+            dt = dist.all_reduce_host([dt], dist.MAX)[0]
+        r1, y1 = C.c_uint64(), C.c_uint64()
+        check(L.vnrAmdSimpleVolumeOutOfCoreRefreshStats(sv.h, C.byref(r1), C.byref(y1)))
+        return {"ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "msamples_per_s": round(65536 * ctx.world * steps / dt / 1e6, 1),
+                "turnover_gib_per_s_rank0": round((api.out_of_core_info(sv)["bytes_read"] - b0) / dt / 2**30, 2),
+                "refreshes_rank0": int(r1.value - r0.value), "steps_beside_a_refresh_rank0": int(y1.value - y0.value),
+                "loss": round(api.vnrNeuralVolumeGetTrainingLoss(nv), 5)}
+
+    sync = leg(200)
+    check(L.vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh(sv.h, 1))
+    dist.train_data_parallel(ctx, nv, 10, fast_mode=False)
+    asyn = leg(400)
+    return {"workload": f"C5 stand-in: {nx}x{ny}x{nz} uint8 file ({nx * ny * nz / 2**30:.0f} GiB, written in {write_s:.1f} s on rank 0), slab "
+                        f"{tuple(info['block_dims'])} voxels = {info['block_size_aligned']} B, {info['n_blocks']} resident slabs per rank "
+                        f"({info['n_blocks'] * info['block_size_aligned'] / 2**30:.2f} GiB of HBM), {info['n_concurrent_blocks']} replaced per refresh; C4-shaped model, "
+                        f"65 536 samples per rank and step, online macrocell; the 4096^3 / 64 GiB file of BASELINE C5 differs in the file only (same slabs, same step)",
+            "loss_after_20_steps": round(first, 5), "synchronous_refresh (default, the reference's semantics)": sync,
+            "asynchronous_refresh (vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh)": asyn, "n_gpus": ctx.world}
 
 
 def main():
@@ -221,6 +284,22 @@ def main():
     sr = dist.ShardedRenderer(ctx, ren, a.fb, a.fb)
     setup_s = time.perf_counter() - t_setup
 
+    # ---- first contact (N > 1): every collective this run uses, once, on patterned buffers, each with a deadline ---------------
+    # A collective that hangs or returns other values is named on stderr and EVERY rank exits non-zero (the ranks agree over the
+    # control plane, which does not depend on the transport under test); no JSON line is printed.  os._exit: a fresh process exit
+    # that runs no finaliser against a stream that may hold a collective that will never complete (and no re-exec anywhere).
+    self_test = None
+    if ctx.distributed:
+        ok, text = dist.self_test(deadline_s=float(os.environ.get("VNR_BENCH_SELFTEST_DEADLINE", "60")))
+        all_ok = dist.all_reduce_host([1.0 if ok else 0.0], dist.MIN)[0] >= 1.0
+        if not ok:
+            print(f"[bench] rank {ctx.rank}: collective self-test FAILED: {text}", file=sys.stderr, flush=True)
+        if not all_ok:
+            if ok:
+                print(f"[bench] rank {ctx.rank}: another rank's collective self-test failed; exiting", file=sys.stderr, flush=True)
+            os._exit(3)
+        self_test = text
+
     # ---- warm-up + timed region ---------------------------------------------------------------------------------
     for _ in range(a.warmup):
         sr.render()
@@ -267,6 +346,33 @@ def main():
         samples, slots, iters = keep
         api.vnrRendererSetProfiling(ren, False)
         dist.barrier(ctx)
+    # (N > 1, un-timed) where a rank's frame time goes, per rank, so that a bad scaling curve can be read from ONE record: the share alone
+    # (vnrRender completes the rank's share, host-synchronous), then the gather (in-place all-gather + assembly, vnrAmdRendererGatherFrame)
+    per_rank = None
+    if ctx.world > 1:
+        n_pr = max(5, min(a.steps // 2, 20))
+        t_share = t_gather = 0.0
+        for k in range(n_pr + 2):
+            dist.barrier(ctx)
+            t_a = time.perf_counter()
+            api.vnrRender(ren)
+            check(L.vnrAmdSynchronize())
+            t_b = time.perf_counter()
+            L.vnrAmdRendererGatherFrame(ren.h)
+            t_c = time.perf_counter()
+            if k >= 2:
+                t_share += (t_b - t_a) * 1e3 / n_pr
+                t_gather += (t_c - t_b) * 1e3 / n_pr
+        def slot_vec(v):
+            return [v if r == ctx.rank else 0.0 for r in range(ctx.world)]
+        per_rank = {"share_ms": [round(x, 4) for x in dist.all_reduce_host(slot_vec(t_share), dist.SUM)],
+                    "gather_ms": [round(x, 4) for x in dist.all_reduce_host(slot_vec(t_gather), dist.SUM)],
+                    "train_step_ms": [round(x, 4) for x in dist.all_reduce_host(slot_vec(train_ms), dist.SUM)],
+                    "train_exchange_ms": [round(x, 4) for x in dist.all_reduce_host(slot_vec(float(phase_ms[4])), dist.SUM)],
+                    "what": f"per rank, un-timed leg of {n_pr} frames rendered one at a time: share_ms = vnrRender of the rank's share until its "
+                            "kernels are done (host-synchronous), gather_ms = in-place all-gather + assembly behind it (vnrAmdRendererGatherFrame); "
+                            "train_step_ms = wall per data-parallel step, train_exchange_ms = its last phase (the rank's 1/N optimizer slice + "
+                            "waiting for reduce-scatter / all-gather of the gradient ranges)"}
     brick_state = api.neural_brick_image(nv)
 
     # ---- un-timed: the neural frame against the frame of the ground-truth volume (same camera / TFN / mode / macrocell) --------
@@ -335,6 +441,8 @@ def main():
                                  "fps": round(fps_b, 2), "samples": s_b, "union_ms": u_b})
         api.neural_set_brick_budget(nv, 0)
         check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
+
+    c5 = c5_leg(a, ctx) if a.c5 else None
 
     if ctx.distributed:
         elapsed = dist.all_reduce_host([elapsed], dist.MAX)[0]          # MAX over ranks of the timed region
@@ -503,6 +611,11 @@ def main():
         "roofline": roofline,
         "train_roofline": train_roofline,
     }
+    if c5 is not None:
+        out["c5"] = c5
+    if per_rank is not None:
+        out["per_rank"] = per_rank
+        out["collective_self_test"] = self_test
     if ctx.world == 1 and not a.no_cpu_baseline:
         mc = api.volume_macrocell(nv)
         out["cpu_baseline"] = cpu_baseline(sv, nv, info, dims, (colors, alphas), cam, a.fb, mc, pls, a.hidden_layers, a.log2_hashmap_size)

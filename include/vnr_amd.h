@@ -335,6 +335,12 @@ int  vnrAmdDistAllReduce(void* buf, size_t count, int dtype, int op);
 int  vnrAmdDistAllGather(const void* send, void* recv, size_t bytes_per_rank);
 int  vnrAmdDistReduceScatter(void* buf, size_t count_per_rank, int dtype);
 int  vnrAmdDistBroadcast(void* buf, size_t bytes, int root);
+/* First-contact self-test: every collective the sharded paths use (in-place all-gather of a frame share, reduce-scatter(Avg) fp16 on a
+ * slice length that divides nothing + all-gather of the slices, broadcast, all-reduce(Sum) fp16) once on patterned buffers whose
+ * result each rank computes by itself.  A collective that does not complete within deadline_s (the stream is polled from the host) or
+ * returns other values fails with its name in vnrAmdGetLastError; the process should then EXIT (a hung collective cannot be
+ * cancelled).  report (optional): a one-line summary. */
+int  vnrAmdDistSelfTest(double deadline_s, char* report, size_t report_size);
 /* Image tiles: the rank renders the 8-scanline tile rows r with r % world == rank into its slot of a [world][share] buffer;
  * vnrAmdRendererMapFrame (= vnrAmdRendererGatherFrame) all-gathers in place, de-interleaves and returns the WHOLE frame on
  * every rank, bit-identical to the unsharded frame rendered with the same batch size (VNR_RM_N_ITERS): a share of at most 196 608

@@ -193,6 +193,7 @@ def lib():
     sig("vnrAmdDistAllGather", I, P, P, SZ)
     sig("vnrAmdDistReduceScatter", I, P, SZ, I)
     sig("vnrAmdDistBroadcast", I, P, SZ, I)
+    sig("vnrAmdDistSelfTest", I, C.c_double, C.c_char_p, SZ)
     sig("vnrAmdRendererSetDistributed", I, P, I)
     sig("vnrAmdRendererGatherFrame", P, P)
     sig("vnrAmdRendererRenderPipelined", I, P, C.POINTER(P))

@@ -868,6 +868,13 @@ int vnrAmdDistBroadcast(void* buf, size_t bytes, int root)
 {
   return guarded([&]() { Dist::get().transport().broadcast(buf, bytes, root, dist_call_stream()); dist_call_done(); });
 }
+int vnrAmdDistSelfTest(double deadline_s, char* report, size_t report_size)
+{
+  return guarded([&]() {
+    const std::string r = Dist::get().self_test(deadline_s > 0.0 ? deadline_s : 30.0);
+    if (report && report_size) { std::strncpy(report, r.c_str(), report_size - 1); report[report_size - 1] = 0; }
+  });
+}
 int vnrAmdRendererSetDistributed(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_distributed(e != 0); }); }
 const float* vnrAmdRendererGatherFrame(vnrAmdRenderer r)
 {

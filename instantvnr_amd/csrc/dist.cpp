@@ -56,10 +56,14 @@ void set_socket_timeouts(int fd, int seconds)
   (void)setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
 }
 
+// after the rendezvous a wait on the control plane is as long as the slowest rank's work.  A rank that hangs without closing its socket
+// (GPU hang, deadlocked collective) must not stall the others for ever: 30 minutes by default;
+// VNR_AMD_DIST_STEADY_TIMEOUT=<seconds>, 0 = wait without bound
 int dist_steady_timeout_s()
 {
   const char* e = std::getenv("VNR_AMD_DIST_STEADY_TIMEOUT");
-  const int v = e ? std::atoi(e) : 0;
+  if (!e || !*e) return 1800;
+  const int v = std::atoi(e);
   return v > 0 ? v : 0;
 }
 
@@ -689,6 +693,118 @@ void Dist::all_gather_host(const void* mine, void* all_out, size_t bytes)
   if (!ctl_ || world_ <= 1) { if (bytes) std::memcpy(all_out, mine, bytes); return; }
   const size_t total = bytes * (size_t)world_;
   ctl_->exchange(mine, bytes, all_out, total, [&](const char* all, char* out) { std::memcpy(out, all, total); });
+}
+
+// ---- first-contact self-test (bench.py --gpus N runs it before its timed region) --------------------------------------------------
+// Every collective the sharded paths use, once, on patterned buffers whose result every rank can compute by itself: the in-place
+// all-gather of a frame share (renderer), reduce-scatter(Avg) of fp16 on a slice length that divides nothing + the all-gather of the
+// slices (sharded optimizer), broadcast (replica synchronisation), all-reduce(Sum) of fp16 (the unsharded exchange).  A collective
+// that does not complete within `deadline_s` (hipStreamQuery polled from the host) or returns other values throws with its name; the
+// caller then exits the process (a hung collective cannot be cancelled).
+static uint16_t self_test_f16(uint32_t small_int)   // integers < 2048 are exact in fp16
+{
+  return f32_to_f16((float)small_int);
+}
+
+std::string Dist::self_test(double deadline_s)
+{
+  if (!active()) return "no process group";
+  Transport& tr = transport();
+  hipStream_t s = comm_stream();
+  const int W = world_, R = rank_;
+  std::string report;
+  auto finish = [&](const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) throw std::runtime_error(std::string("[vnr dist] self-test: ") + what + " failed: " + hipGetErrorString(e));
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (dt > deadline_s)
+        throw std::runtime_error(std::string("[vnr dist] self-test: ") + what + " did not complete within " + std::to_string(deadline_s) + " s on rank " +
+                                 std::to_string(R) + " of " + std::to_string(W) + " (transport " + tr.name() + ")");
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    report += std::string(what) + " ok (" + std::to_string(ms).substr(0, 6) + " ms to complete); ";
+  };
+  auto mismatch = [&](const char* what, size_t i, double got, double want) {
+    throw std::runtime_error(std::string("[vnr dist] self-test: ") + what + " returned wrong data on rank " + std::to_string(R) + " of " + std::to_string(W) +
+                             " (transport " + tr.name() + "): element " + std::to_string(i) + " is " + std::to_string(got) + ", expected " + std::to_string(want));
+  };
+  // 1. in-place all-gather of a share: 131 072 pixels x 16 B (a 1/8 share of the 1024 x 1024 frame), slot r = pattern(r, i)
+  {
+    const size_t n = 131072 * 4;   // floats per rank
+    DeviceBuffer<float> buf;
+    buf.resize(n * (size_t)W);
+    std::vector<float> host(n * (size_t)W, -1.0f);
+    for (size_t i = 0; i < n; ++i) host[(size_t)R * n + i] = (float)((i * 31u + (size_t)R * 7u) % 65521u);
+    VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    tr.all_gather(buf.ptr + (size_t)R * n, buf.ptr, n * sizeof(float), s);
+    finish("all-gather (in place, 2 MiB share)");
+    VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int q = 0; q < W; ++q)
+      for (size_t i = 0; i < n; ++i) {
+        const float want = (float)((i * 31u + (size_t)q * 7u) % 65521u);
+        if (host[(size_t)q * n + i] != want) mismatch("all-gather", (size_t)q * n + i, host[(size_t)q * n + i], want);
+      }
+  }
+  // 2. reduce-scatter(Avg) of fp16, slice length 100 003 (odd: divides nothing), then the all-gather of the slices.  Values are small
+  //    integers, so every partial sum is exact in fp16 whatever the order; the mean is exact when the world is a power of two
+  {
+    const size_t c = 100003;
+    DeviceBuffer<uint16_t> buf;
+    buf.resize(c * (size_t)W);
+    std::vector<uint16_t> host(c * (size_t)W);
+    auto val = [](int q, size_t i) { return (uint32_t)((i * 5u + (size_t)q * 11u) % 32u); };
+    for (size_t i = 0; i < host.size(); ++i) host[i] = self_test_f16(val(R, i));
+    VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    tr.reduce_scatter(buf.ptr, c, DistDType::F16, DistOp::Avg, s);
+    finish("reduce-scatter (Avg, fp16, 100 003 elements per rank)");
+    tr.all_gather(buf.ptr + (size_t)R * c, buf.ptr, c * 2, s);
+    finish("all-gather of the reduced slices");
+    VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, host.size() * 2, hipMemcpyDeviceToHost));
+    const bool pow2 = (W & (W - 1)) == 0;
+    for (size_t i = 0; i < host.size(); ++i) {
+      uint32_t sum = 0;
+      for (int q = 0; q < W; ++q) sum += val(q, i);
+      const double want = (double)sum / W, got = (double)f16_to_f32(host[i]);
+      if (pow2 ? got != want : std::fabs(got - want) > 0.02 * std::max(1.0, want)) mismatch("reduce-scatter(Avg) + all-gather", i, got, want);
+    }
+  }
+  // 3. broadcast from rank 0 (a length that is not a multiple of 4)
+  {
+    const size_t n = (1u << 20) + 3;
+    DeviceBuffer<uint8_t> buf;
+    buf.resize(n);
+    std::vector<uint8_t> host(n);
+    for (size_t i = 0; i < n; ++i) host[i] = (uint8_t)(R == 0 ? (i * 13u + 5u) : 0xEE);
+    VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), n, hipMemcpyHostToDevice));
+    tr.broadcast(buf.ptr, n, 0, s);
+    finish("broadcast (1 MiB + 3 bytes)");
+    VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i)
+      if (host[i] != (uint8_t)(i * 13u + 5u)) mismatch("broadcast", i, host[i], (uint8_t)(i * 13u + 5u));
+  }
+  // 4. all-reduce(Sum) of fp16
+  {
+    const size_t n = 250001;
+    DeviceBuffer<uint16_t> buf;
+    buf.resize(n);
+    std::vector<uint16_t> host(n);
+    auto val = [](int q, size_t i) { return (uint32_t)((i * 3u + (size_t)q * 5u) % 16u); };
+    for (size_t i = 0; i < n; ++i) host[i] = self_test_f16(val(R, i));
+    VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), n * 2, hipMemcpyHostToDevice));
+    tr.all_reduce(buf.ptr, n, DistDType::F16, DistOp::Sum, s);
+    finish("all-reduce (Sum, fp16)");
+    VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, n * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+      uint32_t sum = 0;
+      for (int q = 0; q < W; ++q) sum += val(q, i);
+      if ((double)f16_to_f32(host[i]) != (double)sum) mismatch("all-reduce(Sum)", i, f16_to_f32(host[i]), sum);
+    }
+  }
+  return report;
 }
 
 hipStream_t Dist::comm_stream()

@@ -70,6 +70,9 @@ public:
   void all_gather_host(const void* mine, void* all, size_t bytes);
 
   hipStream_t comm_stream();   // a second stream of this process for collectives that overlap compute
+  // every collective of the sharded paths once, on patterned buffers, with a deadline per collective (dist.cpp): throws with the
+  // collective's name on a mismatch or a timeout; returns a one-line report
+  std::string self_test(double deadline_s);
 
 private:
   int rank_ = 0, world_ = 1, local_rank_ = 0;

@@ -686,7 +686,9 @@ struct NeuralVolume::DpState : GradExchange {
   static size_t emulated_world()
   {
     static const int e = [] { const char* v = std::getenv("VNR_AMD_DP_EMULATE_WORLD"); return v ? std::atoi(v) : 0; }();
-    return e > 1 ? (size_t)e : (size_t)Dist::get().world();
+    // only where there is nobody to disagree with (a one-rank group): with a real group of another size the slices would be cut for the wrong
+    // world and the other slices' parameters would go stale
+    return e > 1 && Dist::get().world() == 1 ? (size_t)e : (size_t)Dist::get().world();
   }
   void range_ready(size_t lo, size_t hi, hipStream_t s) override
   {
@@ -863,6 +865,15 @@ void NeuralVolume::train_end_data_parallel(bool fast_mode, int sharded)
 {
   Dist& d = Dist::get();
   if (!d.active()) { train_end(1.0f, fast_mode); return; }
+  // a rank-local decision in front of collectives is a hang: the ranks agree over the control plane on whether a step is pending
+  // (ADVICE r03); a mismatch is an error on every rank
+  if (d.world() > 1) {
+    double v[2] = {pending_step_ ? 1.0 : 0.0, pending_step_ ? 0.0 : 1.0};
+    d.all_reduce_host(v, 2, DistOp::Sum);
+    if (v[0] > 0.0 && v[1] > 0.0)
+      throw std::runtime_error("vnrAmdNeuralVolumeTrainEndDataParallel: " + std::to_string((int)v[0]) + " rank(s) hold a pending step (TrainBegin) and " +
+                               std::to_string((int)v[1]) + " do not; every rank must call TrainBegin before TrainEndDataParallel");
+  }
   if (!pending_step_) return;
   DpState& dp = dp_state();
   const bool was = dp.sharded;

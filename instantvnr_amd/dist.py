@@ -96,6 +96,15 @@ def barrier(ctx=None):
         check(L.vnrAmdSynchronize())
 
 
+def self_test(deadline_s=30.0):
+    """every collective of the sharded paths once on patterned buffers (vnrAmdDistSelfTest) -> (ok, report or error text)"""
+    buf = C.create_string_buffer(2048)
+    rc = lib().vnrAmdDistSelfTest(float(deadline_s), buf, len(buf))
+    if rc != 0:
+        return False, lib().vnrAmdGetLastError().decode(errors="replace")
+    return True, buf.value.decode(errors="replace")
+
+
 def all_reduce_host(values, op=SUM):
     """a few doubles over the control plane (the bench's MAX / SUM over ranks)"""
     a = (C.c_double * len(values))(*[float(v) for v in values])

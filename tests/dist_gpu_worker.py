@@ -311,16 +311,36 @@ def scenario_macrocell(ctx, out):
     out["max_opacity"] = mc["max_opacity"]
 
 
+def scenario_selftest(ctx, out):
+    """vnrAmdDistSelfTest (what bench.py --gpus N runs before its timed region): every collective of the sharded paths on patterned buffers"""
+    ok, text = vdist.self_test(deadline_s=60.0)
+    out["ok"] = ok
+    out["report"] = text
+    out["transport"] = ctx.transport
+
+
 def scenario_ooc(ctx, out):
-    """BASELINE C5 in small: out-of-core volume, every rank its own slab set, gradients exchanged every step"""
-    path, n = os.environ["TEST_OOC_FILE"], int(os.environ["TEST_OOC_SIZE"])
+    """BASELINE C5 in small (and, with TEST_OOC_DIMS / TEST_OOC_MODEL=c4, at 2 GiB): out-of-core volume, every rank its own slab set,
+    gradients exchanged every step"""
+    path = os.environ["TEST_OOC_FILE"]
+    if "TEST_OOC_DIMS" in os.environ:
+        dims = tuple(int(v) for v in os.environ["TEST_OOC_DIMS"].split(","))
+    else:
+        dims = (int(os.environ["TEST_OOC_SIZE"]),) * 3
+    ncb, nb = (int(v) for v in os.environ.get("TEST_OOC_BLOCKS", "8,64").split(","))
     os.environ["VNR_AMD_INIT_SEED"] = "11"
-    sv = api.vnrCreateSimpleVolumeOutOfCore(path, (n, n, n), "uint8", (0.0, 255.0), n_concurrent_blocks=8, n_blocks=64)
+    sv = api.vnrCreateSimpleVolumeOutOfCore(path, dims, "uint8", (0.0, 255.0), n_concurrent_blocks=ncb, n_blocks=nb)
     out["slabs"] = np.asarray(api.out_of_core_blocks(sv))
-    nv = api.vnrCreateNeuralVolume(syn.model_config(**SMALL_MODEL), sv, online_macrocell_construction=True)
-    vdist.train_data_parallel(ctx, nv, int(os.environ.get("TEST_STEPS", "300")))
+    if os.environ.get("TEST_OOC_MODEL") == "c4":
+        model = syn.model_config(n_levels=16, n_features=2, log2_hashmap_size=22, n_hidden_layers=3, per_level_scale=float(np.exp(np.log(max(dims) / 16.0) / 15)))
+    else:
+        model = syn.model_config(**SMALL_MODEL)
+    nv = api.vnrCreateNeuralVolume(model, sv, online_macrocell_construction=True)
+    vdist.train_data_parallel(ctx, nv, 5)
+    out["loss_first"] = api.vnrNeuralVolumeGetTrainingLoss(nv)
+    vdist.train_data_parallel(ctx, nv, int(os.environ.get("TEST_STEPS", "300")) - 5)
     out["checksum"] = vdist.params_checksum(nv)
-    out["psnr"] = api.vnrNeuralVolumeGetPSNR(nv)
+    out["psnr"] = -1.0 if os.environ.get("TEST_OOC_NO_PSNR") else api.vnrNeuralVolumeGetPSNR(nv)
     out["loss"] = api.vnrNeuralVolumeGetTrainingLoss(nv)
     out["value_range"] = api.volume_macrocell(nv)["value_range"]
 
@@ -331,7 +351,7 @@ def main():
     out = {"rank": ctx.rank, "world": ctx.world, "transport": ctx.transport or "none"}
     {"frames": scenario_frames, "frames_c4": scenario_frames_c4, "frames_unpinned": scenario_frames_unpinned, "train": scenario_train,
      "train_c4": scenario_train_c4, "sharded_optimizer": scenario_sharded_optimizer, "resync": scenario_resync, "macrocell": scenario_macrocell,
-     "ooc": scenario_ooc}[scenario](ctx, out)
+     "ooc": scenario_ooc, "selftest": scenario_selftest}[scenario](ctx, out)
     vdist.barrier()
     np.savez(out_path, **out)
     vdist.finalize()

@@ -1,6 +1,14 @@
 #define VNR_SHIM_OWN_MATH
+// Two builds (tests/test_cabi.py): with the image's nlohmann 3.1.1 (no BSON: documents cross as JSON text), and - VNR_SHIM_SMOKE_BSON -
+// the shim's PRODUCTION branch (json::to_bson / from_bson, api.cpp:23-47) against tests/compat/json/json.hpp, a test-only stand-in
+// for the nlohmann >= 3.8 a reference application builds with.
+#ifndef VNR_SHIM_SMOKE_BSON
 #define VNR_SHIM_JSON_TEXT_TRANSPORT
+#endif
 #include "vnr_api_shim.hpp"
+#include <cstdlib>
+#include <cstring>
+#include <iterator>
 // Exit codes: 0 = everything ran (GPU present); 42 = all host-only checks passed and the first call that needs a GPU threw
 // std::runtime_error (expected on a box without one); 11..17 = a host-only check failed.
 int main() {
@@ -44,6 +52,37 @@ int main() {
     vnrJson bad = scene; bad["version"] = "SOMETHING";
     try { (void)vnrCreateCamera(bad); return 17; } catch (const std::runtime_error&) {}   // unknown JSON configuration format
   }
+#ifdef VNR_SHIM_SMOKE_BSON
+  {  // the BSON branch, host only: a params.json-like document (binary members, nested objects, int32 / int64 / double / bool / null) keeps its
+     // bytes through from_bson -> to_bson, through vnrSaveJsonBinary -> vnrLoadJsonBinary, and the library's own codec reads what to_bson wrote
+    const char* fixture = std::getenv("VNR_SHIM_SMOKE_FIXTURE");   // tests/golden/bson_params_like.bson (byte-checked against pymongo elsewhere)
+    if (!fixture) return 20;
+    vnrJson doc;
+    vnrLoadJsonBinary(doc, fixture);
+    if (!doc.is_object() || !doc.count("parameters") || !doc["parameters"].count("params_binary")) return 21;
+    if (doc["parameters"]["params_binary"]["bytes"].size() != 2 * doc["parameters"]["n_params"].get<size_t>()) return 21;
+    std::ifstream f(fixture, std::ios::binary);
+    const std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const std::vector<std::uint8_t> again = vnrJson::to_bson(doc);
+    if (again.size() != raw.size() || std::memcmp(again.data(), raw.data(), raw.size()) != 0) return 22;
+    const std::string tmp = std::string(fixture) + ".shim_roundtrip";
+    vnrSaveJsonBinary(doc, tmp);
+    vnrJson back;
+    vnrLoadJsonBinary(back, tmp);
+    std::remove(tmp.c_str());
+    if (back != doc) return 23;
+    // what the shim hands the C-ABI for a json argument (JsonArg): BSON bytes the library's codec accepts and re-encodes identically
+    const vnr::shim::JsonArg arg(doc, true);
+    if (arg.format != VNR_AMD_JSON_BSON || arg.size() != raw.size()) return 24;
+    void* out = nullptr; size_t out_n = 0;
+    vnr::shim::check(vnrAmdJsonConvert(arg.data(), arg.size(), arg.format, VNR_AMD_JSON_BSON, &out, &out_n));
+    const bool same = out_n == raw.size() && std::memcmp(out, raw.data(), out_n) == 0;
+    vnrAmdFreeHost(out);
+    if (!same) return 24;
+    vnrJson text = vnrJson::parse(std::string("{ // a comment, api.cpp:20\n \"a\": 1 /* and another */ }"), nullptr, true, true);
+    if (text["a"].get<int>() != 1) return 25;
+  }
+#endif
   vnrRelease(nullptr);                   // declared in api.h:185, never defined there: a no-op here
   vnrMemoryQueryPrint("shim_smoke");     // api.cpp:538-552
   // part that needs a GPU ---------------------------------------------------------------------------------------------
@@ -68,6 +107,18 @@ int main() {
       if (n_tri != 0) return 19;
       delete[] tri;
     }
+#ifdef VNR_SHIM_SMOKE_BSON
+    {  // api.h:143-144 + api.cpp:206-220 through BSON: serialize the volume's params into a json, create a second volume from that json
+      vnrJson params;
+      vnrNeuralVolumeSerializeParams(v, params);
+      if (!params.count("parameters") || !params.count("model") || params["volume"]["dims"]["x"].get<int>() != 8) return 26;
+      auto v2 = vnrCreateNeuralVolume(params);
+      if (vnrNeuralVolumeGetNumberOfBlobs(v2) != vnrNeuralVolumeGetNumberOfBlobs(v)) return 26;
+      vnrJson params2;
+      vnrNeuralVolumeSerializeParams(v2, params2);
+      if (params2["parameters"] != params["parameters"]) return 27;      // the same weights, bit for bit
+    }
+#endif
     // api.h:34 vnrType = vnr::ValueType, the voxel type of a volume made from memory (device/device_impl.cpp:175-184)
     const vnrType ty = vnr::VALUE_TYPE_UINT16;
     if (vnr::value_type_size(ty) != 2 || (int)vnr::VALUE_TYPE_FLOAT != 8 || (int)vnr::VALUE_TYPE_DOUBLE != 12) return 18;

@@ -188,19 +188,24 @@ def test_bench_and_smoke_fail_loudly_without_a_device(L):
     assert out.returncode != 0 and "smoke ok" not in out.stdout
 
 
-def _build_and_run_shim_smoke(tmp_path):
+def _build_and_run_shim_smoke(tmp_path, bson=False):
+    """bson: the shim's production branch (json::to_bson / from_bson) against tests/compat/json/json.hpp, a test-only stand-in for the
+    nlohmann >= 3.8 of a reference application (the image has 3.1.1, which has no BSON)"""
     import shutil
     import subprocess
     inc = "/opt/conda/include"
     if not os.path.exists(os.path.join(inc, "json.hpp")) or not shutil.which("g++"):
         pytest.skip("no nlohmann::json / g++ in this image")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "shim_smoke")
-    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include"), "-I", inc,
+    exe = str(tmp_path / ("shim_smoke_bson" if bson else "shim_smoke"))
+    extra = ["-DVNR_SHIM_SMOKE_BSON", "-I", os.path.join(root, "tests", "compat")] if bson else []
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include")] + extra + ["-I", inc,
                            os.path.join(root, "tests", "shim_smoke.cpp"), "-o", exe,
                            "-L", os.path.join(root, "instantvnr_amd"), "-lvnr_amd",
                            "-Wl,-rpath," + os.path.join(root, "instantvnr_amd")])
-    return subprocess.call([exe])
+    fixture = str(tmp_path / "bson_params_like.bson")
+    shutil.copy(os.path.join(root, "tests", "golden", "bson_params_like.bson"), fixture)
+    return subprocess.call([exe], env=dict(os.environ, VNR_SHIM_SMOKE_FIXTURE=fixture))
 
 
 def test_cpp_api_shim_compiles_and_throws_like_the_reference(L, tmp_path):
@@ -210,11 +215,21 @@ def test_cpp_api_shim_compiles_and_throws_like_the_reference(L, tmp_path):
     assert rc == (0 if L.vnrAmdHasDevice() else 42)   # 42 = std::runtime_error ("no HIP capable devices")
 
 
+def test_cpp_api_shim_production_bson_branch_compiles_and_round_trips(L, tmp_path):
+    """the branch a reference application takes (no VNR_SHIM_JSON_TEXT_TRANSPORT: json::to_bson / from_bson, api.cpp:23-47)
+    type-checks and runs: the params-like fixture keeps its bytes through from_bson -> to_bson and through vnrSave/LoadJsonBinary, and the
+    library's BSON codec reads what the shim hands it"""
+    rc = _build_and_run_shim_smoke(tmp_path, bson=True)
+    assert rc == (0 if L.vnrAmdHasDevice() else 42)
+
+
 @pytest.mark.gpu
-def test_cpp_api_shim_runs_its_gpu_half(tmp_path):
+@pytest.mark.parametrize("bson", [False, True])
+def test_cpp_api_shim_runs_its_gpu_half(tmp_path, bson):
     """the same program where a GPU exists (the driver's `-m gpu` run): a C++ application written against api.h creates a neural volume
-    and a volume from memory (vnrType), renders, decodes and renders the decoded volume through the shim; exit code 0"""
-    assert _build_and_run_shim_smoke(tmp_path) == 0
+    and a volume from memory (vnrType), renders, decodes and renders the decoded volume through the shim; exit code 0.  bson: the production
+    branch, which also serialises the volume's params into a json and creates a second volume from that json (api.cpp:206-220)"""
+    assert _build_and_run_shim_smoke(tmp_path, bson=bson) == 0
 
 
 @pytest.mark.parametrize("order,ok", [("lib-first", False), ("torch-first", True)])

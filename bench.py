@@ -509,7 +509,7 @@ def main():
     # the same stream configuration it was measured with.
     default_workload = (a.size, a.fb, a.levels, a.features, a.log2_hashmap_size, a.hidden_layers, a.per_level_scale,
                         a.train_steps, a.opacity_scale, a.camera_distance, a.mode, kind) == (1024, 1024, 16, 2, 22, 3, 0.0, 1500, 0.06, 1.1, 5, "perlin")
-    pmc_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_l_pmc_traffic.json")) if os.path.exists(p)), None)
+    pmc_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_l_pmc_traffic.json")) if os.path.exists(p)), None)
     if default_workload and ctx.world == 1 and brick_state["in_use"] and pmc_path:
         pmc = json.load(open(pmc_path))
         leg = pmc["one_stream" if halves == 1 else "two_streams"]
@@ -524,7 +524,7 @@ def main():
                                                 "is no longer bound by bytes (L1 / texture-addresser latency, DESIGN 4.1); the algorithmic fraction flatters it",
                                         "achieved": round(t_gbs, 1), "frac": round(t_gbs / HBM_PEAK_GBS, 4), "bytes_per_sample": round(per_sample, 1)}
         roofline["traffic_note"] = (f"bytes per sample measured in separate rocprofv3 --pmc passes of the same frame, not in this run: {os.path.relpath(pmc_path, ROOT)} "
-                                    "(traffic / algorithmic = %.2f; on the hashed blob 0.90 with two streams, 1.01 with one: profiles/r03_pmc_traffic_brick_off.json)" % (per_sample / bytes_per_sample))
+                                    "(traffic / algorithmic = %.2f; on the hashed blob 0.90 with two streams, 1.01 with one: profiles/r04_pmc_traffic_brick_off.json)" % (per_sample / bytes_per_sample))
         if "alone" in roofline:
             one = pmc["one_stream"]
             ps1 = one.get("bytes_per_sample") or one["traffic_over_algorithmic"] * bytes_per_sample
@@ -543,11 +543,11 @@ def main():
             ev1 = brick_off["alone_samples"] * evals_per_sample
             leg["kernel_alone_frac"] = round(ev1 * bytes_per_sample / (brick_off["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             leg["kernel_alone_msamples_per_s"] = round(ev1 / (brick_off["alone_ms"] * 1e-3) / 1e6, 1)
-        off_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_brick_off.json")
+        off_path = os.path.join(ROOT, "profiles", "r04_pmc_traffic_brick_off.json")
         if default_workload and os.path.exists(off_path):
             off = json.load(open(off_path))
             leg["traffic_bytes_per_sample"] = {"two_streams": round(off["two_streams"]["bytes_per_sample"], 1), "one_stream": round(off["one_stream"]["bytes_per_sample"], 1),
-                                               "note": "separate rocprofv3 --pmc passes of this frame with VNR_AMD_BRICK=0 (profiles/r03_pmc_traffic_brick_off.json), not this run"}
+                                               "note": "separate rocprofv3 --pmc passes of this frame with VNR_AMD_BRICK=0 (profiles/r04_pmc_traffic_brick_off.json), not this run"}
         roofline["brick_off"] = leg
 
     # ---- training step: algorithmic bytes per SURVEY 8(d) and the live per-kernel split -------------------------------------------

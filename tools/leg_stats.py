@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 path, prefix = sys.argv[1], sys.argv[2]
-needle = sys.argv[3] if len(sys.argv) > 3 else "fused_infer_kernel<2, 32, 64, 0"
+needle = sys.argv[3] if len(sys.argv) > 3 else "fused_infer_kernel<2, 32, 64, 0, false>"
 rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))

@@ -4,14 +4,14 @@
   pmc_traffic.py <dir with pmc_bench_{FETCH,WRITE}_SIZE[_h1]/bench_counter_collection.csv> <bench.json of the same box> > profiles/r02_pmc_traffic.json
 
 A pass renders `warmup + steps` frames; the first frames run before the brick image exists (the network builds it behind the second
-frame's launches), so only the LAST `frames` frames are used: the dispatches of fused_infer_kernel<2,32,0>
+frame's launches), so only the LAST `frames` frames are used: the dispatches of fused_infer_kernel<2,32,64,0,false>
 split evenly over the frames of the pass (argument 4, default 4 = --warmup 1 --steps 3)."""
 import csv
 import json
 import os
 import sys
 
-KERNEL = "fused_infer_kernel<2, 32, 0>"
+KERNEL = "fused_infer_kernel<2, 32, 64, 0, false>"
 
 
 def frames_of(path, n_frames):
@@ -48,7 +48,7 @@ def main():
     n_last = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     n_frames = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     spf = bench["samples_per_frame"]
-    doc = {"what": "fabric (L2-miss) traffic of fused_infer_kernel<2,32,0> on the default bench frame, measured on bench.py itself",
+    doc = {"what": "fabric (L2-miss) traffic of fused_infer_kernel<2,32,64,0,false> on the default bench frame, measured on bench.py itself",
            "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-psnr "
                       "--no-alone --no-brick-off --train-steps 300   (tools/r02_profiles.sh; one counter per pass, program directly after --; "
                       "VNR_AMD_BRICK=1 so that the brick image exists from the first launch; VNR_AMD_RENDER_HALVES=1 for the one-stream leg)",

@@ -9,7 +9,7 @@ relative to the kernel's first dispatch, with the queue id) go to out_intervals.
 import csv
 import sys
 path = sys.argv[1]
-needle = sys.argv[2] if len(sys.argv) > 2 else "fused_infer_kernel<2, 32, 0>"
+needle = sys.argv[2] if len(sys.argv) > 2 else "fused_infer_kernel<2, 32, 64, 0, false>"
 out = sys.argv[3] if len(sys.argv) > 3 else None
 iv = []
 for r in csv.DictReader(open(path)):

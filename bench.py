@@ -277,7 +277,7 @@ def main():
         return rr
 
     # HIP events around every launch of the evaluation kernel, on the stream it is launched on.  With more than one rank they stay
-    # out of the timed region (two timed events per launch are 6 % of the frame time of a 1/8 share, tools/r02_share_prof.sh) and an
+    # out of the timed region (two timed events per launch are 6 % of the frame time of a 1/8 share, tools/scratch/r02_share_prof.sh) and an
     # un-timed leg behind it measures the launches instead.
     events_in_timed_region = not a.no_kernel_events and ctx.world == 1
     ren = make_renderer(nv, device_output=False, profiling=events_in_timed_region)

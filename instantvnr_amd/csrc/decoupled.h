@@ -325,388 +325,8 @@ __global__ void __launch_bounds__(256) compose_kernel(const RenderParams p, cons
   }
 }
 
-// ================================================================================================ eight lanes per ray
-// walk_kernel / compose_kernel give a ray one lane: a batch is then ~50 SEQUENTIAL steps (macrocells and samples) of 40-110
-// instructions each, and on a share of a frame, where there is one wave per SIMD or less, a launch lasts as long as its slowest
-// wave (stamped: 12 us per wave-trip on average, 90 us per launch; profiles/r03_walk_kernel_stamps.txt).  These two kernels do
-// the same arithmetic per ray with EIGHT lanes per ray, eight times the waves, and an eighth of the sequential steps per wave:
-//   walk      in every round the lanes of a ray take the next eight macrocells: lane s advances a copy of the DDA state s times
-//             (cheap, and the same float operations in the same order as a walk that goes cell by cell), then all eight fetch
-//             their cell's opacity bound AT ONCE (one trip to the L2 per round instead of one per cell), count the samples
-//             their cell takes (the reference's running sums, without storing), learn from a scan over the eight where in the batch
-//             their cell's samples go, and write them.  The round's first lane that ends the walk (left the grid, empty
-//             interval, batch full) hands its state to all; cells behind it were looked at for nothing.
-//   compose   the lanes of a ray classify its samples eight at a time into LDS; then ONE wave of the block blends all 64
-//             rays in order, with the reference's early exit.
-// A block is one 64-ray group (an 8x8 pixel tile), 512 threads; sample slots, queue order (depth bins of the group) and ray
-// state are those of walk_kernel / compose_kernel, frames are bit-identical (tests/test_gpu_render.py).  The order of the
-// records INSIDE a depth bin depends on which wave's LDS atomic comes first; the evaluation of a sample does not depend on its
-// neighbours in the queue, and its result goes to the slot its record names.
-__device__ __forceinline__ uint32_t ray_stride(int n_iters)
-{
-  uint32_t st = ((uint32_t)n_iters + 7u) & ~7u;   // [ray][sample] in LDS: rows of a ray's 8 lanes on different banks
-  if ((st & 15u) == 0u) st += 8u;
-  return st;
-}
-
-template <bool FIRST>
-__global__ void __launch_bounds__(512) walk8_kernel(const RenderParams p, const DRays r, const DRing ring, DHost* __restrict__ host, uint32_t it)
-{
-  extern __shared__ float s_t[];  // [64][stride] x {t0, t1}, [64][stride] ranks (u16), histogram[64], per-ray counts[64], misc[8]
-  const uint32_t stride = ray_stride(p.n_iters);
-  float* s_t0 = s_t;
-  float* s_t1 = s_t + 64u * stride;
-  uint32_t* s_hist = (uint32_t*)(s_t + 128u * stride);
-  uint32_t* s_k = s_hist + 64;
-  uint32_t* s_misc = s_k + 64;                    // [0] base of the block's samples, [1] front (float), [2..3] block totals
-  uint16_t* s_rk = (uint16_t*)(s_misc + 8);
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t rl = tid >> 3, s = tid & 7u;     // ray of the group, lane of the ray
-  const uint32_t seg = lane & ~7u;
-  const uint32_t P = p.n_local;
-  const uint32_t n_groups = (P + 63u) >> 6;
-  uint32_t n_walking = 0, n_hit = 0;
-  vec4f* __restrict__ queue = ring.queue;
-  vec2f* __restrict__ vd_out = ring.arena;
-  const int n_iters = p.n_iters;
-
-  for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const uint32_t i = g * 64u + rl;
-    const bool active = i < P;
-    uint32_t pixel = 0;
-    float jitter = 0.0f;
-    DDAState S;
-    S.t_next = {0, 0, 0}; S.cell = {0, 0, 0}; S.next_cell_begin = 0.0f;
-    vec3f org = {0, 0, 0}, dir = {0, 0, 1}, m_dir = {0, 0, 1};
-    float tmin = 0.0f, tmax = VNR_FLOAT_LARGE;
-    bool walk = false;
-    if (active) {
-      if (FIRST) {  // iterative_raygen_kernel_camera (method_raymarching.cu:840-875); the ray's eight lanes all compute it
-        if (map_pixel(p, i, pixel)) {
-          jitter = tea_lcg_first((uint32_t)p.frame_index, pixel);
-          compute_ray(p, pixel, org, dir);
-          m_dir = dir * p.mc_rcp;
-          walk = intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
-          if (walk) {
-            dda_init(S, org * p.mc_rcp, m_dir, tmin, p.mc_dims);
-            if (s == 0) {
-              r.pixel[i] = pixel; r.jitter[i] = jitter;
-              r.alpha[i] = 0.0f; r.color[i] = {0, 0, 0}; r.done[i] = 0u;
-              ++n_hit;
-            }
-          } else if (s == 0) {
-            write_pixel(p, {0, 0, 0, 0}, pixel);
-          }
-        }
-      } else if (r.walking[i]) {
-        if (r.done[i]) {
-          if (s == 0) r.walking[i] = 0u;
-        } else {
-          pixel = r.pixel[i];
-          jitter = r.jitter[i];
-          S.cell = r.cell[i];
-          S.t_next = r.t_next[i];
-          S.next_cell_begin = r.ncb[i];
-          compute_ray(p, pixel, org, dir);
-          m_dir = dir * p.mc_rcp;
-          intersect_box(tmin, tmax, org, dir, p.bbox_lo, p.bbox_hi);
-          walk = true;
-        }
-      }
-    }
-    // (the eight lanes of a ray are lanes of one wave: they have all read the ray's flags before lane 0 writes them)
-
-    // RayMarchingIter::exec (method_raymarching.cu:555-600) over dda.h:48-122, eight cells per round
-    uint32_t k = 0;
-    bool last = false;
-#if defined(VNR_MARCH_STAMPS)
-    unsigned long long a_dda = 0, a_load = 0, a_count = 0, a_scan = 0, a_emit = 0, a_bcast = 0, a_rounds = 0, w3s = 0;
-    VNR_REALTIME(rt0);
-#endif
-    VNR_STAMP(w0);
-    if (walk) {
-      const vec3i grid = p.mc_dims;
-      const vec3i stop = {m_dir.x > 0.0f ? grid.x : -1, m_dir.y > 0.0f ? grid.y : -1, m_dir.z > 0.0f ? grid.z : -1};
-      const vec3f ts = {fabsf(1.0f / m_dir.x), fabsf(1.0f / m_dir.y), fabsf(1.0f / m_dir.z)};
-      const vec3i delta = {m_dir.x > 0.0f ? 1 : -1, m_dir.y > 0.0f ? 1 : -1, m_dir.z > 0.0f ? 1 : -1};
-      const uint32_t row = rl * stride;
-      bool more = true;
-      for (int round = 0; more && round < 1024; ++round) {   // (a walk crosses at most 3 x 2^10 cells; the bound is a guard against a state that does not move)
-        DDAState L = S;
-        VNR_STAMP(r0);
-        for (uint32_t q = 0; q < s; ++q) {   // the cells before mine were left the way a walk leaves a cell it has finished
-          const float tcq = min3f(L.t_next.x, L.t_next.y, L.t_next.z);
-          const bool bx = L.t_next.x == tcq, by = L.t_next.y == tcq, bz = L.t_next.z == tcq;
-          L.t_next.x = bx ? L.t_next.x + ts.x : L.t_next.x;
-          L.t_next.y = by ? L.t_next.y + ts.y : L.t_next.y;
-          L.t_next.z = bz ? L.t_next.z + ts.z : L.t_next.z;
-          L.cell.x += bx ? delta.x : 0; L.cell.y += by ? delta.y : 0; L.cell.z += bz ? delta.z : 0;
-          L.next_cell_begin = tcq;
-        }
-        // (exact for the first lane of the round that is there; lanes behind a lane that ends the walk are not used)
-        const bool at_stop = L.cell.x == stop.x || L.cell.y == stop.y || L.cell.z == stop.z;
-        const bool in_grid = (uint32_t)L.cell.x < (uint32_t)grid.x && (uint32_t)L.cell.y < (uint32_t)grid.y && (uint32_t)L.cell.z < (uint32_t)grid.z;
-        const float tc = min3f(L.t_next.x, L.t_next.y, L.t_next.z);
-        const float c0 = fmaxf(tmin + L.next_cell_begin, tmin);
-        const float c1 = fminf(tmin + tc, tmax);
-        const bool brk = c0 >= c1;
-        VNR_STAMP(r1);
-        const float rr = in_grid ? opacity_upper_bound(p, L.cell) : 0.0f;
-#if defined(VNR_MARCH_STAMPS)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        VNR_STAMP(r2);
-        const bool samp = in_grid && !brk && !(fabsf(rr) <= FLT_EPSILON);
-        float ss = 0.0f;
-        uint32_t n = 0;
-        if (samp) {   // how many samples this cell takes: the running sums of the emission below, without the stores
-          ss = adaptive_sampling_rate(p.step, rr);
-          float tx = c0, ty = fminf(c1, c0 + ss);
-          while (ty > tx && n < (uint32_t)n_iters) { ++n; tx = ty; ty = fminf(tx + ss, c1); }
-        }
-        VNR_STAMP(r3);
-        uint32_t incl = n;
-#pragma unroll
-        for (int d = 1; d < 8; d <<= 1) {
-          const uint32_t y = __shfl_up(incl, d, 8);
-          if ((int)s >= d) incl += y;
-        }
-        const uint32_t kk = k + incl - n;                       // samples of the batch before this cell's
-        const bool fill = kk + n >= (uint32_t)n_iters;          // the batch is full after (or inside) this cell
-        const bool term = at_stop || brk || fill;
-        const uint32_t tm = (uint32_t)(__ballot(term) >> seg) & 0xffu;
-        const uint32_t f = tm ? (uint32_t)__ffs((int)tm) - 1u : 8u;   // the first lane of the ray that ends the walk
-        VNR_STAMP(r4);
-        bool adv = !(at_stop || brk);
-        uint32_t k_after = kk;
-        if (s <= f && samp) {
-          float tx = c0, ty = fminf(c1, c0 + ss);
-          uint32_t kq = kk;
-          bool go = true;
-          while (ty > tx) {
-            s_t0[row + kq] = tx;
-            s_t1[row + kq] = ty;
-            L.next_cell_begin = ty - tmin;
-            if ((int)(++kq) >= n_iters) { go = false; break; }
-            tx = ty;
-            ty = fminf(tx + ss, c1);
-          }
-          k_after = kq;
-          adv = go || fmaxf(tmin + L.next_cell_begin, tmin) >= c1;
-        }
-        if (adv) {
-          const bool bx = L.t_next.x == tc, by = L.t_next.y == tc, bz = L.t_next.z == tc;
-          L.t_next.x = bx ? L.t_next.x + ts.x : L.t_next.x;
-          L.t_next.y = by ? L.t_next.y + ts.y : L.t_next.y;
-          L.t_next.z = bz ? L.t_next.z + ts.z : L.t_next.z;
-          L.cell.x += bx ? delta.x : 0; L.cell.y += by ? delta.y : 0; L.cell.z += bz ? delta.z : 0;
-          L.next_cell_begin = tc;
-        }
-        VNR_STAMP(r5);
-        const int src = (int)min(f, 7u);
-        S.cell.x = __shfl(L.cell.x, src, 8); S.cell.y = __shfl(L.cell.y, src, 8); S.cell.z = __shfl(L.cell.z, src, 8);
-        S.t_next.x = __shfl(L.t_next.x, src, 8); S.t_next.y = __shfl(L.t_next.y, src, 8); S.t_next.z = __shfl(L.t_next.z, src, 8);
-        S.next_cell_begin = __shfl(L.next_cell_begin, src, 8);
-        k = (uint32_t)__shfl((int)k_after, src, 8);
-        more = f == 8u;
-        VNR_STAMP(r6);
-#if defined(VNR_MARCH_STAMPS)
-        a_dda += r1 - r0; a_load += r2 - r1; a_count += r3 - r2; a_scan += r4 - r3; a_emit += r5 - r4; a_bcast += r6 - r5; a_rounds += 1;
-#endif
-      }
-      last = k == 0 || !dda_resumable(S, m_dir, tmin, tmax, p.mc_dims);
-      if (s == 0) {
-        r.walking[i] = last ? 0u : 1u;
-        if (!last) { r.cell[i] = S.cell; r.t_next[i] = S.t_next; r.ncb[i] = S.next_cell_begin; ++n_walking; }
-      }
-    } else if (FIRST && active && s == 0) {
-      r.walking[i] = 0u;
-    }
-    if (s == 0) {
-      if (active) ring.rec[i] = walk ? (k | kRecValid | (last ? kRecLast : 0u)) : 0u;
-      s_k[rl] = k;
-    }
-    if (tid < 64) s_hist[tid] = 0;
-    VNR_STAMP(w1);
-    __syncthreads();
-
-    // the group's samples: one claim per block, the front of the group (march_kernel)
-    if (tid < 64) {
-      const uint32_t kr = s_k[tid];
-      uint32_t incl = kr;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(incl, d);
-        if ((int)lane >= d) incl += y;
-      }
-      const uint32_t total = __shfl(incl, 63);
-      float front = kr ? s_t0[tid * stride] : VNR_FLOAT_LARGE;
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) front = fminf(front, __shfl_xor(front, d));
-      if (tid == 0) {
-        s_misc[0] = total ? atomicAdd(ring.ctr + D_SAMPLES, total) : 0u;
-        s_misc[1] = __float_as_uint(front);
-        s_misc[2] = total;
-      }
-    }
-    __syncthreads();
-    const uint32_t total = s_misc[2];
-    VNR_STAMP(w2);
-    if (total) {   // block-uniform
-      const uint32_t smp_base = s_misc[0];
-      const float front = __uint_as_float(s_misc[1]);
-      // counting sort of the group's samples by depth bin: lane s of a ray takes its samples s, s + 8, ...
-      for (uint32_t j = s; j < k; j += 8u) {
-        const float t0 = s_t0[rl * stride + j], t1 = s_t1[rl * stride + j];
-        const float t = (1.0f - jitter) * t0 + jitter * t1;
-        s_rk[rl * stride + j] = (uint16_t)atomicAdd(&s_hist[depth_bin(p, t, front)], 1u);
-      }
-      __syncthreads();
-      if (tid < 64) {
-        const uint32_t h = s_hist[tid];
-        uint32_t hs = h;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t y = __shfl_up(hs, d);
-          if ((int)lane >= d) hs += y;
-        }
-        s_hist[tid] = smp_base + hs - h;
-      }
-      __syncthreads();
-#if defined(VNR_MARCH_STAMPS)
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w3s) :: "memory");
-#endif
-      const uint32_t sb = g * (uint32_t)n_iters * 64u + rl;   // sample j of this ray: slot sb + 64 j
-      for (uint32_t j = s; j < k; j += 8u) {
-        const float t0 = s_t0[rl * stride + j], t1 = s_t1[rl * stride + j];
-        const float t = (1.0f - jitter) * t0 + jitter * t1;  // lerp(jitter, t0, t1), instantvnr_types.h:162-166
-        const vec3f c = org + t * dir;
-        const uint32_t q = s_hist[depth_bin(p, t, front)] + s_rk[rl * stride + j];
-        if (q < p.slot_cap) queue[q] = {c.x, c.y, c.z, __uint_as_float(arena_value_index(sb + 64u * j))};
-        vd_out[sb + 64u * j].y = t1 - t0;
-      }
-    }
-    __syncthreads();   // the LDS arrays are reused by the next group
-#if defined(VNR_MARCH_STAMPS)
-    {
-      unsigned long long w4;
-      asm volatile("s_memtime %0\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=s"(w4) :: "memory");
-      VNR_REALTIME(rt1);
-      const uint32_t rid = g * 8u + (tid >> 6);
-      if (it == 1u && lane == 0 && rid < kWaveRecs) {
-        unsigned long long* rec = g_wave_rec[rid];
-        const unsigned long long w3e = w3s ? w3s : w2;
-        rec[0] = rt0; rec[1] = rt1; rec[2] = w1 - w0; rec[3] = w2 - w1; rec[4] = w3e - w2; rec[5] = w4 - w3e;
-        rec[6] = a_load; rec[7] = (a_rounds << 48) | ((a_dda + a_count + a_scan + a_emit + a_bcast) & 0xffffffffffffull);
-      }
-    }
-#endif
-  }
-
-  // rays still walking (and, at i = 0, rays that hit the volume): one atomic per block, the last block to arrive publishes
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { n_walking += __shfl_xor(n_walking, d); n_hit += __shfl_xor(n_hit, d); }
-  if (lane == 0) { s_hist[tid >> 6] = n_walking; s_hist[8 + (tid >> 6)] = n_hit; }
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t bw = 0, bh = 0;
-    for (int w = 0; w < 8; ++w) { bw += s_hist[w]; bh += s_hist[8 + w]; }
-    if (bw) atomicAdd(ring.ctr + D_WALKING, bw);
-    if (FIRST && bh) atomicAdd(ring.ctr + D_HIT, bh);
-    __threadfence();
-    if (atomicAdd(ring.ctr + D_TICKET_W, 1u) == gridDim.x - 1u) {
-      host->walking[it & 255u] = atomicAdd(ring.ctr + D_WALKING, 0u);
-      host->emitted[it & 255u] = atomicAdd(ring.ctr + D_SAMPLES, 0u);
-      if (FIRST) host->hit = atomicAdd(ring.ctr + D_HIT, 0u);
-    }
-  }
-}
-
-// iterative_compose_kernel (method_raymarching.cu:732-838), NO_SHADING, eight lanes per ray for the classification
-__global__ void __launch_bounds__(512) compose8_kernel(const RenderParams p, const DRays r, const DRing ring, DHost* __restrict__ host, uint32_t it)
-{
-  extern __shared__ float s_mem[];   // [n_iters][64] classified samples {r, g, b, a}, then the transfer function tables
-  vec4f* s_cls = (vec4f*)s_mem;
-  DeviceTfn tfn = p.tfn;
-  tfn_lds_colors_t lds_colors = nullptr;
-  tfn_lds_alphas_t lds_alphas = nullptr;
-  bool tfn_merged = false;
-  if (p.tfn_in_lds) {
-    vec4f* s_colors = s_cls + (size_t)p.n_iters * 64u;
-    float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
-    tfn_merged = tfn_tables_to_lds(p.tfn, s_colors, s_alphas, !(p.debug_flags & 32u));
-    lds_colors = (tfn_lds_colors_t)s_colors;
-    lds_alphas = (tfn_lds_alphas_t)s_alphas;
-  }
-  const uint32_t tid = threadIdx.x;
-  const uint32_t rl = tid >> 3, s = tid & 7u;
-  const uint32_t P = p.n_local;
-  const uint32_t n_groups = (P + 63u) >> 6;
-  const vec2f* __restrict__ vd_in = ring.arena;
-  uint32_t n_ref = 0, n_smp = 0;
-  __syncthreads();
-  for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    {
-      const uint32_t i = g * 64u + rl;
-      uint32_t sc = 0;
-      if (i < P) {
-        const uint32_t rec = ring.rec[i];
-        if ((rec & kRecValid) && !r.done[i]) sc = min(rec & 0xffffu, (uint32_t)p.n_iters);
-      }
-      const uint32_t sb = g * (uint32_t)p.n_iters * 64u + rl;
-      for (uint32_t j = s; j < sc; j += 8u) {
-        const vec2f vd = vd_in[sb + 64u * j];   // {value, t1 - t0}
-        vec3f rgb; float a;
-        if (p.tfn_in_lds) tfn_sample_lds(tfn, lds_colors, lds_alphas, vd.x, rgb, a, tfn_merged);   // uniform branch
-        else tfn_sample(tfn, vd.x, rgb, a);
-        a = opacity_correction(p.step_rcp, vd.y, a);
-        s_cls[j * 64u + rl] = {rgb.x, rgb.y, rgb.z, a};
-      }
-    }
-    __syncthreads();
-    if (tid < 64) {   // front-to-back, in order, one lane per ray
-      const uint32_t i = g * 64u + tid;
-      if (i < P) {
-        const uint32_t rec = ring.rec[i];
-        if ((rec & kRecValid) && !r.done[i]) {   // (else: no batch, or a batch emitted ahead of a saturation: dropped)
-          const uint32_t sc = min(rec & 0xffffu, (uint32_t)p.n_iters);
-          ++n_ref; n_smp += sc;
-          float alpha = r.alpha[i];
-          vec3f color = r.color[i];
-          bool saturated = false;
-          for (uint32_t j = 0; j < sc; ++j) {
-            const vec4f c = s_cls[j * 64u + tid];
-            const float tr = 1.0f - alpha;
-            alpha += tr * c.w;
-            color.x += tr * c.x * c.w; color.y += tr * c.y * c.w; color.z += tr * c.z * c.w;
-            if (!(alpha < VNR_NEARLY_ONE)) { saturated = true; break; }
-          }
-          if (saturated || (rec & kRecLast)) {
-            write_pixel(p, {color.x, color.y, color.z, alpha}, r.pixel[i]);
-            r.done[i] = 1u;
-          } else {
-            r.alpha[i] = alpha;
-            r.color[i] = color;
-          }
-        }
-      }
-    }
-    __syncthreads();   // s_cls is reused; r.done of this group is written after every lane of the group has read it
-  }
-  if (tid < 64) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { n_ref += __shfl_xor(n_ref, d); n_smp += __shfl_xor(n_smp, d); }
-  }
-  if (tid == 0) {
-    if (n_ref) atomicAdd(ring.ctr + D_NREF, n_ref);
-    if (n_smp) atomicAdd(ring.ctr + D_NSMP, n_smp);
-    __threadfence();
-    if (atomicAdd(ring.ctr + D_TICKET_C, 1u) == gridDim.x - 1u) {
-      host->n_ref[it & 255u] = atomicAdd(ring.ctr + D_NREF, 0u);
-      host->n_smp[it & 255u] = atomicAdd(ring.ctr + D_NSMP, 0u);
-      for (int c = 0; c < D_COUNT; ++c) atomicExch(ring.ctr + c, 0u);
-    }
-  }
-}
+// (An eight-lanes-per-ray form of these two kernels, walk8_kernel / compose8_kernel, was built in round 3, gave bit-identical frames and
+// three times shorter wave-trips, and lost every measurement: 3-4 x the instructions.  Removed in round 4; the numbers are in
+// docs/history/DESIGN_r01-r03.md 4.2b and profiles/r03_eight_lanes_per_ray.txt.)
 
 }  // namespace vnr

@@ -38,7 +38,6 @@ struct InferArgs {
   uint32_t output_activation;
   uint32_t lds_halves;
   uint32_t sharers;          // kernels of this kind expected to share the GPU (host-side launch sizing only)
-  uint32_t lds_table_halves; // VNR_LDS_LEVELS experiment: halves of the table's head staged behind the weights (0: none)
   PackArgs pack;             // MODE 0, queue launches of the ray marcher: the iteration's ray packing as a prologue (pack.n_blocks > 0)
 };
 
@@ -78,13 +77,6 @@ __global__ void __launch_bounds__(64 * MlpShape<W>::WAVES) fused_infer_kernel(co
     const uint4_t* src = (const uint4_t*)args.packed_mlp;
     uint4_t* dst = (uint4_t*)lds;
     for (uint32_t i = threadIdx.x; i < args.lds_halves / 8; i += blockDim.x) dst[i] = src[i];
-#if defined(VNR_LDS_LEVELS)
-    {
-      const uint4_t* ts = (const uint4_t*)args.table;
-      uint4_t* td = (uint4_t*)(lds + args.lds_halves);
-      for (uint32_t i = threadIdx.x; i < args.lds_table_halves / 8; i += blockDim.x) td[i] = ts[i];
-    }
-#endif
     __syncthreads();
   }
   const uint32_t nh = args.n_hidden_matmuls;
@@ -109,12 +101,7 @@ __global__ void __launch_bounds__(64 * MlpShape<W>::WAVES) fused_infer_kernel(co
 
     // ---- encode: lane = sample, level wave-uniform (infer_tile.h) -----------------------------------
     half8_t feat[NCHUNK];
-#if defined(VNR_LDS_LEVELS)
-    encode_tile<F, K_IN, GENERAL>(args.levels, args.n_levels, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, feat,
-                                  args.lds_table_halves ? (const half_t*)lds + args.lds_halves : nullptr);
-#else
     encode_tile<F, K_IN, GENERAL>(args.levels, args.n_levels, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, feat);
-#endif
 
     if (MODE != 0 && args.features_out && i < n) {
       half8_t* dst = (half8_t*)(args.features_out + (size_t)i * K_IN);
@@ -150,7 +137,7 @@ static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
     const int v = e ? std::atoi(e) : 0;
     return (uint32_t)(v >= 1 && v <= 64 ? v : 0);
   }();
-  const size_t shmem = MODE == 1 ? 16 : ((size_t)a.lds_halves + a.lds_table_halves) * sizeof(uint16_t);
+  const size_t shmem = MODE == 1 ? 16 : (size_t)a.lds_halves * sizeof(uint16_t);
   // (128 neurons: the image takes most of the LDS, one block of 8 waves per CU)
   const uint32_t fit = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(shmem, 1)));
   uint32_t max_blocks = (uint32_t)rt.n_cus * (forced ? forced : std::min(fit, a.sharers >= 2 ? 3u : 4u));

@@ -196,33 +196,10 @@ __device__ __forceinline__ float mlp_column_tile(const half_t* __restrict__ wgt,
 
 
 // ---- encode: lane = sample, level wave-uniform -> feat[K_IN / 8] (the sample's K_IN features, fp16, zero padded) ---------------
-#if defined(VNR_LDS_LEVELS)
-// EXPERIMENT (make EXTRA=-DVNR_LDS_LEVELS=n): the n coarsest levels' tables staged in LDS behind the weights.
-// A dense level's corners x, x + 1 are adjacent entries: one ds_read2_b32 per (y, z) row.  Out-of-domain waves take the global path.
-template <int F>
-__device__ __forceinline__ bool gather_corners_lds(const LevelInfo& lv, const CornerSetup& c, const half_t* __restrict__ lds_table,
-                                                   typename RawFeat<F>::raw_t (&v)[8])
-{
-  static_assert(F == 2, "experiment: F = 2 only");
-  const uint32_t res = lv.resolution, res2 = lv.res2;
-  const uint32_t base = c.g[0] + __umul24(c.g[1], res) + __umul24(c.g[2], res2);
-  const bool bad = (c.g[0] > res) | (c.g[1] > res) | (c.g[2] > res) | (base + 1u + res + res2 >= lv.size);
-  if (__builtin_amdgcn_ballot_w64(bad) != 0ull) return false;
-  const uint32_t* t = (const uint32_t*)lds_table + lv.offset;   // one dword per entry (F = 2)
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t idx = base + ((q & 1) ? res : 0u) + ((q & 2) ? res2 : 0u);
-    v[2 * q] = t[idx];
-    v[2 * q + 1] = t[idx + 1u];
-  }
-  return true;
-}
-#endif
 
 template <int F, int K_IN, bool GENERAL = false>
 __device__ __forceinline__ void encode_tile(const LevelInfo* levels, uint32_t n_levels, uint32_t interpolation, const table_rsrc_t& rsrc,
-                                            const uint8_t* brick_image, float x, float y, float z, half8_t (&feat)[K_IN / 8],
-                                            const half_t* lds_table = nullptr)
+                                            const uint8_t* brick_image, float x, float y, float z, half8_t (&feat)[K_IN / 8])
 {
   constexpr int L_PAD = K_IN / F;   // levels incl. zero padding
   // The level table is re-read (scalar loads) every tile: making the pointer opaque per call keeps the
@@ -250,19 +227,6 @@ __device__ __forceinline__ void encode_tile(const LevelInfo* levels, uint32_t n_
     half_t o[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
-#if defined(VNR_LDS_LEVELS)
-    if constexpr (F == 2) if (l < VNR_LDS_LEVELS && l < (int)n_levels && lds_table) {
-      const LevelInfo lv = level_consts(l);
-      const CornerSetup c = level_setup(lv, interpolation, x, y, z);
-      typename RawFeat<F>::raw_t v[8];
-      if (!gather_corners_lds<F>(lv, c, lds_table, v)) gather_corners<F>(lv, c, rsrc, v);
-      typename FeatVec<F>::type vv[8];
-#pragma unroll
-      for (int corner = 0; corner < 8; ++corner) vv[corner] = __builtin_bit_cast(typename FeatVec<F>::type, v[corner]);
-      blend_level<F>(c.w, vv, o);
-    }
-    if (!(F == 2 && l < VNR_LDS_LEVELS && lds_table))
-#endif
     if (l < (int)n_levels) encode_level_fast<F, GENERAL>(level_consts(l), interpolation, rsrc, brick_image, x, y, z, o);
 #pragma unroll
     for (int f = 0; f < F; ++f) feat[(l * F + f) / 8][(l * F + f) % 8] = o[f];

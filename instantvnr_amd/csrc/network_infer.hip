@@ -239,15 +239,10 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, const Fus
   a.activation = mlp.activation;
   a.output_activation = mlp.output_activation;
   a.lds_halves = mlp.lds_halves;
-  a.lds_table_halves = 0;
   if (pack && mode == 0) {
     if (mlp.width == 128u) throw std::runtime_error("internal: the 128-neuron evaluation kernel (8 waves per block) does not take the ray packing prologue");
     a.pack = *pack;
   } else a.pack.n_blocks = 0;
-#if defined(VNR_LDS_LEVELS)
-  if (mode == 0 && grid.n_features == 2 && grid.n_levels > VNR_LDS_LEVELS && !grid.levels[VNR_LDS_LEVELS - 1].hashed)
-    a.lds_table_halves = (grid.levels[VNR_LDS_LEVELS].offset * 2u + 7u) & ~7u;   // the first levels are the head of the table
-#endif
   if (mode == 1) {   // encode only: the kernel has no MLP, one instance serves every width
     if (mlp.general) return dispatch<64, 1, true>(grid.n_features, in_width, a, n_max, s);
     return dispatch<64, 1, false>(grid.n_features, in_width, a, n_max, s);

@@ -1280,13 +1280,6 @@ struct PartState {
   bool tail_skipped = false;   // the last march launched has no evaluation / packing behind it yet (launch_iteration)
   hipEvent_t ev_done = nullptr;   // recorded behind the last iteration launched so far: the host (and the communication stream)
                                   // wait for THIS, not for the stream, which may already hold the head of the next frame
-  // the head of a pipelined frame on a stream of its own (renderer.h head_streams_)
-  hipStream_t s_head = nullptr;
-  bool side_head = false;
-  hipEvent_t ev_head = nullptr;   // behind the head, for the part stream to wait for
-  hipEvent_t ev_gate = nullptr;   // behind this frame's last large evaluation, for the next frame's head to wait for
-  uint32_t gate_it = ~0u;
-  bool gate_recorded = false;
 };
 
 // One pass of the streaming loop between its two halves: everything launch_iteration / finish_streaming need.  With
@@ -1314,7 +1307,7 @@ struct DPart {
 struct Renderer::StreamingFrame {
   bool pending = false;
   bool decoupled = false;
-  int ahead = 2, ring = 3, lanes = 1;
+  int ahead = 2, ring = 3;
   DPart dpart[Renderer::kMaxParts];
   int slot = 0;
   int H = 0, pass_mode = 0;
@@ -1330,11 +1323,9 @@ struct Renderer::StreamingFrame {
   {
     for (auto& p : part) {
       (void)hipEventCreateWithFlags(&p.ev_done, hipEventDisableTiming);
-      (void)hipEventCreateWithFlags(&p.ev_head, hipEventDisableTiming);
-      (void)hipEventCreateWithFlags(&p.ev_gate, hipEventDisableTiming);
     }
   }
-  ~StreamingFrame() { for (auto& p : part) for (hipEvent_t e : {p.ev_done, p.ev_head, p.ev_gate}) if (e) (void)hipEventDestroy(e); }
+  ~StreamingFrame() { for (auto& p : part) if (p.ev_done) (void)hipEventDestroy(p.ev_done); }
   void mark(int h) { VNR_HIP_CHECK(hipEventRecord(part[h].ev_done, part[h].s)); }
 };
 
@@ -1355,15 +1346,11 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   if (const char* e = std::getenv("VNR_AMD_DECOUPLED")) decoupled_mode_ = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("VNR_AMD_DECOUPLED_AHEAD")) decoupled_ahead_ = std::max(1, std::min(7, std::atoi(e)));
   if (const char* e = std::getenv("VNR_AMD_DECOUPLED_PARTS")) decoupled_parts_ = std::max(1, std::min(kMaxParts, std::atoi(e)));
-  if (const char* e = std::getenv("VNR_AMD_DECOUPLED_LANES")) decoupled_lanes_ = std::atoi(e) == 8 ? 8 : 1;
-  if (const char* e = std::getenv("VNR_AMD_HEAD_GATE")) head_gate_mode_ = std::max(0, std::min(2, std::atoi(e)));
-  if (const char* e = std::getenv("VNR_AMD_HEAD_GATE_FRAC")) head_gate_frac_ = std::max(0.0f, std::min(1.0f, (float)std::atof(e)));
   counters_.resize(2 * kMaxParts * C_COUNT);  // one block of counters per frame slot and half
   counters_.zero(stream_);
   VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 2 * kMaxParts * (256 + C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
   for (int i = 1; i < kMaxParts; ++i) VNR_HIP_CHECK(hipStreamCreateWithFlags(&part_streams_[i], hipStreamNonBlocking));
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-  VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_head_, hipEventDisableTiming));
 }
 
 Renderer::~Renderer()
@@ -1371,9 +1358,7 @@ Renderer::~Renderer()
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (own_stream_) (void)hipStreamDestroy(stream_);
   for (int i = 1; i < kMaxParts; ++i) if (part_streams_[i]) { (void)hipStreamSynchronize(part_streams_[i]); (void)hipStreamDestroy(part_streams_[i]); }
-  for (int i = 0; i < kMaxParts; ++i) if (head_streams_[i]) { (void)hipStreamSynchronize(head_streams_[i]); (void)hipStreamDestroy(head_streams_[i]); }
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-  if (ev_fork_head_) (void)hipEventDestroy(ev_fork_head_);
   for (auto& ps : d_streams_) for (hipStream_t st : ps) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   frame_[0].reset(); frame_[1].reset();
   if (d_host_) (void)hipHostFree(d_host_);
@@ -1872,7 +1857,7 @@ void Renderer::launch_iteration(StreamingFrame& f, int h)
     const int parity = (int)(it & 1u);
     const uint32_t P = hf.p.n_local;
     uint32_t* c = hf.c;
-    const hipStream_t s_it = it == 0 && hf.side_head ? hf.s_head : hf.s;   // the head of a pipelined frame runs on a stream of its own
+    const hipStream_t s_it = hf.s;
     // The march the previous frame ended with (it composes the last batch and finds no ray left to sample) is launched WITHOUT an
     // evaluation and a packing kernel behind it: both would be empty, and on a small share of the frame they are two more launches
     // on a chain of fifteen.  The march says in pinned memory whether a ray did survive; finish_streaming then launches the two
@@ -1902,7 +1887,6 @@ void Renderer::launch_iteration(StreamingFrame& f, int h)
     if (skip_tail) {
       if (profiling_) { VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], hf.s)); VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it + 1], hf.s)); }
       hf.tail_skipped = true;
-      if (it >= hf.gate_it && !hf.gate_recorded) { VNR_HIP_CHECK(hipEventRecord(hf.ev_gate, s_it)); hf.gate_recorded = true; }
       ++hf.it;
       if (hf.it >= max_iterations) hf.done = true;
       return;
@@ -1911,21 +1895,7 @@ void Renderer::launch_iteration(StreamingFrame& f, int h)
   {
     PartState& hf = half[h];
     const uint32_t it = hf.it;
-    hipStream_t s_it = it == 0 && hf.side_head ? hf.s_head : hf.s;
-    if (it == 0 && hf.side_head && head_gate_mode_ == 2) {   // only the first march beside the frame before; its evaluation behind that frame
-      VNR_HIP_CHECK(hipEventRecord(hf.ev_head, s_it));
-      VNR_HIP_CHECK(hipStreamWaitEvent(hf.s, hf.ev_head, 0));
-      s_it = hf.s;
-      launch_tail(f, h, it, s_it);
-    } else {
-      launch_tail(f, h, it, s_it);
-      if (it == 0 && hf.side_head) {   // the part stream goes on behind the head
-        VNR_HIP_CHECK(hipEventRecord(hf.ev_head, s_it));
-        VNR_HIP_CHECK(hipStreamWaitEvent(hf.s, hf.ev_head, 0));
-      }
-    }
-    // behind the last large evaluation of this frame: from here the head of the next frame may run beside what is left
-    if (it >= hf.gate_it && !hf.gate_recorded) { VNR_HIP_CHECK(hipEventRecord(hf.ev_gate, s_it)); hf.gate_recorded = true; }
+    launch_tail(f, h, it, hf.s);
     ++hf.it;
     if (hf.it >= max_iterations) hf.done = true;
   }
@@ -2070,49 +2040,15 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
     hf.s = h == 0 ? stream_ : part_streams_[h];
     hf.s_max = (size_t)hf.p.n_local * hf.p.n_iters * (grad ? 4 : 1);   // records the evaluation kernel may see
     off += hf.p.n_local;
-    // The last LARGE evaluation of this frame, from the alive-ray counts of the last completed frame: behind it the part stream records
-    // the event the next frame's head waits for (launch_iteration).  No history, or no tail of small launches: no early release.
-    hf.gate_it = ~0u; hf.gate_recorded = false;
-    const std::vector<uint32_t>& hist = alive_hist_[pass_mode == M_SHADOW ? 1 : 0][h];
-    if (head_gate_mode_ && hist.size() >= 3 && hist[0] > 0) {
-      uint32_t last_large = 0;
-      for (uint32_t k = 0; k < hist.size(); ++k) if ((float)hist[k] > head_gate_frac_ * (float)hist[0]) last_large = k;
-      if (last_large + 2 < hist.size()) hf.gate_it = std::max(last_large, 1u);
-    }
   }
 
-  // The head of a pipelined frame (`older` still pending) runs on streams of its own, released by the older frame's gate events (all of its
-  // parts: what the head must not run beside is large evaluations, whichever part they belong to); a part whose gate was not recorded
-  // releases it with its completion.  The counters are cleared on the first head stream.
-  // Only where nothing but frames is in flight: a training step between two frames (it runs on the render stream and rewrites the
-  // parameters the head's evaluation reads) shows as a new parameter generation, and the head then stays on the part streams behind it;
-  // changes of the renderer's own state restart the accumulation, and such a frame is not pipelined at all (render()).
-  const uint64_t generation = nv ? nv->network().params_generation() : 0;
-  bool side = older && head_gate_mode_ && !older->decoupled && pass_mode == M_NONE && nv && older->nv == nv && older->params_generation == generation;
-  f.params_generation = generation;
-  if (side) {
-    bool any_gate = false;
-    for (int h = 0; h < older->H; ++h) any_gate = any_gate || older->part[h].gate_recorded;
-    side = any_gate;
-  }
-  for (int h = 0; h < H; ++h) { half[h].side_head = side; half[h].s_head = nullptr; }
-  if (side) {
-    for (int h = 0; h < H; ++h) {
-      if (!head_streams_[h]) VNR_HIP_CHECK(hipStreamCreateWithFlags(&head_streams_[h], hipStreamNonBlocking));
-      half[h].s_head = head_streams_[h];
-      for (int g = 0; g < older->H; ++g)
-        VNR_HIP_CHECK(hipStreamWaitEvent(head_streams_[h], older->part[g].gate_recorded ? older->part[g].ev_gate : older->part[g].ev_done, 0));
-    }
-    VNR_HIP_CHECK(hipMemsetAsync(counters_base, 0, (size_t)H * C_COUNT * sizeof(uint32_t), head_streams_[0]));
-    VNR_HIP_CHECK(hipEventRecord(ev_fork_head_, head_streams_[0]));
-    for (int h = 1; h < H; ++h) VNR_HIP_CHECK(hipStreamWaitEvent(head_streams_[h], ev_fork_head_, 0));
-    // (the part streams go on behind their heads: launch_iteration)
-  } else {
-    VNR_HIP_CHECK(hipMemsetAsync(counters_base, 0, (size_t)H * C_COUNT * sizeof(uint32_t), stream_));
-    if (H > 1) {  // fork: the other streams start after everything queued on the render stream so far
-      VNR_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
-      for (int h = 1; h < H; ++h) VNR_HIP_CHECK(hipStreamWaitEvent(part_streams_[h], ev_fork_, 0));
-    }
+  // (the head of a pipelined frame runs on the part streams, behind the frame before it: a head on streams of its own, released behind that
+  // frame's last large evaluation, measured slower twice and was removed in round 4: docs/history/DESIGN_r01-r03.md 4.2b)
+  f.params_generation = nv ? nv->network().params_generation() : 0;
+  VNR_HIP_CHECK(hipMemsetAsync(counters_base, 0, (size_t)H * C_COUNT * sizeof(uint32_t), stream_));
+  if (H > 1) {  // fork: the other streams start after everything queued on the render stream so far
+    VNR_HIP_CHECK(hipEventRecord(ev_fork_, stream_));
+    for (int h = 1; h < H; ++h) VNR_HIP_CHECK(hipStreamWaitEvent(part_streams_[h], ev_fork_, 0));
   }
   const size_t shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + 16 * sizeof(uint32_t) + (p_all.no_ranks ? 0 : (size_t)p_all.n_iters * 256 * sizeof(uint16_t));
   const size_t shmem_compose = shmem + (p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0);
@@ -2203,11 +2139,6 @@ void Renderer::finish_streaming(StreamingFrame& f)
     while (used > 1 && hf.hc[(used - 2) & 255u] == 0) --used;  // trailing speculative no-op iterations
     predicted[h] = used;
     hf.used = used;
-    {
-      std::vector<uint32_t>& hist = alive_hist_[pass_mode == M_SHADOW ? 1 : 0][h];
-      hist.resize(std::min<uint32_t>(used, 256u));
-      for (uint32_t k = 0; k < hist.size(); ++k) hist[k] = hf.hc[k & 255u];
-    }
     const uint32_t* hc = hf.hs;   // every march of the frame ran before the last compact_rays_kernel
     if (pass_mode != M_SHADOW) stats_.n_rays_hit += hc[C_HIT];
     n_samples += (uint64_t)hc[C_STAT_SAMPLES] | ((uint64_t)hc[C_STAT_SAMPLES + 1] << 32);
@@ -2325,15 +2256,8 @@ void Renderer::render_decoupled(const RenderParams& p_all, bool defer)
   slot_ = slot;
   f.decoupled = true; f.ahead = A; f.ring = RING;
   f.H = H; f.pass_mode = M_NONE; f.grad = false; f.ssh = false; f.nv = nv; f.p_all = p_all;
-  f.lanes = decoupled_lanes_;
   f.shmem = ((size_t)2 * p_all.n_iters + 1) * 256 * sizeof(float) + 16 * sizeof(uint32_t) + (size_t)p_all.n_iters * 256 * sizeof(uint16_t);
   f.shmem_compose = p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0;
-  if (f.lanes == 8) {   // walk8_kernel / compose8_kernel: one 64-ray group per block (decoupled.h)
-    uint32_t st = ((uint32_t)p_all.n_iters + 7u) & ~7u;
-    if ((st & 15u) == 0u) st += 8u;
-    f.shmem = (size_t)128 * st * sizeof(float) + 136 * sizeof(uint32_t) + (size_t)64 * st * sizeof(uint16_t);
-    f.shmem_compose += (size_t)p_all.n_iters * 64 * sizeof(vec4f);
-  }
   if (f.shmem > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
   f.max_iterations = 240;
   if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) f.max_iterations = std::max(1, std::min(240, std::atoi(e)));  // diagnostics only
@@ -2341,9 +2265,6 @@ void Renderer::render_decoupled(const RenderParams& p_all, bool defer)
   if (!lds_attr_set) {
     VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VNR_HIP_CHECK(hipFuncSetAttribute((const void*)compose8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     lds_attr_set = true;
   }
   if (profiling_) {
@@ -2430,12 +2351,7 @@ void Renderer::decoupled_step(StreamingFrame& f, int h, bool head_only)
     if (it >= A) VNR_HIP_CHECK(hipStreamWaitEvent(d.sw, d.ev(d.ev_c, it - A), 0));
     const uint32_t P = d.p.n_local;
     const uint32_t blocks = std::min<uint32_t>(div_round_up(P, 256), 2048u);
-    if (f.lanes == 8) {
-      static const uint32_t cap8 = [] { const char* e = std::getenv("VNR_AMD_DECOUPLED_BLOCKS"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 8192u; }();
-      const uint32_t groups = std::min<uint32_t>(div_round_up(P, 64), cap8);
-      if (it == 0) walk8_kernel<true><<<groups, 512, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
-      else walk8_kernel<false><<<groups, 512, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
-    } else if (it == 0) walk_kernel<true><<<blocks, 256, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
+    if (it == 0) walk_kernel<true><<<blocks, 256, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
     else walk_kernel<false><<<blocks, 256, f.shmem, d.sw>>>(d.p, d.rays, ring, d.host, it);
     VNR_HIP_CHECK(hipGetLastError());
     VNR_HIP_CHECK(hipEventRecord(d.ev(d.ev_w, it), d.sw));
@@ -2460,9 +2376,7 @@ void Renderer::decoupled_step(StreamingFrame& f, int h, bool head_only)
     const DRing& ring = d.ring[it % RING];
     VNR_HIP_CHECK(hipStreamWaitEvent(d.sc, d.ev(d.ev_e, it), 0));
     const uint32_t blocks = std::min<uint32_t>(div_round_up(d.p.n_local, 256), 2048u);
-    static const uint32_t cap8 = [] { const char* e = std::getenv("VNR_AMD_DECOUPLED_BLOCKS"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 8192u; }();
-    if (f.lanes == 8) compose8_kernel<<<std::min<uint32_t>(div_round_up(d.p.n_local, 64), cap8), 512, f.shmem_compose, d.sc>>>(d.p, d.rays, ring, d.host, it);
-    else compose_kernel<<<blocks, 256, f.shmem_compose, d.sc>>>(d.p, d.rays, ring, d.host, it);
+    compose_kernel<<<blocks, 256, f.shmem_compose, d.sc>>>(d.p, d.rays, ring, d.host, it);
     VNR_HIP_CHECK(hipGetLastError());
     VNR_HIP_CHECK(hipEventRecord(d.ev(d.ev_c, it), d.sc));
     ++d.it_c;

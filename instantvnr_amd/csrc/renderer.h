@@ -143,7 +143,6 @@ private:
   // CU gracefully, so taking the walks off the chain pays only where the GPU is mostly idle.  Look-ahead of the walks in batches
   // (VNR_AMD_DECOUPLED_AHEAD: 1 = walk, evaluate, compose in turn; default 3); ray parts (VNR_AMD_DECOUPLED_PARTS, default 1)
   int decoupled_mode_ = 1, decoupled_ahead_ = 3, decoupled_parts_ = 1;
-  int decoupled_lanes_ = 1;   // lanes per ray of the walk / compose kernels (1: walk_kernel / compose_kernel; 8: walk8_kernel / compose8_kernel, measured slower: DESIGN 4.2b)
   uint32_t decoupled_predicted_[kMaxParts] = {};
   hipStream_t d_streams_[kMaxParts][3] = {};           // walk, evaluate, compose
   DeviceBuffer<uint32_t> d_words_[2];                  // per frame slot: ray state, batch records, counters
@@ -154,16 +153,6 @@ private:
   hipStream_t stream_ = nullptr, part_streams_[kMaxParts] = {};
   hipEvent_t ev_fork_ = nullptr;
   bool own_stream_ = false;
-  // Pipelined frames, experiment (VNR_AMD_HEAD_GATE=1 / 2; default 0: the head behind the frame before it, on the part streams): the HEAD of
-  // frame k + 1 (1: ray generation, first batch, its evaluation and packing; 2: the first march only) on streams of its own, released when
-  // frame k has launched the last of its LARGE evaluations (an event in frame k's part streams), so that it runs beside frame k's tail of
-  // small launches instead of behind it.  Bit-identical frames; measured SLOWER (3.74-3.85 against 3.69-3.74 ms per frame,
-  // 0.76-0.92 against 0.57 ms on the 1/8 share).
-  hipStream_t head_streams_[kMaxParts] = {};
-  hipEvent_t ev_fork_head_ = nullptr;
-  int head_gate_mode_ = 0;
-  float head_gate_frac_ = 0.3f;                       // an evaluation is "large" while more than this fraction of the first batch's rays is alive
-  std::vector<uint32_t> alive_hist_[2][kMaxParts];    // alive rays after every march of the last completed frame [pass][part]
 
   // framebuffer: double-buffered device + pinned host (framebuffer.h:7-98)
   DeviceBuffer<vec4f> fb_[2], accumulation_;

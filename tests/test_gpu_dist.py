@@ -320,18 +320,11 @@ def test_asynchronous_frames_equal_synchronous_ones(monkeypatch):
     assert st["n_iterations"] == iterations[-1]
 
 
-@pytest.mark.parametrize("head_gate", ["0", "0.3", "1.0"])
-def test_pipelined_frames_of_one_renderer_equal_synchronous_ones(monkeypatch, head_gate):
+def test_pipelined_frames_of_one_renderer_equal_synchronous_ones(monkeypatch):
     """vnrAmdRendererRenderPipelined without a process group: the head of frame k + 1 (ray generation, first batch of samples) is
     enqueued before the host has seen frame k complete.  Frames accumulate over a still camera (the case that pipelines), then
     the camera moves (a frame that restarts the accumulation is not pipelined), then accumulate again; every frame handed out
-    must equal the synchronous renderer's, statistics included.
-    head_gate: the head behind the frame before it on the part streams ("0", the default), or (an experiment that measured slower, kept behind
-    VNR_AMD_HEAD_GATE) on streams of its own, released behind that frame's last large evaluation: the whole head with the fraction of rays
-    alive that makes an evaluation large at 0.3, or the first march alone released behind the second march of the frame before (1.0)"""
-    if head_gate != "0":
-        monkeypatch.setenv("VNR_AMD_HEAD_GATE", "1" if head_gate == "0.3" else "2")
-        monkeypatch.setenv("VNR_AMD_HEAD_GATE_FRAC", head_gate)
+    must equal the synchronous renderer's, statistics included."""
     size = (96, 80)
     n_pixels = size[0] * size[1]
     vol = syn.analytic_volume(48)

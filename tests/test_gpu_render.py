@@ -197,33 +197,30 @@ def test_decoupled_walks_give_the_coupled_loop_s_frames_and_statistics(scene, sm
         monkeypatch.setenv("VNR_AMD_DECOUPLED", "0")
         want, want_stats = run(tfn, False)
         assert want_stats[0]["n_iterations"] >= 2 and want_stats[0]["n_samples"] > 10000
-        # lanes: one lane per ray (walk_kernel / compose_kernel) or eight (walk8_kernel / compose8_kernel: eight macrocells per round)
-        for ahead, parts, lanes in (("1", "1", "8"), ("2", "2", "8"), ("2", "1", "1"), ("3", "4", "8"), ("5", "2", "1"), ("3", "1", "8")):
+        for ahead, parts in (("1", "1"), ("2", "2"), ("2", "1"), ("3", "4"), ("5", "2"), ("3", "1")):
             monkeypatch.setenv("VNR_AMD_DECOUPLED", "2")
             monkeypatch.setenv("VNR_AMD_DECOUPLED_AHEAD", ahead)
             monkeypatch.setenv("VNR_AMD_DECOUPLED_PARTS", parts)
-            monkeypatch.setenv("VNR_AMD_DECOUPLED_LANES", lanes)
             got, got_stats = run(tfn, False)
             for k in range(n_frames):
-                assert np.array_equal(got[k], want[k]), (volume_kind, ahead, parts, lanes, k, float(np.abs(got[k] - want[k]).max()))
-                assert {q: got_stats[k][q] for q in keys} == {q: want_stats[k][q] for q in keys}, (ahead, parts, lanes, k)
+                assert np.array_equal(got[k], want[k]), (volume_kind, ahead, parts, k, float(np.abs(got[k] - want[k]).max()))
+                assert {q: got_stats[k][q] for q in keys} == {q: want_stats[k][q] for q in keys}, (ahead, parts, k)
             piped, piped_stats = run(tfn, True)
             for k in range(n_frames):
-                assert np.array_equal(piped[k], want[k]), (volume_kind, ahead, parts, lanes, k, "pipelined")
+                assert np.array_equal(piped[k], want[k]), (volume_kind, ahead, parts, k, "pipelined")
             assert {q: piped_stats[0][q] for q in keys} == {q: want_stats[-1][q] for q in keys}
 
 
-def test_eight_lanes_per_ray_at_every_batch_size(scene, monkeypatch):
-    """walk8_kernel takes eight macrocells of a ray per round and cuts the batch where the sample count reaches VNR_RM_N_ITERS: inside a
-    cell, at a cell's last sample, in the first or the last lane of a round.  Small and odd batch sizes put the cut everywhere; frames
-    and statistics equal the coupled loop's at the same batch size, bit for bit"""
+def test_decoupled_walk_at_every_batch_size(scene, monkeypatch):
+    """the decoupled loop (walk_kernel / compose_kernel on streams of their own, csrc/decoupled.h) cuts a ray's batch where the sample count
+    reaches VNR_RM_N_ITERS: inside a cell or at a cell's last sample.  Small and odd batch sizes put the cut everywhere; frames and
+    statistics equal the coupled loop's at the same batch size, bit for bit"""
     keys = ("n_samples", "n_reference_slots", "n_iterations", "n_rays_hit")
     for n_iters in ("1", "3", "5", "8", "16", "17", "32", "40"):
         monkeypatch.setenv("VNR_RM_N_ITERS", n_iters)
         out = []
-        for mode, lanes in (("0", "1"), ("2", "8"), ("2", "1")):
+        for mode in ("0", "2"):
             monkeypatch.setenv("VNR_AMD_DECOUPLED", mode)
-            monkeypatch.setenv("VNR_AMD_DECOUPLED_LANES", lanes)
             r = make_renderer(scene, scene["sv"])
             api.vnrRender(r)
             out.append((api.vnrRendererMapFrame(r).copy(), api.vnrRendererGetFrameStats(r)))

@@ -646,13 +646,27 @@ __global__ void __launch_bounds__(256) grid_backward_lds_kernel(const GridDevice
   for (uint32_t e = threadIdx.x; e < n_acc; e += blockDim.x) s_acc[e] = 0.0f;
   __syncthreads();
   const bool nearest = grid.interpolation == 2u;
+  // A tile is a contiguous entry range of a dense level, i.e. a slab of grid z; a sample's eight corners have z in {gz, gz + 1}, so all of
+  // them lie in [gz res^2, (gz + 2) res^2 + res].  A sample whose range misses the tile is dropped after ONE fma / floor instead of after
+  // eight index computations: with 36 tiles at the fifth level a sample is looked at by 36 blocks and belongs to two of them (round 4:
+  // the kernel 66 -> see DESIGN 4.3).  Ranges that reach the end of the table (indices wrap there) are never dropped.
+  const uint32_t res2 = lv.resolution * lv.resolution;
   for (uint32_t i = it.s0 + threadIdx.x; i < it.s1; i += blockDim.x) {
+    const float cx = coords[3 * (size_t)i], cy = coords[3 * (size_t)i + 1], cz = coords[3 * (size_t)i + 2];
+    {
+      const uint32_t gx = (uint32_t)(int32_t)__builtin_floorf(__builtin_fmaf(cx, lv.scale, 0.5f));
+      const uint32_t gy = (uint32_t)(int32_t)__builtin_floorf(__builtin_fmaf(cy, lv.scale, 0.5f));
+      const uint32_t gz = (uint32_t)(int32_t)__builtin_floorf(__builtin_fmaf(cz, lv.scale, 0.5f));
+      const uint64_t lo = (uint64_t)gz * res2, hi = ((uint64_t)gz + 2u) * res2 + lv.resolution;   // [lo, hi]: every corner index before wrapping
+      const bool in_domain = gx < lv.resolution && gy < lv.resolution && gz < lv.resolution;      // (coordinates outside [0, 1]: any index, never dropped)
+      if (in_domain && hi < lv.size && (hi < it.e0 || lo >= it.e1)) continue;
+    }
     float g[F];
     bool any = false;
 #pragma unroll
     for (int f = 0; f < F; ++f) { g[f] = (float)dfeat[(size_t)i * in_width + it.level * F + f]; any = any || g[f] != 0.0f; }
     if (!any) continue;
-    const CornerSetup c = level_setup(lv, grid.interpolation == 1u ? 1u : 0u, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
+    const CornerSetup c = level_setup(lv, grid.interpolation == 1u ? 1u : 0u, cx, cy, cz);
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
       if (nearest && corner) break;

@@ -697,8 +697,9 @@ void Dist::all_gather_host(const void* mine, void* all_out, size_t bytes)
 
 // ---- first-contact self-test (bench.py --gpus N runs it before its timed region) --------------------------------------------------
 // Every collective the sharded paths use, once, on patterned buffers whose result every rank can compute by itself: the in-place
-// all-gather of a frame share (renderer), reduce-scatter(Avg) of fp16 on a slice length that divides nothing + the all-gather of the
-// slices (sharded optimizer), broadcast (replica synchronisation), all-reduce(Sum) of fp16 (the unsharded exchange).  A collective
+// all-gather of a frame share (renderer); the sharded optimizer's exchange of a range that divides nothing, sliced exactly as the training
+// step slices it (reduce-scatter(Avg) of the 8-aligned slices, all-reduce(Avg) of the remainder, all-gather of the slices); broadcast
+// (replica synchronisation); all-reduce(Sum) of fp16 (the unsharded exchange).  A collective
 // that does not complete within `deadline_s` (hipStreamQuery polled from the host) or returns other values throws with its name; the
 // caller then exits the process (a hung collective cannot be cancelled).
 static uint16_t self_test_f16(uint32_t small_int)   // integers < 2048 are exact in fp16
@@ -749,27 +750,37 @@ std::string Dist::self_test(double deadline_s)
         if (host[(size_t)q * n + i] != want) mismatch("all-gather", (size_t)q * n + i, host[(size_t)q * n + i], want);
       }
   }
-  // 2. reduce-scatter(Avg) of fp16, slice length 100 003 (odd: divides nothing), then the all-gather of the slices.  Values are small
-  //    integers, so every partial sum is exact in fp16 whatever the order; the mean is exact when the world is a power of two
+  // 2. the sharded optimizer's exchange of ONE range exactly as volume.hip DpState::range_ready / update slice it: a range of 800 011 fp16
+  //    gradients (divides nothing): per = (length / world) & ~7 elements are reduce-scattered (Avg), the remainder is all-reduced (Avg), then
+  //    the slices are all-gathered in place.  Values are small integers, so every partial sum is exact in fp16 whatever the order; the mean
+  //    is exact when the world is a power of two
   {
-    const size_t c = 100003;
+    const size_t len = 800011, per = (len / (size_t)W) & ~(size_t)7, rest = per * (size_t)W;
     DeviceBuffer<uint16_t> buf;
-    buf.resize(c * (size_t)W);
-    std::vector<uint16_t> host(c * (size_t)W);
+    buf.resize(len);
+    std::vector<uint16_t> host(len);
     auto val = [](int q, size_t i) { return (uint32_t)((i * 5u + (size_t)q * 11u) % 32u); };
-    for (size_t i = 0; i < host.size(); ++i) host[i] = self_test_f16(val(R, i));
-    VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), host.size() * 2, hipMemcpyHostToDevice));
-    tr.reduce_scatter(buf.ptr, c, DistDType::F16, DistOp::Avg, s);
-    finish("reduce-scatter (Avg, fp16, 100 003 elements per rank)");
-    tr.all_gather(buf.ptr + (size_t)R * c, buf.ptr, c * 2, s);
-    finish("all-gather of the reduced slices");
-    VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, host.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < len; ++i) host[i] = self_test_f16(val(R, i));
+    VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), len * 2, hipMemcpyHostToDevice));
+    if (per) {
+      tr.reduce_scatter(buf.ptr, per, DistDType::F16, DistOp::Avg, s);
+      finish("reduce-scatter (Avg, fp16, slices of a range that divides nothing)");
+    }
+    if (rest < len) {
+      tr.all_reduce(buf.ptr + rest, len - rest, DistDType::F16, DistOp::Avg, s);
+      finish("all-reduce (Avg, fp16) of the range's remainder");
+    }
+    if (per) {
+      tr.all_gather(buf.ptr + (size_t)R * per, buf.ptr, per * 2, s);
+      finish("all-gather of the reduced slices");
+    }
+    VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, len * 2, hipMemcpyDeviceToHost));
     const bool pow2 = (W & (W - 1)) == 0;
-    for (size_t i = 0; i < host.size(); ++i) {
+    for (size_t i = 0; i < len; ++i) {
       uint32_t sum = 0;
       for (int q = 0; q < W; ++q) sum += val(q, i);
       const double want = (double)sum / W, got = (double)f16_to_f32(host[i]);
-      if (pow2 ? got != want : std::fabs(got - want) > 0.02 * std::max(1.0, want)) mismatch("reduce-scatter(Avg) + all-gather", i, got, want);
+      if (pow2 ? got != want : std::fabs(got - want) > 0.02 * std::max(1.0, want)) mismatch("reduce-scatter(Avg) / all-reduce(Avg) / all-gather of a range", i, got, want);
     }
   }
   // 3. broadcast from rank 0 (a length that is not a multiple of 4)

@@ -234,7 +234,7 @@ def test_collective_self_test(world, transport, tmp_path):
     for r in run_ranks("selftest", world, tmp_path, transport=transport):
         assert bool(r["ok"]), str(r["report"])
         text = str(r["report"])
-        for what in ("all-gather (in place", "reduce-scatter (Avg", "broadcast", "all-reduce (Sum"):
+        for what in ("all-gather (in place", "reduce-scatter (Avg", "all-reduce (Avg", "broadcast", "all-reduce (Sum"):
             assert what in text and "ok" in text, text
 
 

@@ -339,15 +339,36 @@ def test_reconfiguring_a_model_does_not_reuse_the_old_models_training_scratch(or
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 3e-2
 
 
-def test_a_rendered_frame_of_a_generic_model_equals_the_oracle(oracle):
-    """the renderer's sample queue goes through the same dispatch: a 32-neuron Nearest model renders"""
+RENDERED = [
+    # (n_neurons, interpolation, activation, output_activation, grid type, rendering mode)
+    (32, "Linear", "ReLU", "None", "Hash", 5),
+    (128, "Linear", "ReLU", "None", "Hash", 5),          # blocks of 8 waves: the renderer launches the ray packing itself
+    (16, "Nearest", "ReLU", "None", "Hash", 5),
+    (64, "Linear", "Sigmoid", "None", "Hash", 5),        # a GENERAL instance behind the renderer's sample queue
+    (64, "Linear", "ReLU", "Sigmoid", "Tiled", 5),
+    (32, "Linear", "ReLU", "None", "Hash", 8),           # gradient shading: four evaluations per sample
+    (128, "Smoothstep", "Squareplus", "None", "Dense", 14),   # path tracing: not a 64-neuron common-kind model, so the streaming path tracer
+]
+
+
+@pytest.mark.parametrize("case", RENDERED)
+def test_a_rendered_frame_of_every_kind_of_model_equals_the_oracle(oracle, case):
+    """the renderer's sample queue goes through the same dispatch as vnrNeuralVolumeInference: frames of models of every width / kind
+    equal the oracle's marcher driven by the oracle's network (PSNR > 40 dB on random parameters; modes 5 / 8 / 14)"""
+    W, interp, act, out_act, gtype, mode = case
     cfg = syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
-    cfg["network"]["n_neurons"] = 32
+    cfg["network"]["n_neurons"] = W
+    cfg["network"]["activation"] = act
+    cfg["network"]["output_activation"] = out_act
+    cfg["encoding"]["interpolation"] = interp
+    if gtype != "Hash":
+        cfg["encoding"]["type"] = gtype
     vol = syn.analytic_volume(32)
     sv = api.vnrCreateSimpleVolume(vol)
     nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
     info = api.neural_info(nv)
-    n_mlp = oracle.mlp_n_params(info["padded_width"], 32, 1)
+    assert info["mfma_kernels"] == 1
+    n_mlp = oracle.mlp_n_params(info["padded_width"], W, 1)
     params = syn.random_params(info["n_params"], n_mlp, seed=13)
     api.neural_set_params_fp16(nv, params)
     colors, alphas = syn.tfn_ramp_with_bumps()
@@ -358,11 +379,25 @@ def test_a_rendered_frame_of_a_generic_model_equals_the_oracle(oracle):
     api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
     ren = api.vnrCreateRenderer(nv)
     api.vnrRendererSetTransferFunction(ren, tfn); api.vnrRendererSetCamera(ren, camera); api.vnrRendererSetFramebufferSize(ren, (64, 48))
+    api.vnrRendererSetMode(ren, mode)
     api.vnrRender(ren)
     img = api.vnrRendererMapFrame(ren).copy()
-    ocfg = oracle.grid_config(4, 2, 12, 4)
+    ocfg = oracle.grid_config(4, 2, 12, 4, interpolation=INTERP[interp], grid_type=gtype)
     mo = api.volume_macrocell(nv)["max_opacity"]
-    sc = oracle.SceneHolder(64, 48, (32, 32, 32), oracle.TfnHolder(colors, alphas), mo, cam["from"], cam["at"], cam["up"], cam["fovy"])
-    ref, _, _ = oracle.render_streaming(sc, lambda c: oracle.network_inference(ocfg, 32, 2, params.view(np.uint16), c))
+    code = oracle.act_code(act, out_act)
+    net = lambda c: oracle.network_inference(ocfg, W, 2, params.view(np.uint16), c, activation=code)   # noqa: E731
+    kw = {}
+    if mode == 8:
+        kw = {"shading_mode": 1}
+    sc = oracle.SceneHolder(64, 48, (32, 32, 32), oracle.TfnHolder(colors, alphas), mo, cam["from"], cam["at"], cam["up"], cam["fovy"], **kw)
+    if mode == 14:
+        ref, _, _ = oracle.render_pathtracing(sc, net)
+    else:
+        ref, _, _ = oracle.render_streaming(sc, net)
+    if mode == 14:   # individual paths differ where the two networks' values differ in the last bits (a tracking decision flips): compare coarsely
+        assert (img[..., 3] == 1.0).all()
+        assert abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) < 0.15 * float(ref[..., :3].mean())
+        assert np.corrcoef(img[..., :3].reshape(-1), ref[..., :3].reshape(-1))[0, 1] > 0.8
+        return
     mse = float(((img - ref) ** 2).mean())
-    assert img[..., 3].max() > 0.005 and 10 * np.log10(1.0 / max(mse, 1e-20)) > 40.0
+    assert img[..., 3].max() > 0.002 and 10 * np.log10(1.0 / max(mse, 1e-20)) > 40.0, (case, 10 * np.log10(1.0 / max(mse, 1e-20)))   # (not vacuous: something is visible)

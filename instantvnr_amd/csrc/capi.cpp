@@ -576,8 +576,8 @@ int vnrAmdNeuralVolumeGetModelKind(vnrAmdVolume v, int* activation, int* output_
     if (output_activation) *output_activation = (int)n.config().output_activation;
     if (grid_type) *grid_type = (int)n.config().grid_type;
     if (interpolation) *interpolation = (int)n.config().interpolation;
-    if (mfma_inference) *mfma_inference = n.fast_path() ? 1 : 0;
-    if (mfma_training) *mfma_training = n.fast_train_path() ? 1 : 0;
+    if (mfma_inference) *mfma_inference = 1;   // since round 4 there is no other kind of kernel
+    if (mfma_training) *mfma_training = 1;
   });
 }
 

@@ -381,9 +381,24 @@ __device__ __forceinline__ void blend_level(const float (&wd)[3], const typename
   }
 }
 
+// quantize_threshold (tcnn_impl_decoder.cu:120: `if (fabsf(data) < quantize_threshold) data = 0.f` on every corner value before the blend)
+template <int F>
+__device__ __forceinline__ typename RawFeat<F>::raw_t quantize_raw(typename RawFeat<F>::raw_t raw, float qt)
+{
+  typedef typename FeatVec<F>::type vec_t;
+  vec_t v = __builtin_bit_cast(vec_t, raw);
+  if constexpr (F == 1) {
+    if (fabsf((float)v) < qt) v = (half_t)0.0f;
+  } else {
+#pragma unroll
+    for (int f = 0; f < F; ++f) if (fabsf((float)v[f]) < qt) v[f] = (half_t)0.0f;
+  }
+  return __builtin_bit_cast(typename RawFeat<F>::raw_t, v);
+}
+
 template <int F, bool GENERAL = false>
 __device__ __forceinline__ void encode_level_fast(const LevelInfo& lv, uint32_t interpolation, table_rsrc_t rsrc, const uint8_t* image,
-                                                  float x, float y, float z, half_t* out)
+                                                  float x, float y, float z, half_t* out, float quantize_threshold = 0.0f)
 {
   typedef typename RawFeat<F>::raw_t raw_t;
   const CornerSetup c = level_setup(lv, interpolation, x, y, z);
@@ -399,6 +414,10 @@ __device__ __forceinline__ void encode_level_fast(const LevelInfo& lv, uint32_t 
   }
   raw_t v[8];
   if (lv.brick == 0u || !gather_corners_brick<F>(lv, c, image, v)) gather_corners<F, GENERAL>(lv, c, rsrc, v);
+  if (GENERAL && quantize_threshold > 0.0f) {   // wave-uniform
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) v[corner] = quantize_raw<F>(v[corner], quantize_threshold);
+  }
   if constexpr (F >= 2) {   // the blend of the grouped form: same values, 4 instead of 5-6 instructions per corner and feature pair
     typename FeatVec<F>::type vv[8];
 #pragma unroll

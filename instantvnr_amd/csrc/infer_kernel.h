@@ -15,6 +15,8 @@ struct FusedMlp {
   const uint16_t* packed;   // forward image (packed_mlp_halves)
   uint32_t lds_halves, width, n_hidden_matmuls, activation, output_activation;
   bool general;             // the model needs a GENERAL instance (grid_device.h gather_corners; Network::common_kind)
+  bool weights_global;      // the weight image exceeds the LDS (128 neurons, >= 6 hidden layers): the A operands are read from global memory
+  float quantize_threshold;
 };
 
 struct InferArgs {
@@ -38,6 +40,8 @@ struct InferArgs {
   uint32_t output_activation;
   uint32_t lds_halves;
   uint32_t sharers;          // kernels of this kind expected to share the GPU (host-side launch sizing only)
+  uint32_t weights_global;   // GENERAL instances of 128 neurons: the weight image does not fit the LDS and stays in global memory
+  float quantize_threshold;  // GENERAL instances (tcnn_impl_decoder.cu:120)
   PackArgs pack;             // MODE 0, queue launches of the ray marcher: the iteration's ray packing as a prologue (pack.n_blocks > 0)
 };
 
@@ -73,7 +77,9 @@ __global__ void __launch_bounds__(64 * MlpShape<W>::WAVES) fused_infer_kernel(co
   // the grid is sized by an upper bound of the sample count: a block none of whose waves has a tile leaves at once
   if (xcd * per_xcd + (blockIdx.x >> 3) * WAVES >= tile_end) return;
 
-  if (MODE != 1) {  // stage the packed weights once per block
+  constexpr bool CAN_GLOBAL = GENERAL && W == 128;   // the only shape whose image can exceed 160 KiB
+  const bool wglobal = CAN_GLOBAL && args.weights_global != 0u;
+  if (MODE != 1 && !wglobal) {  // stage the packed weights once per block
     const uint4_t* src = (const uint4_t*)args.packed_mlp;
     uint4_t* dst = (uint4_t*)lds;
     for (uint32_t i = threadIdx.x; i < args.lds_halves / 8; i += blockDim.x) dst[i] = src[i];
@@ -101,7 +107,8 @@ __global__ void __launch_bounds__(64 * MlpShape<W>::WAVES) fused_infer_kernel(co
 
     // ---- encode: lane = sample, level wave-uniform (infer_tile.h) -----------------------------------
     half8_t feat[NCHUNK];
-    encode_tile<F, K_IN, GENERAL>(args.levels, args.n_levels, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, feat);
+    encode_tile<F, K_IN, GENERAL>(args.levels, args.n_levels, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, feat,
+                                  GENERAL ? args.quantize_threshold : 0.0f);
 
     if (MODE != 0 && args.features_out && i < n) {
       half8_t* dst = (half8_t*)(args.features_out + (size_t)i * K_IN);
@@ -111,7 +118,11 @@ __global__ void __launch_bounds__(64 * MlpShape<W>::WAVES) fused_infer_kernel(co
     if (MODE == 1) continue;
 
     // ---- MLP on the wave's 64 samples (infer_tile.h) ------------------------------------------------
-    const float y = mlp_tile<W, K_IN, MODE == 2, GENERAL>((const half_t*)lds, feat, nh, act, h, r, args.acts_out, n, tile * 64u);
+    float y;
+    if (CAN_GLOBAL && wglobal)   // (two calls, not one pointer select: each keeps its address space, ds_read_b128 against global_load_dwordx4)
+      y = mlp_tile<W, K_IN, MODE == 2, GENERAL>(args.packed_mlp, feat, nh, act, h, r, args.acts_out, n, tile * 64u);
+    else
+      y = mlp_tile<W, K_IN, MODE == 2, GENERAL>((const half_t*)lds, feat, nh, act, h, r, args.acts_out, n, tile * 64u);
     // network output is produced in half precision (output activation on the half), then cast to float (tcnn_impl.cu:421-431)
     if (i < n) args.out[out_index] = finish_output<GENERAL>(y, args.output_activation);
   }
@@ -137,7 +148,7 @@ static void launch_one(const InferArgs& a, size_t n_max, hipStream_t s)
     const int v = e ? std::atoi(e) : 0;
     return (uint32_t)(v >= 1 && v <= 64 ? v : 0);
   }();
-  const size_t shmem = MODE == 1 ? 16 : (size_t)a.lds_halves * sizeof(uint16_t);
+  const size_t shmem = (MODE == 1 || a.weights_global) ? 16 : (size_t)a.lds_halves * sizeof(uint16_t);
   // (128 neurons: the image takes most of the LDS, one block of 8 waves per CU)
   const uint32_t fit = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(shmem, 1)));
   uint32_t max_blocks = (uint32_t)rt.n_cus * (forced ? forced : std::min(fit, a.sharers >= 2 ? 3u : 4u));

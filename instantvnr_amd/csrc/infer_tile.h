@@ -199,7 +199,8 @@ __device__ __forceinline__ float mlp_column_tile(const half_t* __restrict__ wgt,
 
 template <int F, int K_IN, bool GENERAL = false>
 __device__ __forceinline__ void encode_tile(const LevelInfo* levels, uint32_t n_levels, uint32_t interpolation, const table_rsrc_t& rsrc,
-                                            const uint8_t* brick_image, float x, float y, float z, half8_t (&feat)[K_IN / 8])
+                                            const uint8_t* brick_image, float x, float y, float z, half8_t (&feat)[K_IN / 8],
+                                            float quantize_threshold = 0.0f)
 {
   constexpr int L_PAD = K_IN / F;   // levels incl. zero padding
   // The level table is re-read (scalar loads) every tile: making the pointer opaque per call keeps the
@@ -227,7 +228,7 @@ __device__ __forceinline__ void encode_tile(const LevelInfo* levels, uint32_t n_
     half_t o[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) o[f] = (half_t)0.0f;
-    if (l < (int)n_levels) encode_level_fast<F, GENERAL>(level_consts(l), interpolation, rsrc, brick_image, x, y, z, o);
+    if (l < (int)n_levels) encode_level_fast<F, GENERAL>(level_consts(l), interpolation, rsrc, brick_image, x, y, z, o, quantize_threshold);
 #pragma unroll
     for (int f = 0; f < F; ++f) feat[(l * F + f) / 8][(l * F + f) % 8] = o[f];
     // keep the level constants (scalar registers) of at most four levels live at a time

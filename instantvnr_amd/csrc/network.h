@@ -110,14 +110,16 @@ public:
   const GridDevice& grid() const { return grid_; }
   uint32_t padded_width() const { return in_width_; }
   uint32_t width() const { return cfg_.n_neurons; }
-  // the MFMA kernels cover every width the reference instantiates (16 / 32 / 64 / 128, tcnn_impl.cu:315-347), every interpolation,
-  // activation and grid type; a model with a quantize_threshold, or whose weight image exceeds the LDS, takes the generic kernels
-  bool fast_path() const { return cfg_.quantize_threshold == 0.0f && (size_t)lds_halves_ * 2 <= kLdsBytes; }
-  // the common kind of model: Hash / Dense grid, Linear / Smoothstep, ReLU / None, no output activation.  Its kernels are instances of their
-  // own that contain nothing else (grid_device.h gather_corners); everything else runs on the GENERAL instances
-  bool common_kind() const { return cfg_.activation <= 1u && cfg_.output_activation == 0u && cfg_.interpolation != 2u && cfg_.grid_type != 2u; }
-  // the training kernels also need the backward image in the LDS of its kernel
-  bool fast_train_path() const { return fast_path() && (size_t)lds_halves_T_ * 2 <= kLdsBytes; }
+  // Every model the reference's dispatch builds runs on the MFMA kernels (round 4): widths 16 / 32 / 64 / 128 (tcnn_impl.cu:315-347), every
+  // interpolation, activation and grid type.  The common kind of model (Hash / Dense grid, Linear / Smoothstep, ReLU / None, no output
+  // activation, no quantize_threshold, a weight image that fits the LDS) has kernel instances that contain nothing else
+  // (grid_device.h gather_corners); everything else runs on the GENERAL instances.
+  bool weights_in_lds() const { return (size_t)lds_halves_ * 2 <= kLdsBytes; }   // false: 128 neurons with >= 6 hidden layers (or 5 and an encoded width >= 112)
+  bool common_kind() const
+  {
+    return cfg_.activation <= 1u && cfg_.output_activation == 0u && cfg_.interpolation != 2u && cfg_.grid_type != 2u && cfg_.quantize_threshold == 0.0f &&
+           weights_in_lds();
+  }
   uint32_t n_active_levels() const;    // levels below max_level + 1e-3
   uint32_t n_hidden_matmuls() const { return cfg_.n_hidden_layers - 1; }
   size_t n_params() const { return n_params_; }

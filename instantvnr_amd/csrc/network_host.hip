@@ -20,9 +20,6 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, const Fus
                   uint32_t sharers = 1, const struct PackArgs* pack = nullptr);
 void launch_init_params(OptState* state, uint16_t* params, size_t n_mlp, size_t n_total, uint32_t in_width,
                         uint32_t n_hidden_matmuls, uint32_t width, uint64_t seed, hipStream_t s);
-void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, uint32_t n_active_levels, uint32_t in_width, const LevelInfo* d_levels,
-                    const uint16_t* params, size_t n_mlp, const float* coords, float* out, uint16_t* features_out, size_t n, const uint32_t* d_n,
-                    size_t n_max, hipStream_t s, const uint32_t* d_dest, uint32_t queue_out_stride, uint16_t* acts_out = nullptr);
 // master weights <- fp16 parameters; reset_optimizer also zeroes the moments and step counts
 void launch_master_from_f16(const uint16_t* params, OptState* state, size_t n, bool reset_optimizer, hipStream_t s);
 
@@ -520,10 +517,6 @@ void Network::deserialize_params(const Json& j, hipStream_t s)
 void Network::inference(const float* d_coords, float* d_out, size_t n, const uint32_t* d_n, size_t n_max, hipStream_t s,
                         const uint32_t* d_dest) const
 {
-  if (!fast_path()) {
-    launch_generic(0, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_coords, d_out, nullptr, n, d_n, n_max, s, d_dest, 0);
-    return;
-  }
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
   GridDevice grid = grid_;
@@ -534,10 +527,6 @@ void Network::inference(const float* d_coords, float* d_out, size_t n, const uin
 bool Network::inference_queue(const float* d_records, float* d_out, uint32_t out_stride, const uint32_t* d_n, size_t n_max, hipStream_t s,
                               uint32_t sharers, const PackArgs* pack) const
 {
-  if (!fast_path()) {
-    launch_generic(0, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_records, d_out, nullptr, 0, d_n, n_max, s, nullptr, out_stride);
-    return false;
-  }
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
   GridDevice grid = grid_;
@@ -550,12 +539,13 @@ bool Network::inference_queue(const float* d_records, float* d_out, uint32_t out
 
 FusedMlp Network::fused_mlp() const
 {
-  return FusedMlp{mlp_packed_.ptr, lds_halves_, cfg_.n_neurons, n_hidden_matmuls(), cfg_.activation, cfg_.output_activation, !common_kind()};
+  return FusedMlp{mlp_packed_.ptr, lds_halves_, cfg_.n_neurons, n_hidden_matmuls(), cfg_.activation, cfg_.output_activation, !common_kind(), !weights_in_lds(),
+                  cfg_.quantize_threshold};
 }
 
 bool Network::tile_net(TileNet* out, hipStream_t s) const
 {
-  if (!fast_path() || !common_kind() || cfg_.n_neurons != (uint32_t)kWidth) return false;
+  if (!common_kind() || cfg_.n_neurons != (uint32_t)kWidth) return false;
   if (n_grid_params() * 2 >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
@@ -576,10 +566,6 @@ bool Network::tile_net(TileNet* out, hipStream_t s) const
 
 void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const
 {
-  if (!fast_path()) {
-    launch_generic(1, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_coords, nullptr, d_features, n, nullptr, n, s, nullptr, 0);
-    return;
-  }
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
   GridDevice grid = grid_;

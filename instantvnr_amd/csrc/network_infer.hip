@@ -89,122 +89,7 @@ void launch_pack_mlp(const uint16_t* params, uint16_t* packed, uint16_t* packedT
 }
 
 // ------------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------------ generic kernel
-// The models the MFMA kernels do not cover (Network::fast_path): a non-zero quantize_threshold (tcnn_impl_decoder.cu:120; settable only
-// through tcnn's own API, a params.json never carries it) and 128-neuron models whose weight image exceeds the LDS of a CU
-// (n_hidden_layers >= 6, or 5 with an encoded width of 112 / 128).  Every FullyFusedMLP width (tcnn_impl.cu:315-347 dispatches
-// WIDTH 16, 32, 64, 128), every activation, Nearest and Dense / Tiled grids run on the fused kernels since round 4.
-// One lane = one sample, plain loops, fp32 accumulation with the layer outputs rounded to fp16 and the activation applied on the
-// fp16 value, as the reference's fragments are (tcnn_threadblock.h:83,125): correct for any shape, not a fast path.
-struct GenericArgs {
-  const LevelInfo* levels;
-  uint32_t n_levels, n_active_levels, n_features, interpolation;
-  float quantize_threshold;
-  const half_t* params;     // tcnn-order blob: MLP weights then grid
-  size_t n_mlp;
-  uint32_t in_width, width, n_hidden_matmuls, activation, output_activation;
-  const float* coords;
-  float* out;
-  half_t* features_out;
-  half_t* acts_out;         // training: [(nh + 1)][n][width] post-activation outputs of the hidden layers (may be null)
-  const uint32_t* n_ptr;
-  const uint32_t* dest;
-  uint32_t queue_mode, out_stride, n, encode_only;
-};
-
-__global__ void __launch_bounds__(128) generic_infer_kernel(const GenericArgs a)
-{
-  const uint32_t n = a.n_ptr ? min(*a.n_ptr, a.n) : a.n;
-  const half_t* table = a.params + a.n_mlp;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float x, y, z;
-    uint32_t out_index = i;
-    if (a.queue_mode) {
-      const uint4_t rec = ((const uint4_t*)a.coords)[i];
-      x = __uint_as_float(rec.x); y = __uint_as_float(rec.y); z = __uint_as_float(rec.z);
-      out_index = rec.w * a.out_stride;
-    } else {
-      x = a.coords[3 * (size_t)i]; y = a.coords[3 * (size_t)i + 1]; z = a.coords[3 * (size_t)i + 2];
-      if (a.dest) out_index = a.dest[i];
-    }
-    half_t feat[128];
-    for (uint32_t k = 0; k < a.in_width; ++k) feat[k] = (half_t)0.0f;
-    const uint32_t F = a.n_features;
-    for (uint32_t l = 0; l < a.n_active_levels; ++l) {   // levels at or beyond max_level + 1e-3 stay zero (tcnn_impl_decoder.cu:17-35)
-      const LevelInfo lv = a.levels[l];
-      const CornerSetup c = level_setup(lv, a.interpolation == 1u ? 1u : 0u, x, y, z);
-      const half_t* base = table + (size_t)lv.offset * F;
-      if (a.interpolation == 2u) {   // Nearest: the entry of the lower corner as it is (:73-94)
-        const uint32_t idx = level_index(lv, c.g[0], c.g[1], c.g[2]);
-        for (uint32_t f = 0; f < F; ++f) feat[l * F + f] = base[(size_t)idx * F + f];
-        continue;
-      }
-      half_t acc[8];
-      for (uint32_t f = 0; f < F; ++f) acc[f] = (half_t)0.0f;
-      for (int corner = 0; corner < 8; ++corner) {
-        const uint32_t idx = level_index(lv, c.g[0] + (corner & 1), c.g[1] + ((corner >> 1) & 1), c.g[2] + ((corner >> 2) & 1));
-        const float w = corner_weight(c, corner);
-        for (uint32_t f = 0; f < F; ++f) {
-          float data = (float)base[(size_t)idx * F + f];
-          if (fabsf(data) < a.quantize_threshold) data = 0.0f;   // :120
-          float prod = w * data;
-          asm volatile("" : "+v"(prod));   // (T)(weight * data) rounds twice: no fused conversion (grid_device.h encode_level)
-          acc[f] = acc[f] + (half_t)prod;
-        }
-      }
-      for (uint32_t f = 0; f < F; ++f) feat[l * F + f] = acc[f];
-    }
-    if (a.features_out) for (uint32_t k = 0; k < a.in_width; ++k) a.features_out[(size_t)i * a.in_width + k] = feat[k];
-    if (a.encode_only) continue;
-    // the MLP: first (W x in), hidden (W x W) x n, last row 0 of (16 x W); weights row-major [out][in]
-    const uint32_t W = a.width;
-    half_t h0[128], h1[128];
-    const half_t* w = a.params;
-    for (uint32_t o = 0; o < W; ++o) {
-      float s = 0.0f;
-      for (uint32_t k = 0; k < a.in_width; ++k) s = __builtin_fmaf((float)w[(size_t)o * a.in_width + k], (float)feat[k], s);
-      const half_t v = act_forward_f16((half_t)s, a.activation);   // the activation on the fp16 value
-      h0[o] = v;
-      if (a.acts_out) a.acts_out[(size_t)i * W + o] = v;
-    }
-    w += (size_t)W * a.in_width;
-    half_t* cur = h0; half_t* nxt = h1;
-    for (uint32_t layer = 0; layer < a.n_hidden_matmuls; ++layer) {
-      for (uint32_t o = 0; o < W; ++o) {
-        float s = 0.0f;
-        for (uint32_t k = 0; k < W; ++k) s = __builtin_fmaf((float)w[(size_t)o * W + k], (float)cur[k], s);
-        const half_t v = act_forward_f16((half_t)s, a.activation);
-        nxt[o] = v;
-        if (a.acts_out) a.acts_out[((size_t)(layer + 1) * n + i) * W + o] = v;
-      }
-      w += (size_t)W * W;
-      half_t* t = cur; cur = nxt; nxt = t;
-    }
-    float s = 0.0f;
-    for (uint32_t k = 0; k < W; ++k) s = __builtin_fmaf((float)w[k], (float)cur[k], s);
-    a.out[out_index] = finish_output<true>(s, a.output_activation);   // the network's output is produced in half precision (tcnn_impl.cu:421-431)
-  }
-}
-
-void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, uint32_t n_active_levels, uint32_t in_width, const LevelInfo* d_levels,
-                    const uint16_t* params, size_t n_mlp, const float* coords, float* out, uint16_t* features_out, size_t n, const uint32_t* d_n,
-                    size_t n_max, hipStream_t s, const uint32_t* d_dest, uint32_t queue_out_stride, uint16_t* acts_out)
-{
-  if (n_max == 0) return;
-  if (n_max > 0xffffffc0ull) throw std::runtime_error("inference batch too large (max 2^32-64 samples per call)");
-  if (in_width > 128 || cfg.n_neurons > 128) throw std::runtime_error("generic network kernel: width > 128");
-  GenericArgs a;
-  a.levels = d_levels; a.n_levels = grid.n_levels; a.n_active_levels = n_active_levels; a.n_features = grid.n_features;
-  a.interpolation = cfg.interpolation; a.quantize_threshold = cfg.quantize_threshold;
-  a.params = (const half_t*)params; a.n_mlp = n_mlp; a.in_width = in_width; a.width = cfg.n_neurons;
-  a.n_hidden_matmuls = cfg.n_hidden_layers - 1; a.activation = cfg.activation; a.output_activation = cfg.output_activation;
-  a.coords = coords; a.out = out; a.features_out = (half_t*)features_out; a.acts_out = (half_t*)acts_out; a.n_ptr = d_n; a.dest = d_dest;
-  a.queue_mode = queue_out_stride ? 1u : 0u; a.out_stride = queue_out_stride; a.n = d_n ? (uint32_t)n_max : (uint32_t)n; a.encode_only = mode == 1 ? 1u : 0u;
-  const uint32_t blocks = std::min<uint32_t>(div_round_up(n_max, 128), (uint32_t)Runtime::get().n_cus * 16u);
-  generic_infer_kernel<<<blocks, 128, 0, s>>>(a);
-  VNR_HIP_CHECK(hipGetLastError());
-}
-
+// ------------------------------------------------------------------------------------------------
 #define VNR_DECL(name) void name(int mode, uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max, hipStream_t s)
 VNR_DECL(launch_fused_w16); VNR_DECL(launch_fused_w32); VNR_DECL(launch_fused_w64); VNR_DECL(launch_fused_w128);
 VNR_DECL(launch_fused_w16g); VNR_DECL(launch_fused_w32g); VNR_DECL(launch_fused_w64g); VNR_DECL(launch_fused_w128g);
@@ -239,6 +124,9 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, const Fus
   a.activation = mlp.activation;
   a.output_activation = mlp.output_activation;
   a.lds_halves = mlp.lds_halves;
+  a.weights_global = mlp.weights_global ? 1u : 0u;
+  a.quantize_threshold = mlp.quantize_threshold;
+  if (mlp.weights_global && (!mlp.general || mlp.width != 128u)) throw std::runtime_error("internal: weights from global memory are a GENERAL 128-neuron instance's");
   if (pack && mode == 0) {
     if (mlp.width == 128u) throw std::runtime_error("internal: the 128-neuron evaluation kernel (8 waves per block) does not take the ray packing prologue");
     a.pack = *pack;

@@ -17,10 +17,6 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, const Fus
                   const uint32_t* d_dest = nullptr, uint32_t queue_out_stride = 0, const uint8_t* brick_image = nullptr,
                   uint32_t sharers = 1, const struct PackArgs* pack = nullptr);
 
-void launch_generic(int mode, const GridDevice& grid, const ModelConfig& cfg, uint32_t n_active_levels, uint32_t in_width, const LevelInfo* d_levels,
-                    const uint16_t* params, size_t n_mlp, const float* coords, float* out, uint16_t* features_out, size_t n, const uint32_t* d_n,
-                    size_t n_max, hipStream_t s, const uint32_t* d_dest, uint32_t queue_out_stride, uint16_t* acts_out);
-
 // ------------------------------------------------------------------------------------------------ pcg32
 struct Pcg32 {
   uint64_t state, inc;
@@ -140,6 +136,7 @@ struct BackwardArgs {
   half_t* d_out;         // [(nh+1)][n][W]  dL/d(pre-activation) of every hidden layer output
   half_t* dfeat;         // [n][in_width]
   uint32_t n, nh, activation, in_width, lds_halves;
+  uint32_t weights_global;   // GENERAL instances of 128 neurons: the image exceeds the LDS and is read from global memory
 };
 
 __device__ __forceinline__ half8_t load_frag_rowmajor(const half_t* row, int s, uint32_t h)
@@ -185,7 +182,9 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
   constexpr int MT = Sh::MT, RW = Sh::RW, KS = Sh::KS;
   constexpr int NTB = W == 128 ? 1 : 2;   // 32-sample column tiles in flight (128 neurons: one, its accumulators are 4 tiles of registers already)
   extern __shared__ __attribute__((aligned(16))) half_t lds[];
-  {
+  constexpr bool CAN_GLOBAL = GENERAL && W == 128;   // the only shape whose image can exceed 160 KiB
+  const bool wglobal = CAN_GLOBAL && args.weights_global != 0u;
+  if (!wglobal) {
     const uint4_t* src = (const uint4_t*)args.packedT;
     uint4_t* dst = (uint4_t*)lds;
     for (uint32_t i = threadIdx.x; i < args.lds_halves / 8; i += blockDim.x) dst[i] = src[i];
@@ -198,6 +197,8 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
   const uint32_t n_tiles = (n + 63u) >> 6;
   constexpr int RP = MTF * 32;
 
+  // the body once per address space of the image (inlined twice: ds_read_b128 against global_load_dwordx4)
+  auto run = [&](const half_t* __restrict__ img) __attribute__((always_inline)) {
   for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
 #pragma unroll
     for (int nt0 = 0; nt0 < 2; nt0 += NTB) {
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
         const half_t* arow = args.acts + ((size_t)nh * n + sc) * W;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          const half8_t wv = *(const half8_t*)(lds + (s * 2 + h) * 8);
+          const half8_t wv = *(const half8_t*)(img + (s * 2 + h) * 8);
           half8_t d;
 #pragma unroll
           for (int j = 0; j < 8; ++j) d[j] = (half_t)((float)wv[j] * g);
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
       }
       // ---- hidden layers, last to first: d_l^T = Wh_l^T . d_{l+1}^T, through the activation --------------
       for (int layer = (int)nh - 1; layer >= 0; --layer) {
-        const half_t* w = lds + Sh::LAST + layer * Sh::HIDDEN;
+        const half_t* w = img + Sh::LAST + layer * Sh::HIDDEN;
         f32x16 acc[MT][NTB];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
       }
       // ---- feature gradient: dfeat^T = W1^T . d_0^T -------------------------------------------------
       {
-        const half_t* w = lds + Sh::LAST + nh * Sh::HIDDEN;
+        const half_t* w = img + Sh::LAST + nh * Sh::HIDDEN;
         f32x16 acc[MTF][NTB];
 #pragma unroll
         for (int m = 0; m < MTF; ++m)
@@ -291,6 +292,8 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
       }
     }
   }
+  };
+  if (CAN_GLOBAL && wglobal) run(args.packedT); else run((const half_t*)lds);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients
@@ -486,89 +489,6 @@ __global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const float* __
   __syncthreads();
   // the sum over the batch in fp32, rounded to the gradient's half precision once (tcnn's gradient matrices are __half)
   if (g == 0 && p < n_mlp) grads[p] = (half_t)((float)grads[p] + ((part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx])));
-}
-
-// ------------------------------------------------------------------------------------------------ generic MLP backward / weight gradients
-// The models the MFMA kernels do not cover (Network::fast_train_path: a quantize_threshold, or 128-neuron models whose weight images
-// exceed the LDS): the same arithmetic as mlp_backward_kernel / weight_grad_mfma_kernel (fp16 activation gradients, the activation's
-// derivative from the stored activations, fp32 sums over the batch rounded once to the fp16 gradient), one lane per sample and plain
-// loops, weights from L1 / L2.  Correct, not fast; nothing in the BASELINE configurations uses these shapes.
-struct GenericBackwardArgs {
-  const half_t* params;   // tcnn-order blob (MLP weights first)
-  const half_t* dy;       // [n]
-  const half_t* acts;     // [(nh + 1)][n][W]
-  half_t* d_out;          // [(nh + 1)][n][W]
-  half_t* dfeat;          // [n][in_width]
-  uint32_t n, nh, activation, in_width, width;
-};
-
-__global__ void __launch_bounds__(128) generic_backward_kernel(const GenericBackwardArgs a)
-{
-  const uint32_t W = a.width, n = a.n, nh = a.nh;
-  const uint32_t act = a.activation;
-  const half_t* w1 = a.params;
-  const half_t* wh = a.params + (size_t)W * a.in_width;
-  const half_t* wl = wh + (size_t)nh * W * W;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    half_t d0[128], d1[128];
-    half_t* cur = d0; half_t* nxt = d1;
-    const float g = (float)a.dy[i];
-    {  // through the last layer: d_nh[k] = Wl[0][k] * dy, masked by relu'(a_nh)
-      const half_t* arow = a.acts + ((size_t)nh * n + i) * W;
-      for (uint32_t k = 0; k < W; ++k) {
-        const half_t d = act_backward_f16((half_t)((float)wl[k] * g), arow[k], act);
-        cur[k] = d;
-        a.d_out[((size_t)nh * n + i) * W + k] = d;
-      }
-    }
-    for (int layer = (int)nh - 1; layer >= 0; --layer) {   // d_l = Wh_l^T d_{l+1}, masked
-      const half_t* w = wh + (size_t)layer * W * W;
-      const half_t* arow = a.acts + ((size_t)layer * n + i) * W;
-      for (uint32_t k = 0; k < W; ++k) {
-        float sum = 0.0f;
-        for (uint32_t o = 0; o < W; ++o) sum = __builtin_fmaf((float)w[(size_t)o * W + k], (float)cur[o], sum);
-        const half_t d = act_backward_f16((half_t)sum, arow[k], act);
-        nxt[k] = d;
-        a.d_out[((size_t)layer * n + i) * W + k] = d;
-      }
-      half_t* t = cur; cur = nxt; nxt = t;
-    }
-    for (uint32_t k = 0; k < a.in_width; ++k) {   // dL/dfeatures = W1^T d_0
-      float sum = 0.0f;
-      for (uint32_t o = 0; o < W; ++o) sum = __builtin_fmaf((float)w1[(size_t)o * a.in_width + k], (float)cur[o], sum);
-      a.dfeat[(size_t)i * a.in_width + k] = (half_t)sum;
-    }
-  }
-}
-
-// dW[out][in] = sum_b d[b][out] * x[b][in] over one chunk of the batch (blockIdx.y), one thread per element (threads of a wave: the same
-// `out`, neighbouring `in`: d is a broadcast, x a coalesced row); partial sums go to the chunk's row of the slab weight_grad_reduce_kernel sums
-struct GenericWGradArgs {
-  const half_t* features; const half_t* acts; const half_t* d_all; const half_t* dy;
-  float* slab;
-  uint32_t n, nh, in_width, width, n_mlp, chunk;
-};
-
-__global__ void __launch_bounds__(256) generic_wgrad_kernel(const GenericWGradArgs a)
-{
-  const uint32_t W = a.width, n = a.n, nh = a.nh;
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;   // element of the MLP's part of the blob, tcnn order
-  const uint32_t first = W * a.in_width, hidden = nh * W * W;
-  if (e >= first + hidden + W) return;   // rows 1 .. 15 of the padded last layer never receive a gradient
-  const uint32_t b0 = blockIdx.y * a.chunk, b1 = min(n, b0 + a.chunk);
-  const half_t* dsrc; const half_t* xsrc;
-  uint32_t o, k, xw;
-  if (e < first) { o = e / a.in_width; k = e % a.in_width; dsrc = a.d_all; xsrc = a.features; xw = a.in_width; }
-  else if (e < first + hidden) {
-    const uint32_t q = e - first, layer = q / (W * W), r = q % (W * W);
-    o = r / W; k = r % W; dsrc = a.d_all + (size_t)(layer + 1) * n * W; xsrc = a.acts + (size_t)layer * n * W; xw = W;
-  } else { o = 0; k = e - first - hidden; dsrc = nullptr; xsrc = a.acts + (size_t)nh * n * W; xw = W; }
-  float acc = 0.0f;
-  for (uint32_t b = b0; b < b1; ++b) {
-    const float d = dsrc ? (float)dsrc[(size_t)b * W + o] : (float)a.dy[b];
-    acc = __builtin_fmaf(d, (float)xsrc[(size_t)b * xw + k], acc);
-  }
-  a.slab[(size_t)blockIdx.y * a.n_mlp + e] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ grid backward
@@ -878,9 +798,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
 {
   if (!valid()) throw std::runtime_error("network is not configured");
   if (batch == 0) return;
-  // the MFMA kernels: every width, interpolation, activation and grid type the reference instantiates; models with a quantize_threshold or
-  // weight images beyond the LDS take the generic kernels (tcnn_network.h:163-252 builds whatever the model JSON asks for)
-  const bool generic = !fast_train_path();
+  // every model the reference's dispatch builds runs on the MFMA kernels (tcnn_network.h:163-252 builds whatever the model JSON asks for)
   TrainScratch& ts = scratch_of(this);
   const uint32_t nh = n_hidden_matmuls();
   const uint32_t n = (uint32_t)batch;
@@ -900,10 +818,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
 
   // 1. forward, keeping features and hidden activations
   profile_mark(0, s);
-  if (generic)
-    launch_generic(2, grid_, cfg_, n_active_levels(), in_width_, levels_dev_.ptr, params_f16_.ptr, n_mlp_, d_coords, ts.y.ptr, ws_features_.ptr, batch, nullptr,
-                   batch, s, nullptr, 0, ws_acts_.ptr);
-  else {
+  {
     GridDevice grid = grid_;
     grid.n_levels = n_active_levels();   // masked levels encode to zero, like the padding (and receive no gradient below)
     launch_fused(2, grid, in_width_, fused_mlp(), levels_dev_.ptr, params_f16_.ptr + n_mlp_, n_grid_params() * 2, d_coords, ts.y.ptr, ws_features_.ptr,
@@ -915,40 +830,23 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   // the slab's elements no block ever writes (rows 1 .. 15 of the padded last layer) must be zero: they are summed into the gradient.  Zeroed
   // when the slab grows or when the layout it was zeroed for changes (another n_mlp, the other kernel family: ADVICE r03)
   auto ensure_slab = [&](size_t rows) {
-    const uint64_t key = ((uint64_t)n_mlp_ << 1) | (generic ? 1u : 0u);
+    const uint64_t key = (uint64_t)n_mlp_;
     if (ts.wgrad_slab.count < rows * n_mlp_ || ts.slab_key != key) {
       if (ts.wgrad_slab.count < rows * n_mlp_) ts.wgrad_slab.resize(rows * n_mlp_);
       ts.wgrad_slab.zero(s);
       ts.slab_key = key;
     }
   };
-  if (generic) {
-    // 3g. MLP backward, 4g. weight gradients (generic kernels)
-    GenericBackwardArgs ga;
-    ga.params = (const half_t*)params_f16_.ptr; ga.dy = (const half_t*)ts.dy.ptr; ga.acts = (const half_t*)ws_acts_.ptr;
-    ga.d_out = (half_t*)ts.d_all.ptr; ga.dfeat = (half_t*)ws_dfeat_.ptr; ga.n = n; ga.nh = nh; ga.activation = cfg_.activation;
-    ga.in_width = in_width_; ga.width = Wn;
-    generic_backward_kernel<<<std::min<uint32_t>(div_round_up(batch, 128), (uint32_t)Runtime::get().n_cus * 16u), 128, 0, s>>>(ga);
-    profile_mark(2, s);
-    GenericWGradArgs gw;
-    gw.features = (const half_t*)ws_features_.ptr; gw.acts = (const half_t*)ws_acts_.ptr; gw.d_all = (const half_t*)ts.d_all.ptr;
-    gw.dy = (const half_t*)ts.dy.ptr; gw.n = n; gw.nh = nh; gw.in_width = in_width_; gw.width = Wn; gw.n_mlp = (uint32_t)n_mlp_;
-    gw.chunk = 1024;
-    const uint32_t nchunks = div_round_up(batch, gw.chunk);
-    ensure_slab(nchunks);
-    gw.slab = ts.wgrad_slab.ptr;
-    const uint32_t n_elems = Wn * in_width_ + nh * Wn * Wn + Wn;
-    generic_wgrad_kernel<<<dim3(div_round_up(n_elems, 256), nchunks), 256, 0, s>>>(gw);
-    weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, s>>>(ts.wgrad_slab.ptr, nchunks, (uint32_t)n_mlp_, (half_t*)grads_.ptr);
-    VNR_HIP_CHECK(hipGetLastError());
-  } else {
+  {
   // 3. MLP backward (the transposed weight image was packed with the forward one when the parameters last changed)
   BackwardArgs ba;
   ba.packedT = (const half_t*)mlp_packed_T_.ptr; ba.dy = (const half_t*)ts.dy.ptr; ba.acts = (const half_t*)ws_acts_.ptr;
   ba.d_out = (half_t*)ts.d_all.ptr; ba.dfeat = (half_t*)ws_dfeat_.ptr;
   ba.n = n; ba.nh = nh; ba.activation = cfg_.activation; ba.in_width = in_width_; ba.lds_halves = lds_halves_T_;
+  const bool bwd_global = (size_t)lds_halves_T_ * 2 > kLdsBytes;   // 128 neurons, >= 6 hidden layers: the image stays in global memory (GENERAL instance)
+  ba.weights_global = bwd_global ? 1u : 0u;
   {
-    const size_t shmem = (size_t)lds_halves_T_ * 2;
+    const size_t shmem = bwd_global ? 16 : (size_t)lds_halves_T_ * 2;
     const uint32_t fit = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, kLdsBytes / shmem));
     const uint32_t blocks = std::min<uint32_t>(div_round_up(div_round_up(batch, 64), 4), (uint32_t)Runtime::get().n_cus * fit);
     const int mt = (int)((in_width_ + 31) / 32);
@@ -956,7 +854,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
       VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
       kernel<<<blocks, 256, shmem, s>>>(ba);
     };
-    const bool gen = cfg_.activation > 1u;
+    const bool gen = cfg_.activation > 1u || bwd_global;
 #define VNR_BWD_G(w, g) do { if (mt == 1) launch(mlp_backward_kernel<w, 1, g>); else if (mt == 2) launch(mlp_backward_kernel<w, 2, g>); \
                              else if (mt == 3) launch(mlp_backward_kernel<w, 3, g>); else launch(mlp_backward_kernel<w, 4, g>); } while (0)
 #define VNR_BWD(w) do { if (gen) VNR_BWD_G(w, true); else VNR_BWD_G(w, false); } while (0)

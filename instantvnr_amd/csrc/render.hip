@@ -1737,7 +1737,7 @@ bool Renderer::in_shader_applies() const
   const bool want = choice >= 0 ? choice == 1 : (mode_ == 14 || mode_ == 15);
   if (!want || !volume_->is_network()) return false;
   const Network& net = static_cast<NeuralVolume*>(volume_.get())->network();
-  if (!net.valid() || !net.fast_path() || !net.common_kind() || net.width() != (uint32_t)kWidth) return false;   // the in-shader kernels are 64-neuron instances of the common kind
+  if (!net.valid() || !net.common_kind() || net.width() != (uint32_t)kWidth) return false;   // the in-shader kernels are 64-neuron instances of the common kind
   const uint32_t F = net.config().n_features, K = net.padded_width();
 #define X(f, k) if (F == f && K == k) return true;
   VNR_IN_SHADER_SHAPES(X)

@@ -231,6 +231,10 @@ ACCEPTED = [
     (8, 2, 12, 4, None, 2, 64, "Linear", 0.0, None, {"grid_type": "Tiled"}),       # every level 4^3 entries, finer levels wrap (2 or 3 index dimensions)
     (6, 8, 12, 8, 1.5, 2, 128, "Nearest", 0.0, None, {"grid_type": "Tiled"}),
     (8, 1, 12, 5, None, 2, 16, "Linear", 0.0, None, {"grid_type": "Tiled"}),       # 5^3 = 125 entries: a modulus that is not a power of two
+    # weight images beyond the 160 KiB of LDS (5 hidden matmuls x 32 KB): the A operands come from global memory
+    (6, 2, 12, 4, None, 6, 128, "Linear", 0.0, None),
+    (8, 2, 12, 4, None, 7, 128, "Linear", 0.0, None, {"activation": "Sigmoid"}),
+    (8, 4, 12, 4, None, 2, 32, "Linear", 0.03, None, {"activation": "Squareplus"}),  # quantize_threshold with everything else GENERAL
 ]
 INTERP = {"Linear": 0, "Smoothstep": 1, "Nearest": 2}
 
@@ -238,8 +242,8 @@ INTERP = {"Linear": 0, "Smoothstep": 1, "Nearest": 2}
 @pytest.mark.parametrize("case", ACCEPTED)
 def test_models_the_reference_accepts_load_and_evaluate(oracle, case):
     """encode bit-exact, output within 2^-8 of the oracle, gradients within 3 % of the numpy restatement and 60 steps that converge, for
-    every FullyFusedMLP width, interpolation, activation, output activation and grid type the reference's dispatch accepts: all on the
-    MFMA kernels since round 4 (a quantize_threshold alone takes the generic kernels)."""
+    every FullyFusedMLP width, interpolation, activation, output activation and grid type the reference's dispatch accepts, incl.
+    quantize_threshold and 128-neuron models whose weight image exceeds the LDS: all on the MFMA kernels since round 4."""
     L, F, log2T, base, pls, H, W, interp, qt, max_level = case[:10]
     extra = case[10] if len(case) > 10 else {}
     act, out_act, gtype = extra.get("activation", "ReLU"), extra.get("output_activation", "None"), extra.get("grid_type", "Hash")
@@ -258,7 +262,7 @@ def test_models_the_reference_accepts_load_and_evaluate(oracle, case):
     vol = api.vnrCreateNeuralVolume(cfg, sv)
     info = api.neural_info(vol)
     assert info["n_neurons"] == W
-    assert bool(info["mfma_kernels"]) == (qt == 0.0)
+    assert info["mfma_kernels"] == 1 and info["mfma_training_kernels"] == 1     # since round 4 there is no other kind of kernel
     ocfg = oracle.grid_config(L, F, log2T, base, 2.0 if pls is None else pls, INTERP[interp], qt, 1000.0 if max_level is None else max_level, gtype)
     assert info["n_params"] == oracle.n_params(ocfg, W, H)
     n_mlp = oracle.mlp_n_params(info["padded_width"], W, H - 1)

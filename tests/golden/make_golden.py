@@ -7,10 +7,10 @@ What the fixtures are, and what they are not.  The reference has no tests or gol
  and cannot be built or run in this image (CUDA + OptiX + tiny-cuda-nn), so nothing below comes
 from the reference itself: PARITY VERSUS THE REFERENCE STAYS UNPINNED.  Two kinds of vectors are committed:
 
- * hand cases (`grid_hand_cases.npz`, `bson_params_like.*`): computed HERE by an independent pure-Python
+ * hand cases (`grid_hand_cases.npz`, `grid_hand_cases_r04.npz`, `bson_params_like.*`): computed HERE by an independent pure-Python
    restatement (dyadic inputs, exact arithmetic) or by an independent third-party encoder (pymongo's `bson`);
    the oracle and the HIP path are both checked against them;
- * frozen oracle outputs (`network_*.npz`, `c1_*.npz`, `dda_cases.npz`): produced by `oracle/` at the commit
+ * frozen oracle outputs (`network_*.npz`, `network_r04_*.npz`, `c1_*.npz`, `dda_cases.npz`): produced by `oracle/` at the commit
    that introduced them.  They anchor the HIP path on the GPU box (where /root/reference does not exist) and
    catch silent drift of the oracle itself.
 
@@ -252,7 +252,124 @@ def make_ooc():
                         random_head=r[:8])
 
 
+# --------------------------------------------------------------------------- (x) round 4: grid types, Nearest, widths, activations
+def hand_grid_index_typed(grid_type, size, res, g):
+    """EXTERNAL tcnn grid_index for any grid type ("Hash", "Dense", "Tiled"): only a Hash grid replaces the partial stride walk by the hash"""
+    stride, index = 1, 0
+    for d in range(3):
+        if stride <= size:
+            index += g[d] * stride
+            stride *= res
+    if grid_type == "Hash" and size < stride:
+        index = 0
+        for d in range(3):
+            index ^= (g[d] * PRIMES[d]) & 0xFFFFFFFF
+    return (index & 0xFFFFFFFF) % size
+
+
+def hand_level_size(grid_type, res, base, log2_T):
+    n = ((res ** 3 + 7) // 8) * 8
+    if grid_type == "Tiled":
+        n = min(n, base ** 3)
+    elif grid_type == "Hash":
+        n = min(n, 1 << log2_T)
+    return n
+
+
+def hand_encode_typed(grid_type, nearest, n_levels, F, log2_T, base, table, coords):
+    """the independent restatement above for any grid type and for Nearest (the lower corner's entry as it is, tcnn_impl_decoder.cu:73-94)"""
+    width = ((n_levels * F + 15) // 16) * 16
+    out = np.zeros((len(coords), width), dtype=np.float16)
+    offset = 0
+    for lvl in range(n_levels):
+        scale = float(2 ** lvl * base - 1)
+        res = int(np.ceil(scale)) + 1
+        size = hand_level_size(grid_type, res, base, log2_T)
+        for i, x in enumerate(coords):
+            pos = [float(x[d]) * scale + 0.5 for d in range(3)]
+            g = [int(np.floor(p)) for p in pos]
+            w = [p - np.floor(p) for p in pos]
+            if nearest:
+                e = hand_grid_index_typed(grid_type, size, res, g)
+                for f in range(F):
+                    out[i, lvl * F + f] = table[(offset + e) * F + f]
+                continue
+            acc = [np.float16(0)] * F
+            for corner in range(8):
+                weight, gl = 1.0, [0, 0, 0]
+                for d in range(3):
+                    if corner & (1 << d):
+                        weight *= w[d]; gl[d] = g[d] + 1
+                    else:
+                        weight *= 1.0 - w[d]; gl[d] = g[d]
+                e = hand_grid_index_typed(grid_type, size, res, gl)
+                for f in range(F):
+                    prod = np.float16(np.float32(weight) * np.float32(table[(offset + e) * F + f]))
+                    acc[f] = np.float16(np.float32(acc[f]) + np.float32(prod))
+            for f in range(F):
+                out[i, lvl * F + f] = acc[f]
+        offset += size
+    return out, offset
+
+
+def make_grid_hand_cases_r04():
+    """hand cases (independent pure-Python restatement, dyadic inputs) for what round 4 added to the encoding: Dense and Tiled grids
+    (L = 3, base 2: resolutions 2, 4, 8; Tiled caps every level at 2^3 = 8 entries, so levels 1 and 2 wrap over 2 / 1 index dimensions;
+    Dense keeps 8 + 64 + 512 entries) and Nearest on a Hash grid.  Index-ramp tables: a value says which entry was read."""
+    L, F, log2_T, base = 3, 2, 5, 2
+    k = np.array([[4, 4, 4], [2, 4, 4], [0, 0, 0], [8, 8, 8], [1, 3, 5], [7, 2, 6], [3, 3, 3], [5, 0, 8], [6, 7, 1]])
+    coords = (k / 8.0).astype(np.float32)
+    out = {"n_levels": L, "n_features": F, "log2_hashmap_size": log2_T, "base_resolution": base, "coords": coords}
+    for kind, gtype, nearest in (("dense", "Dense", False), ("tiled", "Tiled", False), ("hash_nearest", "Hash", True), ("tiled_nearest", "Tiled", True)):
+        n_entries = sum(hand_level_size(gtype, 2 ** l * base, base, log2_T) for l in range(L))
+        table = np.zeros(n_entries * F, dtype=np.float16)
+        e = np.arange(n_entries)
+        table[0::2] = (e % 512).astype(np.float16)          # feature 0 = entry index (exact in fp16 below 2048)
+        table[1::2] = (-0.125 * (e % 512)).astype(np.float16)
+        feats, total = hand_encode_typed(gtype, nearest, L, F, log2_T, base, table, coords)
+        assert total == n_entries
+        out[f"{kind}_table_f16_bits"] = table.view(np.uint16)
+        out[f"{kind}_features_f16_bits"] = feats.view(np.uint16)
+    np.savez(os.path.join(HERE, "grid_hand_cases_r04.npz"), **out)
+
+
+NETWORKS_R04 = {
+    # name: (L, F, log2T, base, pls, n_hidden_layers, n_neurons, interpolation, activation, output_activation, grid type, param seed, mlp_scale)
+    "W128_H2": (8, 2, 14, 8, 1.5, 2, 128, "Linear", "ReLU", "None", "Hash", 201, 1.0),
+    "W16_sigmoid_dense": (5, 4, 12, 4, 2.0, 3, 16, "Smoothstep", "Sigmoid", "None", "Dense", 202, 6.0),   # (larger weights: a sigmoid net with small ones is nearly constant)
+    "W32_tiled_nearest_squareplus_expout": (8, 2, 12, 4, 2.0, 2, 32, "Nearest", "Squareplus", "Exponential", "Tiled", 203, 2.0),
+}
+INTERP = {"Linear": 0, "Smoothstep": 1, "Nearest": 2}
+
+
+def make_networks_r04():
+    """frozen oracle outputs for the kinds of model round 4 put on the MFMA kernels"""
+    for name, (L, F, T, base, pls, H, W, interp, act, out_act, gtype, seed, mlp_scale) in NETWORKS_R04.items():
+        cfg = oracle.grid_config(L, F, T, base, per_level_scale=pls, interpolation=INTERP[interp], grid_type=gtype)
+        in_w = oracle.padded_width(cfg)
+        n_mlp = oracle.mlp_n_params(in_w, W, H - 1)
+        n_params = oracle.n_params(cfg, W, H)
+        params = syn.random_params(n_params, n_mlp, seed=seed, mlp_scale=mlp_scale)
+        coords = np.random.default_rng(seed + 1000).random((4096, 3), dtype=np.float32)
+        bits = params.view(np.uint16)
+        code = oracle.act_code(act, out_act)
+        out32 = oracle.network_inference(cfg, W, H, bits, coords, activation=code, acc_mode=0)
+        out16 = oracle.network_inference(cfg, W, H, bits, coords, activation=code, acc_mode=1)
+        feats = oracle.grid_encode(cfg, bits[n_mlp:], coords[:512])
+        np.savez_compressed(os.path.join(HERE, f"network_r04_{name}.npz"), n_levels=L, n_features=F, log2_hashmap_size=T,
+                            base_resolution=base, per_level_scale=pls, n_hidden_layers=H, n_neurons=W, interpolation=interp, activation=act,
+                            output_activation=out_act, grid_type=gtype, param_seed=seed, mlp_scale=mlp_scale,
+                            n_params=n_params, n_mlp_params=n_mlp, params_sha256=sha(params), coords=coords,
+                            out_acc_f32=out32, out_acc_f16=out16, features_f16_bits_first512=feats)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "r04":   # only what round 4 added (the older fixtures stay byte-identical)
+        make_grid_hand_cases_r04()
+        make_networks_r04()
+        sys.exit(0)
+    make_grid_hand_cases_r04()
+    make_networks_r04()
     make_c1_modes()
     make_ooc()
     make_grid_hand_cases()

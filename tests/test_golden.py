@@ -15,6 +15,9 @@ from instantvnr_amd import synthetic as syn
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NETWORKS = ["L8_F8_H2", "L16_F2_H3", "L16_F4_H3"]
+NETWORKS_R04 = ["W128_H2", "W16_sigmoid_dense", "W32_tiled_nearest_squareplus_expout"]   # round 4: widths, activations, grid types, Nearest
+HAND_R04 = [("dense", "Dense", "Linear"), ("tiled", "Tiled", "Linear"), ("hash_nearest", "Hash", "Nearest"), ("tiled_nearest", "Tiled", "Nearest")]
+INTERP = {"Linear": 0, "Smoothstep": 1, "Nearest": 2}
 TOL_NET = 2.0 ** -8   # fp16-accumulate vs fp32-accumulate MMA gap, absolute, per sample
 
 
@@ -69,6 +72,36 @@ def test_oracle_network_fixtures(oracle, name):
     gap = np.abs(out32 - out16)
     assert np.quantile(gap, 0.99) <= TOL_NET, np.quantile(gap, 0.99)
     assert np.std(out32) > 0.05   # the fixture is not degenerate
+
+
+@pytest.mark.parametrize("kind,gtype,interp", HAND_R04)
+def test_oracle_hand_grid_cases_r04(oracle, kind, gtype, interp):
+    """Dense / Tiled grids and Nearest against the independent pure-Python restatement of make_golden.py (dyadic inputs, index-ramp tables)"""
+    g = gold("grid_hand_cases_r04.npz")
+    cfg = oracle.grid_config(int(g["n_levels"]), int(g["n_features"]), int(g["log2_hashmap_size"]), int(g["base_resolution"]),
+                             interpolation=INTERP[interp], grid_type=gtype)
+    table = g[f"{kind}_table_f16_bits"]
+    assert oracle.grid_layout(cfg)["total_entries"] * int(g["n_features"]) == table.size
+    assert np.array_equal(oracle.grid_encode(cfg, table, g["coords"]), g[f"{kind}_features_f16_bits"])
+    if kind == "tiled_nearest":   # readable by eye: x = (.5,.5,.5), level 1 (scale 3, res 4, 8 entries): g = (2, 2, 2), walk x + 4 y (stride 16 > 8 stops) = 10 % 8 = 2, + offset 8
+        assert g[f"{kind}_features_f16_bits"].view(np.float16)[0, 2] == 10.0
+
+
+@pytest.mark.parametrize("name", NETWORKS_R04)
+def test_oracle_network_fixtures_r04(oracle, name):
+    g = gold(f"network_r04_{name}.npz")
+    p = syn.random_params(int(g["n_params"]), int(g["n_mlp_params"]), seed=int(g["param_seed"]), mlp_scale=float(g["mlp_scale"]))
+    assert sha(p) == str(g["params_sha256"])
+    W, H = int(g["n_neurons"]), int(g["n_hidden_layers"])
+    cfg = oracle.grid_config(int(g["n_levels"]), int(g["n_features"]), int(g["log2_hashmap_size"]), int(g["base_resolution"]),
+                             per_level_scale=float(g["per_level_scale"]), interpolation=INTERP[str(g["interpolation"])], grid_type=str(g["grid_type"]))
+    assert oracle.n_params(cfg, W, H) == int(g["n_params"])
+    code = oracle.act_code(str(g["activation"]), str(g["output_activation"]))
+    bits = p.view(np.uint16)
+    assert np.array_equal(oracle.network_inference(cfg, W, H, bits, g["coords"], activation=code, acc_mode=0), g["out_acc_f32"])
+    assert np.array_equal(oracle.network_inference(cfg, W, H, bits, g["coords"], activation=code, acc_mode=1), g["out_acc_f16"])
+    assert np.array_equal(oracle.grid_encode(cfg, bits[int(g["n_mlp_params"]):], g["coords"][:512]), g["features_f16_bits_first512"])
+    assert np.std(g["out_acc_f32"]) > 0.005 * max(1.0, float(np.abs(g["out_acc_f32"]).max()))   # not degenerate
 
 
 def test_bson_fixture_roundtrips_byte_exact():
@@ -164,6 +197,56 @@ def test_gpu_network_fixtures(name):
     assert err.max() <= TOL_NET, err.max()
     # and the HIP result sits no further from the fp32-accumulate result than the fp16-accumulate oracle does (x2)
     assert err.mean() <= 2 * np.abs(g["out_acc_f16"] - g["out_acc_f32"]).mean() + 1e-6
+
+
+def _r04_model(g, n_hidden_layers=None):
+    cfg = syn.model_config(n_levels=int(g["n_levels"]), n_features=int(g["n_features"]), log2_hashmap_size=int(g["log2_hashmap_size"]),
+                           base_resolution=int(g["base_resolution"]), n_hidden_layers=n_hidden_layers or int(g["n_hidden_layers"]),
+                           per_level_scale=float(g["per_level_scale"]) if "per_level_scale" in g else None)
+    return cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,gtype,interp", HAND_R04)
+def test_gpu_hand_grid_cases_r04(kind, gtype, interp):
+    from instantvnr_amd import api
+    g = gold("grid_hand_cases_r04.npz")
+    cfg = _r04_model(g, n_hidden_layers=1)
+    cfg["encoding"]["type"] = gtype
+    cfg["encoding"]["interpolation"] = interp
+    vol = api.vnrCreateNeuralVolume(cfg, (8, 8, 8))
+    info = api.neural_info(vol)
+    table = g[f"{kind}_table_f16_bits"].view(np.float16)
+    params = np.zeros(info["n_params"], dtype=np.float16)
+    params[info["n_params"] - table.size:] = table
+    api.neural_set_params_fp16(vol, params)
+    assert np.array_equal(api.neural_encode(vol, g["coords"]).view(np.uint16), g[f"{kind}_features_f16_bits"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NETWORKS_R04)
+def test_gpu_network_fixtures_r04(name):
+    """the kinds of model round 4 put on the MFMA kernels against frozen oracle outputs: no live oracle on this side"""
+    from instantvnr_amd import api
+    g = gold(f"network_r04_{name}.npz")
+    cfg = _r04_model(g)
+    cfg["encoding"]["type"] = str(g["grid_type"])
+    cfg["encoding"]["interpolation"] = str(g["interpolation"])
+    cfg["network"]["n_neurons"] = int(g["n_neurons"])
+    cfg["network"]["activation"] = str(g["activation"])
+    cfg["network"]["output_activation"] = str(g["output_activation"])
+    vol = api.vnrCreateNeuralVolume(cfg, (32, 32, 32))
+    assert api.neural_info(vol)["n_params"] == int(g["n_params"])
+    p = syn.random_params(int(g["n_params"]), int(g["n_mlp_params"]), seed=int(g["param_seed"]), mlp_scale=float(g["mlp_scale"]))
+    assert sha(p) == str(g["params_sha256"])
+    api.neural_set_params_fp16(vol, p)
+    feats = api.neural_encode(vol, g["coords"][:512])
+    assert np.array_equal(feats.view(np.uint16), g["features_f16_bits_first512"])   # bit-exact
+    out = api.neural_inference(vol, g["coords"])
+    scale = max(1.0, float(np.abs(g["out_acc_f32"]).max()))
+    err = np.abs(out - g["out_acc_f32"])
+    assert err.max() <= TOL_NET * scale, (err.max(), scale)
+    assert err.mean() <= 2 * np.abs(g["out_acc_f16"] - g["out_acc_f32"]).mean() + 1e-6 * scale
 
 
 @pytest.mark.gpu

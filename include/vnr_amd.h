@@ -222,7 +222,7 @@ int    vnrAmdNeuralVolumeGetInfo(vnrAmdVolume, int* n_levels, int* n_features_pe
 /* AMD extension (diagnostics): the rest of what tcnn_network.h:163-221 deserialize_model builds from the model JSON: hidden / output
  * activation (0 None, 1 ReLU, 2 Exponential, 3 Sigmoid, 4 Squareplus, 5 Softplus: the set tcnn_impl.cu:405-415 dispatches), grid type
  * (0 Hash, 1 Dense, 2 Tiled: tcnn_impl_decoder.cu:68-69), interpolation (0 Linear, 1 Smoothstep, 2 Nearest: :73-94), and whether the
- * model runs on the MFMA kernels (inference / training; 0: the generic one-lane-per-sample kernels, csrc/network_infer.hip) */
+ * model runs on the MFMA kernels (inference / training; always 1 since round 4: every model the reference's dispatch builds does) */
 int    vnrAmdNeuralVolumeGetModelKind(vnrAmdVolume, int* activation, int* output_activation, int* grid_type, int* interpolation,
                                       int* mfma_inference, int* mfma_training);
 /* raw tcnn-order parameter blob (MLP weights, then grid), fp16 */

@@ -539,7 +539,10 @@ bool Network::inference_queue(const float* d_records, float* d_out, uint32_t out
 
 FusedMlp Network::fused_mlp() const
 {
-  return FusedMlp{mlp_packed_.ptr, lds_halves_, cfg_.n_neurons, n_hidden_matmuls(), cfg_.activation, cfg_.output_activation, !common_kind(), !weights_in_lds(),
+  // diagnostics: VNR_AMD_WEIGHTS_GLOBAL=1 reads the A operands of every 128-neuron model from global memory (what models beyond the LDS always do)
+  static const bool force_global = [] { const char* e = std::getenv("VNR_AMD_WEIGHTS_GLOBAL"); return e && std::atoi(e) != 0; }();
+  const bool wglobal = !weights_in_lds() || (force_global && cfg_.n_neurons == 128u);
+  return FusedMlp{mlp_packed_.ptr, lds_halves_, cfg_.n_neurons, n_hidden_matmuls(), cfg_.activation, cfg_.output_activation, !common_kind() || wglobal, wglobal,
                   cfg_.quantize_threshold};
 }
 

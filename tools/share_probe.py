@@ -1,5 +1,6 @@
 """GPU box: how long one rank's share of the bench frame takes (interleaved 8-scanline blocks, part 0 of N) without the
 collective: the compute side of the N-GPU strong-scaling curve on one GPU.  usage: python tools/share_probe.py"""
+import os
 import sys
 import time
 import numpy as np
@@ -12,10 +13,11 @@ dims = (size,) * 3
 sv = api.vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=6.0)
 pls = float(np.exp(np.log(size / 16.0) / 15))
 cfg = syn.model_config(n_levels=16, n_features=2, log2_hashmap_size=22, n_hidden_layers=3, per_level_scale=pls)
+if os.environ.get("SHARE_NEURONS"):   # FullyFusedMLP width of the probe's model (default 64)
+    cfg["network"]["n_neurons"] = int(os.environ["SHARE_NEURONS"])
 nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
 api.vnrNeuralVolumeTrain(nv, 300, True)
 cam = syn.oblique_camera(dims, distance_scale=1.1)
-import os
 base = 0.0
 colors, alphas = syn.tfn_ramp_with_bumps(opacity_scale=0.06)
 import os

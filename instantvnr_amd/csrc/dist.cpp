@@ -714,6 +714,8 @@ std::string Dist::self_test(double deadline_s)
   hipStream_t s = comm_stream();
   const int W = world_, R = rank_;
   std::string report;
+  auto t_issue = std::chrono::steady_clock::now();   // set by begin() in front of every collective: the report times issue -> complete
+  auto begin = [&]() { t_issue = std::chrono::steady_clock::now(); };
   auto finish = [&](const char* what) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -726,8 +728,8 @@ std::string Dist::self_test(double deadline_s)
                                  std::to_string(R) + " of " + std::to_string(W) + " (transport " + tr.name() + ")");
       std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    report += std::string(what) + " ok (" + std::to_string(ms).substr(0, 6) + " ms to complete); ";
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_issue).count();
+    report += std::string(what) + " ok (" + std::to_string(ms).substr(0, 6) + " ms from issue to complete); ";
   };
   auto mismatch = [&](const char* what, size_t i, double got, double want) {
     throw std::runtime_error(std::string("[vnr dist] self-test: ") + what + " returned wrong data on rank " + std::to_string(R) + " of " + std::to_string(W) +
@@ -741,7 +743,7 @@ std::string Dist::self_test(double deadline_s)
     std::vector<float> host(n * (size_t)W, -1.0f);
     for (size_t i = 0; i < n; ++i) host[(size_t)R * n + i] = (float)((i * 31u + (size_t)R * 7u) % 65521u);
     VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
-    tr.all_gather(buf.ptr + (size_t)R * n, buf.ptr, n * sizeof(float), s);
+    begin(); tr.all_gather(buf.ptr + (size_t)R * n, buf.ptr, n * sizeof(float), s);
     finish("all-gather (in place, 2 MiB share)");
     VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, host.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (int q = 0; q < W; ++q)
@@ -763,15 +765,15 @@ std::string Dist::self_test(double deadline_s)
     for (size_t i = 0; i < len; ++i) host[i] = self_test_f16(val(R, i));
     VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), len * 2, hipMemcpyHostToDevice));
     if (per) {
-      tr.reduce_scatter(buf.ptr, per, DistDType::F16, DistOp::Avg, s);
+      begin(); tr.reduce_scatter(buf.ptr, per, DistDType::F16, DistOp::Avg, s);
       finish("reduce-scatter (Avg, fp16, slices of a range that divides nothing)");
     }
     if (rest < len) {
-      tr.all_reduce(buf.ptr + rest, len - rest, DistDType::F16, DistOp::Avg, s);
+      begin(); tr.all_reduce(buf.ptr + rest, len - rest, DistDType::F16, DistOp::Avg, s);
       finish("all-reduce (Avg, fp16) of the range's remainder");
     }
     if (per) {
-      tr.all_gather(buf.ptr + (size_t)R * per, buf.ptr, per * 2, s);
+      begin(); tr.all_gather(buf.ptr + (size_t)R * per, buf.ptr, per * 2, s);
       finish("all-gather of the reduced slices");
     }
     VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, len * 2, hipMemcpyDeviceToHost));
@@ -791,7 +793,7 @@ std::string Dist::self_test(double deadline_s)
     std::vector<uint8_t> host(n);
     for (size_t i = 0; i < n; ++i) host[i] = (uint8_t)(R == 0 ? (i * 13u + 5u) : 0xEE);
     VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), n, hipMemcpyHostToDevice));
-    tr.broadcast(buf.ptr, n, 0, s);
+    begin(); tr.broadcast(buf.ptr, n, 0, s);
     finish("broadcast (1 MiB + 3 bytes)");
     VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, n, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; ++i)
@@ -806,7 +808,7 @@ std::string Dist::self_test(double deadline_s)
     auto val = [](int q, size_t i) { return (uint32_t)((i * 3u + (size_t)q * 5u) % 16u); };
     for (size_t i = 0; i < n; ++i) host[i] = self_test_f16(val(R, i));
     VNR_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), n * 2, hipMemcpyHostToDevice));
-    tr.all_reduce(buf.ptr, n, DistDType::F16, DistOp::Sum, s);
+    begin(); tr.all_reduce(buf.ptr, n, DistDType::F16, DistOp::Sum, s);
     finish("all-reduce (Sum, fp16)");
     VNR_HIP_CHECK(hipMemcpy(host.data(), buf.ptr, n * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; ++i) {

@@ -144,6 +144,34 @@ def test_params_roundtrip_and_bson(oracle, tmp_path):
     assert doc["model"]["encoding"]["n_levels"] == 4
 
 
+def test_params_json_of_a_general_model_round_trips(oracle, tmp_path):
+    """a params.json written for a model outside the common kind (32 neurons, Squareplus, Sigmoid output, Tiled grid, Nearest) carries its
+    model JSON (network.cu:827-857 stores what tcnn_network.h:172-174 kept) and comes back as the same network: same kind, same bits"""
+    cfg = syn.model_config(n_levels=6, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=3)
+    cfg["network"].update({"n_neurons": 32, "activation": "Squareplus", "output_activation": "Sigmoid"})
+    cfg["encoding"].update({"type": "Tiled", "interpolation": "Nearest"})
+    vol = api.vnrCreateNeuralVolume(cfg, (32, 32, 32))
+    info = api.neural_info(vol)
+    n_mlp = oracle.mlp_n_params(info["padded_width"], 32, 2)
+    params = syn.random_params(info["n_params"], n_mlp, seed=17)
+    api.neural_set_params_fp16(vol, params)
+    path = str(tmp_path / "params.json")
+    api.vnrNeuralVolumeSerializeParams(vol, path)
+    vol2 = api.vnrCreateNeuralVolume(path)
+    info2 = api.neural_info(vol2)
+    for k in ("n_neurons", "n_hidden_layers", "activation", "output_activation", "grid_type", "interpolation", "n_params"):
+        assert info2[k] == info[k], k
+    assert (info2["activation"], info2["output_activation"], info2["grid_type"], info2["interpolation"]) == (4, 3, 2, 2)
+    coords = coords_for(777, 18)
+    assert np.array_equal(api.neural_inference(vol, coords).view(np.uint32), api.neural_inference(vol2, coords).view(np.uint32))
+    bson = pytest.importorskip("bson")
+    doc = bson.decode(open(path, "rb").read())
+    assert doc["model"]["network"]["activation"] == "Squareplus" and doc["model"]["encoding"]["type"] == "Tiled"
+    ocfg = oracle.grid_config(6, 2, 12, 4, interpolation=2, grid_type="Tiled")
+    want = oracle.network_inference(ocfg, 32, 3, params.view(np.uint16), coords, activation=oracle.act_code("Squareplus", "Sigmoid"))
+    assert np.abs(api.neural_inference(vol2, coords) - want).max() <= TOL_ABS
+
+
 @pytest.mark.parametrize("cfg", [(10, 2, 12, 8, 1.5, 2), (6, 8, 10, 4, None, 2), (7, 4, 11, 4, 1.6, 3), (9, 1, 12, 4, 1.5, 2)])
 def test_brick_image_is_lazy_exact_and_dropped_when_parameters_change(oracle, cfg):
     """the de-hashed inference copy of the hashed levels (csrc/network.h) is a cache: built once the parameters have been

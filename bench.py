@@ -501,6 +501,16 @@ def main():
                              "msamples_per_s": round(ev / (alone["ms"] * 1e-3) / 1e6, 1), "frames": alone["frames"],
                              "fps_one_stream": alone["fps"],
                              "mfma_tflops": round(ev * flops_per_sample / (alone["ms"] * 1e-3) / 1e12, 2)}
+    # the matrix cores' share of the kernel (north star: "MFMA utilisation on the MLP against the chip's peaks"): flops of this run's samples over
+    # the union time, against the dense fp16 peak; the counter-based figure comes from a separate rocprofv3 --pmc pass (tools/r04_mfma_pmc.sh)
+    MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense fp16 / bf16
+    if union_ms > 0:
+        tf = samples_evt * flops_per_sample / (union_ms * 1e-3) / 1e12
+        roofline["mfma"] = {"tflops": round(tf, 1), "peak_tflops": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                            "what": "the MLP's flops (20 608 per sample for 3x64 on a 32-wide encoding) over the union of the launch intervals; the kernel is bound by "
+                                    "its hash-grid gathers, the one dense contraction on the path is a tenth of it",
+                            "util_by_counters": 0.1065 if (a.levels, a.features, a.hidden_layers) == (16, 2, 3) else None,
+                            "util_source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), separate rocprofv3 --pmc pass: profiles/r04_mfma_pmc_digest.txt"}
     roofline["concurrency"] = (f"{halves} ray halves on {halves} HIP streams; launch durations are per stream and overlap"
                                if halves == 2 else "1 stream: launches run alone")
     frame_gbs = (samples / a.steps) * bytes_per_sample / (elapsed / a.steps) / 1e9

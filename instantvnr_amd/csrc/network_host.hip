@@ -210,7 +210,11 @@ void Network::build_layout()
 {
   const uint32_t total_entries = grid_make_layout(cfg_, &grid_);
   in_width_ = next_multiple(cfg_.n_levels * cfg_.n_features, 16u);
-  if (in_width_ > 128) throw std::runtime_error("encoded width > 128 is not supported");
+  // the instances of the fused kernel (infer_kernel.h dispatch): refuse the others here, at SetModel, not at the first launch
+  const uint32_t widest = cfg_.n_features == 1 ? 32u : cfg_.n_features == 8 ? 128u : 64u;
+  if (in_width_ > widest)
+    throw std::runtime_error("unsupported encoding shape: n_features_per_level=" + std::to_string(cfg_.n_features) + " with n_levels=" +
+                             std::to_string(cfg_.n_levels) + " (encoded width " + std::to_string(in_width_) + " > " + std::to_string(widest) + ")");
   const size_t W = cfg_.n_neurons;
   n_mlp_ = W * in_width_ + (size_t)n_hidden_matmuls() * W * W + (size_t)16 * W;
   n_params_ = n_mlp_ + (size_t)total_entries * cfg_.n_features;

@@ -1,0 +1,337 @@
+"""GPU parity on randomly drawn models: the hand-picked rows of tests/test_gpu_network.py::ACCEPTED cover every axis of the reference's
+dispatch once; this file draws whole model descriptions at random (seeded) from the same space -- level count, features per level, table
+size, base resolution, growth, interpolation, grid type, quantize_threshold, max_level, width, depth, activation, output activation --
+and holds each draw to the same bars: encode bit-exact, network output within 2^-8 of the oracle, gradients within 3 % of the numpy
+restatement.  VNR_FUZZ_DRAWS / VNR_FUZZ_SEED widen the sweep from a shell (tools/r04_fuzz.sh).
+
+Deep networks with growing activations (six hidden layers of Exponential at 128 neurons ...) are legal and numerically poor: the fp16
+rounding of the activations alone moves their output by more than 2^-8.  Where that is so the bar is the oracle's OWN distance from an fp64
+evaluation of the same fp16 parameters (fp64_network below): the HIP path may be as far from the oracle as the oracle is from the unrounded
+network (twice that, for the maximum over samples or entries), never farther.  The first sweeps of 3000 + 2500 draws
+(profiles/r04_fuzz.txt) found fourteen draws past the fixed bars, every one of this kind (one sample of 1025) or sitting on a discontinuity of
+the FUNCTION: an output on its L1 target (the gradient is a sign), or a ReLU unit whose fp32 sum is within rounding of zero (the mask follows
+the order of the sum).  Targets and training coordinates are therefore drawn away from both (away_from_relu_kinks)."""
+import os
+
+import numpy as np
+import pytest
+
+from instantvnr_amd import api
+from instantvnr_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+TOL_ABS = 2.0 ** -8
+INTERP = {"Linear": 0, "Smoothstep": 1, "Nearest": 2}
+MAX_LEVELS = {1: 32, 2: 32, 4: 16, 8: 16}          # the padded encoded widths the kernels are instantiated for (infer_kernel.h dispatch)
+
+
+def _act64(x, a, oracle):
+    a = oracle.ACTIVATIONS.get(a, a)
+    with np.errstate(over="ignore", invalid="ignore"):
+        if a == 0: return x
+        if a == 1: return np.maximum(x, 0)
+        if a == 2: return np.exp(x)
+        if a == 3: return 1 / (1 + np.exp(-x))
+        if a == 4: t = 10 * x; return 0.5 * (t + np.sqrt(t * t + 4)) / 10
+        if a == 5: return np.logaddexp(0, 10 * x) / 10
+    raise ValueError(a)
+
+
+def _dact64(x, y, a, oracle):
+    a = oracle.ACTIVATIONS.get(a, a)
+    with np.errstate(over="ignore", invalid="ignore"):
+        if a == 0: return np.ones_like(x)
+        if a == 1: return (x > 0).astype(np.float64)
+        if a == 2: return y
+        if a == 3: return y * (1 - y)
+        if a == 4: t = 10 * x; return 0.5 * (1 + t / np.sqrt(t * t + 4))
+        if a == 5: return 1 / (1 + np.exp(-10 * x))
+    raise ValueError(a)
+
+
+def away_from_relu_kinks(oracle, ocfg, W, H, params, n_mlp, coords, act, out_act, margin=1e-5):
+    """mask of the samples none of whose ReLU units sums to (nearly) zero: a pre-activation within fp32 rounding of zero gets its sign,
+    hence its backward mask, from the ORDER of the fp32 sum, which the MFMA and the oracle's loop do not share (found by the first
+    sweeps: tests/diag/fuzz_diag.py shows |sum| / sum|terms| of 3e-9 and 4e-7 on the samples behind the two draws that failed).  Like
+    the L1 sign this is a discontinuity of the function, not of an implementation; gradient checks stay away from it."""
+    from oracle import train_oracle as T
+    relu = oracle.ACTIVATIONS["ReLU"]
+    a, oa = oracle.ACTIVATIONS.get(act, act), oracle.ACTIVATIONS.get(out_act, out_act)
+    keep = np.ones(coords.shape[0], bool)
+    if a != relu and oa != relu:
+        return keep
+    in_w = oracle.padded_width(ocfg)
+    w1, wh, wl, _ = T.split_mlp(params, in_w, W, H - 1)
+    feat = oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords)
+    _, acts = oracle.mlp_forward(params[:n_mlp].view(np.uint16), in_w, W, H - 1, feat, activation=oracle.act_code(act, out_act),
+                                 want_activations=True)
+    acts = acts.view(np.float16).astype(np.float64)
+    ins = [feat.view(np.float16).astype(np.float64)] + [acts[j] for j in range(H - 1)]
+    mats = [w1.astype(np.float64)] + [m.astype(np.float64) for m in wh]
+    if a == relu:
+        for x, m in zip(ins, mats):
+            sums, terms = np.abs(x @ m.T), np.abs(x) @ np.abs(m).T
+            keep &= ((sums > margin * terms) | (terms == 0)).all(axis=1)      # (all terms zero: zero in any order)
+    if oa == relu:
+        x, m = acts[H - 1], wl[0].astype(np.float64)
+        sums, terms = np.abs(x @ m), np.abs(x) @ np.abs(m)
+        keep &= (sums > margin * terms) | (terms == 0)
+    return keep
+
+
+def fp64_network(oracle, ocfg, W, H, params, coords, act, out_act, targets=None):
+    """the network on the same fp16 parameters and the oracle's (bit-exact) encode, in fp64 without any rounding of activations or
+    gradients: the yardstick for how much of a difference is fp16 noise.  Returns the outputs and, with targets, the loss-scaled L1
+    gradients of all parameters."""
+    from oracle import train_oracle as T
+    in_w = oracle.padded_width(ocfg)
+    w1, wh, wl, n_mlp = T.split_mlp(params, in_w, W, H - 1)
+    w1, wh, wl0 = w1.astype(np.float64), [m.astype(np.float64) for m in wh], wl[0].astype(np.float64)
+    feat = oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords).view(np.float16).astype(np.float64)
+    pre = [feat @ w1.T]; post = [_act64(pre[0], act, oracle)]
+    for m in wh:
+        pre.append(post[-1] @ m.T); post.append(_act64(pre[-1], act, oracle))
+    z = post[-1] @ wl0
+    y = _act64(z, out_act, oracle)
+    if targets is None:
+        return y
+    B = coords.shape[0]
+    F = ocfg.n_features
+    g = np.zeros(params.size)
+    with np.errstate(over="ignore", invalid="ignore"):
+        dy = T.LOSS_SCALE * np.sign(y - targets) / B * _dact64(z, y, out_act, oracle)
+        off = W * in_w + len(wh) * W * W
+        g[off:off + W] = dy @ post[-1]
+        d = dy[:, None] * wl0[None, :] * _dact64(pre[-1], post[-1], act, oracle)
+        for l in range(len(wh) - 1, -1, -1):
+            o_l = W * in_w + l * W * W
+            g[o_l:o_l + W * W] = (d.T @ post[l]).ravel()
+            d = (d @ wh[l]) * _dact64(pre[l], post[l], act, oracle)
+        g[0:W * in_w] = (d.T @ feat).ravel()
+        dfeat = d @ w1
+    lay = oracle.grid_layout(ocfg)
+    for l, (idxs, ws) in enumerate(T.corner_indices_and_weights(ocfg, lay, coords)):
+        base = n_mlp + int(lay["offsets"][l]) * F
+        for f in range(F):
+            np.add.at(g, base + idxs.ravel() * F + f, (ws.astype(np.float64) * dfeat[:, l * F + f][:, None]).ravel())
+    return y, g
+
+
+def draw(rng):
+    F = int(rng.choice([1, 2, 4, 8]))
+    gtype = str(rng.choice(["Hash", "Hash", "Hash", "Dense", "Tiled"]))
+    base = int(rng.integers(2, 10))
+    if gtype == "Dense":                              # every level is stored whole: keep the finest one at <= 48^3 entries
+        L = int(rng.integers(1, 6))
+        pls = float(rng.choice([1.25, 1.5, 2.0]))
+        while L > 1 and base * pls ** (L - 1) > 48:
+            L -= 1
+    else:
+        L = int(rng.integers(1, MAX_LEVELS[F] + 1))
+        # finest resolution <= 2^16: positions stay far inside the range where float -> uint conversions are defined
+        hi = (65536.0 / base) ** (1.0 / max(1, L - 1))
+        pls = float(min(2.0, rng.choice([1.2, 1.3195, 1.5, 1.75, 2.0]), hi))
+    log2T = int(rng.integers(8, 15))
+    W = int(rng.choice([16, 32, 64, 128]))
+    H = int(rng.integers(1, 5)) if W < 128 else int(rng.integers(1, 7))
+    interp = str(rng.choice(["Linear", "Linear", "Smoothstep", "Nearest"]))
+    act = str(rng.choice(["ReLU", "ReLU", "ReLU", "None", "Sigmoid", "Squareplus", "Softplus", "Exponential"]))
+    out_act = str(rng.choice(["None", "None", "None", "ReLU", "Sigmoid", "Exponential", "Squareplus", "Softplus"]))
+    qt = float(rng.choice([0.0, 0.0, 0.02, 0.05]))
+    max_level = None if rng.uniform() < 0.7 else float(np.round(rng.uniform(0.0, L), 2))
+    return dict(L=L, F=F, log2T=log2T, base=base, pls=pls, H=H, W=W, interp=interp, act=act, out_act=out_act, gtype=gtype, qt=qt,
+                max_level=max_level)
+
+
+def check(oracle, d, seed):
+    """returns the list of checks that could not be made on this draw (vacuous: non-finite or all-zero expectations)"""
+    from oracle import train_oracle as T
+    L, F, W, H = d["L"], d["F"], d["W"], d["H"]
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=d["log2T"], base_resolution=d["base"], n_hidden_layers=H,
+                           per_level_scale=d["pls"])
+    cfg["encoding"]["interpolation"] = d["interp"]
+    cfg["network"]["n_neurons"] = W
+    cfg["network"]["activation"] = d["act"]
+    cfg["network"]["output_activation"] = d["out_act"]
+    if d["gtype"] != "Hash":
+        cfg["encoding"]["type"] = d["gtype"]
+    if d["qt"]:
+        cfg["encoding"]["quantize_threshold"] = d["qt"]
+    if d["max_level"] is not None:
+        cfg["encoding"]["max_level"] = d["max_level"]
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(16))
+    vol = api.vnrCreateNeuralVolume(cfg, sv)
+    info = api.neural_info(vol)
+    ocfg = oracle.grid_config(L, F, d["log2T"], d["base"], d["pls"], INTERP[d["interp"]], d["qt"],
+                              1000.0 if d["max_level"] is None else d["max_level"], d["gtype"])
+    assert info["n_params"] == oracle.n_params(ocfg, W, H), "n_params"
+    assert info["padded_width"] == oracle.padded_width(ocfg), "padded width"
+    assert info["mfma_kernels"] == 1 and info["mfma_training_kernels"] == 1
+    n_mlp = oracle.mlp_n_params(info["padded_width"], W, H - 1)
+    grows = d["act"] in ("Exponential", "Softplus") or d["out_act"] == "Exponential"
+    params = syn.random_params(info["n_params"], n_mlp, seed=seed, mlp_scale=(0.35 if grows else 1.0) * (0.7 if H > 3 else 1.0))
+    api.neural_set_params_fp16(vol, params)
+    rng = np.random.default_rng(seed + 1)
+    coords = rng.uniform(0, 1, (1025, 3)).astype(np.float32)
+    coords[0] = (0, 0, 0); coords[1] = (1, 1, 1); coords[2] = (0.5, 0.5, 0.5); coords[3] = (1, 0, 0.999999)
+    vacuous = []
+    enc = api.neural_encode(vol, coords)
+    want_enc = oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords)
+    assert np.array_equal(enc.view(np.uint16), want_enc), "encode"
+    got = api.neural_inference(vol, coords)
+    code = oracle.act_code(d["act"], d["out_act"])
+    want = oracle.network_inference(ocfg, W, H, params.view(np.uint16), coords, activation=code)
+    if not np.isfinite(want).all() or np.abs(want).max() > 6.0e4:
+        vacuous.append("inference")
+    else:
+        assert np.isfinite(got).all(), "inference finite"
+        err = np.abs(got - want).max()
+        exact = fp64_network(oracle, ocfg, W, H, params, coords, d["act"], d["out_act"])
+        noise = float(np.abs(want - exact).max())            # what fp16 activations cost this model on these samples
+        assert err <= max(TOL_ABS * max(1.0, np.abs(want).max()), 2 * noise), ("inference", err, np.abs(want).max(), noise)
+    B = 320
+    tc = rng.uniform(0, 1, (2 * B, 3)).astype(np.float32)
+    tc = tc[away_from_relu_kinks(oracle, ocfg, W, H, params, n_mlp, tc, d["act"], d["out_act"])][:B]
+    B = tc.shape[0]
+    if B < 64:                                      # (a network whose output is a cancellation everywhere)
+        return vacuous + ["gradients: every sample on a kink"]
+    # targets at least 0.05 from the network's outputs: the L1 gradient is a sign, and a sample whose output sits on its target flips it
+    y_tc = oracle.network_inference(ocfg, W, H, params.view(np.uint16), tc, activation=code)
+    y_tc = np.where(np.isfinite(y_tc), y_tc, 0).astype(np.float32)
+    tt = (y_tc + rng.choice([-1.0, 1.0], B) * rng.uniform(0.05, 0.6, B)).astype(np.float32)
+    grads = api.neural_forward_backward(vol, tc, tt).astype(np.float64)
+    ref = T.training_gradients(ocfg, W, H, params.view(np.uint16), tc, tt, loss="L1", activation=d["act"], output_activation=d["out_act"])
+    w_all = ref["grads"]
+    if "inference" in vacuous or not np.isfinite(w_all).all() or np.abs(w_all).max() > 3.0e4:
+        vacuous.append("gradients")
+    else:
+        y64, x_all = fp64_network(oracle, ocfg, W, H, params, tc, d["act"], d["out_act"], targets=tt)
+        y_noise = float(np.abs(ref["y"] - y64).mean()) if np.isfinite(y64).all() else 0.0      # the L1 loss is a mean of |y - t|
+        assert np.isclose(api.vnrNeuralVolumeGetTrainingLoss(vol), ref["loss"], rtol=2e-3, atol=1e-5 + 2 * y_noise), ("loss", y_noise)
+        assert np.isfinite(grads).all(), "gradients finite"
+        for name, sl in [("mlp", slice(0, n_mlp)), ("grid", slice(n_mlp, None))]:
+            g, w, x = grads[sl], w_all[sl], x_all[sl]
+            if np.abs(w).max() < 1e-3:      # a saturated output activation or a mask over every level: nothing to compare against
+                vacuous.append("gradients " + name)
+                assert np.abs(g).max() < 1e-2, name
+                continue
+            # the restatement's own distance from the unrounded gradients (fp16 activations and fp16 gradient chain of a deep network)
+            noise_rel = np.linalg.norm(w - x) / np.linalg.norm(w) if np.isfinite(x).all() else 0.0
+            noise_abs = np.abs(w - x).max() if np.isfinite(x).all() else 0.0
+            rel = np.linalg.norm(g - w) / np.linalg.norm(w)
+            assert rel < max(3e-2, noise_rel), (name, rel, noise_rel)
+            assert np.abs(g - w).max() < max(6e-2 * np.abs(w).max(), 2 * noise_abs), (name, np.abs(g - w).max(), np.abs(w).max(), noise_abs)
+        last = grads[n_mlp - 16 * W:n_mlp].reshape(16, W)
+        assert np.all(last[1:] == 0), "padded rows of the last layer"
+    api.neural_train_end(vol)
+    api.vnrNeuralVolumeTrain(vol, 3, True)
+    return vacuous
+
+
+def test_randomly_drawn_models_equal_the_oracle(oracle):
+    n = int(os.environ.get("VNR_FUZZ_DRAWS", "40"))
+    seed0 = int(os.environ.get("VNR_FUZZ_SEED", "20260410"))
+    rng = np.random.default_rng(seed0)
+    failures, vacuous_draws = [], 0
+    for i in range(n):
+        d = draw(rng)
+        try:
+            v = check(oracle, d, seed0 % 1000 + i)
+            vacuous_draws += bool(v)
+        except Exception as e:  # collect every failing draw of the sweep, then fail once with all of them
+            failures.append((i, d, repr(e)[:300]))
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"{i} {d} {'FAIL ' + failures[-1][2] if failures and failures[-1][0] == i else ('vacuous ' + str(v) if v else 'ok')}\n")
+    assert not failures, failures
+    assert vacuous_draws <= n // 3, vacuous_draws
+
+
+# ------------------------------------------------------------------------------------------------ the same, behind the renderer
+def draw_scene(rng):
+    d = draw(rng)
+    # a frame through the oracle costs a network evaluation per sample on the host: small grids, shallow networks
+    d["L"] = min(d["L"], 6); d["log2T"] = min(d["log2T"], 12); d["H"] = min(d["H"], 3)
+    if d["gtype"] == "Dense":
+        d["L"] = min(d["L"], 3)
+    d["max_level"] = None if d["max_level"] is None else min(d["max_level"], float(d["L"]))
+    if d["act"] in ("Exponential", "Softplus"):
+        d["act"] = "ReLU"
+    if d["out_act"] in ("Exponential", "Softplus", "Squareplus"):      # values far outside the transfer function's range: nothing to see
+        d["out_act"] = "None"
+    v = rng.normal(size=3); v /= np.linalg.norm(v)
+    if abs(v[1]) > 0.95:                                               # not along the up vector
+        v = np.array([0.6, 0.5, -0.62]); v /= np.linalg.norm(v)
+    d.update(mode=int(rng.choice([5, 5, 8])), size=(int(rng.integers(17, 141)), int(rng.integers(9, 101))),
+             cam_from=tuple(float(x) for x in v * 32 * rng.uniform(1.1, 2.6)), fovy=float(rng.uniform(25, 70)),
+             sampling_rate=float(rng.choice([0.5, 1.0, 1.0, 2.0])), density_scale=float(rng.choice([1.0, 1.0, 0.5, 3.0])))
+    return d
+
+
+def check_frame(oracle, d, seed):
+    L, F, W, H = d["L"], d["F"], d["W"], d["H"]
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=d["log2T"], base_resolution=d["base"], n_hidden_layers=H,
+                           per_level_scale=d["pls"])
+    cfg["encoding"]["interpolation"] = d["interp"]
+    cfg["network"]["n_neurons"] = W
+    cfg["network"]["activation"] = d["act"]
+    cfg["network"]["output_activation"] = d["out_act"]
+    if d["gtype"] != "Hash":
+        cfg["encoding"]["type"] = d["gtype"]
+    if d["qt"]:
+        cfg["encoding"]["quantize_threshold"] = d["qt"]
+    if d["max_level"] is not None:
+        cfg["encoding"]["max_level"] = d["max_level"]
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+    info = api.neural_info(nv)
+    n_mlp = oracle.mlp_n_params(info["padded_width"], W, H - 1)
+    params = syn.random_params(info["n_params"], n_mlp, seed=seed)
+    api.neural_set_params_fp16(nv, params)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas); api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, d["cam_from"], (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), d["fovy"])
+    ren = api.vnrCreateRenderer(nv)
+    api.vnrRendererSetTransferFunction(ren, tfn); api.vnrRendererSetCamera(ren, camera); api.vnrRendererSetFramebufferSize(ren, d["size"])
+    api.vnrRendererSetMode(ren, d["mode"])
+    api.vnrRendererSetVolumeSamplingRate(ren, d["sampling_rate"])
+    api.vnrRendererSetVolumeDensityScale(ren, d["density_scale"])
+    api.vnrRender(ren)
+    img = api.vnrRendererMapFrame(ren).copy()
+    ocfg = oracle.grid_config(L, F, d["log2T"], d["base"], d["pls"], INTERP[d["interp"]], d["qt"],
+                              1000.0 if d["max_level"] is None else d["max_level"], d["gtype"])
+    mo = api.volume_macrocell(nv)["max_opacity"]
+    code = oracle.act_code(d["act"], d["out_act"])
+    net = lambda c: oracle.network_inference(ocfg, W, H, params.view(np.uint16), c, activation=code)   # noqa: E731
+    sc = oracle.SceneHolder(d["size"][0], d["size"][1], (32, 32, 32), oracle.TfnHolder(colors, alphas), mo, d["cam_from"], (0, 0, 0), (0, 1, 0),
+                            d["fovy"], sampling_rate=d["sampling_rate"], density_scale=d["density_scale"], shading_mode=1 if d["mode"] == 8 else 0)
+    ref, _, _ = oracle.render_streaming(sc, net)
+    assert img.shape == ref.shape, (img.shape, ref.shape)
+    assert np.isfinite(img).all(), "frame finite"
+    mse = float(((img - ref) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    assert psnr > 40.0, ("psnr", psnr)
+    return [] if ref[..., 3].max() > 0.002 else ["nothing visible"]
+
+
+def test_randomly_drawn_models_render_like_the_oracle(oracle):
+    n = int(os.environ.get("VNR_FUZZ_FRAMES", "12"))
+    seed0 = int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 17
+    rng = np.random.default_rng(seed0)
+    failures, vacuous_draws = [], 0
+    for i in range(n):
+        d = draw_scene(rng)
+        v = None
+        try:
+            v = check_frame(oracle, d, seed0 % 1000 + i)
+            vacuous_draws += bool(v)
+        except Exception as e:
+            failures.append((i, d, repr(e)[:300]))
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"frame {i} {d} {'FAIL ' + failures[-1][2] if v is None else ('vacuous ' + str(v) if v else 'ok')}\n")
+    assert not failures, failures
+    assert vacuous_draws <= n // 2, vacuous_draws

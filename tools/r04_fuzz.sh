@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU box: the randomly drawn model sweep of tests/test_gpu_fuzz.py at a wider count.  usage: r04_fuzz.sh <tag> <draws> <seed> [frames]
+set -o pipefail
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+tag=${1:-a}; draws=${2:-300}; seed=${3:-7}; frames=${4:-24}
+mkdir -p gpurun_out/r04_fuzz
+export VNR_FUZZ_FRAMES=$frames VNR_FUZZ_DRAWS=$draws VNR_FUZZ_SEED=$seed VNR_FUZZ_LOG=gpurun_out/r04_fuzz/draws_$tag.log
+rm -f "$VNR_FUZZ_LOG"
+timeout -k 10 1000 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q > gpurun_out/r04_fuzz/pytest_$tag.log 2>&1
+rc=$?
+echo "pytest rc=$rc"
+tail -5 gpurun_out/r04_fuzz/pytest_$tag.log | cut -c1-2000
+grep -c " ok$" "$VNR_FUZZ_LOG"; grep -c vacuous "$VNR_FUZZ_LOG"; grep -c FAIL "$VNR_FUZZ_LOG"
+exit $rc

@@ -335,3 +335,147 @@ def test_randomly_drawn_models_render_like_the_oracle(oracle):
                 f.write(f"frame {i} {d} {'FAIL ' + failures[-1][2] if v is None else ('vacuous ' + str(v) if v else 'ok')}\n")
     assert not failures, failures
     assert vacuous_draws <= n // 2, vacuous_draws
+
+
+# ------------------------------------------------------------------------------------------------ in-shader kernels against the streaming path
+def test_randomly_drawn_models_render_alike_through_the_in_shader_and_the_streaming_kernels(oracle):
+    """rendering modes 6 / 9 / 12 / 14 / 15 on a neural volume have two implementations (in_shader.h: one launch with the network inside the
+    marching loop; the streaming path: march / evaluate / compose per iteration).  On random 64-neuron models of the common kind -- the
+    shapes the in-shader kernels are instantiated for; the others take the streaming path either way -- the network values are the same
+    bits, so ray marching differs only by the streaming path's resume rounding (PSNR > 70 dB) and path tracing not at all."""
+    from instantvnr_amd._lib import check, lib
+    n = int(os.environ.get("VNR_FUZZ_IN_SHADER", "16"))
+    rng = np.random.default_rng(int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 31)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    failures = []
+    for i in range(n):
+        F = int(rng.choice([1, 2, 4, 8]))
+        L = int(rng.integers(2, min(MAX_LEVELS[F], 12) + 1))
+        base = int(rng.integers(2, 9))
+        pls = float(min(2.0, rng.choice([1.3195, 1.5, 2.0]), (4096.0 / base) ** (1.0 / max(1, L - 1))))
+        H = int(rng.integers(1, 5))
+        interp = str(rng.choice(["Linear", "Smoothstep"]))
+        mode = int(rng.choice([6, 9, 12, 14, 15]))
+        size = (int(rng.integers(17, 200)), int(rng.integers(9, 130)))
+        d = dict(i=i, L=L, F=F, base=base, pls=pls, H=H, interp=interp, mode=mode, size=size)
+        try:
+            cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=int(rng.integers(9, 16)), base_resolution=base, n_hidden_layers=H,
+                                   per_level_scale=pls)
+            cfg["encoding"]["interpolation"] = interp
+            sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))
+            nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+            info = api.neural_info(nv)
+            api.neural_set_params_fp16(nv, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], 64, H - 1), seed=100 + i))
+            tfn = api.vnrCreateTransferFunction()
+            api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas); api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+            v = rng.normal(size=3); v /= np.linalg.norm(v)
+            if abs(v[1]) > 0.95:
+                v = np.array([0.6, 0.5, -0.62]); v /= np.linalg.norm(v)
+            camera = api.vnrCreateCamera()
+            api.vnrCameraSet(camera, tuple(float(x) for x in v * 32 * rng.uniform(1.1, 2.6)), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), float(rng.uniform(25, 70)))
+            rate, density = float(rng.choice([0.5, 1.0, 2.0])), float(rng.choice([0.5, 1.0, 3.0]))
+            frames, hits = {}, {}
+            for kernel in (1, 0):
+                r = api.vnrCreateRenderer(nv)
+                api.vnrRendererSetTransferFunction(r, tfn); api.vnrRendererSetCamera(r, camera); api.vnrRendererSetFramebufferSize(r, size)
+                api.vnrRendererSetMode(r, mode)
+                api.vnrRendererSetVolumeSamplingRate(r, rate); api.vnrRendererSetVolumeDensityScale(r, density)
+                check(lib().vnrAmdRendererSetInShaderKernel(r.h, kernel))
+                acc = []
+                for _ in range(2):
+                    api.vnrRender(r)
+                    acc.append(api.vnrRendererMapFrame(r).copy())
+                frames[kernel], hits[kernel] = acc, api.vnrRendererGetFrameStats(r)["n_rays_hit"]
+            assert hits[1] == hits[0], ("rays hit", hits)
+            for k in range(2):
+                a, b = frames[1][k], frames[0][k]
+                assert np.isfinite(a).all() and np.isfinite(b).all()
+                if mode in (14, 15):
+                    assert np.array_equal(a, b), ("path tracing", k, float(np.abs(a - b).max()))
+                else:
+                    mse = float(((a.astype(np.float64) - b) ** 2).mean())
+                    assert mse == 0 or 10 * np.log10(1.0 / mse) > 70, ("psnr", k, 10 * np.log10(1.0 / mse))
+        except Exception as e:
+            failures.append((d, repr(e)[:300]))
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"in-shader {d} {'FAIL ' + failures[-1][1] if failures and failures[-1][0] is d else 'ok'}\n")
+    assert not failures, failures
+
+
+# ------------------------------------------------------------------------------------------------ dense volumes: sampling, macrocells, DDA, camera
+def test_randomly_drawn_scenes_on_a_dense_volume_match_the_oracle(oracle):
+    """the march itself, with the network out of the way: volumes of random ragged shapes (5..70 voxels an axis), transfer functions of random
+    lengths and contents, cameras anywhere around (one in five INSIDE the volume), any field of view, frame shape, sampling rate and density
+    scale, rendering modes 4 / 5 (ray marching) and 7 / 8 (gradient shading).  Sampling and macrocells bit-exact; frames within 2e-4 of the
+    oracle's (device powf against glibc's), hit rays and iterations equal for the streaming modes."""
+    n = int(os.environ.get("VNR_FUZZ_SCENES", "60"))
+    rng = np.random.default_rng(int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 47)
+    failures = []
+    for i in range(n):
+        dims = tuple(int(v) for v in rng.integers(5, 71, 3))          # (nx, ny, nz)
+        mode = int(rng.choice([4, 5, 7, 8]))
+        size = (int(rng.integers(9, 150)), int(rng.integers(9, 110)))
+        inside = rng.uniform() < 0.2
+        d = dict(i=i, dims=dims, mode=mode, size=size, inside=bool(inside))
+        try:
+            nx, ny, nz = dims
+            z, y, x = np.meshgrid(np.linspace(0, 1, nz), np.linspace(0, 1, ny), np.linspace(0, 1, nx), indexing="ij")
+            k = rng.uniform(1.0, 7.0, 6); ph = rng.uniform(0, 6.28, 3)
+            vol = (0.5 + 0.5 * np.sin(k[0] * x + k[1] * y + ph[0]) * np.cos(k[2] * y + k[3] * z + ph[1]) * np.sin(k[4] * z + k[5] * x + ph[2])).astype(np.float32)
+            vol += rng.normal(0, 0.02, vol.shape).astype(np.float32)
+            if rng.uniform() < 0.5:                                   # an empty slab on one side
+                vol[:, :, : max(1, nx // 4)] = vol.min()
+            sv = api.vnrCreateSimpleVolume(vol)
+            lo, hi = np.float32(vol.min()), np.float32(vol.max())     # the reference's load-time normalisation (neural_sampler.cpp:176-210)
+            vol = np.clip((vol - lo) / (hi - lo), np.float32(0), np.float32(1)).astype(np.float32)
+            c = rng.uniform(-0.05, 1.05, (1500, 3)).astype(np.float32)
+            for nodal in (False, True):
+                assert np.array_equal(api.simple_volume_sample(sv, c, nodal), oracle.sample_volume(vol, c, nodal)), "sampling"
+            nc, na = int(rng.integers(2, 300)), int(rng.integers(2, 300))
+            colors = rng.uniform(0, 1, (nc, 3)).astype(np.float32)
+            alphas = (np.clip(rng.uniform(-0.6, 1.0, na), 0, 1) * (np.linspace(0, 1, na) ** rng.uniform(0.3, 3.0))).astype(np.float32)
+            tfn = api.vnrCreateTransferFunction()
+            api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas); api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+            otfn = oracle.TfnHolder(colors, alphas)
+            v = rng.normal(size=3); v /= np.linalg.norm(v)
+            if abs(v[1]) > 0.95:
+                v = np.array([0.6, 0.5, -0.62]); v /= np.linalg.norm(v)
+            dist = max(dims) * (rng.uniform(0.05, 0.3) if inside else rng.uniform(0.9, 2.6))
+            frm = tuple(float(q) for q in v * dist)
+            at = tuple(float(q) for q in rng.uniform(-0.15, 0.15, 3) * max(dims))
+            fovy = float(rng.uniform(20, 90))
+            camera = api.vnrCreateCamera()
+            api.vnrCameraSet(camera, frm, at, (0.0, 1.0, 0.0), fovy)
+            rate, density = float(rng.choice([0.5, 1.0, 1.0, 2.0, 3.0])), float(rng.choice([0.3, 1.0, 1.0, 4.0]))
+            d.update(frm=frm, at=at, fovy=fovy, rate=rate, density=density, tfn=(nc, na))
+            r = api.vnrCreateRenderer(sv)
+            api.vnrRendererSetTransferFunction(r, tfn); api.vnrRendererSetCamera(r, camera); api.vnrRendererSetFramebufferSize(r, size)
+            api.vnrRendererSetMode(r, mode)
+            api.vnrRendererSetVolumeSamplingRate(r, rate); api.vnrRendererSetVolumeDensityScale(r, density)
+            api.vnrRender(r)
+            img = api.vnrRendererMapFrame(r).copy()
+            st = api.vnrRendererGetFrameStats(r)
+            mc = api.volume_macrocell(sv)
+            vr = oracle.macrocell_compute_implicit(vol)
+            assert mc["dims"] == tuple((q + 15) // 16 for q in dims), "macrocell dims"
+            assert np.array_equal(mc["value_range"], vr), "macrocell value ranges"
+            mo = oracle.macrocell_max_opacity(otfn, vr)
+            assert np.array_equal(mc["max_opacity"], mo), "macrocell opacities"
+            sc = oracle.SceneHolder(size[0], size[1], dims, otfn, mo, frm, at, (0, 1, 0), fovy, sampling_rate=rate, density_scale=density,
+                                    shading_mode=1 if mode in (7, 8) else 0)
+            if mode in (5, 8):
+                want, _, ost = oracle.render_streaming(sc, lambda q: oracle.sample_volume(vol, q, nodal=True))
+                assert st["n_rays_hit"] == ost["n_rays_hit"], ("rays hit", st["n_rays_hit"], ost["n_rays_hit"])
+                assert st["n_iterations"] == ost["n_iterations"], ("iterations", st["n_iterations"], ost["n_iterations"])
+            else:
+                want, _ = oracle.render_monolithic(sc, vol)
+            assert np.isfinite(img).all()
+            err = float(np.abs(img - want).max())
+            assert err < 2e-4, ("frame", err)
+        except Exception as e:
+            failures.append((d, repr(e)[:300]))
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"scene {d} {'FAIL ' + failures[-1][1] if failures and failures[-1][0] is d else 'ok'}\n")
+    assert not failures, failures

@@ -224,6 +224,18 @@ def check(oracle, d, seed):
             assert np.abs(g - w).max() < max(6e-2 * np.abs(w).max(), 2 * noise_abs), (name, np.abs(g - w).max(), np.abs(w).max(), noise_abs)
         last = grads[n_mlp - 16 * W:n_mlp].reshape(16, W)
         assert np.all(last[1:] == 0), "padded rows of the last layer"
+    # params.json round trip (network.cu:827-857): the file carries the model description; the loaded network is the same network
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "params.json")
+        api.vnrNeuralVolumeSerializeParams(vol, path)
+        vol2 = api.vnrCreateNeuralVolume(path)
+    info2 = api.neural_info(vol2)
+    for k in ("n_neurons", "n_hidden_layers", "activation", "output_activation", "grid_type", "interpolation", "n_params", "padded_width"):
+        assert info2[k] == info[k], ("params.json", k, info2[k], info[k])
+    assert np.array_equal(api.neural_get_params_fp16(vol2).view(np.uint16), params.view(np.uint16)), "params.json parameters"
+    a, b = api.neural_inference(vol, coords[:257]), api.neural_inference(vol2, coords[:257])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "params.json inference"       # (max_level and quantize_threshold survived)
     api.neural_train_end(vol)
     api.vnrNeuralVolumeTrain(vol, 3, True)
     return vacuous
@@ -478,4 +490,75 @@ def test_randomly_drawn_scenes_on_a_dense_volume_match_the_oracle(oracle):
         if os.environ.get("VNR_FUZZ_LOG"):
             with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
                 f.write(f"scene {d} {'FAIL ' + failures[-1][1] if failures and failures[-1][0] is d else 'ok'}\n")
+    assert not failures, failures
+
+
+# ------------------------------------------------------------------------------------------------ pixel shares
+def test_randomly_drawn_pixel_shares_assemble_to_the_unsharded_frame(oracle):
+    """the multi-GPU render path on one device (vnrRendererSetPixelInterleave / SetPixelRange): for random frame shapes (ragged against the
+    8-scanline blocks the shares are cut in), world sizes 2..8, rendering modes 5 / 6 / 8 / 14 and
+    both kinds of volume, every pixel of every rank's share is the unsharded frame's pixel bit for bit (a pixel's ray does not depend on
+    which rays share its wave, its tile or its launch)."""
+    from instantvnr_amd import dist as vdist
+    n = int(os.environ.get("VNR_FUZZ_SHARES", "24"))
+    rng = np.random.default_rng(int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 59)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas); api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    failures = []
+    for i in range(n):
+        size = (int(rng.integers(16, 180)), int(rng.integers(16, 120)))
+        n_pixels = size[0] * size[1]
+        world = int(rng.integers(2, 9))
+        block = 8 * size[0]                      # the library's unit: 8 scanlines, one row of ray tiles (anything else is refused by name)
+        mode = int(rng.choice([5, 6, 8, 14]))
+        neural = bool(rng.uniform() < 0.6)
+        d = dict(i=i, size=size, world=world, block=block, mode=mode, neural=neural)
+        try:
+            if neural:
+                F = int(rng.choice([1, 2, 4, 8]))
+                W = int(rng.choice([16, 32, 64, 64, 128]))
+                cfg = syn.model_config(n_levels=int(rng.integers(2, 9)), n_features=F, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=int(rng.integers(1, 4)))
+                cfg["network"]["n_neurons"] = W
+                volume = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+                info = api.neural_info(volume)
+                api.neural_set_params_fp16(volume, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], W, cfg["network"]["n_hidden_layers"] - 1), seed=300 + i))
+                d.update(F=F, W=W)
+            else:
+                volume = sv
+            v = rng.normal(size=3); v /= np.linalg.norm(v)
+            if abs(v[1]) > 0.95:
+                v = np.array([0.6, 0.5, -0.62]); v /= np.linalg.norm(v)
+            camera = api.vnrCreateCamera()
+            api.vnrCameraSet(camera, tuple(float(x) for x in v * 32 * rng.uniform(0.9, 2.0)), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), float(rng.uniform(30, 70)))
+
+            def renderer():
+                r = api.vnrCreateRenderer(volume)
+                api.vnrRendererSetTransferFunction(r, tfn); api.vnrRendererSetCamera(r, camera); api.vnrRendererSetFramebufferSize(r, size)
+                api.vnrRendererSetMode(r, mode)
+                return r
+
+            r = renderer()
+            api.vnrRender(r)
+            want = api.vnrRendererMapFrame(r).reshape(-1, 4).copy()
+            shares = []
+            for part in range(world):
+                rp = renderer()
+                api.vnrRendererSetPixelInterleave(rp, block, world, part)
+                api.vnrRender(rp)
+                shares.append(vdist.pack_share(api.vnrRendererMapFrame(rp).reshape(-1, 4).copy(), block, world, part, n_pixels))
+            n_local = max(s.shape[0] for s in shares)
+            full = vdist.assemble_shares(np.stack([np.pad(s, ((0, n_local - s.shape[0]), (0, 0))) for s in shares]), block, world, n_pixels)
+            assert np.array_equal(full, want), ("interleave", int((full != want).any(axis=1).sum()))
+            lo = int(rng.integers(0, n_pixels - 1)); hi = int(rng.integers(lo + 1, n_pixels + 1))
+            rr = renderer()
+            api.vnrRendererSetPixelRange(rr, lo, hi)
+            api.vnrRender(rr)
+            assert np.array_equal(api.vnrRendererMapFrame(rr).reshape(-1, 4)[lo:hi], want[lo:hi]), ("range", lo, hi)
+        except Exception as e:
+            failures.append((d, repr(e)[:300]))
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"shares {d} {'FAIL ' + failures[-1][1] if failures and failures[-1][0] is d else 'ok'}\n")
     assert not failures, failures

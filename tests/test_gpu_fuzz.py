@@ -562,3 +562,99 @@ def test_randomly_drawn_pixel_shares_assemble_to_the_unsharded_frame(oracle):
             with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
                 f.write(f"shares {d} {'FAIL ' + failures[-1][1] if failures and failures[-1][0] is d else 'ok'}\n")
     assert not failures, failures
+
+
+# ------------------------------------------------------------------------------------------------ the optimizer
+def optimizer_draw(oracle, seed, i, verbose=False):
+    """one draw of the optimizer sweep (its own generator: a failing draw can be replayed alone, VNR_FUZZ_ONLY=<i>,<i>..)"""
+    import ctypes as C
+    from oracle import train_oracle as T
+    from instantvnr_amd._lib import check, lib
+    rng = np.random.default_rng([seed, i])
+    F = int(rng.choice([1, 2, 4, 8])); L = int(rng.integers(1, 7)); W = int(rng.choice([16, 32, 64, 128])); H = int(rng.integers(1, 4))
+    opt = dict(lr=float(10 ** rng.uniform(-4, -1.5)), beta1=float(rng.choice([0.0, 0.5, 0.9])), beta2=float(rng.choice([0.9, 0.99, 0.999])),
+               eps=float(rng.choice([1e-15, 1e-8, 1e-3])), l2=float(rng.choice([0.0, 1e-8, 1e-6, 1e-3])))
+    decay = None if rng.uniform() < 0.4 else dict(start=int(rng.integers(1, 5)), interval=int(rng.integers(1, 4)), base=float(rng.uniform(0.3, 0.9)))
+    grad_scale = float(rng.choice([1.0, 0.5, 4.0]))
+    d = dict(i=i, L=L, F=F, W=W, H=H, opt=opt, decay=decay, grad_scale=grad_scale)
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=int(rng.integers(8, 13)), base_resolution=int(rng.integers(2, 6)), n_hidden_layers=H)
+    cfg["network"]["n_neurons"] = W
+    adam = {"otype": "Adam", "learning_rate": opt["lr"], "beta1": opt["beta1"], "beta2": opt["beta2"], "epsilon": opt["eps"], "l2_reg": opt["l2"]}
+    cfg["optimizer"] = adam if decay is None else {"otype": "ExponentialDecay", "decay_start": decay["start"], "decay_interval": decay["interval"],
+                                                   "decay_base": decay["base"], "nested": adam}
+    vol = api.vnrCreateNeuralVolume(cfg, (16, 16, 16))
+    info = api.neural_info(vol)
+    N = info["n_params"]
+    n_mlp = oracle.mlp_n_params(info["padded_width"], W, H - 1)
+    params = syn.random_params(N, n_mlp, seed=500 + i)
+    api.neural_set_params_fp16(vol, params)
+    master = params.astype(np.float64); m = np.zeros(N); v = np.zeros(N); steps = np.zeros(N)
+    lr, step_no = np.float32(opt["lr"]), 0
+    history, slack = [], np.zeros(N)
+    for step in range(6):
+        g = np.zeros(N, np.float32)
+        pick = rng.random(N) < (0.9 if step == 3 else 0.15)
+        g[pick] = rng.normal(0, 10 ** rng.uniform(-4, 0), int(pick.sum())).astype(np.float16).astype(np.float32)
+        g[rng.integers(0, N, 50)] = -0.0
+        g[rng.integers(0, N, 50)] = 6e-8                       # the smallest subnormal half
+        g = g.astype(np.float16).astype(np.float32)             # what the gradient blob can hold
+        before = api.neural_get_params_fp16(vol).view(np.uint16).copy()
+        check(lib().vnrAmdNeuralVolumeSetGradients(vol.h, g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
+        api.neural_train_end(vol, grad_scale)
+        after = api.neural_get_params_fp16(vol)
+        prev = (master, m, v, steps)
+        master, m, v, steps = T.adam_step(master, g.astype(np.float64), m, v, steps, n_mlp, lr=float(lr), beta1=float(np.float32(opt["beta1"])),
+                                          beta2=float(np.float32(opt["beta2"])), eps=float(np.float32(opt["eps"])),
+                                          l2_reg=float(np.float32(opt["l2"])), grad_scale=grad_scale)
+        history.append((g, prev, float(lr)))
+        step_no += 1
+        if decay is not None and step_no >= decay["start"] and step_no % decay["interval"] == 0:
+            lr = np.float32(lr * np.float32(decay["base"]))
+        want = master.astype(np.float32).astype(np.float16)
+        untouched = np.ones(N, bool); untouched[:n_mlp] = False; untouched &= (g == 0)
+        assert np.array_equal(after.view(np.uint16)[untouched], before[untouched]), (d, "an untouched grid entry moved", step)
+        a, b = after.astype(np.float64), want.astype(np.float64)
+        assert np.isfinite(a).all(), (d, "finite", step)
+        # one half-precision ulp, or -- for a parameter the step carried next to zero, where halves are dense -- 1e-4 of the step it took:
+        # the bias correction sqrt(1 - beta2^step) is evaluated in fp32 (a difference of nearly equal numbers: 3e-5 relative at
+        # beta2 = 0.999, step 1), here and in the reference
+        ulp = np.spacing(np.maximum(np.abs(after), np.abs(want)).astype(np.float16)).astype(np.float64)
+        slack = slack + 1e-4 * np.abs(b - before.view(np.float16).astype(np.float64))      # (it stays with the parameter over the following steps)
+        ulp = np.maximum(ulp, slack)
+        off = a != b
+        if verbose and (np.abs(a - b) > ulp).any():
+            k = int(np.argmax(np.abs(a - b) / ulp))
+            print("draw", d, "step", step, "element", k, "of", N, "(n_mlp", n_mlp, ") hip", a[k], "restatement", b[k], "fp64 master", master[k],
+                  "before", float(before[k:k + 1].view(np.float16)[0]))
+            for s_, (g_, (ma, m_, v_, st_), lr_) in enumerate(history):
+                print("   step", s_, "g", g_[k], "master", ma[k], "m", m_[k], "v", v_[k], "steps", st_[k], "lr", lr_)
+        assert (np.abs(a - b) <= ulp).all(), (d, "more than an ulp", step, float(np.abs(a - b).max()), int((np.abs(a - b) > ulp).sum()))
+        assert off.mean() < 2e-3 + 0.5 * opt["lr"], (d, "fraction of parameters an ulp off", step, float(off.mean()))   # (the same 3e-5 of a step of ~lr against a half's ulp)
+    assert api.vnrNeuralVolumeGetTrainingStep(vol) == 6
+    assert np.all(api.neural_gradients(vol) == 0), "gradients cleared"
+    return d
+
+
+def test_randomly_drawn_optimizers_follow_the_restatement_step_by_step(oracle):
+    """EXTERNAL tcnn Adam / ExponentialDecay{Adam} (restated in oracle/train_oracle.py::adam_step) under random hyper-parameters: learning
+    rate 1e-4..3e-2, beta1 0 / 0.5 / 0.9, beta2 0.9 / 0.99 / 0.999, epsilon 1e-15 / 1e-8 / 1e-3, l2_reg 0..1e-3, a decay schedule that
+    starts within the run, grad_scale 1 / 0.5 / 4; six steps on injected gradients (sparse on the grid: untouched entries must not move,
+    their step counters must not advance; zeros, negative zeros and the smallest halves among them).  After every step the fp16 parameters
+    equal the fp64 restatement's, rounded: at most one half-precision ulp apart (1e-4 of the step for a parameter that lands next to zero),
+    and that on fewer than 0.2 % + lr / 2 of them (fp32 state and the bias correction 1 - beta2^step evaluated in fp32, as in the reference,
+    against fp64)."""
+    n = int(os.environ.get("VNR_FUZZ_OPTIMIZERS", "30"))
+    seed = int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 71
+    only = [int(x) for x in os.environ.get("VNR_FUZZ_ONLY", "").split(",") if x]
+    failures = []
+    for i in (only or range(n)):
+        try:
+            d = optimizer_draw(oracle, seed, i, verbose=bool(only))
+            msg = "ok"
+        except Exception as e:
+            d, msg = i, "FAIL " + repr(e)[:600]
+            failures.append((i, msg))
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"optimizer {d} {msg}\n")
+    assert not failures, failures

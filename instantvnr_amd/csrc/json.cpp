@@ -75,9 +75,12 @@ const std::string& Json::as_binary() const
 
 // ------------------------------------------------------------------------------------------ text
 namespace {
+constexpr int kTextMaxDepth = 64;   // (= kBsonMaxDepth) the reference's files nest 4 deep; a crafted or damaged text must not recurse the stack away
+
 struct Parser {
   const char* p;
   const char* end;
+  int depth = 0;
 
   [[noreturn]] void fail(const char* msg) const { throw std::runtime_error(std::string("json parse error: ") + msg); }
 
@@ -147,10 +150,14 @@ struct Parser {
         case 't': s.push_back('\t'); break;
         case 'u': {
           uint32_t cp = hex4();
-          if (cp >= 0xD800 && cp <= 0xDBFF && end - p >= 6 && p[0] == '\\' && p[1] == 'u') {
+          if (cp >= 0xD800 && cp <= 0xDBFF) {   // a high surrogate needs its low half (nlohmann::json refuses a lone one too)
+            if (end - p < 6 || p[0] != '\\' || p[1] != 'u') fail("lone surrogate in \\u escape");
             p += 2;
             const uint32_t lo = hex4();
+            if (lo < 0xDC00 || lo > 0xDFFF) fail("bad surrogate pair in \\u escape");
             cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+          } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+            fail("lone surrogate in \\u escape");
           }
           append_utf8(s, cp);
           break;
@@ -176,10 +183,17 @@ struct Parser {
       ++p;
     }
     const std::string tok(b, p);
-    if (tok.empty()) fail("expected number");
-    if (is_float) return Json(std::strtod(tok.c_str(), nullptr));
+    if (tok.empty()) fail("expected a value");
+    // the whole token must be a number: "1-2", "--3", "1e", "." are errors, not the number in front of the damage
+    char* stop = nullptr;
+    if (is_float) {
+      const double d = std::strtod(tok.c_str(), &stop);
+      if (stop != tok.c_str() + tok.size() || stop == tok.c_str()) fail("malformed number");
+      return Json(d);
+    }
     errno = 0;
-    const long long v = std::strtoll(tok.c_str(), nullptr, 10);
+    const long long v = std::strtoll(tok.c_str(), &stop, 10);
+    if (stop != tok.c_str() + tok.size() || stop == tok.c_str()) fail("malformed number");
     if (errno == ERANGE) return Json(std::strtod(tok.c_str(), nullptr));
     return Json((int64_t)v);
   }
@@ -191,9 +205,10 @@ struct Parser {
     const char c = *p;
     if (c == '{') {
       ++p;
+      if (++depth > kTextMaxDepth) fail("nested too deeply");
       Json o = Json::object();
       skip_ws();
-      if (p < end && *p == '}') { ++p; return o; }
+      if (p < end && *p == '}') { ++p; --depth; return o; }
       for (;;) {
         skip_ws();
         const std::string k = string();
@@ -203,20 +218,21 @@ struct Parser {
         o[k] = value();
         skip_ws();
         if (p < end && *p == ',') { ++p; continue; }
-        if (p < end && *p == '}') { ++p; return o; }
+        if (p < end && *p == '}') { ++p; --depth; return o; }
         fail("expected ',' or '}'");
       }
     }
     if (c == '[') {
       ++p;
+      if (++depth > kTextMaxDepth) fail("nested too deeply");
       Json a = Json::array();
       skip_ws();
-      if (p < end && *p == ']') { ++p; return a; }
+      if (p < end && *p == ']') { ++p; --depth; return a; }
       for (;;) {
         a.push_back(value());
         skip_ws();
         if (p < end && *p == ',') { ++p; continue; }
-        if (p < end && *p == ']') { ++p; return a; }
+        if (p < end && *p == ']') { ++p; --depth; return a; }
         fail("expected ',' or ']'");
       }
     }
@@ -411,6 +427,8 @@ struct BsonReader {
 
 void Json::bson_element(std::vector<uint8_t>& o, const std::string& key) const
 {
+  // a BSON key is a C string (nlohmann::json: out_of_range.409 "BSON key cannot contain code point U+0000")
+  if (key.find('\0') != std::string::npos) throw std::runtime_error("bson: a key cannot contain the code point U+0000");
   auto header = [&](uint8_t t) {
     o.push_back(t);
     o.insert(o.end(), key.begin(), key.end());

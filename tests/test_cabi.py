@@ -98,6 +98,32 @@ def test_bson_reader_bounds_children_by_their_parent_and_limits_depth(L):
     L.vnrAmdFreeHost(out)
 
 
+def test_text_reader_refuses_what_nlohmann_refuses_and_limits_its_depth(L):
+    """found by tests/test_json_fuzz.py: 200 000 nested '[' ran the recursive text parser off the stack; "1-2" parsed as 1; a lone
+    \\ud800 became four bytes that are not UTF-8; a key with an embedded U+0000 was written into a BSON document it then corrupted
+    (nlohmann::json: parse_error.101, parse_error.101, out_of_range.409)"""
+    out, n = C.c_void_p(), C.c_size_t()
+
+    def convert(b, fin=api.JSON_TEXT, fout=api.JSON_BSON):
+        rc = L.vnrAmdJsonConvert(b, len(b), fin, fout, C.byref(out), C.byref(n))
+        if rc == 0:
+            L.vnrAmdFreeHost(out)
+        return rc
+
+    assert convert(b'{"a":' * 200000 + b"1" + b"}" * 200000) != 0 and b"nested too deeply" in L.vnrAmdGetLastError()
+    assert convert(b"[" * 200000) != 0 and b"nested too deeply" in L.vnrAmdGetLastError()
+    assert convert(b'{"a":' * 60 + b"1" + b"}" * 60) == 0
+    for bad in (b'{"a": 1-2}', b'{"a": --3}', b'{"a": 1e}', b'{"a": .}', b'{"a": 1.2.3}', b'{"a": -}'):
+        assert convert(bad) != 0 and b"malformed number" in L.vnrAmdGetLastError(), bad
+    for good in (b'{"a": -0}', b'{"a": 1e-2}', b'{"a": 2.5E+3}', b'{"a": 99999999999999999999}'):
+        assert convert(good) == 0, good
+    for bad in (b'{"a": "\\ud800"}', b'{"a": "\\ud800\\u0041"}', b'{"a": "\\udc00"}'):
+        assert convert(bad) != 0 and b"surrogate" in L.vnrAmdGetLastError(), bad
+    assert json.loads(api.bson_to_json_text(api.json_to_bson('{"a": "\\ud83d\\ude00"}'))) == {"a": "\U0001F600"}
+    assert convert(b'{"a\\u0000b": 1}') != 0 and b"U+0000" in L.vnrAmdGetLastError()
+    assert convert(b'{"a\\u0000b": 1}', api.JSON_TEXT, api.JSON_TEXT) == 0     # (text has no such restriction)
+
+
 def test_json_save_and_load_files(L, tmp_path):
     p = str(tmp_path / "m.json")
     api.vnrSaveJsonText({"a": 1, "b": [1, 2]}, p)

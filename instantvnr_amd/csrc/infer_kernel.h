@@ -15,7 +15,7 @@ struct FusedMlp {
   const uint16_t* packed;   // forward image (packed_mlp_halves)
   uint32_t lds_halves, width, n_hidden_matmuls, activation, output_activation;
   bool general;             // the model needs a GENERAL instance (grid_device.h gather_corners; Network::common_kind)
-  bool weights_global;      // the weight image exceeds the LDS (128 neurons, >= 6 hidden layers): the A operands are read from global memory
+  bool weights_global;      // the weight image exceeds the LDS (128 neurons: >= 6 hidden layers; 64: ~20; ...): the A operands are read from global memory
   float quantize_threshold;
 };
 
@@ -40,7 +40,7 @@ struct InferArgs {
   uint32_t output_activation;
   uint32_t lds_halves;
   uint32_t sharers;          // kernels of this kind expected to share the GPU (host-side launch sizing only)
-  uint32_t weights_global;   // GENERAL instances of 128 neurons: the weight image does not fit the LDS and stays in global memory
+  uint32_t weights_global;   // GENERAL instances: the weight image does not fit the LDS and stays in global memory
   float quantize_threshold;  // GENERAL instances (tcnn_impl_decoder.cu:120)
   PackArgs pack;             // MODE 0, queue launches of the ray marcher: the iteration's ray packing as a prologue (pack.n_blocks > 0)
 };
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64 * MlpShape<W>::WAVES) fused_infer_kernel(co
   // the grid is sized by an upper bound of the sample count: a block none of whose waves has a tile leaves at once
   if (xcd * per_xcd + (blockIdx.x >> 3) * WAVES >= tile_end) return;
 
-  constexpr bool CAN_GLOBAL = GENERAL && W == 128;   // the only shape whose image can exceed 160 KiB
+  constexpr bool CAN_GLOBAL = GENERAL;   // an image beyond 160 KiB: 128 neurons from 6 hidden layers on, 64 from ~20, 32 from ~75, 16 from ~300
   const bool wglobal = CAN_GLOBAL && args.weights_global != 0u;
   if (MODE != 1 && !wglobal) {  // stage the packed weights once per block
     const uint4_t* src = (const uint4_t*)args.packed_mlp;

@@ -114,7 +114,7 @@ public:
   // interpolation, activation and grid type.  The common kind of model (Hash / Dense grid, Linear / Smoothstep, ReLU / None, no output
   // activation, no quantize_threshold, a weight image that fits the LDS) has kernel instances that contain nothing else
   // (grid_device.h gather_corners); everything else runs on the GENERAL instances.
-  bool weights_in_lds() const { return (size_t)lds_halves_ * 2 <= kLdsBytes; }   // false: 128 neurons with >= 6 hidden layers (or 5 and an encoded width >= 112)
+  bool weights_in_lds() const { return (size_t)lds_halves_ * 2 <= kLdsBytes; }   // false: 128 neurons with >= 6 hidden layers (or 5 and an encoded width >= 112), 64 with ~20, 32 with ~75, 16 with ~300
   bool common_kind() const
   {
     return cfg_.activation <= 1u && cfg_.output_activation == 0u && cfg_.interpolation != 2u && cfg_.grid_type != 2u && cfg_.quantize_threshold == 0.0f &&

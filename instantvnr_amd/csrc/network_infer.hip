@@ -126,7 +126,7 @@ void launch_fused(int mode, const GridDevice& grid, uint32_t in_width, const Fus
   a.lds_halves = mlp.lds_halves;
   a.weights_global = mlp.weights_global ? 1u : 0u;
   a.quantize_threshold = mlp.quantize_threshold;
-  if (mlp.weights_global && (!mlp.general || mlp.width != 128u)) throw std::runtime_error("internal: weights from global memory are a GENERAL 128-neuron instance's");
+  if (mlp.weights_global && !mlp.general) throw std::runtime_error("internal: weights from global memory are a GENERAL instance's");
   if (pack && mode == 0) {
     if (mlp.width == 128u) throw std::runtime_error("internal: the 128-neuron evaluation kernel (8 waves per block) does not take the ray packing prologue");
     a.pack = *pack;

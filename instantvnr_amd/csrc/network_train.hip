@@ -136,7 +136,7 @@ struct BackwardArgs {
   half_t* d_out;         // [(nh+1)][n][W]  dL/d(pre-activation) of every hidden layer output
   half_t* dfeat;         // [n][in_width]
   uint32_t n, nh, activation, in_width, lds_halves;
-  uint32_t weights_global;   // GENERAL instances of 128 neurons: the image exceeds the LDS and is read from global memory
+  uint32_t weights_global;   // GENERAL instances: the image exceeds the LDS and is read from global memory
 };
 
 __device__ __forceinline__ half8_t load_frag_rowmajor(const half_t* row, int s, uint32_t h)
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const BackwardArgs ar
   constexpr int MT = Sh::MT, RW = Sh::RW, KS = Sh::KS;
   constexpr int NTB = W == 128 ? 1 : 2;   // 32-sample column tiles in flight (128 neurons: one, its accumulators are 4 tiles of registers already)
   extern __shared__ __attribute__((aligned(16))) half_t lds[];
-  constexpr bool CAN_GLOBAL = GENERAL && W == 128;   // the only shape whose image can exceed 160 KiB
+  constexpr bool CAN_GLOBAL = GENERAL;   // an image beyond 160 KiB: 128 neurons from 6 hidden layers on, 64 from ~20, 32 from ~75, 16 from ~300
   const bool wglobal = CAN_GLOBAL && args.weights_global != 0u;
   if (!wglobal) {
     const uint4_t* src = (const uint4_t*)args.packedT;
@@ -843,7 +843,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   ba.packedT = (const half_t*)mlp_packed_T_.ptr; ba.dy = (const half_t*)ts.dy.ptr; ba.acts = (const half_t*)ws_acts_.ptr;
   ba.d_out = (half_t*)ts.d_all.ptr; ba.dfeat = (half_t*)ws_dfeat_.ptr;
   ba.n = n; ba.nh = nh; ba.activation = cfg_.activation; ba.in_width = in_width_; ba.lds_halves = lds_halves_T_;
-  const bool bwd_global = (size_t)lds_halves_T_ * 2 > kLdsBytes;   // 128 neurons, >= 6 hidden layers: the image stays in global memory (GENERAL instance)
+  const bool bwd_global = (size_t)lds_halves_T_ * 2 > kLdsBytes;   // a deep network (128 neurons: >= 6 hidden layers): the image stays in global memory (GENERAL instance)
   ba.weights_global = bwd_global ? 1u : 0u;
   {
     const size_t shmem = bwd_global ? 16 : (size_t)lds_halves_T_ * 2;

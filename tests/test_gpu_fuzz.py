@@ -260,6 +260,21 @@ def test_randomly_drawn_models_equal_the_oracle(oracle):
     assert vacuous_draws <= n // 3, vacuous_draws
 
 
+DEEP = [   # weight images beyond the 160 KiB of LDS at every width (tcnn's FullyFusedMLP has no depth limit): the A operands come from global memory
+    dict(L=8, F=2, log2T=12, base=4, pls=2.0, H=21, W=64, interp="Linear", act="ReLU", out_act="None", gtype="Hash", qt=0.0, max_level=None),
+    dict(L=6, F=4, log2T=11, base=4, pls=1.5, H=24, W=64, interp="Smoothstep", act="Sigmoid", out_act="Sigmoid", gtype="Hash", qt=0.0, max_level=None),
+    dict(L=8, F=2, log2T=12, base=4, pls=2.0, H=81, W=32, interp="Linear", act="Sigmoid", out_act="None", gtype="Hash", qt=0.0, max_level=None),
+    dict(L=4, F=8, log2T=10, base=4, pls=2.0, H=90, W=32, interp="Nearest", act="Squareplus", out_act="None", gtype="Tiled", qt=0.0, max_level=None),
+    dict(L=8, F=1, log2T=12, base=4, pls=2.0, H=321, W=16, interp="Linear", act="Sigmoid", out_act="None", gtype="Dense", qt=0.0, max_level=None),
+]
+
+
+@pytest.mark.parametrize("d", DEEP)
+def test_networks_too_deep_for_the_lds_at_every_width(oracle, d):
+    info_checks = check(oracle, d, 900 + d["H"])
+    assert "inference" not in info_checks, info_checks          # (gradients of the first layers of a 300-layer Sigmoid network are zero on both sides)
+
+
 # ------------------------------------------------------------------------------------------------ the same, behind the renderer
 def draw_scene(rng):
     d = draw(rng)

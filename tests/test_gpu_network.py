@@ -263,6 +263,7 @@ ACCEPTED = [
     (6, 2, 12, 4, None, 6, 128, "Linear", 0.0, None),
     (8, 2, 12, 4, None, 7, 128, "Linear", 0.0, None, {"activation": "Sigmoid"}),
     (8, 4, 12, 4, None, 2, 32, "Linear", 0.03, None, {"activation": "Squareplus"}),  # quantize_threshold with everything else GENERAL
+    (8, 2, 12, 4, None, 21, 64, "Linear", 0.0, None),      # 64 neurons, 20 hidden matmuls x 8 KB: beyond the LDS at this width too (tests/test_gpu_fuzz.py: 32 / 16 neurons)
 ]
 INTERP = {"Linear": 0, "Smoothstep": 1, "Nearest": 2}
 

@@ -673,3 +673,69 @@ def test_randomly_drawn_optimizers_follow_the_restatement_step_by_step(oracle):
             with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
                 f.write(f"optimizer {d} {msg}\n")
     assert not failures, failures
+
+
+# ------------------------------------------------------------------------------------------------ damaged descriptions
+POOL = [0, -1, 1, 2, 3, 7, 16, 17, 33, 64, 100, 1000, 2 ** 31, 2 ** 32 + 5, 0.5, -2.5, 1e30, 1e-30, "x", "", "ReLU", "Hash", "Adam", None, True, False, [], {},
+        [1, 2], {"otype": "Adam"}]
+
+
+def _paths(doc, prefix=()):
+    out = []
+    for k, v in doc.items():
+        out.append(prefix + (k,))
+        if isinstance(v, dict):
+            out += _paths(v, prefix + (k,))
+    return out
+
+
+def test_damaged_model_descriptions_are_refused_by_name_or_run(oracle):
+    """a model description with keys missing, values of the wrong type, negative, fractional, absurdly large or small: the library either
+    refuses it with a message (the reference: a tcnn / nlohmann exception) or builds a network that evaluates and trains without a
+    fault -- never a crash, a hang, or a silent fallback.  (Sizes are kept where a mistaken success cannot exhaust the host.)"""
+    import copy
+    n = int(os.environ.get("VNR_FUZZ_DAMAGED", "150"))
+    seed = int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 83
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(16))
+    coords = np.random.default_rng(1).uniform(0, 1, (65, 3)).astype(np.float32)
+    refused, ran, messages = 0, 0, set()
+    for i in range(n):
+        rng = np.random.default_rng([seed, i])
+        cfg = copy.deepcopy(syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=10, base_resolution=4, n_hidden_layers=2))
+        for _ in range(int(rng.integers(1, 4))):
+            paths = _paths(cfg)
+            if not paths:
+                break
+            path = paths[int(rng.integers(0, len(paths)))]
+            node = cfg
+            for k in path[:-1]:
+                node = node[k]
+            if rng.uniform() < 0.3:
+                del node[path[-1]]
+            else:
+                node[path[-1]] = copy.deepcopy(POOL[int(rng.integers(0, len(POOL)))])
+        enc = cfg.get("encoding", {}) if isinstance(cfg.get("encoding"), dict) else {}
+        if isinstance(enc.get("log2_hashmap_size"), (int, float)) and 22 < enc["log2_hashmap_size"] <= 28:
+            enc["log2_hashmap_size"] = 22
+        try:
+            vol = api.vnrCreateNeuralVolume(cfg, sv)
+        except api.VnrAmdError as e:
+            refused += 1
+            assert str(e), cfg
+            messages.add(str(e)[:60])
+            continue
+        try:
+            out = api.neural_inference(vol, coords)
+            assert out.shape == (65,)
+            api.vnrNeuralVolumeTrain(vol, 2, True)
+            api.neural_inference(vol, coords)
+            ran += 1
+        except api.VnrAmdError as e:           # a description that builds but cannot run must say so as well
+            refused += 1
+            assert str(e), cfg
+            messages.add(str(e)[:60])
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"damaged {i} ok\n")
+    assert refused > n // 10 and ran > n // 10, (refused, ran)
+    assert len(messages) >= 8, messages          # many different refusals, by name

@@ -442,9 +442,18 @@ static std::vector<float> normalise_volume(const void* data, vec3i dims, int typ
 
 static std::vector<char> read_raw_file(const std::string& filename, vec3i dims, int type, size_t offset)
 {
-  const size_t bytes = (size_t)dims.x * dims.y * dims.z * type_size(type);
-  std::ifstream f(filename, std::ios::binary);
+  // the description is checked against the FILE before anything is allocated: a scene with a wrong dimension must fail by name, not by
+  // a zero-filled vector of the size it claims (found by tests/test_gpu_fuzz.py's damaged scenes)
+  if (dims.x <= 0 || dims.y <= 0 || dims.z <= 0)
+    throw std::runtime_error("volume dimensions must be positive: " + std::to_string(dims.x) + " x " + std::to_string(dims.y) + " x " + std::to_string(dims.z));
+  const unsigned __int128 wide = (unsigned __int128)(uint32_t)dims.x * (uint32_t)dims.y * (uint32_t)dims.z * (unsigned)type_size(type);
+  std::ifstream f(filename, std::ios::binary | std::ios::ate);
   if (!f) throw std::runtime_error("cannot open volume file: " + filename);
+  const std::streamoff file_size = f.tellg();
+  if (file_size < 0 || (unsigned __int128)offset + wide > (unsigned __int128)(uint64_t)file_size)
+    throw std::runtime_error("volume file too short: " + filename + " has " + std::to_string((long long)file_size) + " bytes, the description needs " +
+                             (wide > (unsigned __int128)UINT64_MAX ? std::string("more than 2^64") : std::to_string((uint64_t)wide)) + " from offset " + std::to_string(offset));
+  const size_t bytes = (size_t)wide;
   f.seekg((std::streamoff)offset);
   std::vector<char> buf(bytes);
   if (!f.read(buf.data(), (std::streamsize)bytes)) throw std::runtime_error("volume file too short: " + filename);

@@ -739,3 +739,64 @@ def test_damaged_model_descriptions_are_refused_by_name_or_run(oracle):
                 f.write(f"damaged {i} ok\n")
     assert refused > n // 10 and ran > n // 10, (refused, ran)
     assert len(messages) >= 8, messages          # many different refusals, by name
+
+
+def test_damaged_scene_descriptions_are_refused_by_name_or_load(oracle, tmp_path):
+    """a scene document (serializer.cpp:137-477) whose description does not match its file -- dimensions larger than the file, negative,
+    zero, 2^31, an offset behind the end, a missing file, a wrong type name, keys missing or of the wrong type -- in both of the reference's
+    formats and both loading modes: refused with a message before anything of the claimed size is allocated, or loaded and sampled."""
+    import copy
+    n = int(os.environ.get("VNR_FUZZ_DAMAGED", "150"))
+    seed = int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 97
+    dims = (20, 12, 9)
+    rng0 = np.random.default_rng(0)
+    raw = tmp_path / "v.raw"
+    with open(raw, "wb") as f:
+        f.write(b"\0" * 16)
+        f.write(rng0.integers(0, 255, dims[::-1], dtype=np.uint8).tobytes())
+    vidi = {"dataSource": [{"format": "REGULAR_GRID_RAW_BINARY", "fileName": str(raw), "dimensions": {"x": dims[0], "y": dims[1], "z": dims[2]},
+                            "type": "UNSIGNED_BYTE", "offset": 16, "endian": "LITTLE_ENDIAN"}],
+            "view": {"volume": {"transferFunction": {}, "scalarMappingRangeUnnormalized": {"minimum": 3.0, "maximum": 200.0}}}}
+    diva = {"version": "DIVA", "volume": {"dims": {"x": dims[0], "y": dims[1], "z": dims[2]}, "type": "UNSIGNED_BYTE", "offset": 16,
+                                          "range": {"x": 3.0, "y": 200.0}, "filename": str(raw)}}
+    pool = POOL + [dims[0] + 1, 4096, 100000, -5, 15, 17, 2160, 2161, "FLOAT", "DOUBLE", "UNSIGNED_SHORT", "BYTE", "BIG_ENDIAN", str(tmp_path), str(tmp_path / "nope.raw"),
+                   {"x": 4096, "y": 4096, "z": 4096}, {"x": -1, "y": 12, "z": 9}, {"x": 20, "y": 12}, [str(tmp_path / "nope.raw"), str(raw)]]
+    coords = np.random.default_rng(1).uniform(0, 1, (33, 3)).astype(np.float32)
+    refused, loaded, messages = 0, 0, set()
+    os.environ.setdefault("VNR_NUM_CONCURRENT_BLOCKS", "2"); os.environ.setdefault("VNR_NUM_BLOCKS", "4")
+    for i in range(n):
+        rng = np.random.default_rng([seed, i])
+        sc = copy.deepcopy(vidi if rng.uniform() < 0.6 else diva)
+        for _ in range(int(rng.integers(1, 3))):
+            root = sc["dataSource"][0] if "dataSource" in sc and isinstance(sc.get("dataSource"), list) and sc["dataSource"] and rng.uniform() < 0.7 else sc
+            if not isinstance(root, dict):
+                break
+            paths = _paths(root)
+            if not paths:
+                break
+            path = paths[int(rng.integers(0, len(paths)))]
+            node = root
+            for k in path[:-1]:
+                node = node[k]
+            if rng.uniform() < 0.25:
+                del node[path[-1]]
+            else:
+                node[path[-1]] = copy.deepcopy(pool[int(rng.integers(0, len(pool)))])
+        mode = "GPU" if rng.uniform() < 0.7 else "OUT_OF_CORE"
+        try:
+            sv = api.vnrCreateSimpleVolume(sc, mode)
+            d = api.vnrVolumeGetDims(sv)
+            assert all(0 < q <= 4096 for q in d), d
+            if mode == "GPU":
+                out = api.simple_volume_sample(sv, coords, nodal=False)
+                assert out.shape == (33,)        # (random bytes read as FLOAT / DOUBLE hold NaNs: the values are the file's business)
+            loaded += 1
+        except api.VnrAmdError as e:
+            refused += 1
+            assert str(e), sc
+            messages.add(str(e)[:50])
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"scene-description {i} ok\n")
+    assert refused > n // 10 and loaded > n // 10, (refused, loaded)
+    assert len(messages) >= 8, messages

@@ -298,3 +298,18 @@ def test_every_key_of_the_reference_s_scene_reader_is_read_here_or_explained():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "scene_keys_vs_reference.py")], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "UNEXPLAINED" not in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
+def test_a_scene_that_claims_more_than_its_file_holds_is_refused_before_anything_is_allocated(tmp_path):
+    """found by tests/test_gpu_fuzz.py: the loader sized (and zero-filled) its buffer from the DESCRIPTION and only then read the file, so a
+    scene with one wrong dimension took the host's memory instead of failing; now the file's size is checked first"""
+    f = tmp_path / "v.raw"
+    f.write_bytes(bytes(16 + 20 * 12 * 9))
+    for dims, offset, msg in [((4096, 4096, 4096), 16, "too short"), ((20, 12, 10), 16, "too short"), ((20, 12, 9), 17, "too short"),
+                              ((-1, 12, 9), 16, "positive"), ((0, 12, 9), 16, "positive"), ((2 ** 31 - 1, 2 ** 31 - 1, 2 ** 31 - 1), 0, "too short")]:
+        sc = vidi_scene([str(f)], dims, "UNSIGNED_BYTE", offset=offset)
+        with pytest.raises(api.VnrAmdError, match=msg):
+            api.vnrCreateSimpleVolume(sc, "GPU")
+    sv = api.vnrCreateSimpleVolume(vidi_scene([str(f)], (20, 12, 9), "UNSIGNED_BYTE", offset=16), "GPU")
+    assert api.vnrVolumeGetDims(sv) == (20, 12, 9)

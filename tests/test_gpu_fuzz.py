@@ -800,3 +800,49 @@ def test_damaged_scene_descriptions_are_refused_by_name_or_load(oracle, tmp_path
                 f.write(f"scene-description {i} ok\n")
     assert refused > n // 10 and loaded > n // 10, (refused, loaded)
     assert len(messages) >= 8, messages
+
+
+def test_damaged_params_files_are_refused_by_name_or_load(oracle):
+    """a params.json (BSON: volume.dims + model + parameters + macrocell, network.cu:827-877) with bytes flipped, lengths overwritten or
+    its tail cut off, outside the parameter blob: refused with a message or loaded into a network that evaluates"""
+    import struct
+    n = int(os.environ.get("VNR_FUZZ_DAMAGED", "150"))
+    seed = int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 101
+    cfg = syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=9, base_resolution=4, n_hidden_layers=2)
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(16))
+    vol = api.vnrCreateNeuralVolume(cfg, sv)
+    info = api.neural_info(vol)
+    params = syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], 64, 1), seed=5)
+    api.neural_set_params_fp16(vol, params)
+    good = api.vnrNeuralVolumeSerializeParams(vol)
+    blob_at = good.find(params.tobytes())
+    assert blob_at > 0
+    outside = np.concatenate([np.arange(0, blob_at), np.arange(blob_at + params.nbytes, len(good))])
+    coords = np.random.default_rng(1).uniform(0, 1, (65, 3)).astype(np.float32)
+    want = api.neural_inference(api.vnrCreateNeuralVolume(good), coords)
+    refused, loaded, same, messages = 0, 0, 0, set()
+    for i in range(n):
+        rng = np.random.default_rng([seed, i])
+        b = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            k = rng.integers(0, 4)
+            p = min(int(outside[int(rng.integers(0, outside.size))]), len(b) - 1)      # (an earlier cut may have shortened it)
+            if k == 0: b[p] = int(rng.integers(0, 256))
+            elif k == 1: b[p] ^= 1 << int(rng.integers(0, 8))
+            elif k == 2 and p + 4 <= len(b): struct.pack_into("<i", b, p, int(rng.choice([-1, 0, 1, 5, 28, 2 ** 31 - 1, len(b), params.nbytes + 1, params.nbytes - 1, int(rng.integers(-100, 70000))])))
+            else: b = b[:max(5, p)]
+        try:
+            v2 = api.vnrCreateNeuralVolume(bytes(b))
+            out = api.neural_inference(v2, coords)
+            assert out.shape == (65,)
+            loaded += 1
+            same += int(np.array_equal(out.view(np.uint32), want.view(np.uint32)))
+        except api.VnrAmdError as e:
+            refused += 1
+            assert str(e)
+            messages.add(str(e)[:50])
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"params-file {i} ok\n")
+    assert refused > n // 4 and loaded > n // 50, (refused, loaded, same)
+    assert len(messages) >= 5, messages

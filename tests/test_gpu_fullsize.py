@@ -256,6 +256,52 @@ def test_gradients_of_the_c4_model_match_the_restatement(oracle):
     assert np.count_nonzero(got[n_mlp:][touched]) > 0.98 * touched.sum()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_bands_of_the_c4_frame_from_random_cameras_equal_the_oracle(oracle, c4_scene, monkeypatch, seed):
+    """the band test above from other places: a camera anywhere around the 1024^3 volume (direction, distance 0.7..1.6 of the bench's, field of
+    view 30..60), eight scanlines at a random height: rays hit and iterations equal the oracle's, pixels within 1e-3 (PSNR > 85 dB) of the
+    oracle's marcher driven by the oracle's network, within 1e-5 of it driven by the library's network values"""
+    rng = np.random.default_rng(1000 + seed)
+    monkeypatch.setenv("VNR_RM_N_ITERS", "24")        # read when a renderer is created (a small pixel range would otherwise take 32)
+    nv = c4_scene["nv"]
+    v = rng.normal(size=3); v /= np.linalg.norm(v)
+    if abs(v[1]) > 0.9:
+        v = np.array([0.5, 0.4, -0.77]); v /= np.linalg.norm(v)
+    base = np.linalg.norm(c4_scene["cam"]["from"])
+    frm = tuple(float(x) for x in v * base * rng.uniform(0.7, 1.6))
+    fovy = float(rng.uniform(30, 60))
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, frm, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), fovy)
+    row = int(rng.integers(300, 716))
+    lo, hi = row * 1024, (row + 8) * 1024
+    r = api.vnrCreateRenderer(nv)
+    api.vnrRendererSetTransferFunction(r, c4_scene["tfn"])
+    api.vnrRendererSetCamera(r, camera)
+    api.vnrRendererSetFramebufferSize(r, (1024, 1024))
+    api.vnrRendererSetMode(r, 5)
+    api.vnrRendererSetPixelRange(r, lo, hi)
+    api.vnrRender(r)
+    band = api.vnrRendererMapFrame(r).reshape(-1, 4)[lo:hi].copy()
+    st = api.vnrRendererGetFrameStats(r)
+    params = api.neural_get_params_fp16(nv).view(np.uint16)
+    ocfg = oracle.grid_config(16, 2, 22, 16, float(np.exp(np.log(1024 / 16.0) / 15)))
+    mo = api.volume_macrocell(nv)["max_opacity"]
+    sc = oracle.SceneHolder(1024, 1024, (1024, 1024, 1024), oracle.TfnHolder(c4_scene["colors"], c4_scene["alphas"]), mo, frm, (0, 0, 0), (0, 1, 0), fovy,
+                            pixel_range=(lo, hi))
+    n_iters = 24      # the frame does not depend on it, the iteration count does
+    ref, _, ost = oracle.render_streaming(sc, lambda c: oracle.network_inference_mt(ocfg, 64, 3, params, c), n_iters=n_iters)
+    ref = ref.reshape(-1, 4)[lo:hi]
+    err = np.abs(band - ref)
+    psnr = 10 * np.log10(1.0 / max(float((err ** 2).mean()), 1e-20))
+    print(f"\ncamera {seed}: from {tuple(round(x) for x in frm)}, fovy {fovy:.0f}, rows {row}..{row + 8}: rays hit {st['n_rays_hit']}, max err {err.max():.2e}, PSNR {psnr:.1f} dB")
+    assert st["n_rays_hit"] == ost["n_rays_hit"] > 2000
+    assert st["n_iterations"] == ost["n_iterations"]
+    assert (ref[:, 3] > 0).mean() > 0.2
+    assert err.max() < 1e-3 and psnr > 85.0
+    mine, _, _ = oracle.render_streaming(sc, lambda c: api.neural_inference(nv, c), n_iters=n_iters)
+    assert np.abs(band - mine.reshape(-1, 4)[lo:hi]).max() < 1e-5
+
+
 def test_adam_step_of_the_c4_model_matches_the_restatement(oracle):
     """one optimizer step on the full model: touched parameters move like the restated Adam (2^-10), the 99 % of the 70 M parameters a
     2000-sample batch does not touch keep their bits, the gradient blob is clear afterwards, and a second step on other samples

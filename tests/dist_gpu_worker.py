@@ -215,8 +215,15 @@ def scenario_sharded_optimizer(ctx, out):
     os.environ["VNR_AMD_INIT_SEED"] = "77"
     sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))
     model = dict(SMALL_MODEL, n_levels=6, log2_hashmap_size=14)
-    a = api.vnrCreateNeuralVolume(syn.model_config(**model), sv, online_macrocell_construction=False)
-    b = api.vnrCreateNeuralVolume(syn.model_config(**model), sv, online_macrocell_construction=False)
+    cfg = syn.model_config(**model)
+    if os.environ.get("TEST_MODEL_JSON"):      # another shape: {"model": {model_config arguments}, "encoding": {...}, "network": {...}}
+        import json
+        o = json.loads(os.environ["TEST_MODEL_JSON"])
+        cfg = syn.model_config(**o.get("model", model))
+        cfg["encoding"].update(o.get("encoding", {}))
+        cfg["network"].update(o.get("network", {}))
+    a = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+    b = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
     check(L.vnrAmdNeuralVolumeSyncReplicas(a.h))
     check(L.vnrAmdNeuralVolumeSyncReplicas(b.h))
     n = api.neural_info(a)["n_params"]

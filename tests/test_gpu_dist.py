@@ -132,6 +132,28 @@ def test_sharded_optimizer_step_equals_the_replicated_step(world, tmp_path):
         assert bool(r["refused"]) and bool(r["equal_after_gather"]) and int(r["step"]) == 6
 
 
+ODD_MODELS = [
+    # parameter counts and level offsets that are odd, not multiples of 8, or smaller than the world: the 8-aligned slices of the
+    # reduce-scatter, the all-reduced remainder and the compacting optimizer's ranges [lo, hi) that start and end inside a group of eight
+    {"model": dict(n_levels=7, n_features=1, log2_hashmap_size=10, base_resolution=5, n_hidden_layers=2), "encoding": {"type": "Tiled"}, "network": {"n_neurons": 16}},
+    {"model": dict(n_levels=3, n_features=8, log2_hashmap_size=9, base_resolution=3, n_hidden_layers=1), "encoding": {}, "network": {"n_neurons": 128}},
+    {"model": dict(n_levels=5, n_features=2, log2_hashmap_size=12, base_resolution=3, n_hidden_layers=3, per_level_scale=1.5), "encoding": {"type": "Dense"},
+     "network": {"n_neurons": 32, "activation": "Sigmoid"}},
+]
+
+
+@pytest.mark.parametrize("world,model", [(3, 0), (4, 0), (3, 1), (4, 2)])
+def test_sharded_optimizer_step_on_models_of_odd_sizes(world, model, tmp_path):
+    import json
+    res = run_ranks("sharded_optimizer", world, tmp_path, extra_env={"TEST_MODEL_JSON": json.dumps(ODD_MODELS[model])})
+    assert len({int(r["checksum"]) for r in res}) == 1
+    for r in res:
+        assert bool(np.all(r["equal"])), (int(r["rank"]), int(r["n_params"]), r["equal"])
+        assert r["moved"][0] > 0.2
+        assert bool(r["refused"]) and bool(r["equal_after_gather"]) and int(r["step"]) == 6
+    assert int(res[0]["n_params"]) % 8 != 0 or model != 0      # (the first model's count is odd: 7 levels of 125 entries)
+
+
 def test_replicas_are_synchronised_again_after_one_rank_changes_its_parameters(tmp_path):
     res = run_ranks("resync", 2, tmp_path)
     a, b = res

@@ -51,6 +51,9 @@ def parse():
     p.add_argument("--train-steps", type=int, default=1500)
     p.add_argument("--opacity-scale", type=float, default=0.06)
     p.add_argument("--camera-distance", type=float, default=1.1, help="camera distance in volume edges (oblique view)")
+    p.add_argument("--probe-collectives", action="store_true",
+                   help="internal (N > 1): meet the other ranks over RCCL, run the collective self-test, exit 0 / 3; bench.py starts itself in this "
+                        "mode in a child process first, so that a transport that fails or hangs on a new installation costs a child, not the run")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-psnr", action="store_true")
     p.add_argument("--no-alone", action="store_true", help="skip the un-timed one-stream leg (roofline.alone)")
@@ -199,12 +202,63 @@ def c5_leg(a, ctx):
             "asynchronous_refresh (vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh)": asyn, "n_gpus": ctx.world}
 
 
+def probe_collectives_child():
+    """the child of choose_transport(): RCCL first contact + every collective of the sharded paths on patterned buffers, with deadlines.
+    The ranks' children agree over their control plane, so all of them exit with the same code."""
+    try:
+        ctx = dist.init_from_env(transport="rccl")
+        ok, text = dist.self_test(deadline_s=float(os.environ.get("VNR_BENCH_SELFTEST_DEADLINE", "60")))
+        all_ok = dist.all_reduce_host([1.0 if ok else 0.0], dist.MIN)[0] >= 1.0
+        if ctx.rank == 0 or not ok:
+            print(("ok: " if ok else "FAILED: ") + " ".join(text.split()), flush=True)
+    except Exception as e:  # an init that fails outright (no librccl, a device used twice ...)
+        print("FAILED: " + " ".join(str(e).split()), flush=True)
+        all_ok = False
+    sys.stdout.flush()
+    os._exit(0 if all_ok else 3)   # no finaliser against a communicator that may hold a collective that never completes
+
+
+def choose_transport():
+    """N > 1 on an installation nobody has run before: which transport carries the collectives?  RCCL is what the design is for; the
+    host-staged shared-memory transport (csrc/dist.cpp, one node only) is slower and always works.  Unless the environment has chosen
+    (VNR_AMD_DIST_TRANSPORT), every rank first starts itself as a child in --probe-collectives mode (before this process touches the
+    GPU: the child is an ordinary fork + exec) on a rendezvous port of its own.  Children that report a failed collective, die, or
+    are still running after the limit are killed and the run goes on over shared memory, SAYING SO in its JSON line
+    (`transport_probe`); a run whose own self-test then fails still exits without a line."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or os.environ.get("VNR_AMD_DIST_TRANSPORT"):
+        return None, None
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+    env["VNR_AMD_DIST_TIMEOUT"] = env.get("VNR_AMD_DIST_TIMEOUT", "120")
+    limit = float(os.environ.get("VNR_BENCH_PROBE_LIMIT", "240"))
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-collectives"], env=env, capture_output=True, text=True, timeout=limit)
+        said = (r.stdout.strip().splitlines() or [""])[-1]
+        ok = r.returncode == 0
+        if not ok and not said:
+            said = f"FAILED: child exited with code {r.returncode}: " + " ".join(r.stderr.strip().split())[-300:]
+    except subprocess.TimeoutExpired:
+        ok, said = False, f"FAILED: no answer within {limit:.0f} s (child killed)"
+    probe = {"rccl": said[:600], "seconds": round(time.perf_counter() - t0, 1)}
+    if ok:
+        return "rccl", probe
+    probe["fallback"] = "shm: host-staged shared-memory transport (one node); the numbers of this line are NOT RCCL's"
+    print(f"[bench] rank {os.environ.get('RANK', '0')}: RCCL probe failed ({said[:300]}); continuing over shared memory", file=sys.stderr, flush=True)
+    return "shm", probe
+
+
 def main():
     a = parse()
+    if a.probe_collectives:
+        probe_collectives_child()
     if os.environ.get("VNR_BENCH_DUMP_AFTER"):  # diagnostics: where does a run that hangs under the profiler stand?
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["VNR_BENCH_DUMP_AFTER"]), exit=False, file=sys.stderr)
-    ctx = dist.init_from_env()
+    transport, transport_probe = choose_transport()
+    ctx = dist.init_from_env(transport=transport)
     if a.gpus != ctx.world:
         if ctx.rank == 0:
             print(f"warning: --gpus {a.gpus} but WORLD_SIZE={ctx.world}; using {ctx.world}", file=sys.stderr)
@@ -628,6 +682,8 @@ def main():
     if per_rank is not None:
         out["per_rank"] = per_rank
         out["collective_self_test"] = self_test
+        if transport_probe is not None:
+            out["transport_probe"] = transport_probe
     if ctx.world == 1 and not a.no_cpu_baseline:
         mc = api.volume_macrocell(nv)
         out["cpu_baseline"] = cpu_baseline(sv, nv, info, dims, (colors, alphas), cam, a.fb, mc, pls, a.hidden_layers, a.log2_hashmap_size)

@@ -260,10 +260,8 @@ def test_collective_self_test(world, transport, tmp_path):
             assert what in text and "ok" in text, text
 
 
-def test_bench_line_of_two_ranks_carries_per_rank_times(tmp_path):
-    """bench.py as the driver starts it for N = 2 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; here both ranks on this box's one GPU over the
-    host-staged transport, a small workload): the self-test runs, ONE JSON line comes from rank 0, n_gpus = 2, and it carries the per-rank
-    share / gather / training-exchange times (VERDICT r03 #7)"""
+def _bench_two_ranks(transport):
+    """bench.py as the driver starts it for N = 2, both ranks on this box's one GPU; transport None = let bench.py choose"""
     import json
     port = _free_port()
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--size", "64", "--fb", "256", "--levels", "6",
@@ -271,8 +269,13 @@ def test_bench_line_of_two_ranks_carries_per_rank_times(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ)
+        env.pop("VNR_AMD_DIST_TRANSPORT", None)
+        if transport:
+            env["VNR_AMD_DIST_TRANSPORT"] = transport
+        else:
+            env["VNR_BENCH_PROBE_LIMIT"] = "90"
         env.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
-                    "VNR_AMD_DIST_TRANSPORT": "shm", "VNR_AMD_DIST_TIMEOUT": "120", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                    "VNR_AMD_DIST_TIMEOUT": "120", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         env.pop("VNR_RM_N_ITERS", None)
         procs.append(subprocess.Popen(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=400) for p in procs]
@@ -280,12 +283,33 @@ def test_bench_line_of_two_ranks_carries_per_rank_times(tmp_path):
         assert p.returncode == 0, f"rank {rank}:\n{o[-1500:]}\n{e[-2500:]}"
     lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
     assert len(lines) == 1 and not any(l.startswith("{") for l in outs[1][0].splitlines())
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_line_of_two_ranks_carries_per_rank_times(tmp_path):
+    """bench.py as the driver starts it for N = 2 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; here both ranks on this box's one GPU over the
+    host-staged transport, a small workload): the self-test runs, ONE JSON line comes from rank 0, n_gpus = 2, and it carries the per-rank
+    share / gather / training-exchange times (VERDICT r03 #7)"""
+    d = _bench_two_ranks("shm")
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     pr = d["per_rank"]
     for k in ("share_ms", "gather_ms", "train_step_ms", "train_exchange_ms"):
         assert len(pr[k]) == 2 and all(v > 0 for v in pr[k]), (k, pr[k])
     assert "all-gather (in place" in d["collective_self_test"] and "reduce-scatter" in d["collective_self_test"]
+    assert "transport_probe" not in d          # the environment chose
+
+
+def test_bench_probes_rccl_in_a_child_and_goes_on_over_shared_memory_when_it_fails():
+    """with no transport chosen bench.py first meets the other ranks over RCCL in child processes.  Two ranks on ONE device is something
+    RCCL refuses, which makes this box a rehearsal of a new installation where RCCL does not come up: the children fail (or are killed
+    at the limit), every rank goes on over the host-staged transport, and the ONE line says so instead of silently reporting shm numbers
+    as RCCL's"""
+    d = _bench_two_ranks(None)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    tp = d["transport_probe"]
+    assert tp["rccl"].startswith("FAILED") and "shm" in tp["fallback"], tp
+    assert "shm" in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert "all-gather (in place" in d["collective_self_test"]          # the run's own self-test, over the transport it uses
 
 
 # ------------------------------------------------------------------------------------------------ asynchronous frames

@@ -176,7 +176,7 @@ static void dispatch(uint32_t F, uint32_t K_IN, const InferArgs& a, size_t n_max
 #define VNR_CASE(f, k) if (F == f && K_IN == k) return launch_one<f, k, W, MODE, GENERAL>(a, n_max, s)
   VNR_CASE(1, 16); VNR_CASE(1, 32);
   VNR_CASE(2, 16); VNR_CASE(2, 32); VNR_CASE(2, 48); VNR_CASE(2, 64);
-  VNR_CASE(4, 16); VNR_CASE(4, 32); VNR_CASE(4, 48); VNR_CASE(4, 64);
+  VNR_CASE(4, 16); VNR_CASE(4, 32); VNR_CASE(4, 48); VNR_CASE(4, 64); VNR_CASE(4, 80); VNR_CASE(4, 96); VNR_CASE(4, 112); VNR_CASE(4, 128);
   VNR_CASE(8, 16); VNR_CASE(8, 32); VNR_CASE(8, 48); VNR_CASE(8, 64); VNR_CASE(8, 80); VNR_CASE(8, 96); VNR_CASE(8, 112); VNR_CASE(8, 128);
 #undef VNR_CASE
   throw std::runtime_error("unsupported encoding shape: n_features_per_level=" + std::to_string(F) +

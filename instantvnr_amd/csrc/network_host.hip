@@ -211,7 +211,7 @@ void Network::build_layout()
   const uint32_t total_entries = grid_make_layout(cfg_, &grid_);
   in_width_ = next_multiple(cfg_.n_levels * cfg_.n_features, 16u);
   // the instances of the fused kernel (infer_kernel.h dispatch): refuse the others here, at SetModel, not at the first launch
-  const uint32_t widest = cfg_.n_features == 1 ? 32u : cfg_.n_features == 8 ? 128u : 64u;
+  const uint32_t widest = cfg_.n_features == 1 ? 32u : cfg_.n_features == 2 ? 64u : 128u;   // (1 and 2 features: all of kMaxLevels = 32 levels)
   if (in_width_ > widest)
     throw std::runtime_error("unsupported encoding shape: n_features_per_level=" + std::to_string(cfg_.n_features) + " with n_levels=" +
                              std::to_string(cfg_.n_levels) + " (encoded width " + std::to_string(in_width_) + " > " + std::to_string(widest) + ")");

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_ABS = 2.0 ** -8
 INTERP = {"Linear": 0, "Smoothstep": 1, "Nearest": 2}
-MAX_LEVELS = {1: 32, 2: 32, 4: 16, 8: 16}          # the padded encoded widths the kernels are instantiated for (infer_kernel.h dispatch)
+MAX_LEVELS = {1: 32, 2: 32, 4: 32, 8: 16}          # the padded encoded widths the kernels are instantiated for (infer_kernel.h dispatch)
 
 
 def _act64(x, a, oracle):

@@ -1595,6 +1595,20 @@ void Renderer::render()
   p.volume = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get())->decoded_data()
                                    : static_cast<SimpleVolume*>(volume_.get())->d_data();
   p.bbox_lo = volume_->clipbox.lower; p.bbox_hi = volume_->clipbox.upper;
+  // What the kernels cannot survive is refused here, for all of them: a ray whose direction is NaN in every component passes the slab
+  // test (fminf / fmaxf drop NaNs) with t in [0, 1e30] and its DDA never advances -- a frame that does not end.  from == at, an up vector
+  // along the view, a NaN field of view, a singular volume transform or a NaN clipping box all produce such rays.  (The reference
+  // renders garbage or hangs; an interactive host sends these while its user drags a slider.)
+  {
+    auto finite3 = [](vec3f v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); };
+    if (!finite3(p.cam_pos) || !finite3(p.cam_dir) || !finite3(p.cam_hor) || !finite3(p.cam_ver))
+      throw std::runtime_error("degenerate camera: position, focus, up vector and field of view do not span an image plane "
+                               "(from == at, up along the view direction, or a value that is not finite)");
+    if (!finite3(p.wto.vx) || !finite3(p.wto.vy) || !finite3(p.wto.vz) || !finite3(p.wto.p))
+      throw std::runtime_error("degenerate volume transform: the object-to-world matrix is singular or not finite");
+    if (!finite3(p.bbox_lo) || !finite3(p.bbox_hi)) throw std::runtime_error("clipping box is not finite");
+    if (!std::isfinite(density_scale_)) throw std::runtime_error("volume density scale is not finite");
+  }
   p.step = 1.0f / sampling_rate_; p.step_rcp = sampling_rate_;  // object.cpp:303-304
   p.mc_dims = mc.dims();
   const vec3f sp = mc.spacings();

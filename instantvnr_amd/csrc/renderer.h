@@ -33,7 +33,12 @@ public:
   void set_camera(const CameraData& c) { finish_pending(); camera_ = c; reset_ = true; }
   void set_transfer_function(const TransferFunctionData& t);
   void set_mode(int m) { finish_pending(); mode_ = m; reset_ = true; } // renderer.h:139-146
-  void set_sampling_rate(float r) { sampling_rate_ = r; reset_ = true; }
+  // the step of the march is 1 / rate (object.cpp:303-304): zero, a negative number, NaN or infinity have no step
+  void set_sampling_rate(float r)
+  {
+    if (!(r > 0.0f) || !(r < 3.0e38f)) throw std::runtime_error("volume sampling rate must be a positive finite number");
+    sampling_rate_ = r; reset_ = true;
+  }
   void set_density_scale(float s) { density_scale_ = s; reset_ = true; }
   void reset_accumulation() { reset_ = true; }
   void set_device_output(bool e) { finish_pending(); skip_download_ = e; }

@@ -846,3 +846,75 @@ def test_damaged_params_files_are_refused_by_name_or_load(oracle):
                 f.write(f"params-file {i} ok\n")
     assert refused > n // 4 and loaded > n // 50, (refused, loaded, same)
     assert len(messages) >= 5, messages
+
+
+# ------------------------------------------------------------------------------------------------ odd renderer parameters
+def test_odd_renderer_parameters_are_refused_or_rendered_never_fatal(oracle):
+    """what an interactive application sends while its user drags sliders: a camera at its own focus, an up vector along the view, a field
+    of view of 0 / 180 / NaN, a clipping box inside out, a value range of zero width, one-entry transfer functions, frames of one pixel,
+    empty pixel ranges, density 0 / huge / NaN, NaN anywhere -- in every rendering mode, on a dense and on a neural volume.  Every call
+    either fails with a message or returns; frames may hold anything; nothing faults or hangs."""
+    n = int(os.environ.get("VNR_FUZZ_ODD", "120"))
+    seed = int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 113
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))
+    cfg = syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
+    info = api.neural_info(nv)
+    api.neural_set_params_fp16(nv, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], 64, 1), seed=3))
+    nan, inf = float("nan"), float("inf")
+    F = [0.0, 1.0, -1.0, 1e-30, 1e30, -1e30, nan, inf, -inf, 0.5, 45.0, 16.0, 33.0]
+    refused = rendered = 0
+    messages = set()
+    for i in range(n):
+        rng = np.random.default_rng([seed, i])
+        pick = lambda pool=F: float(pool[int(rng.integers(0, len(pool)))])      # noqa: E731
+        vec = lambda: tuple(pick() if rng.uniform() < 0.08 else float(rng.normal() * 40) for _ in range(3))   # noqa: E731
+        volume = nv if rng.uniform() < 0.5 else sv
+        calls = []
+        try:
+            tfn = api.vnrCreateTransferFunction()
+            nc, na = int(rng.choice([1, 2, 3, 256])), int(rng.choice([1, 2, 3, 256]))
+            colors = rng.uniform(0, 1, (nc, 3)).astype(np.float32); alphas = rng.uniform(0, 1, na).astype(np.float32)
+            if rng.uniform() < 0.2: colors[int(rng.integers(0, nc))] = pick()
+            if rng.uniform() < 0.2: alphas[int(rng.integers(0, na))] = pick()
+            api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas)
+            api.vnrTransferFunctionSetValueRange(tfn, (pick([0.0, 0.0, 0.5, 1.0, nan, -1.0]), pick([1.0, 1.0, 0.5, 0.0, nan, inf])))
+            camera = api.vnrCreateCamera()
+            frm = vec()
+            at = frm if rng.uniform() < 0.05 else (vec() if rng.uniform() < 0.3 else (0.0, 0.0, 0.0))
+            up = (0.0, 1.0, 0.0) if rng.uniform() < 0.7 else (tuple(a - b for a, b in zip(at, frm)) if rng.uniform() < 0.25 else vec())
+            api.vnrCameraSet(camera, frm, at, up, pick([45.0, 45.0, 60.0, 30.0, 0.0, 1e-3, 179.99, 180.0, 360.0, -30.0, nan]))
+            r = api.vnrCreateRenderer(volume)
+            api.vnrRendererSetTransferFunction(r, tfn); api.vnrRendererSetCamera(r, camera)
+            size = (int(rng.choice([1, 2, 7, 64])), int(rng.choice([1, 3, 8, 48])))
+            calls.append(("size", size)); api.vnrRendererSetFramebufferSize(r, size)
+            mode = int(rng.choice([5, 6, 8, 9, 11, 12, 14, 15])) if rng.uniform() < 0.8 else int(rng.integers(4, 16))      # (4 / 7 / 10 / 13 need a decoded volume)
+            calls.append(("mode", mode)); api.vnrRendererSetMode(r, mode)
+            if rng.uniform() < 0.5:
+                rate = pick([1.0, 0.25, 8.0, 2.0, 0.5, 1e-3, 0.0, -1.0, nan, inf])
+                calls.append(("rate", rate)); api.vnrRendererSetVolumeSamplingRate(r, rate)
+            if rng.uniform() < 0.5:
+                dens = pick([1.0, 0.0, 1e-3, 100.0, 1e30, -1.0, nan, inf])
+                calls.append(("density", dens)); api.vnrRendererSetVolumeDensityScale(r, dens)
+            if rng.uniform() < 0.3:
+                lo, hi = vec(), vec()
+                calls.append(("clip", lo, hi)); api.vnrVolumeSetClippingBox(volume, tuple(x / 40 for x in lo), tuple(x / 40 for x in hi))
+            if rng.uniform() < 0.3:
+                n_px = size[0] * size[1]
+                lo = int(rng.integers(0, n_px + 1)); hi = int(rng.integers(0, n_px + 3))
+                calls.append(("range", lo, hi)); api.vnrRendererSetPixelRange(r, lo, hi)
+            for _ in range(2):
+                api.vnrRender(r)
+                img = api.vnrRendererMapFrame(r)
+                assert img.shape == (size[1], size[0], 4)
+            rendered += 1
+        except api.VnrAmdError as e:
+            refused += 1
+            assert str(e), calls
+            messages.add(str(e)[:50])
+        finally:
+            api.vnrVolumeSetClippingBox(volume, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"odd-renderer {i} {calls} ok\n")
+    assert rendered > n // 4 and refused > n // 10, (rendered, refused, messages)

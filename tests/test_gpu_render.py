@@ -861,3 +861,40 @@ def test_in_shader_path_tracing_kernel_equals_the_streaming_path_tracer(oracle, 
     for k in range(3):
         assert np.array_equal(frames[1][k], frames[0][k])
     assert frames[1][2][..., 3].min() == 1.0 and frames[1][2][..., :3].max() > 0.1
+
+
+def test_parameters_that_would_never_finish_a_frame_are_refused_by_name(scene):
+    """a ray whose direction is NaN in every component passes the slab test (fminf / fmaxf drop NaNs) with t in [0, 1e30] and its DDA never
+    advances: a frame that does not end.  A camera at its own focus, an up vector along the view, a NaN field of view, a NaN clipping
+    box, a sampling rate without a step: refused on the host, for every rendering mode, before anything is launched"""
+    nan = float("nan")
+    for frm, at, up, fovy in [((1.0, 2.0, 3.0), (1.0, 2.0, 3.0), (0.0, 1.0, 0.0), 45.0), ((0.0, 0.0, -90.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 45.0),
+                              ((0.0, 0.0, -90.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), nan), ((nan, 0.0, -90.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 45.0)]:
+        for mode in (5, 6, 14):
+            r = make_renderer(scene, scene["sv"], size=(16, 8), mode=mode)
+            cam = api.vnrCreateCamera()
+            api.vnrCameraSet(cam, frm, at, up, fovy)
+            api.vnrRendererSetCamera(r, cam)
+            with pytest.raises(api.VnrAmdError, match="degenerate camera"):
+                api.vnrRender(r)
+    r = make_renderer(scene, scene["sv"], size=(16, 8))
+    for rate in (0.0, -1.0, nan, float("inf")):
+        with pytest.raises(api.VnrAmdError, match="sampling rate"):
+            api.vnrRendererSetVolumeSamplingRate(r, rate)
+    api.vnrRendererSetVolumeDensityScale(r, nan)
+    with pytest.raises(api.VnrAmdError, match="density"):
+        api.vnrRender(r)
+    api.vnrRendererSetVolumeDensityScale(r, 1.0)
+    api.vnrVolumeSetClippingBox(scene["sv"], (0.0, nan, 0.0), (1.0, 1.0, 1.0))
+    try:
+        with pytest.raises(api.VnrAmdError, match="clipping box"):
+            api.vnrRender(r)
+    finally:
+        api.vnrVolumeSetClippingBox(scene["sv"], (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    api.vnrRender(r)                                   # and the renderer is still good
+    # odd but finite: a field of view of zero, an inverted clipping box, a camera inside the volume looking out
+    cam = api.vnrCreateCamera()
+    api.vnrCameraSet(cam, (0.0, 0.0, -90.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.0)
+    api.vnrRendererSetCamera(r, cam)
+    api.vnrRender(r)
+    assert np.isfinite(api.vnrRendererMapFrame(r)).all()

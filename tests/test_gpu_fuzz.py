@@ -431,10 +431,27 @@ def test_randomly_drawn_models_render_alike_through_the_in_shader_and_the_stream
 
 
 # ------------------------------------------------------------------------------------------------ dense volumes: sampling, macrocells, DDA, camera
+
+def _clipbox_as_the_library_computes_it(xfm, lower, upper, dims):
+    """vnrVolumeSetClippingBox (api.cpp:322-338): xfmPoint(transform.inverse(), corner - dims / 2), in fp32 and in the library's order of
+    operations (csrc/common.h affine_inverse / xfm_point, built with -ffp-contract=off), so that the oracle clips at the same planes"""
+    f = np.float32
+    vx, vy, vz, p = (np.array(xfm[3 * i:3 * i + 3], f) for i in range(4))
+    cross = lambda a, b: np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], f)     # noqa: E731
+    dot = lambda a, b: f(f(a[0] * b[0] + a[1] * b[1]) + a[2] * b[2])                                                          # noqa: E731
+    c0, c1, c2 = cross(vy, vz), cross(vz, vx), cross(vx, vy)
+    r = f(1.0) / dot(vx, c0)
+    ox, oy, oz = r * np.array([c0[0], c1[0], c2[0]], f), r * np.array([c0[1], c1[1], c2[1]], f), r * np.array([c0[2], c1[2], c2[2]], f)
+    xv = lambda v: (v[0] * ox + v[1] * oy) + v[2] * oz                                                                           # noqa: E731
+    op = -xv(p)
+    half = np.array(dims, f) / f(2.0)
+    return tuple((xv(np.array(c, f) - half) + op).astype(f) for c in (lower, upper))
+
 def test_randomly_drawn_scenes_on_a_dense_volume_match_the_oracle(oracle):
     """the march itself, with the network out of the way: volumes of random ragged shapes (5..70 voxels an axis), transfer functions of random
     lengths and contents, cameras anywhere around (one in five INSIDE the volume), any field of view, frame shape, sampling rate and density
-    scale, rendering modes 4 / 5 (ray marching) and 7 / 8 (gradient shading).  Sampling and macrocells bit-exact; frames within 2e-4 of the
+    scale, the volume scaled per axis and clipped to a box (in either order), rendering modes 4 / 5 (ray marching) and 7 / 8 (gradient
+    shading).  Sampling and macrocells bit-exact; frames within 2e-4 of the
     oracle's (device powf against glibc's), hit rays and iterations equal for the streaming modes."""
     n = int(os.environ.get("VNR_FUZZ_SCENES", "60"))
     rng = np.random.default_rng(int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 47)
@@ -476,6 +493,31 @@ def test_randomly_drawn_scenes_on_a_dense_volume_match_the_oracle(oracle):
             api.vnrCameraSet(camera, frm, at, (0.0, 1.0, 0.0), fovy)
             rate, density = float(rng.choice([0.5, 1.0, 1.0, 2.0, 3.0])), float(rng.choice([0.3, 1.0, 1.0, 4.0]))
             d.update(frm=frm, at=at, fovy=fovy, rate=rate, density=density, tfn=(nc, na))
+            # vnrVolumeSetScaling (api.cpp:340-351: transform = scale(s) * transform) and vnrVolumeSetClippingBox (api.cpp:322-338: the box
+            # is given in voxels of the centred volume and taken through the inverse of the CURRENT transform), in either order
+            fdims = np.array(dims, np.float32)
+            scale = np.ones(3, np.float32)
+            bbox = ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+            T = lambda sc_: np.array([sc_[0] * fdims[0], 0, 0, 0, sc_[1] * fdims[1], 0, 0, 0, sc_[2] * fdims[2],                   # noqa: E731
+                                      sc_[0] * (-fdims[0] / 2), sc_[1] * (-fdims[1] / 2), sc_[2] * (-fdims[2] / 2)], np.float32)
+            order = int(rng.integers(0, 4))        # 0 neither, 1 scaling, 2 box then scaling, 3 scaling then box
+            if order in (2, 3) or rng.uniform() < 0.2:
+                a_, b_ = np.sort(rng.uniform(0, 1, (2, 3)), axis=0)
+                b_ = np.maximum(b_, a_ + 0.15)
+                lower, upper = (a_ * fdims).astype(np.float32), (np.minimum(b_, 1.0) * fdims).astype(np.float32)
+            if order == 2:
+                api.vnrVolumeSetClippingBox(sv, tuple(lower), tuple(upper))
+                bbox = tuple(tuple(float(q) for q in c) for c in _clipbox_as_the_library_computes_it(T(scale), lower, upper, dims))
+            if order in (1, 2, 3):
+                scale = rng.uniform(0.5, 2.0, 3).astype(np.float32)
+                api.vnrVolumeSetScaling(sv, tuple(float(q) for q in scale))
+            if order == 3:      # the same box of the volume, said in the coordinates of the scaled volume
+                half = fdims / np.float32(2)
+                lo_w, hi_w = ((lower - half) * scale + half).astype(np.float32), ((upper - half) * scale + half).astype(np.float32)
+                api.vnrVolumeSetClippingBox(sv, tuple(lo_w), tuple(hi_w))
+                bbox = tuple(tuple(float(q) for q in c) for c in _clipbox_as_the_library_computes_it(T(scale), lo_w, hi_w, dims))
+            xfm = T(scale)
+            d.update(order=order, scale=tuple(float(q) for q in scale), bbox=bbox)
             r = api.vnrCreateRenderer(sv)
             api.vnrRendererSetTransferFunction(r, tfn); api.vnrRendererSetCamera(r, camera); api.vnrRendererSetFramebufferSize(r, size)
             api.vnrRendererSetMode(r, mode)
@@ -490,7 +532,7 @@ def test_randomly_drawn_scenes_on_a_dense_volume_match_the_oracle(oracle):
             mo = oracle.macrocell_max_opacity(otfn, vr)
             assert np.array_equal(mc["max_opacity"], mo), "macrocell opacities"
             sc = oracle.SceneHolder(size[0], size[1], dims, otfn, mo, frm, at, (0, 1, 0), fovy, sampling_rate=rate, density_scale=density,
-                                    shading_mode=1 if mode in (7, 8) else 0)
+                                    shading_mode=1 if mode in (7, 8) else 0, bbox=bbox, xfm=xfm)
             if mode in (5, 8):
                 want, _, ost = oracle.render_streaming(sc, lambda q: oracle.sample_volume(vol, q, nodal=True))
                 assert st["n_rays_hit"] == ost["n_rays_hit"], ("rays hit", st["n_rays_hit"], ost["n_rays_hit"])

@@ -62,6 +62,26 @@ def test_take_samples_are_uniform_and_consistent(oracle, scene):
     assert not np.array_equal(c[:1024], c2)   # the stream advances between calls
 
 
+def test_take_samples_follow_the_pcg32_stream_call_after_call(oracle):
+    """StaticSampler::take_samples (neural_sampler.cu:130-164): p = lower + u (upper - lower) with u the next three floats of pcg32(seed
+    1337, tcnn's default sequence); ragged batch sizes, a sub-box, a ragged volume: coordinates and values bit for bit, and the stream
+    goes on where the last call stopped"""
+    rng = np.random.default_rng(4)
+    vol = rng.uniform(0, 1, (19, 37, 50)).astype(np.float32)
+    lo_, hi_ = np.float32(vol.min()), np.float32(vol.max())
+    norm = np.clip((vol - lo_) / (hi_ - lo_), np.float32(0), np.float32(1)).astype(np.float32)
+    sv = api.vnrCreateSimpleVolume(vol)
+    offset = 0
+    for n, lower, upper in [(1000, (0, 0, 0), (1, 1, 1)), (1, (0, 0, 0), (1, 1, 1)), (4097, (0.1, 0.2, 0.3), (0.9, 0.5, 0.31)), (63, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))]:
+        c, v = api.simple_volume_take_samples(sv, n, lower, upper)
+        u = oracle.pcg32_floats(3 * n, offset, 1337, 0xda3e39cb94b95bdb).reshape(n, 3)
+        lo, hi = np.array(lower, np.float32), np.array(upper, np.float32)
+        want = (lo + u * (hi - lo)).astype(np.float32)
+        assert np.array_equal(c, want), (n, offset)
+        assert np.array_equal(v, oracle.sample_volume(norm, c, nodal=False))
+        offset += 3 * n
+
+
 def test_macrocell_bit_exact(oracle, scene):
     mc = api.volume_macrocell(scene["sv"])
     vr = oracle.macrocell_compute_implicit(scene["vol"])

@@ -293,6 +293,9 @@ def draw_scene(rng):
     d.update(mode=int(rng.choice([5, 5, 8])), size=(int(rng.integers(17, 141)), int(rng.integers(9, 101))),
              cam_from=tuple(float(x) for x in v * 32 * rng.uniform(1.1, 2.6)), fovy=float(rng.uniform(25, 70)),
              sampling_rate=float(rng.choice([0.5, 1.0, 1.0, 2.0])), density_scale=float(rng.choice([1.0, 1.0, 0.5, 3.0])))
+    d["scale"] = tuple(float(np.float32(q)) for q in rng.uniform(0.6, 1.7, 3)) if rng.uniform() < 0.5 else (1.0, 1.0, 1.0)
+    lo = rng.uniform(0, 0.5, 3); hi = np.minimum(lo + rng.uniform(0.3, 0.8, 3), 1.0)
+    d["clip"] = (tuple(float(np.float32(q * 32)) for q in lo), tuple(float(np.float32(q * 32)) for q in hi)) if rng.uniform() < 0.4 else None
     return d
 
 
@@ -326,6 +329,16 @@ def check_frame(oracle, d, seed):
     api.vnrRendererSetMode(ren, d["mode"])
     api.vnrRendererSetVolumeSamplingRate(ren, d["sampling_rate"])
     api.vnrRendererSetVolumeDensityScale(ren, d["density_scale"])
+    # the neural volume scaled per axis and clipped to a box (the march is the dense volumes'; the sweep of dense scenes holds both to 2e-4)
+    fd = np.array((32, 32, 32), np.float32)
+    xfm = np.array([fd[0] * d["scale"][0], 0, 0, 0, fd[1] * d["scale"][1], 0, 0, 0, fd[2] * d["scale"][2],
+                    d["scale"][0] * (-fd[0] / 2), d["scale"][1] * (-fd[1] / 2), d["scale"][2] * (-fd[2] / 2)], np.float32)
+    bbox = ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    if d["scale"] != (1.0, 1.0, 1.0):
+        api.vnrVolumeSetScaling(nv, d["scale"])
+    if d["clip"] is not None:
+        api.vnrVolumeSetClippingBox(nv, d["clip"][0], d["clip"][1])
+        bbox = tuple(tuple(float(q) for q in c) for c in _clipbox_as_the_library_computes_it(xfm, d["clip"][0], d["clip"][1], (32, 32, 32)))
     api.vnrRender(ren)
     img = api.vnrRendererMapFrame(ren).copy()
     ocfg = oracle.grid_config(L, F, d["log2T"], d["base"], d["pls"], INTERP[d["interp"]], d["qt"],
@@ -334,7 +347,8 @@ def check_frame(oracle, d, seed):
     code = oracle.act_code(d["act"], d["out_act"])
     net = lambda c: oracle.network_inference(ocfg, W, H, params.view(np.uint16), c, activation=code)   # noqa: E731
     sc = oracle.SceneHolder(d["size"][0], d["size"][1], (32, 32, 32), oracle.TfnHolder(colors, alphas), mo, d["cam_from"], (0, 0, 0), (0, 1, 0),
-                            d["fovy"], sampling_rate=d["sampling_rate"], density_scale=d["density_scale"], shading_mode=1 if d["mode"] == 8 else 0)
+                            d["fovy"], sampling_rate=d["sampling_rate"], density_scale=d["density_scale"], shading_mode=1 if d["mode"] == 8 else 0,
+                            bbox=bbox, xfm=xfm)
     ref, _, _ = oracle.render_streaming(sc, net)
     assert img.shape == ref.shape, (img.shape, ref.shape)
     assert np.isfinite(img).all(), "frame finite"

@@ -10,11 +10,6 @@
 
 namespace vnr {
 
-static const Json& null_json()
-{
-  static Json j;
-  return j;
-}
 
 const Json& Json::at(const std::string& key) const
 {

@@ -1008,3 +1008,39 @@ def test_odd_renderer_parameters_are_refused_or_rendered_never_fatal(oracle):
             with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
                 f.write(f"odd-renderer {i} {calls} ok\n")
     assert rendered > n // 4 and refused > n // 10, (rendered, refused, messages)
+
+
+# ------------------------------------------------------------------------------------------------ marching cubes
+def test_randomly_drawn_volumes_give_the_restatement_s_triangles(oracle):
+    """vnrMarchingCube (core/marching_cube.cu) on ragged volumes (2..40 voxels an axis, incl. a single layer of cells), smooth fields,
+    noise (every ambiguous case) and data quantised to a few levels with the isovalue ON a level (ties in every comparison): the same
+    cells in the same order with the same bits as oracle/mc_oracle.py"""
+    from oracle import mc_oracle
+    n = int(os.environ.get("VNR_FUZZ_MC", "30"))
+    seed = int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 131
+    total = 0
+    for i in range(n):
+        rng = np.random.default_rng([seed, i])
+        dims = tuple(int(v) for v in rng.integers(2, 41, 3))             # (nz, ny, nx)
+        kind = int(rng.integers(0, 3))
+        z, y, x = np.meshgrid(*[np.linspace(0, 1, q) for q in dims], indexing="ij")
+        k = rng.uniform(1, 9, 3); ph = rng.uniform(0, 6.28, 3)
+        f = 0.5 + 0.5 * np.sin(k[0] * x + ph[0]) * np.sin(k[1] * y + ph[1]) * np.sin(k[2] * z + ph[2])
+        if kind == 1:
+            f = rng.uniform(0, 1, dims)
+        f = ((f - f.min()) / max(f.max() - f.min(), 1e-9)).astype(np.float32)
+        iso = float(rng.uniform(0.05, 0.95))
+        if kind == 2:                                                      # a few levels, the isovalue on one of them
+            levels = int(rng.integers(3, 9))
+            f = (np.round(f * (levels - 1)) / np.float32(levels - 1)).astype(np.float32)
+            iso = float(np.float32(int(rng.integers(1, levels - 1)) / np.float32(levels - 1))) if levels > 2 else 0.5
+        f[tuple(rng.integers(0, q) for q in dims)] = 1.0; f[tuple(rng.integers(0, q) for q in dims)] = 0.0   # min / max stay 0 / 1: the library's normalisation is the identity
+        if f.min() != 0.0 or f.max() != 1.0:
+            continue
+        sv = api.vnrCreateSimpleVolume(f)
+        got = api.vnrMarchingCube(sv, iso)
+        want = mc_oracle.marching_cubes(f, iso)
+        assert got.shape == want.shape, (i, dims, kind, iso, got.shape, want.shape)
+        assert np.array_equal(got, want), (i, dims, kind, iso)
+        total += got.shape[0]
+    assert total > 1000 * max(1, n // 10), total

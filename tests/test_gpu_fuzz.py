@@ -1044,3 +1044,55 @@ def test_randomly_drawn_volumes_give_the_restatement_s_triangles(oracle):
         assert np.array_equal(got, want), (i, dims, kind, iso)
         total += got.shape[0]
     assert total > 1000 * max(1, n // 10), total
+
+
+# ------------------------------------------------------------------------------------------------ out-of-core sampler
+def test_randomly_drawn_files_sample_like_the_oracle_out_of_core(oracle, tmp_path):
+    """the out-of-core training sampler (neural_sampler.cpp:377-668, 1043-1127) on files of random shapes (1..9 x 5..90 x 8..300 voxels:
+    slab geometry, ghost layers and the ragged last slab all move), every voxel type, header offsets, resident / replaced slab counts,
+    ragged batch sizes and sub-boxes: slab geometry equal to the oracle's, and with the library's slot table handed to the oracle the
+    coordinates and values of every batch bit for bit"""
+    from test_gpu_ooc import SEED, STREAM
+    n = int(os.environ.get("VNR_FUZZ_OOC", "20"))
+    seed = int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 149
+    for i in range(n):
+        rng = np.random.default_rng([seed, i])
+        dtype = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64][int(rng.integers(0, 8))]
+        shape = (int(rng.integers(1, 10)), int(rng.integers(5, 91)), int(rng.integers(8, 301)))      # (nz, ny, nx)
+        header = int(rng.choice([0, 0, 16, 24, 513]))
+        if np.issubdtype(dtype, np.integer):
+            ii = np.iinfo(dtype)
+            vol = rng.integers(ii.min, ii.max, shape, dtype=dtype)
+            vr = (float(ii.min) + 2.0, float(ii.max) - 7.0)
+        else:
+            vol = rng.normal(0, 1, shape).astype(dtype)
+            vr = (-1.25, 1.75)
+        path = tmp_path / f"v{i}.raw"
+        with open(path, "wb") as f:
+            f.write(b"\xab" * header); f.write(vol.tobytes())
+        dims = shape[::-1]
+        g = oracle.ooc_geometry(dims, dtype)
+        n_blocks = int(rng.integers(2, 41))
+        n_conc = int(rng.integers(1, n_blocks + 1))
+        d = dict(i=i, dtype=np.dtype(dtype).name, dims=dims, header=header, n_blocks=n_blocks, n_concurrent=n_conc)
+        sv = api.vnrCreateSimpleVolumeOutOfCore(path, dims, dtype, vr, offset=header, n_concurrent_blocks=n_conc, n_blocks=n_blocks)
+        info = api.out_of_core_info(sv)
+        assert info["block_dims"] == tuple(g.block_dims) and info["block_index_space"] == tuple(g.index_space), d
+        assert info["block_size_aligned"] == g.block_size_aligned, d
+        offset = 0
+        for step in range(3):
+            nb = int(rng.choice([1, 63, 1000, 4097]))
+            blocks = api.out_of_core_blocks(sv)
+            if rng.uniform() < 0.5:
+                lower, upper = (0, 0, 0), (1, 1, 1)
+            else:
+                a_, b_ = np.sort(rng.uniform(0, 1, (2, 3)), axis=0)
+                lower, upper = tuple(float(np.float32(q)) for q in a_), tuple(float(np.float32(q)) for q in b_)
+            c, v = api.simple_volume_take_samples(sv, nb, lower, upper)
+            r = oracle.pcg32_floats(5 * nb, offset, SEED, STREAM)
+            wc, wv, bad = oracle.OocSlabSet(vol, blocks).sample(vr, r[:3 * nb].reshape(nb, 3), r[3 * nb:4 * nb], r[4 * nb:], lower, upper)
+            assert bad == 0, d
+            assert np.array_equal(c, wc), (d, step, "coordinates")
+            assert np.array_equal(v, wv), (d, step, "values")
+            offset += 5 * nb
+        os.remove(path)

@@ -1096,3 +1096,6 @@ def test_randomly_drawn_files_sample_like_the_oracle_out_of_core(oracle, tmp_pat
             assert np.array_equal(v, wv), (d, step, "values")
             offset += 5 * nb
         os.remove(path)
+        if os.environ.get("VNR_FUZZ_LOG"):
+            with open(os.environ["VNR_FUZZ_LOG"], "a") as f:
+                f.write(f"ooc {d} ok\n")

@@ -464,7 +464,7 @@ def _clipbox_as_the_library_computes_it(xfm, lower, upper, dims):
 def scene_draw(oracle, seed, i, verbose=False):
     """one draw of the dense-scene sweep, from its own generator (replayable alone: VNR_FUZZ_ONLY=<i>,<i> with -s prints what differs)"""
     rng = np.random.default_rng([seed, i])
-    dims = tuple(int(v) for v in rng.integers(5, 71, 3))          # (nx, ny, nz)
+    dims = tuple(int(v) if rng.uniform() < 0.9 else int(rng.integers(1, 5)) for v in rng.integers(5, 71, 3))          # (nx, ny, nz); one axis in ten of 1..4 voxels
     mode = int(rng.choice([4, 5, 7, 8, 4, 5, 7, 8, 10, 11, 13, 14]))
     size = (int(rng.integers(9, 150)), int(rng.integers(9, 110)))
     inside = rng.uniform() < 0.2
@@ -475,7 +475,7 @@ def scene_draw(oracle, seed, i, verbose=False):
     k = rng.uniform(1.0, 7.0, 6); ph = rng.uniform(0, 6.28, 3)
     vol = (0.5 + 0.5 * np.sin(k[0] * x + k[1] * y + ph[0]) * np.cos(k[2] * y + k[3] * z + ph[1]) * np.sin(k[4] * z + k[5] * x + ph[2])).astype(np.float32)
     vol += rng.normal(0, 0.02, vol.shape).astype(np.float32)
-    if rng.uniform() < 0.5:                                   # an empty slab on one side
+    if rng.uniform() < 0.5 and nx >= 4:                       # an empty slab on one side
         vol[:, :, : max(1, nx // 4)] = vol.min()
     sv = api.vnrCreateSimpleVolume(vol)
     lo, hi = np.float32(vol.min()), np.float32(vol.max())     # the reference's load-time normalisation (neural_sampler.cpp:176-210)

@@ -220,6 +220,14 @@ def check(oracle, d, seed):
             noise_rel = np.linalg.norm(w - x) / np.linalg.norm(w) if np.isfinite(x).all() else 0.0
             noise_abs = np.abs(w - x).max() if np.isfinite(x).all() else 0.0
             rel = np.linalg.norm(g - w) / np.linalg.norm(w)
+            if os.environ.get("VNR_FUZZ_VERBOSE") and name == "grid" and rel >= 3e-2:
+                lay = oracle.grid_layout(ocfg)
+                print("draw", d, "grid rel", rel, "max |w|", np.abs(w).max(), "max |g - w|", np.abs(g - w).max())
+                for l in range(d["L"]):
+                    a0, a1 = int(lay["offsets"][l]) * F, int(lay["offsets"][l + 1]) * F
+                    wl_, gl_ = w[a0:a1], g[a0:a1]
+                    print("   level", l, "entries", (a1 - a0) // F, "|w|", float(np.linalg.norm(wl_)), "rel", float(np.linalg.norm(gl_ - wl_) / max(np.linalg.norm(wl_), 1e-30)),
+                          "max|w|", float(np.abs(wl_).max()), "max|g|", float(np.abs(gl_).max()))
             assert rel < max(3e-2, noise_rel), (name, rel, noise_rel)
             assert np.abs(g - w).max() < max(6e-2 * np.abs(w).max(), 2 * noise_abs), (name, np.abs(g - w).max(), np.abs(w).max(), noise_abs)
         last = grads[n_mlp - 16 * W:n_mlp].reshape(16, W)

@@ -703,7 +703,7 @@ def optimizer_draw(oracle, seed, i, verbose=False):
     api.neural_set_params_fp16(vol, params)
     master = params.astype(np.float64); m = np.zeros(N); v = np.zeros(N); steps = np.zeros(N)
     lr, step_no = np.float32(opt["lr"]), 0
-    history, slack = [], np.zeros(N)
+    history, slack, tied = [], np.zeros(N), np.zeros(N, bool)
     for step in range(6):
         g = np.zeros(N, np.float32)
         pick = rng.random(N) < (0.9 if step == 3 else 0.15)
@@ -735,6 +735,19 @@ def optimizer_draw(oracle, seed, i, verbose=False):
         slack = slack + 1e-4 * np.abs(b - before.view(np.float16).astype(np.float64))      # (it stays with the parameter over the following steps)
         ulp = np.maximum(ulp, slack)
         off = a != b
+        # a parameter whose fp64 master lies within fp32 rounding of the midpoint of two halves rounds either way.  That is not rare here: one
+        # gradient followed by none makes Adam's step a constant (m / sqrt(v) = (1 - b1) / sqrt(1 - b2) whatever the gradient), and when
+        # that constant is k + 1/2 ulps of a binade every parameter of the binade sits on a tie (draw 151 of seed 505: 64 of 512)
+        tied = tied | (off & (np.abs(master - (a + b) / 2) <= 1e-5 * np.abs(master)))    # (and stays an ulp apart in the steps that follow)
+        off = off & ~tied
+        if verbose:
+            print("draw", i, "step", step, "lr", float(lr), "an ulp off: all %.4f  mlp %.4f  grid %.4f  (touched grid entries %.3f)" %
+                  (off.mean(), off[:n_mlp].mean(), off[n_mlp:].mean() if N > n_mlp else 0.0, (g[n_mlp:] != 0).mean() if N > n_mlp else 0.0), "N", N, "n_mlp", n_mlp)
+        if verbose and off.mean() > 0.01:
+            for k in np.flatnonzero(off)[:4]:
+                print("   off by an ulp: element", int(k), "hip", a[k], "restatement", b[k], "fp64 master", master[k], "before", float(before[k:k + 1].view(np.float16)[0]))
+                for s_, (g_, (ma, m_, v_, st_), lr_) in enumerate(history):
+                    print("      step", s_, "g", g_[k], "master", ma[k], "m", m_[k], "v", v_[k], "steps", st_[k], "lr", lr_)
         if verbose and (np.abs(a - b) > ulp).any():
             k = int(np.argmax(np.abs(a - b) / ulp))
             print("draw", d, "step", step, "element", k, "of", N, "(n_mlp", n_mlp, ") hip", a[k], "restatement", b[k], "fp64 master", master[k],
@@ -742,7 +755,7 @@ def optimizer_draw(oracle, seed, i, verbose=False):
             for s_, (g_, (ma, m_, v_, st_), lr_) in enumerate(history):
                 print("   step", s_, "g", g_[k], "master", ma[k], "m", m_[k], "v", v_[k], "steps", st_[k], "lr", lr_)
         assert (np.abs(a - b) <= ulp).all(), (d, "more than an ulp", step, float(np.abs(a - b).max()), int((np.abs(a - b) > ulp).sum()))
-        assert off.mean() < 2e-3 + 0.5 * opt["lr"], (d, "fraction of parameters an ulp off", step, float(off.mean()))   # (the same 3e-5 of a step of ~lr against a half's ulp)
+        assert off.sum() <= max(3, (2e-3 + 0.5 * opt["lr"]) * N), (d, "fraction of parameters an ulp off", step, float(off.mean()), int(off.sum()))   # (the same 3e-5 of a step of ~lr against a half's ulp)
     assert api.vnrNeuralVolumeGetTrainingStep(vol) == 6
     assert np.all(api.neural_gradients(vol) == 0), "gradients cleared"
     return d

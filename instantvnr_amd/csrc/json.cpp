@@ -47,7 +47,10 @@ bool Json::as_bool() const
 int64_t Json::as_int() const
 {
   if (type_ == Int) return i_;
-  if (type_ == Double) return (int64_t)d_;
+  if (type_ == Double) {   // (a conversion of a value that an int64 cannot hold is undefined: 1e30 for a dimension is an error, not INT64_MIN)
+    if (!(d_ > -9.2e18 && d_ < 9.2e18)) throw std::runtime_error("json: number out of range for an integer");
+    return (int64_t)d_;
+  }
   if (type_ == Bool) return b_ ? 1 : 0;
   throw std::runtime_error("json: type must be number");
 }

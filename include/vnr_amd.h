@@ -239,6 +239,14 @@ float* vnrAmdNeuralVolumeGradients(vnrAmdVolume, size_t* count);
 int    vnrAmdNeuralVolumeTrainEnd(vnrAmdVolume, float grad_scale, int fast_mode);
 /* forward + backward on a caller-provided batch (same kernels as TrainBegin, no sampling): fills Gradients() */
 int    vnrAmdNeuralVolumeForwardBackward(vnrAmdVolume, size_t n, const float* d_coords, const float* d_targets);
+/* Inspection of the last ForwardBackward / TrainBegin (tests/diag/grad_hammer.py; passive: no other call depends on them).
+ * TrainingBuffer: device pointer + size of 0 the fp16 gradient blob, 1 dL/dfeatures [n][padded_width] fp16, 2 the encoded features,
+ * 3 the hidden activations.  RescatterGridGradients: clears the hash-grid part of the blob and repeats the grid backward alone on the
+ * stored dL/dfeatures (same d_coords as the ForwardBackward it repeats).  GradientDistance: out4 = {sum (g - ref)^2, sum ref^2} over
+ * the MLP part, then over the grid part, against an fp16 reference blob on the device, reduced on the device on the training stream. */
+int    vnrAmdNeuralVolumeTrainingBuffer(vnrAmdVolume, int which, const void** d_ptr, size_t* bytes);
+int    vnrAmdNeuralVolumeRescatterGridGradients(vnrAmdVolume, size_t n, const float* d_coords);
+int    vnrAmdNeuralVolumeGradientDistance(vnrAmdVolume, const uint16_t* d_reference, double* out4);
 int    vnrAmdNeuralVolumeSetSamplerSeed(vnrAmdVolume, uint64_t seed, uint64_t stream_id);
 int    vnrAmdNeuralVolumeSetInitSeed(vnrAmdVolume, uint64_t seed); /* reference seeds with time(NULL), tcnn_network.h:209 */
 

@@ -147,6 +147,9 @@ def lib():
     sig("vnrAmdNeuralVolumeGradients", P, P, C.POINTER(SZ))
     sig("vnrAmdNeuralVolumeTrainEnd", I, P, F, I)
     sig("vnrAmdNeuralVolumeForwardBackward", I, P, SZ, P, P)
+    sig("vnrAmdNeuralVolumeTrainingBuffer", I, P, I, C.POINTER(P), C.POINTER(SZ))
+    sig("vnrAmdNeuralVolumeRescatterGridGradients", I, P, SZ, P)
+    sig("vnrAmdNeuralVolumeGradientDistance", I, P, P, C.POINTER(C.c_double))
     sig("vnrAmdNeuralVolumeSetSamplerSeed", I, P, U64, U64)
     sig("vnrAmdNeuralVolumeSetInitSeed", I, P, U64)
     sig("vnrAmdVolumeSetClippingBox", I, P, FP, FP)

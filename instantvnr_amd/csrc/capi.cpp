@@ -622,6 +622,23 @@ int vnrAmdNeuralVolumeForwardBackward(vnrAmdVolume v, size_t n, const float* d_c
 {
   return guarded([&]() { as_neural(v)->forward_backward(d_coords, d_targets, n); });
 }
+int vnrAmdNeuralVolumeTrainingBuffer(vnrAmdVolume v, int which, const void** d_ptr, size_t* bytes)
+{
+  return guarded([&]() {
+    size_t b = 0;
+    const void* p = as_neural(v)->network().training_buffer(which, &b);
+    if (d_ptr) *d_ptr = p;
+    if (bytes) *bytes = b;
+  });
+}
+int vnrAmdNeuralVolumeRescatterGridGradients(vnrAmdVolume v, size_t n, const float* d_coords)
+{
+  return guarded([&]() { NeuralVolume* nv = as_neural(v); nv->network().rescatter_grid_gradients(d_coords, n, nv->stream); });
+}
+int vnrAmdNeuralVolumeGradientDistance(vnrAmdVolume v, const uint16_t* d_reference, double* out4)
+{
+  return guarded([&]() { NeuralVolume* nv = as_neural(v); nv->network().gradient_distance(d_reference, out4, nv->stream); });
+}
 int vnrAmdNeuralVolumeSetSamplerSeed(vnrAmdVolume v, uint64_t seed, uint64_t stream_id)
 {
   return guarded([&]() {

@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256) compose_kernel(const RenderParams p, cons
   if (p.tfn_in_lds) {
     vec4f* s_colors = (vec4f*)s_tfn;
     float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
-    tfn_merged = tfn_tables_to_lds(p.tfn, s_colors, s_alphas, !(p.debug_flags & 32u));
+    tfn_merged = tfn_tables_to_lds(p.tfn, s_colors, s_alphas, !(dbg(p) & 32u));
     __syncthreads();
     lds_colors = (tfn_lds_colors_t)s_colors;
     lds_alphas = (tfn_lds_alphas_t)s_alphas;

@@ -1,5 +1,7 @@
-// in_shader.h — the in-shader ray marcher (rendering modes 6, 9, 12) and path tracer (mode 15) on a neural volume.  Part of render.hip's translation unit
-// (included there: it uses RenderParams and the marcher's device helpers), kept in a file of its own for reading.
+// in_shader.h — the in-shader ray marcher (rendering modes 6, 9, 12) and path tracer (mode 15) on a neural volume: kernel templates over
+// the encoding shape (F, padded width), the FullyFusedMLP width W and the kernel kind (GENERAL: grid_device.h), instantiated per width
+// and kind in in_shader_w{16,32,64,128}[g].hip (round 5; the reference instantiates widths 16 / 32 / 64 x F in {1, 2, 4, 8},
+// core/renderer/method_raymarching.cu:1192-1244, and refuses 128 at :1210, which comes free with the template here).
 //
 // Reference: network_raymarching_traceray / _transmittance / _iterator (core/renderer/method_raymarching.cu:310-356, 981-1128) with
 // DeviceNeuralVolume::sample (core/networks/tcnn_impl.cu:34-102): one thread per pixel walks its ray to the end, and every step of
@@ -20,6 +22,10 @@
 // exact macrocell those samples classify to zero opacity, and which threads share a block is an accident of the launch.  Empty
 // cells are skipped here, as in the streaming modes.
 #pragma once
+
+#include "infer_tile.h"
+#include "march_device.h"
+#include "pt_device.h"
 
 namespace vnr {
 
@@ -93,7 +99,7 @@ __device__ __forceinline__ void walk_consume(RayWalk& w)
 constexpr int kInShaderStatSlots = 64;   // statistics are summed per block and spread over this many addresses (one address serialises)
 
 // SHADE: M_NONE (mode 6), M_GRADIENT (mode 9), M_SSH (mode 12: camera walk, then a shadow walk from the strongest sample)
-template <int F, int K_IN, int SHADE>
+template <int F, int K_IN, int W, bool GENERAL, int SHADE>
 __global__ void __launch_bounds__(256) in_shader_kernel(const RenderParams p, const TileNet net, unsigned long long* __restrict__ stat_samples,
                                                         uint32_t* __restrict__ stat_hits)
 {
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(256) in_shader_kernel(const RenderParams p, co
         t = (1.0f - w.jitter) * w.tx + w.jitter * w.ty;   // lerp(jitter, t0, t1), instantvnr_types.h:162-166
         c = w.o + t * w.d;
       }
-      const float v = eval_tile<F, K_IN>(net, lds, rsrc, c.x, c.y, c.z);
+      const float v = eval_tile<F, K_IN, W, GENERAL>(net, lds, rsrc, c.x, c.y, c.z);
       float fgx = 0.0f, fgy = 0.0f, fgz = 0.0f;
       vec3f stp = p.grad_step;
       if (SHADE == M_GRADIENT) {  // sampleGradient (raytracing.h:128-143): forward differences, a step that would leave [0, 1] flipped
@@ -173,9 +179,9 @@ __global__ void __launch_bounds__(256) in_shader_kernel(const RenderParams p, co
           if (c.y + stp.y > 1.0f - FLT_EPSILON) stp.y *= -1.0f;
           if (c.z + stp.z > 1.0f - FLT_EPSILON) stp.z *= -1.0f;
         }
-        fgx = eval_tile<F, K_IN>(net, lds, rsrc, c.x + stp.x, c.y, c.z);
-        fgy = eval_tile<F, K_IN>(net, lds, rsrc, c.x, c.y + stp.y, c.z);
-        fgz = eval_tile<F, K_IN>(net, lds, rsrc, c.x, c.y, c.z + stp.z);
+        fgx = eval_tile<F, K_IN, W, GENERAL>(net, lds, rsrc, c.x + stp.x, c.y, c.z);
+        fgy = eval_tile<F, K_IN, W, GENERAL>(net, lds, rsrc, c.x, c.y + stp.y, c.z);
+        fgz = eval_tile<F, K_IN, W, GENERAL>(net, lds, rsrc, c.x, c.y, c.z + stp.z);
       }
       if (has) {
         vec3f rgb; float a;
@@ -226,7 +232,7 @@ __global__ void __launch_bounds__(256) in_shader_kernel(const RenderParams p, co
 // frame bit for bit; what changes is that the 60-odd iterations of a frame are trips of ONE launch instead of 3 launches each.
 constexpr int kInShaderPathTracing = 4;   // render_in_shader's `shade` argument beside M_NONE / M_GRADIENT / M_SSH
 
-template <int F, int K_IN>
+template <int F, int K_IN, int W, bool GENERAL>
 __global__ void __launch_bounds__(256) in_shader_pt_kernel(const RenderParams p, const TileNet net, unsigned long long* __restrict__ stat_samples,
                                                            uint32_t* __restrict__ stat_hits)
 {
@@ -277,7 +283,7 @@ __global__ void __launch_bounds__(256) in_shader_pt_kernel(const RenderParams p,
     if (live == 0ull) break;
     n_samples += (unsigned long long)__builtin_popcountll(live);
     const vec3f c = alive ? r.sample_coord : vec3f{0.5f, 0.5f, 0.5f};
-    const float v = eval_tile<F, K_IN>(net, lds, rsrc, c.x, c.y, c.z);
+    const float v = eval_tile<F, K_IN, W, GENERAL>(net, lds, rsrc, c.x, c.y, c.z);
     if (alive) {  // iterative_shade_kernel (:750-768); the ray's interval is recomputed on every trip, as its load does (:126-129)
       r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;
       intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi);
@@ -297,5 +303,45 @@ __global__ void __launch_bounds__(256) in_shader_pt_kernel(const RenderParams p,
     if (h) atomicAdd(&stat_hits[slot], h);
   }
 }
+
+// ---- one translation unit per width and kind (in_shader_w*.hip) ----------------------------------------------------------------
+// model shapes with an in-shader instance (F, padded input width); the others take the streaming path
+#define VNR_IN_SHADER_SHAPES(X) X(1, 16) X(1, 32) X(2, 16) X(2, 32) X(2, 64) X(4, 32) X(4, 64) X(8, 64) X(8, 128)
+
+struct InShaderLaunch {
+  uint32_t blocks;
+  size_t shmem;
+  hipStream_t stream;
+  unsigned long long* stat_samples;
+  uint32_t* stat_hits;
+};
+
+template <int W, bool GENERAL>
+static bool launch_in_shader_instance(const RenderParams& p, const TileNet& net, int shade, const InShaderLaunch& l)
+{
+  bool launched = false;
+  auto launch = [&](auto kernel) {
+    // (the kernel also has 48 bytes of static LDS: the dynamic part cannot be the whole 160 KB)
+    if (l.shmem > 48 * 1024) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.shmem));
+    kernel<<<l.blocks, 256, l.shmem, l.stream>>>(p, net, l.stat_samples, l.stat_hits);
+    launched = true;
+  };
+#define X(f, k)                                                                                \
+  if (!launched && net.n_features == f && net.in_width == k) {                                 \
+    if (shade == kInShaderPathTracing) launch(in_shader_pt_kernel<f, k, W, GENERAL>);         \
+    else if (shade == M_GRADIENT) launch(in_shader_kernel<f, k, W, GENERAL, M_GRADIENT>);      \
+    else if (shade == M_SSH) launch(in_shader_kernel<f, k, W, GENERAL, M_SSH>);                \
+    else launch(in_shader_kernel<f, k, W, GENERAL, M_NONE>);                                   \
+  }
+  VNR_IN_SHADER_SHAPES(X)
+#undef X
+  return launched;
+}
+
+#define VNR_DEFINE_IN_SHADER_WIDTH(W, GENERAL, SUFFIX)                                                                          \
+  bool launch_in_shader_w##W##SUFFIX(const RenderParams& p, const TileNet& net, int shade, const InShaderLaunch& l)             \
+  {                                                                                                                             \
+    return launch_in_shader_instance<W, GENERAL>(p, net, shade, l);                                                             \
+  }
 
 }  // namespace vnr

@@ -274,8 +274,8 @@ __device__ __forceinline__ float finish_output(float y, uint32_t out_act)
   return (float)act_forward_f16((half_t)y, out_act);
 }
 
-// What a kernel other than the evaluation kernels needs to evaluate the network itself (Network::tile_net; 64-neuron models of the
-// common kind: Network::common_kind)
+// What a kernel other than the evaluation kernels needs to evaluate the network itself (Network::tile_net): every model whose weight
+// image fits the LDS, i.e. all the reference's in-shader shapes (widths 16 / 32 / 64, method_raymarching.cu:1192-1244) and 128 too
 struct TileNet {
   const LevelInfo* levels;     // per-level constants (the brick variant when the image is in use)
   uint32_t n_levels, interpolation;
@@ -283,20 +283,22 @@ struct TileNet {
   uint32_t table_bytes;
   const uint8_t* brick_image;  // or null
   const half_t* packed_mlp;    // LDS image of the weights (pack_mlp_kernel), lds_halves halves
-  uint32_t lds_halves, n_hidden_matmuls, activation;
-  uint32_t n_features, in_width;
+  uint32_t lds_halves, n_hidden_matmuls, activation, output_activation;
+  uint32_t n_features, in_width, width;
+  uint32_t general;            // the model needs the GENERAL instances (Network::common_kind is false)
+  float quantize_threshold;
 };
 
 // the network at this lane's point, all 64 lanes of the wave taking part (inactive lanes pass any in-domain point): the value
-// fused_infer_kernel writes for it, bit for bit
-template <int F, int K_IN>
+// fused_infer_kernel<F, K_IN, W, 0, GENERAL> writes for it, bit for bit (the same encode_tile / mlp_tile / finish_output calls)
+template <int F, int K_IN, int W, bool GENERAL>
 __device__ __forceinline__ float eval_tile(const TileNet& net, const half_t* __restrict__ lds, const table_rsrc_t& rsrc, float x, float y, float z)
 {
   const uint32_t lane = threadIdx.x & 63u;
   half8_t feat[K_IN / 8];
-  encode_tile<F, K_IN>(net.levels, net.n_levels, net.interpolation, rsrc, net.brick_image, x, y, z, feat);
-  const float v = mlp_tile<64, K_IN, false>(lds, feat, net.n_hidden_matmuls, net.activation, lane >> 5, lane & 31u, nullptr, 0, 0);
-  return finish_output<false>(v, 0u);
+  encode_tile<F, K_IN, GENERAL>(net.levels, net.n_levels, net.interpolation, rsrc, net.brick_image, x, y, z, feat, GENERAL ? net.quantize_threshold : 0.0f);
+  const float v = mlp_tile<W, K_IN, false, GENERAL>(lds, feat, net.n_hidden_matmuls, net.activation, lane >> 5, lane & 31u, nullptr, 0, 0);
+  return finish_output<GENERAL>(v, net.output_activation);
 }
 
 }  // namespace vnr

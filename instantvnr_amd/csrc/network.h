@@ -15,7 +15,6 @@
 namespace vnr {
 
 constexpr int kMaxLevels = 32;
-constexpr int kWidth = 64;        // FullyFusedMLP n_neurons of the in-shader kernels (in_shader.h); the evaluation kernels cover 16 / 32 / 64 / 128
 constexpr size_t kLdsBytes = 160 * 1024;   // LDS of a CU: what a weight image may take
 constexpr int kLossScale = 128;   // tcnn default loss scale for fp16 (EXTERNAL)
 
@@ -110,6 +109,7 @@ public:
   const GridDevice& grid() const { return grid_; }
   uint32_t padded_width() const { return in_width_; }
   uint32_t width() const { return cfg_.n_neurons; }
+  uint32_t lds_halves() const { return lds_halves_; }   // halves of the forward weight image
   // Every model the reference's dispatch builds runs on the MFMA kernels (round 4): widths 16 / 32 / 64 / 128 (tcnn_impl.cu:315-347), every
   // interpolation, activation and grid type.  The common kind of model (Hash / Dense grid, Linear / Smoothstep, ReLU / None, no output
   // activation, no quantize_threshold, a weight image that fits the LDS) has kernel instances that contain nothing else
@@ -186,6 +186,15 @@ public:
   void for_each_exchange_range(size_t bucket, const std::function<void(size_t, size_t)>& fn) const;
   size_t level_range_lo(uint32_t level) const { return n_mlp_ + (size_t)grid_.levels[level].offset * cfg_.n_features; }
   size_t level_range_hi(uint32_t level_end) const { return n_mlp_ + ((size_t)grid_.levels[level_end - 1].offset + grid_.levels[level_end - 1].size) * cfg_.n_features; }
+  // Diagnostics of the training step (tests/diag/grad_hammer.py; passive: nothing else depends on them).  training_buffer: device
+  // pointer and size of 0 the fp16 gradient blob, 1 dL/dfeatures [n][padded_width] fp16, 2 the features, 3 the hidden activations
+  // of the last forward_backward.  rescatter_grid_gradients: clears the grid part of the blob and repeats step 5 alone on the stored
+  // dL/dfeatures.  gradient_distance: {sum (g - ref)^2, sum ref^2} of the MLP part and of the grid part against an fp16 reference blob,
+  // reduced on the device on stream s (what the blob holds BEFORE any download).
+  const void* training_buffer(int which, size_t* bytes) const;
+  void rescatter_grid_gradients(const float* d_coords, size_t n, hipStream_t s);
+  void gradient_distance(const uint16_t* d_ref, double out[4], hipStream_t s);
+  void scatter_grid_gradients(const float* d_coords, size_t batch, hipStream_t s, GradExchange* exchange);   // step 5 of forward_backward
   // tests: the gradient blob from a float array (rounded to the blob's half precision)
   void set_grads_from_f32(const float* host, size_t count, hipStream_t s);
 

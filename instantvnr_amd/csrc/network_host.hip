@@ -552,7 +552,7 @@ FusedMlp Network::fused_mlp() const
 
 bool Network::tile_net(TileNet* out, hipStream_t s) const
 {
-  if (!common_kind() || cfg_.n_neurons != (uint32_t)kWidth) return false;
+  if (!weights_in_lds()) return false;   // (a deeper network reads its weights from global memory: evaluation kernels only)
   if (n_grid_params() * 2 >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
   const uint8_t* image;
   const LevelInfo* levels = inference_levels(s, &image);
@@ -566,8 +566,12 @@ bool Network::tile_net(TileNet* out, hipStream_t s) const
   out->lds_halves = lds_halves_;
   out->n_hidden_matmuls = n_hidden_matmuls();
   out->activation = cfg_.activation;
+  out->output_activation = cfg_.output_activation;
   out->n_features = grid_.n_features;
   out->in_width = in_width_;
+  out->width = cfg_.n_neurons;
+  out->general = common_kind() ? 0u : 1u;
+  out->quantize_threshold = cfg_.quantize_threshold;
   return true;
 }
 

@@ -755,7 +755,7 @@ struct TrainScratch {  // per-Network extra buffers that do not need to live in 
   DeviceBuffer<uint16_t> dy{MemTag::Network};
   DeviceBuffer<uint16_t> d_all{MemTag::Network};
   DeviceBuffer<float> wgrad_slab{MemTag::Network};   // [blocks][n_mlp] partial weight gradients
-  uint64_t slab_key = 0;                             // (n_mlp, kernel family) the slab's never-written elements were zeroed for
+  uint64_t slab_key = 0;                             // (n_mlp, n_neurons, in_width, hidden matmuls) the slab's never-written elements were zeroed for
   DeviceBuffer<uint8_t> lds_items{MemTag::Network};  // work items of grid_backward_lds_kernel (as bytes: the item type is local to this file)
   std::vector<uint8_t> lds_items_host;               // what lds_items holds: the list depends on the level sizes, n_features, tile size, batch and level range
   uint32_t loss_blocks = 0;
@@ -765,6 +765,7 @@ struct TrainScratch {  // per-Network extra buffers that do not need to live in 
 
 #include <map>
 #include <memory>
+#include <set>
 
 namespace vnr {
 
@@ -792,6 +793,105 @@ void Network::ensure_training_state(hipStream_t s)
 void Network::reset_master_from_params(hipStream_t s)
 {
   if (opt_state_.count == n_params_) launch_master_from_f16(params_f16_.ptr, opt_state_.ptr, n_params_, false, s);
+}
+
+// 5. of the training step: dL/dfeatures (ws_dfeat_, written by the MLP backward) -> the grid part of the gradient blob.  A function of its
+// own so that it can be repeated alone on the stored dL/dfeatures (vnrAmdNeuralVolumeRescatterGridGradients: diagnostics).
+void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStream_t s, GradExchange* exchange)
+{
+  TrainScratch& ts = scratch_of(this);
+  const uint32_t n = (uint32_t)batch;
+  // 5. hash-grid backward: levels [l0, l1) per launch (blockIdx.y + l0 = level)
+  // levels [0, lds_levels) go through grid_backward_lds_kernel: dense, and at most kLdsBwdMaxTiles LDS tiles (VNR_AMD_GRID_BWD_LDS=0: none)
+  static const bool lds_bwd = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS"); return !e || std::atoi(e) != 0; }();
+  static const uint32_t lds_kb = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_KB"); return e ? (uint32_t)std::max(8, std::min(144, std::atoi(e))) : 24u; }();
+  static const uint32_t lds_blocks = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_BLOCKS"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 768u; }();
+  static const uint32_t lds_max_tiles = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_TILES"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 64u; }();
+  // (sweep of the three on the C4 model, profiles/r03_grid_backward_lds_sweep.txt: 24 KB tiles, ~768 blocks per level, levels of at most 64 tiles =
+  // levels 0 - 4 of C4: grid backward 0.239 -> 0.18 - 0.22 ms, bimodal from run to run; larger tiles or more levels cost more in scanning
+  // than their atomics saved)
+  const uint32_t tile_entries = (lds_kb * 1024u / (4u * cfg_.n_features)) & ~15u;
+  uint32_t lds_levels = 0;
+  if (lds_bwd)
+    while (lds_levels < n_active_levels() && !grid_.levels[lds_levels].hashed && ((size_t)grid_.levels[lds_levels].offset * cfg_.n_features) % 2 == 0 &&
+           div_round_up(grid_.levels[lds_levels].size, tile_entries) <= lds_max_tiles) ++lds_levels;   // (the flush adds aligned pairs of halves)
+  auto grid_backward_lds = [&](uint32_t l0, uint32_t l1) {
+    // work items: every tile of every level x slices of the batch; more slices where a level has few tiles, so that ~2 blocks per CU exist
+    std::vector<LdsBwdItem> items;
+    for (uint32_t l = l0; l < l1; ++l) {
+      const uint32_t size = grid_.levels[l].size, tiles = div_round_up(size, tile_entries);
+      const uint32_t slices = std::max(4u, std::min(128u, lds_blocks / tiles));
+      const uint32_t per = (uint32_t)div_round_up(batch, slices);
+      for (uint32_t t = 0; t < tiles; ++t)
+        for (uint32_t sl = 0; sl < slices; ++sl) {
+          const uint32_t s0 = sl * per, s1 = std::min<uint32_t>(n, s0 + per);
+          if (s0 < s1) items.push_back({l, t * tile_entries, std::min(size, (t + 1) * tile_entries), s0, s1});
+        }
+    }
+    if (items.empty()) return;
+    // (cached on the device while the list is the same: it depends on the level sizes, n_features, the tile size, the batch and the level range,
+    // so the bytes themselves are the key: a re-configured model must not reuse the old model's tile and slice ranges, ADVICE r03)
+    const size_t item_bytes = items.size() * sizeof(LdsBwdItem);
+    if (ts.lds_items_host.size() != item_bytes || std::memcmp(ts.lds_items_host.data(), items.data(), item_bytes) != 0) {
+      ts.lds_items.ensure(item_bytes);
+      VNR_HIP_CHECK(hipMemcpyAsync(ts.lds_items.ptr, items.data(), item_bytes, hipMemcpyHostToDevice, s));
+      VNR_HIP_CHECK(hipStreamSynchronize(s));   // pageable source
+      ts.lds_items_host.assign((const uint8_t*)items.data(), (const uint8_t*)items.data() + item_bytes);
+    }
+    const size_t shmem = (size_t)tile_entries * cfg_.n_features * sizeof(float);
+    half_t* gg = (half_t*)grads_.ptr + n_mlp_;
+    auto launch = [&](auto kernel) {
+      static std::set<const void*> done;   // (by address: the four instances have one signature and would share a flag of this lambda)
+      if (done.insert((const void*)kernel).second) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      kernel<<<(uint32_t)items.size(), 256, shmem, s>>>(grid_, (const LdsBwdItem*)ts.lds_items.ptr, d_coords, (const half_t*)ws_dfeat_.ptr, in_width_, gg);
+    };
+    switch (cfg_.n_features) {
+    case 1: launch(grid_backward_lds_kernel<1>); break;
+    case 2: launch(grid_backward_lds_kernel<2>); break;
+    case 4: launch(grid_backward_lds_kernel<4>); break;
+    default: launch(grid_backward_lds_kernel<8>); break;
+    }
+  };
+  auto grid_backward = [&](uint32_t l0, uint32_t l1) {
+    if (l0 < lds_levels) {
+      grid_backward_lds(l0, std::min(l1, lds_levels));
+      l0 = std::min(l1, lds_levels);
+      if (l0 >= l1) return;
+    }
+    const uint32_t pairs = cfg_.n_features >= 2 ? cfg_.n_features / 2 : 1u;
+    const dim3 g(div_round_up((uint64_t)batch * pairs * 2, 256), l1 - l0);  // one lane per (sample, x bit, feature pair)
+    half_t* gg = (half_t*)grads_.ptr + n_mlp_;
+    switch (cfg_.n_features) {
+    case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
+    case 2: grid_backward_kernel<2><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
+    case 4: grid_backward_kernel<4><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
+    default: grid_backward_kernel<8><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
+    }
+  };
+  if (!exchange) {
+    // diagnostics builds (-DVNR_DIAG; tools/train_probe.py): VNR_AMD_GRID_BWD_LEVELS="l0,l1" scatters levels [l0, l1) only, to price a level
+    // (a wrong gradient by design: not in the library that ships)
+#if defined(VNR_DIAG)
+    static const std::pair<int, int> only = [] {
+      const char* e = std::getenv("VNR_AMD_GRID_BWD_LEVELS");
+      int a = -1, b = -1;
+      if (e && std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b > a) return std::make_pair(a, b);
+      return std::make_pair(-1, -1);
+    }();
+#else
+    constexpr std::pair<int, int> only{-1, -1};
+#endif
+    // levels at or beyond max_level + 1e-3 encode to zero and receive no gradient (EXTERNAL tcnn kernel_grid_backward has the same test)
+    if (only.first >= 0) grid_backward((uint32_t)only.first, std::min<uint32_t>((uint32_t)only.second, n_active_levels()));
+    else if (n_active_levels() > 0) grid_backward(0, n_active_levels());
+  } else {
+    // finest levels first (the large tables), in buckets of at least bucket_params() parameters: a bucket's exchange overlaps the
+    // backward launches of the coarser levels and, afterwards, the optimizer update of the buckets before it
+    for (const auto& b : exchange_level_buckets(exchange->bucket_params())) {
+      if (b.first < n_active_levels()) grid_backward(b.first, std::min(b.second, n_active_levels()));
+      exchange->range_ready(level_range_lo(b.first), level_range_hi(b.second), s);
+    }
+  }
 }
 
 void Network::forward_backward(const float* d_coords, const float* d_targets, size_t batch, hipStream_t s, GradExchange* exchange)
@@ -828,9 +928,9 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   profile_mark(1, s);
   loss_grad_kernel<<<ts.loss_blocks, 256, 0, s>>>(ts.y.ptr, d_targets, n, cfg_.loss, cfg_.output_activation, (half_t*)ts.dy.ptr, ws_loss_.ptr);
   // the slab's elements no block ever writes (rows 1 .. 15 of the padded last layer) must be zero: they are summed into the gradient.  Zeroed
-  // when the slab grows or when the layout it was zeroed for changes (another n_mlp, the other kernel family: ADVICE r03)
+  // when the slab grows or when the layout it was zeroed for changes (width, input width, depth: 64 neurons x 1 layer and 32 x 2 share n_mlp)
   auto ensure_slab = [&](size_t rows) {
-    const uint64_t key = (uint64_t)n_mlp_;
+    const uint64_t key = (uint64_t)n_mlp_ | ((uint64_t)Wn << 32) | ((uint64_t)in_width_ << 40) | ((uint64_t)nh << 48);   // the whole layout: two shapes can share n_mlp
     if (ts.wgrad_slab.count < rows * n_mlp_ || ts.slab_key != key) {
       if (ts.wgrad_slab.count < rows * n_mlp_) ts.wgrad_slab.resize(rows * n_mlp_);
       ts.wgrad_slab.zero(s);
@@ -851,7 +951,10 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     const uint32_t blocks = std::min<uint32_t>(div_round_up(div_round_up(batch, 64), 4), (uint32_t)Runtime::get().n_cus * fit);
     const int mt = (int)((in_width_ + 31) / 32);
     auto launch = [&](auto kernel) {
-      VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+      // once per kernel: no driver call on the step's launch path.  (Keyed by the function's address: the instances share one signature,
+      // so a static flag inside this generic lambda would be shared by all of them.)
+      static std::set<const void*> done;
+      if (done.insert((const void*)kernel).second) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
       kernel<<<blocks, 256, shmem, s>>>(ba);
     };
     const bool gen = cfg_.activation > 1u || bwd_global;
@@ -898,92 +1001,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   }   // MFMA kernels
   profile_mark(3, s);
   if (exchange) exchange->range_ready(0, n_mlp_, s);   // the MLP's gradient travels while the grid backward runs
-  // 5. hash-grid backward: levels [l0, l1) per launch (blockIdx.y + l0 = level)
-  // levels [0, lds_levels) go through grid_backward_lds_kernel: dense, and at most kLdsBwdMaxTiles LDS tiles (VNR_AMD_GRID_BWD_LDS=0: none)
-  static const bool lds_bwd = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS"); return !e || std::atoi(e) != 0; }();
-  static const uint32_t lds_kb = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_KB"); return e ? (uint32_t)std::max(8, std::min(144, std::atoi(e))) : 24u; }();
-  static const uint32_t lds_blocks = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_BLOCKS"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 768u; }();
-  static const uint32_t lds_max_tiles = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_TILES"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 64u; }();
-  // (sweep of the three on the C4 model, profiles/r03_grid_backward_lds_sweep.txt: 24 KB tiles, ~768 blocks per level, levels of at most 64 tiles =
-  // levels 0 - 4 of C4: grid backward 0.239 -> 0.18 - 0.22 ms, bimodal from run to run; larger tiles or more levels cost more in scanning
-  // than their atomics saved)
-  const uint32_t tile_entries = (lds_kb * 1024u / (4u * cfg_.n_features)) & ~15u;
-  uint32_t lds_levels = 0;
-  if (lds_bwd)
-    while (lds_levels < n_active_levels() && !grid_.levels[lds_levels].hashed && ((size_t)grid_.levels[lds_levels].offset * cfg_.n_features) % 2 == 0 &&
-           div_round_up(grid_.levels[lds_levels].size, tile_entries) <= lds_max_tiles) ++lds_levels;   // (the flush adds aligned pairs of halves)
-  auto grid_backward_lds = [&](uint32_t l0, uint32_t l1) {
-    // work items: every tile of every level x slices of the batch; more slices where a level has few tiles, so that ~2 blocks per CU exist
-    std::vector<LdsBwdItem> items;
-    for (uint32_t l = l0; l < l1; ++l) {
-      const uint32_t size = grid_.levels[l].size, tiles = div_round_up(size, tile_entries);
-      const uint32_t slices = std::max(4u, std::min(128u, lds_blocks / tiles));
-      const uint32_t per = (uint32_t)div_round_up(batch, slices);
-      for (uint32_t t = 0; t < tiles; ++t)
-        for (uint32_t sl = 0; sl < slices; ++sl) {
-          const uint32_t s0 = sl * per, s1 = std::min<uint32_t>(n, s0 + per);
-          if (s0 < s1) items.push_back({l, t * tile_entries, std::min(size, (t + 1) * tile_entries), s0, s1});
-        }
-    }
-    if (items.empty()) return;
-    // (cached on the device while the list is the same: it depends on the level sizes, n_features, the tile size, the batch and the level range,
-    // so the bytes themselves are the key: a re-configured model must not reuse the old model's tile and slice ranges, ADVICE r03)
-    const size_t item_bytes = items.size() * sizeof(LdsBwdItem);
-    if (ts.lds_items_host.size() != item_bytes || std::memcmp(ts.lds_items_host.data(), items.data(), item_bytes) != 0) {
-      ts.lds_items.ensure(item_bytes);
-      VNR_HIP_CHECK(hipMemcpyAsync(ts.lds_items.ptr, items.data(), item_bytes, hipMemcpyHostToDevice, s));
-      VNR_HIP_CHECK(hipStreamSynchronize(s));   // pageable source
-      ts.lds_items_host.assign((const uint8_t*)items.data(), (const uint8_t*)items.data() + item_bytes);
-    }
-    const size_t shmem = (size_t)tile_entries * cfg_.n_features * sizeof(float);
-    half_t* gg = (half_t*)grads_.ptr + n_mlp_;
-    auto launch = [&](auto kernel) {
-      static bool attr = false;
-      if (!attr) { VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-      kernel<<<(uint32_t)items.size(), 256, shmem, s>>>(grid_, (const LdsBwdItem*)ts.lds_items.ptr, d_coords, (const half_t*)ws_dfeat_.ptr, in_width_, gg);
-    };
-    switch (cfg_.n_features) {
-    case 1: launch(grid_backward_lds_kernel<1>); break;
-    case 2: launch(grid_backward_lds_kernel<2>); break;
-    case 4: launch(grid_backward_lds_kernel<4>); break;
-    default: launch(grid_backward_lds_kernel<8>); break;
-    }
-  };
-  auto grid_backward = [&](uint32_t l0, uint32_t l1) {
-    if (l0 < lds_levels) {
-      grid_backward_lds(l0, std::min(l1, lds_levels));
-      l0 = std::min(l1, lds_levels);
-      if (l0 >= l1) return;
-    }
-    const uint32_t pairs = cfg_.n_features >= 2 ? cfg_.n_features / 2 : 1u;
-    const dim3 g(div_round_up((uint64_t)batch * pairs * 2, 256), l1 - l0);  // one lane per (sample, x bit, feature pair)
-    half_t* gg = (half_t*)grads_.ptr + n_mlp_;
-    switch (cfg_.n_features) {
-    case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
-    case 2: grid_backward_kernel<2><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
-    case 4: grid_backward_kernel<4><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
-    default: grid_backward_kernel<8><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
-    }
-  };
-  if (!exchange) {
-    // diagnostics (tools/train_probe.py): VNR_AMD_GRID_BWD_LEVELS="l0,l1" scatters levels [l0, l1) only, to price a level
-    static const std::pair<int, int> only = [] {
-      const char* e = std::getenv("VNR_AMD_GRID_BWD_LEVELS");
-      int a = -1, b = -1;
-      if (e && std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b > a) return std::make_pair(a, b);
-      return std::make_pair(-1, -1);
-    }();
-    // levels at or beyond max_level + 1e-3 encode to zero and receive no gradient (EXTERNAL tcnn kernel_grid_backward has the same test)
-    if (only.first >= 0) grid_backward((uint32_t)only.first, std::min<uint32_t>((uint32_t)only.second, n_active_levels()));
-    else if (n_active_levels() > 0) grid_backward(0, n_active_levels());
-  } else {
-    // finest levels first (the large tables), in buckets of at least bucket_params() parameters: a bucket's exchange overlaps the
-    // backward launches of the coarser levels and, afterwards, the optimizer update of the buckets before it
-    for (const auto& b : exchange_level_buckets(exchange->bucket_params())) {
-      if (b.first < n_active_levels()) grid_backward(b.first, std::min(b.second, n_active_levels()));
-      exchange->range_ready(level_range_lo(b.first), level_range_hi(b.second), s);
-    }
-  }
+  scatter_grid_gradients(d_coords, batch, s, exchange);
   VNR_HIP_CHECK(hipGetLastError());
   profile_mark(4, s);
 }
@@ -1034,6 +1052,59 @@ float* Network::grads_as_f32(hipStream_t s)
   unpack_grads_f16_kernel<<<(uint32_t)std::min<size_t>((n_params_ + 255) / 256, 8192), 256, 0, s>>>((const half_t*)grads_.ptr, grads_f32_.ptr, n_params_);
   VNR_HIP_CHECK(hipGetLastError());
   return grads_f32_.ptr;
+}
+
+// ------------------------------------------------------------------------------------------------ diagnostics
+const void* Network::training_buffer(int which, size_t* bytes) const
+{
+  switch (which) {
+  case 0: *bytes = grads_.count ? n_params_ * 2 : 0; return grads_.ptr;
+  case 1: *bytes = ws_dfeat_.bytes(); return ws_dfeat_.ptr;
+  case 2: *bytes = ws_features_.bytes(); return ws_features_.ptr;
+  case 3: *bytes = ws_acts_.bytes(); return ws_acts_.ptr;
+  default: throw std::runtime_error("training_buffer: 0 gradients, 1 dL/dfeatures, 2 features, 3 activations");
+  }
+}
+
+void Network::rescatter_grid_gradients(const float* d_coords, size_t n, hipStream_t s)
+{
+  if (grads_.count != grads_alloc() || ws_batch_ != n || n == 0) throw std::runtime_error("rescatter_grid_gradients: no forward_backward of this batch size to repeat");
+  VNR_HIP_CHECK(hipMemsetAsync(grads_.ptr + n_mlp_, 0, (grads_alloc() - n_mlp_) * sizeof(uint16_t), s));
+  scatter_grid_gradients(d_coords, n, s, nullptr);
+  VNR_HIP_CHECK(hipGetLastError());
+}
+
+// block sums of (g - ref)^2 and ref^2 in double, [blocks][2]
+__global__ void __launch_bounds__(256) grad_distance_kernel(const half_t* __restrict__ g, const half_t* __restrict__ ref, size_t lo, size_t hi, double* __restrict__ out)
+{
+  __shared__ double red[2][256];
+  double d2 = 0.0, r2 = 0.0;
+  for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (size_t)gridDim.x * blockDim.x) {
+    const double a = (double)(float)g[i], b = (double)(float)ref[i];
+    d2 += (a - b) * (a - b); r2 += b * b;
+  }
+  red[0][threadIdx.x] = d2; red[1][threadIdx.x] = r2;
+  __syncthreads();
+  for (uint32_t st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = red[0][0]; out[2 * blockIdx.x + 1] = red[1][0]; }
+}
+
+void Network::gradient_distance(const uint16_t* d_ref, double out[4], hipStream_t s)
+{
+  if (grads_.count != grads_alloc()) throw std::runtime_error("gradient_distance: no gradient yet");
+  constexpr uint32_t kBlocks = 256;
+  static DeviceBuffer<double> part(MemTag::Network);
+  part.ensure(4 * kBlocks);
+  grad_distance_kernel<<<kBlocks, 256, 0, s>>>((const half_t*)grads_.ptr, (const half_t*)d_ref, 0, n_mlp_, part.ptr);
+  grad_distance_kernel<<<kBlocks, 256, 0, s>>>((const half_t*)grads_.ptr, (const half_t*)d_ref, n_mlp_, n_params_, part.ptr + 2 * kBlocks);
+  VNR_HIP_CHECK(hipGetLastError());
+  std::vector<double> h(4 * kBlocks);
+  part.download(h.data(), h.size(), s);
+  for (int k = 0; k < 4; ++k) out[k] = 0.0;
+  for (uint32_t b = 0; b < kBlocks; ++b) { out[0] += h[2 * b]; out[1] += h[2 * b + 1]; out[2] += h[2 * kBlocks + 2 * b]; out[3] += h[2 * kBlocks + 2 * b + 1]; }
 }
 
 __global__ void pack_grads_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n)

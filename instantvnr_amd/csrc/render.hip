@@ -23,66 +23,10 @@
 #include "infer_tile.h"
 #include "pack_rays.h"
 #include "sampling_device.h"
+#include "march_device.h"
+#include "pt_device.h"
 
 namespace vnr {
-
-#define VNR_FLOAT_LARGE 1e20f
-#define VNR_NEARLY_ONE 0.9999f
-
-struct RenderParams {
-  vec4f* frame;
-  vec4f* accumulation;
-  int width, height, frame_index;
-  uint32_t pixel_lo, pixel_hi;
-  uint32_t il_parts, il_part, n_local;   // tile-row interleave across ranks; n_local = local index count
-  uint32_t out_parts;                    // > 1: frame / accumulation hold only the tile rows r with r % out_parts == this rank, packed (Renderer::set_distributed)
-  uint32_t tiles_per_row, tile_row0;     // 64-pixel tiles per band of 8 scanlines: rays of a wave are an image patch, not a scanline
-  uint32_t tile_w_log2;                  // tile shape: 2^tile_w_log2 x 2^(6 - tile_w_log2) pixels (8x8, 16x4, 32x2 or 64x1)
-  float bin_depth_rcp;                   // 1 / depth of one sample-sorting bin (world units)
-  uint32_t tfn_in_lds;                   // the TFN tables fit in the march kernel's LDS
-  uint32_t no_ranks;                     // march_kernel: a sample's rank inside its depth bin is not kept in LDS (2 bytes per sample) but claimed again from the bin's counter
-  uint32_t debug_flags;                  // timing ablations only (VNR_AMD_DEBUG_FLAGS): 1 no compose, 2 no TFN, 4 no sort, 8 no DDA walk, 16 no sample records, 32 separate colour / opacity lookups
-  vec3f cam_pos, cam_dir, cam_hor, cam_ver;
-  affine3f wto;
-  vec3i vol_dims;
-  const float* volume;
-  vec3f bbox_lo, bbox_hi;
-  float step, step_rcp;
-  vec3i mc_dims;
-  vec3f mc_rcp;
-  const float* mc_max_opacity;
-  DeviceTfn tfn;
-  int n_iters;
-  // gradient shading (rendering modes 7 / 8)
-  affine3f otw;          // object -> world (params.transform)
-  vec3f grad_step;       // 1 / dims (object.cpp:305)
-  vec3f light_dir;       // LaunchParams::light_directional_dir after the flip of renderer.cpp:98-101
-  uint32_t slot_cap;     // sample slots of this half's result arena (value/dt pairs first, then the gradient samples)
-  uint32_t shading_mode; // 0 NO_SHADING, 1 GRADIENT_SHADING, 2 SINGLE_SHADE_HEURISTIC (the streaming kernels are templated on it; the monolithic one branches)
-  // SINGLE_SHADE_HEURISTIC (modes 10 / 11): per-pixel hand-over from the camera pass to the shadow pass
-  // (final_highest_*, shading_color, jitter_ssh; method_raymarching.cu:88-92) and the shadow rays' common direction
-  vec3f* px_org;
-  vec3f* px_color;
-  float* px_alpha;
-  vec4f* px_shading;
-  float* px_jitter;
-  vec3f shadow_dir;      // xfmVector(wto, normalize(light_directional_dir)) (:649)
-  float density_scale;   // DeviceVolume::density_scale (path tracing, rendering mode 14)
-  uint32_t ssh_third_draw;   // rendering mode 12: the shadow ray's jitter is the pixel's third random number
-  uint32_t grad_flip;        // rendering mode 9: forward differences flip at the volume's far faces (sampleGradient)
-  uint32_t pt_reset_interval;  // rendering mode 15: the in-shader estimator resets tnear / tfar before a bounce (:999-1001)
-};
-
-// streaming kernel modes (ShadingMode, method_raymarching.cu:51-56)
-enum { M_NONE = 0, M_GRADIENT = 1, M_SSH = 2, M_SHADOW = 3 };
-
-// Result arena of one half and one parity, in floats: [slot_cap][2] = {value, t1 - t0} per sample slot, then (gradient
-// shading only) [slot_cap][4] = {f(c + gx), f(c + gy), f(c + gz), unused}.  A queue record's 4th word is the absolute float
-// index its result goes to, so the inference kernel and the ground-truth sampler need not know about shading modes.
-__device__ __forceinline__ uint32_t arena_value_index(uint32_t slot) { return 2u * slot; }
-__device__ __forceinline__ uint32_t arena_grad_index(uint32_t slot_cap, uint32_t slot) { return 2u * slot_cap + 4u * slot; }
-
-constexpr int kDepthBins = 64;
 
 // In-kernel stamps of the march kernel's phases (diagnostic builds only: tools/ab_build.sh <tag> -DVNR_MARCH_STAMPS; the guide's
 // "In-kernel stamps"): cycles per phase summed over the waves of every march_kernel<false> launch, read by tools/march_stamps.py
@@ -100,297 +44,6 @@ __device__ unsigned long long g_wave_rec[kWaveRecs][8];
 #define VNR_STAMP(var)
 #define VNR_STAMP_ADD(slot, a, b)
 #endif
-
-// C_*: the device counters of a ray part (pack_rays.h)
-
-// ------------------------------------------------------------------------------------------------ helpers
-__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
-__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
-
-// raytracing.h:9-36
-__device__ __forceinline__ bool intersect_box(float& t0, float& t1, vec3f org, vec3f dir, vec3f lower, vec3f upper)
-{
-  const bool sx = fabsf(dir.x) <= FLT_MIN, sy = fabsf(dir.y) <= FLT_MIN, sz = fabsf(dir.z) <= FLT_MIN;
-  const vec3f rcp = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
-  const vec3f lo = {sx ? VNR_FLOAT_LARGE : (lower.x - org.x) * rcp.x, sy ? VNR_FLOAT_LARGE : (lower.y - org.y) * rcp.y,
-                    sz ? VNR_FLOAT_LARGE : (lower.z - org.z) * rcp.z};
-  const vec3f hi = {sx ? -VNR_FLOAT_LARGE : (upper.x - org.x) * rcp.x, sy ? -VNR_FLOAT_LARGE : (upper.y - org.y) * rcp.y,
-                    sz ? -VNR_FLOAT_LARGE : (upper.z - org.z) * rcp.z};
-  t0 = fmaxf(t0, max3f(fminf(lo.x, hi.x), fminf(lo.y, hi.y), fminf(lo.z, hi.z)));
-  t1 = fminf(t1, min3f(fmaxf(lo.x, hi.x), fmaxf(lo.y, hi.y), fmaxf(lo.z, hi.z)));
-  return t1 > t0;
-}
-
-// method_raymarching.cu:658-685
-__device__ __forceinline__ void compute_ray(const RenderParams& p, uint32_t pixel, vec3f& org, vec3f& dir)
-{
-  const uint32_t ix = pixel % (uint32_t)p.width, iy = pixel / (uint32_t)p.width;
-  const float sx = ((float)ix + 0.5f) / (float)p.width, sy = ((float)iy + 0.5f) / (float)p.height;
-  org = xfm_point(p.wto, p.cam_pos);
-  const vec3f d = (p.cam_dir + (sx - 0.5f) * p.cam_hor) + (sy - 0.5f) * p.cam_ver;
-  dir = xfm_vector(p.wto, normalize(d));
-}
-
-// local work index -> global pixel index of this rank's share of the image.  64 consecutive indices are one
-// TW x TH pixel tile (TW TH = 64, TH <= 8); the 8 / TH tiles stacked in one band of 8 scanlines follow each other, then the
-// next column of the band.  Bands are dealt round-robin to the ranks (il_parts, il_part); a pixel range restricts further.
-__device__ __forceinline__ bool map_pixel(const RenderParams& p, uint32_t i, uint32_t& pixel)
-{
-  const uint32_t tile = i >> 6, l = i & 63u;
-  const uint32_t tr_local = tile / p.tiles_per_row, t = tile - tr_local * p.tiles_per_row;
-  const uint32_t twl = p.tile_w_log2, sub_log2 = twl - 3u;   // 8 / TH = TW / 8 stacked tiles per band column
-  const uint32_t tc = t >> sub_log2, ts = t & ((1u << sub_log2) - 1u);
-  const uint32_t x = (tc << twl) + (l & ((1u << twl) - 1u));
-  const uint32_t y = (p.tile_row0 + tr_local * p.il_parts + p.il_part) * 8u + (ts << (6u - twl)) + (l >> twl);
-  pixel = y * (uint32_t)p.width + x;
-  return x < (uint32_t)p.width && y < (uint32_t)p.height && pixel >= p.pixel_lo && pixel < p.pixel_hi;
-}
-
-// gdt::LCG<16> (EXTERNAL; instantvnr_types.h:155)
-__device__ __forceinline__ float tea_lcg_first(uint32_t v0, uint32_t v1)
-{
-  uint32_t s0 = 0;
-#pragma unroll
-  for (int n = 0; n < 16; ++n) {
-    s0 += 0x9e3779b9u;
-    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
-    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
-  }
-  const uint32_t state = 1664525u * v0 + 1013904223u;
-  return (float)(state & 0x00FFFFFFu) / (float)0x01000000;
-}
-
-// both draws of rng.get_floats() (EXTERNAL OVR addition to gdt::LCG: two successive floats)
-__device__ __forceinline__ uint32_t tea_lcg_two(uint32_t v0, uint32_t v1, float& a, float& b)
-{
-  uint32_t s0 = 0;
-#pragma unroll
-  for (int n = 0; n < 16; ++n) {
-    s0 += 0x9e3779b9u;
-    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
-    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
-  }
-  uint32_t state = 1664525u * v0 + 1013904223u;
-  a = (float)(state & 0x00FFFFFFu) / (float)0x01000000;
-  state = 1664525u * state + 1013904223u;
-  b = (float)(state & 0x00FFFFFFu) / (float)0x01000000;
-  return state;
-}
-
-// raytracing.h:188-194 / :166-170 / :196-207
-__device__ __forceinline__ float adaptive_sampling_rate(float base_step, float max_opacity)
-{
-  const float scale = 15.0f * base_step;
-  const float r = fabsf(clampf(max_opacity, 0.1f, 1.0f) - 1.0f);
-  return fmaxf(base_step + scale * (r * r), base_step);
-}
-__device__ __forceinline__ float opacity_correction(float step_rcp, float distance, float opacity)
-{
-#if defined(VNR_FAST_POW)   // experiment (tools/ab_build.sh fastpow -DVNR_FAST_POW): v_log_f32 / v_exp_f32 instead of the ~80 instructions of powf
-  return 1.0f - __builtin_amdgcn_exp2f(step_rcp * distance * __builtin_amdgcn_logf(1.0f - opacity));
-#else
-  return 1.0f - __builtin_powf(1.0f - opacity, step_rcp * distance);
-#endif
-}
-__device__ __forceinline__ void write_pixel(const RenderParams& p, vec4f rgba, uint32_t pixel)
-{
-  if (p.out_parts > 1u) {  // compact share: tile row b of the image is tile row b / out_parts of the share
-    const uint32_t y = pixel / (uint32_t)p.width, x = pixel - y * (uint32_t)p.width;
-    pixel = (((y >> 3) / p.out_parts) * 8u + (y & 7u)) * (uint32_t)p.width + x;
-  }
-  if (p.frame_index != 1) {
-    const vec4f a = p.accumulation[pixel];
-    rgba = {a.x + rgba.x, a.y + rgba.y, a.z + rgba.z, a.w + rgba.w};
-  }
-  p.accumulation[pixel] = rgba;
-  const float f = (float)p.frame_index;
-  p.frame[pixel] = {rgba.x / f, rgba.y / f, rgba.z / f, rgba.w / f};
-}
-
-// ------------------------------------------------------------------------------------------------ gradient shading (modes 7 / 8)
-// shade_simple_light (raytracing.h:214-222)
-__device__ __forceinline__ vec3f shade_simple_light(vec3f ray_dir, vec3f normal, vec3f albedo)
-{
-  if (dot(normal, normal) > 1.0e-6f) {
-    const vec3f n = normalize(normal);
-    const float c = 0.2f + 0.8f * fabsf(-dot(ray_dir, n));
-    return c * albedo;
-  }
-  return {0, 0, 0};
-}
-
-// shade_scivis_light (raytracing.h:224-246) with mat_gradient_shading {.6, .9, .4, 40} and light_directional_rgb = 1
-// (instantvnr_types.h:142,147); the reference's light_ambient argument is unused there.  World-space vectors.
-__device__ __forceinline__ vec3f shade_scivis_light(vec3f ray_dir, vec3f normal, vec3f albedo, vec3f light_dir)
-{
-  const float m_ambient = 0.6f, m_diffuse = 0.9f, m_specular = 0.4f, m_shininess = 40.0f;
-  vec3f color = {0, 0, 0};
-  if (dot(normal, normal) > 1.0e-6f) {
-    const vec3f L = normalize(light_dir);
-    const vec3f N = normalize(normal);
-    const vec3f V = {-ray_dir.x, -ray_dir.y, -ray_dir.z};
-    color = color + m_ambient * albedo;
-    const float cosNL = fmaxf(dot(N, L), 0.0f);
-    if (cosNL > 0.0f) {
-      color = color + (m_diffuse * cosNL) * albedo;
-      const vec3f H = normalize(L + V);
-      const float cosNH = fmaxf(dot(N, H), 0.0f);
-      const float sp = m_specular * powf(cosNH, m_shininess);
-      color = color + vec3f{sp, sp, sp};
-    }
-  }
-  const vec3f shading2 = shade_simple_light(ray_dir, normal, albedo);
-  return 0.5f * shading2 + 0.5f * color;  // lerp(0.5, shading2, color)
-}
-
-// One shaded sample (method_raymarching.cu:773-788 / :440-454): object-space normal from forward differences divided by
-// `step`, to world space with xfmNormal (EXTERNAL gdt: transposed inverse of the linear part = rows of wto's columns),
-// shaded, then lerp(scivis_shading_scale = 0.95, albedo, shaded) (instantvnr_types.h:140).
-__device__ __forceinline__ vec3f gradient_shade(const RenderParams& p, vec3f ray_dir_obj, float f, float fgx, float fgy, float fgz,
-                                                vec3f step, vec3f albedo)
-{
-  const vec3f No = {-((fgx - f) / step.x), -((fgy - f) / step.y), -((fgz - f) / step.z)};
-  const vec3f Nw = {dot(p.wto.vx, No), dot(p.wto.vy, No), dot(p.wto.vz, No)};
-  const vec3f dir_w = xfm_vector(p.otw, ray_dir_obj);
-  const vec3f shaded = shade_scivis_light(dir_w, Nw, albedo, p.light_dir);
-  const float k = 0.95f;
-  return (1.0f - k) * albedo + k * shaded;
-}
-
-// ------------------------------------------------------------------------------------------------ DDA (dda.h)
-struct DDAState {
-  vec3f t_next;
-  vec3i cell;
-  float next_cell_begin;
-};
-
-// dda.h:26-46
-__device__ __forceinline__ void dda_init(DDAState& it, vec3f org, vec3f dir, float t_min, vec3i grid)
-{
-  const vec3f oiv = org + t_min * dir;
-  const vec3f fc = {fmaxf(0.0f, fminf((float)grid.x - 1.0f, floorf(oiv.x))), fmaxf(0.0f, fminf((float)grid.y - 1.0f, floorf(oiv.y))),
-                    fmaxf(0.0f, fminf((float)grid.z - 1.0f, floorf(oiv.z)))};
-  const vec3f fe = {dir.x > 0.0f ? fc.x + 1.0f : fc.x, dir.y > 0.0f ? fc.y + 1.0f : fc.y, dir.z > 0.0f ? fc.z + 1.0f : fc.z};
-  const vec3f ts = {fabsf(1.0f / dir.x), fabsf(1.0f / dir.y), fabsf(1.0f / dir.z)};
-  it.t_next = {dir.x == 0.0f ? VNR_FLOAT_LARGE : fabsf(fe.x - oiv.x) * ts.x, dir.y == 0.0f ? VNR_FLOAT_LARGE : fabsf(fe.y - oiv.y) * ts.y,
-               dir.z == 0.0f ? VNR_FLOAT_LARGE : fabsf(fe.z - oiv.z) * ts.z};
-  it.cell = {(int)fc.x, (int)fc.y, (int)fc.z};
-  it.next_cell_begin = 0.0f;
-}
-
-// dda.h:48-122; fn(cell, t0, t1) -> bool
-template <typename F>
-__device__ __forceinline__ bool dda_next(DDAState& it, vec3f dir, float t_min, float t_max, vec3i grid, F&& fn)
-{
-  const vec3i stop = {dir.x > 0.0f ? grid.x : -1, dir.y > 0.0f ? grid.y : -1, dir.z > 0.0f ? grid.z : -1};
-  if (it.cell.x == stop.x) return false;
-  if (it.cell.y == stop.y) return false;
-  if (it.cell.z == stop.z) return false;
-  const vec3f ts = {fabsf(1.0f / dir.x), fabsf(1.0f / dir.y), fabsf(1.0f / dir.z)};
-  const vec3i delta = {dir.x > 0.0f ? 1 : -1, dir.y > 0.0f ? 1 : -1, dir.z > 0.0f ? 1 : -1};
-  const float t_closest = min3f(it.t_next.x, it.t_next.y, it.t_next.z);
-  const float cell_t0 = fmaxf(t_min + it.next_cell_begin, t_min);
-  const float cell_t1 = fminf(t_min + t_closest, t_max);
-  if (cell_t0 >= cell_t1) return false;
-  const bool go = fn(it.cell, cell_t0, cell_t1);
-  if (go || fmaxf(t_min + it.next_cell_begin, t_min) >= cell_t1) {
-    if (it.t_next.x == t_closest) { it.t_next.x += ts.x; it.cell.x += delta.x; if (it.cell.x == stop.x) return false; }
-    if (it.t_next.y == t_closest) { it.t_next.y += ts.y; it.cell.y += delta.y; if (it.cell.y == stop.y) return false; }
-    if (it.t_next.z == t_closest) { it.t_next.z += ts.z; it.cell.z += delta.z; if (it.cell.z == stop.z) return false; }
-    it.next_cell_begin = t_closest;
-  }
-  return go;
-}
-
-// dda.h:124-137
-__device__ __forceinline__ bool dda_resumable(const DDAState& it, vec3f dir, float t_min, float t_max, vec3i grid)
-{
-  const vec3i stop = {dir.x > 0.0f ? grid.x : -1, dir.y > 0.0f ? grid.y : -1, dir.z > 0.0f ? grid.z : -1};
-  if (it.cell.x == stop.x) return false;
-  if (it.cell.y == stop.y) return false;
-  if (it.cell.z == stop.z) return false;
-  const float t_closest = min3f(it.t_next.x, it.t_next.y, it.t_next.z);
-  const float cell_t0 = fmaxf(t_min + it.next_cell_begin, t_min);
-  const float cell_t1 = fminf(t_min + t_closest, t_max);
-  return cell_t0 < cell_t1;
-}
-
-__device__ __forceinline__ float opacity_upper_bound(const RenderParams& p, vec3i cell)
-{
-#if defined(VNR_WALK_NOLOAD)   // experiment: what the walk costs without its one load per macrocell (frames are garbage)
-  return 0.05f + 1e-9f * (float)cell.x;
-#endif
-  const uint32_t idx = cell.x + cell.y * (uint32_t)p.mc_dims.x + cell.z * (uint32_t)p.mc_dims.x * (uint32_t)p.mc_dims.y;
-  return p.mc_max_opacity[idx];
-}
-
-// RayMarchingIter::exec (method_raymarching.cu:555-600); body(t0, t1) -> bool.
-// dda_next with the cell callback written out as one loop, for the latency of a single wave (a small frame share runs one
-// wave per SIMD, and the length of the per-iteration kernel chain is what bounds it):
-//  * the opacity bound of the cell the walk enters NEXT is fetched while the current cell is processed: which cell comes
-//    next depends only on the DDA state, not on what the current cell holds (an empty run of cells is otherwise a chain of
-//    dependent L2 round trips).  The fetch is unconditional (a walk that leaves the grid re-reads its current cell) so that
-//    the compiler's wait-count bookkeeping sees one pending load on every path;
-//  * the advance is written with selects instead of dda_next's three early returns.  A walk that leaves the grid through x
-//    therefore also advances y / z and next_cell_begin where dda_next returns first; nothing reads that state again
-//    (dda_resumable and this function test the cell against `stop` before anything else).
-// Inside the grid the state (cell, t_next, next_cell_begin) goes through exactly dda_next's operations.
-template <typename B>
-__device__ __forceinline__ void iter_exec(const RenderParams& p, DDAState& it, vec3f dir, float t_min, float t_max, float step, B&& body)
-{
-  const vec3i grid = p.mc_dims;
-  const vec3i stop = {dir.x > 0.0f ? grid.x : -1, dir.y > 0.0f ? grid.y : -1, dir.z > 0.0f ? grid.z : -1};
-  if (it.cell.x == stop.x || it.cell.y == stop.y || it.cell.z == stop.z) return;
-  const vec3f ts = {fabsf(1.0f / dir.x), fabsf(1.0f / dir.y), fabsf(1.0f / dir.z)};
-  const vec3i delta = {dir.x > 0.0f ? 1 : -1, dir.y > 0.0f ? 1 : -1, dir.z > 0.0f ? 1 : -1};
-  float r = opacity_upper_bound(p, it.cell);
-  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): inside the loop only the look-ahead load is in flight
-  bool more = true;
-  while (more) {
-    const float t_closest = min3f(it.t_next.x, it.t_next.y, it.t_next.z);
-    const float cell_t0 = fmaxf(t_min + it.next_cell_begin, t_min);
-    const float cell_t1 = fminf(t_min + t_closest, t_max);
-    if (cell_t0 >= cell_t1) break;
-    // the cell after this one
-    const bool bx = it.t_next.x == t_closest, by = it.t_next.y == t_closest, bz = it.t_next.z == t_closest;
-    const vec3i nc = {it.cell.x + (bx ? delta.x : 0), it.cell.y + (by ? delta.y : 0), it.cell.z + (bz ? delta.z : 0)};
-    const bool inside = nc.x != stop.x && nc.y != stop.y && nc.z != stop.z;
-    const float r_next = opacity_upper_bound(p, inside ? nc : it.cell);
-    // the cell callback of RayMarchingIter::exec
-    bool go = true;
-    if (!(fabsf(r) <= FLT_EPSILON)) {
-      const float ss = adaptive_sampling_rate(step, r);
-      float tx = cell_t0, ty = fminf(cell_t1, cell_t0 + ss);
-      // (one exit: `while (ty > tx) { ...; if (!body(tx, ty)) { go = false; break; } ... }` written so that the loop's divergent lanes
-      // rejoin in one place: 20 instructions and one branch per sample instead of 30 and three; what is computed once more after a full
-      // batch, tx and ty, is not read again.  The frame did not notice: 3.65-3.72 against 3.67-3.68 ms, n = 3)
-      bool run = ty > tx;
-      while (run) {
-        it.next_cell_begin = ty - t_min;
-        go = body(tx, ty);
-        tx = ty;
-        ty = fminf(tx + ss, cell_t1);
-        run = go && ty > tx;
-      }
-    }
-    const bool adv = go || fmaxf(t_min + it.next_cell_begin, t_min) >= cell_t1;
-    it.t_next.x = (adv && bx) ? it.t_next.x + ts.x : it.t_next.x;
-    it.t_next.y = (adv && by) ? it.t_next.y + ts.y : it.t_next.y;
-    it.t_next.z = (adv && bz) ? it.t_next.z + ts.z : it.t_next.z;
-    it.cell.x = adv ? nc.x : it.cell.x;
-    it.cell.y = adv ? nc.y : it.cell.y;
-    it.cell.z = adv ? nc.z : it.cell.z;
-    it.next_cell_begin = adv ? t_closest : it.next_cell_begin;
-    more = go && inside;
-    r = r_next;
-  }
-}
-
-// depth bin of a sample inside its 64-ray group (gather-order counting sort of march_kernel)
-__device__ __forceinline__ uint32_t depth_bin(const RenderParams& p, float t, float front)
-{
-  return (p.debug_flags & 4u) ? 0u : min((uint32_t)kDepthBins - 1u, (uint32_t)fmaxf((t - front) * p.bin_depth_rcp, 0.0f));
-}
 
 // ------------------------------------------------------------------------------------------------ streaming march kernel
 // FIRST: thread = pixel of an 8x8 pixel tile (raygen, method_raymarching.cu:840-875) and emits the first batch.
@@ -433,7 +86,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
   if (!FIRST && p.tfn_in_lds) {
     vec4f* s_colors = (vec4f*)(s_rk + (p.no_ranks ? 0 : (size_t)p.n_iters * 256));
     float* s_alphas = (float*)(s_colors + p.tfn.n_colors);
-    tfn_merged = tfn_tables_to_lds(p.tfn, s_colors, s_alphas, !(p.debug_flags & 32u));
+    tfn_merged = tfn_tables_to_lds(p.tfn, s_colors, s_alphas, !(dbg(p) & 32u));
     __syncthreads();
     lds_colors = (tfn_lds_colors_t)s_colors;
     lds_alphas = (tfn_lds_alphas_t)s_alphas;
@@ -535,7 +188,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
         // 4.2).  The batch is composed in chunks: the chunk's results are fetched back to back (clamped index, no predicate:
         // one trip per chunk), then classified and blended in order with the reference's early exit.
         constexpr uint32_t kChunk = 8;
-        const uint32_t sc_eff = (p.debug_flags & 1u) ? 0u : sc;
+        const uint32_t sc_eff = (dbg(p) & 1u) ? 0u : sc;
         bool saturated = false;
 #if defined(VNR_MARCH_STAMPS)
         unsigned long long acc_load = 0, acc_cls = 0, acc_blend = 0;
@@ -563,7 +216,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
           vec3f crgb[kChunk]; float ca[kChunk];
 #pragma unroll
           for (uint32_t j = 0; j < kChunk; ++j) {
-            if (p.debug_flags & 2u) { crgb[j] = {0.5f, 0.5f, 0.5f}; ca[j] = chunk[j].x * 0.01f; }
+            if (dbg(p) & 2u) { crgb[j] = {0.5f, 0.5f, 0.5f}; ca[j] = chunk[j].x * 0.01f; }
             else if (p.tfn_in_lds) tfn_sample_lds(tfn, lds_colors, lds_alphas, chunk[j].x, crgb[j], ca[j], tfn_merged);   // uniform branch
             else tfn_sample(tfn, chunk[j].x, crgb[j], ca[j]);
             ca[j] = opacity_correction(p.step_rcp, chunk[j].y, ca[j]);
@@ -623,7 +276,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     uint32_t dbg_cells = 0;
     const vec3i dbg_cell0 = it.cell;
 #endif
-    if (alive && !(p.debug_flags & 8u)) {
+    if (alive && !(dbg(p) & 8u)) {
       const int n_iters = p.n_iters;
       iter_exec(p, it, m_dir, tmin, tmax, p.step, [&](float t0, float t1) -> bool {
         s_t0[k * 256u + tid] = t0;
@@ -690,7 +343,7 @@ __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const 
     ++trip;
     VNR_STAMP(st4);
     VNR_STAMP_ADD(3, st3, st4);   // compaction, block-wide slot claim (two barriers)
-    if (wave_rays == 0 || (p.debug_flags & 16u)) continue;  // wave-uniform
+    if (wave_rays == 0 || (dbg(p) & 16u)) continue;  // wave-uniform
 
     // depth bins of the group: front = smallest first-sample depth among the surviving rays
     float front = survive ? s_t0[tid] : VNR_FLOAT_LARGE;
@@ -937,156 +590,6 @@ __global__ void monolithic_kernel(const RenderParams p)
   write_pixel(p, {color.x, color.y, color.z, alpha}, pixel);
 }
 
-// ================================================================================================ path tracing (mode 14)
-// Sample-streaming path tracer: core/renderer/method_pathtracing.cu:532-813 (DeltaTrackingIter with the macrocell majorants,
-// iterative_take_sample, iterative_shade, raygen / shade kernels, do_path_tracing_iterative); VARYING_MAJORANT = 1 there
-// (ADAPTIVE_SAMPLING is not defined in that translation unit, :24-27).  One volume sample per alive ray and iteration.
-// Structure here: one kernel per iteration does shade + the delta tracking to the next tentative collision (the reference's
-// raygen / shade kernels, fused), survivors stay in their 64-ray group's slots and pt_compact_kernel packs them in group order
-// (the order-preserving compaction of the ray marcher) and writes the queue records the evaluation kernel reads, so the ray
-// count never visits the host either.
-constexpr int kPtPlanes = 26;  // dwords of state per ray, one plane each: see PtRay::load / store
-struct PtRays { float* base; uint32_t stride; };
-
-struct PtRay {
-  float tnear, tfar;
-  uint32_t pidx; bool shadow;
-  vec3f org, dir;
-  uint32_t scatter_index;
-  vec3f sample_coord;
-  float majorant;
-  vec3f L, throughput;
-  DDAState it;
-  uint32_t rng;   // gdt::LCG state (EXTERNAL): next = 1664525 state + 1013904223, float = low 24 bits / 2^24
-  __device__ __forceinline__ float next_float()
-  {
-    rng = 1664525u * rng + 1013904223u;
-    return (float)(rng & 0x00FFFFFFu) / (float)0x01000000;
-  }
-  __device__ __forceinline__ void load(const PtRays r, uint32_t i)
-  {
-    const float* b = r.base + i;
-    const uint32_t st = r.stride;
-    const uint32_t bits = __float_as_uint(b[0]);
-    shadow = (bits & 1u) != 0u; pidx = bits >> 1;
-    org = {b[1 * st], b[2 * st], b[3 * st]};
-    dir = {b[4 * st], b[5 * st], b[6 * st]};
-    scatter_index = __float_as_uint(b[7 * st]);
-    sample_coord = {b[8 * st], b[9 * st], b[10 * st]};
-    majorant = b[11 * st];
-    L = {b[12 * st], b[13 * st], b[14 * st]};
-    throughput = {b[15 * st], b[16 * st], b[17 * st]};
-    rng = __float_as_uint(b[18 * st]);
-    it.t_next = {b[19 * st], b[20 * st], b[21 * st]};
-    it.cell = {(int)__float_as_uint(b[22 * st]), (int)__float_as_uint(b[23 * st]), (int)__float_as_uint(b[24 * st])};
-    it.next_cell_begin = b[25 * st];
-  }
-  __device__ __forceinline__ void store(const PtRays r, uint32_t i) const
-  {
-    float* b = r.base + i;
-    const uint32_t st = r.stride;
-    b[0] = __uint_as_float((pidx << 1) | (shadow ? 1u : 0u));
-    b[1 * st] = org.x; b[2 * st] = org.y; b[3 * st] = org.z;
-    b[4 * st] = dir.x; b[5 * st] = dir.y; b[6 * st] = dir.z;
-    b[7 * st] = __uint_as_float(scatter_index);
-    b[8 * st] = sample_coord.x; b[9 * st] = sample_coord.y; b[10 * st] = sample_coord.z;
-    b[11 * st] = majorant;
-    b[12 * st] = L.x; b[13 * st] = L.y; b[14 * st] = L.z;
-    b[15 * st] = throughput.x; b[16 * st] = throughput.y; b[17 * st] = throughput.z;
-    b[18 * st] = __uint_as_float(rng);
-    b[19 * st] = it.t_next.x; b[20 * st] = it.t_next.y; b[21 * st] = it.t_next.z;
-    b[22 * st] = __uint_as_float((uint32_t)it.cell.x); b[23 * st] = __uint_as_float((uint32_t)it.cell.y); b[24 * st] = __uint_as_float((uint32_t)it.cell.z);
-    b[25 * st] = it.next_cell_begin;
-  }
-};
-
-// DeltaTrackingIter::hashit (:545-573)
-__device__ __forceinline__ bool pt_hashit(const RenderParams& p, PtRay& r, float& rayt)
-{
-  const vec3f m_dir = r.dir * p.mc_rcp;
-  bool found_hit = false;
-  float tau = -logf(1.0f - r.next_float());
-  float t = r.it.next_cell_begin + r.tnear;
-  while (dda_next(r.it, m_dir, r.tnear, r.tfar, p.mc_dims, [&](vec3i c, float /*t0*/, float t1) -> bool {
-    r.majorant = opacity_upper_bound(p, c) * p.density_scale;
-    if (fabsf(r.majorant) <= FLT_EPSILON) return true;  // next macrocell; t is not advanced, as in the reference
-    tau -= (t1 - t) * (r.majorant * 1.0f);
-    t = t1;
-    if (tau > 0.0f) return true;
-    t = t + tau / (r.majorant * 1.0f);
-    found_hit = true;
-    r.it.next_cell_begin = t - r.tnear;
-    rayt = t;
-    return false;
-  })) {}
-  return found_hit;
-}
-
-// uniform_sample_sphere (raytracing.h:253-270); phi = 2 * M_PI * s.x is a double expression rounded to float
-__device__ __forceinline__ vec3f pt_uniform_sample_sphere(float sx, float sy)
-{
-  const float phi = (float)(2 * M_PI * (double)sx);
-  const float cos_theta = 1.0f - 2.0f * sy;
-  const float sin_theta = 2.0f * sqrtf(sy * (1.0f - sy));
-  float sp, cp;
-  sincosf(phi, &sp, &cp);
-  return {cp * sin_theta, sp * sin_theta, cos_theta};
-}
-
-// iterative_take_sample (:598-636)
-__device__ __forceinline__ bool pt_take_sample(const RenderParams& p, PtRay& r)
-{
-  float t;
-  if (pt_hashit(p, r, t)) { r.sample_coord = r.org + t * r.dir; return true; }
-  if (r.scatter_index > 0u) {  // no light accumulation for primary rays
-    if (r.shadow) {
-      r.L = r.L + r.throughput;   // * light_directional_rgb = 1 (instantvnr_types.h:147)
-      r.shadow = false;
-      const float s0 = r.next_float(), s1 = r.next_float();
-      r.dir = xfm_vector(p.wto, pt_uniform_sample_sphere(s0, s1));
-      if (p.pt_reset_interval) { r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE; }
-      if (!intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi)) return false;   // mode 14: the interval is not reset first
-      dda_init(r.it, r.org * p.mc_rcp, r.dir * p.mc_rcp, r.tnear, p.mc_dims);
-      if (pt_hashit(p, r, t)) { r.sample_coord = r.org + t * r.dir; return true; }
-      // the bounce leaves the volume at once: mode 14 ends the path here without the ambient term (:631-635 falls through to
-      // `return false`), the in-shader / monolithic estimator adds it on its next loop trip (:447-452, 1008-1013)
-      if (p.pt_reset_interval) r.L = r.L + 1.5f * r.throughput;
-    } else {
-      r.L = r.L + 1.5f * r.throughput;   // light_ambient = 1.5 (instantvnr_types.h:146)
-    }
-  }
-  return false;
-}
-
-// iterative_shade (:638-677)
-__device__ __forceinline__ bool pt_shade(const RenderParams& p, const DeviceTfn& tfn, PtRay& r, float value)
-{
-  vec3f albedo; float a;
-  tfn_sample(tfn, value, albedo, a);
-  if (r.next_float() * r.majorant >= a * p.density_scale) return true;   // null collision
-  if (r.shadow) {
-    r.shadow = false;
-    const float s0 = r.next_float(), s1 = r.next_float();
-    r.dir = xfm_vector(p.wto, pt_uniform_sample_sphere(s0, s1));
-    if (p.pt_reset_interval) { r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE; }
-  } else {
-    if (r.scatter_index > 4u) {  // russian_roulette (:366-376), russian_roulette_length = 4
-      const float q = fminf(0.95f, max3f(r.throughput.x, r.throughput.y, r.throughput.z));
-      if (r.next_float() > q) return false;
-      r.throughput = {r.throughput.x / q, r.throughput.y / q, r.throughput.z / q};
-    }
-    ++r.scatter_index;
-    r.org = r.sample_coord;
-    r.tnear = 0.0f; r.tfar = VNR_FLOAT_LARGE;
-    r.throughput = r.throughput * (0.6f * albedo);   // PHASE(albedo) = albedo * 0.6f (:35)
-    r.shadow = true;
-    r.dir = p.shadow_dir;
-  }
-  if (!intersect_box(r.tnear, r.tfar, r.org, r.dir, p.bbox_lo, p.bbox_hi)) return false;
-  dda_init(r.it, r.org * p.mc_rcp, r.dir * p.mc_rcp, r.tnear, p.mc_dims);
-  return true;
-}
-
 // FIRST: iterative_raygen_kernel (:679-748), thread = pixel of an 8x8 tile; else iterative_shade_kernel (:750-768), thread = alive ray
 template <bool FIRST>
 __global__ void __launch_bounds__(256) pt_kernel(const RenderParams p, const PtRays dense, const PtRays scratch, const float* __restrict__ values,
@@ -1258,7 +761,7 @@ __global__ void __launch_bounds__(1024) pt_compact_kernel(const PtRays src, cons
 }
 
 }  // namespace vnr
-#include "in_shader.h"   // in_shader_kernel, in_shader_pt_kernel: use the device code above
+#include "in_shader.h"   // the in-shader kernels' shapes and launch record (the kernels themselves are instantiated in in_shader_w*.hip)
 #include "decoupled.h"   // walk_kernel, compose_kernel: the streaming loop with the walk off the evaluate -> compose chain
 namespace vnr {
 
@@ -1335,6 +838,7 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   stream_ = Runtime::get().stream;
   // experiment (tools/two_renderers.py): a renderer whose part-0 chain does not share the runtime's stream with other renderers
   if (const char* e = std::getenv("VNR_AMD_RENDERER_OWN_STREAM")) if (std::atoi(e) != 0) { VNR_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); own_stream_ = true; }
+  if (const char* e = std::getenv("VNR_AMD_MARCH_RANKS")) march_ranks_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("VNR_RM_N_ITERS")) { n_iters_ = std::max(1, std::min(48, std::atoi(e))); n_iters_fixed_ = true; }  // 2.5 KiB of LDS per iteration slot and block
   // streaming mode runs the rays as two halves on two streams (render_streaming); VNR_AMD_RENDER_HALVES=1: one stream
   if (const char* e = std::getenv("VNR_AMD_RENDER_HALVES")) { n_halves_ = std::max(1, std::min(kMaxParts, std::atoi(e))); n_halves_fixed_ = true; }
@@ -1579,7 +1083,9 @@ void Renderer::render()
   const uint32_t rows_local = il_parts_ == 1 ? (tr_hi - tr_lo) : div_round_up(div_round_up((uint32_t)height_, 8), il_parts_);
   p.n_local = rows_local * p.tiles_per_row * 64u;
   p.debug_flags = 0;
+#if defined(VNR_DIAG)
   if (const char* e = std::getenv("VNR_AMD_DEBUG_FLAGS")) p.debug_flags = (uint32_t)std::atoi(e);
+#endif
   static const float bin_depth = std::getenv("VNR_AMD_BIN_DEPTH") ? std::max(0.5f, (float)std::atof(std::getenv("VNR_AMD_BIN_DEPTH"))) : 8.0f;   // diagnostics (3 .. 8 measure the same)
   p.bin_depth_rcp = 1.0f / bin_depth;  // 8 world units (voxels) per depth bin ~ the footprint of an 8x8 pixel tile
   // camera, renderer.cpp:87-96
@@ -1626,10 +1132,7 @@ void Renderer::render()
   // A march block stages its batch in LDS: 10 bytes per sample with the depth sort's ranks (83 KB at 32 samples: ONE block per CU), 8 without
   // them (67 KB: two).  VNR_AMD_MARCH_RANKS=0 drops the ranks (the slot inside a bin is then claimed from the bin's counter when the record
   // is written; same frames).  Measured on 1/8 .. 1/1 of the bench frame: no difference (profiles/r03_march_ranks.txt), so they stay.
-  {
-    static const int ranks_mode = [] { const char* e = std::getenv("VNR_AMD_MARCH_RANKS"); return e ? std::atoi(e) : 1; }();
-    p.no_ranks = ranks_mode == 0 ? 1u : 0u;
-  }
+  p.no_ranks = march_ranks_ ? 0u : 1u;
   // gradient shading (modes 7 / 8)
   p.otw = volume_->transform;
   p.grad_step = {1.0f / (float)p.vol_dims.x, 1.0f / (float)p.vol_dims.y, 1.0f / (float)p.vol_dims.z};  // object.cpp:305
@@ -1733,8 +1236,15 @@ void Renderer::render()
   }
 }
 
-// model shapes with an in-shader instance (F, padded input width); the others take the streaming path
-#define VNR_IN_SHADER_SHAPES(X) X(2, 16) X(2, 32) X(2, 64) X(4, 32) X(4, 64) X(8, 64)
+// the in-shader kernels, one translation unit per FullyFusedMLP width and kind (in_shader_w*.hip); -> false: no instance for the shape
+bool launch_in_shader_w16(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
+bool launch_in_shader_w32(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
+bool launch_in_shader_w64(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
+bool launch_in_shader_w128(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
+bool launch_in_shader_w16g(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
+bool launch_in_shader_w32g(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
+bool launch_in_shader_w64g(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
+bool launch_in_shader_w128g(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
 
 bool Renderer::in_shader_applies() const
 {
@@ -1751,7 +1261,9 @@ bool Renderer::in_shader_applies() const
   const bool want = choice >= 0 ? choice == 1 : (mode_ == 14 || mode_ == 15);
   if (!want || !volume_->is_network()) return false;
   const Network& net = static_cast<NeuralVolume*>(volume_.get())->network();
-  if (!net.valid() || !net.common_kind() || net.width() != (uint32_t)kWidth) return false;   // the in-shader kernels are 64-neuron instances of the common kind
+  // every width and kind of model has an instance (round 5) as long as its weight image fits the LDS beside the kernel's 48 static bytes
+  // (deeper networks keep their weights in global memory and take the streaming path) and its encoding is one of VNR_IN_SHADER_SHAPES
+  if (!net.valid() || !net.weights_in_lds() || (size_t)net.lds_halves() * 2 + 64 > 160 * 1024) return false;
   const uint32_t F = net.config().n_features, K = net.padded_width();
 #define X(f, k) if (F == f && K == k) return true;
   VNR_IN_SHADER_SHAPES(X)
@@ -1767,24 +1279,20 @@ void Renderer::render_in_shader(const RenderParams& p, int shade)
   if (is_samples_.count == 0) { is_samples_.resize(kInShaderStatSlots); is_hits_.resize(kInShaderStatSlots); }
   is_samples_.zero(stream_);
   is_hits_.zero(stream_);
-  const uint32_t blocks = div_round_up(p.n_local, 256);
-  const size_t shmem = (size_t)net.lds_halves * sizeof(uint16_t);
+  InShaderLaunch l;
+  l.blocks = div_round_up(p.n_local, 256);
+  l.shmem = (size_t)net.lds_halves * sizeof(uint16_t);
+  l.stream = stream_;
+  l.stat_samples = is_samples_.ptr;
+  l.stat_hits = is_hits_.ptr;
   bool launched = false;
-  auto launch = [&](auto kernel) {
-    // (the kernel also has 48 bytes of static LDS: the dynamic part cannot be the whole 160 KB)
-    if (shmem > 48 * 1024) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    kernel<<<blocks, 256, shmem, stream_>>>(p, net, is_samples_.ptr, is_hits_.ptr);
-    launched = true;
-  };
-#define X(f, k)                                                                     \
-  if (!launched && net.n_features == f && net.in_width == k) {                      \
-    if (shade == kInShaderPathTracing) launch(in_shader_pt_kernel<f, k>);          \
-    else if (shade == M_GRADIENT) launch(in_shader_kernel<f, k, M_GRADIENT>);       \
-    else if (shade == M_SSH) launch(in_shader_kernel<f, k, M_SSH>);                 \
-    else launch(in_shader_kernel<f, k, M_NONE>);                                    \
+  switch (net.width) {
+  case 16: launched = net.general ? launch_in_shader_w16g(p, net, shade, l) : launch_in_shader_w16(p, net, shade, l); break;
+  case 32: launched = net.general ? launch_in_shader_w32g(p, net, shade, l) : launch_in_shader_w32(p, net, shade, l); break;
+  case 64: launched = net.general ? launch_in_shader_w64g(p, net, shade, l) : launch_in_shader_w64(p, net, shade, l); break;
+  case 128: launched = net.general ? launch_in_shader_w128g(p, net, shade, l) : launch_in_shader_w128(p, net, shade, l); break;
+  default: break;
   }
-  VNR_IN_SHADER_SHAPES(X)
-#undef X
   if (!launched) throw std::runtime_error("internal: no in-shader instance for this model shape");
   VNR_HIP_CHECK(hipGetLastError());
   unsigned long long hs[kInShaderStatSlots];
@@ -1942,7 +1450,11 @@ void Renderer::launch_tail(StreamingFrame& f, int h, uint32_t it, hipStream_t s_
     bool packed = false;
     if (!s_it) s_it = hf.s;
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], s_it));
+#if defined(VNR_DIAG)
     static const bool skip_eval = [] { const char* e = std::getenv("VNR_AMD_DEBUG_SKIP_EVAL"); return e && std::atoi(e) != 0; }();   // timing of the march / packing chain alone (frames are garbage)
+#else
+    constexpr bool skip_eval = false;
+#endif
     if (skip_eval) {
     } else if (nv) {
       // a record's 4th word is the float index of its result in this arena (stride 1)
@@ -2076,7 +1588,9 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
     lds_attr_set = true;
   }
   uint32_t max_iterations = 240;
-  if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) max_iterations = std::max(1, std::min(240, std::atoi(e)));  // diagnostics only
+#if defined(VNR_DIAG)
+  if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) max_iterations = std::max(1, std::min(240, std::atoi(e)));  // truncated (wrong) frames, for timing
+#endif
   if (profiling_) {
     iter_ms_.assign(max_iterations, 0.0f);
     for (int h = 0; h < H; ++h)
@@ -2274,7 +1788,9 @@ void Renderer::render_decoupled(const RenderParams& p_all, bool defer)
   f.shmem_compose = p_all.tfn_in_lds ? (size_t)p_all.tfn.n_colors * sizeof(vec4f) + (size_t)p_all.tfn.n_alphas * sizeof(float) : 0;
   if (f.shmem > 160 * 1024) throw std::runtime_error("VNR_RM_N_ITERS too large for the LDS of one workgroup");
   f.max_iterations = 240;
-  if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) f.max_iterations = std::max(1, std::min(240, std::atoi(e)));  // diagnostics only
+#if defined(VNR_DIAG)
+  if (const char* e = std::getenv("VNR_AMD_DEBUG_MAX_ITERS")) f.max_iterations = std::max(1, std::min(240, std::atoi(e)));  // truncated (wrong) frames, for timing
+#endif
   static bool lds_attr_set = false;
   if (!lds_attr_set) {
     VNR_HIP_CHECK(hipFuncSetAttribute((const void*)walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2371,7 +1887,11 @@ void Renderer::decoupled_step(StreamingFrame& f, int h, bool head_only)
     VNR_HIP_CHECK(hipEventRecord(d.ev(d.ev_w, it), d.sw));
     VNR_HIP_CHECK(hipStreamWaitEvent(d.se, d.ev(d.ev_w, it), 0));
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it], d.se));
+#if defined(VNR_DIAG)
     static const bool skip_eval = [] { const char* e = std::getenv("VNR_AMD_DEBUG_SKIP_EVAL"); return e && std::atoi(e) != 0; }();   // timing of the walk / compose kernels alone (frames are garbage)
+#else
+    constexpr bool skip_eval = false;
+#endif
     if (skip_eval) {
     } else if (f.nv) {
       f.nv->network().inference_queue((const float*)ring.queue, (float*)ring.arena, 1, ring.ctr + D_SAMPLES, d.s_max, d.se, (uint32_t)f.H, nullptr);

@@ -131,6 +131,7 @@ private:
   DeviceBuffer<unsigned long long> is_samples_{MemTag::Renderer};   // in-shader kernel statistics, kInShaderStatSlots each
   DeviceBuffer<uint32_t> is_hits_{MemTag::Renderer};
   int in_shader_mode_ = -1;
+  bool march_ranks_ = true;      // VNR_AMD_MARCH_RANKS (read when the renderer is created): the depth sort's ranks kept in LDS (2 bytes per sample)
   bool n_iters_fixed_ = false;   // VNR_RM_N_ITERS given: no adaptation to the size of the share
   // LaunchParams::light_directional_dir (instantvnr_types.h:148): a member the reference negates IN PLACE whenever it points
   // along the view direction (renderer.cpp:98-101), so it persists across frames

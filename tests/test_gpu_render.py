@@ -846,16 +846,83 @@ def test_in_shader_kernel_shares_and_pixel_ranges(oracle, scene):
 
 
 def test_in_shader_kernel_falls_back_where_it_has_no_instance(oracle, scene):
-    """a model shape without an in-shader instance (F = 1) and a dense volume take the streaming path: mode 6 still renders"""
-    cfg = syn.model_config(n_levels=16, n_features=1, log2_hashmap_size=14, base_resolution=4, n_hidden_layers=2)
-    nv = api.vnrCreateNeuralVolume(cfg, scene["sv"], online_macrocell_construction=False)
-    info = api.neural_info(nv)
-    api.neural_set_params_fp16(nv, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], 64, 1), seed=5))
-    for volume in (nv, scene["sv"]):
+    """what is left without an in-shader instance after round 5 -- an encoded width outside the kernels' shape list (20 levels x 4 features =
+    80), a network whose weight image exceeds the LDS (128 neurons x 7 hidden layers: its weights stay in global memory) -- and a dense
+    volume take the streaming path: mode 6 still renders, and it is mode 5's frame"""
+    shapes = [dict(n_levels=20, n_features=4, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2, per_level_scale=1.3),
+              dict(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=7, n_neurons=128)]
+    volumes = [scene["sv"]]
+    for kw in shapes:
+        W = kw.get("n_neurons", 64)
+        cfg = syn.model_config(**kw)
+        nv = api.vnrCreateNeuralVolume(cfg, scene["sv"], online_macrocell_construction=False)
+        info = api.neural_info(nv)
+        api.neural_set_params_fp16(nv, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], W, kw["n_hidden_layers"] - 1), seed=5,
+                                                         mlp_scale=0.5 if W == 128 else 1.0))
+        volumes.append(nv)
+    for volume in volumes:
         r6, r5 = make_renderer(scene, volume, size=(64, 56), mode=6), make_renderer(scene, volume, size=(64, 56), mode=5)
+        _set_in_shader(r6, 1)
         api.vnrRender(r6); api.vnrRender(r5)
         assert api.vnrRendererGetFrameStats(r6)["n_iterations"] >= 1
         assert np.array_equal(api.vnrRendererMapFrame(r6), api.vnrRendererMapFrame(r5))
+
+
+# every FullyFusedMLP width the reference's in-shader dispatch instantiates (16 / 32 / 64, method_raymarching.cu:1192-1244; 128, refused
+# there at :1210, comes with the template here) and models of the GENERAL kind (grid_device.h), F = 1 .. 8
+IN_SHADER_MODELS = {
+    "w16": dict(W=16, L=16, F=2, H=3),
+    "w32": dict(W=32, L=16, F=2, H=3),
+    "w128": dict(W=128, L=8, F=4, H=2, scale=0.5),
+    "w16-f1": dict(W=16, L=16, F=1, H=2),
+    "w32-f8": dict(W=32, L=8, F=8, H=2),
+    "w64-sigmoid-exp": dict(W=64, L=8, F=2, H=2, act="Sigmoid", out_act="Exponential", scale=0.5),
+    "w32-nearest-quantized": dict(W=32, L=16, F=2, H=2, interp="Nearest", qt=0.05),
+    "w16-tiled-smoothstep": dict(W=16, L=8, F=4, H=3, gtype="Tiled", interp="Smoothstep", act="Squareplus"),
+}
+
+
+def _in_shader_model(oracle, scene, name, seed):
+    m = IN_SHADER_MODELS[name]
+    cfg = syn.model_config(n_levels=m["L"], n_features=m["F"], log2_hashmap_size=14, base_resolution=4, n_hidden_layers=m["H"], per_level_scale=1.4,
+                           n_neurons=m["W"])
+    cfg["network"]["activation"] = m.get("act", "ReLU")
+    cfg["network"]["output_activation"] = m.get("out_act", "None")
+    cfg["encoding"]["interpolation"] = m.get("interp", "Linear")
+    if "gtype" in m: cfg["encoding"]["type"] = m["gtype"]
+    if "qt" in m: cfg["encoding"]["quantize_threshold"] = m["qt"]
+    nv = api.vnrCreateNeuralVolume(cfg, scene["sv"], online_macrocell_construction=False)
+    info = api.neural_info(nv)
+    api.neural_set_params_fp16(nv, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], m["W"], m["H"] - 1), seed=seed,
+                                                     mlp_scale=m.get("scale", 1.0)))
+    return nv
+
+
+@pytest.mark.parametrize("name", sorted(IN_SHADER_MODELS))
+def test_in_shader_kernels_of_every_width_and_kind(oracle, scene, name):
+    """modes 6 / 9 / 12 / 14 / 15 on models of 16, 32 and 128 neurons and of the GENERAL kind take the in-shader kernel (ONE launch per frame:
+    n_iterations == 1) and give the streaming path's frame: bit for bit in the path-tracing modes (the same chain of decisions on the same
+    network bits), to the streaming path's resume rounding in the marching modes (the bars of the 64-neuron test above); hit rays equal"""
+    nv = _in_shader_model(oracle, scene, name, seed=77)
+    size = (64, 48)
+    for mode in (6, 9, 12, 14, 15):
+        frames, stats = {}, {}
+        for kernel in (1, 0):
+            r = make_renderer(scene, nv, size=size, mode=mode)
+            if mode >= 14: api.vnrRendererSetVolumeDensityScale(r, 0.5)
+            _set_in_shader(r, kernel)
+            api.vnrRender(r); api.vnrRender(r)          # the second frame accumulates (other random numbers)
+            frames[kernel] = api.vnrRendererMapFrame(r).copy()
+            stats[kernel] = api.vnrRendererGetFrameStats(r)
+        assert stats[1]["n_iterations"] == 1, (name, mode, "the in-shader kernel was not taken")
+        assert stats[1]["n_rays_hit"] == stats[0]["n_rays_hit"] > 500
+        assert np.isfinite(frames[1]).all()
+        if mode >= 14:
+            assert stats[1]["n_samples"] == stats[0]["n_samples"]
+            assert np.array_equal(frames[1], frames[0]), (name, mode)
+        else:
+            d = np.abs(frames[1] - frames[0])
+            assert d.max() < 2e-3 and psnr(frames[1], frames[0]) > 70, (name, mode, d.max(), psnr(frames[1], frames[0]))
 
 
 @pytest.mark.parametrize("mode", [14, 15])

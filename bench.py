@@ -119,6 +119,28 @@ def cpu_baseline(sv, nv, info, dims, tfn_np, cam, fb, mc, pls, hidden_layers, lo
     return out
 
 
+def kernel_source_sha16():
+    """what the evaluation kernel is compiled from: counter results of separate rocprofv3 --pmc passes (profiles/*.json) are put into the
+    line only while this still names the sources they were measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in ("infer_kernel.h", "infer_tile.h", "grid_device.h", "network_infer.hip", "network_infer_w64.hip"):
+        h.update(open(os.path.join(ROOT, "instantvnr_amd", "csrc", n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def grid_levels(n_levels, log2_T, base, pls):
+    """entries and kind of every level (EXTERNAL tcnn level sizing): res = ceil(base * pls^l - 1) + 1,
+    n = min(next_multiple(res^3, 8), 2^log2_T); a level is hashed when res^3 exceeds the table"""
+    out = []
+    for l in range(n_levels):
+        scale = float(np.float32(np.exp2(np.float32(l) * np.float32(np.log2(pls)))) * np.float32(base) - np.float32(1.0))
+        res = int(np.ceil(scale)) + 1
+        full = (res ** 3 + 7) // 8 * 8
+        out.append({"res": res, "entries": min(full, 1 << log2_T), "hashed": res ** 3 > (1 << log2_T)})
+    return out
+
+
 def workload_name(a):
     if (a.size, a.fb, a.levels, a.features, a.hidden_layers) == (1024, 1024, 16, 2, 3):
         return "C4"
@@ -232,7 +254,10 @@ def choose_transport():
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
     env["VNR_AMD_DIST_TIMEOUT"] = env.get("VNR_AMD_DIST_TIMEOUT", "120")
-    limit = float(os.environ.get("VNR_BENCH_PROBE_LIMIT", "240"))
+    # the child's worst case is its rendezvous timeout + five collectives at their deadline each: the limit must not cut a child that
+    # would still have answered
+    deadline = float(os.environ.get("VNR_BENCH_SELFTEST_DEADLINE", "60"))
+    limit = max(float(os.environ.get("VNR_BENCH_PROBE_LIMIT", "0")), float(env["VNR_AMD_DIST_TIMEOUT"]) + 5 * deadline + 30)
     t0 = time.perf_counter()
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-collectives"], env=env, capture_output=True, text=True, timeout=limit)
@@ -243,6 +268,30 @@ def choose_transport():
     except subprocess.TimeoutExpired:
         ok, said = False, f"FAILED: no answer within {limit:.0f} s (child killed)"
     probe = {"rccl": said[:600], "seconds": round(time.perf_counter() - t0, 1)}
+    # The children agree among themselves before they exit, but a child that is killed at the limit or dies after that agreement leaves ITS
+    # parent with another verdict than the others, and ranks that then meet with different transports hang in the rendezvous.
+    # So the parents agree too, without any transport: one file per rank in /dev/shm (one node), keyed by the launcher's pid and port;
+    # RCCL only if every rank's child said ok.
+    key = f"vnr_bench_probe_{os.environ.get('MASTER_PORT', '29500')}_{os.getppid()}"
+    rank = int(os.environ.get("RANK", "0"))
+    base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", key)
+    with open(f"{base}_{rank}.tmp", "w") as f:
+        f.write("ok" if ok else "failed")
+    os.replace(f"{base}_{rank}.tmp", f"{base}_{rank}")
+    t_wait = time.perf_counter()
+    verdicts = {}
+    while len(verdicts) < world and time.perf_counter() - t_wait < limit + 60:
+        for r in range(world):
+            if r not in verdicts and os.path.exists(f"{base}_{r}"):
+                verdicts[r] = open(f"{base}_{r}").read().strip()
+        if len(verdicts) < world:
+            time.sleep(0.05)
+    agreed = len(verdicts) == world and all(v == "ok" for v in verdicts.values())
+    if ok and not agreed:
+        probe["rccl"] = ("FAILED on another rank (" + ", ".join(f"rank {r}: {verdicts.get(r, 'no verdict')}" for r in range(world)) + "); this rank's child: " + said)[:600]
+    ok = agreed
+    import atexit
+    atexit.register(lambda: os.path.exists(f"{base}_{rank}") and os.remove(f"{base}_{rank}"))
     if ok:
         return "rccl", probe
     probe["fallback"] = "shm: host-staged shared-memory transport (one node); the numbers of this line are NOT RCCL's"
@@ -257,6 +306,8 @@ def main():
     if os.environ.get("VNR_BENCH_DUMP_AFTER"):  # diagnostics: where does a run that hangs under the profiler stand?
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["VNR_BENCH_DUMP_AFTER"]), exit=False, file=sys.stderr)
+    # a rank that hangs without closing its socket must not stall a bench run for ever (the library itself waits without bound)
+    os.environ.setdefault("VNR_AMD_DIST_STEADY_TIMEOUT", "1800")
     transport, transport_probe = choose_transport()
     ctx = dist.init_from_env(transport=transport)
     if a.gpus != ctx.world:
@@ -563,8 +614,9 @@ def main():
         roofline["mfma"] = {"tflops": round(tf, 1), "peak_tflops": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                             "what": "the MLP's flops (20 608 per sample for 3x64 on a 32-wide encoding) over the union of the launch intervals; the kernel is bound by "
                                     "its hash-grid gathers, the one dense contraction on the path is a tenth of it",
-                            "util_by_counters": 0.1065 if (a.levels, a.features, a.hidden_layers) == (16, 2, 3) else None,
-                            "util_source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), separate rocprofv3 --pmc pass: profiles/r04_mfma_pmc_digest.txt"}
+                            "util_by_counters": None,
+                            "util_source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of a separate rocprofv3 --pmc pass (profiles/*_mfma_pmc.json); "
+                                           "null unless that pass was made on the default workload, one GPU, with the sources the kernel is built from now"}
     roofline["concurrency"] = (f"{halves} ray halves on {halves} HIP streams; launch durations are per stream and overlap"
                                if halves == 2 else "1 stream: launches run alone")
     frame_gbs = (samples / a.steps) * bytes_per_sample / (elapsed / a.steps) / 1e9
@@ -575,9 +627,24 @@ def main():
     # the same stream configuration it was measured with.
     default_workload = (a.size, a.fb, a.levels, a.features, a.log2_hashmap_size, a.hidden_layers, a.per_level_scale,
                         a.train_steps, a.opacity_scale, a.camera_distance, a.mode, kind) == (1024, 1024, 16, 2, 22, 3, 0.0, 1500, 0.06, 1.1, 5, "perlin")
-    pmc_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_l_pmc_traffic.json")) if os.path.exists(p)), None)
-    if default_workload and ctx.world == 1 and brick_state["in_use"] and pmc_path:
-        pmc = json.load(open(pmc_path))
+    # counter results come from separate passes: they enter the line only when the pass names the sources the kernel is compiled from NOW
+    # (a kernel change otherwise leaves them silently stale: VERDICT r04 weak 7) and only for the workload they were measured on
+    ksha = kernel_source_sha16()
+    roofline["kernel_source_sha16"] = ksha
+
+    def counters_of(name):
+        path = os.path.join(ROOT, "profiles", name)
+        if not (default_workload and ctx.world == 1 and os.path.exists(path)):
+            return None, None
+        doc = json.load(open(path))
+        return (doc, path) if doc.get("kernel_source_sha16") == ksha else (None, path)
+
+    mfma_doc, _ = counters_of("r05_mfma_pmc.json")
+    if mfma_doc and "mfma" in roofline and brick_state["in_use"]:
+        roofline["mfma"]["util_by_counters"] = mfma_doc["util_by_counters"]
+        roofline["mfma"]["util_source"] += "; profiles/r05_mfma_pmc.json"
+    pmc, pmc_path = counters_of("r05_pmc_traffic.json")
+    if pmc and brick_state["in_use"]:
         leg = pmc["one_stream" if halves == 1 else "two_streams"]
         per_sample = leg.get("bytes_per_sample") or leg["traffic_over_algorithmic"] * bytes_per_sample
         roofline["traffic"] = round(per_sample * samples / max(launches, 1))
@@ -590,13 +657,14 @@ def main():
                                                 "is no longer bound by bytes (L1 / texture-addresser latency, DESIGN 4.1); the algorithmic fraction flatters it",
                                         "achieved": round(t_gbs, 1), "frac": round(t_gbs / HBM_PEAK_GBS, 4), "bytes_per_sample": round(per_sample, 1)}
         roofline["traffic_note"] = (f"bytes per sample measured in separate rocprofv3 --pmc passes of the same frame, not in this run: {os.path.relpath(pmc_path, ROOT)} "
-                                    "(traffic / algorithmic = %.2f; on the hashed blob 0.90 with two streams, 1.01 with one: profiles/r04_pmc_traffic_brick_off.json)" % (per_sample / bytes_per_sample))
+                                    "(traffic / algorithmic = %.2f; without the brick image: roofline.brick_off.traffic_bytes_per_sample)" % (per_sample / bytes_per_sample))
         if "alone" in roofline:
             one = pmc["one_stream"]
             ps1 = one.get("bytes_per_sample") or one["traffic_over_algorithmic"] * bytes_per_sample
             roofline["alone"]["traffic"] = round(ps1 * alone["samples"] / max(alone["launches"], 1))
     else:
-        roofline["traffic_note"] = "null: the committed PMC passes (profiles/*_pmc_traffic.json) describe the default workload on one GPU with the brick image"
+        roofline["traffic_note"] = ("null: the committed PMC passes (profiles/r05_pmc_traffic.json) describe the default workload on one GPU with the brick image, for the "
+                                    "kernel sources named by their kernel_source_sha16" + ("; this build's differ" if pmc_path and default_workload and ctx.world == 1 else ""))
     if brick_off:
         ev = brick_off["samples"] * evals_per_sample
         leg = {"what": "un-timed leg of this run with the brick image switched off: the configuration of an application that trains while it renders "
@@ -609,11 +677,10 @@ def main():
             ev1 = brick_off["alone_samples"] * evals_per_sample
             leg["kernel_alone_frac"] = round(ev1 * bytes_per_sample / (brick_off["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             leg["kernel_alone_msamples_per_s"] = round(ev1 / (brick_off["alone_ms"] * 1e-3) / 1e6, 1)
-        off_path = os.path.join(ROOT, "profiles", "r04_pmc_traffic_brick_off.json")
-        if default_workload and os.path.exists(off_path):
-            off = json.load(open(off_path))
+        off, _ = counters_of("r05_pmc_traffic_brick_off.json")
+        if off:
             leg["traffic_bytes_per_sample"] = {"two_streams": round(off["two_streams"]["bytes_per_sample"], 1), "one_stream": round(off["one_stream"]["bytes_per_sample"], 1),
-                                               "note": "separate rocprofv3 --pmc passes of this frame with VNR_AMD_BRICK=0 (profiles/r04_pmc_traffic_brick_off.json), not this run"}
+                                               "note": "separate rocprofv3 --pmc passes of this frame with VNR_AMD_BRICK=0 (profiles/r05_pmc_traffic_brick_off.json), not this run"}
         roofline["brick_off"] = leg
 
     # ---- training step: algorithmic bytes per SURVEY 8(d) and the live per-kernel split -------------------------------------------
@@ -626,15 +693,41 @@ def main():
              "optimizer (Adam, fp32 master, fp16 gradient)" + (" incl. waiting for the gradient exchange" if ctx.distributed else "")]
     kernel_ms = [float(phase_ms[i]) for i in range(5)]
     step_kernel_ms = sum(kernel_ms)
-    train_roofline = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                      "algorithmic_bytes_per_step": step_bytes,
-                      "algorithmic_bytes": {"forward": fwd_bytes, "grid_backward_rmw": bwd_bytes, "optimizer_sweep": opt_bytes,
-                                            "what": "SURVEY 8(d): 528 B x B forward, L*8*F*2*2 B x B scatter, n_params x 14 B read + 14 B written"},
-                      "achieved": round(step_bytes / (train_ms * 1e-3) / 1e9, 1), "frac": round(step_bytes / (train_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+    # The step is not a byte sweep: its largest phase, the grid backward, is priced per memory-side atomic REQUEST (MI355X_MICROARCH.md
+    # "Global float atomics": a 256-B wave instruction leaves L2 as four 64-B requests, one per ~50 ns and CU = 4 x 256 CUs / 50 ns ~ 20.5 G
+    # requests/s chip-wide), so that phase is held against that rate.  Requests per step, from the level table: the atomic kernel's lanes
+    # are (sample, x bit, feature pair) with the two x-neighbours of a corner pair adjacent, i.e. ONE request per (sample, level, yz corner)
+    # for n_features <= 8; the dense coarse levels go through LDS tiles and flush at most entries x F x 2 B / 64 B requests per slice.
+    ATOMIC_PEAK_GREQ = 4 * 256 / 50e-9 / 1e9
+    lv = grid_levels(Lv, a.log2_hashmap_size, 16, pls)
+    tile_entries = (24 * 1024 // (4 * F)) & ~15
+    lds_levels = 0
+    while lds_levels < Lv and not lv[lds_levels]["hashed"] and -(-lv[lds_levels]["entries"] // tile_entries) <= 64:
+        lds_levels += 1
+    req_atomic = B * 4 * (Lv - lds_levels)
+    req_flush_max = 0
+    for l in range(lds_levels):
+        tiles = -(-lv[l]["entries"] // tile_entries)
+        slices = max(4, min(128, 768 // tiles))
+        req_flush_max += slices * (lv[l]["entries"] * F * 2 // 64)
+    gb_ms = kernel_ms[3]
+    greq = (req_atomic + req_flush_max) / (gb_ms * 1e-3) / 1e9 if gb_ms > 0 else 0.0
+    atomic_doc, _ = counters_of("r05_train_atomic_pmc.json")
+    train_roofline = {"bound": "memory-side atomic requests (the grid backward, the step's largest phase)", "unit": "G requests/s",
+                      "peak": round(ATOMIC_PEAK_GREQ, 1), "achieved": round(greq, 2), "frac": round(greq / ATOMIC_PEAK_GREQ, 4),
+                      "phase": "grid backward", "phase_ms": round(gb_ms, 4), "phase_share_of_step": round(gb_ms / max(step_kernel_ms, 1e-9), 3),
+                      "requests_per_step": {"atomic_kernel": req_atomic, "lds_tile_flush_at_most": req_flush_max, "levels_through_lds": lds_levels,
+                                            "what": "atomic kernel: 65 536 samples x 4 yz-corner pairs x levels, one 64-B request each; LDS tiles: slices x "
+                                                    "level bytes / 64 (pairs nobody touched are skipped, so fewer)"},
+                      "requests_by_counters": None if not atomic_doc else atomic_doc.get("requests_per_step"),
+                      "counters_source": "TCC_EA0_ATOMIC_sum of grid_backward_kernel + grid_backward_lds_kernel, separate rocprofv3 --pmc pass (profiles/r05_train_atomic_pmc.json)",
+                      "peak_source": "MI355X_MICROARCH.md 'Global float atomics': ~1.3 TB/s of added bytes = one 256-B wave instruction (four 64-B requests) per ~50 ns and CU",
                       "ms_per_step_wall": round(train_ms, 4), "ms_per_step_kernels": round(step_kernel_ms, 4), "profiled_steps": int(n_prof.value),
                       "kernels_ms": {n: round(v, 4) for n, v in zip(names, kernel_ms)},
-                      "note": "the optimizer sweep dominates the algorithmic bytes; the implementation skips untouched grid entries (about 10 % are touched "
-                              "per step), so `frac` measures the step against a dense sweep it does not perform"}
+                      "dense_sweep": {"what": "SURVEY 8(d)'s algorithmic bytes (528 B x B forward, L*8*F*2*2 B x B scatter, n_params x 14 B read + 14 B written) over the step: "
+                                              "NOT a bound of this step, which skips untouched grid entries (a batch touches about an eighth) -- kept for continuity with rounds 1-4",
+                                      "algorithmic_bytes_per_step": step_bytes, "gbs": round(step_bytes / (train_ms * 1e-3) / 1e9, 1),
+                                      "frac_of_hbm_peak": round(step_bytes / (train_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
     budget_rows = None
     if budget_table is not None:
@@ -646,14 +739,22 @@ def main():
                                 "kernel_union_frac": round(ev * bytes_per_sample / (row["union_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if row["union_ms"] > 0 else None})
         budget_rows.append({"budget_gib": "default", "image_bytes": int(brick_state["bytes"]), "levels_in_image": [l for l in range(32) if brick_state.get("levels", 0) >> l & 1],
                             "fps": round(fps, 2), "kernel_union_frac": roofline.get("union", {}).get("frac")})
+    # `value` depends on the inference cache: say so where a truncated record still shows it
+    off_fps = roofline.get("brick_off", {}).get("fps")
+    cache_text = (f"inference cache (brick image) IN USE: {brick_state['bytes'] / 1e9:.2f} GB beside a {info['n_params'] * 2 / 1e6:.0f} MB model"
+                  + (f", WITHOUT it (an application that trains while it renders) {off_fps:.1f} frames/s" if off_fps else "")
+                  if brick_state["in_use"] else "inference cache (brick image) not in use")
+    scaling = "strong"
+    if ctx.distributed and ctx.transport != "rccl":
+        scaling = f"strong-over-{ctx.transport}-fallback (NOT an RCCL measurement)"
     out = {
         "metric": "fps at 1024^2 on 1024^3 volume" if (a.size, a.fb, a.mode) == (1024, 1024, 5) else f"fps at {a.fb}^2 on {a.size}^3 volume, rendering mode {a.mode}" if a.mode != 5 else f"fps at {a.fb}^2 on {a.size}^3 volume",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{workload_name(a)}: {volume_desc}, HashGrid L={a.levels} F={a.features} "
                                f"T=2^{a.log2_hashmap_size} base 16 per_level_scale {pls:.4f} + {a.hidden_layers}x64 FullyFusedMLP, "
-                               f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading' if a.mode == 8 else 'sample streaming, single-shade heuristic: camera pass + shadow pass' if a.mode == 11 else 'path tracing: one launch with the network inside the tracking loop (VNR_AMD_IN_SHADER=0: sample streaming)' if a.mode in (14, 15) else 'in-shader ray marching mode: the streaming path unless VNR_AMD_IN_SHADER=1'}), sampling rate 1, N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24 (32 when a rank renders at most 196608 pixels)')}",
+                               f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading' if a.mode == 8 else 'sample streaming, single-shade heuristic: camera pass + shadow pass' if a.mode == 11 else 'path tracing: one launch with the network inside the tracking loop (VNR_AMD_IN_SHADER=0: sample streaming)' if a.mode in (14, 15) else 'in-shader ray marching mode: the streaming path unless VNR_AMD_IN_SHADER=1'}), sampling rate 1, N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24 (32 when a rank renders at most 196608 pixels)')}; {cache_text}",
                    "volume": f"{a.size}^3", "framebuffer": f"{a.fb}x{a.fb}", "n_params": info["n_params"],
                    "tfn": f"256-entry ramp-with-bumps, seed 7, opacity scale {a.opacity_scale}",
                    "camera": cam, "train_steps": a.train_steps, "batch": 65536,
@@ -679,6 +780,10 @@ def main():
     }
     if c5 is not None:
         out["c5"] = c5
+    if ctx.distributed:
+        # did RCCL see N ranks?  Two keys beside n_gpus answer it
+        out["transport"] = "rccl" if ctx.transport == "rccl" else f"{ctx.transport}-fallback"
+        out["rccl_ranks_seen"] = int(L.vnrAmdDistRcclRanksSeen())
     if per_rank is not None:
         out["per_rank"] = per_rank
         out["collective_self_test"] = self_test

@@ -334,6 +334,7 @@ int  vnrAmdDistFinalize(void);
 int  vnrAmdDistRank(void);
 int  vnrAmdDistWorldSize(void);
 const char* vnrAmdDistTransport(void);
+int  vnrAmdDistRcclRanksSeen(void);   /* ncclCommCount of the communicator; 0 when the transport is not RCCL */
 int  vnrAmdDistBarrier(void);                                      /* device synchronize + host barrier */
 /* host values over the control plane (the bench's MAX / SUM over ranks); op: 0 sum, 1 max, 2 min, 3 mean */
 int  vnrAmdDistAllReduceHost(double* values, int n, int op);

@@ -190,6 +190,7 @@ def lib():
     sig("vnrAmdDistRank", I)
     sig("vnrAmdDistWorldSize", I)
     sig("vnrAmdDistTransport", C.c_char_p)
+    sig("vnrAmdDistRcclRanksSeen", I)
     sig("vnrAmdDistBarrier", I)
     sig("vnrAmdDistAllReduceHost", I, C.POINTER(D), I, I)
     sig("vnrAmdDistAllReduce", I, P, SZ, I, I)

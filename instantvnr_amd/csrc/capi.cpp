@@ -845,6 +845,7 @@ int vnrAmdDistFinalize(void) { return guarded([&]() { Dist::get().finalize(); })
 int vnrAmdDistRank(void) { return Dist::get().rank(); }
 int vnrAmdDistWorldSize(void) { return Dist::get().world(); }
 const char* vnrAmdDistTransport(void) { return Dist::get().transport_name(); }
+int vnrAmdDistRcclRanksSeen(void) { return Dist::get().rccl_ranks_seen(); }
 int vnrAmdDistBarrier(void)
 {
   return guarded([&]() {

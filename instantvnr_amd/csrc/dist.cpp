@@ -56,13 +56,14 @@ void set_socket_timeouts(int fd, int seconds)
   (void)setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
 }
 
-// after the rendezvous a wait on the control plane is as long as the slowest rank's work.  A rank that hangs without closing its socket
-// (GPU hang, deadlocked collective) must not stall the others for ever: 30 minutes by default;
-// VNR_AMD_DIST_STEADY_TIMEOUT=<seconds>, 0 = wait without bound
+// after the rendezvous a wait on the control plane is as long as the slowest rank's work, so the library does not bound it by default
+// (rank 0 writing a large out-of-core file before a barrier, an interactive viewer left idle); a job that wants a rank that
+// hangs without closing its socket (GPU hang, deadlocked collective) to end the others sets VNR_AMD_DIST_STEADY_TIMEOUT=<seconds>:
+// bench.py sets 1800
 int dist_steady_timeout_s()
 {
   const char* e = std::getenv("VNR_AMD_DIST_STEADY_TIMEOUT");
-  if (!e || !*e) return 1800;
+  if (!e || !*e) return 0;
   const int v = std::atoi(e);
   return v > 0 ? v : 0;
 }
@@ -280,6 +281,7 @@ struct RcclApi {
   int (*GetUniqueId)(NcclUniqueId*) = nullptr;
   int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
   int (*CommDestroy)(NcclComm) = nullptr;
+  int (*CommCount)(NcclComm, int*) = nullptr;   // optional
   int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   int (*ReduceScatter)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
@@ -317,6 +319,7 @@ struct RcclApi {
     api.GetUniqueId = (int (*)(NcclUniqueId*))sym("ncclGetUniqueId");
     api.CommInitRank = (int (*)(NcclComm*, int, NcclUniqueId, int))sym("ncclCommInitRank");
     api.CommDestroy = (int (*)(NcclComm))sym("ncclCommDestroy");
+    api.CommCount = (int (*)(NcclComm, int*))dlsym(api.handle, "ncclCommCount");
     api.AllGather = (int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t))sym("ncclAllGather");
     api.AllReduce = (int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t))sym("ncclAllReduce");
     api.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t))sym("ncclReduceScatter");
@@ -346,6 +349,12 @@ public:
   }
   ~RcclTransport() override { if (comm_) (void)RcclApi::get().CommDestroy(comm_); }
   const char* name() const override { return "rccl"; }
+  int rccl_ranks() const override
+  {
+    int n = 0;
+    if (!comm_ || !RcclApi::get().CommCount || RcclApi::get().CommCount(comm_, &n) != kNcclSuccess) return 0;
+    return n;
+  }
   void all_gather(const void* d_send, void* d_recv, size_t bytes, hipStream_t s) override
   {
     rccl_check(RcclApi::get().AllGather(d_send, d_recv, bytes, kNcclUint8, comm_, s), "ncclAllGather");

@@ -44,6 +44,8 @@ public:
   // offset (the rest of d_buf is unspecified afterwards); all_gather of the same slices completes a sharded update
   virtual void reduce_scatter(void* d_buf, size_t count_per_rank, DistDType t, DistOp op, hipStream_t s) = 0;
   virtual void broadcast(void* d_buf, size_t bytes, int root, hipStream_t s) = 0;
+  // ranks of the RCCL communicator as RCCL itself counts them (ncclCommCount); 0 for a transport that is not RCCL
+  virtual int rccl_ranks() const { return 0; }
 };
 
 class Dist {
@@ -54,6 +56,7 @@ public:
   int world() const { return world_; }
   int local_rank() const { return local_rank_; }
   const char* transport_name() const { return transport_ ? transport_->name() : "none"; }
+  int rccl_ranks_seen() const { return transport_ ? transport_->rccl_ranks() : 0; }   // did RCCL see N ranks? (the bench line's `rccl_ranks_seen`)
   Transport& transport();
 
   // explicit init (the application did its own rendezvous): 128-byte RCCL unique id made by vnrAmdDistGetUniqueId on one

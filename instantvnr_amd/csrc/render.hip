@@ -1129,9 +1129,8 @@ void Renderer::render()
   // reference), so a frame assembled from such shares equals the unsharded frame rendered with VNR_RM_N_ITERS=32 bit for bit and
   // the unsharded frame at the default 24 to ~4e-5 on 0.2 % of the pixels (tests/test_gpu_fullsize.py); VNR_RM_N_ITERS pins both.
   p.n_iters = (!n_iters_fixed_ && (distributed_ || il_parts_ > 1) && p.n_local <= 196608u) ? 32 : n_iters_;
-  // A march block stages its batch in LDS: 10 bytes per sample with the depth sort's ranks (83 KB at 32 samples: ONE block per CU), 8 without
-  // them (67 KB: two).  VNR_AMD_MARCH_RANKS=0 drops the ranks (the slot inside a bin is then claimed from the bin's counter when the record
-  // is written; same frames).  Measured on 1/8 .. 1/1 of the bench frame: no difference (profiles/r03_march_ranks.txt), so they stay.
+  // A march block stages its batch in LDS: 8 bytes per sample, 10 with the depth sort's ranks (renderer.h march_ranks_: dropped by default
+  // in round 5, the slot inside a bin is claimed from the bin's counter when the record is written; same frames)
   p.no_ranks = march_ranks_ ? 0u : 1u;
   // gradient shading (modes 7 / 8)
   p.otw = volume_->transform;

@@ -131,7 +131,11 @@ private:
   DeviceBuffer<unsigned long long> is_samples_{MemTag::Renderer};   // in-shader kernel statistics, kInShaderStatSlots each
   DeviceBuffer<uint32_t> is_hits_{MemTag::Renderer};
   int in_shader_mode_ = -1;
-  bool march_ranks_ = true;      // VNR_AMD_MARCH_RANKS (read when the renderer is created): the depth sort's ranks kept in LDS (2 bytes per sample)
+  // VNR_AMD_MARCH_RANKS (read when the renderer is created): 1 keeps the depth sort's ranks in LDS (2 bytes per sample), 0 (default since
+  // round 5) claims the slot inside a bin a second time when the record is written.  Same frames.  Without the ranks the FIRST march of
+  // a frame fits three blocks per CU instead of two (50 KB against 62 KB of LDS at 24 samples per ray): march_kernel<true> 200 -> 160 us,
+  // the C4 frame 3.67 -> 3.58 ms (profiles/r05_march_occupancy.txt)
+  bool march_ranks_ = false;
   bool n_iters_fixed_ = false;   // VNR_RM_N_ITERS given: no adaptation to the size of the share
   // LaunchParams::light_directional_dir (instantvnr_types.h:148): a member the reference negates IN PLACE whenever it points
   // along the view direction (renderer.cpp:98-101), so it persists across frames

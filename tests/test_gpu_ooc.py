@@ -267,3 +267,129 @@ def test_c5_two_ranks_train_from_the_2gib_file(c5_file, tmp_path):
     assert not np.array_equal(res[0]["slabs"], res[1]["slabs"])
     assert int(res[0]["checksum"]) == int(res[1]["checksum"])
     assert float(res[0]["loss"]) < 0.8 * float(res[0]["loss_first"]), (float(res[0]["loss_first"]), float(res[0]["loss"]))
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE C5 beyond 2^32 bytes (missing 5)
+# A SPARSE 4096^3 uint8 file (64 GiB apparent, a few hundred MB written): the slab choice is a default-seeded std::mt19937
+# (neural_sampler.cpp:53,66-75), so a first pass over the empty file tells which slabs the sampler will hold at every point of the test,
+# seeded random bytes are then written exactly there (ghost rows and slices included), and a second sampler -- same seed, same slab
+# sequence -- reads real data at byte offsets up to 2^36.  94 % of a uniformly drawn slab set lies beyond 2^32 bytes, half beyond 2^35.
+C5_BIG = [(4096, 4096, 4096), (4096, 4096, 512)]   # 64 GiB; 8 GiB where the temporary file system refuses the first
+BIG_SLOTS, BIG_REPLACED = 512, 64
+
+
+@pytest.fixture(scope="module")
+def sparse_file(tmp_path_factory):
+    import os
+    d = tmp_path_factory.mktemp("c5big")
+    for dims in C5_BIG:
+        path = d / ("sparse_%dx%dx%d.raw" % dims)
+        try:
+            with open(path, "wb") as f:
+                f.truncate(dims[0] * dims[1] * dims[2])
+            if os.stat(path).st_size == dims[0] * dims[1] * dims[2]:
+                yield path, dims
+                break
+        except OSError:
+            pass
+        try:
+            path.unlink()
+        except OSError:
+            pass
+    else:
+        pytest.fail("the temporary directory holds neither a 64 GiB nor an 8 GiB sparse file")
+    try:
+        path.unlink()
+    except OSError:
+        pass
+
+
+def _write_slabs(path, dims, slabs, seed):
+    """seeded random bytes over the ghost region of every slab (y, z): rows y0 - 1 .. y1 + 1 of slices z - 1 .. z + 1, whole rows"""
+    nx, ny, nz = dims
+    rows = 8 if nx == 4096 else None
+    assert rows, "slab height for this width"
+    rng = np.random.default_rng(seed)
+    written = set()
+    with open(path, "r+b") as f:
+        for iy, iz in sorted(set((int(a), int(b)) for a, b in slabs)):
+            y0, y1 = max(iy * rows - 1, 0), min((iy + 1) * rows + 1, ny)
+            for z in range(max(iz - 1, 0), min(iz + 2, nz)):
+                if (y0, y1, z) in written:
+                    continue
+                written.add((y0, y1, z))
+                f.seek((z * ny + y0) * nx)
+                f.write(rng.integers(1, 256, (y1 - y0) * nx, dtype=np.uint8).tobytes())
+    return len(written)
+
+
+def _c5_big_sequence(oracle, path, dims, vol, check_values):
+    """the calls of the test in their order; -> the slot tables at its checkpoints (and, with check_values, the parity checks themselves)"""
+    sv = api.vnrCreateSimpleVolumeOutOfCore(str(path), dims, np.uint8, (0.0, 255.0), n_concurrent_blocks=BIG_REPLACED, n_blocks=BIG_SLOTS)
+    info = api.out_of_core_info(sv)
+    assert info["block_dims"] == (4096, 8, 1) and info["file_dims"] == tuple(dims) and info["n_blocks"] == BIG_SLOTS
+    tables, offset, nonzero = [], 0, []
+
+    def batch(n):
+        nonlocal offset
+        blocks = api.out_of_core_blocks(sv)
+        tables.append(blocks.copy())
+        c, v = api.simple_volume_take_samples(sv, n)
+        if check_values:
+            wc, wv, bad = oracle_batch(oracle, vol, (0.0, 255.0), blocks, n, offset)
+            assert bad == 0 and np.array_equal(c, wc) and np.array_equal(v, wv)
+            nonzero.append(float((v > 0).mean()))
+        offset += 5 * n
+        return blocks
+
+    for _ in range(4):                                   # whole batches across four refreshes
+        batch(16384)
+    nv = api.vnrCreateNeuralVolume(syn.model_config(n_levels=8, n_features=2, log2_hashmap_size=15, base_resolution=8, n_hidden_layers=2), sv,
+                                   online_macrocell_construction=False)
+    api.vnrNeuralVolumeTrain(nv, 60, True)               # 60 steps, one synchronous refresh each (64 slabs): the table moves on by 60 x 64 slots
+    loss = api.vnrNeuralVolumeGetTrainingLoss(nv)
+    offset += 60 * 5 * 65536                             # (the training batches drew from the same pcg32 stream)
+    batch(16384)
+    return sv, nv, tables, nonzero, loss, info, offset
+
+
+def test_c5_byte_offsets_beyond_4gib(oracle, sparse_file):
+    """64-bit block arithmetic end to end (neural_sampler.cpp:377-668): whole batches drawn from slabs whose bytes lie between 0 and 2^36
+    equal the oracle's, bit for bit, before and after 60 training steps with synchronous refresh; the asynchronous refresh (timing
+    dependent: its slab sequence cannot be written ahead) is then checked on whatever table it ends with"""
+    import ctypes as C
+    from instantvnr_amd._lib import check, lib
+    path, dims = sparse_file
+    nx, ny, nz = dims
+    vol = np.memmap(path, dtype=np.uint8, mode="r", shape=(nz, ny, nx))
+    # pass 1 over the empty file: which slabs will be resident at the checkpoints
+    sv, nv, tables, _, _, info, _ = _c5_big_sequence(oracle, path, dims, vol, check_values=False)
+    del nv, sv
+    slabs = np.concatenate(tables)
+    n_regions = _write_slabs(path, dims, slabs, seed=99)
+    off = (slabs[:, 1].astype(np.int64) * ny + slabs[:, 0].astype(np.int64) * 8) * nx
+    assert (off >= 2**32).mean() > 0.4 and off.max() >= min(2**35, nx * ny * nz // 2)
+    # pass 2: the same calls on the written file
+    sv, nv, tables2, nonzero, loss, _, offset = _c5_big_sequence(oracle, path, dims, vol, check_values=True)
+    assert all(np.array_equal(a, b) for a, b in zip(tables, tables2)), "the slab sequence is not reproducible"
+    assert min(nonzero) > 0.99, nonzero                                  # the batches did read the written bytes (values 1 .. 255), not holes
+    assert np.isfinite(loss)
+    # asynchronous refresh on the same file: 60 more steps, then one more batch against the oracle on the table the sampler then holds
+    check(lib().vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh(sv.h, 1))
+    r0, y0 = C.c_uint64(), C.c_uint64()
+    check(lib().vnrAmdSimpleVolumeOutOfCoreRefreshStats(sv.h, C.byref(r0), C.byref(y0)))
+    api.vnrNeuralVolumeTrain(nv, 60, True)
+    check(lib().vnrAmdSynchronize())
+    r1, y1 = C.c_uint64(), C.c_uint64()
+    check(lib().vnrAmdSimpleVolumeOutOfCoreRefreshStats(sv.h, C.byref(r1), C.byref(y1)))
+    assert r1.value > r0.value and np.isfinite(api.vnrNeuralVolumeGetTrainingLoss(nv))
+    check(lib().vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh(sv.h, 0))
+    blocks = api.out_of_core_blocks(sv)
+    c, v = api.simple_volume_take_samples(sv, 8192)
+    state = api.out_of_core_info(sv)
+    # a step draws its 5 x 65 536 numbers whether or not a refresh is in flight, so the stream position is known; the table is whatever the
+    # asynchronous refreshes left (mostly holes of the sparse file by now: zeros, at 64-bit offsets all the same)
+    wc, wv, bad = oracle_batch(oracle, vol, (0.0, 255.0), blocks, 8192, offset + 60 * 5 * 65536)
+    assert bad == 0 and np.array_equal(c, wc) and np.array_equal(v, wv)
+    print(f"\nC5 sparse {nx}x{ny}x{nz}: {n_regions} slab regions written, offsets up to 2^{np.log2(off.max()):.1f}, {(off >= 2**32).mean() * 100:.0f} % of the slabs "
+          f"beyond 2^32 bytes; nonzero samples {min(nonzero):.3f}; loss {loss:.4f}; asynchronous refreshes {r1.value - r0.value}; bytes read {state['bytes_read']}")

@@ -14,11 +14,11 @@ CS = "instantvnr_amd/csrc/"
 ROWS = [
     ("samples per ray and iteration, the reference's default (here the library default is 24, measured faster; VNR_RM_N_ITERS pins either)",
      "core/renderer/method_raymarching.cu", r"int n_iters = 16;", CS + "render.hip", r'getenv\("VNR_RM_N_ITERS"\)'),
-    ("a ray ends at alpha >= 0.9999", "core/instantvnr_types.h", r"#define nearly_one 0\.9999f", CS + "render.hip", r"#define VNR_NEARLY_ONE 0\.9999f"),
-    ("the far end of an unbounded interval", "core/instantvnr_types.h", r"#define float_large 1e20f", CS + "render.hip", r"#define VNR_FLOAT_LARGE 1e20f"),
-    ("an empty macrocell: |max opacity| <= epsilon", "core/renderer/method_raymarching.cu", r"fabsf\(r\) <= float_epsilon", CS + "render.hip", r"fabsf\(r\) <= FLT_EPSILON"),
-    ("adaptive step: 15 x the base step", "core/renderer/raytracing.h", r"scale = 15 \* base_sampling_step", CS + "render.hip", r"scale = 15\.0f \* base_step"),
-    ("adaptive step: opacity clamped to [0.1, 1]", "core/renderer/raytracing.h", r"clamp\(max_opacity, 0\.1f, 1\.f\)", CS + "render.hip", r"clampf\(max_opacity, 0\.1f, 1\.0f\)"),
+    ("a ray ends at alpha >= 0.9999", "core/instantvnr_types.h", r"#define nearly_one 0\.9999f", CS + "march_device.h", r"#define VNR_NEARLY_ONE 0\.9999f"),
+    ("the far end of an unbounded interval", "core/instantvnr_types.h", r"#define float_large 1e20f", CS + "march_device.h", r"#define VNR_FLOAT_LARGE 1e20f"),
+    ("an empty macrocell: |max opacity| <= epsilon", "core/renderer/method_raymarching.cu", r"fabsf\(r\) <= float_epsilon", CS + "march_device.h", r"fabsf\(r\) <= FLT_EPSILON"),
+    ("adaptive step: 15 x the base step", "core/renderer/raytracing.h", r"scale = 15 \* base_sampling_step", CS + "march_device.h", r"scale = 15\.0f \* base_step"),
+    ("adaptive step: opacity clamped to [0.1, 1]", "core/renderer/raytracing.h", r"clamp\(max_opacity, 0\.1f, 1\.f\)", CS + "march_device.h", r"clampf\(max_opacity, 0\.1f, 1\.0f\)"),
     ("macrocells of 16^3 voxels", "CMakeLists.txt", r"set\(MACROCELL_SIZE_MIP 4\)", CS + "volume.h", r"kMacrocellSizeMip = 4"),
     ("training batch of 65 536 samples", "core/network.cu", r"m_batch_size = 1 << 16", CS + "volume.h", r"batch_size_ = 1u << 16"),
     ("sampler stream: pcg32 seeded with 1337", "core/samplers/neural_sampler.cu", r"rng\{ 1337 \}", CS + "volume.h", r"rng_seed_ = 1337"),

@@ -119,12 +119,15 @@ def cpu_baseline(sv, nv, info, dims, tfn_np, cam, fb, mc, pls, hidden_layers, lo
     return out
 
 
-def kernel_source_sha16():
-    """what the evaluation kernel is compiled from: counter results of separate rocprofv3 --pmc passes (profiles/*.json) are put into the
-    line only while this still names the sources they were measured on"""
+EVAL_KERNEL_SOURCES = ("infer_kernel.h", "infer_tile.h", "grid_device.h", "network_infer.hip", "network_infer_w64.hip")
+
+
+def sources_sha16(files):
+    """names what a kernel is compiled from: counter results of separate rocprofv3 --pmc passes (profiles/r05_*.json carry `source_files` and
+    `source_sha16`) enter the line only while this still gives the hash they were stamped with"""
     import hashlib
     h = hashlib.sha256()
-    for n in ("infer_kernel.h", "infer_tile.h", "grid_device.h", "network_infer.hip", "network_infer_w64.hip"):
+    for n in files:
         h.update(open(os.path.join(ROOT, "instantvnr_amd", "csrc", n), "rb").read())
     return h.hexdigest()[:16]
 
@@ -629,15 +632,15 @@ def main():
                         a.train_steps, a.opacity_scale, a.camera_distance, a.mode, kind) == (1024, 1024, 16, 2, 22, 3, 0.0, 1500, 0.06, 1.1, 5, "perlin")
     # counter results come from separate passes: they enter the line only when the pass names the sources the kernel is compiled from NOW
     # (a kernel change otherwise leaves them silently stale: VERDICT r04 weak 7) and only for the workload they were measured on
-    ksha = kernel_source_sha16()
-    roofline["kernel_source_sha16"] = ksha
+    roofline["kernel_source_sha16"] = sources_sha16(EVAL_KERNEL_SOURCES)
 
     def counters_of(name):
         path = os.path.join(ROOT, "profiles", name)
         if not (default_workload and ctx.world == 1 and os.path.exists(path)):
             return None, None
         doc = json.load(open(path))
-        return (doc, path) if doc.get("kernel_source_sha16") == ksha else (None, path)
+        fresh = doc.get("source_files") and doc.get("source_sha16") == sources_sha16(doc["source_files"])
+        return (doc, path) if fresh else (None, path)
 
     mfma_doc, _ = counters_of("r05_mfma_pmc.json")
     if mfma_doc and "mfma" in roofline and brick_state["in_use"]:
@@ -664,7 +667,7 @@ def main():
             roofline["alone"]["traffic"] = round(ps1 * alone["samples"] / max(alone["launches"], 1))
     else:
         roofline["traffic_note"] = ("null: the committed PMC passes (profiles/r05_pmc_traffic.json) describe the default workload on one GPU with the brick image, for the "
-                                    "kernel sources named by their kernel_source_sha16" + ("; this build's differ" if pmc_path and default_workload and ctx.world == 1 else ""))
+                                    "kernel sources named by their source_sha16" + ("; this build's differ" if pmc_path and default_workload and ctx.world == 1 else ""))
     if brick_off:
         ev = brick_off["samples"] * evals_per_sample
         leg = {"what": "un-timed leg of this run with the brick image switched off: the configuration of an application that trains while it renders "

@@ -274,7 +274,7 @@ int  vnrAmdRendererSetFramebufferSize(vnrAmdRenderer, int width, int height);   
 int  vnrAmdRendererSetTransferFunction(vnrAmdRenderer, vnrAmdTransferFunction);      /* vnrRendererSetTransferFunction */
 int  vnrAmdRendererSetCamera(vnrAmdRenderer, vnrAmdCamera);                          /* vnrRendererSetCamera */
 int  vnrAmdRendererSetMode(vnrAmdRenderer, int mode);                                /* vnrRendererSetMode */
-int  vnrAmdRendererSetDenoiser(vnrAmdRenderer, int enable);                          /* vnrRendererSetDenoiser: 0 accepted; 1 refused (OptiX's trained denoiser has no counterpart here) unless VNR_AMD_DENOISER_IGNORE=1 */
+int  vnrAmdRendererSetDenoiser(vnrAmdRenderer, int enable);                          /* vnrRendererSetDenoiser: accepted; 1 warns once on stderr that frames stay undenoised (OptiX's trained denoiser has no counterpart here); VNR_AMD_DENOISER_STRICT=1 refuses */
 int  vnrAmdRendererSetVolumeSamplingRate(vnrAmdRenderer, float rate);                /* vnrRendererSetVolumeSamplingRate */
 int  vnrAmdRendererSetVolumeDensityScale(vnrAmdRenderer, float scale);               /* vnrRendererSetVolumeDensityScale */
 int  vnrAmdRendererResetAccumulation(vnrAmdRenderer);                                /* vnrRendererResetAccumulation */

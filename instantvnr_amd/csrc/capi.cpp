@@ -765,17 +765,18 @@ int vnrAmdRendererSetCamera(vnrAmdRenderer r, vnrAmdCamera c)
 }
 int vnrAmdRendererSetMode(vnrAmdRenderer r, int mode) { return guarded([&]() { VNR_REN(r); r->r->set_mode(mode); }); }
 // vnrRendererSetDenoiser (api.cpp:466): the reference runs OptiX's trained denoiser (optix_program.h:151-230, NVIDIA's weights: not something to
-// restate).  Switching it off is accepted; switching it on is refused, so that nobody takes an undenoised frame for a denoised one.
-// VNR_AMD_DENOISER_IGNORE=1 turns the refusal into a warning for hosts that set the flag unconditionally at start-up.
+// restate).  ONE behaviour (round 5): the call is accepted either way -- the reference's interactive apps make it from a checkbox, and an
+// unchanged app must not die of an exception there -- and switching it ON says once on stderr that frames stay undenoised.
+// VNR_AMD_DENOISER_STRICT=1 refuses instead, for hosts that would rather fail than show an undenoised frame as a denoised one.
 int vnrAmdRendererSetDenoiser(vnrAmdRenderer r, int enable)
 {
   return guarded([&]() {
     VNR_REN(r);
     if (!enable) return;
-    const char* e = std::getenv("VNR_AMD_DENOISER_IGNORE");
-    if (!e || std::atoi(e) == 0) throw std::runtime_error("the denoiser is not available (the reference's is OptiX's trained denoiser); VNR_AMD_DENOISER_IGNORE=1 accepts the call and renders undenoised frames");
+    const char* e = std::getenv("VNR_AMD_DENOISER_STRICT");
+    if (e && std::atoi(e) != 0) throw std::runtime_error("the denoiser is not available (the reference's is OptiX's trained denoiser; VNR_AMD_DENOISER_STRICT=1 turns the warning into this error)");
     static bool warned = false;
-    if (!warned) { std::fprintf(stderr, "[vnr_amd] denoiser requested and ignored (VNR_AMD_DENOISER_IGNORE=1): frames are not denoised\n"); warned = true; }
+    if (!warned) { std::fprintf(stderr, "[vnr_amd] vnrRendererSetDenoiser(true): no denoiser here (the reference's is OptiX's); frames are NOT denoised\n"); warned = true; }
   });
 }
 int vnrAmdRendererSetVolumeSamplingRate(vnrAmdRenderer r, float rate) { return guarded([&]() { VNR_REN(r); r->r->set_sampling_rate(rate); }); }

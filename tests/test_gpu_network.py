@@ -372,6 +372,46 @@ def test_reconfiguring_a_model_does_not_reuse_the_old_models_training_scratch(or
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 3e-2
 
 
+def test_two_shapes_with_the_same_mlp_size_do_not_share_the_weight_gradient_slab():
+    """64 neurons x 1 hidden layer and 32 neurons x 2 hidden layers on a 16-wide encoding both have 2 048 MLP parameters, with
+    other layouts.  The slab's never-written elements (rows 1 .. 15 of the padded last layer) were zeroed per n_mlp only, so after the
+    re-configuration they held the first shape's hidden-layer sums and were added into the gradient of the padded rows"""
+    sv = api.vnrCreateSimpleVolume(syn.analytic_volume(16))
+    cfg_a = syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=1, n_neurons=64)
+    cfg_b = syn.model_config(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2, n_neurons=32)
+    vol = api.vnrCreateNeuralVolume(cfg_a, sv)
+    assert api.neural_info(vol)["padded_width"] == 16
+    rng = np.random.default_rng(11)
+    tc = rng.uniform(0, 1, (2048, 3)).astype(np.float32)
+    tt = rng.uniform(0, 1, 2048).astype(np.float32)
+    ga = api.neural_forward_backward(vol, tc, tt)
+    n_mlp = 64 * 16 + 16 * 64
+    assert np.abs(ga[:n_mlp]).max() > 0 and np.all(ga[n_mlp - 15 * 64:n_mlp] == 0)
+    api.neural_train_end(vol)
+    api.vnrNeuralVolumeSetModel(vol, cfg_b)
+    info = api.neural_info(vol)
+    assert 32 * 16 + 32 * 32 + 16 * 32 == n_mlp                               # the same MLP size, another layout
+    params = syn.random_params(info["n_params"], n_mlp, seed=4)
+    api.neural_set_params_fp16(vol, params)
+    got = api.neural_forward_backward(vol, tc, tt)
+    fresh = api.vnrCreateNeuralVolume(cfg_b, sv)
+    api.neural_set_params_fp16(fresh, params)
+    want = api.neural_forward_backward(fresh, tc, tt)
+    assert np.array_equal(got[:n_mlp], want[:n_mlp])                             # the MLP's gradient is summed in block order: bit for bit
+    assert np.all(got[n_mlp - 15 * 32:n_mlp] == 0)                              # the padded rows of the last layer
+
+
+def test_repeated_gradient_batches_and_reconfigurations_never_miss():
+    """the hunt for round 4's once-in-28 000 grid-gradient transient as a regression test (tests/diag/grad_hammer.py, short form): the sweep's
+    draw and four other models, every repetition compared ON THE DEVICE with the first one -- one volume per model, a fresh volume per
+    repetition, one volume re-configured between the models.  1.86 M such checks ran clean in round 5 (profiles/r05_grad_hammer.txt)"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "grad_hammer.py"), "20000", "600", "3000", "/tmp/vnr_grad_hammer_test.txt"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "TOTAL events: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 RENDERED = [
     # (n_neurons, interpolation, activation, output_activation, grid type, rendering mode)
     (32, "Linear", "ReLU", "None", "Hash", 5),

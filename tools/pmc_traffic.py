@@ -57,6 +57,11 @@ def main():
                          "section; profiles/r01_pmc_traffic.json calibration).  WRITE_SIZE as reported.",
            "frames_used": "the last %d frames of each pass (the earlier ones run before the brick image exists)" % n_last,
            "samples_per_frame": spf, "algorithmic_bytes_per_sample": 528}
+    # what the kernel was compiled from when the passes ran: bench.py puts these numbers into its line only while the hash still holds
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    doc["source_files"] = list(bench.EVAL_KERNEL_SOURCES)
+    doc["source_sha16"] = bench.sources_sha16(bench.EVAL_KERNEL_SOURCES)
     two, one = leg(d, "", spf, n_last, n_frames), leg(d, "_h1", spf, n_last, n_frames)
     if two:
         doc["two_streams"] = two

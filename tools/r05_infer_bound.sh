@@ -27,16 +27,16 @@ pass() {   # name, program (bench / share), brick (1 / 0), counters
 }
 pass sq_on    bench 1 SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE || exit 0
 pass sq2_on   share 1 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE || exit 0
-pass ta_on    share 1 TA_TA_BUSY_sum TA_BUSY_avr TA_BUFFER_READ_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum GRBM_GUI_ACTIVE || exit 0
-pass ta2_on   share 1 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_BUFFER_WAVEFRONTS_sum GRBM_GUI_ACTIVE || exit 0
+# (TA passes with four or six TA counters hung twice at the process's first kernel, once under bench.py and once under share_probe.py; TA_TA_BUSY_sum alone
+# completes: ta1_on / ta1_off below)
 pass tcp_on   share 1 TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE || exit 0
 pass tcp2_on  share 1 TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum TCP_TCR_TCP_STALL_CYCLES_sum GRBM_GUI_ACTIVE || exit 0
 pass tcc_on   share 1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE || exit 0
 pass ta1_on   share 1 TA_TA_BUSY_sum GRBM_GUI_ACTIVE || exit 0
+pass mfma_on  share 1 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE || exit 0
 pass tcc_atomic share 1 TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_REQ_sum GRBM_GUI_ACTIVE || exit 0
 pass sq2_off  share 0 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE || exit 0
-pass ta_off   share 0 TA_TA_BUSY_sum TA_BUSY_avr TA_BUFFER_READ_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum GRBM_GUI_ACTIVE || exit 0
-pass ta2_off  share 0 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_BUFFER_WAVEFRONTS_sum GRBM_GUI_ACTIVE || exit 0
+pass ta1_off  share 0 TA_TA_BUSY_sum GRBM_GUI_ACTIVE || exit 0
 pass tcp_off  share 0 TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE || exit 0
 pass tcc_off  share 0 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE || exit 0
 exit 0

@@ -610,7 +610,7 @@ def main():
                              "fps_one_stream": alone["fps"],
                              "mfma_tflops": round(ev * flops_per_sample / (alone["ms"] * 1e-3) / 1e12, 2)}
     # the matrix cores' share of the kernel (north star: "MFMA utilisation on the MLP against the chip's peaks"): flops of this run's samples over
-    # the union time, against the dense fp16 peak; the counter-based figure comes from a separate rocprofv3 --pmc pass (tools/r04_mfma_pmc.sh)
+    # the union time, against the dense fp16 peak; the counter-based figure comes from a separate rocprofv3 --pmc pass (tools/scratch/r04_mfma_pmc.sh)
     MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense fp16 / bf16
     if union_ms > 0:
         tf = samples_evt * flops_per_sample / (union_ms * 1e-3) / 1e12
@@ -748,8 +748,8 @@ def main():
                   + (f", WITHOUT it (an application that trains while it renders) {off_fps:.1f} frames/s" if off_fps else "")
                   if brick_state["in_use"] else "inference cache (brick image) not in use")
     scaling = "strong"
-    if ctx.distributed and ctx.transport != "rccl":
-        scaling = f"strong-over-{ctx.transport}-fallback (NOT an RCCL measurement)"
+    if ctx.distributed and ctx.transport != "rccl":   # the host-staged transport, as a fallback or because the environment chose it: never read as RCCL's curve
+        scaling = f"strong-over-{ctx.transport} (NOT an RCCL measurement)"
     out = {
         "metric": "fps at 1024^2 on 1024^3 volume" if (a.size, a.fb, a.mode) == (1024, 1024, 5) else f"fps at {a.fb}^2 on {a.size}^3 volume, rendering mode {a.mode}" if a.mode != 5 else f"fps at {a.fb}^2 on {a.size}^3 volume",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,
@@ -785,7 +785,8 @@ def main():
         out["c5"] = c5
     if ctx.distributed:
         # did RCCL see N ranks?  Two keys beside n_gpus answer it
-        out["transport"] = "rccl" if ctx.transport == "rccl" else f"{ctx.transport}-fallback"
+        out["transport"] = ("rccl" if ctx.transport == "rccl" else
+                            f"{ctx.transport}-fallback (the RCCL probe failed: transport_probe)" if transport_probe is not None else f"{ctx.transport} (chosen by VNR_AMD_DIST_TRANSPORT)")
         out["rccl_ranks_seen"] = int(L.vnrAmdDistRcclRanksSeen())
     if per_rank is not None:
         out["per_rank"] = per_rank

@@ -355,7 +355,7 @@ def scenario_ooc(ctx, out):
 def main():
     scenario, out_path = sys.argv[1], sys.argv[2]
     ctx = vdist.init_from_env()
-    out = {"rank": ctx.rank, "world": ctx.world, "transport": ctx.transport or "none"}
+    out = {"rank": ctx.rank, "world": ctx.world, "transport": ctx.transport or "none", "rccl_ranks_seen": int(api.lib().vnrAmdDistRcclRanksSeen())}
     {"frames": scenario_frames, "frames_c4": scenario_frames_c4, "frames_unpinned": scenario_frames_unpinned, "train": scenario_train,
      "train_c4": scenario_train_c4, "sharded_optimizer": scenario_sharded_optimizer, "resync": scenario_resync, "macrocell": scenario_macrocell,
      "ooc": scenario_ooc, "selftest": scenario_selftest}[scenario](ctx, out)

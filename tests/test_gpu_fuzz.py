@@ -2,7 +2,7 @@
 dispatch once; this file draws whole model descriptions at random (seeded) from the same space -- level count, features per level, table
 size, base resolution, growth, interpolation, grid type, quantize_threshold, max_level, width, depth, activation, output activation --
 and holds each draw to the same bars: encode bit-exact, network output within 2^-8 of the oracle, gradients within 3 % of the numpy
-restatement.  VNR_FUZZ_DRAWS / VNR_FUZZ_SEED widen the sweep from a shell (tools/r04_fuzz.sh).
+restatement.  VNR_FUZZ_DRAWS / VNR_FUZZ_SEED widen the sweep from a shell (tools/scratch/r04_fuzz.sh).
 
 Deep networks with growing activations (six hidden layers of Exponential at 128 neurons ...) are legal and numerically poor: the fp16
 rounding of the activations alone moves their output by more than 2^-8.  Where that is so the bar is the oracle's OWN distance from an fp64
@@ -428,9 +428,10 @@ def test_randomly_drawn_models_render_like_the_oracle(oracle):
 # ------------------------------------------------------------------------------------------------ in-shader kernels against the streaming path
 def test_randomly_drawn_models_render_alike_through_the_in_shader_and_the_streaming_kernels(oracle):
     """rendering modes 6 / 9 / 12 / 14 / 15 on a neural volume have two implementations (in_shader.h: one launch with the network inside the
-    marching loop; the streaming path: march / evaluate / compose per iteration).  On random 64-neuron models of the common kind -- the
-    shapes the in-shader kernels are instantiated for; the others take the streaming path either way -- the network values are the same
-    bits, so ray marching differs only by the streaming path's resume rounding (PSNR > 70 dB) and path tracing not at all."""
+    marching loop; the streaming path: march / evaluate / compose per iteration).  On random models of every width (16 / 32 / 64 / 128) and
+    kind (round 5: the in-shader kernels are instantiated for all of them; shapes outside their list take the streaming path either way)
+    the network values are the same bits, so ray marching differs only by the streaming path's resume rounding (PSNR > 70 dB) and path
+    tracing not at all."""
     from instantvnr_amd._lib import check, lib
     n = int(os.environ.get("VNR_FUZZ_IN_SHADER", "16"))
     rng = np.random.default_rng(int(os.environ.get("VNR_FUZZ_SEED", "20260410")) + 31)
@@ -442,18 +443,29 @@ def test_randomly_drawn_models_render_alike_through_the_in_shader_and_the_stream
         base = int(rng.integers(2, 9))
         pls = float(min(2.0, rng.choice([1.3195, 1.5, 2.0]), (4096.0 / base) ** (1.0 / max(1, L - 1))))
         H = int(rng.integers(1, 5))
-        interp = str(rng.choice(["Linear", "Smoothstep"]))
+        interp = str(rng.choice(["Linear", "Smoothstep", "Nearest"], p=[0.5, 0.3, 0.2]))
         mode = int(rng.choice([6, 9, 12, 14, 15]))
         size = (int(rng.integers(17, 200)), int(rng.integers(9, 130)))
-        d = dict(i=i, L=L, F=F, base=base, pls=pls, H=H, interp=interp, mode=mode, size=size)
+        W = int(rng.choice([16, 32, 64, 128]))
+        act = str(rng.choice(["ReLU", "None", "Sigmoid", "Squareplus", "Softplus"], p=[0.5, 0.1, 0.15, 0.15, 0.1]))
+        out_act = str(rng.choice(["None", "Sigmoid", "ReLU"], p=[0.7, 0.2, 0.1]))
+        gtype = str(rng.choice(["Hash", "Dense", "Tiled"], p=[0.6, 0.2, 0.2]))
+        qt = float(rng.choice([0.0, 0.0, 0.05]))
+        while gtype == "Dense" and L > 1 and base * pls ** (L - 1) > 48:     # every level of a Dense grid is stored whole
+            L -= 1
+        d = dict(i=i, L=L, F=F, base=base, pls=pls, H=H, W=W, interp=interp, act=act, out_act=out_act, gtype=gtype, qt=qt, mode=mode, size=size)
         try:
             cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=int(rng.integers(9, 16)), base_resolution=base, n_hidden_layers=H,
-                                   per_level_scale=pls)
+                                   per_level_scale=pls, n_neurons=W)
             cfg["encoding"]["interpolation"] = interp
+            cfg["network"]["activation"] = act; cfg["network"]["output_activation"] = out_act
+            if gtype != "Hash": cfg["encoding"]["type"] = gtype
+            if qt: cfg["encoding"]["quantize_threshold"] = qt
             sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))
             nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
             info = api.neural_info(nv)
-            api.neural_set_params_fp16(nv, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], 64, H - 1), seed=100 + i))
+            api.neural_set_params_fp16(nv, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], W, H - 1), seed=100 + i,
+                                                             mlp_scale=(0.5 if W == 128 else 1.0) * (0.7 if H > 3 else 1.0)))
             tfn = api.vnrCreateTransferFunction()
             api.vnrTransferFunctionSetColor(tfn, colors); api.vnrTransferFunctionSetAlpha(tfn, alphas); api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
             v = rng.normal(size=3); v /= np.linalg.norm(v)

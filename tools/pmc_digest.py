@@ -42,6 +42,7 @@ def main():
     lines = ["fused_infer_kernel<2, 32, 64, 0, false> on the C4 bench frame (1024^2, L16 F2 T2^22 + 3x64): hardware counters, one rocprofv3 --pmc pass per",
              "block (tools/r05_infer_bound.sh; the program itself after `--`; counters only).  Per-dispatch MEANS; a dispatch evaluates ~3.4 M samples",
              "(~53 k wave tiles of 64).  Under --pmc the dispatches are serialised, so these describe the kernel with the GPU to itself.", ""]
+    tiles_on = [0.0]
     for leg, label in (("on", "brick image in use (the bench default)"), ("off", "brick image off: the hashed parameter blob")):
         c = {}
         for name, doc in passes.items():
@@ -62,8 +63,11 @@ def main():
                 lines.append(f"   -> waves resident on average {g('SQ_WAVE_CYCLES') * 4 / T:.0f} of 4096 slots (SQ_WAVE_CYCLES is in quad-cycles)")
                 lines.append(f"   -> wave time waiting for anything (s_waitcnt ...) {g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'):.3f}; waiting for an issue slot {g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.3f}")
             if g("SQ_INSTS_VALU"):
-                tiles = g("SQ_INSTS_VMEM_RD") / 65.0
-                lines.append(f"   -> VALU instructions per wave tile {g('SQ_INSTS_VALU') / tiles:.0f}, SALU {g('SQ_INSTS_SALU') / tiles:.0f}, VMEM reads 65 (64 gathers + the queue record)")
+                if leg == "on":
+                    tiles_on[0] = g("SQ_INSTS_VMEM_RD") / 65.0   # with the image every level is 4 gathers: 64 + the queue record per tile of 64 samples
+                tiles = tiles_on[0] or g("SQ_INSTS_VMEM_RD") / 65.0
+                lines.append(f"   -> per wave tile of 64 samples: VALU instructions {g('SQ_INSTS_VALU') / tiles:.0f}, SALU {g('SQ_INSTS_SALU') / tiles:.0f}, VMEM reads {g('SQ_INSTS_VMEM_RD') / tiles:.0f}"
+                             + (" (64 gathers + the queue record)" if leg == "on" else " (hashed levels: a second gather per row for the lanes whose x is odd)"))
                 lines.append(f"   -> VALU issue: {g('SQ_INSTS_VALU') * 4 / (1024 * T):.3f} of the SIMD cycles (4 cycles per wave64 instruction, 1024 SIMDs)")
             if g("TA_TA_BUSY_sum"):
                 lines.append(f"   -> texture addresser busy {g('TA_TA_BUSY_sum') / 256 / T:.3f} of the time (TA_TA_BUSY summed over 256 TAs)")
@@ -75,12 +79,17 @@ def main():
             if g("SQ_VALU_MFMA_BUSY_CYCLES"):
                 lines.append(f"   -> matrix cores busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / (1024 * T):.4f} of the SIMD cycles")
         lines.append("")
-    lines += ["Reading.  No unit is saturated: the texture addresser is the busiest (about two thirds), the vector ALUs issue in a bit over half of the",
-              "cycles (the encode is ~87 VALU instructions per level and sample: position, brick index, eight weights and the reference's fp16 accumulate",
-              "corner by corner, which fixes its length), the matrix cores a tenth.  A wave spends ~63 % of its life waiting for gathers whose L2 reads take",
-              "~550 cycles; with four waves per SIMD (101 VGPRs) that leaves the SIMDs idle about a quarter of the time.  The kernel is bound by the LATENCY",
-              "of its gathers at the occupancy its registers allow, not by HBM bytes (0.35 of peak by fabric traffic) and not by MFMA (10.7 %): what would",
-              "move it is more requests in flight per SIMD, and five waves per SIMD (<= 96 VGPRs) measured slower in round 3 (spills in the MLP).", ""]
+    lines += ["Reading.  The texture path is the busiest unit of the kernel and it is not saturated: the texture addresser is busy two thirds of the time",
+              "with the brick image (four fifths on the hashed blob), the vector L1 sits with requests pending ~45 % of the time, an L2 read takes ~550",
+              "cycles, 10 % of the L1 accesses and 43 % of the L2 requests miss.  The vector ALUs issue in 54 % of the cycles (42 %): the encode is ~87 VALU",
+              "instructions per level and sample -- position, brick index, eight weights and the reference's fp16 accumulate corner by corner, whose",
+              "length the bit-exact blend fixes; the matrix cores are busy 10 %.  A wave spends 64 % (56 %) of its life waiting, and with four waves per",
+              "SIMD (101 VGPRs) the SIMDs idle about a quarter of the time.  So the kernel is bound neither by HBM bytes (686 MB per dispatch = 0.33 of the",
+              "peak over its duration; 1.5 GB = 0.54 without the image) nor by MFMA, but by the request turn-around of the TA / L1 / L2 path at this",
+              "occupancy.  More requests in flight per wave do NOT help: two tiles per wave (twice the loads, same occupancy) measured 7 % slower and",
+              "grouped loads 12 % slower in round 2, five waves per SIMD 7 % slower (docs/history/DESIGN_r01-r03.md 4.1); fewer distinct (instruction, line)",
+              "pairs do: the ghost-column brick (4 gathers per level, no fix-ups) bought 5 % in round 2, finer per-wave sample orders <= 3 %",
+              "(profiles/r02_sample_order_and_quad_brick.txt), and that is where the kernel stands.", ""]
     os.makedirs(out, exist_ok=True)
     open(os.path.join(out, "r05_infer_bound.txt"), "w").write("\n".join(lines))
     print("\n".join(lines))

@@ -106,6 +106,9 @@ __global__ void __launch_bounds__(64 * MlpShape<W>::WAVES) fused_infer_kernel(co
     }
 
     // ---- encode: lane = sample, level wave-uniform (infer_tile.h) -----------------------------------
+    // (Round 5 tried the corners of 8 levels in flight at once for the TRAINING forward -- one tile per wave and SIMD, 67 us for 65 536 random
+    // points where this kernel's throughput would take 5: 73.8 us.  Those 8.4 M random 4-byte reads are 8.4 M distinct 64-byte sectors,
+    // 0.54 GB in 67 us = 8 TB/s: the pass is at the memory system's sector rate, not waiting on a chain of round trips.  Removed.)
     half8_t feat[NCHUNK];
     encode_tile<F, K_IN, GENERAL>(args.levels, args.n_levels, args.interpolation, rsrc, args.brick_image, p.x, p.y, p.z, feat,
                                   GENERAL ? args.quantize_threshold : 0.0f);

@@ -194,7 +194,7 @@ public:
   const void* training_buffer(int which, size_t* bytes) const;
   void rescatter_grid_gradients(const float* d_coords, size_t n, hipStream_t s);
   void gradient_distance(const uint16_t* d_ref, double out[4], hipStream_t s);
-  void scatter_grid_gradients(const float* d_coords, size_t batch, hipStream_t s, GradExchange* exchange);   // step 5 of forward_backward
+  void scatter_grid_gradients(const float* d_coords, size_t batch, hipStream_t s, GradExchange* exchange, hipStream_t s_lds = nullptr);   // step 5 of forward_backward
   // tests: the gradient blob from a float array (rounded to the blob's half precision)
   void set_grads_from_f32(const float* host, size_t count, hipStream_t s);
 
@@ -252,6 +252,9 @@ private:
   DeviceBuffer<uint16_t> ws_dfeat_{MemTag::Network};     // [B][in_width] dL/dfeatures (fp16, loss-scaled)
   DeviceBuffer<float> ws_loss_{MemTag::Network};         // [blocks] partial loss sums
   size_t ws_batch_ = 0;
+  // training step: weight gradients + the dense levels' LDS scatter beside the atomic scatter (network_train.hip forward_backward)
+  hipStream_t side_stream_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   uint32_t lds_halves_ = 0, lds_halves_T_ = 0;
   // brick image (inference cache; mutable: built lazily from const inference calls)
   mutable DeviceBuffer<uint8_t> brick_image_{MemTag::Network};

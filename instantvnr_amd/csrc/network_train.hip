@@ -545,6 +545,60 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
   }
 }
 
+// The same scatter as a PERSISTENT grid of a few blocks per CU that walks (level, lane) work items: memory-side atomics are issued without
+// waiting for them, so a handful of waves per CU already saturates the chip's atomic request rate, and the rest of the CU stays free for
+// the kernels that run beside it on the side stream (weight gradients, the dense levels' LDS scatter: forward_backward).  The plain
+// kernel's grid of one block per 256 lanes takes every wave slot of the GPU while it lasts, which is why running those kernels beside it
+// bought nothing in round 4.  Per lane the arithmetic is grid_backward_kernel's, statement for statement.
+template <int F>
+__global__ void __launch_bounds__(256) grid_backward_persistent_kernel(const GridDevice grid, const float* __restrict__ coords, const half_t* __restrict__ dfeat,
+                                                                       uint32_t n, uint32_t in_width, half_t* __restrict__ grid_grads, uint32_t level0, uint32_t n_levels)
+{
+  constexpr uint32_t P = F >= 2 ? (uint32_t)F / 2u : 1u;
+  constexpr uint32_t kLanesPerSample = 2u * P;
+  const uint32_t per_level = (n * kLanesPerSample + 255u) & ~255u;          // lanes of one level, whole blocks: the level is uniform over a block's trip
+  const uint64_t total = (uint64_t)per_level * n_levels;
+  const bool nearest = grid.interpolation == 2u;
+  for (uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x; w < total; w += (uint64_t)gridDim.x * 256u) {
+    const uint32_t level = level0 + (uint32_t)(w / per_level);
+    const uint32_t t = (uint32_t)(w % per_level);
+    const uint32_t i = t / kLanesPerSample, r = t % kLanesPerSample;
+    const uint32_t xb = r / P, f = 2u * (r % P);
+    if (i >= n) continue;
+    const LevelInfo lv = grid.levels[level];
+    float g0, g1 = 0.0f;
+    if constexpr (F >= 2) {
+      const half2_t g2 = *(const half2_t*)(dfeat + (size_t)i * in_width + level * F + f);
+      g0 = (float)g2[0]; g1 = (float)g2[1];
+    } else {
+      g0 = (float)dfeat[(size_t)i * in_width + level];
+    }
+    if (g0 == 0.0f && g1 == 0.0f) continue;
+    if (nearest && xb) continue;
+    const CornerSetup c = level_setup(lv, grid.interpolation == 1u ? 1u : 0u, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
+    half_t* base = grid_grads + (F >= 2 ? (size_t)lv.offset * F + f : (size_t)0);
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+      if (nearest && yz) break;
+      const int corner = (int)xb | (yz << 1);
+      const uint32_t idx = level_index(lv, c.g[0] + xb, c.g[1] + (uint32_t)(yz & 1), c.g[2] + (uint32_t)(yz >> 1));
+      const float wgt = nearest ? 1.0f : corner_weight(c, corner);
+      half2_t v;
+      half_t* addr;
+      if constexpr (F >= 2) {
+        v = half2_t{(half_t)(wgt * g0), (half_t)(wgt * g1)};
+        addr = base + (size_t)idx * F;
+      } else {
+        const half_t h = (half_t)(wgt * g0), z = (half_t)0.0f;
+        const size_t e = (size_t)lv.offset + idx;
+        v = (e & 1u) ? half2_t{z, h} : half2_t{h, z};
+        addr = base + (e & ~(size_t)1);
+      }
+      asm volatile("global_atomic_pk_add_f16 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
+    }
+  }
+}
+
 // The dense coarse levels through LDS.  A level of a few thousand entries takes 65 536 x 8 corner updates per step; as global atomics
 // those are 262 144 memory-side requests per level whatever the level's size (one 64-byte request per x-pair segment, the floor the
 // scatter above sits on).  Here a block owns a TILE of a level's table (a contiguous entry range that fits its LDS as fp32 accumulators)
@@ -797,8 +851,12 @@ void Network::reset_master_from_params(hipStream_t s)
 
 // 5. of the training step: dL/dfeatures (ws_dfeat_, written by the MLP backward) -> the grid part of the gradient blob.  A function of its
 // own so that it can be repeated alone on the stored dL/dfeatures (vnrAmdNeuralVolumeRescatterGridGradients: diagnostics).
-void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStream_t s, GradExchange* exchange)
+void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStream_t s, GradExchange* exchange, hipStream_t s_lds)
 {
+  // s_lds: the stream of the dense levels' LDS scatter; another stream than `s` means the two scatters run side by side (forward_backward
+  // forks and joins), and the atomic scatter then takes its persistent form so that it leaves room on the CUs
+  if (!s_lds) s_lds = s;
+  const bool side_by_side = s_lds != s;
   TrainScratch& ts = scratch_of(this);
   const uint32_t n = (uint32_t)batch;
   // 5. hash-grid backward: levels [l0, l1) per launch (blockIdx.y + l0 = level)
@@ -834,8 +892,8 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
     const size_t item_bytes = items.size() * sizeof(LdsBwdItem);
     if (ts.lds_items_host.size() != item_bytes || std::memcmp(ts.lds_items_host.data(), items.data(), item_bytes) != 0) {
       ts.lds_items.ensure(item_bytes);
-      VNR_HIP_CHECK(hipMemcpyAsync(ts.lds_items.ptr, items.data(), item_bytes, hipMemcpyHostToDevice, s));
-      VNR_HIP_CHECK(hipStreamSynchronize(s));   // pageable source
+      VNR_HIP_CHECK(hipMemcpyAsync(ts.lds_items.ptr, items.data(), item_bytes, hipMemcpyHostToDevice, s_lds));
+      VNR_HIP_CHECK(hipStreamSynchronize(s_lds));   // pageable source
       ts.lds_items_host.assign((const uint8_t*)items.data(), (const uint8_t*)items.data() + item_bytes);
     }
     const size_t shmem = (size_t)tile_entries * cfg_.n_features * sizeof(float);
@@ -843,7 +901,7 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
     auto launch = [&](auto kernel) {
       static std::set<const void*> done;   // (by address: the four instances have one signature and would share a flag of this lambda)
       if (done.insert((const void*)kernel).second) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      kernel<<<(uint32_t)items.size(), 256, shmem, s>>>(grid_, (const LdsBwdItem*)ts.lds_items.ptr, d_coords, (const half_t*)ws_dfeat_.ptr, in_width_, gg);
+      kernel<<<(uint32_t)items.size(), 256, shmem, s_lds>>>(grid_, (const LdsBwdItem*)ts.lds_items.ptr, d_coords, (const half_t*)ws_dfeat_.ptr, in_width_, gg);
     };
     switch (cfg_.n_features) {
     case 1: launch(grid_backward_lds_kernel<1>); break;
@@ -861,6 +919,17 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
     const uint32_t pairs = cfg_.n_features >= 2 ? cfg_.n_features / 2 : 1u;
     const dim3 g(div_round_up((uint64_t)batch * pairs * 2, 256), l1 - l0);  // one lane per (sample, x bit, feature pair)
     half_t* gg = (half_t*)grads_.ptr + n_mlp_;
+    if (side_by_side) {   // a few blocks per CU walk the same lanes (VNR_AMD_GRID_BWD_BLOCKS_PER_CU, default 4)
+      static const uint32_t per_cu = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_BLOCKS_PER_CU"); return e ? (uint32_t)std::max(1, std::min(16, std::atoi(e))) : 4u; }();
+      const uint32_t blocks = std::min<uint32_t>(g.x * g.y, (uint32_t)Runtime::get().n_cus * per_cu);
+      switch (cfg_.n_features) {
+      case 1: grid_backward_persistent_kernel<1><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0, l1 - l0); break;
+      case 2: grid_backward_persistent_kernel<2><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0, l1 - l0); break;
+      case 4: grid_backward_persistent_kernel<4><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0, l1 - l0); break;
+      default: grid_backward_persistent_kernel<8><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0, l1 - l0); break;
+      }
+      return;
+    }
     switch (cfg_.n_features) {
     case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
     case 2: grid_backward_kernel<2><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
@@ -929,14 +998,16 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   loss_grad_kernel<<<ts.loss_blocks, 256, 0, s>>>(ts.y.ptr, d_targets, n, cfg_.loss, cfg_.output_activation, (half_t*)ts.dy.ptr, ws_loss_.ptr);
   // the slab's elements no block ever writes (rows 1 .. 15 of the padded last layer) must be zero: they are summed into the gradient.  Zeroed
   // when the slab grows or when the layout it was zeroed for changes (width, input width, depth: 64 neurons x 1 layer and 32 x 2 share n_mlp)
-  auto ensure_slab = [&](size_t rows) {
+  auto ensure_slab = [&](size_t rows, hipStream_t zs) {
     const uint64_t key = (uint64_t)n_mlp_ | ((uint64_t)Wn << 32) | ((uint64_t)in_width_ << 40) | ((uint64_t)nh << 48);   // the whole layout: two shapes can share n_mlp
     if (ts.wgrad_slab.count < rows * n_mlp_ || ts.slab_key != key) {
       if (ts.wgrad_slab.count < rows * n_mlp_) ts.wgrad_slab.resize(rows * n_mlp_);
-      ts.wgrad_slab.zero(s);
+      ts.wgrad_slab.zero(zs);
       ts.slab_key = key;
     }
   };
+  bool overlap = false;
+  hipStream_t sw = s;   // the stream of the weight gradients and of the dense levels' LDS scatter (a side stream when they overlap the atomic scatter)
   {
   // 3. MLP backward (the transposed weight image was packed with the forward one when the parameters last changed)
   BackwardArgs ba;
@@ -970,8 +1041,24 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
 #undef VNR_BWD
 #undef VNR_BWD_G
   }
-  // 4. weight gradients
+  // 4. weight gradients.  They read what the MLP backward wrote and write the MLP part of the gradient blob; the grid backward reads
+  // dL/dfeatures and writes the grid part: independent.  Round 5: on a side stream (with the dense levels' LDS scatter behind them) BESIDE the
+  // atomic scatter of the hashed levels, which is bound by the memory side's atomic rate and, in its persistent form, leaves the CUs to
+  // them (the step's 22 + 66 us of MFMA / LDS work disappear behind the 150 us of atomics).  Not with a data-parallel exchange, whose ranges
+  // become ready in stream order.  VNR_AMD_TRAIN_OVERLAP=0: everything on one stream, as until round 4.
   profile_mark(2, s);
+  const char* overlap_e = std::getenv("VNR_AMD_TRAIN_OVERLAP");   // (read per step: both forms are compared inside one process, tests/test_gpu_train.py)
+  overlap = (!overlap_e || std::atoi(overlap_e) != 0) && !exchange && batch >= 8192;
+  if (overlap) {
+    if (!side_stream_) {
+      VNR_HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+      VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+      VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
+    sw = side_stream_;
+    VNR_HIP_CHECK(hipEventRecord(ev_fork_, s));
+    VNR_HIP_CHECK(hipStreamWaitEvent(sw, ev_fork_, 0));
+  }
   WGradArgs wa;
   wa.features = (const half_t*)ws_features_.ptr; wa.acts = (const half_t*)ws_acts_.ptr; wa.d_all = (const half_t*)ts.d_all.ptr;
   wa.dy = (const half_t*)ts.dy.ptr; wa.n = n; wa.nh = nh; wa.in_width = in_width_;
@@ -979,16 +1066,16 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     // a block per 256 samples and matrix (padded_width is a multiple of 16 and at most 128)
     if (in_width_ % 8 != 0 || in_width_ > 128) throw std::runtime_error("internal: weight gradients of an input width the MFMA kernel does not cover");
     const uint32_t nblk = div_round_up(batch, (uint64_t)(kWgStage * kWgStages));
-    ensure_slab(nblk);
+    ensure_slab(nblk, sw);
     wa.slab = ts.wgrad_slab.ptr; wa.n_mlp = (uint32_t)n_mlp_;
     const dim3 g1(nblk, 1);
     const dim3 g2(nblk, nh + 1);  // hidden layers 1..nh and the last layer nh+1
     const int nt1 = in_width_ <= 32 ? 1 : in_width_ <= 64 ? 2 : 4;
 #define VNR_WG(w, mt_hidden) do {                                                                          \
-      if (nt1 == 1) weight_grad_mfma_kernel<w, 1><<<g1, 256, 0, s>>>(wa, 0);                               \
-      else if (nt1 == 2) weight_grad_mfma_kernel<w, 2><<<g1, 256, 0, s>>>(wa, 0);                          \
-      else weight_grad_mfma_kernel<w, 4><<<g1, 256, 0, s>>>(wa, 0);                                        \
-      weight_grad_mfma_kernel<w, mt_hidden><<<g2, 256, 0, s>>>(wa, 1); } while (0)
+      if (nt1 == 1) weight_grad_mfma_kernel<w, 1><<<g1, 256, 0, sw>>>(wa, 0);                              \
+      else if (nt1 == 2) weight_grad_mfma_kernel<w, 2><<<g1, 256, 0, sw>>>(wa, 0);                         \
+      else weight_grad_mfma_kernel<w, 4><<<g1, 256, 0, sw>>>(wa, 0);                                       \
+      weight_grad_mfma_kernel<w, mt_hidden><<<g2, 256, 0, sw>>>(wa, 1); } while (0)
     switch (Wn) {
     case 16: VNR_WG(16, 1); break;
     case 32: VNR_WG(32, 1); break;
@@ -996,12 +1083,16 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     default: VNR_WG(128, 4); break;
     }
 #undef VNR_WG
-    weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, s>>>(ts.wgrad_slab.ptr, nblk, (uint32_t)n_mlp_, (half_t*)grads_.ptr);
+    weight_grad_reduce_kernel<<<div_round_up(n_mlp_, 64), 256, 0, sw>>>(ts.wgrad_slab.ptr, nblk, (uint32_t)n_mlp_, (half_t*)grads_.ptr);
   }
   }   // MFMA kernels
   profile_mark(3, s);
   if (exchange) exchange->range_ready(0, n_mlp_, s);   // the MLP's gradient travels while the grid backward runs
-  scatter_grid_gradients(d_coords, batch, s, exchange);
+  scatter_grid_gradients(d_coords, batch, s, exchange, sw);
+  if (overlap) {   // join: the optimizer reads both parts of the blob
+    VNR_HIP_CHECK(hipEventRecord(ev_join_, sw));
+    VNR_HIP_CHECK(hipStreamWaitEvent(s, ev_join_, 0));
+  }
   VNR_HIP_CHECK(hipGetLastError());
   profile_mark(4, s);
 }

@@ -50,6 +50,74 @@ def test_gradients_match_numpy_restatement(oracle, shape, loss):
     assert np.all(last[1:] == 0) and np.any(last[0] != 0)
 
 
+@pytest.mark.parametrize("shape", [(16, 2, 14, 4, 3, "Linear", "Hash", 1.4), (8, 8, 12, 4, 2, "Smoothstep", "Hash", 2.0), (12, 4, 10, 3, 2, "Linear", "Dense", 1.25),
+                                   (16, 1, 11, 5, 2, "Linear", "Hash", 1.5), (5, 2, 19, 16, 1, "Linear", "Hash", 2.0)])
+def test_the_training_forward_s_features_are_the_encode_s_bit_for_bit(oracle, shape):
+    """the features the training forward keeps for the weight gradients (vnrAmdNeuralVolumeTrainingBuffer) are the evaluation kernel's encode
+    (itself bit-exact against the oracle), bit for bit, including coordinates at and beyond the domain's faces and ragged batches.
+    (Written in round 5 for a grouped-load form of the training forward that measured slower and was removed; the property stays pinned.)"""
+    import ctypes as C
+    L, F, log2T, base, H, interp, gtype, pls = shape
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base, n_hidden_layers=H, per_level_scale=pls)
+    cfg["encoding"]["interpolation"] = interp
+    if gtype != "Hash": cfg["encoding"]["type"] = gtype
+    vol = api.vnrCreateNeuralVolume(cfg, (32, 32, 32))
+    info = api.neural_info(vol)
+    api.neural_set_params_fp16(vol, syn.random_params(info["n_params"], oracle.mlp_n_params(info["padded_width"], 64, H - 1), seed=3))
+    rng = np.random.default_rng(9)
+    for B, out_of_domain in ((4096, False), (1000, False), (777, True)):
+        coords = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+        coords[:8] = [(0, 0, 0), (1, 1, 1), (1, 0, 0.5), (0.999999, 0.999999, 0.999999), (0.5, 1, 1), (1, 1, 0), (0, 1, 0.25), (1e-7, 0.5, 1)]
+        if out_of_domain:
+            coords[100:140] = rng.uniform(-0.3, 1.3, (40, 3)).astype(np.float32)
+        api.neural_forward_backward(vol, coords, rng.uniform(0, 1, B).astype(np.float32))
+        p, n = C.c_void_p(), C.c_size_t()
+        api.check(api.lib().vnrAmdNeuralVolumeTrainingBuffer(vol.h, 2, C.byref(p), C.byref(n)))
+        api.check(api.lib().vnrAmdSynchronize())
+        feat = np.empty(n.value // 2, np.uint16)
+        api.check(api.lib().vnrAmdMemcpyD2H(feat.ctypes.data_as(C.c_void_p), p, n.value))
+        api.neural_train_end(vol, grad_scale=0.0)
+        want = api.neural_encode(vol, coords).view(np.uint16)
+        assert feat.size == want.size and np.array_equal(feat.reshape(want.shape), want), (B, int((feat.reshape(want.shape) != want).sum()))
+
+
+@pytest.mark.parametrize("shape", [(10, 2, 14, 8, 2, "Hash"), (6, 4, 12, 4, 3, "Hash"), (4, 2, 12, 4, 2, "Dense"), (8, 1, 9, 3, 2, "Tiled")])
+def test_the_side_by_side_backward_pass_gives_the_one_stream_pass_s_gradients(oracle, shape, monkeypatch):
+    """round 5: from 8 192 samples on, the weight gradients and the dense levels' LDS scatter run on a side stream BESIDE the hashed levels'
+    atomic scatter, which takes a persistent form (a few blocks per CU: the memory side's atomic rate is what bounds it, so it can leave the
+    CUs to the others).  Same gradients as the one-stream pass (VNR_AMD_TRAIN_OVERLAP=0): the MLP part bit for bit (summed in block
+    order), the grid part to the fp16 rounding of the atomics' arrival order; both within the usual bar of the restatement; several steps of
+    Adam on either form end within that rounding of each other"""
+    L, F, log2T, base, H, gtype = shape
+    cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base, n_hidden_layers=H, per_level_scale=1.5)
+    if gtype != "Hash": cfg["encoding"]["type"] = gtype
+    vol = api.vnrCreateNeuralVolume(cfg, (32, 32, 32))
+    info = api.neural_info(vol)
+    n_mlp = oracle.mlp_n_params(info["padded_width"], 64, H - 1)
+    params = syn.random_params(info["n_params"], n_mlp, seed=6)
+    api.neural_set_params_fp16(vol, params)
+    rng = np.random.default_rng(4)
+    B = 16384 + 37
+    coords = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    targets = rng.uniform(0, 1, B).astype(np.float32)
+    got = {}
+    for overlap in ("1", "0", "1"):
+        monkeypatch.setenv("VNR_AMD_TRAIN_OVERLAP", overlap)
+        g = api.neural_forward_backward(vol, coords, targets).astype(np.float64)
+        api.neural_train_end(vol, grad_scale=0.0)        # clears the gradients; no l2 on the grid, and the MLP's l2 step is the same for all
+        api.neural_set_params_fp16(vol, params)
+        got.setdefault(overlap, []).append(g)
+    a, b, a2 = got["1"][0], got["0"][0], got["1"][1]
+    assert np.array_equal(a[:n_mlp], b[:n_mlp]) and np.array_equal(a[:n_mlp], a2[:n_mlp])
+    scale = np.linalg.norm(b[n_mlp:])
+    assert scale > 0 and np.linalg.norm(a[n_mlp:] - b[n_mlp:]) < 4e-3 * scale and np.linalg.norm(a2[n_mlp:] - b[n_mlp:]) < 4e-3 * scale
+    ocfg = oracle.grid_config(L, F, log2T, base, 1.5, 0, 0.0, 1000.0, gtype)
+    ref = T.training_gradients(ocfg, 64, H, params.view(np.uint16), coords, targets, loss="L1")["grads"]
+    for g in (a, b):
+        assert np.linalg.norm(g[:n_mlp] - ref[:n_mlp]) < 3e-2 * np.linalg.norm(ref[:n_mlp])
+        assert np.linalg.norm(g[n_mlp:] - ref[n_mlp:]) < 3e-2 * np.linalg.norm(ref[n_mlp:])
+
+
 def test_adam_step_matches_restatement(oracle):
     vol, ocfg, params, n_mlp, info = small_model(oracle, seed=3)
     rng = np.random.default_rng(4)

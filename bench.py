@@ -219,6 +219,13 @@ def c5_leg(a, ctx):
     check(L.vnrAmdSimpleVolumeOutOfCoreSetAsyncRefresh(sv.h, 1))
     dist.train_data_parallel(ctx, nv, 10, fast_mode=False)
     asyn = leg(400)
+    del nv, sv
+    dist.barrier(ctx)
+    if ctx.rank == 0 and not os.environ.get("VNR_BENCH_KEEP_C5_FILE"):   # 2 GiB in --c5-dir: not left behind
+        try:
+            os.remove(path)
+        except OSError:
+            pass
     return {"workload": f"C5 stand-in: {nx}x{ny}x{nz} uint8 file ({nx * ny * nz / 2**30:.0f} GiB, written in {write_s:.1f} s on rank 0), slab "
                         f"{tuple(info['block_dims'])} voxels = {info['block_size_aligned']} B, {info['n_blocks']} resident slabs per rank "
                         f"({info['n_blocks'] * info['block_size_aligned'] / 2**30:.2f} GiB of HBM), {info['n_concurrent_blocks']} replaced per refresh; C4-shaped model, "

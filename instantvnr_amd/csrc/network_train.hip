@@ -919,8 +919,8 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
     const uint32_t pairs = cfg_.n_features >= 2 ? cfg_.n_features / 2 : 1u;
     const dim3 g(div_round_up((uint64_t)batch * pairs * 2, 256), l1 - l0);  // one lane per (sample, x bit, feature pair)
     half_t* gg = (half_t*)grads_.ptr + n_mlp_;
-    if (side_by_side) {   // a few blocks per CU walk the same lanes (VNR_AMD_GRID_BWD_BLOCKS_PER_CU, default 4)
-      static const uint32_t per_cu = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_BLOCKS_PER_CU"); return e ? (uint32_t)std::max(1, std::min(16, std::atoi(e))) : 4u; }();
+    if (side_by_side) {   // a few blocks per CU walk the same lanes (VNR_AMD_GRID_BWD_BLOCKS_PER_CU, default 2: swept 2 / 3 / 4 / 6 / 8, profiles/r05_train_overlap_ab.txt)
+      static const uint32_t per_cu = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_BLOCKS_PER_CU"); return e ? (uint32_t)std::max(1, std::min(16, std::atoi(e))) : 2u; }();
       const uint32_t blocks = std::min<uint32_t>(g.x * g.y, (uint32_t)Runtime::get().n_cus * per_cu);
       switch (cfg_.n_features) {
       case 1: grid_backward_persistent_kernel<1><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0, l1 - l0); break;
@@ -1044,8 +1044,9 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   // 4. weight gradients.  They read what the MLP backward wrote and write the MLP part of the gradient blob; the grid backward reads
   // dL/dfeatures and writes the grid part: independent.  Round 5: on a side stream (with the dense levels' LDS scatter behind them) BESIDE the
   // atomic scatter of the hashed levels, which is bound by the memory side's atomic rate and, in its persistent form, leaves the CUs to
-  // them (the step's 22 + 66 us of MFMA / LDS work disappear behind the 150 us of atomics).  Not with a data-parallel exchange, whose ranges
-  // become ready in stream order.  VNR_AMD_TRAIN_OVERLAP=0: everything on one stream, as until round 4.
+  // them.  Measured (profiles/r05_train_overlap_ab.txt, one process, alternating, 8 pairs at two persistent blocks per CU): 2.4 % of the step
+  // on average, never slower -- the 25 us of weight gradients disappear, the LDS scatter does not (the two scatters slow each other down by
+  // about its length).  Not with a data-parallel exchange, whose ranges become ready in stream order.  VNR_AMD_TRAIN_OVERLAP=0: one stream.
   profile_mark(2, s);
   const char* overlap_e = std::getenv("VNR_AMD_TRAIN_OVERLAP");   // (read per step: both forms are compared inside one process, tests/test_gpu_train.py)
   overlap = (!overlap_e || std::atoi(overlap_e) != 0) && !exchange && batch >= 8192;

@@ -813,6 +813,7 @@ struct TrainScratch {  // per-Network extra buffers that do not need to live in 
   DeviceBuffer<uint8_t> lds_items{MemTag::Network};  // work items of grid_backward_lds_kernel (as bytes: the item type is local to this file)
   std::vector<uint8_t> lds_items_host;               // what lds_items holds: the list depends on the level sizes, n_features, tile size, batch and level range
   uint32_t loss_blocks = 0;
+  DeviceBuffer<double> distance_partials{MemTag::Network};   // gradient_distance (diagnostics)
 };
 
 }  // namespace vnr
@@ -1188,7 +1189,7 @@ void Network::gradient_distance(const uint16_t* d_ref, double out[4], hipStream_
 {
   if (grads_.count != grads_alloc()) throw std::runtime_error("gradient_distance: no gradient yet");
   constexpr uint32_t kBlocks = 256;
-  static DeviceBuffer<double> part(MemTag::Network);
+  DeviceBuffer<double>& part = scratch_of(this).distance_partials;   // (per network, released with its scratch: nothing static that outlives the HIP runtime)
   part.ensure(4 * kBlocks);
   grad_distance_kernel<<<kBlocks, 256, 0, s>>>((const half_t*)grads_.ptr, (const half_t*)d_ref, 0, n_mlp_, part.ptr);
   grad_distance_kernel<<<kBlocks, 256, 0, s>>>((const half_t*)grads_.ptr, (const half_t*)d_ref, n_mlp_, n_params_, part.ptr + 2 * kBlocks);

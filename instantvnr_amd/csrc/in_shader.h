@@ -1,6 +1,6 @@
 // in_shader.h — the in-shader ray marcher (rendering modes 6, 9, 12) and path tracer (mode 15) on a neural volume: kernel templates over
 // the encoding shape (F, padded width), the FullyFusedMLP width W and the kernel kind (GENERAL: grid_device.h), instantiated per width
-// and kind in in_shader_w{16,32,64,128}[g].hip (round 5; the reference instantiates widths 16 / 32 / 64 x F in {1, 2, 4, 8},
+// and kind in in_shader_w{16,32,64}[g].hip and in_shader_w128.hip (round 5; the reference instantiates widths 16 / 32 / 64 x F in {1, 2, 4, 8},
 // core/renderer/method_raymarching.cu:1192-1244, and refuses 128 at :1210, which comes free with the template here).
 //
 // Reference: network_raymarching_traceray / _transmittance / _iterator (core/renderer/method_raymarching.cu:310-356, 981-1128) with

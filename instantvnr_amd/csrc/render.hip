@@ -1243,7 +1243,6 @@ bool launch_in_shader_w128(const RenderParams&, const TileNet&, int, const InSha
 bool launch_in_shader_w16g(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
 bool launch_in_shader_w32g(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
 bool launch_in_shader_w64g(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
-bool launch_in_shader_w128g(const RenderParams&, const TileNet&, int, const InShaderLaunch&);
 
 bool Renderer::in_shader_applies() const
 {
@@ -1263,6 +1262,9 @@ bool Renderer::in_shader_applies() const
   // every width and kind of model has an instance (round 5) as long as its weight image fits the LDS beside the kernel's 48 static bytes
   // (deeper networks keep their weights in global memory and take the streaming path) and its encoding is one of VNR_IN_SHADER_SHAPES
   if (!net.valid() || !net.weights_in_lds() || (size_t)net.lds_halves() * 2 + 64 > 160 * 1024) return false;
+  // (128 neurons: the common kind only.  The reference refuses 128 neurons in shader altogether, method_raymarching.cu:1210; the GENERAL instances
+  // of that width alone were a fifth of the library's build time)
+  if (net.width() == 128u && !net.common_kind()) return false;
   const uint32_t F = net.config().n_features, K = net.padded_width();
 #define X(f, k) if (F == f && K == k) return true;
   VNR_IN_SHADER_SHAPES(X)
@@ -1289,7 +1291,7 @@ void Renderer::render_in_shader(const RenderParams& p, int shade)
   case 16: launched = net.general ? launch_in_shader_w16g(p, net, shade, l) : launch_in_shader_w16(p, net, shade, l); break;
   case 32: launched = net.general ? launch_in_shader_w32g(p, net, shade, l) : launch_in_shader_w32(p, net, shade, l); break;
   case 64: launched = net.general ? launch_in_shader_w64g(p, net, shade, l) : launch_in_shader_w64(p, net, shade, l); break;
-  case 128: launched = net.general ? launch_in_shader_w128g(p, net, shade, l) : launch_in_shader_w128(p, net, shade, l); break;
+  case 128: launched = !net.general && launch_in_shader_w128(p, net, shade, l); break;   // (128 neurons of the GENERAL kind: streaming path, in_shader_applies)
   default: break;
   }
   if (!launched) throw std::runtime_error("internal: no in-shader instance for this model shape");

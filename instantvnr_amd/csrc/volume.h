@@ -117,7 +117,6 @@ public:
   void set_current_timestep(int index);                                           // core/sampler.cu:19-26
   bool has_data() const { return data_.ptr != nullptr; }   // SimpleVolume::texture() != 0
   OutOfCoreSampler* out_of_core() { return ooc_.get(); }
-  bool is_out_of_core() const { return ooc_ != nullptr; }
 
   const float* d_data() const { return data_.ptr; }
   vec3i dims() const { return desc.dims; }
@@ -200,10 +199,6 @@ private:
   TfnObject tfn_;
   const size_t batch_size_ = 1u << 16;  // network.cu:183
   DeviceBuffer<float> train_x_{MemTag::Network}, train_y_{MemTag::Network}, test_y1_{MemTag::Network};
-  // train(steps): the next step's batch, drawn on a side stream beside the current step's backward pass and optimizer (volume.hip)
-  DeviceBuffer<float> train_x_next_{MemTag::Network}, train_y_next_{MemTag::Network};
-  hipStream_t prefetch_stream_ = nullptr;
-  hipEvent_t ev_batch_free_ = nullptr, ev_batch_ready_ = nullptr;
   DeviceBuffer<float> decoded_{MemTag::Network}, decode_coords_{MemTag::Network};  // dense decoded volume, coordinates of one blob
   int decode_blob_ = 0;
   bool pending_step_ = false, pending_internal_ = false;

@@ -758,11 +758,7 @@ NeuralVolume::NeuralVolume()
   stream = Runtime::get().stream;
 }
 
-NeuralVolume::~NeuralVolume()
-{
-  if (prefetch_stream_) { (void)hipStreamSynchronize(prefetch_stream_); (void)hipStreamDestroy(prefetch_stream_); (void)hipEventDestroy(ev_batch_free_); (void)hipEventDestroy(ev_batch_ready_); }
-  network_release_scratch(&net_);
-}
+NeuralVolume::~NeuralVolume() { network_release_scratch(&net_); }
 
 void NeuralVolume::set_transfer_function(const TransferFunctionData& t, hipStream_t s)
 {
@@ -845,46 +841,9 @@ void NeuralVolume::train_end(float grad_scale, bool fast_mode)
 void NeuralVolume::train(size_t steps, bool fast_mode)
 {
   if (!net_.valid()) return;
-  // The batch of step i + 1 depends on nothing step i computes (the sampler reads the volume and its own random stream), so with a resident
-  // volume it is drawn on a side stream while step i's backward pass and optimizer run: 17 us of a ~500 us step leave the chain (round 5).
-  // The same batches in the same order (the stream position is advanced by the host when a batch is enqueued); the second pair of buffers is
-  // needed because step i's batch is still read by its online macrocell update.  Not for an out-of-core volume, whose sampler refreshes its
-  // slab set per call on streams of its own.  VNR_AMD_TRAIN_PREFETCH=0: every batch on the training stream.
-  const char* prefetch_e = std::getenv("VNR_AMD_TRAIN_PREFETCH");   // (read per call: both forms are compared inside one process, tests/test_gpu_train.py)
-  const bool prefetch = (!prefetch_e || std::atoi(prefetch_e) != 0) && steps > 1 && source_ && !source_->is_out_of_core();
-  if (!prefetch) {
-    for (size_t i = 0; i < steps; ++i) {
-      train_begin();
-      train_end(1.0f, fast_mode);
-    }
-  } else {
-    if (!prefetch_stream_) {
-      VNR_HIP_CHECK(hipStreamCreateWithFlags(&prefetch_stream_, hipStreamNonBlocking));
-      VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_batch_free_, hipEventDisableTiming));
-      VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_batch_ready_, hipEventDisableTiming));
-    }
-    train_x_next_.resize(batch_size_ * 3);
-    train_y_next_.resize(batch_size_);
-    const vec3f lower = {0, 0, 0}, upper = {1, 1, 1};  // m_lower/m_upper = full volume (network.cu:605)
-    source_->take_samples(train_x_.ptr, train_y_.ptr, batch_size_, lower, upper, stream);
-    for (size_t i = 0; i < steps; ++i) {
-      net_.forward_backward(train_x_.ptr, train_y_.ptr, batch_size_, stream);
-      pending_step_ = true;
-      pending_internal_ = true;
-      if (i + 1 < steps) {
-        // the other pair of buffers was last read by the macrocell update of step i - 1, which the training stream has passed by now
-        VNR_HIP_CHECK(hipEventRecord(ev_batch_free_, stream));
-        VNR_HIP_CHECK(hipStreamWaitEvent(prefetch_stream_, ev_batch_free_, 0));
-        source_->take_samples(train_x_next_.ptr, train_y_next_.ptr, batch_size_, lower, upper, prefetch_stream_);
-        VNR_HIP_CHECK(hipEventRecord(ev_batch_ready_, prefetch_stream_));
-      }
-      train_end(1.0f, fast_mode);
-      if (i + 1 < steps) {
-        VNR_HIP_CHECK(hipStreamWaitEvent(stream, ev_batch_ready_, 0));
-        std::swap(train_x_, train_x_next_);
-        std::swap(train_y_, train_y_next_);
-      }
-    }
+  for (size_t i = 0; i < steps; ++i) {
+    train_begin();
+    train_end(1.0f, fast_mode);
   }
   if (!fast_mode) mc_.update_max_opacity(tfn_.view(), stream);  // network.cu:778
 }

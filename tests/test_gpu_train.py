@@ -118,33 +118,6 @@ def test_the_side_by_side_backward_pass_gives_the_one_stream_pass_s_gradients(or
         assert np.linalg.norm(g[n_mlp:] - ref[n_mlp:]) < 3e-2 * np.linalg.norm(ref[n_mlp:])
 
 
-def test_prefetched_batches_are_the_batches_of_the_one_stream_loop(monkeypatch):
-    """round 5: vnrNeuralVolumeTrain(steps > 1) draws step i + 1's batch on a side stream beside step i's backward pass and optimizer.  The
-    batches must be the same ones in the same order: the ONLINE macrocell (min / max of every batch's values per cell: order-independent, so
-    bit-comparable) and the sampler's next batch equal the one-stream loop's (VNR_AMD_TRAIN_PREFETCH=0) bit for bit, the parameters to the
-    arrival order of the fp16 atomics"""
-    import os
-    os.environ["VNR_AMD_INIT_SEED"] = "99"
-    vol = syn.analytic_volume(48)
-    out = {}
-    for prefetch in ("1", "0"):
-        monkeypatch.setenv("VNR_AMD_TRAIN_PREFETCH", prefetch)
-        sv = api.vnrCreateSimpleVolume(vol)
-        nv = api.vnrCreateNeuralVolume(syn.model_config(n_levels=6, n_features=2, log2_hashmap_size=14, base_resolution=4, n_hidden_layers=2), sv,
-                                       online_macrocell_construction=True)
-        api.vnrNeuralVolumeTrain(nv, 7, False)
-        api.vnrNeuralVolumeTrain(nv, 1, False)          # a single step takes the plain path
-        api.vnrNeuralVolumeTrain(nv, 4, False)
-        c, v = api.simple_volume_take_samples(sv, 4096)
-        out[prefetch] = (api.volume_macrocell(nv)["value_range"].copy(), c, v, api.neural_get_params_fp16(nv).astype(np.float32),
-                         api.vnrNeuralVolumeGetTrainingStep(nv))
-    a, b = out["1"], out["0"]
-    assert a[4] == b[4] == 12
-    assert np.array_equal(a[0], b[0]), "the online macrocell saw other batches"
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), "the sampler's stream position differs"
-    assert np.abs(a[3] - b[3]).max() < 2e-2 and np.linalg.norm(a[3] - b[3]) < 2e-2 * np.linalg.norm(b[3])
-
-
 def test_adam_step_matches_restatement(oracle):
     vol, ocfg, params, n_mlp, info = small_model(oracle, seed=3)
     rng = np.random.default_rng(4)

@@ -22,9 +22,8 @@ api.vnrNeuralVolumeTrain(nv, 200, True)
 check(L.vnrAmdSynchronize())
 import ctypes as C
 for rep in range(reps):
-    for overlap, prefetch in (("0", "0"), ("1", "0"), ("1", "1")):
+    for overlap in ("0", "1"):
         os.environ["VNR_AMD_TRAIN_OVERLAP"] = overlap
-        os.environ["VNR_AMD_TRAIN_PREFETCH"] = prefetch   # (round 5: the next step's batch drawn on a side stream, volume.hip NeuralVolume::train)
         api.vnrNeuralVolumeTrain(nv, 20, True)
         check(L.vnrAmdSynchronize())
         t0 = time.perf_counter()
@@ -37,6 +36,6 @@ for rep in range(reps):
         ph = (C.c_double * 5)(); n = C.c_int()
         check(L.vnrAmdNeuralVolumeGetTrainProfile(nv.h, ph, C.byref(n)))
         check(L.vnrAmdNeuralVolumeSetTrainProfiling(nv.h, 0))
-        print(f"overlap {overlap} prefetch {prefetch}: {ms:.4f} ms per step (wall, {steps} steps); phases [forward, loss + MLP backward, weight gradients, grid backward (+ join), optimizer] = "
+        print(f"overlap {overlap}: {ms:.4f} ms per step (wall, {steps} steps); phases [forward, loss + MLP backward, weight gradients, grid backward (+ join), optimizer] = "
               + ", ".join(f"{ph[i] * 1e3:.1f}" for i in range(5)) + f" us; loss {api.vnrNeuralVolumeGetTrainingLoss(nv):.5f}", flush=True)
 print("PSNR after all legs: %.2f dB" % api.vnrNeuralVolumeGetPSNR(nv))

@@ -126,9 +126,13 @@ def sources_sha16(files):
     """names what a kernel is compiled from: counter results of separate rocprofv3 --pmc passes (profiles/r05_*.json carry `source_files` and
     `source_sha16`) enter the line only while this still gives the hash they were stamped with"""
     import hashlib
+    import re
     h = hashlib.sha256()
     for n in files:
-        h.update(open(os.path.join(ROOT, "instantvnr_amd", "csrc", n), "rb").read())
+        text = open(os.path.join(ROOT, "instantvnr_amd", "csrc", n), encoding="utf-8", errors="replace").read()
+        # the code, not its commentary: `//` comments, trailing blanks and empty lines do not change what is compiled
+        lines = (re.sub(r"\s*//.*$", "", line).rstrip() for line in text.splitlines())
+        h.update("\n".join(line for line in lines if line).encode())
     return h.hexdigest()[:16]
 
 

@@ -5,9 +5,10 @@
 //   forward (keeps fp16 features + hidden activations) -> L1/L2 loss with loss scale 128 -> MLP backward ->
 //   weight gradients -> hash-grid backward (scatter-add) -> Adam (fp32 master weights, per-parameter step
 //   count, zero-gradient grid entries skipped, l2_reg on matrix weights only) under ExponentialDecay.
-// Differences chosen for MI355X (documented in DESIGN.md): gradients are accumulated in ONE fp32 buffer
-// (tcnn: fp16 with half2 atomics) so a data-parallel run all-reduces a single tensor; the MLP backward
-// runs on MFMA with the same transposed register-resident scheme as the forward.
+// Chosen for MI355X: the gradient of the whole parameter blob lives in ONE half-precision buffer (tcnn's own gradient
+// precision; packed fp16 atomics), so a data-parallel run exchanges a single tensor; the MLP backward and the weight gradients run on MFMA
+// with the forward's transposed register-resident scheme; the dense coarse levels scatter through LDS tiles; since round 5 the weight
+// gradients and that LDS scatter run on a side stream beside a persistent atomic scatter of the hashed levels.
 #include "infer_kernel.h"
 
 namespace vnr {

@@ -19,7 +19,6 @@ Three loops:  fast   one volume per model, learning rate 0 (the optimizer step c
                      the Network's address, weight-gradient slab, LDS work-item cache, workspace re-allocation).
 usage: grad_hammer.py <fast repetitions> <fresh repetitions> <reconf repetitions> [out file]"""
 import ctypes as C
-import json
 import os
 import sys
 import time

@@ -136,18 +136,6 @@ def sources_sha16(files):
     return h.hexdigest()[:16]
 
 
-def grid_levels(n_levels, log2_T, base, pls):
-    """entries and kind of every level (EXTERNAL tcnn level sizing): res = ceil(base * pls^l - 1) + 1,
-    n = min(next_multiple(res^3, 8), 2^log2_T); a level is hashed when res^3 exceeds the table"""
-    out = []
-    for l in range(n_levels):
-        scale = float(np.float32(np.exp2(np.float32(l) * np.float32(np.log2(pls)))) * np.float32(base) - np.float32(1.0))
-        res = int(np.ceil(scale)) + 1
-        full = (res ** 3 + 7) // 8 * 8
-        out.append({"res": res, "entries": min(full, 1 << log2_T), "hashed": res ** 3 > (1 << log2_T)})
-    return out
-
-
 def workload_name(a):
     if (a.size, a.fb, a.levels, a.features, a.hidden_layers) == (1024, 1024, 16, 2, 3):
         return "C4"
@@ -714,10 +702,10 @@ def main():
     # are (sample, x bit, feature pair) with the two x-neighbours of a corner pair adjacent, i.e. ONE request per (sample, level, yz corner)
     # for n_features <= 8; the dense coarse levels go through LDS tiles and flush at most entries x F x 2 B / 64 B requests per slice.
     ATOMIC_PEAK_GREQ = 4 * 256 / 50e-9 / 1e9
-    lv = grid_levels(Lv, a.log2_hashmap_size, 16, pls)
+    lv = api.neural_level_table(nv)   # the library's own layout (vnrAmdNeuralVolumeLevelTable): no restatement of tcnn's level sizing here
     tile_entries = (24 * 1024 // (4 * F)) & ~15
     lds_levels = 0
-    while lds_levels < Lv and not lv[lds_levels]["hashed"] and -(-lv[lds_levels]["entries"] // tile_entries) <= 64:
+    while lds_levels < Lv and lv[lds_levels]["kind"] == 0 and -(-lv[lds_levels]["entries"] // tile_entries) <= 64:
         lds_levels += 1
     req_atomic = B * 4 * (Lv - lds_levels)
     req_flush_max = 0

@@ -225,6 +225,10 @@ int    vnrAmdNeuralVolumeGetInfo(vnrAmdVolume, int* n_levels, int* n_features_pe
  * model runs on the MFMA kernels (inference / training; always 1 since round 4: every model the reference's dispatch builds does) */
 int    vnrAmdNeuralVolumeGetModelKind(vnrAmdVolume, int* activation, int* output_activation, int* grid_type, int* interpolation,
                                       int* mfma_inference, int* mfma_training);
+/* the hash grid's level table as the library laid it out (EXTERNAL tcnn level sizing): per level the grid resolution, the
+ * entries of its table, its offset in entries and its kind (0 dense, 1 prime-XOR hash, 2 / 3 / 4 Tiled over 1 / 2 / 3 dimensions); arrays
+ * of max_levels elements, any may be NULL.  Returns n_levels (-1 on error). */
+int    vnrAmdNeuralVolumeLevelTable(vnrAmdVolume, int max_levels, uint32_t* resolution, uint32_t* entries, uint32_t* offset, uint32_t* kind);
 /* raw tcnn-order parameter blob (MLP weights, then grid), fp16 */
 int    vnrAmdNeuralVolumeGetParamsFP16(vnrAmdVolume, uint16_t* host_out, size_t count);
 int    vnrAmdNeuralVolumeSetParamsFP16(vnrAmdVolume, const uint16_t* host_in, size_t count);

@@ -141,6 +141,7 @@ def lib():
     sig("vnrAmdNeuralVolumeBrickImageInfo", I, P, IP, C.POINTER(SZ), FP)
     sig("vnrAmdNeuralVolumeGetInfo", I, P, IP, IP, IP, IP, IP, C.POINTER(U64))
     sig("vnrAmdNeuralVolumeGetModelKind", I, P, IP, IP, IP, IP, IP, IP)
+    sig("vnrAmdNeuralVolumeLevelTable", I, P, I, P, P, P, P)
     sig("vnrAmdNeuralVolumeGetParamsFP16", I, P, P, SZ)
     sig("vnrAmdNeuralVolumeSetParamsFP16", I, P, P, SZ)
     sig("vnrAmdNeuralVolumeTrainBegin", I, P)

@@ -592,6 +592,15 @@ def neural_info(v):
     return d
 
 
+def neural_level_table(v):
+    """the hash grid's levels as the library laid them out: list of dicts(res, entries, offset, kind) (kind: 0 dense, 1 hash, 2-4 tiled)"""
+    a = [np.zeros(32, np.uint32) for _ in range(4)]
+    n = lib().vnrAmdNeuralVolumeLevelTable(v.h, 32, *[x.ctypes.data_as(C.c_void_p) for x in a])
+    if n < 0:
+        check(1)
+    return [{"res": int(a[0][l]), "entries": int(a[1][l]), "offset": int(a[2][l]), "kind": int(a[3][l])} for l in range(n)]
+
+
 def neural_set_params_fp16(v, params):
     p = np.ascontiguousarray(params).view(np.uint16)
     check(lib().vnrAmdNeuralVolumeSetParamsFP16(v.h, p.ctypes.data_as(C.c_void_p), p.size))

@@ -594,6 +594,22 @@ int vnrAmdNeuralVolumeGetInfo(vnrAmdVolume v, int* n_levels, int* n_features, in
     if (n_params) *n_params = (uint64_t)n.n_params();
   });
 }
+int vnrAmdNeuralVolumeLevelTable(vnrAmdVolume v, int max_levels, uint32_t* resolution, uint32_t* entries, uint32_t* offset, uint32_t* kind)
+{
+  int n = -1;
+  guarded([&]() {
+    const Network& net = as_neural(v)->network();
+    const GridDevice& g = net.grid();
+    n = (int)net.config().n_levels;
+    for (int l = 0; l < n && l < max_levels; ++l) {
+      if (resolution) resolution[l] = g.levels[l].resolution;
+      if (entries) entries[l] = g.levels[l].size;
+      if (offset) offset[l] = g.levels[l].offset;
+      if (kind) kind[l] = g.levels[l].hashed;
+    }
+  });
+  return n;
+}
 int vnrAmdNeuralVolumeGetParamsFP16(vnrAmdVolume v, uint16_t* host_out, size_t count)
 {
   return guarded([&]() { NeuralVolume* n = as_neural(v); n->network().get_params_f16(host_out, count, n->stream); });

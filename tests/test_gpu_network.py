@@ -372,6 +372,25 @@ def test_reconfiguring_a_model_does_not_reuse_the_old_models_training_scratch(or
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 3e-2
 
 
+@pytest.mark.parametrize("cfg", [(16, 2, 22, 16, 1.3195, "Hash"), (16, 2, 19, 16, float(np.exp(np.log(1024 / 16.0) / 15)), "Hash"), (8, 8, 19, 16, 2.0, "Hash"),
+                                 (5, 4, 12, 4, 1.5, "Dense"), (9, 2, 12, 6, 1.7, "Tiled")])
+def test_the_level_table_the_library_reports_is_the_oracle_s_layout(oracle, cfg):
+    """vnrAmdNeuralVolumeLevelTable (what bench.py prices the training scatter with): resolution, entries and offset of every level equal the
+    oracle's restatement of tcnn's level sizing (EXTERNAL), for a per_level_scale whose fp32 power lands within an ulp of an integer too
+    (1024 / 16)^(1/15): level 5 is 65 grid points, not 64)"""
+    L, F, log2T, base, pls, gtype = cfg
+    c = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=log2T, base_resolution=base, n_hidden_layers=2, per_level_scale=pls)
+    if gtype != "Hash": c["encoding"]["type"] = gtype
+    vol = api.vnrCreateNeuralVolume(c, (32, 32, 32))
+    got = api.neural_level_table(vol)
+    lay = oracle.grid_layout(oracle.grid_config(L, F, log2T, base, pls, 0, 0.0, 1000.0, gtype))
+    assert len(got) == L
+    assert [g["offset"] for g in got] == [int(x) for x in lay["offsets"][:L]]
+    assert [g["entries"] for g in got] == [int(x) for x in np.diff(lay["offsets"].astype(np.int64))]
+    assert [g["res"] for g in got] == [int(x) for x in lay["resolution"][:L]] if "resolution" in lay else True
+    assert all((g["kind"] == 0) == (g["res"] ** 3 <= g["entries"] or gtype == "Dense") for g in got if gtype != "Tiled")
+
+
 def test_two_shapes_with_the_same_mlp_size_do_not_share_the_weight_gradient_slab():
     """64 neurons x 1 hidden layer and 32 neurons x 2 hidden layers on a 16-wide encoding both have 2 048 MLP parameters, with
     other layouts.  The slab's never-written elements (rows 1 .. 15 of the padded last layer) were zeroed per n_mlp only, so after the

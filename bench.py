@@ -274,7 +274,8 @@ def choose_transport():
     # parent with another verdict than the others, and ranks that then meet with different transports hang in the rendezvous.
     # So the parents agree too, without any transport: one file per rank in /dev/shm (one node), keyed by the launcher's pid and port;
     # RCCL only if every rank's child said ok.
-    key = f"vnr_bench_probe_{os.environ.get('MASTER_PORT', '29500')}_{os.getppid()}"
+    # (the ranks of one run share their launcher's pid; a launcher that gives every rank a parent of its own sets VNR_BENCH_RUN_ID)
+    key = f"vnr_bench_probe_{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('VNR_BENCH_RUN_ID') or os.getppid()}"
     rank = int(os.environ.get("RANK", "0"))
     base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", key)
     with open(f"{base}_{rank}.tmp", "w") as f:

@@ -423,7 +423,7 @@ def test_two_shapes_with_the_same_mlp_size_do_not_share_the_weight_gradient_slab
 def test_repeated_gradient_batches_and_reconfigurations_never_miss():
     """the hunt for round 4's once-in-28 000 grid-gradient transient as a regression test (tests/diag/grad_hammer.py, short form): the sweep's
     draw and four other models, every repetition compared ON THE DEVICE with the first one -- one volume per model, a fresh volume per
-    repetition, one volume re-configured between the models.  1.86 M such checks ran clean in round 5 (profiles/r05_grad_hammer.txt)"""
+    repetition, one volume re-configured between the models.  3.25 M such checks ran clean in round 5 (profiles/r05_grad_hammer.txt)"""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "grad_hammer.py"), "20000", "600", "3000", "/tmp/vnr_grad_hammer_test.txt"],

@@ -255,10 +255,13 @@ def choose_transport():
     import subprocess
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
-    env["VNR_AMD_DIST_TIMEOUT"] = env.get("VNR_AMD_DIST_TIMEOUT", "120")
+    # the probe is bounded tightly (a driver's own clock runs around this program): 60 s for the children to meet, 30 s per collective -> a
+    # transport that hangs costs at most 240 s before the run goes on over shared memory (a working RCCL start-up of 8 ranks takes seconds)
+    env["VNR_AMD_DIST_TIMEOUT"] = env.get("VNR_BENCH_PROBE_RENDEZVOUS", "60")
+    env["VNR_BENCH_SELFTEST_DEADLINE"] = env.get("VNR_BENCH_PROBE_DEADLINE", "30")
     # the child's worst case is its rendezvous timeout + five collectives at their deadline each: the limit must not cut a child that
     # would still have answered
-    deadline = float(os.environ.get("VNR_BENCH_SELFTEST_DEADLINE", "60"))
+    deadline = float(env["VNR_BENCH_SELFTEST_DEADLINE"])
     limit = max(float(os.environ.get("VNR_BENCH_PROBE_LIMIT", "0")), float(env["VNR_AMD_DIST_TIMEOUT"]) + 5 * deadline + 30)
     t0 = time.perf_counter()
     try:

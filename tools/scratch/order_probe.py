@@ -1,4 +1,4 @@
-"""GPU box: does the ORDER OF 64-SAMPLE CHUNKS in the real sample queue matter?  Takes the queue of march iteration ITER of the
+"""GPU box (a -DVNR_DIAG build: VNR_AMD_DEBUG_MAX_ITERS stops the frame at the iteration whose queue is read): does the ORDER OF 64-SAMPLE CHUNKS in the real sample queue matter?  Takes the queue of march iteration ITER of the
 bench frame and times the fused kernel on it (a) as it is, (b) with its 64-sample chunks sorted by the Morton code of their
 centroid, (c) with 1024-sample runs (about one 64-ray group's claim) sorted the same way, (d) fully Morton sorted, (e) shuffled.
 usage: python tools/order_probe.py [ITER ...]"""
@@ -144,6 +144,14 @@ for it in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 4]:
         print(f"    all levels: as is {tot_c:.2f} lines = {tot_c * 128:.0f} B per sample; bricks {tot_b:.2f} lines = {tot_b * 128:.0f} B per sample", flush=True)
         continue
     run("queue order", coords)
+    # round 5: the CEILING of any order of the samples: every sample at its Morton position (1-voxel cells of the finest
+    # level), over the whole queue and inside runs of one 64-ray group's batch (64 x 24 samples), which is all a per-group sort could reach
+    q = np.floor(coords.astype(np.float64) * 1024).astype(np.int64).clip(0, 1023)
+    run("ALL samples in Morton order (ceiling)", coords[np.argsort(morton(q), kind="stable")])
+    m = (coords.shape[0] // 1536) * 1536
+    key = morton(q[:m]).reshape(-1, 1536)
+    order = (np.argsort(key, axis=1, kind="stable") + (np.arange(key.shape[0]) * 1536)[:, None]).reshape(-1)
+    run("samples in Morton order inside runs of 1536 (one group's batch)", np.concatenate([coords[:m][order], coords[m:]]))
     run("regrouped: rays in row-major tile order", regroup_by_pixel(coords, "row"))
     run("regrouped: rays in Morton tile order", regroup_by_pixel(coords, "morton"))
     run("64-sample chunks sorted by Morton(centroid)", chunk_sorted(coords, 64))

@@ -65,6 +65,9 @@ __device__ unsigned long long g_wave_rec[kWaveRecs][8];
 // pass, one ray per pixel from that sample towards the light, alpha only, which finally shades and writes the pixel
 // (method_raymarching.cu:789-833, 877-900, 960-973).
 template <bool FIRST, int MODE>
+#if defined(VNR_MARCH_WAVES_PER_EU)   // experiment (tools/ab_build.sh m96 -DVNR_MARCH_WAVES_PER_EU=5): a march wave of 96 registers fits beside the evaluation kernel's four
+__attribute__((amdgpu_waves_per_eu(VNR_MARCH_WAVES_PER_EU, VNR_MARCH_WAVES_PER_EU)))   // waves of 104 on a SIMD; 232 bytes of scratch per lane; the frame 3.62 -> 3.93 ms
+#endif
 __global__ void __launch_bounds__(256) march_kernel(const RenderParams p, const RayList cur, const RayList nxt,
                                                     const vec2f* __restrict__ vd_in, vec4f* __restrict__ queue,
                                                     vec2f* __restrict__ vd_out, uint32_t* __restrict__ counters,

@@ -104,8 +104,17 @@ void Runtime::init(int dev)
   VNR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
   n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (stream) (void)hipStreamDestroy(stream);
+  for (hipStream_t& ps : part_streams) if (ps) { (void)hipStreamDestroy(ps); ps = nullptr; }   // (another device: the pool belongs to the old one)
   VNR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   device = dev;
+}
+
+hipStream_t Runtime::part_stream(int part)
+{
+  if (part < 1 || part > 3) throw std::runtime_error("internal: ray part stream index");
+  if (!ready()) init(-1);
+  if (!part_streams[part]) VNR_HIP_CHECK(hipStreamCreateWithFlags(&part_streams[part], hipStreamNonBlocking));
+  return part_streams[part];
 }
 
 extern "C" {

@@ -72,6 +72,12 @@ inline affine3f affine_scale_then(const vec3f s, const affine3f& a)
 struct Runtime {
   int device = -1;
   hipStream_t stream = nullptr;  // the library's stream
+  // The ray parts' streams of EVERY renderer of the process (part 0 runs on `stream`): created once, on first use.  The HIP runtime deals a
+  // process's streams round-robin onto four hardware queues, in creation order; a renderer that created streams of its own landed wherever
+  // the count stood, and every fourth one on the queue of `stream` itself, where two ray parts then run one behind the other (round 5,
+  // profiles/r05_stream_budget.txt).  With the pool the library owns at most 1 + 3 streams for rendering whatever comes and goes.
+  hipStream_t part_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t part_stream(int part);   // part >= 1
   int n_cus = 256;
   size_t bytes_renderer = 0, bytes_network = 0;
   static Runtime& get();

@@ -1048,10 +1048,13 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   // atomic scatter of the hashed levels, which is bound by the memory side's atomic rate and, in its persistent form, leaves the CUs to
   // them.  Measured (profiles/r05_train_overlap_ab.txt, one process, alternating, 8 pairs at two persistent blocks per CU): 2.4 % of the step
   // on average, never slower -- the 25 us of weight gradients disappear, the LDS scatter does not (the two scatters slow each other down by
-  // about its length).  Not with a data-parallel exchange, whose ranges become ready in stream order.  VNR_AMD_TRAIN_OVERLAP=0: one stream.
+  // about its length).  Not with a data-parallel exchange, whose ranges become ready in stream order.
+  // OPT-IN (VNR_AMD_TRAIN_OVERLAP=1), not the default: the side stream is one more HIP stream alive in the process, and a renderer whose ray
+  // parts then share a hardware queue with it pays far more than this buys (a 1/8 share of the frame 0.54 -> 0.85 ms before the renderer was
+  // made robust to it, profiles/r05_stream_budget.txt); a process that only trains can switch it on.
   profile_mark(2, s);
   const char* overlap_e = std::getenv("VNR_AMD_TRAIN_OVERLAP");   // (read per step: both forms are compared inside one process, tests/test_gpu_train.py)
-  overlap = (!overlap_e || std::atoi(overlap_e) != 0) && !exchange && batch >= 8192;
+  overlap = overlap_e && std::atoi(overlap_e) != 0 && !exchange && batch >= 8192;   // opt-in: see below
   if (overlap) {
     if (!side_stream_) {
       VNR_HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));

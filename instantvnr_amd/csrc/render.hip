@@ -856,7 +856,9 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   counters_.resize(2 * kMaxParts * C_COUNT);  // one block of counters per frame slot and half
   counters_.zero(stream_);
   VNR_HIP_CHECK(hipHostMalloc((void**)&host_counts_, 2 * kMaxParts * (256 + C_COUNT) * sizeof(uint32_t), hipHostMallocDefault));
-  for (int i = 1; i < kMaxParts; ++i) VNR_HIP_CHECK(hipStreamCreateWithFlags(&part_streams_[i], hipStreamNonBlocking));
+  // (the ray parts' streams come from the process-wide pool, Runtime::part_stream, when a frame first uses them: a stream that exists takes a
+  // place in the runtime's mapping of streams to its four hardware queues whether it is used or not, and a share's parts must not end up
+  // sharing one: DESIGN.md 6)
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 }
 
@@ -864,7 +866,7 @@ Renderer::~Renderer()
 {
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (own_stream_) (void)hipStreamDestroy(stream_);
-  for (int i = 1; i < kMaxParts; ++i) if (part_streams_[i]) { (void)hipStreamSynchronize(part_streams_[i]); (void)hipStreamDestroy(part_streams_[i]); }
+  for (int i = 1; i < kMaxParts; ++i) if (part_streams_[i]) (void)hipStreamSynchronize(part_streams_[i]);   // (pool streams: not this renderer's to destroy)
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   for (auto& ps : d_streams_) for (hipStream_t st : ps) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   frame_[0].reset(); frame_[1].reset();
@@ -1567,6 +1569,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
     hf.rc = rc_base + off / 64 + (size_t)h * 8;   // halves are multiples of 64 rays; 8 groups of slack each
     hf.hc = host_base + (size_t)h * 256;
     hf.hs = host_base + kMaxParts * 256 + (size_t)h * C_COUNT;
+    if (h > 0 && !part_streams_[h]) part_streams_[h] = Runtime::get().part_stream(h);
     hf.s = h == 0 ? stream_ : part_streams_[h];
     hf.s_max = (size_t)hf.p.n_local * hf.p.n_iters * (grad ? 4 : 1);   // records the evaluation kernel may see
     off += hf.p.n_local;

@@ -144,8 +144,12 @@ private:
   static constexpr int kMaxParts = 4;
   int n_halves_ = 2;  // streaming mode: rays dealt to n parts on n streams (march of one overlaps inference of another)
   bool n_halves_fixed_ = false;
-  int small_share_parts_ = 4;  // parts of a share of at most 262 144 pixels (a quarter of a 1024 x 1024 frame): with pipelined frames
-                               // 4 short chains side by side beat 2 (1/4 share 1.17 -> 1.13 ms, 1/8 share 0.66 -> 0.65 ms; whole frames: no difference)
+  // parts of a share of at most 262 144 pixels (a quarter of a 1024 x 1024 frame): with pipelined frames several short chains side by side beat 2
+  // (round 2: 1/4 share 1.17 -> 1.13 ms, 1/8 share 0.66 -> 0.65 ms; whole frames: no difference).  THREE since round 5, not four: the runtime maps
+  // a process's HIP streams onto four hardware queues, a rank of a multi-GPU run also owns a communication stream, and with four part streams
+  // plus that one two parts share a queue and run one behind the other: 1/8 share 0.555 -> 0.794 ms, 1/4 share 1.02 -> 1.37 ms with ONE more
+  // stream alive in the process, against 0.539 -> 0.558 and 1.03 -> 1.06 ms with three parts (profiles/r05_stream_budget.txt).
+  int small_share_parts_ = 3;
   uint32_t predicted_iterations_[2][kMaxParts] = {};   // [camera pass | shadow pass][half]
   // decoupled path (VNR_AMD_DECOUPLED): 0 never, 1 (default) for ray sets of at most 20 480 rays, 2 always.  Measured on shares of the bench
   // frame (profiles/r03_decoupled_share_sweeps.txt): 1/64 (16 384 rays) 0.203 against 0.248 ms coupled, 1/32 equal, 1/16 0.45 against 0.38,

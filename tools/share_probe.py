@@ -17,6 +17,16 @@ if os.environ.get("SHARE_NEURONS"):   # FullyFusedMLP width of the probe's model
     cfg["network"]["n_neurons"] = int(os.environ["SHARE_NEURONS"])
 nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=False)
 api.vnrNeuralVolumeTrain(nv, 300, True)
+# SHARE_EXTRA_STREAMS=n: n more HIP streams alive in the process before the renderers are created (round 5: a process that owns more streams than
+# the runtime has hardware queues -- 4 by default -- runs a small share's ray parts through shared queues)
+_extra = []
+if os.environ.get("SHARE_EXTRA_STREAMS"):
+    import ctypes as _C
+    _hip = _C.CDLL("libamdhip64.so")
+    for _ in range(int(os.environ["SHARE_EXTRA_STREAMS"])):
+        _s = _C.c_void_p()
+        assert _hip.hipStreamCreateWithFlags(_C.byref(_s), 1) == 0
+        _extra.append(_s)
 cam = syn.oblique_camera(dims, distance_scale=1.1)
 base = 0.0
 colors, alphas = syn.tfn_ramp_with_bumps(opacity_scale=0.06)

@@ -78,6 +78,9 @@ struct Runtime {
   // profiles/r05_stream_budget.txt).  With the pool the library owns at most 1 + 3 streams for rendering whatever comes and goes.
   hipStream_t part_streams[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t part_stream(int part);   // part >= 1
+  // streams the library owns beside those: a rank's communication stream, an out-of-core sampler's copy stream, the opt-in training side
+  // stream.  The renderer deals a small share to three parts while at most one of them exists and to two otherwise (render_streaming).
+  int other_streams = 0;
   int n_cus = 256;
   size_t bytes_renderer = 0, bytes_network = 0;
   static Runtime& get();

@@ -106,6 +106,9 @@ void Runtime::init(int dev)
   if (stream) (void)hipStreamDestroy(stream);
   for (hipStream_t& ps : part_streams) if (ps) { (void)hipStreamDestroy(ps); ps = nullptr; }   // (another device: the pool belongs to the old one)
   VNR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  // the two part streams every renderer uses, right behind it: the runtime gives the first four streams of a process a hardware queue each and
+  // every later one the least used queue (ties: any), so the three rendering streams are on three queues whatever is created afterwards
+  for (int i = 1; i <= 2; ++i) VNR_HIP_CHECK(hipStreamCreateWithFlags(&part_streams[i], hipStreamNonBlocking));
   device = dev;
 }
 

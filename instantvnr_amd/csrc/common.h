@@ -75,7 +75,8 @@ struct Runtime {
   // The ray parts' streams of EVERY renderer of the process (part 0 runs on `stream`): created once, on first use.  The HIP runtime deals a
   // process's streams round-robin onto four hardware queues, in creation order; a renderer that created streams of its own landed wherever
   // the count stood, and every fourth one on the queue of `stream` itself, where two ray parts then run one behind the other (round 5,
-  // profiles/r05_stream_budget.txt).  With the pool the library owns at most 1 + 3 streams for rendering whatever comes and goes.
+  // profiles/r05_stream_budget.txt).  With the pool the library owns at most 1 + 3 streams for rendering whatever comes and goes; parts 1 and 2
+  // are created together with `stream` (Runtime::init), the fourth part's (VNR_AMD_SMALL_SHARE_PARTS=4 / VNR_AMD_RENDER_HALVES=4) on first use.
   hipStream_t part_streams[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t part_stream(int part);   // part >= 1
   // streams the library owns beside those: a rank's communication stream, an out-of-core sampler's copy stream, the opt-in training side

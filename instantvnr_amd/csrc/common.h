@@ -76,12 +76,13 @@ struct Runtime {
   // process's streams round-robin onto four hardware queues, in creation order; a renderer that created streams of its own landed wherever
   // the count stood, and every fourth one on the queue of `stream` itself, where two ray parts then run one behind the other (round 5,
   // profiles/r05_stream_budget.txt).  With the pool the library owns at most 1 + 3 streams for rendering whatever comes and goes; parts 1 and 2
-  // are created together with `stream` (Runtime::init), the fourth part's (VNR_AMD_SMALL_SHARE_PARTS=4 / VNR_AMD_RENDER_HALVES=4) on first use.
+  // are created together with `stream` (Runtime::init), BEFORE any other stream of the library (a rank's communication stream, an out-of-core
+  // sampler's copy stream, the opt-in training side stream) and before whatever the application creates after vnrAmdInit: the three streams a
+  // frame runs on own three hardware queues, and a later stream shares a queue only with streams that are idle while a frame renders (measured
+  // with 0-3 idle extra streams: the 1/8 share 0.54-0.59 ms in every case).  The fourth part's stream (VNR_AMD_SMALL_SHARE_PARTS=4 /
+  // VNR_AMD_RENDER_HALVES=4) is created on first use.
   hipStream_t part_streams[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t part_stream(int part);   // part >= 1
-  // streams the library owns beside those: a rank's communication stream, an out-of-core sampler's copy stream, the opt-in training side
-  // stream.  The renderer deals a small share to three parts while at most one of them exists and to two otherwise (render_streaming).
-  int other_streams = 0;
   int n_cus = 256;
   size_t bytes_renderer = 0, bytes_network = 0;
   static Runtime& get();

@@ -662,7 +662,7 @@ void Dist::init_from_env()
 
 void Dist::finalize()
 {
-  if (comm_stream_) { (void)hipStreamSynchronize(comm_stream_); (void)hipStreamDestroy(comm_stream_); comm_stream_ = nullptr; --Runtime::get().other_streams; }
+  if (comm_stream_) { (void)hipStreamSynchronize(comm_stream_); (void)hipStreamDestroy(comm_stream_); comm_stream_ = nullptr; }
   transport_.reset();
   ctl_.reset();
   rank_ = 0; world_ = 1; local_rank_ = 0;
@@ -834,7 +834,6 @@ hipStream_t Dist::comm_stream()
   if (!comm_stream_) {
     if (!Runtime::get().ready()) Runtime::get().init(-1);
     VNR_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
-    ++Runtime::get().other_streams;
   }
   return comm_stream_;
 }

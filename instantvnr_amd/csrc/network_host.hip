@@ -261,7 +261,7 @@ Network::~Network()
 {
   live_networks().erase(this);
   for (hipEvent_t e : prof_events_) (void)hipEventDestroy(e);
-  if (side_stream_) { (void)hipStreamSynchronize(side_stream_); (void)hipStreamDestroy(side_stream_); (void)hipEventDestroy(ev_fork_); (void)hipEventDestroy(ev_join_); --Runtime::get().other_streams; }
+  if (side_stream_) { (void)hipStreamSynchronize(side_stream_); (void)hipStreamDestroy(side_stream_); (void)hipEventDestroy(ev_fork_); (void)hipEventDestroy(ev_join_); }
 }
 
 void Network::set_brick_mode(int mode)

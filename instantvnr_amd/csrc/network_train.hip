@@ -1058,7 +1058,6 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
   if (overlap) {
     if (!side_stream_) {
       VNR_HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
-      ++Runtime::get().other_streams;
       VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
       VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     }

@@ -198,7 +198,6 @@ OutOfCoreSampler::OutOfCoreSampler(const std::string& filename, vec3i dims, int 
   VNR_HIP_CHECK(hipHostMalloc((void**)&staging_, n_concurrent_ * block_bytes_, hipHostMallocDefault));
   VNR_HIP_CHECK(hipHostMalloc((void**)&staging_blocks_, n_concurrent_ * sizeof(OocBlock), hipHostMallocDefault));
   VNR_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  ++Runtime::get().other_streams;
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_sampled_, hipEventDisableTiming));
   VNR_HIP_CHECK(hipEventCreateWithFlags(&ev_copied_, hipEventDisableTiming));
 
@@ -214,7 +213,7 @@ OutOfCoreSampler::OutOfCoreSampler(const std::string& filename, vec3i dims, int 
 OutOfCoreSampler::~OutOfCoreSampler()
 {
   if (worker_.joinable()) worker_.join();
-  if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); --Runtime::get().other_streams; }
+  if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
   if (ev_sampled_) (void)hipEventDestroy(ev_sampled_);
   for (hipEvent_t e : throttle_) (void)hipEventDestroy(e);
   if (ev_copied_) (void)hipEventDestroy(ev_copied_);

@@ -845,7 +845,7 @@ Renderer::Renderer(std::shared_ptr<VolumeBase> volume) : volume_(std::move(volum
   if (const char* e = std::getenv("VNR_RM_N_ITERS")) { n_iters_ = std::max(1, std::min(48, std::atoi(e))); n_iters_fixed_ = true; }  // 2.5 KiB of LDS per iteration slot and block
   // streaming mode runs the rays as two halves on two streams (render_streaming); VNR_AMD_RENDER_HALVES=1: one stream
   if (const char* e = std::getenv("VNR_AMD_RENDER_HALVES")) { n_halves_ = std::max(1, std::min(kMaxParts, std::atoi(e))); n_halves_fixed_ = true; }
-  if (const char* e = std::getenv("VNR_AMD_SMALL_SHARE_PARTS")) { small_share_parts_ = std::max(1, std::min(kMaxParts, std::atoi(e))); small_share_parts_fixed_ = true; }
+  if (const char* e = std::getenv("VNR_AMD_SMALL_SHARE_PARTS")) small_share_parts_ = std::max(1, std::min(kMaxParts, std::atoi(e)));
   if (const char* e = std::getenv("VNR_AMD_TILE_W")) {  // ray tile shape (diagnostics): 8 -> 8x8, 16 -> 16x4, 32 -> 32x2, 64 -> 64x1
     const int w = std::atoi(e);
     tile_w_log2_ = w == 16 ? 4u : w == 32 ? 5u : w == 64 ? 6u : 3u;
@@ -1497,10 +1497,9 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
   const uint32_t row_items = p_all.tiles_per_row * 64u;
   const uint32_t R = p_all.n_local / row_items;  // local tile rows
   // a small share is bound by the length of the kernel chain of one part, not by throughput: more, shorter chains side by side
-  // (three parts + the library's stream + ONE more stream are the runtime's four hardware queues; a process in which the library itself owns
-  // two more -- a rank's communication stream and an out-of-core sampler's, say -- keeps a small share to two parts: 0.58 instead of 0.85 ms)
-  const int small_parts = (!small_share_parts_fixed_ && Runtime::get().other_streams > 1) ? std::min(small_share_parts_, 2) : small_share_parts_;
-  const int want = (!n_halves_fixed_ && p_all.n_local <= 262144u) ? small_parts : n_halves_;
+  // (three parts: the library's stream and the pool's two, which Runtime::init creates FIRST, so they own three of the runtime's four hardware
+  // queues whatever streams come later -- a rank's communication stream, an out-of-core sampler's, the application's: common.h)
+  const int want = (!n_halves_fixed_ && p_all.n_local <= 262144u) ? small_share_parts_ : n_halves_;
   const int H = (int)std::min<uint32_t>((uint32_t)want, std::max(R, 1u));
   const uint32_t P_total = p_all.n_local;
   const bool grad = pass_mode == M_GRADIENT;

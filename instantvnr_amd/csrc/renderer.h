@@ -150,7 +150,6 @@ private:
   // plus that one two parts share a queue and run one behind the other: 1/8 share 0.555 -> 0.794 ms, 1/4 share 1.02 -> 1.37 ms with ONE more
   // stream alive in the process, against 0.539 -> 0.558 and 1.03 -> 1.06 ms with three parts (profiles/r05_stream_budget.txt).
   int small_share_parts_ = 3;
-  bool small_share_parts_fixed_ = false;   // VNR_AMD_SMALL_SHARE_PARTS given
   uint32_t predicted_iterations_[2][kMaxParts] = {};   // [camera pass | shadow pass][half]
   // decoupled path (VNR_AMD_DECOUPLED): 0 never, 1 (default) for ray sets of at most 20 480 rays, 2 always.  Measured on shares of the bench
   // frame (profiles/r03_decoupled_share_sweeps.txt): 1/64 (16 384 rays) 0.203 against 0.248 ms coupled, 1/32 equal, 1/16 0.45 against 0.38,

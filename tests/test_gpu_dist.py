@@ -320,13 +320,14 @@ def test_a_rank_s_share_is_as_fast_with_a_fifth_stream_alive_in_the_process():
     queue each and every later one the least used queue; a small share's ray parts run one behind the other when two of them share a queue.
     With FOUR parts (rounds 2 - 4) one more stream in the process -- which every multi-GPU rank has: its communication stream -- made the 1/8
     share of the bench frame 45 % slower (0.55 -> 0.85 ms), i.e. the first 8-GPU run would have scaled 4.3 x where the one-GPU probe promised
-    6.5 x.  Three parts on streams created together with the library's own must not care: tools/share_probe.py as a rank runs it"""
+    6.5 x.  Three parts on streams created together with the library's own (Runtime::init) must not care how many streams come later -- one (a
+    rank's communication stream) or two (an out-of-core sampler's beside it): tools/share_probe.py as a rank runs it"""
     import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ms = {}
-    for extra in (0, 1, 0, 1):
+    for extra in (0, 1, 2, 0):
         env = dict(os.environ)
         env.update({"SHARE_PARTS": "8", "SHARE_FRAMES": "40", "SHARE_PIPELINED": "1", "SHARE_EXTRA_STREAMS": str(extra)})
         for k in ("VNR_AMD_SMALL_SHARE_PARTS", "VNR_RM_N_ITERS", "VNR_AMD_RENDER_HALVES", "GPU_MAX_HW_QUEUES"):
@@ -335,8 +336,8 @@ def test_a_rank_s_share_is_as_fast_with_a_fifth_stream_alive_in_the_process():
         m = re.search(r"share 1/8: ([0-9.]+) ms per frame", out.stdout)
         assert out.returncode == 0 and m, out.stdout[-1500:] + out.stderr[-1500:]
         ms.setdefault(extra, []).append(float(m.group(1)))
-    alone, beside = min(ms[0]), min(ms[1])
-    print(f"\n1/8 share of the bench frame: {alone:.3f} ms alone, {beside:.3f} ms with one more stream alive in the process")
+    alone, beside = min(ms[0]), max(ms[1] + ms[2])
+    print(f"\n1/8 share of the bench frame: {alone:.3f} ms alone, {ms[1][0]:.3f} / {ms[2][0]:.3f} ms with one / two more streams alive in the process")
     assert beside < 1.15 * alone, (ms, "two ray parts of the share ended up on one hardware queue")
     assert alone < 0.75, ms          # (0.54 - 0.57 measured; 0.85 was the broken state)
 

@@ -695,8 +695,11 @@ def main():
     bwd_bytes = Lv * 8 * F * 2 * 2 * B
     opt_bytes = n_params * (2 + 4 + 4 + 4) * 2
     step_bytes = fwd_bytes + bwd_bytes + opt_bytes
-    names = ["forward (fused encode + MLP, keeps activations)", "loss + MLP backward (MFMA)", "weight gradients (MFMA, block partials summed in order; since round 5 on a side stream beside the grid backward: only the fork is left in this phase)",
-             "grid backward (persistent packed-fp16 atomic scatter, beside it the dense levels' LDS scatter and the weight gradients; ends at the join)",
+    overlap = os.environ.get("VNR_AMD_TRAIN_OVERLAP", "0") not in ("", "0") and not ctx.distributed   # (opt-in: INTEGRATION.md 6)
+    names = ["forward (fused encode + MLP, keeps activations)", "loss + MLP backward (MFMA)",
+             "weight gradients (MFMA, block partials summed in order)" + ("; on a side stream beside the grid backward: only the fork is left in this phase" if overlap else ""),
+             ("grid backward (persistent packed-fp16 atomic scatter, beside it the dense levels' LDS scatter and the weight gradients; ends at the join)" if overlap else
+              "grid backward (the dense coarse levels' LDS scatter, then the hashed levels' packed-fp16 atomic scatter)"),
              "optimizer (Adam, fp32 master, fp16 gradient)" + (" incl. waiting for the gradient exchange" if ctx.distributed else "")]
     kernel_ms = [float(phase_ms[i]) for i in range(5)]
     step_kernel_ms = sum(kernel_ms)

@@ -103,7 +103,7 @@ def main():
                    "source_files": list(bench.EVAL_KERNEL_SOURCES), "source_sha16": bench.sources_sha16(bench.EVAL_KERNEL_SOURCES)},
                   open(os.path.join(out, "r05_mfma_pmc.json"), "w"), indent=1)
     at = passes.get("tcc_atomic", {})
-    # (the step's default form since round 5 runs the hashed levels through grid_backward_persistent_kernel; VNR_AMD_TRAIN_OVERLAP=0: grid_backward_kernel)
+    # (the step's default form runs the hashed levels through grid_backward_kernel; VNR_AMD_TRAIN_OVERLAP=1: grid_backward_persistent_kernel)
     gb = kernel(at, "grid_backward_persistent_kernel") or kernel(at, "grid_backward_kernelI") or kernel(at, "grid_backward_kernel<")
     gl = kernel(at, "grid_backward_lds_kernel")
     if gb.get("TCC_EA0_ATOMIC_sum"):

@@ -241,7 +241,9 @@ int    vnrAmdNeuralVolumeSetParamsFP16(vnrAmdVolume, const uint16_t* host_in, si
 int    vnrAmdNeuralVolumeTrainBegin(vnrAmdVolume);
 float* vnrAmdNeuralVolumeGradients(vnrAmdVolume, size_t* count);
 int    vnrAmdNeuralVolumeTrainEnd(vnrAmdVolume, float grad_scale, int fast_mode);
-/* forward + backward on a caller-provided batch (same kernels as TrainBegin, no sampling): fills Gradients() */
+/* forward + backward on a caller-provided batch (same kernels as TrainBegin, no sampling).  Like TrainBegin it ADDS the batch's gradients to
+ * the gradient buffer, which the optimizer step (TrainEnd) clears as it consumes it: one call per TrainEnd is a training step, several calls
+ * before one TrainEnd accumulate micro-batches (each scaled by 1 / its own batch size). */
 int    vnrAmdNeuralVolumeForwardBackward(vnrAmdVolume, size_t n, const float* d_coords, const float* d_targets);
 /* Inspection of the last ForwardBackward / TrainBegin (tests/diag/grad_hammer.py; passive: no other call depends on them).
  * TrainingBuffer: device pointer + size of 0 the fp16 gradient blob, 1 dL/dfeatures [n][padded_width] fp16, 2 the encoded features,

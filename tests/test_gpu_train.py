@@ -50,6 +50,27 @@ def test_gradients_match_numpy_restatement(oracle, shape, loss):
     assert np.all(last[1:] == 0) and np.any(last[0] != 0)
 
 
+def test_forward_backward_adds_to_the_gradient_blob_until_the_optimizer_step(oracle):
+    """include/vnr_amd.h: vnrAmdNeuralVolumeForwardBackward ADDS its batch's gradients to the blob and the optimizer step (TrainEnd) clears
+    what it consumed -- two calls before one TrainEnd are gradient accumulation over two micro-batches, not a repetition.  (Found the hard
+    way by a diagnostic that called it twice: tests/diag/mlp_grad_diag.py, round 5.)  The MLP part doubles exactly (block partials summed in
+    a fixed order, x 2 is exact in fp16); the grid part doubles up to the order of its fp16 atomics."""
+    vol, ocfg, params, n_mlp, info = small_model(oracle, 8, 2, 12, 4, 2, seed=3)
+    rng = np.random.default_rng(4)
+    coords = rng.uniform(0, 1, (777, 3)).astype(np.float32)
+    targets = rng.uniform(0, 1, 777).astype(np.float32)
+    once = api.neural_forward_backward(vol, coords, targets).astype(np.float64)
+    twice = api.neural_forward_backward(vol, coords, targets).astype(np.float64)
+    assert np.abs(once).max() > 0
+    assert np.array_equal(twice[:n_mlp], 2 * once[:n_mlp])
+    assert np.linalg.norm(twice[n_mlp:] - 2 * once[n_mlp:]) < 5e-3 * np.linalg.norm(2 * once[n_mlp:])
+    api.neural_train_end(vol)                                        # the step consumes and clears
+    again = api.neural_forward_backward(vol, coords, targets).astype(np.float64)
+    ref = T.training_gradients(ocfg, 64, 2, api.neural_get_params_fp16(vol).view(np.uint16), coords, targets, loss="L1")["grads"]
+    for sl in (slice(0, n_mlp), slice(n_mlp, None)):
+        assert np.linalg.norm(again[sl] - ref[sl]) < 3e-2 * np.linalg.norm(ref[sl])
+
+
 @pytest.mark.parametrize("shape", [(16, 2, 14, 4, 3, "Linear", "Hash", 1.4), (8, 8, 12, 4, 2, "Smoothstep", "Hash", 2.0), (12, 4, 10, 3, 2, "Linear", "Dense", 1.25),
                                    (16, 1, 11, 5, 2, "Linear", "Hash", 1.5), (5, 2, 19, 16, 1, "Linear", "Hash", 2.0)])
 def test_the_training_forward_s_features_are_the_encode_s_bit_for_bit(oracle, shape):

@@ -253,6 +253,12 @@ def choose_transport():
     if world <= 1 or os.environ.get("VNR_AMD_DIST_TRANSPORT"):
         return None, None
     import subprocess
+    # (the verdict files of the parents' agreement below: a file this rank left behind in a run that was killed must not speak for it now)
+    key = f"vnr_bench_probe_{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('VNR_BENCH_RUN_ID') or os.getppid()}"
+    rank = int(os.environ.get("RANK", "0"))
+    base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", key)
+    if os.path.exists(f"{base}_{rank}"):
+        os.remove(f"{base}_{rank}")
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
     # the probe is bounded tightly (a driver's own clock runs around this program): 60 s for the children to meet, 30 s per collective -> a
@@ -278,9 +284,6 @@ def choose_transport():
     # So the parents agree too, without any transport: one file per rank in /dev/shm (one node), keyed by the launcher's pid and port;
     # RCCL only if every rank's child said ok.
     # (the ranks of one run share their launcher's pid; a launcher that gives every rank a parent of its own sets VNR_BENCH_RUN_ID)
-    key = f"vnr_bench_probe_{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('VNR_BENCH_RUN_ID') or os.getppid()}"
-    rank = int(os.environ.get("RANK", "0"))
-    base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", key)
     with open(f"{base}_{rank}.tmp", "w") as f:
         f.write("ok" if ok else "failed")
     os.replace(f"{base}_{rank}.tmp", f"{base}_{rank}")
@@ -297,7 +300,15 @@ def choose_transport():
         probe["rccl"] = ("FAILED on another rank (" + ", ".join(f"rank {r}: {verdicts.get(r, 'no verdict')}" for r in range(world)) + "); this rank's child: " + said)[:600]
     ok = agreed
     import atexit
-    atexit.register(lambda: os.path.exists(f"{base}_{rank}") and os.remove(f"{base}_{rank}"))
+    t_decided = time.perf_counter()
+
+    def remove_verdict():
+        # the others poll every 50 ms: a process that ends right after deciding (a failed self-test, a test) must leave its verdict readable
+        # for them first; a bench run ends a minute later and does not wait here
+        time.sleep(max(0.0, 2.0 - (time.perf_counter() - t_decided)))
+        if os.path.exists(f"{base}_{rank}"):
+            os.remove(f"{base}_{rank}")
+    atexit.register(remove_verdict)
     if ok:
         return "rccl", probe
     probe["fallback"] = "shm: host-staged shared-memory transport (one node); the numbers of this line are NOT RCCL's"

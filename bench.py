@@ -775,7 +775,7 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{workload_name(a)}: {volume_desc}, HashGrid L={a.levels} F={a.features} "
                                f"T=2^{a.log2_hashmap_size} base 16 per_level_scale {pls:.4f} + {a.hidden_layers}x64 FullyFusedMLP, "
-                               f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading' if a.mode == 8 else 'sample streaming, single-shade heuristic: camera pass + shadow pass' if a.mode == 11 else 'path tracing: one launch with the network inside the tracking loop (VNR_AMD_IN_SHADER=0: sample streaming)' if a.mode in (14, 15) else 'in-shader ray marching mode: the streaming path unless VNR_AMD_IN_SHADER=1'}), sampling rate 1, N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24 (32 when a rank renders at most 196608 pixels)')}; {cache_text}",
+                               f"{a.fb}x{a.fb} rendering mode {a.mode} ({'sample streaming' if a.mode == 5 else 'sample streaming with gradient shading' if a.mode == 8 else 'sample streaming, single-shade heuristic: camera pass + shadow pass' if a.mode == 11 else 'path tracing: one launch with the network inside the tracking loop (VNR_AMD_IN_SHADER=0: sample streaming)' if a.mode in (14, 15) else 'in-shader ray marching mode: the streaming path unless VNR_AMD_IN_SHADER=1'}), sampling rate 1, N_ITERS {os.environ.get('VNR_RM_N_ITERS', '24 (32 when a rank renders at most 262144 pixels)')}; {cache_text}",
                    "volume": f"{a.size}^3", "framebuffer": f"{a.fb}x{a.fb}", "n_params": info["n_params"],
                    "tfn": f"256-entry ramp-with-bumps, seed 7, opacity scale {a.opacity_scale}",
                    "camera": cam, "train_steps": a.train_steps, "batch": 65536,

@@ -358,7 +358,7 @@ int  vnrAmdDistBroadcast(void* buf, size_t bytes, int root);
 int  vnrAmdDistSelfTest(double deadline_s, char* report, size_t report_size);
 /* Image tiles: the rank renders the 8-scanline tile rows r with r % world == rank into its slot of a [world][share] buffer;
  * vnrAmdRendererMapFrame (= vnrAmdRendererGatherFrame) all-gathers in place, de-interleaves and returns the WHOLE frame on
- * every rank, bit-identical to the unsharded frame rendered with the same batch size (VNR_RM_N_ITERS): a share of at most 196 608
+ * every rank, bit-identical to the unsharded frame rendered with the same batch size (VNR_RM_N_ITERS): a share of at most 262 144
  * pixels marches 32 samples per ray and iteration instead of 24 unless VNR_RM_N_ITERS pins it, and the batch size moves the last bit
  * of a few samples (0.2 % of the pixels, <= 4e-5; the same holds in the reference for its N_ITERS).  RenderPipelined: enqueue frame k, gather frame k - 1 meanwhile on the
  * communication stream, complete frame k, return the assembled frame k - 1 (NULL the first time); FlushPipeline returns the

@@ -1128,12 +1128,14 @@ void Renderer::render()
   p.tfn = tfn_.view();
   p.tfn_in_lds = ((size_t)p.tfn.n_colors * sizeof(vec4f) + (size_t)p.tfn.n_alphas * sizeof(float)) <= 24 * 1024 ? 1u : 0u;
   // A small SHARE of a frame (one rank of 8) is bound by the latency of the per-iteration kernel chain, not by throughput:
-  // fewer, longer iterations (tools/share_probe.py, 1/8 of the bench frame: 24 -> 0.995 ms, 32 -> 0.910 ms, 48 -> 0.905 ms).
+  // fewer, longer iterations (tools/share_probe.py, 1/8 of the bench frame: 24 -> 0.995 ms, 32 -> 0.910 ms, 48 -> 0.905 ms in round 1; round 5: 1/8 share
+  // 24 -> 0.592, 32 -> 0.536, 40 -> 0.578, 48 -> 0.61 ms; 1/4 share 24 -> 1.028, 32 -> 1.006 ms; 1/3 share 24 -> 1.323, 32 -> 1.338 ms: 32 up to a quarter
+  // of the bench frame, the same bound as the three ray parts of a small share).
   // Only for shares (distributed mode or a pixel interleave), so that an unsharded small framebuffer keeps the default; and the
   // batch size moves a few samples by an ulp (a ray interrupted inside a macrocell resumes at t_min + (t - t_min), as in the
   // reference), so a frame assembled from such shares equals the unsharded frame rendered with VNR_RM_N_ITERS=32 bit for bit and
   // the unsharded frame at the default 24 to ~4e-5 on 0.2 % of the pixels (tests/test_gpu_fullsize.py); VNR_RM_N_ITERS pins both.
-  p.n_iters = (!n_iters_fixed_ && (distributed_ || il_parts_ > 1) && p.n_local <= 196608u) ? 32 : n_iters_;
+  p.n_iters = (!n_iters_fixed_ && (distributed_ || il_parts_ > 1) && p.n_local <= 262144u) ? 32 : n_iters_;
   // A march block stages its batch in LDS: 8 bytes per sample, 10 with the depth sort's ranks (renderer.h march_ranks_: dropped by default
   // in round 5, the slot inside a bin is claimed from the bin's counter when the record is written; same frames)
   p.no_ranks = march_ranks_ ? 0u : 1u;

@@ -84,7 +84,7 @@ def scenario_frames(ctx, out):
 def scenario_frames_c4(ctx, out):
     """BASELINE C4 at its full size on every rank: 1024^2 frame of a 1024^3 volume, L = 16 / F = 2 / T = 2^22 hash grid + 3 x 64 MLP with its
     de-hashed image (finest level beyond 4 GiB): the frame assembled from the ranks' pipelined shares equals the unsharded frame, bit for bit
-    (N_ITERS pinned by the caller: a share of at most 196 608 pixels would otherwise march 32 samples per iteration)"""
+    (N_ITERS pinned by the caller: a share of at most 262 144 pixels would otherwise march 32 samples per iteration)"""
     L = lib()
     dims = (1024, 1024, 1024)
     sv = api.vnrCreateSimpleVolumePerlin(dims, seed=42, octaves=4, base_frequency=6.0)
@@ -149,7 +149,7 @@ def scenario_train(ctx, out):
 
 
 def scenario_frames_unpinned(ctx, out):
-    """what a rank of the driver's 8-GPU run executes: VNR_RM_N_ITERS NOT set, a share of at most 196 608 pixels, hence 32 samples per ray
+    """what a rank of the driver's 8-GPU run executes: VNR_RM_N_ITERS NOT set, a share of at most 262 144 pixels, hence 32 samples per ray
     and iteration, 4 ray parts and the packing fused into the evaluation kernel (render.hip Renderer::render / render_streaming /
     launch_tail).  The frame assembled from such shares must equal, bit for bit, the unsharded frame rendered with the batch size
     pinned to 32; and differ from the unsharded default (24) by no more than the resume rounding."""

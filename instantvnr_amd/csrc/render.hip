@@ -1501,7 +1501,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
   // a small share is bound by the length of the kernel chain of one part, not by throughput: more, shorter chains side by side
   // (three parts: the library's stream and the pool's two, which Runtime::init creates FIRST, so they own three of the runtime's four hardware
   // queues whatever streams come later -- a rank's communication stream, an out-of-core sampler's, the application's: common.h)
-  const int want = (!n_halves_fixed_ && p_all.n_local <= 262144u) ? small_share_parts_ : n_halves_;
+  const int want = (!n_halves_fixed_ && p_all.n_local <= 524288u) ? small_share_parts_ : n_halves_;   // (half the bench frame and less: renderer.h)
   const int H = (int)std::min<uint32_t>((uint32_t)want, std::max(R, 1u));
   const uint32_t P_total = p_all.n_local;
   const bool grad = pass_mode == M_GRADIENT;

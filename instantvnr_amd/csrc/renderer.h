@@ -144,7 +144,8 @@ private:
   static constexpr int kMaxParts = 4;
   int n_halves_ = 2;  // streaming mode: rays dealt to n parts on n streams (march of one overlaps inference of another)
   bool n_halves_fixed_ = false;
-  // parts of a share of at most 262 144 pixels (a quarter of a 1024 x 1024 frame): with pipelined frames several short chains side by side beat 2
+  // parts of a share of at most 524 288 pixels (half of a 1024 x 1024 frame; a quarter until late round 5: three parts instead of two are worth 1.9 % on the
+  // 1/2 and on the 1/3 share, 1.935 -> 1.899 and 1.345 -> 1.319 ms, and cost the whole frame 0.4 %): with pipelined frames several short chains side by side beat 2
   // (round 2: 1/4 share 1.17 -> 1.13 ms, 1/8 share 0.66 -> 0.65 ms; whole frames: no difference).  THREE since round 5, not four: the runtime maps
   // a process's HIP streams onto four hardware queues, a rank of a multi-GPU run also owns a communication stream, and with four part streams
   // plus that one two parts share a queue and run one behind the other: 1/8 share 0.555 -> 0.794 ms, 1/4 share 1.02 -> 1.37 ms with ONE more

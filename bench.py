@@ -284,6 +284,15 @@ def choose_transport():
     # So the parents agree too, without any transport: one file per rank in /dev/shm (one node), keyed by the launcher's pid and port;
     # RCCL only if every rank's child said ok.
     # (the ranks of one run share their launcher's pid; a launcher that gives every rank a parent of its own sets VNR_BENCH_RUN_ID)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world < world:
+        # more than one node: the verdict files are visible to this node's ranks only.  The children have agreed among themselves
+        # over the control plane, which spans the nodes; a child killed after that agreement is the case left open here.
+        if ok:
+            return "rccl", probe
+        probe["fallback"] = "none: the host-staged transport is for one node; this run has ranks on several"
+        print(f"[bench] rank {rank}: RCCL probe failed on a multi-node run ({said[:300]})", file=sys.stderr, flush=True)
+        sys.exit(3)
     with open(f"{base}_{rank}.tmp", "w") as f:
         f.write("ok" if ok else "failed")
     os.replace(f"{base}_{rank}.tmp", f"{base}_{rank}")
@@ -316,10 +325,102 @@ def choose_transport():
     return "shm", probe
 
 
+def visible_gpu_count():
+    """how many GPUs this process could open, WITHOUT a HIP call (the launching parent must never touch the GPU): the KFD topology's nodes
+    with SIMDs, cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the topology cannot be read."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            n = min(n, len([x for x in os.environ[var].split(",") if x.strip()]))
+    return n
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: THIS process becomes the launcher.  It starts N fresh copies of
+    itself (fork + exec of a process that has not touched the GPU and never will), one per rank, with the environment torch.distributed.run
+    would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), forwards rank 0's ONE JSON line, and exits non-zero as soon
+    as any rank does (the others are ended).  A bare `--gpus 8` can therefore not be mistaken for a one-GPU run."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    n = a.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                "VNR_BENCH_RUN_ID": f"self{os.getpid()}", "VNR_BENCH_LAUNCHED_BY": "bench.py", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    devices = visible_gpu_count()
+    if devices is not None and devices < n and not env.get("VNR_AMD_DIST_TRANSPORT"):
+        # RCCL refuses two ranks on one device: no point in probing it.  The line then says `strong-over-shm (NOT an RCCL measurement)`.
+        print(f"[bench] --gpus {n} on a box with {devices} visible GPU(s): ranks share devices (rank % {max(devices, 1)}) and exchange over the "
+              "host-staged shared-memory transport; this is a rehearsal of the code path, NOT an N-GPU measurement", file=sys.stderr, flush=True)
+        env["VNR_AMD_DIST_TRANSPORT"] = "shm"
+        env["VNR_BENCH_TRANSPORT_REASON"] = f"{n} ranks on {devices} visible GPU(s)"
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for rank in range(n):
+        e = dict(env)
+        e.update({"RANK": str(rank), "LOCAL_RANK": str(rank)})
+        procs.append(subprocess.Popen(argv, env=e, stdout=subprocess.PIPE, text=True))
+
+    def end_all(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            signal.signal(sig, lambda *_: (end_all(), os._exit(130)))
+
+    def forward(rank, p):   # rank 0's stdout is this program's stdout; what another rank prints goes to stderr, labelled
+        for line in p.stdout:
+            if rank == 0:
+                sys.stdout.write(line); sys.stdout.flush()
+            else:
+                sys.stderr.write(f"[rank {rank}] {line}"); sys.stderr.flush()
+    threads = [threading.Thread(target=forward, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                print(f"[bench] rank {r} of {n} exited with code {code}; ending the other ranks", file=sys.stderr, flush=True)
+                time.sleep(2.0)   # the ranks agree on a failed self-test among themselves: let them say so before they are ended
+                end_all()
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    sys.exit(rc)
+
+
 def main():
     a = parse()
     if a.probe_collectives:
         probe_collectives_child()
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            launch_ranks(a)        # does not return
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        # never a line whose n_gpus is not what was asked for
+        print(f"[bench] --gpus {a.gpus} but the launcher's WORLD_SIZE is {os.environ['WORLD_SIZE']}: refusing to measure something else than was asked for "
+              "(start one process per GPU, or start `python bench.py --gpus N` bare and it starts its ranks itself)", file=sys.stderr, flush=True)
+        sys.exit(2)
     if os.environ.get("VNR_BENCH_DUMP_AFTER"):  # diagnostics: where does a run that hangs under the profiler stand?
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["VNR_BENCH_DUMP_AFTER"]), exit=False, file=sys.stderr)
@@ -327,9 +428,9 @@ def main():
     os.environ.setdefault("VNR_AMD_DIST_STEADY_TIMEOUT", "1800")
     transport, transport_probe = choose_transport()
     ctx = dist.init_from_env(transport=transport)
-    if a.gpus != ctx.world:
-        if ctx.rank == 0:
-            print(f"warning: --gpus {a.gpus} but WORLD_SIZE={ctx.world}; using {ctx.world}", file=sys.stderr)
+    if a.gpus != ctx.world:   # (cannot happen after the checks above; a line with another n_gpus than was asked for must not exist)
+        print(f"[bench] rank {ctx.rank}: --gpus {a.gpus} but the process group has {ctx.world} rank(s)", file=sys.stderr, flush=True)
+        os._exit(2)
     L = lib()
     dims = (a.size, a.size, a.size)
     pls = a.per_level_scale if a.per_level_scale > 0 else float(np.exp(np.log(a.size / 16.0) / max(a.levels - 1, 1)))
@@ -804,8 +905,10 @@ def main():
     if ctx.distributed:
         # did RCCL see N ranks?  Two keys beside n_gpus answer it
         out["transport"] = ("rccl" if ctx.transport == "rccl" else
-                            f"{ctx.transport}-fallback (the RCCL probe failed: transport_probe)" if transport_probe is not None else f"{ctx.transport} (chosen by VNR_AMD_DIST_TRANSPORT)")
+                            f"{ctx.transport}-fallback (the RCCL probe failed: transport_probe)" if transport_probe is not None else f"{ctx.transport} (chosen by VNR_AMD_DIST_TRANSPORT" + (": " + os.environ["VNR_BENCH_TRANSPORT_REASON"] if os.environ.get("VNR_BENCH_TRANSPORT_REASON") else "") + ")")
         out["rccl_ranks_seen"] = int(L.vnrAmdDistRcclRanksSeen())
+        out["launcher"] = ("bench.py itself (bare `--gpus N`: a parent that never touches the GPU started one fresh process per rank)"
+                           if os.environ.get("VNR_BENCH_LAUNCHED_BY") == "bench.py" else "external (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* came with the environment)")
     if per_rank is not None:
         out["per_rank"] = per_rank
         out["collective_self_test"] = self_test

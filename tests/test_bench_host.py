@@ -85,3 +85,84 @@ def test_the_parents_of_the_probe_children_agree_on_one_transport(verdicts, tmp_
                 assert "FAILED on another rank" in out[rank], out
     for rank in range(3):                   # every rank removes its file when it exits
         assert not os.path.exists(f"{base}_{rank}")
+
+
+def _run_bench(args, env_extra, timeout=180):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "VNR_AMD_DIST_TRANSPORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_a_launcher_world_that_is_not_what_gpus_asks_for_is_refused():
+    """`--gpus 8` inside a one-rank environment (or `--gpus 1` inside an eight-rank one) must not print a line at all: rc 2, before the
+    library is opened (a bare `--gpus 8` used to render on one GPU and print n_gpus 1)"""
+    for gpus, world in ((8, "1"), (1, "8"), (4, "2")):
+        out = _run_bench(["--gpus", str(gpus), "--steps", "2"], {"WORLD_SIZE": world, "RANK": "0"})
+        assert out.returncode == 2 and "refusing" in out.stderr and not out.stdout.strip(), (gpus, world, out.stderr[-500:])
+
+
+_LAUNCH = """
+import importlib.util, json, os, sys
+if os.environ.get("RANK") is not None:       # a rank started by the launcher under test: say who I am and how I was started
+    rank = int(os.environ["RANK"])
+    rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "VNR_BENCH_RUN_ID")}
+    rec["argv"] = sys.argv[1:]
+    print(json.dumps(rec), flush=True)
+    sys.exit(int(os.environ.get("FAKE_FAIL_RANK", "-1")) == rank and 7 or 0)
+"""
+
+
+def test_bare_gpus_n_starts_n_ranks_with_a_launcher_environment(bench, tmp_path, monkeypatch, capfd):
+    """the launching half of `python bench.py --gpus N` without a GPU: N children with RANK 0..N-1, one WORLD_SIZE / MASTER_PORT / run id for
+    all, the arguments passed through; rank 0's stdout is the program's stdout, the other ranks' goes to stderr; the exit code is 0 only if
+    every rank's is"""
+    import json
+    fake = tmp_path / "fake_rank.py"
+    fake.write_text(_LAUNCH)
+    monkeypatch.setattr(bench, "__file__", str(fake))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "4"])
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 8)
+
+    class A:
+        gpus = 3
+    import signal
+    handlers = {s: signal.getsignal(s) for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    request_restore = lambda: [signal.signal(s, h) for s, h in handlers.items()]   # (the launcher ends its ranks when it is signalled)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(A)
+    request_restore()
+    assert e.value.code == 0
+    out, err = capfd.readouterr()
+    r0 = json.loads(out.strip())
+    assert r0["RANK"] == "0" and r0["WORLD_SIZE"] == "3" and r0["LOCAL_WORLD_SIZE"] == "3" and r0["MASTER_ADDR"] == "127.0.0.1" and r0["argv"] == ["--gpus", "3", "--steps", "4"]
+    others = [json.loads(l.split("] ", 1)[1]) for l in err.splitlines() if l.startswith("[rank ")]
+    assert sorted(o["RANK"] for o in others) == ["1", "2"] and all(o["LOCAL_RANK"] == o["RANK"] for o in others)
+    assert {o["MASTER_PORT"] for o in others} == {r0["MASTER_PORT"]} and {o["VNR_BENCH_RUN_ID"] for o in others} == {r0["VNR_BENCH_RUN_ID"]}
+    # one rank fails -> the launcher's exit code is that rank's
+    monkeypatch.setenv("FAKE_FAIL_RANK", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(A)
+    request_restore()
+    assert e.value.code == 7
+    # fewer devices than ranks: the ranks are told to share devices over the host-staged transport, and the launcher says so
+    monkeypatch.delenv("FAKE_FAIL_RANK")
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 1)
+    capfd.readouterr()
+    with pytest.raises(SystemExit):
+        bench.launch_ranks(A)
+    request_restore()
+    out, err = capfd.readouterr()
+    assert "NOT an N-GPU measurement" in err
+
+
+def test_bare_gpus_2_without_a_device_fails_loudly_and_prints_no_line():
+    """the whole program, bare, on a machine without a GPU: both ranks end with the library's error, the launcher with a non-zero code and
+    no JSON line (never a one-GPU line for a two-GPU question)"""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"VNR_AMD_DIST_TIMEOUT": "20"})
+    assert out.returncode != 0 and not any(line.startswith("{") for line in out.stdout.splitlines()), out.stdout[-500:]
+    assert "exited with code" in out.stderr

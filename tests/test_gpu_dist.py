@@ -315,6 +315,30 @@ def test_bench_probes_rccl_in_a_child_and_goes_on_over_shared_memory_when_it_fai
     assert "all-gather (in place" in d["collective_self_test"]          # the run's own self-test, over the transport it uses
 
 
+def test_bare_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher environment must measure two ranks, not print n_gpus 1 for a
+    one-GPU run.  bench.py becomes the launcher (a parent that never touches the GPU starts two fresh copies of itself with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*); on this one-GPU box it sees fewer devices than ranks, tells the ranks to share the device over the host-staged
+    transport and says so: ONE line on stdout, n_gpus 2, not called an RCCL curve."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "VNR_AMD_DIST_TRANSPORT", "VNR_RM_N_ITERS")}
+    env["VNR_AMD_DIST_TIMEOUT"] = "120"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--size", "64", "--fb", "256", "--levels", "6",
+                          "--log2-hashmap-size", "14", "--hidden-layers", "2", "--train-steps", "120", "--no-psnr", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["launcher"].startswith("bench.py")
+    assert d["transport"].startswith("shm") and "2 ranks on 1 visible GPU" in d["transport"] and "NOT an RCCL" in d["scaling"] and d["rccl_ranks_seen"] == 0
+    assert len(d["per_rank"]["share_ms"]) == 2 and "NOT an N-GPU measurement" in out.stderr
+    # and a launcher environment that contradicts --gpus is refused, on a GPU box too
+    env.update({"WORLD_SIZE": "1", "RANK": "0"})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and not out.stdout.strip()
+
+
 def test_a_rank_s_share_is_as_fast_with_a_fifth_stream_alive_in_the_process():
     """the stream budget (profiles/r05_stream_budget.txt): the HIP runtime gives the first four streams of a process a hardware
     queue each and every later one the least used queue; a small share's ray parts run one behind the other when two of them share a queue.
@@ -338,8 +362,11 @@ def test_a_rank_s_share_is_as_fast_with_a_fifth_stream_alive_in_the_process():
         ms.setdefault(extra, []).append(float(m.group(1)))
     alone, beside = min(ms[0]), max(ms[1] + ms[2])
     print(f"\n1/8 share of the bench frame: {alone:.3f} ms alone, {ms[1][0]:.3f} / {ms[2][0]:.3f} ms with one / two more streams alive in the process")
-    assert beside < 1.15 * alone, (ms, "two ray parts of the share ended up on one hardware queue")
-    assert alone < 0.75, ms          # (0.54 - 0.57 measured; 0.85 was the broken state)
+    # wall-clock bars belong to a perf run, not to the correctness suite (a busy or different GPU fails them without a defect: ADVICE r05):
+    # the figures are always printed, the bars hold with VNR_TEST_TIMING=1 (the builder's own GPU runs set it)
+    if os.environ.get("VNR_TEST_TIMING") == "1":
+        assert beside < 1.15 * alone, (ms, "two ray parts of the share ended up on one hardware queue")
+        assert alone < 0.75, ms          # (0.54 - 0.57 measured; 0.85 was the broken state)
 
 
 # ------------------------------------------------------------------------------------------------ asynchronous frames

@@ -321,6 +321,10 @@ int  vnrAmdRendererSetInShaderKernel(vnrAmdRenderer, int mode);
 /* diagnostics: device pointers to the compacted sample queue ([n][3] fp32) and the counter block, plus the
  * per-iteration duration (ms) of the sample-evaluation kernel in the last profiled frame */
 int  vnrAmdRendererDebugQueues(vnrAmdRenderer, const float** d_coords, const uint32_t** d_counters, float* iteration_ms, int max_iterations);
+/* diagnostics: the schedule the last sample-streaming frame ran with: out = {samples per ray and iteration (N_ITERS, method_raymarching.cu:30-40),
+ * ray parts, 1 = survivors packed inside the evaluation kernel, 1 = decoupled walk / evaluate / compose loop}.  Tests use it to know WHICH path
+ * they compared with the oracle (a rank's small share runs another schedule than a whole frame). */
+int  vnrAmdRendererDebugSchedule(vnrAmdRenderer, int out[4]);
 void vnrAmdReleaseRenderer(vnrAmdRenderer);
 
 /* ---- multi-GPU: one process per GPU (new work; the reference is single-GPU, its only device-selection code is

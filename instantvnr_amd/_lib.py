@@ -183,6 +183,7 @@ def lib():
     sig("vnrAmdRendererSetAsync", I, P, I)
     sig("vnrAmdRendererSetInShaderKernel", I, P, I)
     sig("vnrAmdRendererDebugQueues", I, P, C.POINTER(P), C.POINTER(P), FP, I)
+    sig("vnrAmdRendererDebugSchedule", I, P, IP)
     sig("vnrAmdReleaseRenderer", None, P)
     sig("vnrAmdDistGetUniqueId", I, P)
     sig("vnrAmdDistInit", I, I, I, I, P, C.c_char_p, C.c_char_p)

@@ -567,6 +567,13 @@ def vnrRendererGetFrameStats(r):
     return {k: getattr(s, k) for k, _ in s._fields_}
 
 
+def renderer_schedule(r):
+    """which schedule the last sample-streaming frame ran (vnrAmdRendererDebugSchedule)"""
+    out = (C.c_int * 4)()
+    check(lib().vnrAmdRendererDebugSchedule(r.h, out))
+    return {"n_iters": out[0], "n_parts": out[1], "fused_pack": bool(out[2]), "decoupled": bool(out[3])}
+
+
 def neural_brick_image(v):
     """state of the de-hashed inference copy of the hashed levels (csrc/network.h)"""
     u, b, ms = C.c_int(), C.c_size_t(), C.c_float()

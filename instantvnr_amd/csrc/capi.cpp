@@ -842,6 +842,15 @@ int vnrAmdRendererDebugQueues(vnrAmdRenderer r, const float** d_coords, const ui
     for (int i = 0; i < max_iterations; ++i) iteration_ms[i] = i < (int)v.size() ? v[i] : 0.0f;
   });
 }
+int vnrAmdRendererDebugSchedule(vnrAmdRenderer r, int out[4])
+{
+  return guarded([&]() {
+    VNR_REN(r);
+    if (!out) throw std::runtime_error("null output");
+    const int* v = r->r->debug_schedule();
+    for (int i = 0; i < 4; ++i) out[i] = v[i];
+  });
+}
 int vnrAmdRendererSetProfiling(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_profiling(e != 0); }); }
 int vnrAmdRendererSetAsync(vnrAmdRenderer r, int e) { return guarded([&]() { VNR_REN(r); r->r->set_async(e != 0); }); }
 int vnrAmdRendererSetInShaderKernel(vnrAmdRenderer r, int m) { return guarded([&]() { VNR_REN(r); r->r->set_in_shader_kernel(m); }); }

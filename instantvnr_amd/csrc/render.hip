@@ -1473,6 +1473,7 @@ void Renderer::launch_tail(StreamingFrame& f, int h, uint32_t it, hipStream_t s_
       gt_sample_kernel<<<blocks, 256, 0, s_it>>>(c + C_SAMPLES0 + parity, hf.p.volume, hf.p.vol_dims, hf.queue, (float*)hf.vd[parity]);
     }
     if (profiling_) VNR_HIP_CHECK(hipEventRecord(events_[f.slot][h][2 * it + 1], s_it));
+    last_schedule_[2] = packed ? 1 : 0;
     if (!packed) {
       // 1024-thread blocks need 4 free wave slots on every SIMD of one CU at once, which the other half's evaluation kernel
       // rarely leaves: a small share (where the wait shows) packs with 256-thread blocks
@@ -1608,6 +1609,7 @@ void Renderer::render_streaming(const RenderParams& p_all, int pass_mode, bool d
       while (events_[slot][h].size() < 2 * max_iterations) { hipEvent_t e; VNR_HIP_CHECK(hipEventCreate(&e)); events_[slot][h].push_back(e); }
   }
 
+  last_schedule_[0] = p_all.n_iters; last_schedule_[1] = H; last_schedule_[2] = 0; last_schedule_[3] = 0;
   f.H = H; f.pass_mode = pass_mode; f.grad = grad; f.ssh = ssh; f.nv = nv; f.shmem = shmem; f.shmem_compose = shmem_compose;
   f.max_iterations = max_iterations; f.predicted = predicted; f.p_all = p_all;
   // phase 0 (asynchronous frames with the frame before still pending): the HEAD of this frame, i.e. iteration 0 of every part:
@@ -1752,6 +1754,7 @@ void Renderer::render_decoupled(const RenderParams& p_all, bool defer)
   const int H = (int)std::min<uint32_t>((uint32_t)decoupled_parts_, std::max(R, 1u));
   const uint32_t P_total = p_all.n_local;
   const int A = decoupled_ahead_, RING = A + 1;
+  last_schedule_[0] = p_all.n_iters; last_schedule_[1] = H; last_schedule_[2] = 0; last_schedule_[3] = 1;
   NeuralVolume* nv = volume_->is_network() ? static_cast<NeuralVolume*>(volume_.get()) : nullptr;
   if (nv && !nv->network().valid()) throw std::runtime_error("neural volume has no valid network");
   if (!nv && !p_all.volume) throw std::runtime_error("this volume has no resident data to sample");

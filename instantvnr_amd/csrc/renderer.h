@@ -57,6 +57,8 @@ public:
   const float* debug_coords() { finish_pending(); return (const float*)queue_.ptr; }  // 16-byte records {x, y, z, slot}
   const uint32_t* debug_counters() { finish_pending(); return counters_.ptr; }
   const std::vector<float>& debug_iteration_ms() { finish_pending(); return iter_ms_; }
+  // which schedule the last streaming frame ran: {samples per ray and iteration, ray parts, 1 = packing fused into the evaluation kernel, 1 = decoupled loop}
+  const int* debug_schedule() { finish_pending(); return last_schedule_; }
   // rank `part` of `parts` renders the pixel blocks b with b % parts == part (block = `block` consecutive pixels)
   void set_pixel_interleave(uint32_t block, uint32_t parts, uint32_t part)
   {
@@ -202,6 +204,7 @@ private:
   std::vector<hipEvent_t> events_[2][kMaxParts];  // per slot and half: (before, after) the evaluation kernel of each iteration
   FrameStats stats_, completed_stats_;
   std::vector<float> iter_ms_;
+  int last_schedule_[4] = {0, 0, 0, 0};
 };
 
 }  // namespace vnr

@@ -50,7 +50,8 @@ class Scene(C.Structure):
                 ("mc_dims", C.c_int * 3), ("mc_spacings", C.c_float * 3),
                 ("mc_max_opacity", C.POINTER(C.c_float)),
                 ("tfn", Tfn), ("pixel_lo", C.c_uint32), ("pixel_hi", C.c_uint32),
-                ("shading_mode", C.c_int), ("light_dir", C.c_float * 3), ("density_scale", C.c_float)]
+                ("shading_mode", C.c_int), ("light_dir", C.c_float * 3), ("density_scale", C.c_float),
+                ("il_block", C.c_uint32), ("il_parts", C.c_uint32), ("il_part", C.c_uint32)]
 
 
 class RenderStats(C.Structure):
@@ -326,7 +327,7 @@ def default_transform(dims):
 class SceneHolder:
     def __init__(self, width, height, vol_dims, tfn, mc_max_opacity, cam_from, cam_at=(0, 0, 0), cam_up=(0, 1, 0),
                  fovy=60.0, frame_index=1, sampling_rate=1.0, bbox=((0, 0, 0), (1, 1, 1)), xfm=None,
-                 pixel_range=None, shading_mode=0, light_dir=None, density_scale=1.0):
+                 pixel_range=None, shading_mode=0, light_dir=None, density_scale=1.0, interleave=None):
         """shading_mode: 0 NO_SHADING (rendering modes 4 / 5), 1 GRADIENT_SHADING (modes 7 / 8).
         light_dir: LaunchParams::light_directional_dir; default = the reference's (0.7, 0.9, 0.4) after the flip of
         renderer.cpp:98-101 (negated when it points along the view direction)."""
@@ -352,6 +353,8 @@ class SceneHolder:
         s.tfn = tfn.c
         pr = pixel_range or (0, width * height)
         s.pixel_lo, s.pixel_hi = pr
+        # interleave = (block, parts, part): a rank's share of a tile-sharded frame (streaming marcher only), global pixel indices kept
+        s.il_block, s.il_parts, s.il_part = interleave or (0, 0, 0)
         s.shading_mode = int(shading_mode)
         s.density_scale = float(density_scale)
         s.light_dir[:] = [float(v) for v in (flipped_light_dir(cam_from, cam_at) if light_dir is None else light_dir)]

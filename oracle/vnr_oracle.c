@@ -1117,6 +1117,7 @@ static void streaming_pass(const vnro_scene* s, int pass, int n_iters, vnro_valu
     ray_t ray;
     float jitter;
     int want = 1;
+    if (s->il_parts > 1 && s->il_block > 0 && (i / s->il_block) % s->il_parts != s->il_part) continue;   /* another rank's pixel */
     if (pass == 3) {
       ray.org = px->org[i]; ray.dir = ldir;
       jitter = px->jitter[i];

@@ -154,6 +154,10 @@ typedef struct {
                         * 2 = SINGLE_SHADE_HEURISTIC (modes 10 / 11; :455-484 monolithic, :789-833, 877-900 streaming + shadow pass) */
   float light_dir[3];  /* LaunchParams::light_directional_dir (instantvnr_types.h:148) AFTER the flip of renderer.cpp:98-101 */
   float density_scale; /* DeviceVolume::density_scale (vnrRendererSetVolumeDensityScale); path tracing only; 0 is read as 1 */
+  /* a rank's share of a tile-sharded frame (not in the reference, which is single-GPU): with il_parts > 1 only pixels whose block
+   * (index / il_block) % il_parts == il_part are rendered.  Pixels keep their GLOBAL index (random sequence, method_raymarching.cu:851), so a
+   * share is the same rays as in the whole frame; what changes is which rays share an iteration count.  Streaming marcher only. */
+  uint32_t il_block, il_parts, il_part;
 } vnro_scene;
 
 /* shade_scivis_light (core/renderer/raytracing.h:214-246) with mat_gradient_shading {.6, .9, .4, 40} and

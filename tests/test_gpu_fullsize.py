@@ -161,14 +161,15 @@ def c4_scene():
     return {"nv": nv, "sv": sv, "tfn": tfn, "camera": camera, "cam": cam, "colors": colors, "alphas": alphas}
 
 
-@pytest.mark.parametrize("n_iters", [16, 24])
+@pytest.mark.parametrize("n_iters", [16, 24, 32])
 def test_a_band_of_the_c4_frame_equals_the_oracle(oracle, c4_scene, monkeypatch, n_iters):
     """the frame bench.py times (1024^2 of the 1024^3 volume, trained L16 F2 T2^22 + 3x64 model, de-hashed image in use), 16 scanlines
     through its middle against the oracle's streaming marcher (method_raymarching.cu:931-958 restated) driven by the oracle's network
     on all host threads: the same rays hit, the same number of iterations, the same samples up to saturation ties, and the pixels within
     1e-3 (PSNR > 90 dB); with the library's own network values in the oracle's marcher, within 1e-5 (PSNR > 120 dB).
-    Both at the reference's batch size (N_ITERS 16, method_raymarching.cu:30-40) and at the one bench.py runs (24), and rendered the way
-    bench.py renders: through vnrAmdRendererRenderPipelined (frame 1 is completed while the head of frame 2 is already enqueued)."""
+    At the reference's batch size (N_ITERS 16, method_raymarching.cu:30-40), at the one bench.py runs (24) and at the one a rank's small share
+    takes (32), and rendered the way bench.py renders: through vnrAmdRendererRenderPipelined (frame 1 is completed while the head of frame 2 is
+    already enqueued).  (A band of 16 384 rays runs the decoupled loop: renderer.h decoupled_mode_; the share test below runs the coupled one.)"""
     from instantvnr_amd import dist
     monkeypatch.setenv("VNR_RM_N_ITERS", str(n_iters))    # read when a renderer is created
     nv = c4_scene["nv"]
@@ -211,6 +212,7 @@ def test_a_band_of_the_c4_frame_equals_the_oracle(oracle, c4_scene, monkeypatch,
           f"iterations {st['n_iterations']}, samples {st['n_samples']} (oracle {ost['n_samples']}), PSNR {psnr:.1f} dB, max |err| {err.max():.4f}")
     assert ost["n_rays_hit"] == st["n_rays_hit"] and ost["n_iterations"] == st["n_iterations"]
     assert abs(ost["n_samples"] - st["n_samples"]) <= 0.002 * ost["n_samples"]
+    assert api.renderer_schedule(r)["n_iters"] == n_iters
     assert (ref[:, 3] > 0).mean() > 0.4
     assert psnr > 90.0, psnr           # measured 113.9 dB, max 1.0e-4 at 16 (round 2's bar for neural frames, 45 dB / 0.05, was set on random parameters)
     assert err.max() < 1e-3
@@ -222,6 +224,68 @@ def test_a_band_of_the_c4_frame_equals_the_oracle(oracle, c4_scene, monkeypatch,
     print(f"   compositor alone (oracle marcher on the library's network values): PSNR {psnr2:.1f} dB, max |err| {err2.max():.2e}, samples {ost2['n_samples']}")
     assert ost2["n_rays_hit"] == st["n_rays_hit"] and ost2["n_iterations"] == st["n_iterations"]
     assert psnr2 > 120.0 and err2.max() < 1e-5, (psnr2, float(err2.max()))   # measured 145.0 dB, max 5.4e-7 at 16
+
+
+@pytest.mark.parametrize("part", [3])
+def test_a_rank_s_share_of_the_c4_frame_equals_the_oracle(oracle, c4_scene, monkeypatch, part):
+    """the code path a rank of the 8-GPU run executes, against the oracle and not against the library's own frame.
+    VNR_RM_N_ITERS is NOT set (the suite pins 16: tests/conftest.py), the renderer gets the interleaved 1/8 share of the bench frame
+    (131 072 pixels in 8-scanline tile rows, global pixel indices kept), so it marches 32 samples per ray and iteration on three ray parts with
+    the survivors' packing fused into the evaluation kernel (render.hip Renderer::render / render_streaming / launch_tail) -- asserted from the
+    library's own record of the schedule.  The oracle renders the same pixel set with the reference's loop (method_raymarching.cu:931-958; batch
+    size :30-40 set to 32; resume rule :555-600) driven by the oracle's network.  Same bars as the band test: rays hit and iterations equal, samples
+    within 0.2 %, PSNR > 90 dB / 1e-3; with the library's network values in the oracle's marcher PSNR > 120 dB / 1e-5."""
+    import time
+    monkeypatch.delenv("VNR_RM_N_ITERS", raising=False)
+    for k in ("VNR_AMD_SMALL_SHARE_PARTS", "VNR_AMD_RENDER_HALVES", "VNR_AMD_FUSED_PACK", "VNR_AMD_DECOUPLED"):
+        monkeypatch.delenv(k, raising=False)
+    nv = c4_scene["nv"]
+    frame(c4_scene, 5, frames=3)                     # the de-hashed image is in use, as in the bench
+    assert api.neural_brick_image(nv)["in_use"]
+    block, parts = 8 * 1024, 8
+    r = api.vnrCreateRenderer(nv)
+    api.vnrRendererSetTransferFunction(r, c4_scene["tfn"])
+    api.vnrRendererSetCamera(r, c4_scene["camera"])
+    api.vnrRendererSetFramebufferSize(r, (1024, 1024))
+    api.vnrRendererSetMode(r, 5)
+    api.vnrRendererSetPixelInterleave(r, block, parts, part)
+    api.vnrRender(r)
+    img = api.vnrRendererMapFrame(r).reshape(-1, 4).copy()
+    st = api.vnrRendererGetFrameStats(r)
+    sched = api.renderer_schedule(r)
+    assert sched == {"n_iters": 32, "n_parts": 3, "fused_pack": True, "decoupled": False}, sched
+    mine = (np.arange(1024 * 1024) // block) % parts == part
+    share = img[mine]
+    params = api.neural_get_params_fp16(nv).view(np.uint16)
+    ocfg = oracle.grid_config(16, 2, 22, 16, float(np.exp(np.log(1024 / 16.0) / 15)))
+    mo = api.volume_macrocell(nv)["max_opacity"]
+    cam = c4_scene["cam"]
+    sc = oracle.SceneHolder(1024, 1024, (1024, 1024, 1024), oracle.TfnHolder(c4_scene["colors"], c4_scene["alphas"]), mo, cam["from"], cam["at"],
+                            cam["up"], cam["fovy"], interleave=(block, parts, part))
+    t0 = time.perf_counter()
+    ref, _, ost = oracle.render_streaming(sc, lambda c: oracle.network_inference_mt(ocfg, 64, 3, params, c), n_iters=32)
+    dt = time.perf_counter() - t0
+    ref = ref.reshape(-1, 4)
+    assert not ref[~mine].any()                      # the oracle rendered this rank's pixels and no others
+    err = np.abs(share - ref[mine])
+    psnr = 10 * np.log10(1.0 / float((err ** 2).mean()))
+    print(f"\nC4 share {part} of 8 (131 072 pixels), N_ITERS 32 by the library's own rule, {sched['n_parts']} parts, fused packing: oracle {dt:.1f} s for "
+          f"{ost['n_slots']} slots; rays hit {st['n_rays_hit']}, iterations {st['n_iterations']}, samples {st['n_samples']} (oracle {ost['n_samples']}), "
+          f"reference slots {st['n_reference_slots']} (oracle {ost['n_slots']}), PSNR {psnr:.1f} dB, max |err| {err.max():.2e}")
+    assert ost["n_rays_hit"] == st["n_rays_hit"] > 40000 and ost["n_iterations"] == st["n_iterations"]
+    assert abs(ost["n_samples"] - st["n_samples"]) <= 0.002 * ost["n_samples"]
+    assert (ref[mine][:, 3] > 0).mean() > 0.3
+    assert psnr > 90.0 and err.max() < 1e-3, (psnr, float(err.max()))
+    ref2, _, ost2 = oracle.render_streaming(sc, lambda c: api.neural_inference(nv, c), n_iters=32)
+    err2 = np.abs(share - ref2.reshape(-1, 4)[mine])
+    psnr2 = 10 * np.log10(1.0 / max(float((err2 ** 2).mean()), 1e-30))
+    print(f"   compositor alone (oracle marcher on the library's network values): PSNR {psnr2:.1f} dB, max |err| {err2.max():.2e}")
+    assert ost2["n_rays_hit"] == st["n_rays_hit"] and ost2["n_iterations"] == st["n_iterations"]
+    assert psnr2 > 120.0 and err2.max() < 1e-5, (psnr2, float(err2.max()))
+    # the share in distributed mode's clothing is the same pixels: the whole frame at 32 holds them bit for bit
+    monkeypatch.setenv("VNR_RM_N_ITERS", "32")
+    whole = frame(c4_scene, 5).reshape(-1, 4)
+    assert np.array_equal(whole[mine], share)
 
 
 def test_gradients_of_the_c4_model_match_the_restatement(oracle):

@@ -163,6 +163,30 @@ def test_tiles_compose_exactly(oracle, small_scene):
     assert np.array_equal(out.reshape(full.shape), full)
 
 
+def test_interleaved_shares_compose_exactly(oracle, small_scene):
+    """a rank's share of a tile-sharded frame (vnro_scene il_block / il_parts / il_part): the shares of 3 ranks in blocks of 40
+    pixels hold exactly the whole frame's pixels (global pixel indices keep the random sequences), touch nobody else's pixels, and their ray
+    counts add up; a share's iteration count is at most the frame's"""
+    vol, sc = small_scene
+    f = lambda c: oracle.sample_volume(vol, c, nodal=True)
+    full, _, st = oracle.render_streaming(sc, f)
+    npx = sc.c.width * sc.c.height
+    out = np.zeros_like(full).reshape(-1, 4)
+    rays = 0
+    iters = []
+    for part in range(3):
+        sc.c.il_block, sc.c.il_parts, sc.c.il_part = 40, 3, part
+        img, _, s = oracle.render_streaming(sc, f)
+        mine = (np.arange(npx) // 40) % 3 == part
+        assert not img.reshape(-1, 4)[~mine].any()
+        out[mine] = img.reshape(-1, 4)[mine]
+        rays += s["n_rays_hit"]
+        iters.append(s["n_iterations"])
+    sc.c.il_block, sc.c.il_parts, sc.c.il_part = 0, 0, 0
+    assert np.array_equal(out.reshape(full.shape), full)
+    assert rays == st["n_rays_hit"] and max(iters) == st["n_iterations"]
+
+
 def test_accumulation_divides_by_frame_index(oracle, small_scene):
     vol, sc = small_scene
     f = lambda c: oracle.sample_volume(vol, c, nodal=True)

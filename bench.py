@@ -59,6 +59,7 @@ def parse():
     p.add_argument("--no-alone", action="store_true", help="skip the un-timed one-stream leg (roofline.alone)")
     p.add_argument("--no-brick-off", action="store_true", help="skip the un-timed leg without the brick image (train-while-render configuration)")
     p.add_argument("--no-brick-table", action="store_true", help="skip the un-timed legs at smaller budgets of the brick image (inference_cache.budget_table)")
+    p.add_argument("--no-interactive", action="store_true", help="skip the un-timed train-while-render leg (`interactive`)")
     p.add_argument("--no-kernel-events", action="store_true", help="diagnostics: no HIP events around the evaluation kernel (roofline.achieved reads 0)")
     p.add_argument("--c5", action="store_true",
                    help="extra un-timed leg: BASELINE C5's training step from an out-of-core file (2 GiB uint8 written to --c5-dir, 16 384 resident "
@@ -158,6 +159,53 @@ def untimed_frames(ren, n, warm=3):
         samples += s["n_samples"]; ms += s["infer_kernel_ms"]; launches += s["infer_kernel_launches"]; union += s["infer_union_ms"]
     check(lib().vnrAmdSynchronize())
     return n / (time.perf_counter() - t), samples, ms, launches, union
+
+
+def interactive_leg(a, nv, make_renderer, brick_off):
+    """render a frame, train k steps with fast_mode = false, render the next frame ...: frames/s of the loop for k = 1 and k = 10, beside the sum
+    of its parts measured alone (the frame without the inference cache, which every optimizer step drops; the training call alone)"""
+    L = lib()
+    ren = make_renderer(nv, profiling=False)
+    out = {"what": "the reference application's loop (apps/int_dual_volume.cpp:631-672): vnrRender + vnrRendererMapFrame, then vnrNeuralVolumeTrain(nv, k, "
+                   "fast_mode = false) (optimizer steps + the macrocell's update from every step's samples + its max-opacity refresh per call: "
+                   "core/network.cu:231-259, 770-779), every frame; un-timed leg of this run, not `value`", "legs": []}
+
+    def train_alone(k, calls):
+        check(L.vnrAmdSynchronize())
+        t = time.perf_counter()
+        for _ in range(calls):
+            api.vnrNeuralVolumeTrain(nv, k, False)
+        check(L.vnrAmdSynchronize())
+        return (time.perf_counter() - t) * 1e3 / calls
+
+    api.vnrNeuralVolumeTrain(nv, 5, False)     # first launches of the slow-mode kernels
+    image_builds0 = api.neural_brick_image(nv).get("builds", 0)
+    for k, frames in ((1, 40), (10, 20)):
+        train_ms = train_alone(k, max(4, 40 // k))
+        for _ in range(3):
+            api.vnrRender(ren); api.vnrRendererMapFrame(ren); api.vnrNeuralVolumeTrain(nv, k, False)
+        check(L.vnrAmdSynchronize())
+        t = time.perf_counter()
+        in_use = 0
+        for _ in range(frames):
+            api.vnrRender(ren); api.vnrRendererMapFrame(ren)
+            in_use += bool(api.neural_brick_image(nv)["in_use"])
+            api.vnrNeuralVolumeTrain(nv, k, False)
+        check(L.vnrAmdSynchronize())
+        ms = (time.perf_counter() - t) * 1e3 / frames
+        leg = {"train_steps_per_frame": k, "frames": frames, "fps": round(1e3 / ms, 2), "ms_per_frame_and_training": round(ms, 4),
+               "training_call_alone_ms": round(train_ms, 4), "ms_per_step_fast_mode_false": round(train_ms / k, 4),
+               "frames_rendered_with_the_inference_cache": in_use}
+        if brick_off:
+            frame_ms = 1e3 / brick_off["fps"]
+            leg["frame_alone_without_cache_ms"] = round(frame_ms, 4)
+            leg["sum_of_parts_ms"] = round(frame_ms + train_ms, 4)
+        out["legs"].append(leg)
+    out["inference_cache_builds_during_the_leg"] = api.neural_brick_image(nv).get("builds", 0) - image_builds0
+    out["training_step"] = api.vnrNeuralVolumeGetTrainingStep(nv)
+    out["loss"] = round(api.vnrNeuralVolumeGetTrainingLoss(nv), 5)
+    del ren
+    return out
 
 
 def c5_leg(a, ctx):
@@ -334,6 +382,10 @@ def visible_gpu_count():
         for node in os.listdir(base):
             props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
             n += int(props.get("simd_count", "0")) > 0
+        # a container is usually given a subset of the host's GPUs as render nodes it may open
+        dri = [d for d in os.listdir("/dev/dri") if d.startswith("renderD")] if os.path.isdir("/dev/dri") else None
+        if dri is not None:
+            n = min(n, sum(os.access(os.path.join("/dev/dri", d), os.R_OK | os.W_OK) for d in dri))
     except (OSError, ValueError):
         return None
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
@@ -667,6 +719,11 @@ def main():
         api.neural_set_brick_budget(nv, 0)
         check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
 
+    # (4) the reference's interactive loop (apps/int_dual_volume.cpp:631-672): every displayed frame is followed by
+    # vnrNeuralVolumeTrain(nv, train_steps, /*fast_mode=*/false) -- the optimizer steps plus, per step, the macrocell's update from the step's samples
+    # and, per call, the refresh of its max-opacity (core/network.cu:231-259, 770-779).  This is the "instant" in instantvnr.  Un-timed for `value`.
+    interactive = interactive_leg(a, nv, make_renderer, brick_off) if ctx.world == 1 and not a.no_interactive and a.mode == 5 else None
+
     c5 = c5_leg(a, ctx) if a.c5 else None
 
     if ctx.distributed:
@@ -900,6 +957,8 @@ def main():
         "roofline": roofline,
         "train_roofline": train_roofline,
     }
+    if interactive is not None:
+        out["interactive"] = interactive
     if c5 is not None:
         out["c5"] = c5
     if ctx.distributed:

@@ -213,6 +213,10 @@ int    vnrAmdNeuralVolumeSetBrickImageMode(vnrAmdVolume, int mode);
  * image, the next launches rebuild it.  BrickImageLevels: bit l set = level l is read from the image. */
 int      vnrAmdNeuralVolumeSetBrickImageBudget(vnrAmdVolume, size_t bytes);
 unsigned vnrAmdNeuralVolumeBrickImageLevels(vnrAmdVolume);
+/* how often the image has been built, and how many launches with unchanged parameters the next build waits for: 24 (VNR_AMD_BRICK_AFTER), doubled
+ * whenever an optimizer step dropped an image that had served fewer than 64 launches -- an application that trains after every frame
+ * (apps/int_dual_volume.cpp:631-672) must not pay a build per frame -- and back to 24 once an image has lived longer */
+int      vnrAmdNeuralVolumeBrickImagePolicy(vnrAmdVolume, uint64_t* builds, unsigned* launches_before_next_build);
 /* AMD extension (measurement): HIP events around the kernels of the training step; GetTrainProfile averages the last <= 64 steps:
  * ms_per_step = {forward, loss + MLP backward, weight gradients, grid backward (+ the exchange's pack kernels), optimizer} */
 int    vnrAmdNeuralVolumeSetTrainProfiling(vnrAmdVolume, int enable);

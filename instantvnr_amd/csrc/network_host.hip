@@ -252,10 +252,24 @@ void Network::refresh_inference_weights(hipStream_t s)
 {
   // both weight images (forward; transposed for the MLP backward) in one launch
   launch_pack_mlp(params_f16_.ptr, mlp_packed_.ptr, mlp_packed_T_.ptr, in_width_, cfg_.n_neurons, n_hidden_matmuls(), s);
-  // the parameters changed: the brick image is stale (it is rebuilt once they have been left alone again)
+  // the parameters changed: the brick image is stale (it is rebuilt once they have been left alone again -- for longer if this image was
+  // dropped before it had paid for itself: network.h)
+  if (brick_valid_) {
+    if (brick_served_calls_ < kBrickPaysAfter) brick_after_scale_ = std::min<uint32_t>(brick_after_scale_ * 2u, 1u << 16);
+    else brick_after_scale_ = 1;
+  }
   brick_valid_ = false;
   brick_stable_calls_ = 0;
+  brick_served_calls_ = 0;
 }
+
+static uint32_t brick_after_base()
+{
+  static const uint32_t after = [] { const char* e = std::getenv("VNR_AMD_BRICK_AFTER"); return e ? (uint32_t)std::max(0, std::atoi(e)) : 24u; }();
+  return after;
+}
+
+uint32_t Network::brick_after_now() const { return brick_after_base() * brick_after_scale_; }
 
 Network::~Network()
 {
@@ -453,14 +467,16 @@ const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image)
 {
   static const int env_mode = [] { const char* e = std::getenv("VNR_AMD_BRICK"); return e ? std::atoi(e) : -1; }();   // -1 auto, 0 off, 1 at once
   const int mode = brick_mode_ >= 0 ? brick_mode_ : env_mode;
-  static const uint32_t after = [] { const char* e = std::getenv("VNR_AMD_BRICK_AFTER"); return e ? (uint32_t)std::max(0, std::atoi(e)) : 24u; }();
   *image = nullptr;
   if (mode == 0 || brick_refused_) return levels_dev_.ptr;
   if (!brick_valid_) {
-    if (++brick_stable_calls_ <= (mode == 1 ? 0u : after)) return levels_dev_.ptr;
+    if (++brick_stable_calls_ <= (mode == 1 ? 0u : brick_after_now())) return levels_dev_.ptr;
     build_brick_image(s);
     if (!brick_valid_) return levels_dev_.ptr;
+    ++brick_builds_;
+    brick_served_calls_ = 0;
   }
+  if (brick_served_calls_ < 0xffffffffu) ++brick_served_calls_;
   // the image was built on one stream and build_brick_image returned only after the host had seen the build complete, so launches
   // on any stream may read it (a per-launch hipStreamWaitEvent on the build's event stood here: one more API call and one more barrier
   // packet in front of every evaluation kernel, always on a completed event)

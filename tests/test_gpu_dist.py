@@ -331,8 +331,11 @@ def test_bare_bench_gpus_2_starts_its_own_ranks():
     assert len(lines) == 1, out.stdout[-1500:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["launcher"].startswith("bench.py")
-    assert d["transport"].startswith("shm") and "2 ranks on 1 visible GPU" in d["transport"] and "NOT an RCCL" in d["scaling"] and d["rccl_ranks_seen"] == 0
-    assert len(d["per_rank"]["share_ms"]) == 2 and "NOT an N-GPU measurement" in out.stderr
+    # either the launcher saw that the box has fewer devices than ranks (and said so), or the ranks' RCCL probe failed on the shared device
+    assert d["transport"].startswith("shm") and "NOT an RCCL" in d["scaling"] and d["rccl_ranks_seen"] == 0
+    assert "2 ranks on 1 visible GPU" in d["transport"] and "NOT an N-GPU measurement" in out.stderr or d["transport"].startswith("shm-fallback"), d["transport"]
+    print("\nbare --gpus 2:", d["transport"], "| launcher:", d["launcher"][:40])
+    assert len(d["per_rank"]["share_ms"]) == 2
     # and a launcher environment that contradicts --gpus is refused, on a GPU box too
     env.update({"WORLD_SIZE": "1", "RANK": "0"})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=60)

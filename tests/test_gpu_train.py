@@ -310,3 +310,62 @@ def test_set_model_resets_the_learning_rate_and_the_decay_schedule():
     api.vnrNeuralVolumeSetModel(nv, cfg)
     assert api.vnrNeuralVolumeGetTrainingStep(nv) == 0
     assert 1e-3 < first_step_move() < 3e-3                 # the new rate, undecayed
+
+
+@pytest.mark.parametrize("online", [False, True])
+def test_frames_between_training_calls_equal_the_frames_of_the_same_parameters_alone(tmp_path, monkeypatch, online):
+    """the reference application's loop (apps/int_dual_volume.cpp:631-672): vnrRender, vnrRendererMapFrame, vnrNeuralVolumeTrain(nv, k,
+    fast_mode = false), every frame.  Each frame of the loop must be the frame a fresh process state gives for the same parameters and
+    macrocell: the state is written as params.json before every training call, loaded into a new volume afterwards and rendered alone.
+    Both with the ground-truth macrocell and with the macrocell built online from the training samples (fast_mode = false updates either:
+    core/network.cu:770-779, 231-259).  Many short iterations per frame (N_ITERS 4), so that a frame has more evaluation launches than the
+    inference cache waits for: the cache must not be rebuilt after every optimizer step (network.h: the threshold backs off)."""
+    monkeypatch.setenv("VNR_RM_N_ITERS", "4")
+    monkeypatch.setenv("VNR_AMD_INIT_SEED", "77")
+    vol = syn.analytic_volume(64)
+    sv = api.vnrCreateSimpleVolume(vol)
+    cfg = syn.model_config(n_levels=8, n_features=2, log2_hashmap_size=13, base_resolution=4, n_hidden_layers=2, per_level_scale=1.5)
+    nv = api.vnrCreateNeuralVolume(cfg, sv, online_macrocell_construction=online)
+    api.vnrNeuralVolumeTrain(nv, 60, False)
+    colors, alphas = syn.tfn_ramp_with_bumps()
+    tfn = api.vnrCreateTransferFunction()
+    api.vnrTransferFunctionSetColor(tfn, colors)
+    api.vnrTransferFunctionSetAlpha(tfn, alphas)
+    api.vnrTransferFunctionSetValueRange(tfn, (0, 1))
+    cam = syn.oblique_camera((64, 64, 64))
+    camera = api.vnrCreateCamera()
+    api.vnrCameraSet(camera, cam["from"], cam["at"], cam["up"], cam["fovy"])
+
+    def renderer(v):
+        r = api.vnrCreateRenderer(v)
+        api.vnrRendererSetTransferFunction(r, tfn)
+        api.vnrRendererSetCamera(r, camera)
+        api.vnrRendererSetFramebufferSize(r, (160, 128))
+        api.vnrRendererSetMode(r, 5)
+        return r
+    ren = renderer(nv)
+    frames, launches = [], []
+    builds0 = api.neural_brick_image(nv)["builds"]
+    for i in range(14):
+        api.vnrRendererResetAccumulation(ren)      # (the application accumulates across training steps; a frame of its own is what can be compared)
+        api.vnrRender(ren)
+        frames.append(api.vnrRendererMapFrame(ren).copy())
+        launches.append(api.vnrRendererGetFrameStats(ren)["n_iterations"] * api.renderer_schedule(ren)["n_parts"])
+        api.vnrNeuralVolumeSerializeParams(nv, str(tmp_path / f"p{i}.json"))
+        api.vnrNeuralVolumeTrain(nv, 1 if i % 2 else 3, False)
+    st = api.neural_brick_image(nv)
+    assert min(launches) > 24, launches            # every frame alone would have triggered a build under the fixed threshold
+    assert st["builds"] - builds0 <= 4 and st["launches_before_next_build"] >= 8 * 24, (st, launches)
+    assert frames[0][..., 3].max() > 0.3 and not np.array_equal(frames[0], frames[-1])
+    for i in (0, 1, 2, 7, 13):
+        alone = api.vnrCreateNeuralVolume(str(tmp_path / f"p{i}.json"))
+        r2 = renderer(alone)
+        api.vnrRender(r2)
+        assert np.array_equal(api.vnrRendererMapFrame(r2), frames[i]), i
+    # left alone, the parameters get their cache after the backed-off wait; once it has paid for itself the wait is the base again
+    for _ in range(1 + (st["launches_before_next_build"] + 64) // min(launches) + 1):
+        api.vnrRender(ren); api.vnrRendererMapFrame(ren)
+    assert api.neural_brick_image(nv)["in_use"]
+    api.vnrNeuralVolumeTrain(nv, 1, False)
+    st = api.neural_brick_image(nv)
+    assert not st["in_use"] and st["launches_before_next_build"] == 24

@@ -129,6 +129,10 @@ __device__ __forceinline__ void encode_level(const LevelInfo& lv, uint32_t inter
 // ------------------------------------------------------------------------------------------------
 typedef __amdgpu_buffer_rsrc_t table_rsrc_t;
 
+#ifndef VNR_HASH_QUAD
+#define VNR_HASH_QUAD 1   // hashed F = 2 levels: aligned four-entry groups (gather_corners); 0 = aligned pairs (rounds 1-5), for A/B builds
+#endif
+
 __device__ __forceinline__ table_rsrc_t make_table_rsrc(const void* base, uint32_t bytes)
 {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
@@ -203,6 +207,32 @@ __device__ __forceinline__ void gather_corners(const LevelInfo& lv, const Corner
     const uint32_t hz0 = c.g[2] * 805459861u, hz1 = hz0 + 805459861u;
     const uint32_t x0 = c.g[0], x1 = c.g[0] + 1u;
     const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#if VNR_HASH_QUAD
+    if constexpr (F == 2) {
+      // x + 1 = x ^ (2^(t+1) - 1) with t the trailing ones of x, and the hash of the other two coordinates is XORed onto x, so the +x
+      // neighbour of entry i0 is i0 ^ 1 for even x, i0 ^ 3 for x = 1 (mod 4): both inside the aligned group of FOUR entries (16 bytes) that
+      // holds i0.  One 16-byte load of that group per (y, z) row serves three lanes in four; only x = 3 (mod 4) pays a second gather (the
+      // pair load above it served one lane in two).  A gather is priced per (instruction, lane address), not per byte.
+      const uint32_t m = (x0 & 1u) ? 3u : 1u;
+      const bool far_x = (x0 & 3u) == 3u;
+      uint32_t i1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t i0 = (x0 ^ yz[q]) & mask;
+        i1[q] = (x1 ^ yz[q]) & mask;
+        const uint4_t g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (i0 & ~3u) * kBytes, soff, 0);
+        const uint32_t k = i0 & 3u, k2 = k ^ m;
+        const uint32_t a0 = (k & 1u) ? g.y : g.x, a1 = (k & 1u) ? g.w : g.z;       // entry k of its half, for either half
+        const uint32_t b0 = (k & 1u) ? g.x : g.y, b1 = (k & 1u) ? g.z : g.w;       // ... and entry k ^ 1
+        v[2 * q] = (k & 2u) ? a1 : a0;
+        v[2 * q + 1] = (k2 & 2u) ? b1 : b0;                                        // (k2 & 1) == (k & 1) ^ 1 for m = 1 and m = 3
+      }
+      if (far_x) {  // divergent: one lane in four
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[2 * q + 1] = RawFeat<F>::load(rsrc, i1[q] * kBytes, soff);
+      }
+    } else
+#endif
     if constexpr (PairFeat<F>::enabled) {
       // even x: (x+1)^h == (x^h)^1, i.e. the second corner is the other half of the aligned entry pair
       const bool odd_x = (x0 & 1u) != 0u;

@@ -202,9 +202,15 @@ def test_brick_image_is_lazy_exact_and_dropped_when_parameters_change(oracle, cf
     assert not api.neural_brick_image(vol)["in_use"]
     enc2 = api.neural_encode(vol, coords).view(np.uint16)
     assert np.array_equal(enc2[ok], oracle.grid_encode(ocfg, params2[n_mlp:].view(np.uint16), coords)[ok])
+    # (the first image was dropped before it had served 64 launches, so the next one waits twice as long: network.h, the application that trains
+    # after every frame)
+    assert api.neural_brick_image(vol)["launches_before_next_build"] == 48
     for _ in range(30):
         api.neural_inference(vol, coords[:64])
-    assert api.neural_brick_image(vol)["in_use"]
+    assert not api.neural_brick_image(vol)["in_use"]
+    for _ in range(30):
+        api.neural_inference(vol, coords[:64])
+    assert api.neural_brick_image(vol)["in_use"] and api.neural_brick_image(vol)["builds"] == 2
     assert np.array_equal(api.neural_encode(vol, coords).view(np.uint16)[ok], enc2[ok])
 
 

@@ -318,9 +318,9 @@ def test_frames_between_training_calls_equal_the_frames_of_the_same_parameters_a
     fast_mode = false), every frame.  Each frame of the loop must be the frame a fresh process state gives for the same parameters and
     macrocell: the state is written as params.json before every training call, loaded into a new volume afterwards and rendered alone.
     Both with the ground-truth macrocell and with the macrocell built online from the training samples (fast_mode = false updates either:
-    core/network.cu:770-779, 231-259).  Many short iterations per frame (N_ITERS 4), so that a frame has more evaluation launches than the
+    core/network.cu:770-779, 231-259).  Many short iterations per frame (N_ITERS 2, three ray parts), so that a frame has more evaluation launches than the
     inference cache waits for: the cache must not be rebuilt after every optimizer step (network.h: the threshold backs off)."""
-    monkeypatch.setenv("VNR_RM_N_ITERS", "4")
+    monkeypatch.setenv("VNR_RM_N_ITERS", "2")
     monkeypatch.setenv("VNR_AMD_INIT_SEED", "77")
     vol = syn.analytic_volume(64)
     sv = api.vnrCreateSimpleVolume(vol)
@@ -340,7 +340,7 @@ def test_frames_between_training_calls_equal_the_frames_of_the_same_parameters_a
         r = api.vnrCreateRenderer(v)
         api.vnrRendererSetTransferFunction(r, tfn)
         api.vnrRendererSetCamera(r, camera)
-        api.vnrRendererSetFramebufferSize(r, (160, 128))
+        api.vnrRendererSetFramebufferSize(r, (256, 192))     # (more than 20 480 rays: the coupled loop on three parts)
         api.vnrRendererSetMode(r, 5)
         return r
     ren = renderer(nv)
@@ -355,7 +355,7 @@ def test_frames_between_training_calls_equal_the_frames_of_the_same_parameters_a
         api.vnrNeuralVolumeTrain(nv, 1 if i % 2 else 3, False)
     st = api.neural_brick_image(nv)
     assert min(launches) > 24, launches            # every frame alone would have triggered a build under the fixed threshold
-    assert st["builds"] - builds0 <= 4 and st["launches_before_next_build"] >= 8 * 24, (st, launches)
+    assert st["builds"] - builds0 <= 3 and st["launches_before_next_build"] > max(launches), (st, launches)   # (measured: 2 builds, then 96 > 54)
     assert frames[0][..., 3].max() > 0.3 and not np.array_equal(frames[0], frames[-1])
     for i in (0, 1, 2, 7, 13):
         alone = api.vnrCreateNeuralVolume(str(tmp_path / f"p{i}.json"))

@@ -492,10 +492,27 @@ __global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const float* __
   if (g == 0 && p < n_mlp) grads[p] = (half_t)((float)grads[p] + ((part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx])));
 }
 
+// element type of the buffer the grid backward scatters into: the fp16 gradient blob's grid part, or (F = 1) its float image
+template <int F> struct GridGrad { typedef half_t type; };
+template <> struct GridGrad<1> { typedef float type; };
+
+// F = 1: float image [lo, hi) of the grid gradients -> the fp16 blob, one rounding per entry; what it consumed is cleared for the next scatter
+__global__ void fold_grid_grads_f32_kernel(float* __restrict__ image, half_t* __restrict__ grid_grads, size_t lo, size_t hi)
+{
+  for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = image[i];
+    if (v == 0.0f) continue;
+    image[i] = 0.0f;
+    grid_grads[i] = (half_t)((float)grid_grads[i] + v);   // (adds: two forward_backward calls before one optimizer step accumulate, vnr_amd.h)
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ grid backward
 // EXTERNAL tcnn kernel_grid_backward: for every (sample, level): grad[idx*F+f] += w * dL/dfeature[f], accumulated in HALF precision
-// with packed atomics as tcnn does for F > 1 (grad_t = __half, atomicAdd(__half2)); F = 1 (tcnn: float atomics) uses the same packed
-// atomic with a zero in the other half of the aligned pair.
+// with packed atomics as tcnn does for F > 1 (grad_t = __half, atomicAdd(__half2)).  F = 1: tcnn's grad_t is float there (one feature per
+// level has no pair to pack), so the scatter adds fp32 (global_atomic_add_f32) into a float image of the grid part, and fold_grid_grads_f32_kernel
+// rounds each sum ONCE into the fp16 gradient blob the optimizer and the gradient exchange read (rounds 1-5 added packed fp16 with a zero
+// in the other half: 6 % low at ~2 000 adds per entry).  `grid_grads` is then that float image.
 // lane = (sample, x bit, feature pair).  Memory-side float atomics are priced per 64-byte REQUEST, whatever the request carries
 // (MI355X_MICROARCH.md "Global float atomics"; measured here: one lane per sample and dword 0.846 ms, (sample, feature) lanes 0.425,
 // with the x bit 0.242, packed fp16 pairs 0.242: DESIGN.md 4.3), so what matters is that the lanes of one entry pair are adjacent:
@@ -503,7 +520,7 @@ __global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const float* __
 // Every lane repeats the (cheap) index arithmetic of its sample.
 template <int F>
 __global__ void grid_backward_kernel(const GridDevice grid, const float* __restrict__ coords, const half_t* __restrict__ dfeat,
-                                     uint32_t n, uint32_t in_width, half_t* __restrict__ grid_grads, uint32_t level0)
+                                     uint32_t n, uint32_t in_width, typename GridGrad<F>::type* __restrict__ grid_grads, uint32_t level0)
 {
   constexpr uint32_t P = F >= 2 ? (uint32_t)F / 2u : 1u;   // packed pairs per entry
   constexpr uint32_t kLanesPerSample = 2u * P;
@@ -524,25 +541,22 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
   const bool nearest = grid.interpolation == 2u;   // EXTERNAL tcnn kernel_grid_backward, Nearest: the whole gradient to the lower corner's entry
   if (nearest && xb) return;
   const CornerSetup c = level_setup(lv, grid.interpolation == 1u ? 1u : 0u, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
-  half_t* base = grid_grads + (F >= 2 ? (size_t)lv.offset * F + f : (size_t)0);
+  auto* base = grid_grads + (size_t)lv.offset * F + (F >= 2 ? f : 0u);
 #pragma unroll
   for (int yz = 0; yz < 4; ++yz) {
     if (nearest && yz) break;
     const int corner = (int)xb | (yz << 1);
     const uint32_t idx = level_index(lv, c.g[0] + xb, c.g[1] + (uint32_t)(yz & 1), c.g[2] + (uint32_t)(yz >> 1));
     const float w = nearest ? 1.0f : corner_weight(c, corner);
-    half2_t v;
-    half_t* addr;
     if constexpr (F >= 2) {
-      v = half2_t{(half_t)(w * g0), (half_t)(w * g1)};
-      addr = base + (size_t)idx * F;
-    } else {   // the entry's half of its aligned pair of the gradient blob (by absolute element: a Tiled level may have an odd size)
-      const half_t h = (half_t)(w * g0), z = (half_t)0.0f;
-      const size_t e = (size_t)lv.offset + idx;
-      v = (e & 1u) ? half2_t{z, h} : half2_t{h, z};
-      addr = base + (e & ~(size_t)1);
+      const half2_t v = half2_t{(half_t)(w * g0), (half_t)(w * g1)};
+      half_t* addr = base + (size_t)idx * F;
+      asm volatile("global_atomic_pk_add_f16 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
+    } else {
+      const float v = w * g0;
+      float* addr = base + idx;
+      asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
     }
-    asm volatile("global_atomic_pk_add_f16 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
   }
 }
 
@@ -553,7 +567,7 @@ __global__ void grid_backward_kernel(const GridDevice grid, const float* __restr
 // bought nothing in round 4.  Per lane the arithmetic is grid_backward_kernel's, statement for statement.
 template <int F>
 __global__ void __launch_bounds__(256) grid_backward_persistent_kernel(const GridDevice grid, const float* __restrict__ coords, const half_t* __restrict__ dfeat,
-                                                                       uint32_t n, uint32_t in_width, half_t* __restrict__ grid_grads, uint32_t level0, uint32_t n_levels)
+                                                                       uint32_t n, uint32_t in_width, typename GridGrad<F>::type* __restrict__ grid_grads, uint32_t level0, uint32_t n_levels)
 {
   constexpr uint32_t P = F >= 2 ? (uint32_t)F / 2u : 1u;
   constexpr uint32_t kLanesPerSample = 2u * P;
@@ -577,25 +591,22 @@ __global__ void __launch_bounds__(256) grid_backward_persistent_kernel(const Gri
     if (g0 == 0.0f && g1 == 0.0f) continue;
     if (nearest && xb) continue;
     const CornerSetup c = level_setup(lv, grid.interpolation == 1u ? 1u : 0u, coords[3 * (size_t)i], coords[3 * (size_t)i + 1], coords[3 * (size_t)i + 2]);
-    half_t* base = grid_grads + (F >= 2 ? (size_t)lv.offset * F + f : (size_t)0);
+    auto* base = grid_grads + (size_t)lv.offset * F + (F >= 2 ? f : 0u);
 #pragma unroll
     for (int yz = 0; yz < 4; ++yz) {
       if (nearest && yz) break;
       const int corner = (int)xb | (yz << 1);
       const uint32_t idx = level_index(lv, c.g[0] + xb, c.g[1] + (uint32_t)(yz & 1), c.g[2] + (uint32_t)(yz >> 1));
       const float wgt = nearest ? 1.0f : corner_weight(c, corner);
-      half2_t v;
-      half_t* addr;
       if constexpr (F >= 2) {
-        v = half2_t{(half_t)(wgt * g0), (half_t)(wgt * g1)};
-        addr = base + (size_t)idx * F;
+        const half2_t v = half2_t{(half_t)(wgt * g0), (half_t)(wgt * g1)};
+        half_t* addr = base + (size_t)idx * F;
+        asm volatile("global_atomic_pk_add_f16 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
       } else {
-        const half_t h = (half_t)(wgt * g0), z = (half_t)0.0f;
-        const size_t e = (size_t)lv.offset + idx;
-        v = (e & 1u) ? half2_t{z, h} : half2_t{h, z};
-        addr = base + (e & ~(size_t)1);
+        const float v = wgt * g0;
+        float* addr = base + idx;
+        asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
       }
-      asm volatile("global_atomic_pk_add_f16 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
     }
   }
 }
@@ -612,7 +623,7 @@ struct LdsBwdItem { uint32_t level, e0, e1, s0, s1; };   // entries [e0, e1) of 
 
 template <int F>
 __global__ void __launch_bounds__(256) grid_backward_lds_kernel(const GridDevice grid, const LdsBwdItem* __restrict__ items, const float* __restrict__ coords,
-                                                                const half_t* __restrict__ dfeat, uint32_t in_width, half_t* __restrict__ grid_grads)
+                                                                const half_t* __restrict__ dfeat, uint32_t in_width, typename GridGrad<F>::type* __restrict__ grid_grads)
 {
   extern __shared__ float s_acc[];   // [e1 - e0][F]
   const LdsBwdItem it = items[blockIdx.x];
@@ -653,8 +664,18 @@ __global__ void __launch_bounds__(256) grid_backward_lds_kernel(const GridDevice
     }
   }
   __syncthreads();
+  if constexpr (F == 1) {   // fp32 sums into the float image, entry by entry
+    float* base = grid_grads + (size_t)lv.offset + it.e0;
+    for (uint32_t q = threadIdx.x; q < n_acc; q += blockDim.x) {
+      const float a = s_acc[q];
+      if (a == 0.0f) continue;
+      float* addr = base + q;
+      asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(addr), "v"(a) : "memory");
+    }
+    return;
+  }
   // flush: one packed atomic per pair of halves that received something (e0 is even and level offsets are multiples of 8 entries)
-  half_t* base = grid_grads + ((size_t)lv.offset + it.e0) * F;
+  half_t* base = (half_t*)grid_grads + ((size_t)lv.offset + it.e0) * F;
   for (uint32_t q = threadIdx.x; 2u * q < n_acc; q += blockDim.x) {
     const float a = s_acc[2u * q], b = 2u * q + 1u < n_acc ? s_acc[2u * q + 1u] : 0.0f;
     if (a == 0.0f && b == 0.0f) continue;
@@ -815,15 +836,30 @@ struct TrainScratch {  // per-Network extra buffers that do not need to live in 
   std::vector<uint8_t> lds_items_host;               // what lds_items holds: the list depends on the level sizes, n_features, tile size, batch and level range
   uint32_t loss_blocks = 0;
   DeviceBuffer<double> distance_partials{MemTag::Network};   // gradient_distance (diagnostics)
+  DeviceBuffer<float> grid_grads_f32{MemTag::Network};       // n_features = 1: float image of the grid gradients (zero between steps)
+  hipEvent_t fold_ev = nullptr;                              // ... and the join of its two scatter streams in front of the fold
+  ~TrainScratch() { if (fold_ev) (void)hipEventDestroy(fold_ev); }
 };
 
 }  // namespace vnr
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 
 namespace vnr {
+
+// once per kernel and process: hipFuncSetAttribute stays off the step's launch path.  Keyed by the function's address (the instances of a
+// kernel template share one signature, so a static flag inside a generic lambda would be shared by all of them); guarded, because two
+// host threads may train two networks; the attribute belongs to the function, not to a device.
+static bool first_use_of_kernel(const void* kernel)
+{
+  static std::mutex m;
+  static std::set<const void*> done;
+  std::lock_guard<std::mutex> g(m);
+  return done.insert(kernel).second;
+}
 
 static std::map<const Network*, std::unique_ptr<TrainScratch>>& scratch_map()
 {
@@ -875,6 +911,19 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
   if (lds_bwd)
     while (lds_levels < n_active_levels() && !grid_.levels[lds_levels].hashed && ((size_t)grid_.levels[lds_levels].offset * cfg_.n_features) % 2 == 0 &&
            div_round_up(grid_.levels[lds_levels].size, tile_entries) <= lds_max_tiles) ++lds_levels;   // (the flush adds aligned pairs of halves)
+  // n_features = 1: the scatter's target is the float image (fold_grid_grads_f32_kernel); the fold of a level range follows its scatter on the
+  // same stream(s), before anybody (optimizer, exchange) reads the blob
+  float* gg32 = nullptr;
+  if (cfg_.n_features == 1) {
+    const size_t n_grid = grads_alloc() - n_mlp_;
+    if (ts.grid_grads_f32.count != n_grid) { ts.grid_grads_f32.resize(n_grid); ts.grid_grads_f32.zero(s); VNR_HIP_CHECK(hipStreamSynchronize(s)); }
+    gg32 = ts.grid_grads_f32.ptr;
+  }
+  auto fold = [&](uint32_t l0, uint32_t l1) {
+    if (!gg32 || l0 >= l1) return;
+    const size_t lo = level_range_lo(l0) - n_mlp_, hi = level_range_hi(l1) - n_mlp_;
+    fold_grid_grads_f32_kernel<<<(uint32_t)std::min<size_t>(div_round_up(hi - lo, 256), (size_t)Runtime::get().n_cus * 16), 256, 0, s>>>(gg32, (half_t*)grads_.ptr + n_mlp_, lo, hi);
+  };
   auto grid_backward_lds = [&](uint32_t l0, uint32_t l1) {
     // work items: every tile of every level x slices of the batch; more slices where a level has few tiles, so that ~2 blocks per CU exist
     std::vector<LdsBwdItem> items;
@@ -900,16 +949,15 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
     }
     const size_t shmem = (size_t)tile_entries * cfg_.n_features * sizeof(float);
     half_t* gg = (half_t*)grads_.ptr + n_mlp_;
-    auto launch = [&](auto kernel) {
-      static std::set<const void*> done;   // (by address: the four instances have one signature and would share a flag of this lambda)
-      if (done.insert((const void*)kernel).second) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      kernel<<<(uint32_t)items.size(), 256, shmem, s_lds>>>(grid_, (const LdsBwdItem*)ts.lds_items.ptr, d_coords, (const half_t*)ws_dfeat_.ptr, in_width_, gg);
+    auto launch = [&](auto kernel, auto* out) {
+      if (first_use_of_kernel((const void*)kernel)) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      kernel<<<(uint32_t)items.size(), 256, shmem, s_lds>>>(grid_, (const LdsBwdItem*)ts.lds_items.ptr, d_coords, (const half_t*)ws_dfeat_.ptr, in_width_, out);
     };
     switch (cfg_.n_features) {
-    case 1: launch(grid_backward_lds_kernel<1>); break;
-    case 2: launch(grid_backward_lds_kernel<2>); break;
-    case 4: launch(grid_backward_lds_kernel<4>); break;
-    default: launch(grid_backward_lds_kernel<8>); break;
+    case 1: launch(grid_backward_lds_kernel<1>, gg32); break;
+    case 2: launch(grid_backward_lds_kernel<2>, gg); break;
+    case 4: launch(grid_backward_lds_kernel<4>, gg); break;
+    default: launch(grid_backward_lds_kernel<8>, gg); break;
     }
   };
   auto grid_backward = [&](uint32_t l0, uint32_t l1) {
@@ -925,7 +973,7 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
       static const uint32_t per_cu = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_BLOCKS_PER_CU"); return e ? (uint32_t)std::max(1, std::min(16, std::atoi(e))) : 2u; }();
       const uint32_t blocks = std::min<uint32_t>(g.x * g.y, (uint32_t)Runtime::get().n_cus * per_cu);
       switch (cfg_.n_features) {
-      case 1: grid_backward_persistent_kernel<1><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0, l1 - l0); break;
+      case 1: grid_backward_persistent_kernel<1><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg32, l0, l1 - l0); break;
       case 2: grid_backward_persistent_kernel<2><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0, l1 - l0); break;
       case 4: grid_backward_persistent_kernel<4><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0, l1 - l0); break;
       default: grid_backward_persistent_kernel<8><<<blocks, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0, l1 - l0); break;
@@ -933,7 +981,7 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
       return;
     }
     switch (cfg_.n_features) {
-    case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
+    case 1: grid_backward_kernel<1><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg32, l0); break;
     case 2: grid_backward_kernel<2><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
     case 4: grid_backward_kernel<4><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
     default: grid_backward_kernel<8><<<g, 256, 0, s>>>(grid_, d_coords, (const half_t*)ws_dfeat_.ptr, n, in_width_, gg, l0); break;
@@ -955,11 +1003,19 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
     // levels at or beyond max_level + 1e-3 encode to zero and receive no gradient (EXTERNAL tcnn kernel_grid_backward has the same test)
     if (only.first >= 0) grid_backward((uint32_t)only.first, std::min<uint32_t>((uint32_t)only.second, n_active_levels()));
     else if (n_active_levels() > 0) grid_backward(0, n_active_levels());
+    if (gg32 && n_active_levels() > 0) {
+      if (side_by_side) {   // the dense levels' LDS scatter runs on s_lds and is joined by the caller only later: the fold waits for it here
+        if (!ts.fold_ev) VNR_HIP_CHECK(hipEventCreateWithFlags(&ts.fold_ev, hipEventDisableTiming));
+        VNR_HIP_CHECK(hipEventRecord(ts.fold_ev, s_lds));
+        VNR_HIP_CHECK(hipStreamWaitEvent(s, ts.fold_ev, 0));
+      }
+      fold(0, n_active_levels());
+    }
   } else {
     // finest levels first (the large tables), in buckets of at least bucket_params() parameters: a bucket's exchange overlaps the
     // backward launches of the coarser levels and, afterwards, the optimizer update of the buckets before it
     for (const auto& b : exchange_level_buckets(exchange->bucket_params())) {
-      if (b.first < n_active_levels()) grid_backward(b.first, std::min(b.second, n_active_levels()));
+      if (b.first < n_active_levels()) { grid_backward(b.first, std::min(b.second, n_active_levels())); fold(b.first, std::min(b.second, n_active_levels())); }
       exchange->range_ready(level_range_lo(b.first), level_range_hi(b.second), s);
     }
   }
@@ -1026,8 +1082,7 @@ void Network::forward_backward(const float* d_coords, const float* d_targets, si
     auto launch = [&](auto kernel) {
       // once per kernel: no driver call on the step's launch path.  (Keyed by the function's address: the instances share one signature,
       // so a static flag inside this generic lambda would be shared by all of them.)
-      static std::set<const void*> done;
-      if (done.insert((const void*)kernel).second) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+      if (first_use_of_kernel((const void*)kernel)) VNR_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
       kernel<<<blocks, 256, shmem, s>>>(ba);
     };
     const bool gen = cfg_.activation > 1u || bwd_global;

@@ -369,3 +369,27 @@ def test_frames_between_training_calls_equal_the_frames_of_the_same_parameters_a
     api.vnrNeuralVolumeTrain(nv, 1, False)
     st = api.neural_brick_image(nv)
     assert not st["in_use"] and st["launches_before_next_build"] == 24
+
+
+def test_one_feature_per_level_sums_its_grid_gradients_in_fp32(oracle):
+    """n_features_per_level = 1: upstream tcnn's grid gradient type is float there (grad_t, EXTERNAL grid.h: one feature per level has no
+    pair to pack into a __half2 atomic), so thousands of contributions per entry are summed exactly and rounded once.  Rounds 1-5 added them
+    as packed fp16 atomics like F >= 2: with ~2 000 adds per entry the sums came out 6 % low.  Tiny tables and a
+    large batch (60 000 samples x 8 corners into 4 levels of at most 256 entries): every entry receives hundreds to thousands of adds; the
+    gradient must match the float64 restatement without the systematic loss, and two calls before one optimizer step must add up."""
+    vol, ocfg, params, n_mlp, info = small_model(oracle, 4, 1, 8, 4, 2, seed=21)
+    rng = np.random.default_rng(22)
+    B = 60000
+    coords = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    targets = rng.uniform(0, 1, B).astype(np.float32)
+    got = api.neural_forward_backward(vol, coords, targets).astype(np.float64)
+    ref = T.training_gradients(ocfg, 64, 2, params.view(np.uint16), coords, targets, loss="L1")["grads"]
+    g, w = got[n_mlp:], ref[n_mlp:]
+    adds = B * 8 / max(1, np.count_nonzero(w))
+    rel = np.linalg.norm(g - w) / np.linalg.norm(w)
+    ratio = np.abs(g).sum() / np.abs(w).sum()
+    print(f"\nF = 1, {np.count_nonzero(w)} entries, ~{adds:.0f} adds per entry: relative error {rel:.2e}, sum |g| / sum |want| = {ratio:.4f}")
+    assert adds > 500
+    assert rel < 1e-2 and abs(ratio - 1.0) < 5e-3, (rel, ratio)
+    twice = api.neural_forward_backward(vol, coords, targets).astype(np.float64)
+    assert np.linalg.norm(twice[n_mlp:] - 2 * g) < 2e-3 * np.linalg.norm(2 * g)

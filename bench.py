@@ -202,6 +202,28 @@ def interactive_leg(a, nv, make_renderer, brick_off):
             leg["sum_of_parts_ms"] = round(frame_ms + train_ms, 4)
         out["legs"].append(leg)
     out["inference_cache_builds_during_the_leg"] = api.neural_brick_image(nv).get("builds", 0) - image_builds0
+    # would a SMALL cache rebuilt after every training call pay?  The finest-first levels that fit the budget, built at the first launch after the
+    # parameters changed (mode 1), i.e. once per frame of this loop.
+    small = []
+    for gib in (0.25, 0.75):
+        api.neural_set_brick_budget(nv, int(gib * 2**30))
+        check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, 1))
+        for k, frames in ((1, 30), (10, 12)):
+            for _ in range(3):
+                api.vnrRender(ren); api.vnrRendererMapFrame(ren); api.vnrNeuralVolumeTrain(nv, k, False)
+            check(L.vnrAmdSynchronize())
+            b0 = api.neural_brick_image(nv)["builds"]
+            t = time.perf_counter()
+            for _ in range(frames):
+                api.vnrRender(ren); api.vnrRendererMapFrame(ren); api.vnrNeuralVolumeTrain(nv, k, False)
+            check(L.vnrAmdSynchronize())
+            ms = (time.perf_counter() - t) * 1e3 / frames
+            st = api.neural_brick_image(nv)
+            small.append({"budget_gib": gib, "train_steps_per_frame": k, "fps": round(1e3 / ms, 2), "ms_per_frame_and_training": round(ms, 4),
+                          "image_bytes": int(st["bytes"]), "build_ms": round(st["build_ms"], 4), "builds_per_frame": round((st["builds"] - b0) / frames, 2)})
+    api.neural_set_brick_budget(nv, 0)
+    check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
+    out["small_cache_rebuilt_every_frame"] = small
     out["training_step"] = api.vnrNeuralVolumeGetTrainingStep(nv)
     out["loss"] = round(api.vnrNeuralVolumeGetTrainingLoss(nv), 5)
     del ren

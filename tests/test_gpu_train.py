@@ -390,6 +390,6 @@ def test_one_feature_per_level_sums_its_grid_gradients_in_fp32(oracle):
     ratio = np.abs(g).sum() / np.abs(w).sum()
     print(f"\nF = 1, {np.count_nonzero(w)} entries, ~{adds:.0f} adds per entry: relative error {rel:.2e}, sum |g| / sum |want| = {ratio:.4f}")
     assert adds > 500
-    assert rel < 1e-2 and abs(ratio - 1.0) < 5e-3, (rel, ratio)
+    assert rel < 2e-3 and abs(ratio - 1.0) < 1e-3, (rel, ratio)      # measured 2.1e-4 and 1.0000 (packed fp16 adds: 6 % low)
     twice = api.neural_forward_backward(vol, coords, targets).astype(np.float64)
     assert np.linalg.norm(twice[n_mlp:] - 2 * g) < 2e-3 * np.linalg.norm(2 * g)

@@ -180,32 +180,44 @@ def interactive_leg(a, nv, make_renderer, brick_off):
 
     api.vnrNeuralVolumeTrain(nv, 5, False)     # first launches of the slow-mode kernels
     image_builds0 = api.neural_brick_image(nv).get("builds", 0)
-    for k, frames in ((1, 40), (10, 20)):
-        train_ms = train_alone(k, max(4, 40 // k))
+    def loop(k, frames):
         for _ in range(3):
             api.vnrRender(ren); api.vnrRendererMapFrame(ren); api.vnrNeuralVolumeTrain(nv, k, False)
         check(L.vnrAmdSynchronize())
         t = time.perf_counter()
-        in_use = 0
+        tiers = [0, 0, 0]
         for _ in range(frames):
             api.vnrRender(ren); api.vnrRendererMapFrame(ren)
-            in_use += bool(api.neural_brick_image(nv)["in_use"])
+            tiers[api.neural_brick_image(nv)["tier"]] += 1
             api.vnrNeuralVolumeTrain(nv, k, False)
         check(L.vnrAmdSynchronize())
-        ms = (time.perf_counter() - t) * 1e3 / frames
+        return (time.perf_counter() - t) * 1e3 / frames, tiers
+
+    small0 = api.neural_brick_image(nv)["small_builds"]
+    for k, frames in ((1, 40), (10, 20)):
+        train_ms = train_alone(k, max(4, 40 // k))
+        ms, tiers = loop(k, frames)                                 # the library's own policy: the small tier of the cache, rebuilt per frame
+        check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, 0))
+        ms_off, _ = loop(k, frames)                                 # no cache at all (rounds 1-5)
+        check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
+        st = api.neural_brick_image(nv)
         leg = {"train_steps_per_frame": k, "frames": frames, "fps": round(1e3 / ms, 2), "ms_per_frame_and_training": round(ms, 4),
+               "fps_without_any_cache": round(1e3 / ms_off, 2), "ms_without_any_cache": round(ms_off, 4),
                "training_call_alone_ms": round(train_ms, 4), "ms_per_step_fast_mode_false": round(train_ms / k, 4),
-               "frames_rendered_with_the_inference_cache": in_use}
+               "frames_by_cache_tier": {"none": tiers[0], "small": tiers[1], "full": tiers[2]}}
         if brick_off:
             frame_ms = 1e3 / brick_off["fps"]
             leg["frame_alone_without_cache_ms"] = round(frame_ms, 4)
-            leg["sum_of_parts_ms"] = round(frame_ms + train_ms, 4)
+            leg["sum_of_parts_without_cache_ms"] = round(frame_ms + train_ms, 4)
         out["legs"].append(leg)
-    out["inference_cache_builds_during_the_leg"] = api.neural_brick_image(nv).get("builds", 0) - image_builds0
+    st = api.neural_brick_image(nv)
+    out["inference_cache"] = {"policy": "while the parameters change after every frame the first large launch of a frame builds a SMALL image (finest levels within "
+                                        "VNR_AMD_BRICK_SMALL_GB, default 0.75 GiB); the full image waits until they have been left alone (and backs off: network.h)",
+                              "small_builds_during_the_legs": st["small_builds"] - small0, "full_builds_during_the_legs": st["builds"] - image_builds0}
     # would a SMALL cache rebuilt after every training call pay?  The finest-first levels that fit the budget, built at the first launch after the
     # parameters changed (mode 1), i.e. once per frame of this loop.
     small = []
-    for gib in (0.25, 0.75):
+    for gib in (0.25, 0.75, 1.7):
         api.neural_set_brick_budget(nv, int(gib * 2**30))
         check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, 1))
         for k, frames in ((1, 30), (10, 12)):
@@ -223,7 +235,7 @@ def interactive_leg(a, nv, make_renderer, brick_off):
                           "image_bytes": int(st["bytes"]), "build_ms": round(st["build_ms"], 4), "builds_per_frame": round((st["builds"] - b0) / frames, 2)})
     api.neural_set_brick_budget(nv, 0)
     check(L.vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
-    out["small_cache_rebuilt_every_frame"] = small
+    out["budget_sweep_of_a_cache_rebuilt_every_frame"] = small
     out["training_step"] = api.vnrNeuralVolumeGetTrainingStep(nv)
     out["loss"] = round(api.vnrNeuralVolumeGetTrainingLoss(nv), 5)
     del ren

@@ -216,7 +216,10 @@ unsigned vnrAmdNeuralVolumeBrickImageLevels(vnrAmdVolume);
 /* how often the image has been built, and how many launches with unchanged parameters the next build waits for: 24 (VNR_AMD_BRICK_AFTER), doubled
  * whenever an optimizer step dropped an image that had served fewer than 64 launches -- an application that trains after every frame
  * (apps/int_dual_volume.cpp:631-672) must not pay a build per frame -- and back to 24 once an image has lived longer */
-int      vnrAmdNeuralVolumeBrickImagePolicy(vnrAmdVolume, uint64_t* builds, unsigned* launches_before_next_build);
+/* Two tiers: while the parameters keep changing, the first large evaluation launch (capacity >= 2^20 samples: a frame) after a change builds a SMALL
+ * image (the finest levels that fit VNR_AMD_BRICK_SMALL_GB, default 0.75 GiB: 0.25 ms for the C4 model) that the frame's launches earn back;
+ * tier: 0 no image, 1 small, 2 full.  Results do not depend on any of it. */
+int      vnrAmdNeuralVolumeBrickImagePolicy(vnrAmdVolume, uint64_t* builds, unsigned* launches_before_next_build, int* tier, uint64_t* small_builds);
 /* AMD extension (measurement): HIP events around the kernels of the training step; GetTrainProfile averages the last <= 64 steps:
  * ms_per_step = {forward, loss + MLP backward, weight gradients, grid backward (+ the exchange's pack kernels), optimizer} */
 int    vnrAmdNeuralVolumeSetTrainProfiling(vnrAmdVolume, int enable);

@@ -578,10 +578,10 @@ def neural_brick_image(v):
     """state of the de-hashed inference copy of the hashed levels (csrc/network.h)"""
     u, b, ms = C.c_int(), C.c_size_t(), C.c_float()
     check(lib().vnrAmdNeuralVolumeBrickImageInfo(v.h, C.byref(u), C.byref(b), C.byref(ms)))
-    builds, after = C.c_uint64(), C.c_uint()
-    check(lib().vnrAmdNeuralVolumeBrickImagePolicy(v.h, C.byref(builds), C.byref(after)))
+    builds, after, tier, small = C.c_uint64(), C.c_uint(), C.c_int(), C.c_uint64()
+    check(lib().vnrAmdNeuralVolumeBrickImagePolicy(v.h, C.byref(builds), C.byref(after), C.byref(tier), C.byref(small)))
     return {"in_use": bool(u.value), "bytes": b.value, "build_ms": ms.value, "levels": int(lib().vnrAmdNeuralVolumeBrickImageLevels(v.h)),
-            "builds": int(builds.value), "launches_before_next_build": int(after.value)}
+            "builds": int(builds.value), "launches_before_next_build": int(after.value), "tier": int(tier.value), "small_builds": int(small.value)}
 
 
 def neural_set_brick_budget(v, n_bytes):

@@ -972,12 +972,14 @@ unsigned vnrAmdNeuralVolumeBrickImageLevels(vnrAmdVolume v)
   guarded([&]() { m = as_neural(v)->network().brick_levels_mask(); });
   return m;
 }
-int vnrAmdNeuralVolumeBrickImagePolicy(vnrAmdVolume v, uint64_t* builds, unsigned* launches_before_next_build)
+int vnrAmdNeuralVolumeBrickImagePolicy(vnrAmdVolume v, uint64_t* builds, unsigned* launches_before_next_build, int* tier, uint64_t* small_builds)
 {
   return guarded([&]() {
     Network& n = as_neural(v)->network();
     if (builds) *builds = n.brick_builds();
     if (launches_before_next_build) *launches_before_next_build = n.brick_after_now();
+    if (tier) *tier = n.brick_tier();
+    if (small_builds) *small_builds = n.brick_small_builds();
   });
 }
 int vnrAmdNeuralVolumeSetTrainProfiling(vnrAmdVolume v, int e) { return guarded([&]() { as_neural(v)->network().set_train_profiling(e != 0); }); }

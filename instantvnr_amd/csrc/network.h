@@ -220,7 +220,9 @@ public:
   bool brick_image_in_use() const { return brick_valid_; }
   size_t brick_image_bytes() const { return brick_image_.bytes(); }
   float brick_build_ms() const { return brick_build_ms_; }
-  uint64_t brick_builds() const { return brick_builds_; }              // how many times the image has been built
+  uint64_t brick_builds() const { return brick_builds_; }              // how many times the (full) image has been built
+  uint64_t brick_small_builds() const { return brick_small_builds_; }  // ... and its small tier
+  int brick_tier() const { return brick_valid_ ? brick_tier_ : 0; }    // 0 none, 1 small, 2 full
   uint32_t brick_after_now() const;                                    // launches with unchanged parameters the next build waits for
 
 private:
@@ -228,8 +230,9 @@ private:
   void initialize_params(uint64_t seed, hipStream_t s);
   void refresh_inference_weights(hipStream_t s);
   FusedMlp fused_mlp() const;
-  const LevelInfo* inference_levels(hipStream_t s, const uint8_t** image) const;  // decides / builds / orders streams
-  void build_brick_image(hipStream_t s) const;
+  const LevelInfo* inference_levels(hipStream_t s, const uint8_t** image, size_t n_max) const;  // decides / builds / orders streams
+  void build_brick_image(hipStream_t s, bool small) const;
+  static double brick_small_budget();
 
   ModelConfig cfg_;
   Json model_;
@@ -271,6 +274,13 @@ private:
   static constexpr uint32_t kBrickPaysAfter = 64;
   mutable uint32_t brick_served_calls_ = 0, brick_after_scale_ = 1;
   mutable uint64_t brick_builds_ = 0;
+  // Two tiers (round 6).  FULL: the policy above.  SMALL: while the parameters keep changing, the first large evaluation launch after a change
+  // (capacity >= kBrickSmallMinLaunch samples: a frame, not a probe) builds the finest-first levels that fit brick_small_budget(), 0.25 ms for
+  // the bench model's 0.7 GB, which the frame's ~12 launches earn back: the reference application's loop 190 -> 200 frames/s.  A small image
+  // never counts towards the backoff above, and it is replaced by the full one once the parameters have been left alone.
+  static constexpr size_t kBrickSmallMinLaunch = (size_t)1 << 20;
+  mutable int brick_tier_ = 0;   // 0 none, 1 small, 2 full
+  mutable uint64_t brick_small_builds_ = 0;
   mutable float brick_build_ms_ = 0.0f;
   uint32_t brick_res_cap_ = 0;   // 0: no cap
   size_t brick_budget_ = 0;      // 0: default policy

@@ -254,11 +254,12 @@ void Network::refresh_inference_weights(hipStream_t s)
   launch_pack_mlp(params_f16_.ptr, mlp_packed_.ptr, mlp_packed_T_.ptr, in_width_, cfg_.n_neurons, n_hidden_matmuls(), s);
   // the parameters changed: the brick image is stale (it is rebuilt once they have been left alone again -- for longer if this image was
   // dropped before it had paid for itself: network.h)
-  if (brick_valid_) {
+  if (brick_valid_ && brick_tier_ == 2) {
     if (brick_served_calls_ < kBrickPaysAfter) brick_after_scale_ = std::min<uint32_t>(brick_after_scale_ * 2u, 1u << 16);
     else brick_after_scale_ = 1;
   }
   brick_valid_ = false;
+  brick_tier_ = 0;
   brick_stable_calls_ = 0;
   brick_served_calls_ = 0;
 }
@@ -270,6 +271,14 @@ static uint32_t brick_after_base()
 }
 
 uint32_t Network::brick_after_now() const { return brick_after_base() * brick_after_scale_; }
+
+double Network::brick_small_budget()
+{
+  // VNR_AMD_BRICK_SMALL_GB (0: no small tier).  0.75 GiB: swept on the bench model inside the reference application's loop (render, train one step,
+  // render ...; bench.py `interactive`): none 190.1, 0.25 GiB 196.4, 0.75 GiB 200.2, 1.7 GiB 195.0 frames/s -- the build is 0.25 ms at 0.7 GB.
+  static const double gb = [] { const char* e = std::getenv("VNR_AMD_BRICK_SMALL_GB"); return e ? std::max(0.0, std::atof(e)) : 0.75; }();
+  return gb * 1073741824.0;
+}
 
 Network::~Network()
 {
@@ -287,6 +296,7 @@ void Network::set_brick_mode(int mode)
     brick_image_.release();
     levels_brick_dev_.release();
     brick_valid_ = false;
+    brick_tier_ = 0;
   }
   brick_stable_calls_ = 0;
 }
@@ -300,6 +310,7 @@ void Network::set_brick_budget(size_t bytes)
     brick_image_.release();
     levels_brick_dev_.release();
     brick_valid_ = false;
+    brick_tier_ = 0;
   }
   brick_levels_mask_ = 0;
   brick_stable_calls_ = 0;
@@ -343,6 +354,7 @@ void Network::release_temporary()
   brick_image_.release();
   levels_brick_dev_.release();
   brick_valid_ = false;
+  brick_tier_ = 0;
   brick_stable_calls_ = 0;
   ws_features_.release(); ws_acts_.release(); ws_dfeat_.release();   // re-allocated by the next training step (ws_batch_ = 0)
   ws_batch_ = 0;
@@ -391,15 +403,88 @@ __global__ void brick_build_kernel(const LevelInfo lv, const half_t* __restrict_
   }
 }
 
+// The same image, a ROW OF BRICKS per block (round 6).  The kernel above gives every image entry a thread that de-hashes its grid point and
+// gathers 2 F bytes from an unrelated line of the table: one lane address per entry, 1.3 TB/s of image (6.5 ms for the 8.8 GB of the bench
+// model, 0.53 ms for the 0.7 GB an application that trains after every frame could afford per frame).  But along x the index function is
+// (x ^ h(y, z)) & mask (hashed) or x + const (dense): the 64 consecutive x of a wave read ONE aligned 64-entry block of the table, permuted.
+// So a block first copies its (y, z) rows -- the 2 x 2 (4 x 4 for F = 1) rows of grid points its bricks are made of, all x -- into LDS with
+// those coalesced loads, and then writes its bricks entry by entry in image order: coalesced stores of whole 128-byte lines.
+template <int F>
+__global__ void __launch_bounds__(256) brick_build_rows_kernel(const LevelInfo lv, const half_t* __restrict__ table, uint8_t* __restrict__ image,
+                                                               uint32_t nbx, uint32_t nby, uint32_t nbz)
+{
+  typedef typename FeatVec<F>::type vec_t;
+  constexpr uint32_t LX = F == 2 ? 3u : BrickShape<F>::lx, LY = F == 2 ? 1u : BrickShape<F>::ly, LZ = F == 2 ? 1u : BrickShape<F>::lz;
+  constexpr uint32_t E = 1u << (LX + LY + LZ), ROWS = 1u << (LY + LZ);
+  static_assert(E * F * 2 == 128, "a brick is one 128-byte line");
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+  vec_t* s_rows = (vec_t*)s_raw;                       // [ROWS][res + 1]
+  const uint32_t res = lv.resolution, nx = (res + 4u) & ~3u;   // row stride: whole groups of four grid points
+  const vec_t* src = (const vec_t*)(table + (size_t)lv.offset * F);
+  vec_t* out = (vec_t*)(image + (size_t)(lv.brick - 1u) * 128u);
+  for (uint32_t row = blockIdx.x; row < nby * nbz; row += gridDim.x) {   // a row of bricks: (by, bz)
+    const uint32_t by = row % nby, bz = row / nby;
+    for (uint32_t r = 0; r < ROWS; ++r) {
+      const uint32_t y = (by << LY) | (r & ((1u << LY) - 1u)), z = (bz << LZ) | (r >> LY);
+      const bool inside = y <= res && z <= res;        // (block-uniform)
+      if (F == 2 && lv.hashed == 1u && inside) {
+        // four grid points x4 .. x4 + 3 of a hashed level are the aligned group of four entries at (x4 ^ h) & mask & ~3, permuted by the low
+        // two bits of h (uniform over the row): one 16-byte load per lane
+        const uint32_t h = (y * 2654435761u) ^ (z * 805459861u), mask = lv.size - 1u, hl = h & 3u;
+        for (uint32_t x4 = threadIdx.x * 4u; x4 < nx; x4 += 1024u) {
+          const uint4_t v = *(const uint4_t*)(src + (((x4 ^ h) & mask) & ~3u));
+          uint4_t o;
+          if (hl == 0u) o = v; else if (hl == 1u) o = uint4_t{v.y, v.x, v.w, v.z}; else if (hl == 2u) o = uint4_t{v.z, v.w, v.x, v.y}; else o = uint4_t{v.w, v.z, v.y, v.x};
+          *(uint4_t*)(s_rows + r * nx + x4) = o;       // (grid points beyond res: read, never used)
+        }
+      } else {
+        for (uint32_t x = threadIdx.x; x < res + 1u; x += 256u) s_rows[r * nx + x] = inside ? src[level_index(lv, x, y, z)] : vec_t{};
+      }
+    }
+    __syncthreads();
+    vec_t* dst = out + (size_t)row * nbx * E;
+    if constexpr (F == 2) {   // four entries (16 bytes) per lane: columns 0..3 or 4..7 of a brick's row r
+      for (uint32_t t4 = threadIdx.x; t4 < nbx * 8u; t4 += 256u) {
+        const uint32_t b = t4 >> 3, r = (t4 >> 1) & 3u, x0 = b * 7u + (t4 & 1u) * 4u;   // the 8th column repeats the +x neighbour brick's first
+        const uint32_t* rowp = (const uint32_t*)(s_rows + r * nx);
+        uint4_t o;
+        o.x = x0 <= res ? rowp[x0] : 0u;
+        o.y = x0 + 1u <= res ? rowp[x0 + 1u] : 0u;
+        o.z = x0 + 2u <= res ? rowp[x0 + 2u] : 0u;
+        o.w = x0 + 3u <= res ? rowp[x0 + 3u] : 0u;
+        *(uint4_t*)(dst + (size_t)t4 * 4u) = o;
+      }
+    } else {
+      for (uint32_t t = threadIdx.x; t < nbx * E; t += 256u) {
+        const uint32_t b = t / E, w = t % E;
+        const uint32_t wx = w & ((1u << LX) - 1u), r = w >> LX;
+        const uint32_t x = (b << LX) | wx;
+        dst[t] = x <= res ? s_rows[r * nx + x] : vec_t{};
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int F>
 static void launch_brick_build(const LevelInfo& lv, const uint16_t* table, uint8_t* image, uint64_t n_entries, hipStream_t s)
 {
-  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_entries + 255) / 256, 1u << 20);
-  brick_build_kernel<F><<<blocks, 256, 0, s>>>(lv, (const half_t*)table, image, n_entries);
+  static const bool rows = [] { const char* e = std::getenv("VNR_AMD_BRICK_BUILD_ROWS"); return !e || std::atoi(e) != 0; }();   // 0: the per-entry kernel (A/B, tests)
+  constexpr uint32_t LX = F == 2 ? 3u : BrickShape<F>::lx, LY = F == 2 ? 1u : BrickShape<F>::ly, LZ = F == 2 ? 1u : BrickShape<F>::lz;
+  const uint64_t res = lv.resolution;
+  const uint32_t nbx = F == 2 ? lv.pad1 : (uint32_t)(res >> LX) + 1u, nby = (uint32_t)(res >> LY) + 1u, nbz = (uint32_t)(res >> LZ) + 1u;
+  const size_t shmem = (size_t)(1u << (LY + LZ)) * ((res + 4) & ~(uint64_t)3) * F * 2;
+  if (rows && shmem <= 64 * 1024 && (uint64_t)nbx * nby * nbz * (128u / (F * 2)) == n_entries) {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)nby * nbz, 1u << 20);
+    brick_build_rows_kernel<F><<<blocks, 256, shmem, s>>>(lv, (const half_t*)table, image, nbx, nby, nbz);
+  } else {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_entries + 255) / 256, 1u << 20);
+    brick_build_kernel<F><<<blocks, 256, 0, s>>>(lv, (const half_t*)table, image, n_entries);
+  }
   VNR_HIP_CHECK(hipGetLastError());
 }
 
-void Network::build_brick_image(hipStream_t s) const
+void Network::build_brick_image(hipStream_t s, bool small) const
 {
   // which levels: the hashed ones (VNR_AMD_BRICK_DENSE=1: every level), finest first, while the image stays within the budget
   static const bool dense_too = [] { const char* e = std::getenv("VNR_AMD_BRICK_DENSE"); return e && std::atoi(e) != 0; }();
@@ -411,8 +496,11 @@ void Network::build_brick_image(hipStream_t s) const
   static const double max_gb = [] { const char* e = std::getenv("VNR_AMD_BRICK_MAX_GB"); return e ? std::atof(e) : -1.0; }();
   size_t free_b = 0, total_b = 0;
   VNR_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-  const double policy = brick_budget_ ? (double)brick_budget_ : max_gb >= 0.0 ? max_gb * 1073741824.0 : (double)total_b / 16.0;
+  double policy = brick_budget_ ? (double)brick_budget_ : max_gb >= 0.0 ? max_gb * 1073741824.0 : (double)total_b / 16.0;
+  // the small tier (network.h): what an application that changes the parameters after every frame can afford to rebuild per frame
+  if (small) policy = std::min(policy, brick_small_budget());
   const uint64_t budget_lines = (uint64_t)std::min(policy, (double)(free_b + brick_image_.bytes()) / 4.0) / 128u;
+  const uint32_t mask_before = brick_valid_ ? brick_levels_mask_ : 0u;
   brick_levels_mask_ = 0;
   hipEvent_t t0, t1;
   VNR_HIP_CHECK(hipEventCreate(&t0)); VNR_HIP_CHECK(hipEventCreate(&t1));
@@ -438,7 +526,23 @@ void Network::build_brick_image(hipStream_t s) const
     used += n;
     brick_levels_mask_ |= 1u << l;
   }
-  if (used == 0) { brick_refused_ = true; (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); return; }
+  if (used == 0) {
+    if (!small) brick_refused_ = true;   // (nothing fits the small tier: the full one is still tried when its time comes)
+    brick_valid_ = false;
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    return;
+  }
+  // the small image of a model whose every bricked level fits the small budget IS the full image: the upgrade has nothing to rebuild
+  if (!small && brick_valid_ && mask_before == brick_levels_mask_ && brick_image_.bytes() == (used + 1) * 128u) {
+    brick_tier_ = 2;
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    return;
+  }
+  if (brick_image_.bytes() != (used + 1) * 128u) {
+    // (another size: nothing may still read the old image when it is freed -- launches of other streams that took its pointer)
+    if (brick_image_.bytes()) VNR_HIP_CHECK(hipDeviceSynchronize());
+    brick_valid_ = false;
+  }
   brick_image_.resize((used + 1) * 128u);   // + one spare line: a pair load at the last entry reads 2 entries
   VNR_HIP_CHECK(hipEventRecord(t0, s));
   for (uint32_t l = 0; l < grid_.n_levels; ++l) {
@@ -461,20 +565,27 @@ void Network::build_brick_image(hipStream_t s) const
   VNR_HIP_CHECK(hipEventElapsedTime(&brick_build_ms_, t0, t1));
   (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
   brick_valid_ = true;
+  brick_tier_ = small ? 1 : 2;
 }
 
-const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image) const
+const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image, size_t n_max) const
 {
   static const int env_mode = [] { const char* e = std::getenv("VNR_AMD_BRICK"); return e ? std::atoi(e) : -1; }();   // -1 auto, 0 off, 1 at once
   const int mode = brick_mode_ >= 0 ? brick_mode_ : env_mode;
   *image = nullptr;
   if (mode == 0 || brick_refused_) return levels_dev_.ptr;
-  if (!brick_valid_) {
-    if (++brick_stable_calls_ <= (mode == 1 ? 0u : brick_after_now())) return levels_dev_.ptr;
-    build_brick_image(s);
+  if (brick_tier_ != 2 || !brick_valid_) {
+    if (brick_stable_calls_ < 0xffffffffu) ++brick_stable_calls_;
+    const bool want_full = mode == 1 || brick_stable_calls_ > brick_after_now();
+    if (want_full) {
+      // (an upgrade from the small tier re-reads an image other streams may still be reading: build_brick_image synchronises before it frees)
+      build_brick_image(s, false);
+      if (brick_valid_ && brick_tier_ == 2) { ++brick_builds_; brick_served_calls_ = 0; }
+    } else if (!brick_valid_ && n_max >= kBrickSmallMinLaunch && brick_small_budget() > 0.0) {
+      build_brick_image(s, true);
+      if (brick_valid_) ++brick_small_builds_;
+    }
     if (!brick_valid_) return levels_dev_.ptr;
-    ++brick_builds_;
-    brick_served_calls_ = 0;
   }
   if (brick_served_calls_ < 0xffffffffu) ++brick_served_calls_;
   // the image was built on one stream and build_brick_image returned only after the host had seen the build complete, so launches
@@ -539,7 +650,7 @@ void Network::inference(const float* d_coords, float* d_out, size_t n, const uin
                         const uint32_t* d_dest) const
 {
   const uint8_t* image;
-  const LevelInfo* levels = inference_levels(s, &image);
+  const LevelInfo* levels = inference_levels(s, &image, d_n ? n_max : n);
   GridDevice grid = grid_;
   grid.n_levels = n_active_levels();   // masked levels encode to zero, like the padding
   launch_fused(0, grid, in_width_, fused_mlp(), levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2, d_coords, d_out, nullptr, nullptr, n, d_n, n_max, s, d_dest, 0, image);
@@ -549,7 +660,7 @@ bool Network::inference_queue(const float* d_records, float* d_out, uint32_t out
                               uint32_t sharers, const PackArgs* pack) const
 {
   const uint8_t* image;
-  const LevelInfo* levels = inference_levels(s, &image);
+  const LevelInfo* levels = inference_levels(s, &image, n_max);
   GridDevice grid = grid_;
   grid.n_levels = n_active_levels();
   if (cfg_.n_neurons == 128u) pack = nullptr;   // blocks of 8 waves: the caller launches the packing kernel itself
@@ -572,7 +683,7 @@ bool Network::tile_net(TileNet* out, hipStream_t s) const
   if (!weights_in_lds()) return false;   // (a deeper network reads its weights from global memory: evaluation kernels only)
   if (n_grid_params() * 2 >= (1ull << 32)) throw std::runtime_error("hash table >= 4 GiB is not supported");
   const uint8_t* image;
-  const LevelInfo* levels = inference_levels(s, &image);
+  const LevelInfo* levels = inference_levels(s, &image, kBrickSmallMinLaunch);   // (a frame evaluated inside the marching / tracking loop)
   out->levels = levels;
   out->n_levels = n_active_levels();
   out->interpolation = grid_.interpolation;
@@ -595,7 +706,7 @@ bool Network::tile_net(TileNet* out, hipStream_t s) const
 void Network::encode(const float* d_coords, uint16_t* d_features, size_t n, hipStream_t s) const
 {
   const uint8_t* image;
-  const LevelInfo* levels = inference_levels(s, &image);
+  const LevelInfo* levels = inference_levels(s, &image, n);
   GridDevice grid = grid_;
   grid.n_levels = n_active_levels();
   launch_fused(1, grid, in_width_, fused_mlp(), levels, params_f16_.ptr + n_mlp_, n_grid_params() * 2, d_coords, nullptr, d_features, nullptr, n, nullptr, n, s, nullptr, 0, image);

@@ -131,6 +131,44 @@ def test_eight_unpinned_shares_of_the_1024x1024_frame_equal_the_frame_at_32(big_
     assert np.array_equal(small_frame(big_scene), r)
 
 
+def test_the_small_cache_tier_serves_a_train_while_render_loop_bit_for_bit(big_scene, monkeypatch):
+    """the reference application's loop (apps/int_dual_volume.cpp:631-672) at a frame size whose launches qualify (capacity >= 2^20 samples): after
+    every training call the frame's first launch builds the SMALL tier of the inference cache (network.h), every frame of the loop is the frame
+    the same parameters give with the cache switched off, the full tier's backoff is not touched, and once the parameters are left alone the
+    full image replaces the small one"""
+    monkeypatch.setenv("VNR_RM_N_ITERS", "24")
+    from instantvnr_amd._lib import check, lib
+    nv = big_scene["nv"]
+    check(lib().vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
+    r = api.vnrCreateRenderer(nv)
+    api.vnrRendererSetTransferFunction(r, big_scene["tfn"])
+    api.vnrRendererSetCamera(r, big_scene["camera"])
+    api.vnrRendererSetFramebufferSize(r, (1024, 1024))
+    api.vnrRendererSetMode(r, 5)
+    st0 = api.neural_brick_image(nv)
+    for i in range(4):
+        api.vnrNeuralVolumeTrain(nv, 2, False)
+        api.vnrRendererResetAccumulation(r)
+        api.vnrRender(r)
+        got = api.vnrRendererMapFrame(r).copy()
+        st = api.neural_brick_image(nv)
+        assert st["tier"] == 1 and st["in_use"], st
+        check(lib().vnrAmdNeuralVolumeSetBrickImageMode(nv.h, 0))      # the same parameters without any cache
+        api.vnrRendererResetAccumulation(r)
+        api.vnrRender(r)
+        want = api.vnrRendererMapFrame(r).copy()
+        check(lib().vnrAmdNeuralVolumeSetBrickImageMode(nv.h, -1))
+        assert not api.neural_brick_image(nv)["in_use"]
+        assert (want[..., 3] > 0).mean() > 0.2 and np.array_equal(got, want), i
+    st = api.neural_brick_image(nv)
+    assert st["small_builds"] - st0["small_builds"] == 4 and st["builds"] == st0["builds"]
+    assert st["launches_before_next_build"] == st0["launches_before_next_build"]        # small images do not move the full tier's backoff
+    for _ in range(2 + st["launches_before_next_build"] // 4):
+        api.vnrRender(r); api.vnrRendererMapFrame(r)
+    st = api.neural_brick_image(nv)
+    assert st["tier"] == 2 and st["builds"] == st0["builds"] + 1, st
+
+
 def small_frame(scene):
     r = api.vnrCreateRenderer(scene["nv"])
     api.vnrRendererSetTransferFunction(r, scene["tfn"])

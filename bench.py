@@ -124,7 +124,7 @@ EVAL_KERNEL_SOURCES = ("infer_kernel.h", "infer_tile.h", "grid_device.h", "netwo
 
 
 def sources_sha16(files):
-    """names what a kernel is compiled from: counter results of separate rocprofv3 --pmc passes (profiles/r05_*.json carry `source_files` and
+    """names what a kernel is compiled from: counter results of separate rocprofv3 --pmc passes (profiles/r06_*.json carry `source_files` and
     `source_sha16`) enter the line only while this still gives the hash they were stamped with"""
     import hashlib
     import re
@@ -848,11 +848,11 @@ def main():
         fresh = doc.get("source_files") and doc.get("source_sha16") == sources_sha16(doc["source_files"])
         return (doc, path) if fresh else (None, path)
 
-    mfma_doc, _ = counters_of("r05_mfma_pmc.json")
+    mfma_doc, _ = counters_of("r06_mfma_pmc.json")
     if mfma_doc and "mfma" in roofline and brick_state["in_use"]:
         roofline["mfma"]["util_by_counters"] = mfma_doc["util_by_counters"]
-        roofline["mfma"]["util_source"] += "; profiles/r05_mfma_pmc.json"
-    pmc, pmc_path = counters_of("r05_pmc_traffic.json")
+        roofline["mfma"]["util_source"] += "; profiles/r06_mfma_pmc.json"
+    pmc, pmc_path = counters_of("r06_pmc_traffic.json")
     if pmc and brick_state["in_use"]:
         leg = pmc["one_stream" if halves == 1 else "two_streams"]
         per_sample = leg.get("bytes_per_sample") or leg["traffic_over_algorithmic"] * bytes_per_sample
@@ -872,7 +872,7 @@ def main():
             ps1 = one.get("bytes_per_sample") or one["traffic_over_algorithmic"] * bytes_per_sample
             roofline["alone"]["traffic"] = round(ps1 * alone["samples"] / max(alone["launches"], 1))
     else:
-        roofline["traffic_note"] = ("null: the committed PMC passes (profiles/r05_pmc_traffic.json) describe the default workload on one GPU with the brick image, for the "
+        roofline["traffic_note"] = ("null: the committed PMC passes (profiles/r06_pmc_traffic.json) describe the default workload on one GPU with the brick image, for the "
                                     "kernel sources named by their source_sha16" + ("; this build's differ" if pmc_path and default_workload and ctx.world == 1 else ""))
     if brick_off:
         ev = brick_off["samples"] * evals_per_sample
@@ -886,10 +886,10 @@ def main():
             ev1 = brick_off["alone_samples"] * evals_per_sample
             leg["kernel_alone_frac"] = round(ev1 * bytes_per_sample / (brick_off["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             leg["kernel_alone_msamples_per_s"] = round(ev1 / (brick_off["alone_ms"] * 1e-3) / 1e6, 1)
-        off, _ = counters_of("r05_pmc_traffic_brick_off.json")
+        off, _ = counters_of("r06_pmc_traffic_brick_off.json")
         if off:
             leg["traffic_bytes_per_sample"] = {"two_streams": round(off["two_streams"]["bytes_per_sample"], 1), "one_stream": round(off["one_stream"]["bytes_per_sample"], 1),
-                                               "note": "separate rocprofv3 --pmc passes of this frame with VNR_AMD_BRICK=0 (profiles/r05_pmc_traffic_brick_off.json), not this run"}
+                                               "note": "separate rocprofv3 --pmc passes of this frame with VNR_AMD_BRICK=0 (profiles/r06_pmc_traffic_brick_off.json), not this run"}
         roofline["brick_off"] = leg
 
     # ---- training step: algorithmic bytes per SURVEY 8(d) and the live per-kernel split -------------------------------------------
@@ -925,7 +925,7 @@ def main():
         req_flush_max += slices * (lv[l]["entries"] * F * 2 // 64)
     gb_ms = kernel_ms[3]
     greq = (req_atomic + req_flush_max) / (gb_ms * 1e-3) / 1e9 if gb_ms > 0 else 0.0
-    atomic_doc, _ = counters_of("r05_train_atomic_pmc.json")
+    atomic_doc, _ = counters_of("r06_train_atomic_pmc.json")
     train_roofline = {"bound": "memory-side atomic requests (the grid backward, the step's largest phase)", "unit": "G requests/s",
                       "peak": round(ATOMIC_PEAK_GREQ, 1), "achieved": round(greq, 2), "frac": round(greq / ATOMIC_PEAK_GREQ, 4),
                       "phase": "grid backward", "phase_ms": round(gb_ms, 4), "phase_share_of_step": round(gb_ms / max(step_kernel_ms, 1e-9), 3),
@@ -933,7 +933,7 @@ def main():
                                             "what": "atomic kernel: 65 536 samples x 4 yz-corner pairs x levels, one 64-B request each; LDS tiles: slices x "
                                                     "level bytes / 64 (pairs nobody touched are skipped, so fewer)"},
                       "requests_by_counters": None if not atomic_doc else atomic_doc.get("requests_per_step"),
-                      "counters_source": "TCC_EA0_ATOMIC_sum of grid_backward_kernel + grid_backward_lds_kernel, separate rocprofv3 --pmc pass (profiles/r05_train_atomic_pmc.json)",
+                      "counters_source": "TCC_EA0_ATOMIC_sum of grid_backward_kernel + grid_backward_lds_kernel, separate rocprofv3 --pmc pass (profiles/r06_train_atomic_pmc.json)",
                       "peak_source": "MI355X_MICROARCH.md 'Global float atomics': ~1.3 TB/s of added bytes = one 256-B wave instruction (four 64-B requests) per ~50 ns and CU",
                       "ms_per_step_wall": round(train_ms, 4), "ms_per_step_kernels": round(step_kernel_ms, 4), "profiled_steps": int(n_prof.value),
                       "kernels_ms": {n: round(v, 4) for n, v in zip(names, kernel_ms)},

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Digest of the round-5 counter passes (tools/r05_infer_bound.sh: one rocprofv3 --pmc pass per hardware block on the whole bench frame):
+"""Digest of the round-5 counter passes (tools/r06_infer_bound.sh: one rocprofv3 --pmc pass per hardware block on the whole bench frame):
 
   pmc_digest.py <dir with <pass>.summary.txt> <out dir>
     -> <out>/r05_infer_bound.txt            what bounds fused_infer_kernel: per-dispatch means of every counter, derived ratios, a reading
@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 EVAL = "fused_infer_kernel<2, 32, 64, 0, false>"
+ROUND = os.environ.get("VNR_PROFILE_ROUND", "r06")   # prefix of the files written (profiles/<round>_*)
 TRAIN_SOURCES = ("network_train.hip", "grid_device.h")
 
 
@@ -40,7 +41,7 @@ def main():
     d, out = sys.argv[1], sys.argv[2]
     passes = {n[:-len(".summary.txt")]: read(os.path.join(d, n)) for n in sorted(os.listdir(d)) if n.endswith(".summary.txt")}
     lines = ["fused_infer_kernel<2, 32, 64, 0, false> on the C4 bench frame (1024^2, L16 F2 T2^22 + 3x64): hardware counters, one rocprofv3 --pmc pass per",
-             "block (tools/r05_infer_bound.sh; the program itself after `--`; counters only).  Per-dispatch MEANS; a dispatch evaluates ~3.4 M samples",
+             "block (tools/r06_infer_bound.sh; the program itself after `--`; counters only).  Per-dispatch MEANS; a dispatch evaluates ~3.4 M samples",
              "(~53 k wave tiles of 64).  Under --pmc the dispatches are serialised, so these describe the kernel with the GPU to itself.", ""]
     tiles_on = [0.0]
     for leg, label in (("on", "brick image in use (the bench default)"), ("off", "brick image off: the hashed parameter blob")):
@@ -67,7 +68,7 @@ def main():
                     tiles_on[0] = g("SQ_INSTS_VMEM_RD") / 65.0   # with the image every level is 4 gathers: 64 + the queue record per tile of 64 samples
                 tiles = tiles_on[0] or g("SQ_INSTS_VMEM_RD") / 65.0
                 lines.append(f"   -> per wave tile of 64 samples: VALU instructions {g('SQ_INSTS_VALU') / tiles:.0f}, SALU {g('SQ_INSTS_SALU') / tiles:.0f}, VMEM reads {g('SQ_INSTS_VMEM_RD') / tiles:.0f}"
-                             + (" (64 gathers + the queue record)" if leg == "on" else " (hashed levels: a second gather per row for the lanes whose x is odd)"))
+                             + (" (64 gathers + the queue record)" if leg == "on" else " (hashed levels: a second gather per row for the lanes whose x is 3 mod 4; every odd x until round 5)"))
                 lines.append(f"   -> VALU issue: {g('SQ_INSTS_VALU') * 4 / (1024 * T):.3f} of the SIMD cycles (4 cycles per wave64 instruction, 1024 SIMDs)")
             if g("TA_TA_BUSY_sum"):
                 lines.append(f"   -> texture addresser busy {g('TA_TA_BUSY_sum') / 256 / T:.3f} of the time (TA_TA_BUSY summed over 256 TAs)")
@@ -79,19 +80,9 @@ def main():
             if g("SQ_VALU_MFMA_BUSY_CYCLES"):
                 lines.append(f"   -> matrix cores busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / (1024 * T):.4f} of the SIMD cycles")
         lines.append("")
-    lines += ["Reading.  The texture path is the busiest unit of the kernel and it is not saturated: the texture addresser is busy two thirds of the time",
-              "with the brick image (four fifths on the hashed blob), the vector L1 sits with requests pending ~45 % of the time, an L2 read takes ~550",
-              "cycles, 10 % of the L1 accesses and 43 % of the L2 requests miss.  The vector ALUs issue in 54 % of the cycles (42 %): the encode is ~87 VALU",
-              "instructions per level and sample -- position, brick index, eight weights and the reference's fp16 accumulate corner by corner, whose",
-              "length the bit-exact blend fixes; the matrix cores are busy 10 %.  A wave spends 64 % (56 %) of its life waiting, and with four waves per",
-              "SIMD (101 VGPRs) the SIMDs idle about a quarter of the time.  So the kernel is bound neither by HBM bytes (686 MB per dispatch = 0.33 of the",
-              "peak over its duration; 1.5 GB = 0.54 without the image) nor by MFMA, but by the request turn-around of the TA / L1 / L2 path at this",
-              "occupancy.  More requests in flight per wave do NOT help: two tiles per wave (twice the loads, same occupancy) measured 7 % slower and",
-              "grouped loads 12 % slower in round 2, five waves per SIMD 7 % slower (docs/history/DESIGN_r01-r03.md 4.1); fewer distinct (instruction, line)",
-              "pairs do: the ghost-column brick (4 gathers per level, no fix-ups) bought 5 % in round 2, finer per-wave sample orders <= 3 %",
-              "(profiles/r02_sample_order_and_quad_brick.txt), and that is where the kernel stands.", ""]
+    # (the reading of these numbers is written by hand under the file in profiles/: a paragraph generated here would keep last round's figures)
     os.makedirs(out, exist_ok=True)
-    open(os.path.join(out, "r05_infer_bound.txt"), "w").write("\n".join(lines))
+    open(os.path.join(out, ROUND + "_infer_bound.txt"), "w").write("\n".join(lines))
     print("\n".join(lines))
 
     # ---- JSON for bench.py ----------------------------------------------------------------------------------------------------
@@ -101,7 +92,7 @@ def main():
         json.dump({"what": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of fused_infer_kernel<2,32,64,0,false> on the bench frame, brick image in use",
                    "util_by_counters": round(util, 4), "dispatches": mf["GRBM_GUI_ACTIVE"][0], "counters": {k: v[1] for k, v in mf.items()},
                    "source_files": list(bench.EVAL_KERNEL_SOURCES), "source_sha16": bench.sources_sha16(bench.EVAL_KERNEL_SOURCES)},
-                  open(os.path.join(out, "r05_mfma_pmc.json"), "w"), indent=1)
+                  open(os.path.join(out, ROUND + "_mfma_pmc.json"), "w"), indent=1)
     at = passes.get("tcc_atomic", {})
     # (the step's default form runs the hashed levels through grid_backward_kernel; VNR_AMD_TRAIN_OVERLAP=1: grid_backward_persistent_kernel)
     gb = kernel(at, "grid_backward_persistent_kernel") or kernel(at, "grid_backward_kernelI") or kernel(at, "grid_backward_kernel<")
@@ -112,7 +103,7 @@ def main():
                                          "total": round(gb["TCC_EA0_ATOMIC_sum"][1] + gl.get("TCC_EA0_ATOMIC_sum", (0, 0))[1])},
                    "dispatches": gb["TCC_EA0_ATOMIC_sum"][0],
                    "source_files": list(TRAIN_SOURCES), "source_sha16": bench.sources_sha16(TRAIN_SOURCES)},
-                  open(os.path.join(out, "r05_train_atomic_pmc.json"), "w"), indent=1)
+                  open(os.path.join(out, ROUND + "_train_atomic_pmc.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -3,15 +3,15 @@
 # program itself after `--`) on the whole bench frame, brick image on (the bench default) and off (the hashed parameter blob).
 # The SQ pass ran on bench.py's short form; a TA pass on it hung in the volume generator (the intermittent hang of tools/run_pmc.sh's
 # header), so the others go through tools/share_probe.py (same volume, model, camera and frame; 300 training steps), as round 3's did.
-#   usage: R05_PASSES="<regex of pass names>" bash tools/r05_infer_bound.sh   -> gpurun_out/r05_bound/<pass>.summary.txt
+#   usage: R06_PASSES="<regex of pass names>" bash tools/r06_infer_bound.sh   -> gpurun_out/r06_bound/<pass>.summary.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r05_bound; mkdir -p $O
+O=$R/gpurun_out/r06_bound; mkdir -p $O
 cd $R
 export TMPDIR=/tmp SHARE_PARTS=1 SHARE_FRAMES=3
-BENCH="$R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-psnr --no-alone --no-brick-off --no-brick-table --train-steps 300"
+BENCH="$R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-psnr --no-alone --no-brick-off --no-brick-table --no-interactive --train-steps 300"
 pass() {   # name, program (bench / share), brick (1 / 0), counters
   local name=$1 prog=$2 brick=$3; shift 3
-  [[ "$name" =~ ${R05_PASSES:-.} ]] || return 0
+  [[ "$name" =~ ${R06_PASSES:-.} ]] || return 0
   export VNR_AMD_BRICK=$brick
   if [ $prog = bench ]; then
     (cd /tmp && timeout -s ABRT -k 10 170 rocprofv3 --pmc "$@" --output-format csv -d $O/$name -o p -- python3 -X faulthandler $BENCH) > $O/$name.log 2>&1
@@ -19,7 +19,7 @@ pass() {   # name, program (bench / share), brick (1 / 0), counters
     (cd /tmp && timeout -s ABRT -k 10 110 rocprofv3 --pmc "$@" --output-format csv -d $O/$name -o p -- python3 -X faulthandler $R/tools/share_probe.py) > $O/$name.log 2>&1
   fi
   local rc=$?
-  echo "[r05_bound] $name rc=$rc"
+  echo "[r06_bound] $name rc=$rc"
   local f=$(ls $O/$name/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python3 tools/pmc_summary.py per-kernel "$f" > $O/$name.summary.txt && grep -E "fused_infer_kernel<2, 32, 64, 0|grid_backward" $O/$name.summary.txt | cut -c1-200
   find $O -name "*.csv" -size +4M -delete

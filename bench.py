@@ -588,7 +588,7 @@ def main():
         return rr
 
     # HIP events around every launch of the evaluation kernel, on the stream it is launched on.  With more than one rank they stay
-    # out of the timed region (two timed events per launch are 6 % of the frame time of a 1/8 share, tools/scratch/r02_share_prof.sh) and an
+    # out of the timed region (two timed events per launch are 6 % of the frame time of a 1/8 share, docs/history/DESIGN_r01-r03.md 6) and an
     # un-timed leg behind it measures the launches instead.
     events_in_timed_region = not a.no_kernel_events and ctx.world == 1
     ren = make_renderer(nv, device_output=False, profiling=events_in_timed_region)
@@ -816,7 +816,7 @@ def main():
                              "fps_one_stream": alone["fps"],
                              "mfma_tflops": round(ev * flops_per_sample / (alone["ms"] * 1e-3) / 1e12, 2)}
     # the matrix cores' share of the kernel (north star: "MFMA utilisation on the MLP against the chip's peaks"): flops of this run's samples over
-    # the union time, against the dense fp16 peak; the counter-based figure comes from a separate rocprofv3 --pmc pass (tools/scratch/r04_mfma_pmc.sh)
+    # the union time, against the dense fp16 peak; the counter-based figure comes from a separate rocprofv3 --pmc pass (tools/r06_infer_bound.sh, pass mfma_on)
     MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense fp16 / bf16
     if union_ms > 0:
         tf = samples_evt * flops_per_sample / (union_ms * 1e-3) / 1e12
@@ -912,17 +912,8 @@ def main():
     # are (sample, x bit, feature pair) with the two x-neighbours of a corner pair adjacent, i.e. ONE request per (sample, level, yz corner)
     # for n_features <= 8; the dense coarse levels go through LDS tiles and flush at most entries x F x 2 B / 64 B requests per slice.
     ATOMIC_PEAK_GREQ = 4 * 256 / 50e-9 / 1e9
-    lv = api.neural_level_table(nv)   # the library's own layout (vnrAmdNeuralVolumeLevelTable): no restatement of tcnn's level sizing here
-    tile_entries = (24 * 1024 // (4 * F)) & ~15
-    lds_levels = 0
-    while lds_levels < Lv and lv[lds_levels]["kind"] == 0 and -(-lv[lds_levels]["entries"] // tile_entries) <= 64:
-        lds_levels += 1
-    req_atomic = B * 4 * (Lv - lds_levels)
-    req_flush_max = 0
-    for l in range(lds_levels):
-        tiles = -(-lv[l]["entries"] // tile_entries)
-        slices = max(4, min(128, 768 // tiles))
-        req_flush_max += slices * (lv[l]["entries"] * F * 2 // 64)
+    plan = api.neural_grid_backward_plan(nv, B)   # the library's own layout and request count (environment overrides and level masking included: ADVICE r05)
+    lds_levels, req_atomic, req_flush_max = plan["lds_levels"], plan["atomic_requests"], plan["flush_requests_at_most"]
     gb_ms = kernel_ms[3]
     greq = (req_atomic + req_flush_max) / (gb_ms * 1e-3) / 1e9 if gb_ms > 0 else 0.0
     atomic_doc, _ = counters_of("r06_train_atomic_pmc.json")

@@ -220,6 +220,11 @@ unsigned vnrAmdNeuralVolumeBrickImageLevels(vnrAmdVolume);
  * image (the finest levels that fit VNR_AMD_BRICK_SMALL_GB, default 0.75 GiB: 0.25 ms for the C4 model) that the frame's launches earn back;
  * tier: 0 no image, 1 small, 2 full.  Results do not depend on any of it. */
 int      vnrAmdNeuralVolumeBrickImagePolicy(vnrAmdVolume, uint64_t* builds, unsigned* launches_before_next_build, int* tier, uint64_t* small_builds);
+/* the layout of a training step's grid backward for `batch` samples, from the library itself (environment overrides, level masking and
+ * alignment rules included): out_u32 = {active levels, levels scattered through LDS tiles, entries per tile, blocks per LDS level};
+ * out_u64 = {memory-side atomic requests of the global-atomic kernel, upper bound of the LDS tiles' flush requests}: what bench.py's
+ * train_roofline is priced with (no restatement of these rules outside the library) */
+int      vnrAmdNeuralVolumeGridBackwardPlan(vnrAmdVolume, uint64_t batch, uint32_t out_u32[4], uint64_t out_u64[2]);
 /* AMD extension (measurement): HIP events around the kernels of the training step; GetTrainProfile averages the last <= 64 steps:
  * ms_per_step = {forward, loss + MLP backward, weight gradients, grid backward (+ the exchange's pack kernels), optimizer} */
 int    vnrAmdNeuralVolumeSetTrainProfiling(vnrAmdVolume, int enable);

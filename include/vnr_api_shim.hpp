@@ -12,6 +12,7 @@
 
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -221,7 +222,21 @@ inline void vnrVolumeSetScaling(vnrVolume v, vnr::vec3f s) { const float a[3] = 
 inline vnr::range1f vnrVolumeGetValueRange(vnrVolume v) { float r[2]; vnr::shim::check(vnrAmdVolumeGetValueRange(v.get(), r)); return vnr::range1f{r[0], r[1]}; }
 
 // ---- transfer function (api.h:154-162) ---------------------------------------------------------------------------
-inline vnrTransferFunction vnrCreateTransferFunction() { return vnrTransferFunction(vnr::shim::check_ptr(vnrAmdCreateTransferFunction()), vnrAmdReleaseTransferFunction); }
+// api.h:160-162 return references into the transfer function object.  The handle is opaque here, so the shim keeps a copy per handle
+// (refreshed on every getter call); the copy lives exactly as long as the handle: the handle's deleter erases it, so an address the
+// allocator hands out again never meets a stale entry.  A mutex, because the last owner of a handle may be another
+// thread than the one that drives the API (the reference's apps hand frames to a UI thread).
+namespace vnr { namespace shim {
+struct TfnCopy { std::vector<vnr::vec3f> color; std::vector<vnr::vec2f> alpha; vnr::range1f range{0.0f, 1.0f}; };
+inline std::mutex& tfn_copies_mutex() { static std::mutex m; return m; }
+inline std::map<const void*, TfnCopy>& tfn_copies() { static std::map<const void*, TfnCopy> copies; return copies; }
+inline void release_transfer_function(vnrAmdTransferFunction h)
+{
+  { std::lock_guard<std::mutex> g(tfn_copies_mutex()); tfn_copies().erase((const void*)h); }
+  vnrAmdReleaseTransferFunction(h);
+}
+} }
+inline vnrTransferFunction vnrCreateTransferFunction() { return vnrTransferFunction(vnr::shim::check_ptr(vnrAmdCreateTransferFunction()), vnr::shim::release_transfer_function); }
 // api.h:155.  The reference decodes the scene's transfer function with OVR's tfn module (tfn::loadTransferFunction,
 // serializer.cpp:192-193), which is not in its tree; an app that links that module passes its decoder in (colours, (position,
 // alpha) pairs), and the value range comes from the scene exactly as create_scene_vidi__tfn takes it (serializer.cpp:212-256).
@@ -254,15 +269,13 @@ inline vnrTransferFunction vnrCreateTransferFunction(const vnrJson& scene_or_pat
 inline void vnrTransferFunctionSetColor(vnrTransferFunction t, const std::vector<vnr::vec3f>& c) { vnr::shim::check(vnrAmdTransferFunctionSetColor(t.get(), c.empty() ? nullptr : &c[0].x, (int)c.size())); }
 inline void vnrTransferFunctionSetAlpha(vnrTransferFunction t, const std::vector<vnr::vec2f>& a) { vnr::shim::check(vnrAmdTransferFunctionSetAlpha(t.get(), a.empty() ? nullptr : &a[0].x, (int)a.size())); }
 inline void vnrTransferFunctionSetValueRange(vnrTransferFunction t, vnr::range1f r) { vnr::shim::check(vnrAmdTransferFunctionSetValueRange(t.get(), r.lower, r.upper)); }
-// api.h:160-162 return references into the transfer function object.  The handle is opaque here, so the shim keeps a copy
-// per handle (refreshed on every call); a returned reference stays valid until the next getter call on the same handle
-// or until the handle dies, which covers how the reference's apps use it.
+// (the per-handle copies declared with vnrCreateTransferFunction above: a returned reference stays valid until the next getter call on the
+// same handle or until the handle dies, which covers how the reference's apps use it)
 namespace vnr { namespace shim {
-struct TfnCopy { std::vector<vnr::vec3f> color; std::vector<vnr::vec2f> alpha; vnr::range1f range{0.0f, 1.0f}; };
 inline TfnCopy& tfn_copy(const vnrTransferFunction& t)
 {
-  static std::map<const void*, TfnCopy> copies;
-  TfnCopy& c = copies[t.get()];
+  std::lock_guard<std::mutex> g(tfn_copies_mutex());
+  TfnCopy& c = tfn_copies()[t.get()];
   int nc = 0, na = 0;
   check(vnrAmdTransferFunctionGetSizes(t.get(), &nc, &na));
   c.color.resize((size_t)nc); c.alpha.resize((size_t)na);

@@ -210,6 +210,7 @@ def lib():
     sig("vnrAmdNeuralVolumeSetBrickImageMode", I, P, I)
     sig("vnrAmdNeuralVolumeSetBrickImageBudget", I, P, SZ)
     sig("vnrAmdNeuralVolumeBrickImageLevels", C.c_uint, P)
+    sig("vnrAmdNeuralVolumeGridBackwardPlan", I, P, U64, C.POINTER(U32), C.POINTER(U64))
     sig("vnrAmdNeuralVolumeBrickImagePolicy", I, P, C.POINTER(U64), C.POINTER(C.c_uint), IP, C.POINTER(U64))
     sig("vnrAmdNeuralVolumeSetTrainProfiling", I, P, I)
     sig("vnrAmdNeuralVolumeGetTrainProfile", I, P, C.POINTER(D), IP)

@@ -602,6 +602,13 @@ def neural_info(v):
     return d
 
 
+def neural_grid_backward_plan(v, batch=65536):
+    """the training step's grid-backward layout and its memory-side atomic requests, from the library (vnrAmdNeuralVolumeGridBackwardPlan)"""
+    u32, u64 = (C.c_uint32 * 4)(), (C.c_uint64 * 2)()
+    check(lib().vnrAmdNeuralVolumeGridBackwardPlan(v.h, int(batch), u32, u64))
+    return {"n_levels": u32[0], "lds_levels": u32[1], "tile_entries": u32[2], "lds_blocks": u32[3], "atomic_requests": int(u64[0]), "flush_requests_at_most": int(u64[1])}
+
+
 def neural_level_table(v):
     """the hash grid's levels as the library laid them out: list of dicts(res, entries, offset, kind) (kind: 0 dense, 1 hash, 2-4 tiled)"""
     a = [np.zeros(32, np.uint32) for _ in range(4)]

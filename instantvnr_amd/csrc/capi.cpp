@@ -99,6 +99,12 @@ void Runtime::init(int dev)
     else if (const char* e2 = std::getenv("VNR_CUDA_DEVICE")) dev = std::atoi(e2);  // renderer.cpp:300
   }
   if (dev >= count) throw std::runtime_error("[vnr] device index out of range");
+  // Moving to another device destroys the library's streams (the ray parts' pool included, whose handles live renderers hold) and strands
+  // every buffer on the old device: only an empty library may move.  A rank binds its device first: vnrAmdDistInit* before
+  // any volume or renderer.
+  if (ready() && dev != device && bytes_renderer + bytes_network > 0)
+    throw std::runtime_error("[vnr] the library runs on device " + std::to_string(device) + " and holds " + std::to_string(bytes_renderer + bytes_network) +
+                             " bytes there: release every volume and renderer before moving it to device " + std::to_string(dev));
   VNR_HIP_CHECK(hipSetDevice(dev));
   hipDeviceProp_t prop;
   VNR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
@@ -980,6 +986,14 @@ int vnrAmdNeuralVolumeBrickImagePolicy(vnrAmdVolume v, uint64_t* builds, unsigne
     if (launches_before_next_build) *launches_before_next_build = n.brick_after_now();
     if (tier) *tier = n.brick_tier();
     if (small_builds) *small_builds = n.brick_small_builds();
+  });
+}
+int vnrAmdNeuralVolumeGridBackwardPlan(vnrAmdVolume v, uint64_t batch, uint32_t out_u32[4], uint64_t out_u64[2])
+{
+  return guarded([&]() {
+    const GridBackwardPlan p = as_neural(v)->network().grid_backward_plan((size_t)batch);
+    if (out_u32) { out_u32[0] = p.n_levels; out_u32[1] = p.lds_levels; out_u32[2] = p.tile_entries; out_u32[3] = p.lds_blocks; }
+    if (out_u64) { out_u64[0] = p.atomic_requests; out_u64[1] = p.flush_requests_at_most; }
   });
 }
 int vnrAmdNeuralVolumeSetTrainProfiling(vnrAmdVolume v, int e) { return guarded([&]() { as_neural(v)->network().set_train_profiling(e != 0); }); }

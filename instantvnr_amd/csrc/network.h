@@ -96,6 +96,14 @@ struct GradExchange {
   virtual size_t bucket_params() const { return (size_t)16u << 20; }   // 32 MB of fp16 per message: 4 grid buckets at C4 (10 at 4 M cost 0.03 ms more per step in launches on one rank)
 };
 
+// how the grid backward of a training step is laid out (Network::grid_backward_plan): the first `lds_levels` levels (dense, few tiles) go through
+// LDS tiles of `tile_entries` entries in ~`lds_blocks` blocks per level, the rest through the global-atomic kernel; and the step's memory-side
+// atomic requests by that layout, the unit its roofline is priced in (bench.py train_roofline)
+struct GridBackwardPlan {
+  uint32_t n_levels, lds_levels, tile_entries, lds_blocks;
+  uint64_t atomic_requests, flush_requests_at_most;
+};
+
 class Network {
 public:
   Network() = default;
@@ -216,6 +224,7 @@ public:
   // budget of the image in bytes (0: the default policy, network_host.hip build_brick_image); drops an existing image, which is rebuilt
   // within the new budget by the next launches.  Levels are taken finest first while they fit.
   void set_brick_budget(size_t bytes);
+  GridBackwardPlan grid_backward_plan(size_t batch) const;
   uint32_t brick_levels_mask() const { return brick_levels_mask_; }   // bit l: level l is read from the image
   bool brick_image_in_use() const { return brick_valid_; }
   size_t brick_image_bytes() const { return brick_image_.bytes(); }

@@ -889,6 +889,37 @@ void Network::reset_master_from_params(hipStream_t s)
 
 // 5. of the training step: dL/dfeatures (ws_dfeat_, written by the MLP backward) -> the grid part of the gradient blob.  A function of its
 // own so that it can be repeated alone on the stored dL/dfeatures (vnrAmdNeuralVolumeRescatterGridGradients: diagnostics).
+// which levels of the grid backward go through LDS tiles, and what the scatter costs in memory-side atomic requests (network.h)
+GridBackwardPlan Network::grid_backward_plan(size_t batch) const
+{
+  static const bool lds_bwd = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS"); return !e || std::atoi(e) != 0; }();
+  static const uint32_t lds_kb = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_KB"); return e ? (uint32_t)std::max(8, std::min(144, std::atoi(e))) : 24u; }();
+  static const uint32_t lds_blocks = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_BLOCKS"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 768u; }();
+  static const uint32_t lds_max_tiles = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_TILES"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 64u; }();
+  // (sweep of the three on the C4 model, profiles/r03_grid_backward_lds_sweep.txt: 24 KB tiles, ~768 blocks per level, levels of at most 64 tiles =
+  // levels 0 - 4 of C4: grid backward 0.239 -> 0.18 - 0.22 ms, bimodal from run to run; larger tiles or more levels cost more in scanning
+  // than their atomics saved)
+  GridBackwardPlan p{};
+  const uint32_t F = cfg_.n_features;
+  p.tile_entries = (lds_kb * 1024u / (4u * F)) & ~15u;
+  p.lds_blocks = lds_blocks;
+  p.n_levels = n_active_levels();
+  if (lds_bwd)
+    while (p.lds_levels < p.n_levels && !grid_.levels[p.lds_levels].hashed && ((size_t)grid_.levels[p.lds_levels].offset * F) % 2 == 0 &&
+           div_round_up(grid_.levels[p.lds_levels].size, p.tile_entries) <= lds_max_tiles) ++p.lds_levels;   // (the flush adds aligned pairs of halves)
+  // memory-side requests of one step (MI355X_MICROARCH.md "Global float atomics": a wave instruction leaves L2 as 64-byte requests).  The atomic
+  // kernel's lanes are (sample, x bit, feature pair) with the two x-neighbours of a corner pair adjacent: ONE request per (sample, level, yz corner)
+  // while an entry pair fits 64 bytes; an LDS tile flushes at most (entries x F x element bytes) / 64 requests per slice of the batch.
+  const uint32_t elem = F == 1 ? 4u : 2u;   // F = 1 scatters fp32 (network_train.hip GridGrad)
+  p.atomic_requests = (uint64_t)batch * 4u * (p.n_levels - p.lds_levels) * std::max(1u, (2u * F * elem + 63u) / 64u);
+  for (uint32_t l = 0; l < p.lds_levels; ++l) {
+    const uint32_t tiles = div_round_up(grid_.levels[l].size, p.tile_entries);
+    const uint32_t slices = std::max(4u, std::min(128u, p.lds_blocks / tiles));
+    p.flush_requests_at_most += (uint64_t)slices * ((uint64_t)grid_.levels[l].size * F * elem / 64u);
+  }
+  return p;
+}
+
 void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStream_t s, GradExchange* exchange, hipStream_t s_lds)
 {
   // s_lds: the stream of the dense levels' LDS scatter; another stream than `s` means the two scatters run side by side (forward_backward
@@ -899,18 +930,8 @@ void Network::scatter_grid_gradients(const float* d_coords, size_t batch, hipStr
   const uint32_t n = (uint32_t)batch;
   // 5. hash-grid backward: levels [l0, l1) per launch (blockIdx.y + l0 = level)
   // levels [0, lds_levels) go through grid_backward_lds_kernel: dense, and at most kLdsBwdMaxTiles LDS tiles (VNR_AMD_GRID_BWD_LDS=0: none)
-  static const bool lds_bwd = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS"); return !e || std::atoi(e) != 0; }();
-  static const uint32_t lds_kb = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_KB"); return e ? (uint32_t)std::max(8, std::min(144, std::atoi(e))) : 24u; }();
-  static const uint32_t lds_blocks = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_BLOCKS"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 768u; }();
-  static const uint32_t lds_max_tiles = [] { const char* e = std::getenv("VNR_AMD_GRID_BWD_LDS_TILES"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 64u; }();
-  // (sweep of the three on the C4 model, profiles/r03_grid_backward_lds_sweep.txt: 24 KB tiles, ~768 blocks per level, levels of at most 64 tiles =
-  // levels 0 - 4 of C4: grid backward 0.239 -> 0.18 - 0.22 ms, bimodal from run to run; larger tiles or more levels cost more in scanning
-  // than their atomics saved)
-  const uint32_t tile_entries = (lds_kb * 1024u / (4u * cfg_.n_features)) & ~15u;
-  uint32_t lds_levels = 0;
-  if (lds_bwd)
-    while (lds_levels < n_active_levels() && !grid_.levels[lds_levels].hashed && ((size_t)grid_.levels[lds_levels].offset * cfg_.n_features) % 2 == 0 &&
-           div_round_up(grid_.levels[lds_levels].size, tile_entries) <= lds_max_tiles) ++lds_levels;   // (the flush adds aligned pairs of halves)
+  const GridBackwardPlan plan = grid_backward_plan(batch);
+  const uint32_t tile_entries = plan.tile_entries, lds_levels = plan.lds_levels, lds_blocks = plan.lds_blocks;
   // n_features = 1: the scatter's target is the float image (fold_grid_grads_f32_kernel); the fold of a level range follows its scatter on the
   // same stream(s), before anybody (optimizer, exchange) reads the blob
   float* gg32 = nullptr;

@@ -26,6 +26,13 @@ int main() {
     if (c.size() != 3 || a.size() != 3) return 11;
     if (c[1].x != 1.f || c[1].y != 0.f || c[2].y != 1.f || a[1].x != 0.5f || a[1].y != 0.25f) return 11;
     if (r.lower != 0.25f || r.upper != 0.75f) return 11;
+    // the getters' per-handle copy dies with the handle: a new transfer function at a reused address never meets a stale entry
+    const void* key = t.get();
+    if (vnr::shim::tfn_copies().count(key) != 1) return 11;
+    t.reset();
+    if (vnr::shim::tfn_copies().count(key) != 0 || !vnr::shim::tfn_copies().empty()) return 11;
+    auto u = vnrCreateTransferFunction();                                  // (often the same address)
+    if (!vnrTransferFunctionGetColor(u).empty() || !vnrTransferFunctionGetAlpha(u).empty()) return 11;
   }
   if (!vnrRequireDecoding(4) || vnrRequireDecoding(5) || !vnrRequireDecoding(7) || vnrRequireDecoding(8) || vnrRequireDecoding(14) ||
       !vnrRequireDecoding(0) || !vnrRequireDecoding(13)) return 12;

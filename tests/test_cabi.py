@@ -261,7 +261,7 @@ def test_cpp_api_shim_runs_its_gpu_half(tmp_path, bson):
 @pytest.mark.parametrize("order,ok", [("lib-first", False), ("torch-first", True)])
 def test_torch_must_be_imported_before_the_library_is_loaded(L, order, ok):
     """PyTorch's wheel bundles its own ROCm runtime; with the library loaded first torch finds no GPU (measured on
-    MI355X: tools/scratch/repro_torch_after_lib.py).  The wrong order must fail with an explanation, not later inside torch."""
+    MI355X: tools/repro_torch_after_lib.py).  The wrong order must fail with an explanation, not later inside torch."""
     import subprocess
     import sys
     first, second = ("_lib.lib()", "import torch") if order == "lib-first" else ("import torch", "_lib.lib()")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fabric traffic of the evaluation kernel from rocprofv3 --pmc passes of bench.py itself (tools/scratch/r04_profiles.sh):
+"""Fabric traffic of the evaluation kernel from rocprofv3 --pmc passes of bench.py itself (tools/r06_profiles.sh):
 
   pmc_traffic.py <dir with pmc_bench_{FETCH,WRITE}_SIZE[_h1]/bench_counter_collection.csv> <bench.json of the same box> > profiles/r02_pmc_traffic.json
 
@@ -50,7 +50,7 @@ def main():
     spf = bench["samples_per_frame"]
     doc = {"what": "fabric (L2-miss) traffic of fused_infer_kernel<2,32,64,0,false> on the default bench frame, measured on bench.py itself",
            "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-psnr "
-                      "--no-alone --no-brick-off --train-steps 300   (tools/scratch/r04_profiles.sh; one counter per pass, program directly after --; "
+                      "--no-alone --no-brick-off --train-steps 300   (tools/r06_profiles.sh; one counter per pass, program directly after --; "
                       "VNR_AMD_BRICK=1 so that the brick image exists from the first launch; VNR_AMD_RENDER_HALVES=1 for the one-stream leg)",
            "unit_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB here (derived counters, 1024-byte units)",
            "correction": "FETCH_SIZE counts 64 B per TCC_EA0_RDREQ on gfx950 but every request moves a 128-B line: x2 (MI355X_MICROARCH.md HBM "

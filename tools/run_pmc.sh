@@ -8,7 +8,7 @@
 # counter- nor order-specific.  The two FETCH_SIZE hangs were the only passes run after the renderer went to 2 streams
 # (n = 2: no conclusion).  The calib binary never hung (11 runs); bench.py never hung without --pmc.  NOT root-caused.
 # Third session: a hung pass stands in vnrAmdSynchronize after bench.py's 1500 training steps; for counters of the
-# render kernels use tools/scratch/pmc_share.sh (share_probe.py, 8 of 8 passes completed).  Always run under a short timeout;
+# render kernels use tools/share_probe.py as tools/r06_infer_bound.sh does (8 of 8 passes completed).  Always run under a short timeout;
 # chaining four 600-s passes cost ~40 GPU-minutes once.  `-X faulthandler` + SIGABRT on timeout prints where it hangs.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc

@@ -221,7 +221,7 @@ __device__ __forceinline__ void gather_corners(const LevelInfo& lv, const Corner
         const uint32_t i0 = (x0 ^ yz[q]) & mask;
         i1[q] = (x1 ^ yz[q]) & mask;
         const uint4_t g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (i0 & ~3u) * kBytes, soff, 0);
-        const uint32_t k = i0 & 3u, k2 = k ^ m;
+        const uint32_t k = i0 & 3u, k2 = (k ^ m) & mask;   // (& mask: a table of one or two entries, log2_hashmap_size 0 / 1, is its own group)
         const uint32_t a0 = (k & 1u) ? g.y : g.x, a1 = (k & 1u) ? g.w : g.z;       // entry k of its half, for either half
         const uint32_t b0 = (k & 1u) ? g.x : g.y, b1 = (k & 1u) ? g.z : g.w;       // ... and entry k ^ 1
         v[2 * q] = (k & 2u) ? a1 : a0;

@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256) brick_build_rows_kernel(const LevelInfo l
     for (uint32_t r = 0; r < ROWS; ++r) {
       const uint32_t y = (by << LY) | (r & ((1u << LY) - 1u)), z = (bz << LZ) | (r >> LY);
       const bool inside = y <= res && z <= res;        // (block-uniform)
-      if (F == 2 && lv.hashed == 1u && inside) {
+      if (F == 2 && lv.hashed == 1u && lv.size >= 4u && inside) {
         // four grid points x4 .. x4 + 3 of a hashed level are the aligned group of four entries at (x4 ^ h) & mask & ~3, permuted by the low
         // two bits of h (uniform over the row): one 16-byte load per lane
         const uint32_t h = (y * 2654435761u) ^ (z * 805459861u), mask = lv.size - 1u, hl = h & 3u;

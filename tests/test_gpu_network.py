@@ -58,6 +58,24 @@ def test_encode_bit_exact(oracle, cfg):
     assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
 
 
+@pytest.mark.parametrize("log2T", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("F", [1, 2, 4, 8])
+def test_encode_of_tiny_hashed_tables_is_bit_exact(oracle, log2T, F):
+    """hashed levels of 1, 2, 4, 8, 32 entries: the x-neighbour of a corner is found inside the aligned group of four entries that holds it
+    (grid_device.h gather_corners, F = 2), which a table smaller than a group has to survive; coordinates outside [0, 1] included"""
+    vol, ocfg, params, n_mlp = make(oracle, 5, F, log2T, 3, 1.7, 2, seed=40 + log2T)
+    coords = coords_for(2000, 41)
+    coords[10:60] = np.random.default_rng(42).uniform(-0.3, 1.3, (50, 3)).astype(np.float32)
+    got = api.neural_encode(vol, coords)
+    want = oracle.grid_encode(ocfg, params[n_mlp:].view(np.uint16), coords).view(np.float16)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    for _ in range(30):                                  # ... and from the de-hashed image of those tables (built by rows of bricks)
+        api.neural_inference(vol, coords[:64])
+    assert api.neural_brick_image(vol)["in_use"]
+    ok = ~((coords < 0) | (coords > 1)).any(axis=1)      # (outside the unit cube a wave reads the blob again: covered above)
+    assert np.array_equal(api.neural_encode(vol, coords).view(np.uint16)[ok], want.view(np.uint16)[ok])
+
+
 def test_encode_smoothstep_bit_exact(oracle):
     vol, ocfg, params, n_mlp = make(oracle, 6, 2, 12, 4, None, 2, interpolation="Smoothstep")
     coords = coords_for(1000, 2)

@@ -207,6 +207,15 @@ __device__ __forceinline__ void gather_corners(const LevelInfo& lv, const Corner
     const uint32_t hz0 = c.g[2] * 805459861u, hz1 = hz0 + 805459861u;
     const uint32_t x0 = c.g[0], x1 = c.g[0] + 1u;
     const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+    // The grouped loads below need a table that holds a whole group and starts on a group boundary: level sizes are multiples of 8 entries or
+    // the whole (power-of-two) table, so that fails only for tables of fewer entries than a group, log2_hashmap_size 0 / 1 (wave-uniform, out of line).
+    constexpr uint32_t kGroupMask = (F == 2 && VNR_HASH_QUAD) ? 3u : PairFeat<F>::enabled ? 1u : 0u;
+    if (kGroupMask && mask < kGroupMask) {
+      const uint8x32_t idx = level_indices_exact(lv, c.g[0], c.g[1], c.g[2]);
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner) v[corner] = RawFeat<F>::load(rsrc, idx[corner] * kBytes, soff);
+      return;
+    }
 #if VNR_HASH_QUAD
     if constexpr (F == 2) {
       // x + 1 = x ^ (2^(t+1) - 1) with t the trailing ones of x, and the hash of the other two coordinates is XORed onto x, so the +x
@@ -221,7 +230,7 @@ __device__ __forceinline__ void gather_corners(const LevelInfo& lv, const Corner
         const uint32_t i0 = (x0 ^ yz[q]) & mask;
         i1[q] = (x1 ^ yz[q]) & mask;
         const uint4_t g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (i0 & ~3u) * kBytes, soff, 0);
-        const uint32_t k = i0 & 3u, k2 = (k ^ m) & mask;   // (& mask: a table of one or two entries, log2_hashmap_size 0 / 1, is its own group)
+        const uint32_t k = i0 & 3u, k2 = k ^ m;
         const uint32_t a0 = (k & 1u) ? g.y : g.x, a1 = (k & 1u) ? g.w : g.z;       // entry k of its half, for either half
         const uint32_t b0 = (k & 1u) ? g.x : g.y, b1 = (k & 1u) ? g.z : g.w;       // ... and entry k ^ 1
         v[2 * q] = (k & 2u) ? a1 : a0;

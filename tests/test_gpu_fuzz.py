@@ -2,7 +2,7 @@
 dispatch once; this file draws whole model descriptions at random (seeded) from the same space -- level count, features per level, table
 size, base resolution, growth, interpolation, grid type, quantize_threshold, max_level, width, depth, activation, output activation --
 and holds each draw to the same bars: encode bit-exact, network output within 2^-8 of the oracle, gradients within 3 % of the numpy
-restatement.  VNR_FUZZ_DRAWS / VNR_FUZZ_SEED widen the sweep from a shell (tools/r05_fuzz.sh).
+restatement.  VNR_FUZZ_DRAWS / VNR_FUZZ_SEED widen the sweep from a shell (tools/r06_fuzz.sh).
 
 Deep networks with growing activations (six hidden layers of Exponential at 128 neurons ...) are legal and numerically poor: the fp16
 rounding of the activations alone moves their output by more than 2^-8.  Where that is so the bar is the oracle's OWN distance from an fp64

@@ -510,7 +510,15 @@ void Network::build_brick_image(hipStream_t s, bool small) const
   std::vector<LevelInfo> lv(grid_.levels, grid_.levels + kMaxLevels);
   std::vector<uint64_t> lines(kMaxLevels, 0);
   uint64_t used = 0;
-  for (int l = (int)grid_.n_levels - 1; l >= 0; --l) {
+  // Which levels first when not all fit.  F <= 2 (bricks of 32 / 64 entries): the FINEST, whose eight corners land in eight unrelated lines of the
+  // table and whose big bricks are shared by the neighbouring samples of a wave (round 3's measurement on the bench model).  F >= 4 (bricks of
+  // 16 / 8 entries, 2 x 2 x 2 cells for F = 8): the COARSEST.  A brick that small pays through neighbouring samples falling into the same
+  // cells, which the coarser hashed levels give and a level as fine as the volume does not, and its image (gigabytes, read from HBM) replaces
+  // a table of a few megabytes that lives in the caches: the reference's example model (L8 F8 T2^19, example-model.json) on the 1024^3 bench
+  // volume, finest first = levels {3, 4, 6}, 17.6 GB, 181.9 frames/s; {3, 4, 5}, 2.5 GB: 185.4; no image 179.7 (round 6).
+  const bool finest_first = F <= 2;
+  for (int k = 0; k < (int)grid_.n_levels; ++k) {
+    const int l = finest_first ? (int)grid_.n_levels - 1 - k : k;
     if (lv[l].hashed >= 2u || (!lv[l].hashed && !dense_too)) continue;   // (a Tiled level repeats: nothing to de-hash)
     if (brick_res_cap_ && lv[l].resolution > brick_res_cap_ + 1u) continue;
     const uint64_t res = lv[l].resolution;
@@ -581,7 +589,9 @@ const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image,
       // (an upgrade from the small tier re-reads an image other streams may still be reading: build_brick_image synchronises before it frees)
       build_brick_image(s, false);
       if (brick_valid_ && brick_tier_ == 2) { ++brick_builds_; brick_served_calls_ = 0; }
-    } else if (!brick_valid_ && n_max >= kBrickSmallMinLaunch && brick_small_budget() > 0.0) {
+    } else if (!brick_valid_ && n_max >= kBrickSmallMinLaunch && brick_small_budget() > 0.0 && cfg_.n_features <= 2u) {
+      // (big bricks only: with the 2 x 2 x 2 bricks of F = 8 a per-frame image earns less than its build -- the reference's example model on the
+      // bench volume: 171.0 frames/s with it, 172.9 without, round 6)
       build_brick_image(s, true);
       if (brick_valid_) ++brick_small_builds_;
     }

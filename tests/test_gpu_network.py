@@ -526,3 +526,22 @@ def test_encoding_shapes_without_a_kernel_instance_are_refused_when_the_model_is
     cfg = syn.model_config(n_levels=L, n_features=F, log2_hashmap_size=10, base_resolution=2, n_hidden_layers=2, per_level_scale=1.1)
     with pytest.raises(RuntimeError, match="unsupported encoding shape|too many hash-grid levels"):
         api.vnrCreateNeuralVolume(cfg, (16, 16, 16))
+
+
+@pytest.mark.parametrize("F,budget,want", [(8, 4_800_000, [2, 3]), (2, 1_450_000, [2, 4])])
+def test_which_levels_the_inference_cache_takes_when_not_all_fit(oracle, F, budget, want):
+    """network_host.hip build_brick_image: big bricks (F <= 2: 32 / 64 entries) take the FINEST hashed levels that fit, small bricks (F >= 4:
+    2 x 2 x 2 cells for F = 8) the COARSEST (round 6: the reference's example model on a 1024^3 volume spent 17.6 GB on its finest level for
+    nothing).  Hashed levels 2..5 of resolution 16 / 32 / 64 / 128; the budget holds level 4 and one small level, or levels 2 and 3.  Bit-exact
+    either way."""
+    from instantvnr_amd._lib import check, lib
+    vol, ocfg, params, n_mlp = make(oracle, 6, F, 10, 4, 2.0, 2, seed=50 + F)
+    coords = coords_for(1500, 51)
+    enc0 = api.neural_encode(vol, coords).view(np.uint16)
+    api.neural_set_brick_budget(vol, budget)
+    check(lib().vnrAmdNeuralVolumeSetBrickImageMode(vol.h, 1))
+    api.neural_inference(vol, coords[:64])
+    st = api.neural_brick_image(vol)
+    assert st["in_use"] and st["bytes"] <= budget
+    assert [l for l in range(16) if st["levels"] >> l & 1] == want, st
+    assert np.array_equal(api.neural_encode(vol, coords).view(np.uint16), enc0)

@@ -178,6 +178,16 @@ def small_frame(scene):
     return api.vnrRendererMapFrame(r).copy()
 
 
+def assert_renderer_alone(err, n_ties, what):
+    """the oracle's marcher on the LIBRARY's network values against the library's frame: what is left is the renderer alone, float rounding of
+    the blend (< 1e-5; 5e-7 measured) -- except for a SATURATION TIE: a ray whose opacity comes within that rounding of the early-exit threshold
+    0.9999 (method_raymarching.cu:806) stops one sample earlier in one of the two, and everything behind the threshold weighs at most 1 - 0.9999 =
+    1e-4.  On 131 072 pixels that happens to about one ray in every third run (4.6e-5 on one pixel, round 6); never more than a handful."""
+    worst = err.max(axis=1) if err.ndim == 2 else err
+    assert float(worst.max()) < 1.05e-4, (what, float(worst.max()))
+    assert int((worst > 1e-5).sum()) <= n_ties, (what, int((worst > 1e-5).sum()), float(worst.max()))
+
+
 @pytest.fixture(scope="module")
 def c4_scene():
     """BASELINE C4 as bench.py sets it up: 1024^3 Perlin volume, the 70 M-parameter model trained on it, the bench's transfer function
@@ -261,7 +271,8 @@ def test_a_band_of_the_c4_frame_equals_the_oracle(oracle, c4_scene, monkeypatch,
     psnr2 = 10 * np.log10(1.0 / max(float((err2 ** 2).mean()), 1e-30))
     print(f"   compositor alone (oracle marcher on the library's network values): PSNR {psnr2:.1f} dB, max |err| {err2.max():.2e}, samples {ost2['n_samples']}")
     assert ost2["n_rays_hit"] == st["n_rays_hit"] and ost2["n_iterations"] == st["n_iterations"]
-    assert psnr2 > 120.0 and err2.max() < 1e-5, (psnr2, float(err2.max()))   # measured 145.0 dB, max 5.4e-7 at 16
+    assert psnr2 > 120.0, psnr2                          # measured 145.0 dB, max 5.4e-7 at 16
+    assert_renderer_alone(err2, 2, "band")
 
 
 @pytest.mark.parametrize("part", [3])
@@ -319,7 +330,8 @@ def test_a_rank_s_share_of_the_c4_frame_equals_the_oracle(oracle, c4_scene, monk
     psnr2 = 10 * np.log10(1.0 / max(float((err2 ** 2).mean()), 1e-30))
     print(f"   compositor alone (oracle marcher on the library's network values): PSNR {psnr2:.1f} dB, max |err| {err2.max():.2e}")
     assert ost2["n_rays_hit"] == st["n_rays_hit"] and ost2["n_iterations"] == st["n_iterations"]
-    assert psnr2 > 120.0 and err2.max() < 1e-5, (psnr2, float(err2.max()))
+    assert psnr2 > 120.0, psnr2                          # measured 146.5 dB, max 6e-7; with one saturation tie 138.8 dB, max 4.6e-5
+    assert_renderer_alone(err2, 8, "share")
     # the share in distributed mode's clothing is the same pixels: the whole frame at 32 holds them bit for bit
     monkeypatch.setenv("VNR_RM_N_ITERS", "32")
     whole = frame(c4_scene, 5).reshape(-1, 4)
@@ -401,7 +413,7 @@ def test_bands_of_the_c4_frame_from_random_cameras_equal_the_oracle(oracle, c4_s
     assert (ref[:, 3] > 0).mean() > 0.2
     assert err.max() < 1e-3 and psnr > 85.0
     mine, _, _ = oracle.render_streaming(sc, lambda c: api.neural_inference(nv, c), n_iters=n_iters)
-    assert np.abs(band - mine.reshape(-1, 4)[lo:hi]).max() < 1e-5
+    assert_renderer_alone(np.abs(band - mine.reshape(-1, 4)[lo:hi]), 2, "random camera")
 
 
 def test_adam_step_of_the_c4_model_matches_the_restatement(oracle):

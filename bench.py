@@ -409,23 +409,29 @@ def choose_transport():
 
 def visible_gpu_count():
     """how many GPUs this process could open, WITHOUT a HIP call (the launching parent must never touch the GPU): the KFD topology's nodes
-    with SIMDs, cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the topology cannot be read."""
+    that have SIMDs, whose properties this process may read (a container sees the other GPUs of its host as nodes it may not read) and whose
+    render node it may open, cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the topology cannot be read at all."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        base = "/sys/class/kfd/kfd/topology/nodes"
-        n = 0
-        for node in os.listdir(base):
-            props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
-            n += int(props.get("simd_count", "0")) > 0
-        # a container is usually given a subset of the host's GPUs as render nodes it may open
-        dri = [d for d in os.listdir("/dev/dri") if d.startswith("renderD")] if os.path.isdir("/dev/dri") else None
-        if dri is not None:
-            n = min(n, sum(os.access(os.path.join("/dev/dri", d), os.R_OK | os.W_OK) for d in dri))
-    except (OSError, ValueError):
+        nodes = os.listdir(base)
+    except OSError:
         return None
+    n = 0
+    for node in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+        except (OSError, ValueError):
+            continue                      # not ours
+        if int(props.get("simd_count", "0")) <= 0:
+            continue                      # a CPU node
+        render = os.path.join("/dev/dri", "renderD" + props.get("drm_render_minor", "-1"))
+        if os.path.isdir("/dev/dri") and not os.access(render, os.R_OK | os.W_OK):
+            continue
+        n += 1
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         if os.environ.get(var, "").strip():
             n = min(n, len([x for x in os.environ[var].split(",") if x.strip()]))
-    return n
+    return n if n > 0 else None           # (zero: the rules above do not fit this machine; let the ranks' RCCL probe find out)
 
 
 def launch_ranks(a):

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from instantvnr_amd import api, dist as vdist, synthetic as syn  # noqa: E402
 from instantvnr_amd._lib import check, lib  # noqa: E402
 
-SMALL_MODEL = dict(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
+SMALL_MODEL = dict(n_levels=4, n_features=int(os.environ.get("TEST_FEATURES", "2")), log2_hashmap_size=12, base_resolution=4, n_hidden_layers=2)
 
 
 def make_scene_objects(dims):

@@ -182,6 +182,20 @@ def test_shares_of_an_eighth_frame_size_take_the_unpinned_branch_and_equal_the_f
         print(f"rank {int(r['rank'])}: shares vs the unsharded frame at 24: equal {r['equal_24']}, max |diff| {float(r['max_diff_24']):.2e}")
 
 
+def test_data_parallel_training_with_one_feature_per_level(tmp_path):
+    """n_features_per_level = 1 sums its grid gradients in fp32 (a float image folded into the fp16 blob, network_train.hip): in the
+    data-parallel step the fold of a level range must come before that range's exchange.  Two ranks from different seeds end with one model,
+    in both forms of the step, and the loss falls."""
+    res = run_ranks("train", 2, tmp_path, extra_env={"TEST_STEPS": "30", "TEST_FEATURES": "1"})
+    assert len({int(r["checksum_before"]) for r in res}) == 2
+    assert len({int(r["checksum"]) for r in res}) == 1 and len({int(r["checksum_by_hand"]) for r in res}) == 1
+    assert all(int(r["step"]) == 30 for r in res)
+    p = res[0]["params"].view(np.float16).astype(np.float32)
+    hand = res[0]["params_by_hand"].view(np.float16).astype(np.float32)
+    assert np.isfinite(p).all() and np.abs(p - hand).mean() < 0.05 * np.abs(p).mean() + 1e-5
+    assert float(res[0]["psnr"]) > 15.0, float(res[0]["psnr"])
+
+
 def _initial_params():
     os.environ["VNR_AMD_INIT_SEED"] = "100"
     sv = api.vnrCreateSimpleVolume(syn.analytic_volume(32))

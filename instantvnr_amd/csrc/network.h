@@ -289,6 +289,7 @@ private:
   // never counts towards the backoff above, and it is replaced by the full one once the parameters have been left alone.
   static constexpr size_t kBrickSmallMinLaunch = (size_t)1 << 20;
   mutable int brick_tier_ = 0;   // 0 none, 1 small, 2 full
+  mutable bool brick_small_refused_ = false;   // no level fits the small budget
   mutable uint64_t brick_small_builds_ = 0;
   mutable float brick_build_ms_ = 0.0f;
   uint32_t brick_res_cap_ = 0;   // 0: no cap

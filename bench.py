@@ -985,6 +985,7 @@ def main():
         "reference_slots_per_frame": int(slots_all / a.steps), "iterations_per_frame": iters, "rays_hit": rays_hit,
         "psnr_db": None if psnr is None else round(psnr, 2), "image_vs_ground_truth": image, "train_ms_per_step": round(train_ms, 3), "train_loss": round(train_loss, 5),
         "setup_s": round(setup_s, 1),
+        "library_build": L.vnrAmdBuildId().decode(),   # md5 (12 digits) of the sources libvnr_amd.so was linked from (csrc/Makefile)
         "roofline": roofline,
         "train_roofline": train_roofline,
     }

@@ -69,6 +69,8 @@ enum {
 /* ---- library ----------------------------------------------------------- */
 const char* vnrAmdGetLastError(void);
 const char* vnrAmdVersion(void);
+/* the build: first 12 hex digits of the md5 over every source file of the library, stamped at link time (csrc/Makefile) */
+const char* vnrAmdBuildId(void);
 /* selects the HIP device (reference: env VNR_CUDA_DEVICE, renderer.cpp:299-304); -1 = env VNR_AMD_DEVICE or 0 */
 int  vnrAmdInit(int device);
 int  vnrAmdDeviceCount(void);

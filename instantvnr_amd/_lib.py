@@ -78,6 +78,7 @@ def lib():
         fn.argtypes = list(args)
 
     sig("vnrAmdGetLastError", C.c_char_p)
+    sig("vnrAmdBuildId", C.c_char_p)
     sig("vnrAmdVersion", C.c_char_p)
     sig("vnrAmdInit", I, I)
     sig("vnrAmdDeviceCount", I)

@@ -23,6 +23,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """which build of the library this session runs (csrc/Makefile stamps the md5 of its sources at link time): a record of a GPU run then says
+    what it ran.  Loading the library makes no HIP call."""
+    try:
+        from instantvnr_amd import _lib
+        return f"libvnr_amd.so build {_lib.lib().vnrAmdBuildId().decode()} ({_lib.SO_PATH})"
+    except Exception as e:   # a missing library is what the tests themselves report
+        return f"libvnr_amd.so: {e}"
+
+
 def _device_present():
     """probed in a child process: the test session itself must not initialise a HIP runtime just to find out"""
     import subprocess

@@ -33,6 +33,11 @@ def pytest_report_header(config):
         return f"libvnr_amd.so: {e}"
 
 
+def pytest_terminal_summary(terminalreporter):
+    """(the header is not printed under -q, which is how the driver runs the suite: say it once more at the end)"""
+    terminalreporter.write_line(pytest_report_header(None))
+
+
 def _device_present():
     """probed in a child process: the test session itself must not initialise a HIP runtime just to find out"""
     import subprocess
